@@ -1,0 +1,221 @@
+/* rawhash_amd -- MI355X-native raw-signal mapping path: C ABI.
+ *
+ * Drop-in boundary for ONE path of CMU-SAFARI/RawHash (RawHash2 v2.1): the per-read mapping pipeline that
+ * `kt_for(p->n_threads, map_worker_for, step_mt*, n_sig)` runs (reference src/rmap.cpp:700), i.e.
+ *   raw signal -> pA+filter -> normalise -> event segmentation -> quantise+hash sketch -> seed lookup
+ *   -> anchor sort -> chaining DP -> regions/MAPQ -> mapping decision -> PAF record.
+ * The reference has no FFI of its own (single C/C++ program); every entry point below names the reference
+ * function(s) it replaces as file:line relative to the reference's src/.  INTEGRATION.md shows the binding a
+ * RawHash2 maintainer would add in rmap.cpp.
+ *
+ * Conventions: plain C, opaque handles, `int` status (0 ok, -1 error; rh_last_error() gives the text),
+ * caller-owned buffers, no torch/HIP types in any signature.  One rh_ctx per GPU; calls on one context must be
+ * serialised by the caller (contexts on different GPUs are independent).  The library has NO CPU fallback:
+ * every compute entry point fails with -1 when no gfx950 device is present.
+ */
+#ifndef RAWHASH_AMD_H
+#define RAWHASH_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RH_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------------ types */
+
+typedef struct { uint64_t x, y; } rh_mm128_t;      /* = mm128_t, rutils.h:20 */
+
+/* index flags, roptions.h:8-16 */
+#define RH_I_MIN            0x2
+#define RH_I_STORE_SIG      0x10
+#define RH_I_SIG_TARGET     0x20
+#define RH_I_NO_REV_TARGET  0x40
+/* map flags, roptions.h:18-34 */
+#define RH_M_RMQ            0x2
+#define RH_M_HARD_MLEVEL    0x4
+#define RH_M_NO_ADAPTIVE    0x20
+#define RH_M_DTW_EVALUATE_CHAINS 0x40
+#define RH_M_ALL_CHAINS     0x2000
+
+/* Indexing options: the fields of ri_idxopt_t (roptions.h:50-67) that reach the path. */
+typedef struct rh_idxopt_s {
+	int32_t b, w, e, n, q, k, flag, lev_col;
+	float diff, fine_min, fine_max, fine_range;
+} rh_idxopt_t;
+
+/* Mapping options: the fields of ri_mapopt_t (roptions.h:69-143) that reach the path. */
+typedef struct rh_mapopt_s {
+	uint32_t bp_per_sec, sample_rate, chunk_size;
+	float sample_per_base;
+	float mid_occ_frac;
+	int32_t min_mid_occ, max_mid_occ;
+	int32_t mid_occ, max_max_occ, occ_dist;
+	uint32_t min_events;
+	int32_t bw, bw_long, max_target_gap_length, max_query_gap_length, max_chain_iter;
+	int32_t max_num_skips, min_num_anchors, min_chaining_score, min_chaining_score2;
+	float chain_gap_scale, chain_skip_scale;
+	float w_bestq, w_bestmq, w_bestmc, w_threshold;
+	float mask_level; int32_t mask_len;
+	float pri_ratio; int32_t best_n;
+	float alt_drop;
+	uint32_t max_num_chunk;
+	int32_t min_mapq;
+	int64_t flag;
+	uint32_t window_length1, window_length2;
+	float threshold1, threshold2, peak_height;
+} rh_mapopt_t;
+
+/* One output record = ri_map_t (rmap.h:12-22) + the integer tag values rmap.cpp:523-571 formats.
+ * Unmapped reads get exactly one record with mapped=0 (rmap.cpp:521-556). */
+typedef struct rh_map_record_s {
+	uint32_t read_idx;                /* index in the submitted batch */
+	uint32_t read_length;             /* ri_map_t::read_length */
+	uint32_t ref_id;
+	uint32_t read_start_position, read_end_position;
+	uint32_t fragment_start_position, fragment_length;
+	uint8_t  mapq, rev, mapped, _pad;
+	int32_t  tag_ci, tag_sl, tag_cm, tag_nc, tag_s1;   /* ci:i sl:i cm:i nc:i s1:i */
+} rh_map_record_t;
+
+/* A batch of reads in structure-of-arrays / CSR form (replaces step_mt::sig[], rmap.h:60-67 + ri_sig_t
+ * rsig.h:20-28).  Samples are the RAW int16 ADC values; the pA conversion + 30<pA<200 filter of
+ * rsig.c:496-503 happens on the device. */
+typedef struct rh_read_batch_s {
+	uint32_t n_reads;
+	const int16_t  *samples;          /* concatenated raw samples */
+	const uint64_t *offsets;          /* n_reads+1 sample offsets into samples[] */
+	const double   *cal_offset;       /* per read: slow5 `offset`                (may be NULL -> 0) */
+	const float    *cal_scale;        /* per read: (float)(range/digitisation)   (may be NULL -> 1) */
+	const uint32_t *name_rank;        /* only for RH_M_ALL_CHAINS: rank of the read name among target names
+	                                     such that strcmp(qname, tname) >= 0  <=>  name_rank[q] >= target id
+	                                     (see INTEGRATION.md); NULL otherwise */
+	int samples_on_device;            /* 1: samples/offsets/cal_* are device pointers already resident in HBM */
+} rh_read_batch_t;
+
+typedef struct rh_index_s rh_index;  /* host-side parsed .ind (flattened) */
+typedef struct rh_ctx_s   rh_ctx;    /* one GPU: streams, arenas, resident index */
+
+/* ------------------------------------------------------------------------------------------- utilities */
+RH_API const char *rh_last_error(void);
+RH_API const char *rh_version(void);
+RH_API int rh_device_count(void);                       /* number of visible HIP devices (0 if none) */
+
+/* ------------------------------------------------------------------------------------------- options */
+RH_API void rh_idxopt_init(rh_idxopt_t *io);             /* ri_idxopt_init roptions.c:4  */
+RH_API void rh_mapopt_init(rh_mapopt_t *mo);             /* ri_mapopt_init roptions.c:34 */
+RH_API int  rh_set_preset(const char *preset, rh_idxopt_t *io, rh_mapopt_t *mo); /* ri_set_opt main.cpp:111; preset NULL = defaults */
+
+/* ------------------------------------------------------------------------------------------- index (.ind) */
+RH_API rh_index *rh_index_load(const char *ind_path);    /* ri_idx_load rindex.c:650 (format: rindex.c:545) */
+/* ri_idx_gen rindex.c:900 + ri_idx_dump rindex.c:545: build from FASTA (plain or .gz is NOT supported: plain only)
+ * + k-mer model (load_pore rutils.c:133) and optionally write `out_ind` (may be NULL). */
+RH_API rh_index *rh_index_build(const char *fasta_path, const char *pore_model_path, const rh_idxopt_t *io,
+                                const char *out_ind, int n_threads);
+RH_API void      rh_index_destroy(rh_index *idx);
+RH_API void      rh_mapopt_update(rh_mapopt_t *mo, const rh_index *idx); /* ri_mapopt_update rindex.c:1041 (+ ri_idx_cal_max_occ :1018) */
+RH_API uint32_t  rh_index_n_seq(const rh_index *idx);
+RH_API const char *rh_index_seq_name(const rh_index *idx, uint32_t i);
+RH_API uint32_t  rh_index_seq_len(const rh_index *idx, uint32_t i);
+RH_API void      rh_index_params(const rh_index *idx, rh_idxopt_t *out);  /* w,e,n,q,k,flag,diff,fine_* stored in the header */
+RH_API uint64_t  rh_index_n_keys(const rh_index *idx);
+RH_API uint64_t  rh_index_n_positions(const rh_index *idx);
+/* ri_idx_get rindex.c:497 on the host copy (used by tests and by the CLI's sanity checks) */
+RH_API const uint64_t *rh_index_get(const rh_index *idx, uint64_t hashval, int *n);
+
+/* ------------------------------------------------------------------------------------------- device context */
+RH_API int  rh_ctx_create(rh_ctx **out, int device_id);
+RH_API void rh_ctx_destroy(rh_ctx *ctx);
+/* Flatten + upload the index into this GPU's HBM (bucketed open-addressing table + positions array). */
+RH_API int  rh_index_upload(rh_ctx *ctx, const rh_index *idx);
+/* Multi-GPU replication over RCCL is done by the caller on the raw device blob (torch.distributed broadcast
+ * in bench.py / rawhash_amd.dist): rank 0 uploads, every rank allocates `bytes`, broadcasts, then adopts. */
+RH_API int  rh_index_device_blob(rh_ctx *ctx, void **dev_ptr, uint64_t *bytes, void *header_out /* >= 256 B */);
+RH_API int  rh_index_adopt_blob(rh_ctx *ctx, const rh_index *idx_meta /* may be NULL */, void *dev_ptr, uint64_t bytes,
+                                const void *header /* from rank 0 */, int take_ownership);
+
+/* ------------------------------------------------------------------------------------------- the hot path */
+/* = kt_for(n_threads, map_worker_for, step, n_sig)  rmap.cpp:700 / map_worker_for rmap.cpp:389.
+ * out must hold at least rh_map_max_records(batch, mo) records; *n_out receives the count.  Records are ordered by
+ * read_idx (then chain order), the order step 2 prints them in (rmap.cpp:740). */
+RH_API uint64_t rh_map_max_records(const rh_read_batch_t *in, const rh_mapopt_t *mo);
+RH_API int  rh_map_batch(rh_ctx *ctx, const rh_mapopt_t *mo, const rh_read_batch_t *in,
+                         rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out);
+
+/* Counters of the last rh_map_batch call (for the roofline model). */
+typedef struct rh_map_stats_s {
+	uint64_t n_reads, n_chunks, n_samples_raw, n_samples_used, n_events, n_seeds, n_hits, n_anchors, n_chained;
+	double   ms_total;                /* device time of the whole call (hipEvents on the context's stream) */
+	double   ms_kernel[16];           /* per-stage device time, see rh_stage_name() */
+	uint32_t n_launch[16];
+} rh_map_stats_t;
+RH_API int  rh_map_last_stats(rh_ctx *ctx, rh_map_stats_t *out);
+RH_API const char *rh_stage_name(int i);
+
+/* Stage-level entry points (same kernels as rh_map_batch, one stage at a time) for the parity tests.
+ * All buffers are HOST buffers; CSR offsets have n+1 entries. */
+/* detect_events revent.c:257 over chunk `chunk` (0-based) of every read, with the running sums carried from
+ * chunks 0..chunk-1 (rmap.cpp:412-421).  Also returns l_sig (filtered length, rsig.c:496-503). */
+RH_API int  rh_events_batch(rh_ctx *ctx, const rh_mapopt_t *mo, const rh_read_batch_t *in, uint32_t chunk,
+                            float *events, uint64_t events_cap, uint64_t *ev_offsets, uint32_t *l_sig);
+/* ri_sketch rsketch.c:271 on per-read event arrays */
+RH_API int  rh_sketch_batch(rh_ctx *ctx, uint32_t n_reads, const float *events, const uint64_t *ev_offsets,
+                            rh_mm128_t *seeds, uint64_t seeds_cap, uint64_t *seed_offsets);
+/* collect_seed_hits rmap.cpp:51 (lookup, mid_occ filter, rep_len, expansion, + carried anchors, exact sort) */
+RH_API int  rh_seed_batch(rh_ctx *ctx, const rh_mapopt_t *mo, uint32_t n_reads, const rh_mm128_t *seeds, const uint64_t *seed_offsets,
+                          const uint32_t *q_offset /* reg->offset per read, may be NULL */,
+                          const rh_mm128_t *prev, const uint64_t *prev_offsets /* may be NULL */,
+                          rh_mm128_t *anchors, uint64_t anchors_cap, uint64_t *anchor_offsets, int32_t *rep_len);
+/* mg_lchain_dp lchain.c:385 (+ backtrack :95, compact_a :214): returns chained anchors and u[] per read */
+RH_API int  rh_chain_batch(rh_ctx *ctx, const rh_mapopt_t *mo, uint32_t n_reads, const rh_mm128_t *anchors, const uint64_t *anchor_offsets,
+                           rh_mm128_t *chained, uint64_t chained_cap, uint64_t *chained_offsets,
+                           uint64_t *u, uint64_t u_cap, uint64_t *u_offsets,
+                           rh_mm128_t *prev_out /* the *_a copy = next chunk's prev_anchors, may be NULL */);
+/* radix_sort_128x ksort.h:101-151 (exact, unstable permutation) on independent segments */
+RH_API int  rh_sort128x_batch(rh_ctx *ctx, uint32_t n_seg, rh_mm128_t *a, const uint64_t *offsets);
+
+/* ------------------------------------------------------------------------------------------- PAF (host) */
+/* One PAF line per record exactly as rmap.cpp:740-783 prints it; `mt_ms` fills the mt:f: tag (wall clock in the
+ * reference, excluded from parity).  Returns bytes written (excluding NUL) or -1 if cap is too small. */
+RH_API int  rh_paf_format(const rh_index *idx, const rh_map_record_t *rec, const char *read_name, double mt_ms,
+                          char *buf, size_t cap);
+
+/* ------------------------------------------------------------------------------------------- read container */
+/* Minimal own container ("RHR1") used by the CLI, tests and bench until a BLOW5 reader lands:
+ * magic, u32 n; per read: u32 name_len, name, u32 n_samples, f64 digitisation, f64 range, f64 offset, i16[n]. */
+typedef struct rh_reads_s rh_reads;
+RH_API rh_reads *rh_reads_load(const char *path);
+RH_API void      rh_reads_destroy(rh_reads *r);
+RH_API uint32_t  rh_reads_n(const rh_reads *r);
+RH_API const char *rh_reads_name(const rh_reads *r, uint32_t i);
+RH_API int       rh_reads_batch(const rh_reads *r, rh_read_batch_t *out);   /* views into r; valid until destroy */
+RH_API int       rh_reads_write(const char *path, uint32_t n, const char *const *names, const int16_t *samples,
+                                const uint64_t *offsets, double digitisation, double range, double offset);
+
+/* ------------------------------------------------------------------------------------------- synthetic workload */
+/* Deterministic, integer-only generator (same bytes on any host): i.i.d. genome, 6-mer pore model ~N(90,12) pA,
+ * R9.4-like reads (dwell ~Gamma(2) mean ~8.9 samples/base, gaussian-ish noise), SURVEY §8d. */
+typedef struct rh_synth_cfg_s {
+	uint64_t model_seed, genome_seed, read_seed;
+	uint32_t n_chrom, chrom_len;      /* n_chrom sequences "chr<i>" of chrom_len bases each */
+	uint32_t n_samples;               /* raw samples per read (fixed) */
+	uint32_t junk_per_1024;           /* reads whose bases are random (unmappable), per 1024 */
+	uint32_t noise_q24;               /* noise scale; 0 -> default (sigma ~1.5 pA) */
+	double   digitisation, range, offset;
+} rh_synth_cfg_t;
+RH_API void rh_synth_cfg_init(rh_synth_cfg_t *c);
+RH_API int  rh_synth_write_model(const rh_synth_cfg_t *c, const char *path);
+RH_API int  rh_synth_write_fasta(const rh_synth_cfg_t *c, const char *path);
+/* reads [first, first+n): samples must hold n*n_samples int16; names (optional) n*64 chars */
+RH_API int  rh_synth_reads(const rh_synth_cfg_t *c, const char *model_path, uint64_t first, uint32_t n,
+                           int16_t *samples, char *names64, int n_threads);
+/* true origin of read `idx` (for "maps to origin" sanity checks): chrom, 0-based start base, strand, junk flag */
+RH_API int  rh_synth_origin(const rh_synth_cfg_t *c, uint64_t idx, uint32_t *chrom, uint32_t *pos, uint32_t *strand, uint32_t *junk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAWHASH_AMD_H */
