@@ -151,18 +151,24 @@ def _declare(lib):
 EXPORTS = None
 
 
+def load(path):
+    """dlopen a build of the C ABI and attach the prototypes of include/rawhash_amd.h (fails on a missing symbol)."""
+    global EXPORTS
+    l = C.CDLL(path)
+    EXPORTS = _declare(l)
+    return l
+
+
 def lib():
     """The product shared library; raises if it has not been built (no fallback)."""
-    global _lib, EXPORTS
+    global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU/Python fallback for the mapping path)")
-        l = C.CDLL(LIB_PATH)
-        EXPORTS = _declare(l)
-        _lib = l
+        _lib = load(LIB_PATH)
     return _lib
 
 
-def last_error():
-    return lib().rh_last_error().decode()
+def last_error(l=None):
+    return (l or lib()).rh_last_error().decode()

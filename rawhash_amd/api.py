@@ -1,0 +1,316 @@
+"""Host-side mirror of the reference interface for the mapping path, on top of the C ABI.
+
+Names follow the reference: an *index* (`.ind`, ri_idx_t), *map options* (ri_mapopt_t + `-x` presets), a *batch of
+reads* (step_mt), `map_batch` (= kt_for(map_worker_for), rmap.cpp:700) returning one record per read (ri_map_t) that
+`paf_lines` prints exactly like rmap.cpp:740-783.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from ._capi import IdxOpt, MapOpt, MapRecord, MapStats, ReadBatch, SynthCfg, RECORD, MM128, ptr
+
+
+class RhError(RuntimeError):
+    pass
+
+
+def _check(rc, l):
+    if rc != 0:
+        raise RhError(_capi.last_error(l))
+
+
+class MapOptions:
+    """ri_idxopt_t + ri_mapopt_t with the reference's presets (main.cpp:111-210)."""
+
+    def __init__(self, preset=None, lib=None):
+        self._l = lib or _capi.lib()
+        self.io, self.mo = IdxOpt(), MapOpt()
+        self._l.rh_set_preset(None, C.byref(self.io), C.byref(self.mo))
+        if preset not in (None, "default"):
+            _check(self._l.rh_set_preset(preset.encode(), C.byref(self.io), C.byref(self.mo)), self._l)
+
+    def update(self, index):
+        """ri_mapopt_update (rindex.c:1041): calibrates mid_occ from the index."""
+        self._l.rh_mapopt_update(C.byref(self.mo), index.h)
+        return self
+
+
+class Index:
+    """Host copy of a RawHash2 index (.ind)."""
+
+    def __init__(self, handle, lib):
+        self.h, self._l = handle, lib
+
+    @classmethod
+    def load(cls, path, lib=None):
+        l = lib or _capi.lib()
+        h = l.rh_index_load(os.fsencode(path))
+        if not h:
+            raise RhError(_capi.last_error(l))
+        return cls(h, l)
+
+    @classmethod
+    def build(cls, fasta, pore_model, opts, out_ind=None, n_threads=8, lib=None):
+        l = lib or _capi.lib()
+        h = l.rh_index_build(os.fsencode(fasta), os.fsencode(pore_model), C.byref(opts.io),
+                             os.fsencode(out_ind) if out_ind else None, n_threads)
+        if not h:
+            raise RhError(_capi.last_error(l))
+        return cls(h, l)
+
+    def close(self):
+        if self.h:
+            self._l.rh_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_seq(self):
+        return self._l.rh_index_n_seq(self.h)
+
+    def seq_name(self, i):
+        return self._l.rh_index_seq_name(self.h, i).decode()
+
+    def seq_len(self, i):
+        return self._l.rh_index_seq_len(self.h, i)
+
+    @property
+    def n_keys(self):
+        return self._l.rh_index_n_keys(self.h)
+
+    @property
+    def n_positions(self):
+        return self._l.rh_index_n_positions(self.h)
+
+    def params(self):
+        io = IdxOpt()
+        self._l.rh_index_params(self.h, C.byref(io))
+        return io
+
+    def get(self, hashval):
+        n = C.c_int(0)
+        p = self._l.rh_index_get(self.h, int(hashval), C.byref(n))
+        if n.value == 0:
+            return np.zeros(0, dtype=np.uint64)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n.value,)).copy()
+
+
+class Reads:
+    """A batch of raw reads (int16 ADC samples + calibration), SoA/CSR."""
+
+    def __init__(self, samples, offsets, names, cal_offset, cal_scale):
+        self.samples = np.ascontiguousarray(samples, dtype=np.int16)
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.names = list(names)
+        n = len(self.offsets) - 1
+        self.cal_offset = np.ascontiguousarray(np.broadcast_to(np.asarray(cal_offset, dtype=np.float64), (n,)))
+        self.cal_scale = np.ascontiguousarray(np.broadcast_to(np.asarray(cal_scale, dtype=np.float32), (n,)))
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def batch(self):
+        return _capi.make_batch(self.samples, self.offsets, self.cal_offset, self.cal_scale)
+
+    def subset(self, idx):
+        idx = list(idx)
+        parts = [self.samples[int(self.offsets[i]):int(self.offsets[i + 1])] for i in idx]
+        off = np.zeros(len(idx) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(p) for p in parts])
+        return Reads(np.concatenate(parts) if parts else np.zeros(0, np.int16), off, [self.names[i] for i in idx],
+                     self.cal_offset[idx], self.cal_scale[idx])
+
+    @classmethod
+    def load(cls, path, lib=None):
+        l = lib or _capi.lib()
+        h = l.rh_reads_load(os.fsencode(path))
+        if not h:
+            raise RhError(_capi.last_error(l))
+        try:
+            b = ReadBatch()
+            l.rh_reads_batch(h, C.byref(b))
+            n = b.n_reads
+            off = np.ctypeslib.as_array(C.cast(b.offsets, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+            tot = int(off[n])
+            smp = np.ctypeslib.as_array(C.cast(b.samples, C.POINTER(C.c_int16)), shape=(max(tot, 1),))[:tot].copy()
+            co = np.ctypeslib.as_array(C.cast(b.cal_offset, C.POINTER(C.c_double)), shape=(max(n, 1),))[:n].copy()
+            cs = np.ctypeslib.as_array(C.cast(b.cal_scale, C.POINTER(C.c_float)), shape=(max(n, 1),))[:n].copy()
+            names = [l.rh_reads_name(h, i).decode() for i in range(n)]
+        finally:
+            l.rh_reads_destroy(h)
+        return cls(smp, off, names, co, cs)
+
+    def write(self, path, digitisation, rng, offset, lib=None):
+        l = lib or _capi.lib()
+        arr = (C.c_char_p * len(self.names))(*[n.encode() for n in self.names])
+        _check(l.rh_reads_write(os.fsencode(path), len(self.names), arr, ptr(self.samples), ptr(self.offsets),
+                                float(digitisation), float(rng), float(offset)), l)
+
+
+class Context:
+    """One GPU: HIP stream, device arenas and the HBM-resident index."""
+
+    def __init__(self, device=0, lib=None):
+        self._l = lib or _capi.lib()
+        h = C.c_void_p()
+        _check(self._l.rh_ctx_create(C.byref(h), device), self._l)
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self._l.rh_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, index):
+        _check(self._l.rh_index_upload(self.h, index.h), self._l)
+        return self
+
+    def device_blob(self):
+        p, n, hdr = C.c_void_p(), C.c_uint64(), C.create_string_buffer(256)
+        _check(self._l.rh_index_device_blob(self.h, C.byref(p), C.byref(n), hdr), self._l)
+        return p.value, n.value, hdr.raw
+
+    def adopt_blob(self, dev_ptr, nbytes, header, take_ownership=False):
+        _check(self._l.rh_index_adopt_blob(self.h, None, C.c_void_p(dev_ptr), nbytes, header, int(take_ownership)), self._l)
+
+    def map_batch(self, opts, batch):
+        """kt_for(map_worker_for): one record per read, in read order.  `batch` is a Reads or a ReadBatch."""
+        b = batch.batch() if isinstance(batch, Reads) else batch
+        cap = self._l.rh_map_max_records(C.byref(b), C.byref(opts.mo))
+        out = np.zeros(max(cap, 1), dtype=RECORD)
+        n = C.c_uint64(0)
+        _check(self._l.rh_map_batch(self.h, C.byref(opts.mo), C.byref(b), ptr(out), cap, C.byref(n)), self._l)
+        return out[: n.value]
+
+    def stats(self):
+        s = MapStats()
+        self._l.rh_map_last_stats(self.h, C.byref(s))
+        d = {k: getattr(s, k) for k in ("n_reads", "n_chunks", "n_samples_raw", "n_samples_used", "n_events", "n_seeds",
+                                         "n_hits", "n_anchors", "n_chained", "ms_total")}
+        d["stages"] = {self._l.rh_stage_name(i).decode(): (s.ms_kernel[i], s.n_launch[i]) for i in range(16)
+                       if self._l.rh_stage_name(i)}
+        return d
+
+    # ---- stage-level entry points (parity tests)
+    def events(self, opts, reads, chunk):
+        b = reads.batch()
+        n = len(reads)
+        cap = n * 2048 + 16
+        ev = np.zeros(cap, dtype=np.float32)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        lsig = np.zeros(max(n, 1), dtype=np.uint32)
+        _check(self._l.rh_events_batch(self.h, C.byref(opts.mo), C.byref(b), chunk, ptr(ev), cap, ptr(off), ptr(lsig)), self._l)
+        return ev[: int(off[n])], off, lsig[:n]
+
+    def sketch(self, events, ev_off):
+        n = len(ev_off) - 1
+        cap = len(events) * 4 + 16
+        sd = np.zeros(cap, dtype=MM128)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        ev = np.ascontiguousarray(events, dtype=np.float32)
+        eo = np.ascontiguousarray(ev_off, dtype=np.uint64)
+        _check(self._l.rh_sketch_batch(self.h, n, ptr(ev), ptr(eo), ptr(sd), cap, ptr(off)), self._l)
+        return sd[: int(off[n])], off
+
+    def seed(self, opts, seeds, seed_off, q_offset=None, prev=None, prev_off=None, cap=None):
+        n = len(seed_off) - 1
+        cap = cap or (len(seeds) * 600 + (0 if prev is None else len(prev)) + 1024)
+        an = np.zeros(cap, dtype=MM128)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        rep = np.zeros(max(n, 1), dtype=np.int32)
+        sd = np.ascontiguousarray(seeds, dtype=MM128)
+        so = np.ascontiguousarray(seed_off, dtype=np.uint64)
+        qo = None if q_offset is None else np.ascontiguousarray(q_offset, dtype=np.uint32)
+        pv = None if prev is None else np.ascontiguousarray(prev, dtype=MM128)
+        po = None if prev_off is None else np.ascontiguousarray(prev_off, dtype=np.uint64)
+        _check(self._l.rh_seed_batch(self.h, C.byref(opts.mo), n, ptr(sd), ptr(so), ptr(qo), ptr(pv), ptr(po),
+                                     ptr(an), cap, ptr(off), ptr(rep)), self._l)
+        return an[: int(off[n])], off, rep[:n]
+
+    def chain(self, opts, anchors, a_off):
+        n = len(a_off) - 1
+        cap = len(anchors) + 16
+        ch = np.zeros(cap, dtype=MM128)
+        pv = np.zeros(cap, dtype=MM128)
+        co = np.zeros(n + 1, dtype=np.uint64)
+        u = np.zeros(cap, dtype=np.uint64)
+        uo = np.zeros(n + 1, dtype=np.uint64)
+        an = np.ascontiguousarray(anchors, dtype=MM128)
+        ao = np.ascontiguousarray(a_off, dtype=np.uint64)
+        _check(self._l.rh_chain_batch(self.h, C.byref(opts.mo), n, ptr(an), ptr(ao), ptr(ch), cap, ptr(co), ptr(u), cap, ptr(uo), ptr(pv)), self._l)
+        return ch[: int(co[n])], co, u[: int(uo[n])], uo, pv[: int(co[n])]
+
+    def sort128x(self, arr, offsets):
+        a = np.ascontiguousarray(arr, dtype=MM128).copy()
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _check(self._l.rh_sort128x_batch(self.h, len(off) - 1, ptr(a), ptr(off)), self._l)
+        return a
+
+
+def paf_lines(index, recs, names, mt_ms=0.0, lib=None):
+    """PAF text of the records exactly as rmap.cpp:740-783 prints it (mt:f: filled with mt_ms)."""
+    l = lib or _capi.lib()
+    buf = C.create_string_buffer(4096)
+    out = []
+    for r in recs:
+        rec = MapRecord.from_buffer_copy(r.tobytes())
+        n = l.rh_paf_format(index.h, C.byref(rec), names[int(r["read_idx"])].encode(), mt_ms, buf, 4096)
+        if n < 0:
+            raise RhError(_capi.last_error(l))
+        if n:
+            out.append(buf.value.decode())
+    return out
+
+
+def strip_mt(line):
+    """Drop the wall-clock mt:f: tag (excluded from parity)."""
+    return "\t".join(f for f in line.rstrip("\n").split("\t") if not f.startswith("mt:f:"))
+
+
+class SynthWorkload:
+    """Deterministic synthetic genome / pore model / reads, generated by the C library."""
+
+    def __init__(self, chrom_len=4_600_000, n_chrom=1, n_samples=40_000, junk_per_1024=0, noise_q24=0,
+                 model_seed=1, genome_seed=2, read_seed=3, lib=None):
+        self._l = lib or _capi.lib()
+        c = SynthCfg()
+        self._l.rh_synth_cfg_init(C.byref(c))
+        c.chrom_len, c.n_chrom, c.n_samples = chrom_len, n_chrom, n_samples
+        c.junk_per_1024, c.noise_q24 = junk_per_1024, noise_q24
+        c.model_seed, c.genome_seed, c.read_seed = model_seed, genome_seed, read_seed
+        self.cfg = c
+
+    def write_reference(self, directory):
+        os.makedirs(directory, exist_ok=True)
+        model, fasta = os.path.join(directory, "model.txt"), os.path.join(directory, "ref.fa")
+        _check(self._l.rh_synth_write_model(C.byref(self.cfg), os.fsencode(model)), self._l)
+        _check(self._l.rh_synth_write_fasta(C.byref(self.cfg), os.fsencode(fasta)), self._l)
+        return fasta, model
+
+    def reads(self, model_path, first, n, n_threads=8, with_names=True):
+        ns = self.cfg.n_samples
+        smp = np.zeros(n * ns, dtype=np.int16)
+        names = C.create_string_buffer(n * 64) if with_names else None
+        _check(self._l.rh_synth_reads(C.byref(self.cfg), os.fsencode(model_path), first, n, ptr(smp), names, n_threads), self._l)
+        nm = [names.raw[i * 64:(i + 1) * 64].split(b"\0")[0].decode() for i in range(n)] if with_names else [f"r{first + i}" for i in range(n)]
+        off = np.arange(n + 1, dtype=np.uint64) * np.uint64(ns)
+        return Reads(smp, off, nm, self.cfg.offset, np.float32(self.cfg.range / self.cfg.digitisation))
+
+    def origin(self, idx):
+        ch, pos, st, jk = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(self._l.rh_synth_origin(C.byref(self.cfg), idx, C.byref(ch), C.byref(pos), C.byref(st), C.byref(jk)), self._l)
+        return ch.value, pos.value, st.value, bool(jk.value)

@@ -1,0 +1,564 @@
+// C-ABI entry points that touch the GPU: context, index residency, the batched mapping call
+// (= kt_for(map_worker_for), reference rmap.cpp:700) and the stage-level calls used by the parity tests.
+// Host orchestration only: all arithmetic of the path is in rh_kernels.hip.  There is no CPU fallback.
+#include "rh_kernels.h"
+#include <chrono>
+#include <cmath>
+#include <memory>
+
+namespace {
+
+struct DevBuf {
+	void *p = nullptr; size_t cap = 0;
+	int ensure(size_t bytes)
+	{
+		if (bytes <= cap) return 0;
+		if (p) { RH_HIP(hipFree(p)); p = nullptr; cap = 0; }
+		const size_t want = bytes + bytes / 4 + 256;
+		RH_HIP(hipMalloc(&p, want));
+		cap = want;
+		return 0;
+	}
+	void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+	template <class T> T *as() const { return (T*)p; }
+};
+
+enum Stage { ST_H2D = 0, ST_PREFILTER, ST_EVENTS, ST_SKETCH, ST_PROBE, ST_SCAN, ST_EXPAND, ST_SORT, ST_CHAIN, ST_BACKTRACK, ST_REGIONS, ST_COMPACT, ST_FINALIZE, ST_D2H, ST_N };
+const char *kStageName[16] = {"h2d", "prefilter", "events", "sketch", "probe", "scan", "expand", "sort", "chain", "backtrack", "regions", "compact", "finalize", "d2h", "", ""};
+
+} // namespace
+
+struct rh_ctx_s {
+	int device = -1;
+	hipStream_t stream = nullptr;
+	// resident index
+	DevBuf blob; bool blob_owned = true;
+	rh_dev_index dix{};
+	bool have_index = false;
+	unsigned char header[256] = {0};
+	// logf table
+	DevBuf logf_tab;
+	// batch state + per-round arenas (grow only)
+	DevBuf raw, off, cal_off, cal_scale;
+	DevBuf st[24];
+	DevBuf act[2], n_act_dev;
+	DevBuf ev, n_ev, skip, sx, sy, n_seed, m_val, m_n, m_meta, m_pref, n_match, n_new, rep_len, a_off;
+	DevBuf anc, prev[2], u, n_u, n_v, ws, counters, rec;
+	// timing
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	rh_map_stats_t stats{};
+};
+
+namespace {
+
+struct StageTimer {
+	rh_ctx *c; int stage;
+	StageTimer(rh_ctx *ctx, int st) : c(ctx), stage(st) { (void)hipEventRecord(c->e0, c->stream); }
+	~StageTimer()
+	{
+		(void)hipEventRecord(c->e1, c->stream);
+		(void)hipEventSynchronize(c->e1);
+		float ms = 0;
+		(void)hipEventElapsedTime(&ms, c->e0, c->e1);
+		c->stats.ms_kernel[stage] += ms;
+		c->stats.n_launch[stage] += 1;
+	}
+};
+
+int fill_dev_opt(const rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
+{
+	if (mo->chunk_size == 0 || mo->chunk_size > RH_CHUNK_MAX) { rh_set_error("chunk_size %u not supported on the device (1..%d)", mo->chunk_size, RH_CHUNK_MAX); return -1; }
+	if (mo->max_num_chunk > RH_MAX_CHUNKS) { rh_set_error("max_num_chunk %u > %d not supported", mo->max_num_chunk, RH_MAX_CHUNKS); return -1; }
+	if (mo->flag & (RH_M_NO_ADAPTIVE | RH_M_ALL_CHAINS)) { rh_set_error("whole-read / all-vs-all (Rawsamble) mode is not built on the device yet"); return -1; }
+	if (mo->flag & (RH_M_RMQ | RH_M_DTW_EVALUATE_CHAINS)) { rh_set_error("RMQ chaining / DTW re-scoring are out of scope of this path"); return -1; }
+	if (mo->bw_long > mo->bw) { rh_set_error("bw_long > bw (RMQ re-chaining) is out of scope of this path"); return -1; }
+	if (mo->window_length1 > 64 || mo->window_length2 > 64) { rh_set_error("segmentation windows > 64 not supported"); return -1; }
+	memset(o, 0, sizeof(*o));
+	o->chunk_size = mo->chunk_size; o->max_num_chunk = mo->max_num_chunk; o->min_events = mo->min_events;
+	o->w1 = mo->window_length1; o->w2 = mo->window_length2; o->thr1 = mo->threshold1; o->thr2 = mo->threshold2; o->peak_height = mo->peak_height;
+	o->mid_occ = mo->mid_occ;
+	o->max_dist_t = mo->max_target_gap_length; o->max_dist_q = mo->max_query_gap_length; o->bw = mo->bw;
+	o->max_skip = mo->max_num_skips; o->max_iter = mo->max_chain_iter; o->min_cnt = mo->min_num_anchors;
+	o->min_sc = mo->min_chaining_score; o->min_sc2 = mo->min_chaining_score2;
+	if (c->have_index) {	// rmap.cpp:318: computed in double, narrowed to float
+		const int span = c->dix.sp.e + c->dix.sp.k - 1;
+		o->pen_gap = (float)((double)mo->chain_gap_scale * 0.01 * span);
+		o->pen_skip = (float)((double)mo->chain_skip_scale * 0.01 * span);
+		o->sig_target = (c->dix.flag & RH_I_SIG_TARGET) ? 1 : 0;
+	}
+	o->mask_level = mo->mask_level; o->mask_len = mo->mask_len; o->pri_ratio = mo->pri_ratio; o->best_n = mo->best_n;
+	o->min_strand_sc = (int32_t)(mo->max_target_gap_length * 0.8);   // rmap.cpp:354
+	o->w_bestq = mo->w_bestq; o->w_bestmq = mo->w_bestmq; o->w_bestmc = mo->w_bestmc; o->w_threshold = mo->w_threshold;
+	o->min_mapq = mo->min_mapq; o->sample_per_base = mo->sample_per_base; o->flag = mo->flag;
+	return 0;
+}
+
+// upload (or adopt) the read batch; fills rd with device pointers and allocates the per-read state
+int stage_reads(rh_ctx *c, const rh_read_batch_t *in, rh_dev_reads *rd)
+{
+	const uint32_t R = in->n_reads;
+	memset(rd, 0, sizeof(*rd));
+	rd->n_reads = R;
+	if (in->samples_on_device) {
+		if (!in->cal_offset || !in->cal_scale) { rh_set_error("device batches must carry cal_offset and cal_scale"); return -1; }
+		rd->raw = in->samples; rd->off = in->offsets; rd->cal_off = in->cal_offset; rd->cal_scale = in->cal_scale;
+	} else {
+		const uint64_t total = R ? in->offsets[R] : 0;
+		if (c->raw.ensure(total * 2 + 2) || c->off.ensure((size_t)(R + 1) * 8) || c->cal_off.ensure((size_t)(R + 1) * 8) || c->cal_scale.ensure((size_t)(R + 1) * 4)) return -1;
+		if (total) RH_HIP(hipMemcpyAsync(c->raw.p, in->samples, total * 2, hipMemcpyHostToDevice, c->stream));
+		RH_HIP(hipMemcpyAsync(c->off.p, in->offsets, (size_t)(R + 1) * 8, hipMemcpyHostToDevice, c->stream));
+		std::vector<double> co(R, 0.0); std::vector<float> cs(R, 1.0f);
+		if (in->cal_offset) memcpy(co.data(), in->cal_offset, (size_t)R * 8);
+		if (in->cal_scale) memcpy(cs.data(), in->cal_scale, (size_t)R * 4);
+		if (R) {
+			RH_HIP(hipMemcpyAsync(c->cal_off.p, co.data(), (size_t)R * 8, hipMemcpyHostToDevice, c->stream));
+			RH_HIP(hipMemcpyAsync(c->cal_scale.p, cs.data(), (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
+		}
+		RH_HIP(hipStreamSynchronize(c->stream));   // co/cs are stack-owned
+		rd->raw = c->raw.as<int16_t>(); rd->off = c->off.as<uint64_t>(); rd->cal_off = c->cal_off.as<double>(); rd->cal_scale = c->cal_scale.as<float>();
+	}
+	const size_t n = R ? R : 1;
+	size_t k = 0;
+	auto U32 = [&](uint32_t *&p, size_t cnt) { if (c->st[k].ensure(cnt * 4)) return -1; p = c->st[k].as<uint32_t>(); ++k; return 0; };
+	auto I32 = [&](int32_t *&p, size_t cnt) { if (c->st[k].ensure(cnt * 4)) return -1; p = c->st[k].as<int32_t>(); ++k; return 0; };
+	if (U32(rd->l_sig, n) || U32(rd->chunk_start, n * (RH_MAX_CHUNKS + 1)) || U32(rd->n_sum, n) || U32(rd->ev_off, n) || U32(rd->n_prev, n) || U32(rd->stop_chunk, n)) return -1;
+	if (c->st[k].ensure(n * 8)) return -1; rd->sum = c->st[k++].as<double>();
+	if (c->st[k].ensure(n * 8)) return -1; rd->sum2 = c->st[k++].as<double>();
+	if (c->st[k].ensure(n * 8)) return -1; rd->prev_off = c->st[k++].as<uint64_t>();
+	if (c->st[k].ensure(n)) return -1; rd->done = c->st[k++].as<uint8_t>();
+	if (I32(rd->ls_ncregs, n) || I32(rd->ls_cnt, n) || I32(rd->ls_score, n) || I32(rd->ls_mapq, n) || I32(rd->ls_qs, n) || I32(rd->ls_qe, n) ||
+	    I32(rd->ls_rs, n) || I32(rd->ls_re, n) || I32(rd->ls_rid, n) || I32(rd->ls_rev, n)) return -1;
+	return 0;
+}
+
+// per-round arrays for n_act active reads
+int stage_round(rh_ctx *c, uint32_t n_act, rh_dev_round *rr)
+{
+	const size_t n = n_act ? n_act : 1, cap = (size_t)n * RH_EV_CAP;
+	if (c->ev.ensure(cap * 4) || c->n_ev.ensure(n * 4) || c->skip.ensure(n) || c->sx.ensure(cap * 8) || c->sy.ensure(cap * 8) || c->n_seed.ensure(n * 4) ||
+	    c->m_val.ensure(cap * 8) || c->m_n.ensure(cap * 4) || c->m_meta.ensure(cap * 4) || c->m_pref.ensure((size_t)n * (RH_EV_CAP + 1) * 4) ||
+	    c->n_match.ensure(n * 4) || c->n_new.ensure(n * 4) || c->rep_len.ensure(n * 4) || c->a_off.ensure((n + 1) * 8) || c->n_u.ensure(n * 4) || c->n_v.ensure(n * 4) ||
+	    c->counters.ensure(16 * 8)) return -1;
+	rr->n_act = n_act;
+	rr->ev = c->ev.as<float>(); rr->n_ev = c->n_ev.as<uint32_t>(); rr->skip = c->skip.as<uint8_t>();
+	rr->sx = c->sx.as<uint64_t>(); rr->sy = c->sy.as<uint64_t>(); rr->n_seed = c->n_seed.as<uint32_t>();
+	rr->m_val = c->m_val.as<uint64_t>(); rr->m_n = c->m_n.as<uint32_t>(); rr->m_meta = c->m_meta.as<uint32_t>(); rr->m_pref = c->m_pref.as<uint32_t>();
+	rr->n_match = c->n_match.as<uint32_t>(); rr->n_new = c->n_new.as<uint32_t>(); rr->rep_len = c->rep_len.as<int32_t>();
+	rr->a_off = c->a_off.as<uint64_t>(); rr->n_u = c->n_u.as<uint32_t>(); rr->n_v = c->n_v.as<uint32_t>();
+	rr->counters = c->counters.as<uint64_t>();
+	return 0;
+}
+
+// anchor-sized arenas for `total` anchors; prev_out = c->prev[which]
+int stage_anchors(rh_ctx *c, uint64_t total, int which, rh_dev_round *rr)
+{
+	const size_t t = total ? total : 1;
+	if (c->anc.ensure(t * 16) || c->prev[which].ensure(t * 16) || c->u.ensure(t * 8) || c->ws.ensure(t * RH_WS_PER_ANCHOR + 4096)) return -1;
+	rr->anc = c->anc.as<rh_mm128_t>(); rr->prev_out = c->prev[which].as<rh_mm128_t>(); rr->prev_in = c->prev[which ^ 1].as<rh_mm128_t>();
+	rr->u = c->u.as<uint64_t>(); rr->ws = c->ws.as<unsigned char>();
+	return 0;
+}
+
+int need_index(rh_ctx *c) { if (!c->have_index) { rh_set_error("no index resident on this context (rh_index_upload first)"); return -1; } return 0; }
+
+} // namespace
+
+// =================================================================================================== context
+extern "C" int rh_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+extern "C" int rh_ctx_create(rh_ctx **out, int device_id)
+{
+	*out = nullptr;
+	const int n = rh_device_count();
+	if (n <= 0) { rh_set_error("no HIP device visible: the mapping path has no CPU fallback"); return -1; }
+	if (device_id < 0 || device_id >= n) { rh_set_error("device %d out of range (%d visible)", device_id, n); return -1; }
+	RH_HIP(hipSetDevice(device_id));
+	std::unique_ptr<rh_ctx> c(new rh_ctx());
+	c->device = device_id;
+	RH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	RH_HIP(hipEventCreate(&c->e0));
+	RH_HIP(hipEventCreate(&c->e1));
+	// logf() of small integers from the HOST libm: hit.c:525-533 feeds integer scores to logf and truncates, so MAPQ
+	// parity needs the host's roundings (device logf may differ in the last ulp)
+	std::vector<float> tab(RH_LOGF_N);
+	for (uint32_t i = 0; i < RH_LOGF_N; ++i) tab[i] = logf((float)i);
+	if (c->logf_tab.ensure((size_t)RH_LOGF_N * 4)) return -1;
+	RH_HIP(hipMemcpy(c->logf_tab.p, tab.data(), (size_t)RH_LOGF_N * 4, hipMemcpyHostToDevice));
+	*out = c.release();
+	return 0;
+}
+
+extern "C" void rh_ctx_destroy(rh_ctx *c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	DevBuf *all[] = {&c->logf_tab, &c->raw, &c->off, &c->cal_off, &c->cal_scale, &c->act[0], &c->act[1], &c->n_act_dev, &c->ev, &c->n_ev, &c->skip, &c->sx, &c->sy,
+	                 &c->n_seed, &c->m_val, &c->m_n, &c->m_meta, &c->m_pref, &c->n_match, &c->n_new, &c->rep_len, &c->a_off, &c->anc, &c->prev[0], &c->prev[1], &c->u,
+	                 &c->n_u, &c->n_v, &c->ws, &c->counters, &c->rec};
+	for (DevBuf *b : all) b->release();
+	for (DevBuf &b : c->st) b.release();
+	if (c->blob_owned) c->blob.release();
+	if (c->e0) (void)hipEventDestroy(c->e0);
+	if (c->e1) (void)hipEventDestroy(c->e1);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+// =================================================================================================== index residency
+// Blob layout: [table: nb*8 slots of 16 B][pos: n_pos u64][seq_len: n_seq u32]; the 256-byte header describes it so
+// that another rank can adopt a broadcast copy.
+namespace {
+struct BlobHeader {
+	uint64_t magic, bytes, table_off, pos_off, len_off, n_pos;
+	int32_t lg_buckets; uint32_t n_seq; int32_t flag;
+	rh_sketch_par sp;
+};
+const uint64_t kBlobMagic = 0x3130424958444952ULL;   // "RIDXIB01"
+
+int bind_blob(rh_ctx *c, const BlobHeader &h)
+{
+	unsigned char *base = c->blob.as<unsigned char>();
+	c->dix.table = (const rh_tslot*)(base + h.table_off);
+	c->dix.pos = (const uint64_t*)(base + h.pos_off);
+	c->dix.seq_len = (const uint32_t*)(base + h.len_off);
+	c->dix.lg_buckets = h.lg_buckets; c->dix.n_seq = h.n_seq; c->dix.flag = h.flag; c->dix.sp = h.sp;
+	memset(c->header, 0, sizeof(c->header));
+	memcpy(c->header, &h, sizeof(h));
+	c->have_index = true;
+	return 0;
+}
+} // namespace
+
+extern "C" int rh_index_upload(rh_ctx *c, const rh_index *ix)
+{
+	RH_HIP(hipSetDevice(c->device));
+	if (ix->e > 16 || ix->w > RH_DEV_MAXW) { rh_set_error("index parameters e=%d w=%d exceed the device sketch limits (e<=16, w<=%d)", ix->e, ix->w, RH_DEV_MAXW); return -1; }
+	std::vector<rh_tslot> slots;
+	const int lg = rh_index_make_table(*ix, slots);
+	BlobHeader h{};
+	h.magic = kBlobMagic;
+	h.table_off = 0;
+	h.pos_off = slots.size() * sizeof(rh_tslot);
+	h.n_pos = ix->pos.size();
+	h.len_off = h.pos_off + (h.n_pos ? h.n_pos : 1) * 8;
+	h.bytes = h.len_off + (ix->lens.size() ? ix->lens.size() : 1) * 4;
+	h.lg_buckets = lg; h.n_seq = (uint32_t)ix->lens.size(); h.flag = ix->flag;
+	h.sp = rh_sketch_par{ix->e, ix->w, ix->q, ix->k, ix->diff, ix->fine_min, ix->fine_max, ix->fine_range};
+	if (!c->blob_owned) { c->blob.p = nullptr; c->blob.cap = 0; c->blob_owned = true; }
+	if (c->blob.ensure(h.bytes)) return -1;
+	unsigned char *base = c->blob.as<unsigned char>();
+	RH_HIP(hipMemcpy(base + h.table_off, slots.data(), slots.size() * sizeof(rh_tslot), hipMemcpyHostToDevice));
+	if (h.n_pos) RH_HIP(hipMemcpy(base + h.pos_off, ix->pos.data(), h.n_pos * 8, hipMemcpyHostToDevice));
+	if (h.n_seq) RH_HIP(hipMemcpy(base + h.len_off, ix->lens.data(), (size_t)h.n_seq * 4, hipMemcpyHostToDevice));
+	return bind_blob(c, h);
+}
+
+extern "C" int rh_index_device_blob(rh_ctx *c, void **dev_ptr, uint64_t *bytes, void *header_out)
+{
+	if (need_index(c)) return -1;
+	BlobHeader h; memcpy(&h, c->header, sizeof(h));
+	*dev_ptr = c->blob.p; *bytes = h.bytes;
+	if (header_out) memcpy(header_out, c->header, 256);
+	return 0;
+}
+
+extern "C" int rh_index_adopt_blob(rh_ctx *c, const rh_index *, void *dev_ptr, uint64_t bytes, const void *header, int take_ownership)
+{
+	BlobHeader h; memcpy(&h, header, sizeof(h));
+	if (h.magic != kBlobMagic || h.bytes != bytes) { rh_set_error("index blob header mismatch"); return -1; }
+	if (c->blob_owned) c->blob.release();
+	c->blob.p = dev_ptr; c->blob.cap = bytes; c->blob_owned = take_ownership != 0;
+	return bind_blob(c, h);
+}
+
+// =================================================================================================== the hot path
+extern "C" uint64_t rh_map_max_records(const rh_read_batch_t *in, const rh_mapopt_t *) { return in->n_reads; }
+
+extern "C" const char *rh_stage_name(int i) { return (i >= 0 && i < 16) ? kStageName[i] : ""; }
+
+extern "C" int rh_map_last_stats(rh_ctx *c, rh_map_stats_t *out) { *out = c->stats; return 0; }
+
+extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out)
+{
+	*n_out = 0;
+	if (need_index(c)) return -1;
+	RH_HIP(hipSetDevice(c->device));
+	rh_dev_opt o;
+	if (fill_dev_opt(c, mo, &o)) return -1;
+	const uint32_t R = in->n_reads;
+	if (out_cap < R) { rh_set_error("output capacity %llu < %u reads", (unsigned long long)out_cap, R); return -1; }
+	if (R == 0) return 0;
+	memset(&c->stats, 0, sizeof(c->stats));
+	const auto t_begin = std::chrono::steady_clock::now();
+	hipStream_t s = c->stream;
+	rh_dev_reads rd;
+	{ StageTimer t(c, ST_H2D); if (stage_reads(c, in, &rd)) return -1; }
+	if (c->act[0].ensure((size_t)R * 4) || c->act[1].ensure((size_t)R * 4) || c->n_act_dev.ensure(64) || c->counters.ensure(16 * 8) || c->rec.ensure((size_t)R * sizeof(rh_map_record_t))) return -1;
+	RH_HIP(hipMemsetAsync(c->counters.p, 0, 16 * 8, s));
+	{ StageTimer t(c, ST_PREFILTER); rhk_prefilter(s, o, rd); }
+	int cur = 0;
+	{ StageTimer t(c, ST_COMPACT); rhk_compact_active(s, o, rd, nullptr, R, 0, c->act[cur].as<uint32_t>(), c->n_act_dev.as<uint32_t>()); }
+	uint32_t n_act = 0;
+	RH_HIP(hipMemcpyAsync(&n_act, c->n_act_dev.p, 4, hipMemcpyDeviceToHost, s));
+	RH_HIP(hipStreamSynchronize(s));
+	int which = 0;
+	for (uint32_t chunk = 0; chunk < mo->max_num_chunk && n_act > 0; ++chunk) {
+		rh_dev_round rr{};
+		if (stage_round(c, n_act, &rr)) return -1;
+		rr.act = c->act[cur].as<uint32_t>(); rr.chunk = chunk;
+		rr.prev_in = c->prev[which ^ 1].as<rh_mm128_t>();
+		{ StageTimer t(c, ST_EVENTS); rhk_events(s, o, rd, rr); }
+		{ StageTimer t(c, ST_SKETCH); rhk_sketch(s, o, c->dix, rd, rr); }
+		{ StageTimer t(c, ST_PROBE); rhk_probe(s, o, c->dix, rd, rr); }
+		uint64_t total = 0;
+		{ StageTimer t(c, ST_SCAN); rhk_scan_anchors(s, rd, rr); RH_HIP(hipMemcpyAsync(&total, rr.a_off + n_act, 8, hipMemcpyDeviceToHost, s)); }
+		RH_HIP(hipStreamSynchronize(s));
+		if (stage_anchors(c, total, which, &rr)) return -1;
+		{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rr); }
+		{ StageTimer t(c, ST_SORT); rhk_sort(s, rr); }
+		{ StageTimer t(c, ST_CHAIN); rhk_chain(s, o, rr); }
+		{ StageTimer t(c, ST_BACKTRACK); rhk_backtrack(s, o, rd, rr); }
+		{ StageTimer t(c, ST_REGIONS); rhk_regions(s, o, rd, rr, c->logf_tab.as<float>()); }
+		{ StageTimer t(c, ST_COMPACT); rhk_compact_active(s, o, rd, rr.act, n_act, chunk + 1, c->act[cur ^ 1].as<uint32_t>(), c->n_act_dev.as<uint32_t>()); }
+		RH_HIP(hipMemcpyAsync(&n_act, c->n_act_dev.p, 4, hipMemcpyDeviceToHost, s));
+		RH_HIP(hipStreamSynchronize(s));
+		cur ^= 1; which ^= 1;
+	}
+	{ StageTimer t(c, ST_FINALIZE); rhk_finalize(s, o, c->dix, rd, c->rec.as<rh_map_record_t>()); }
+	{
+		StageTimer t(c, ST_D2H);
+		RH_HIP(hipMemcpyAsync(out, c->rec.p, (size_t)R * sizeof(rh_map_record_t), hipMemcpyDeviceToHost, s));
+		uint64_t cnt[16];
+		RH_HIP(hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, s));
+		RH_HIP(hipStreamSynchronize(s));
+		c->stats.n_events = cnt[0]; c->stats.n_seeds = cnt[1]; c->stats.n_hits = cnt[2]; c->stats.n_anchors = cnt[3]; c->stats.n_chained = cnt[4];
+		c->stats.n_samples_used = cnt[5]; c->stats.n_chunks = cnt[6];
+	}
+	RH_HIP(hipGetLastError());
+	c->stats.n_reads = R;
+	c->stats.n_samples_raw = in->samples_on_device ? 0 : in->offsets[R];
+	c->stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+	*n_out = R;
+	return 0;
+}
+
+// =================================================================================================== stage-level calls
+namespace {
+
+// identity active list 0..n-1 on the device
+int make_identity(rh_ctx *c, uint32_t n, int slot)
+{
+	std::vector<uint32_t> id(n ? n : 1);
+	for (uint32_t i = 0; i < n; ++i) id[i] = i;
+	if (c->act[slot].ensure((size_t)(n ? n : 1) * 4)) return -1;
+	if (n) RH_HIP(hipMemcpy(c->act[slot].p, id.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+	return 0;
+}
+
+template <class T> int d2h(std::vector<T> &dst, const void *src, size_t n) { dst.resize(n ? n : 1); if (n) RH_HIP(hipMemcpy(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost)); return 0; }
+template <class T> int h2d(void *dst, const T *src, size_t n) { if (n) RH_HIP(hipMemcpy(dst, src, n * sizeof(T), hipMemcpyHostToDevice)); return 0; }
+
+// state arrays for stage calls that do not start from raw signal
+int stage_state_only(rh_ctx *c, uint32_t R, rh_dev_reads *rd)
+{
+	rh_read_batch_t empty{};
+	std::vector<uint64_t> off((size_t)R + 1, 0);
+	empty.n_reads = R; empty.offsets = off.data(); empty.samples = nullptr;
+	if (stage_reads(c, &empty, rd)) return -1;
+	const size_t n = R ? R : 1;
+	RH_HIP(hipMemset(rd->ev_off, 0, n * 4)); RH_HIP(hipMemset(rd->n_prev, 0, n * 4)); RH_HIP(hipMemset(rd->prev_off, 0, n * 8));
+	RH_HIP(hipMemset(rd->done, 0, n)); RH_HIP(hipMemset(rd->ls_ncregs, 0, n * 4));
+	return 0;
+}
+
+} // namespace
+
+extern "C" int rh_events_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, uint32_t chunk, float *events, uint64_t events_cap, uint64_t *ev_offsets, uint32_t *l_sig)
+{
+	RH_HIP(hipSetDevice(c->device));
+	rh_mapopt_t m2 = *mo;
+	m2.max_num_chunk = RH_MAX_CHUNKS; m2.flag = 0; m2.bw_long = 0;
+	if (chunk >= RH_MAX_CHUNKS) { rh_set_error("chunk %u out of range", chunk); return -1; }
+	rh_dev_opt o;
+	if (fill_dev_opt(c, &m2, &o)) return -1;
+	o.min_events = 0;
+	const uint32_t R = in->n_reads;
+	hipStream_t s = c->stream;
+	rh_dev_reads rd;
+	if (stage_reads(c, in, &rd)) return -1;
+	if (c->act[0].ensure((size_t)(R ? R : 1) * 4) || c->act[1].ensure((size_t)(R ? R : 1) * 4) || c->n_act_dev.ensure(64) || c->counters.ensure(16 * 8)) return -1;
+	rhk_prefilter(s, o, rd);
+	std::vector<uint32_t> act_h; std::vector<uint32_t> nev_h; std::vector<float> ev_h;
+	uint32_t n_act = 0;
+	for (uint32_t cc = 0; cc <= chunk; ++cc) {
+		rhk_compact_active(s, o, rd, nullptr, R, cc, c->act[0].as<uint32_t>(), c->n_act_dev.as<uint32_t>());
+		RH_HIP(hipMemcpyAsync(&n_act, c->n_act_dev.p, 4, hipMemcpyDeviceToHost, s));
+		RH_HIP(hipStreamSynchronize(s));
+		if (n_act == 0) break;
+		rh_dev_round rr{};
+		if (stage_round(c, n_act, &rr)) return -1;
+		rr.act = c->act[0].as<uint32_t>(); rr.chunk = cc;
+		rhk_events(s, o, rd, rr);
+		RH_HIP(hipStreamSynchronize(s));
+		if (cc == chunk) { if (d2h(act_h, rr.act, n_act) || d2h(nev_h, rr.n_ev, n_act) || d2h(ev_h, rr.ev, (size_t)n_act * RH_EV_CAP)) return -1; }
+	}
+	RH_HIP(hipGetLastError());
+	if (l_sig && R) RH_HIP(hipMemcpy(l_sig, rd.l_sig, (size_t)R * 4, hipMemcpyDeviceToHost));
+	std::vector<int64_t> slot(R, -1);
+	if (act_h.size() >= n_act) for (uint32_t a = 0; a < n_act && !nev_h.empty(); ++a) slot[act_h[a]] = a;
+	uint64_t k = 0;
+	ev_offsets[0] = 0;
+	for (uint32_t r = 0; r < R; ++r) {
+		if (slot[r] >= 0) {
+			const uint32_t ne = nev_h[slot[r]];
+			if (k + ne > events_cap) { rh_set_error("events buffer too small"); return -1; }
+			memcpy(events + k, ev_h.data() + (size_t)slot[r] * RH_EV_CAP, (size_t)ne * 4);
+			k += ne;
+		}
+		ev_offsets[r + 1] = k;
+	}
+	return 0;
+}
+
+extern "C" int rh_sketch_batch(rh_ctx *c, uint32_t R, const float *events, const uint64_t *ev_offsets, rh_mm128_t *seeds, uint64_t seeds_cap, uint64_t *seed_offsets)
+{
+	if (need_index(c)) return -1;
+	RH_HIP(hipSetDevice(c->device));
+	rh_dev_opt o{};
+	rh_dev_reads rd;
+	if (stage_state_only(c, R, &rd)) return -1;
+	rh_dev_round rr{};
+	if (stage_round(c, R, &rr) || make_identity(c, R, 0)) return -1;
+	rr.act = c->act[0].as<uint32_t>();
+	std::vector<float> evp((size_t)(R ? R : 1) * RH_EV_CAP, 0.0f); std::vector<uint32_t> nev(R ? R : 1, 0); std::vector<uint8_t> skip(R ? R : 1, 0);
+	for (uint32_t r = 0; r < R; ++r) {
+		const uint64_t ne = ev_offsets[r + 1] - ev_offsets[r];
+		if (ne > RH_EV_CAP) { rh_set_error("read %u has %llu events (> %d per chunk)", r, (unsigned long long)ne, RH_EV_CAP); return -1; }
+		memcpy(&evp[(size_t)r * RH_EV_CAP], events + ev_offsets[r], ne * 4); nev[r] = (uint32_t)ne;
+	}
+	if (h2d(rr.ev, evp.data(), evp.size()) || h2d(rr.n_ev, nev.data(), R) || h2d(rr.skip, skip.data(), R)) return -1;
+	RH_HIP(hipMemset(rr.counters, 0, 16 * 8));
+	rhk_sketch(c->stream, o, c->dix, rd, rr);
+	RH_HIP(hipStreamSynchronize(c->stream));
+	RH_HIP(hipGetLastError());
+	std::vector<uint64_t> sx, sy; std::vector<uint32_t> ns;
+	if (d2h(sx, rr.sx, (size_t)R * RH_EV_CAP) || d2h(sy, rr.sy, (size_t)R * RH_EV_CAP) || d2h(ns, rr.n_seed, R)) return -1;
+	uint64_t k = 0;
+	seed_offsets[0] = 0;
+	for (uint32_t r = 0; r < R; ++r) {
+		if (k + ns[r] > seeds_cap) { rh_set_error("seed buffer too small"); return -1; }
+		for (uint32_t i = 0; i < ns[r]; ++i) { seeds[k].x = sx[(size_t)r * RH_EV_CAP + i]; seeds[k].y = sy[(size_t)r * RH_EV_CAP + i]; ++k; }
+		seed_offsets[r + 1] = k;
+	}
+	return 0;
+}
+
+extern "C" int rh_seed_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, const rh_mm128_t *seeds, const uint64_t *seed_offsets, const uint32_t *q_offset,
+                             const rh_mm128_t *prev, const uint64_t *prev_offsets, rh_mm128_t *anchors, uint64_t anchors_cap, uint64_t *anchor_offsets, int32_t *rep_len)
+{
+	if (need_index(c)) return -1;
+	RH_HIP(hipSetDevice(c->device));
+	rh_mapopt_t m2 = *mo; m2.flag = 0; m2.bw_long = 0;
+	rh_dev_opt o;
+	if (fill_dev_opt(c, &m2, &o)) return -1;
+	rh_dev_reads rd;
+	if (stage_state_only(c, R, &rd)) return -1;
+	rh_dev_round rr{};
+	if (stage_round(c, R, &rr) || make_identity(c, R, 0)) return -1;
+	rr.act = c->act[0].as<uint32_t>();
+	const size_t n = R ? R : 1;
+	std::vector<uint64_t> sx(n * RH_EV_CAP, 0), sy(n * RH_EV_CAP, 0); std::vector<uint32_t> ns(n, 0); std::vector<uint8_t> skip(n, 0);
+	for (uint32_t r = 0; r < R; ++r) {
+		const uint64_t m = seed_offsets[r + 1] - seed_offsets[r];
+		if (m > RH_EV_CAP) { rh_set_error("read %u has %llu seeds (> %d per chunk)", r, (unsigned long long)m, RH_EV_CAP); return -1; }
+		for (uint64_t i = 0; i < m; ++i) { sx[(size_t)r * RH_EV_CAP + i] = seeds[seed_offsets[r] + i].x; sy[(size_t)r * RH_EV_CAP + i] = seeds[seed_offsets[r] + i].y; }
+		ns[r] = (uint32_t)m;
+	}
+	if (h2d(rr.sx, sx.data(), sx.size()) || h2d(rr.sy, sy.data(), sy.size()) || h2d(rr.n_seed, ns.data(), R) || h2d(rr.skip, skip.data(), R)) return -1;
+	if (q_offset && h2d(rd.ev_off, q_offset, R)) return -1;
+	uint64_t n_prev_total = 0;
+	if (prev_offsets) {
+		std::vector<uint32_t> np(n, 0);
+		for (uint32_t r = 0; r < R; ++r) np[r] = (uint32_t)(prev_offsets[r + 1] - prev_offsets[r]);
+		n_prev_total = prev_offsets[R];
+		if (c->prev[1].ensure((n_prev_total ? n_prev_total : 1) * 16)) return -1;
+		if (h2d(c->prev[1].p, prev, n_prev_total) || h2d(rd.n_prev, np.data(), R) || h2d(rd.prev_off, prev_offsets, R)) return -1;
+	} else if (c->prev[1].ensure(16)) return -1;
+	rr.prev_in = c->prev[1].as<rh_mm128_t>();
+	RH_HIP(hipMemset(rr.counters, 0, 16 * 8));
+	hipStream_t s = c->stream;
+	rhk_probe(s, o, c->dix, rd, rr);
+	rhk_scan_anchors(s, rd, rr);
+	uint64_t total = 0;
+	RH_HIP(hipMemcpyAsync(&total, rr.a_off + R, 8, hipMemcpyDeviceToHost, s));
+	RH_HIP(hipStreamSynchronize(s));
+	if (stage_anchors(c, total, 0, &rr)) return -1;
+	rr.prev_in = c->prev[1].as<rh_mm128_t>();
+	rhk_expand(s, o, c->dix, rd, rr);
+	rhk_sort(s, rr);
+	RH_HIP(hipStreamSynchronize(s));
+	RH_HIP(hipGetLastError());
+	if (total > anchors_cap) { rh_set_error("anchor buffer too small (%llu needed)", (unsigned long long)total); return -1; }
+	RH_HIP(hipMemcpy(anchor_offsets, rr.a_off, (size_t)(R + 1) * 8, hipMemcpyDeviceToHost));
+	if (total) RH_HIP(hipMemcpy(anchors, rr.anc, total * 16, hipMemcpyDeviceToHost));
+	if (rep_len && R) RH_HIP(hipMemcpy(rep_len, rr.rep_len, (size_t)R * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+extern "C" int rh_chain_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, const rh_mm128_t *anchors, const uint64_t *anchor_offsets, rh_mm128_t *chained, uint64_t chained_cap,
+                              uint64_t *chained_offsets, uint64_t *u, uint64_t u_cap, uint64_t *u_offsets, rh_mm128_t *prev_out)
+{
+	if (need_index(c)) return -1;
+	RH_HIP(hipSetDevice(c->device));
+	rh_mapopt_t m2 = *mo; m2.flag = 0; m2.bw_long = 0;
+	rh_dev_opt o;
+	if (fill_dev_opt(c, &m2, &o)) return -1;
+	rh_dev_reads rd;
+	if (stage_state_only(c, R, &rd)) return -1;
+	rh_dev_round rr{};
+	if (stage_round(c, R, &rr) || make_identity(c, R, 0)) return -1;
+	rr.act = c->act[0].as<uint32_t>();
+	const uint64_t total = anchor_offsets[R];
+	if (stage_anchors(c, total, 0, &rr)) return -1;
+	std::vector<uint8_t> skip(R ? R : 1, 0);
+	if (h2d(rr.a_off, anchor_offsets, (size_t)R + 1) || h2d(rr.anc, anchors, total) || h2d(rr.skip, skip.data(), R)) return -1;
+	RH_HIP(hipMemset(rr.counters, 0, 16 * 8));
+	RH_HIP(hipMemset(rr.n_u, 0, (size_t)(R ? R : 1) * 4)); RH_HIP(hipMemset(rr.n_v, 0, (size_t)(R ? R : 1) * 4));
+	hipStream_t s = c->stream;
+	rhk_chain(s, o, rr);
+	rhk_backtrack(s, o, rd, rr);
+	RH_HIP(hipStreamSynchronize(s));
+	RH_HIP(hipGetLastError());
+	std::vector<uint32_t> nu, nv; std::vector<rh_mm128_t> an, pv; std::vector<uint64_t> uu;
+	if (d2h(nu, rr.n_u, R) || d2h(nv, rr.n_v, R) || d2h(an, rr.anc, total) || d2h(pv, rr.prev_out, total) || d2h(uu, rr.u, total)) return -1;
+	uint64_t k = 0, ku = 0;
+	chained_offsets[0] = 0; u_offsets[0] = 0;
+	for (uint32_t r = 0; r < R; ++r) {
+		const uint64_t b = anchor_offsets[r];
+		if (k + nv[r] > chained_cap || ku + nu[r] > u_cap) { rh_set_error("chain output buffers too small"); return -1; }
+		for (uint32_t i = 0; i < nv[r]; ++i) { chained[k + i] = an[b + i]; if (prev_out) prev_out[k + i] = pv[b + i]; }
+		for (uint32_t i = 0; i < nu[r]; ++i) u[ku + i] = uu[b + i];
+		k += nv[r]; ku += nu[r];
+		chained_offsets[r + 1] = k; u_offsets[r + 1] = ku;
+	}
+	return 0;
+}
+
+extern "C" int rh_sort128x_batch(rh_ctx *c, uint32_t n_seg, rh_mm128_t *a, const uint64_t *offsets)
+{
+	RH_HIP(hipSetDevice(c->device));
+	const uint64_t total = n_seg ? offsets[n_seg] : 0;
+	if (c->anc.ensure((total ? total : 1) * 16) || c->a_off.ensure((size_t)(n_seg + 1) * 8) || c->ws.ensure((size_t)(n_seg ? n_seg : 1) * 2048)) return -1;
+	if (h2d(c->anc.p, a, total) || h2d(c->a_off.p, offsets, (size_t)n_seg + 1)) return -1;
+	rhk_sort_segments(c->stream, n_seg, c->anc.as<rh_mm128_t>(), c->a_off.as<uint64_t>(), c->ws.as<unsigned char>());
+	RH_HIP(hipStreamSynchronize(c->stream));
+	RH_HIP(hipGetLastError());
+	if (total) RH_HIP(hipMemcpy(a, c->anc.p, total * 16, hipMemcpyDeviceToHost));
+	return 0;
+}

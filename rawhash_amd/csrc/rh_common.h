@@ -1,6 +1,6 @@
 // Shared host-side helpers of librawhash_amd (error reporting, small utilities).
 #pragma once
-#include "../../include/rawhash_amd.h"
+#include "rawhash_amd.h"
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>

@@ -1,0 +1,24 @@
+// HIP runtime glue for gfx950: error checks, launch macro, host/device qualifier.
+// (tests/emu/ holds a same-named header that shadows this one when the kernel sources are compiled for the
+//  CPU-side SIMT logic emulator used by the `not gpu` tests; the product build never sees it.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+#define RH_HD __host__ __device__
+#define RH_DEV __device__ __forceinline__
+#define RH_WAVE 64
+
+void rh_set_error(const char *fmt, ...);
+
+#define RH_HIP(call)                                                                                   \
+	do {                                                                                               \
+		hipError_t e_ = (call);                                                                        \
+		if (e_ != hipSuccess) {                                                                        \
+			rh_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_));    \
+			return -1;                                                                                 \
+		}                                                                                              \
+	} while (0)
+
+// kernel<<<grid, block, lds, stream>>>(args...)
+#define RH_LAUNCH(kernel, grid, block, lds, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, __VA_ARGS__)

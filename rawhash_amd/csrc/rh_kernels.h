@@ -1,0 +1,90 @@
+// Device-side data structures and kernel launch wrappers of the mapping path (gfx950).
+// Layout: batch-of-reads, structure-of-arrays, CSR offsets; no per-read allocation anywhere.
+#pragma once
+#include "rh_gpu.h"
+#include "rh_core.h"
+#include "rh_index.h"
+
+#define RH_CHUNK_MAX   4096          // samples of one chunk held in LDS by the event kernel
+#define RH_EV_CAP      2048          // events per chunk: peaks are >= 2 samples apart (revent.c:140)
+#define RH_MAX_CHUNKS  32            // chunk boundaries kept per read
+#define RH_WS_PER_ANCHOR 96          // bytes of per-anchor scratch shared by sort / DP / backtrack / regions
+#define RH_LOGF_N      (1u << 20)    // host-libm logf() table for integer arguments (MAPQ parity, hit.c:525-533)
+#define RH_DEV_MAXW    16            // largest minimiser window the device sketch supports
+
+// index resident in HBM
+struct rh_dev_index {
+	const rh_tslot *table;           // (1 << lg_buckets) buckets x RH_TB_SLOTS slots
+	const uint64_t *pos;             // concatenated position lists
+	const uint32_t *seq_len;
+	int32_t lg_buckets;
+	uint32_t n_seq;
+	int32_t flag;
+	rh_sketch_par sp;
+};
+
+// scalar parameters every kernel may need
+struct rh_dev_opt {
+	uint32_t chunk_size, max_num_chunk, min_events;
+	uint32_t w1, w2; float thr1, thr2, peak_height;
+	int32_t mid_occ;
+	int32_t max_dist_t, max_dist_q, bw, max_skip, max_iter, min_cnt, min_sc, min_sc2;
+	float pen_gap, pen_skip;
+	float mask_level; int32_t mask_len; float pri_ratio; int32_t best_n; int32_t min_strand_sc;
+	float w_bestq, w_bestmq, w_bestmc, w_threshold;
+	int32_t min_mapq;
+	float sample_per_base;
+	int64_t flag;
+	int32_t sig_target;
+};
+
+// per-batch read state (all arrays have n_reads entries unless noted)
+struct rh_dev_reads {
+	uint32_t n_reads;
+	const int16_t *raw; const uint64_t *off; const double *cal_off; const float *cal_scale;
+	uint32_t *l_sig;                 // filtered length (sl:i tag)
+	uint32_t *chunk_start;           // n_reads x (RH_MAX_CHUNKS+1): raw index of the first sample of chunk c
+	double *sum, *sum2; uint32_t *n_sum;   // running normalisation sums (rmap.cpp:412-413)
+	uint32_t *ev_off;                // events accepted so far (reg->offset)
+	uint32_t *n_prev; uint64_t *prev_off;  // carried chain anchors (reg->prev_anchors)
+	uint8_t *done;                   // 1 once a mapping decision stopped the read
+	uint32_t *stop_chunk;            // chunk index at which it stopped
+	// summary of the regions of the last processed chunk (what the record is built from)
+	int32_t *ls_ncregs, *ls_cnt, *ls_score, *ls_mapq, *ls_qs, *ls_qe, *ls_rs, *ls_re, *ls_rid, *ls_rev;
+};
+
+// per-round work arrays indexed by active slot a in [0, n_act)
+struct rh_dev_round {
+	const uint32_t *act;             // read ids active this round
+	uint32_t n_act; uint32_t chunk;
+	float *ev; uint32_t *n_ev;       // n_act x RH_EV_CAP
+	uint8_t *skip;                   // chunk produced < min_events events (rmap.cpp:232)
+	uint64_t *sx, *sy; uint32_t *n_seed;     // n_act x RH_EV_CAP seeds
+	uint64_t *m_val; uint32_t *m_n, *m_meta, *m_pref; uint32_t *n_match, *n_new; int32_t *rep_len;   // kept seed matches
+	uint64_t *a_off;                 // n_act+1 anchor offsets (exclusive scan of n_new + n_prev)
+	rh_mm128_t *anc;                 // anchors (sorted in place)
+	rh_mm128_t *chn;                 // chained anchors, chains ordered by target position
+	const rh_mm128_t *prev_in; rh_mm128_t *prev_out;
+	uint64_t *u; uint32_t *n_u, *n_v;        // chains: score<<32 | count
+	unsigned char *ws;               // RH_WS_PER_ANCHOR bytes per anchor
+	uint64_t *counters;              // [0] events [1] seeds [2] hits [3] anchors [4] chained [5] samples used [6] chunks
+};
+
+struct rh_launch_ctx { hipStream_t stream; };
+
+// kernel launchers (rh_kernels.hip)
+void rhk_prefilter(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd);
+void rhk_events(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
+void rhk_sketch(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
+void rhk_probe(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
+void rhk_scan_anchors(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r);
+void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
+void rhk_sort(hipStream_t s, const rh_dev_round &r);
+void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
+void rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
+void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r, const float *logf_tab);
+void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act_in, uint32_t n_in, uint32_t next_chunk,
+                        uint32_t *act_out, uint32_t *n_out);
+void rhk_finalize(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, rh_map_record_t *rec);
+// generic segmented exact sort (test entry point rh_sort128x_batch)
+void rhk_sort_segments(hipStream_t s, uint32_t n_seg, rh_mm128_t *a, const uint64_t *off, unsigned char *ws);

@@ -1,0 +1,90 @@
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def product_lib():
+    """The hipcc-built product library (host-side entry points work without a GPU)."""
+    from rawhash_amd import _capi, build as rb
+    if not os.path.exists(_capi.LIB_PATH):
+        rb.build()
+    return _capi.lib()
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """Same sources compiled against the SIMT emulator (tests/emu) -- CPU-side kernel-logic checks only."""
+    from rawhash_amd import _capi
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    return _capi.load(build_emu.build())
+
+
+class Workload:
+    """Synthetic reference + index + reads, generated from seeds by the product library's host code."""
+
+    def __init__(self, directory, lib, preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=12_000, n_reads=48,
+                 junk=150, noise=150_000, read_seed=3, index_lib=None):
+        from rawhash_amd.api import SynthWorkload, MapOptions, Index
+        self.dir, self.preset = str(directory), preset
+        self.wl = SynthWorkload(chrom_len=chrom_len, n_chrom=n_chrom, n_samples=n_samples, junk_per_1024=junk, noise_q24=noise,
+                                read_seed=read_seed, lib=lib)
+        self.fasta, self.model = self.wl.write_reference(self.dir)
+        self.opts = MapOptions(preset, lib=lib)
+        self.ind = os.path.join(self.dir, f"ref_{preset}.ind")
+        self.index = Index.build(self.fasta, self.model, self.opts, out_ind=self.ind, n_threads=8, lib=lib)
+        self.opts.update(self.index)
+        self.reads = self.wl.reads(self.model, 0, n_reads)
+
+    def oracle(self):
+        import oracle_lib as O
+        oix = O.OracleIndex(self.ind)
+        _, mo = O.preset(self.preset)
+        O.lib().ro_mapopt_update(C.byref(mo), oix.h)
+        return oix, mo
+
+    def oracle_paf(self, reads=None, n_threads=4):
+        import oracle_lib as O
+        reads = reads or self.reads
+        oix, mo = self.oracle()
+        recs = O.map_batch(oix, mo, reads.batch(), n_threads=n_threads)
+        return [O.strip_mt(x) for x in O.paf_lines(oix, recs, reads.names)]
+
+
+@pytest.fixture(scope="session")
+def make_workload(tmp_path_factory, product_lib):
+    cache = {}
+
+    def make(lib=None, **kw):
+        key = (id(lib),) + tuple(sorted(kw.items()))
+        if key not in cache:
+            cache[key] = Workload(tmp_path_factory.mktemp("wl"), lib or product_lib, **kw)
+        return cache[key]
+    return make
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx_factory(product_lib):
+    from rawhash_amd.api import Context
+    made = []
+
+    def make():
+        c = Context(0, lib=product_lib)
+        made.append(c)
+        return c
+    yield make
+    for c in made:
+        c.close()

@@ -1,0 +1,43 @@
+"""TEST INFRASTRUCTURE ONLY: compile the unchanged product sources against the SIMT emulator header (tests/emu/rh_gpu.h)
+into tests/emu/_build/librawhash_emu.so with g++.  Used by the `not gpu` tests to exercise kernel logic on the CPU."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "rawhash_amd", "csrc")
+BUILD = os.path.join(HERE, "_build")
+OUT = os.path.join(BUILD, "librawhash_emu.so")
+
+
+def build(force=False):
+    src_dir = os.path.join(BUILD, "src")
+    os.makedirs(src_dir, exist_ok=True)
+    srcs = []
+    newest = 0.0
+    for f in sorted(os.listdir(CSRC)):
+        if f == "rh_gpu.h" or not f.endswith((".h", ".cpp", ".hip")):
+            continue
+        dst = os.path.join(src_dir, f)
+        if os.path.lexists(dst):
+            os.remove(dst)
+        os.symlink(os.path.join(CSRC, f), dst)       # same files, but rh_gpu.h now resolves to the emulator's
+        newest = max(newest, os.path.getmtime(os.path.join(CSRC, f)))
+        if f.endswith((".cpp", ".hip")):
+            srcs.append(dst)
+    for f in ("rh_gpu.h", "emu_runtime.cpp"):
+        shutil.copy(os.path.join(HERE, f), os.path.join(src_dir, f))
+        newest = max(newest, os.path.getmtime(os.path.join(HERE, f)))
+    srcs.append(os.path.join(src_dir, "emu_runtime.cpp"))
+    newest = max(newest, os.path.getmtime(os.path.join(ROOT, "include", "rawhash_amd.h")))
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
+        return OUT
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-pthread", "-w",
+           "-I", src_dir, "-I", os.path.join(ROOT, "include"), "-x", "c++"] + srcs + ["-o", OUT, "-lz"]
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,74 @@
+// TEST INFRASTRUCTURE ONLY: SIMT logic emulator that shadows rawhash_amd/csrc/rh_gpu.h when the *unchanged* kernel
+// and host sources are compiled with g++ into tests/emu/_build/librawhash_emu.so (see tests/emu/build_emu.py).
+// It lets the `not gpu` tests run the real kernel code (block barriers, wave ballots, shuffles, LDS) on the CPU so
+// indexing/ordering bugs are caught without a GPU.  Each thread of a block is a ucontext fiber; blocks run one after
+// another.  Nothing here is compiled into, or loaded by, the product library.
+#pragma once
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define RH_HD
+#define RH_DEV static inline
+#define RH_WAVE 64
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+
+void rh_set_error(const char *fmt, ...);
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+extern dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+// ---- device-side intrinsics
+void emu_syncthreads();
+unsigned long long emu_ballot(int pred);
+unsigned long long emu_shfl_down_bits(unsigned long long bits, unsigned delta);
+#define __syncthreads() emu_syncthreads()
+#define __ballot(p) emu_ballot((p) ? 1 : 0)
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline double __shfl_down(double v, int d) { unsigned long long b; memcpy(&b, &v, 8); b = emu_shfl_down_bits(b, (unsigned)d); memcpy(&v, &b, 8); return v; }
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
+
+// ---- host runtime subset
+typedef int hipError_t;
+typedef void *hipStream_t;
+typedef void *hipEvent_t;
+enum { hipSuccess = 0 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum { hipStreamNonBlocking = 1 };
+static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); if (*p) memset(*p, 0xCD, n); return *p ? hipSuccess : 2; }
+template <class T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, int) { *s = (void*)1; return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (void*)1; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+
+#define RH_HIP(call)                                                                                   \
+	do {                                                                                               \
+		hipError_t e_ = (call);                                                                        \
+		if (e_ != hipSuccess) { rh_set_error("%s:%d: %s failed", __FILE__, __LINE__, #call); return -1; } \
+	} while (0)
+
+void emu_launch(unsigned grid, unsigned block, const std::function<void()> &body);
+#define RH_LAUNCH(kernel, grid, block, lds, stream, ...) emu_launch((unsigned)(grid), (unsigned)(block), [&]() { kernel(__VA_ARGS__); })

@@ -1,0 +1,54 @@
+"""Regenerate tests/golden/*.paf with the reference (run in the build container, where /root/reference exists):
+
+    python tests/golden/make_golden.py
+
+For every case: synthetic reference + reads from seeds (rawhash_amd host code) -> `ref_harness index` (the reference's
+own index builder) -> `ref_harness map -t 1` (the reference's own mapper + PAF printer) -> PAF minus the mt:f: tag.
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CASES = [
+    {"name": "small_sensitive", "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=160, junk=150, noise=150_000, read_seed=11)},
+    {"name": "small_fast", "workload": dict(preset="fast", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=160, junk=150, noise=150_000, read_seed=12)},
+    {"name": "small_faster_minimizers", "workload": dict(preset="faster", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=160, junk=150, noise=150_000, read_seed=13)},
+    {"name": "small_viral_dense", "workload": dict(preset="viral", chrom_len=150_000, n_chrom=1, n_samples=20_000, n_reads=120, junk=100, noise=100_000, read_seed=14)},
+    {"name": "clean_ecoli_like", "workload": dict(preset="sensitive", chrom_len=1_000_000, n_chrom=1, n_samples=40_000, n_reads=200, junk=102, noise=0, read_seed=15)},
+]
+
+
+def main():
+    import oracle_lib as O
+    from conftest import Workload
+    from rawhash_amd import _capi
+    lib = _capi.lib()
+    assert O.have_reference(), "build oracle/_ref first (make -C oracle ref)"
+    for case in CASES:
+        with tempfile.TemporaryDirectory() as d:
+            w = Workload(d, lib, **case["workload"])
+            cfg = w.wl.cfg
+            rhr = os.path.join(d, "reads.rhr")
+            w.reads.write(rhr, cfg.digitisation, cfg.range, cfg.offset)
+            preset = case["workload"]["preset"]
+            ref_ind = os.path.join(d, "refbuilt.ind")
+            subprocess.run([O.REF_HARNESS, "index", preset, w.fasta, w.model, ref_ind, "4"], check=True, stderr=subprocess.DEVNULL)
+            out = subprocess.run([O.REF_HARNESS, "map", preset, ref_ind, rhr, "1"], check=True, capture_output=True, text=True).stdout
+            lines = [O.strip_mt(l) for l in out.splitlines()]
+            assert len(lines) == len(w.reads)
+            with open(os.path.join(HERE, case["name"] + ".paf"), "w") as f:
+                f.write("\n".join(lines) + "\n")
+            print(case["name"], len(lines), "lines,", sum(1 for l in lines if l.split("\t")[4] != "*"), "mapped")
+    with open(os.path.join(HERE, "cases.json"), "w") as f:
+        json.dump(CASES, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

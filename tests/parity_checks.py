@@ -1,0 +1,139 @@
+"""Backend-independent parity checks: `lib` is either the HIP product library (GPU tests) or the SIMT-emulator build
+of the same sources (CPU tests).  The checker is always the CPU oracle (oracle/rh_oracle.c)."""
+import ctypes as C
+
+import numpy as np
+
+import oracle_lib as O
+from rawhash_amd._capi import MM128, ptr
+from rawhash_amd.api import Context, paf_lines, strip_mt
+
+
+def check_events(ctx, wl, chunks=(0, 1, 2)):
+    b = wl.reads.batch()
+    n = len(wl.reads)
+    for c in chunks:
+        ev, off, lsig = ctx.events(wl.opts, wl.reads, c)
+        cap = n * 2048 + 16
+        oev = np.zeros(cap, dtype=np.float32)
+        ooff = np.zeros(n + 1, dtype=np.uint64)
+        olsig = np.zeros(n, dtype=np.uint32)
+        assert O.lib().ro_events_batch(C.byref(wl.opts.mo), C.byref(b), c, ptr(oev), cap, ptr(ooff), ptr(olsig)) == 0
+        assert np.array_equal(lsig, olsig)
+        assert np.array_equal(off, ooff), f"event counts differ in chunk {c}"
+        # bit-exact fp32 (the emitted seed set depends on it); tolerance = 0 ulp
+        assert np.array_equal(ev.view(np.uint32), oev[: int(ooff[n])].view(np.uint32)), f"event values differ in chunk {c}"
+    return ev, off
+
+
+def oracle_events(wl, chunk=0):
+    b = wl.reads.batch()
+    n = len(wl.reads)
+    cap = n * 2048 + 16
+    oev = np.zeros(cap, dtype=np.float32)
+    ooff = np.zeros(n + 1, dtype=np.uint64)
+    assert O.lib().ro_events_batch(C.byref(wl.opts.mo), C.byref(b), chunk, ptr(oev), cap, ptr(ooff), None) == 0
+    return oev[: int(ooff[n])], ooff
+
+
+def oracle_seeds(wl, ev, eoff):
+    oix, mo = wl.oracle()
+    n = len(eoff) - 1
+    cap = len(ev) * 4 + 16
+    sd = np.zeros(cap, dtype=MM128)
+    so = np.zeros(n + 1, dtype=np.uint64)
+    assert O.lib().ro_sketch_batch(oix.h, n, ptr(ev), ptr(eoff), ptr(sd), cap, ptr(so)) == 0
+    return sd[: int(so[n])], so
+
+
+def oracle_anchors(wl, sd, so, q_offset=None, prev=None, prev_off=None):
+    oix, mo = wl.oracle()
+    n = len(so) - 1
+    cap = len(sd) * (mo.mid_occ + 1) + (0 if prev is None else len(prev)) + 1024
+    an = np.zeros(cap, dtype=MM128)
+    ao = np.zeros(n + 1, dtype=np.uint64)
+    rep = np.zeros(n, dtype=np.int32)
+    assert O.lib().ro_seed_batch(oix.h, C.byref(mo), n, ptr(sd), ptr(so), ptr(q_offset), ptr(prev), ptr(prev_off), ptr(an), cap, ptr(ao), ptr(rep)) == 0
+    return an[: int(ao[n])], ao, rep
+
+
+def oracle_chains(wl, an, ao):
+    oix, mo = wl.oracle()
+    n = len(ao) - 1
+    cap = len(an) + 16
+    ch = np.zeros(cap, dtype=MM128)
+    pv = np.zeros(cap, dtype=MM128)
+    co = np.zeros(n + 1, dtype=np.uint64)
+    u = np.zeros(cap, dtype=np.uint64)
+    uo = np.zeros(n + 1, dtype=np.uint64)
+    assert O.lib().ro_chain_batch(oix.h, C.byref(mo), n, ptr(an), ptr(ao), ptr(ch), cap, ptr(co), ptr(u), cap, ptr(uo), ptr(pv)) == 0
+    return ch[: int(co[n])], co, u[: int(uo[n])], uo, pv[: int(co[n])]
+
+
+def check_stages(ctx, wl):
+    """events -> sketch -> seed/anchors(+exact sort) -> chain, each stage fed with the oracle's output of the previous one."""
+    ev, eoff = oracle_events(wl, 0)
+    sd, so = ctx.sketch(ev, eoff)
+    osd, oso = oracle_seeds(wl, ev, eoff)
+    assert np.array_equal(so, oso) and np.array_equal(sd, osd), "seeds differ"
+    n = len(oso) - 1
+    qoff = (np.arange(n, dtype=np.uint32) * 7) % 500
+    oan, oao, orep = oracle_anchors(wl, osd, oso, qoff)
+    an, ao, rep = ctx.seed(wl.opts, osd, oso, q_offset=qoff, cap=len(oan) + 1024)
+    assert np.array_equal(ao, oao), "anchor counts differ"
+    assert np.array_equal(rep, orep), "rep_len differs"
+    assert np.array_equal(an, oan), "sorted anchors differ (exact radix_sort_128x permutation)"
+    och, oco, ou, ouo, opv = oracle_chains(wl, oan, oao)
+    ch, co, u, uo, pv = ctx.chain(wl.opts, oan, oao)
+    assert np.array_equal(co, oco) and np.array_equal(uo, ouo), "chain counts differ"
+    assert np.array_equal(u, ou) and np.array_equal(ch, och) and np.array_equal(pv, opv), "chains differ"
+    # second round: carried anchors merged into the next chunk's anchor set
+    ev1, eoff1 = oracle_events(wl, 1)
+    osd1, oso1 = oracle_seeds(wl, ev1, eoff1)
+    qoff1 = (eoff[1:] - eoff[:-1]).astype(np.uint32)
+    oan1, oao1, orep1 = oracle_anchors(wl, osd1, oso1, qoff1, opv, oco)
+    an1, ao1, rep1 = ctx.seed(wl.opts, osd1, oso1, q_offset=qoff1, prev=opv, prev_off=oco, cap=len(oan1) + 1024)
+    assert np.array_equal(ao1, oao1) and np.array_equal(an1, oan1) and np.array_equal(rep1, orep1), "anchors with carried chain differ"
+    return len(oan), len(och)
+
+
+def check_sort(ctx, seed=0, n_seg=40):
+    """Exact unstable-permutation emulation of radix_sort_128x, with heavy key ties in every byte position."""
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(0, 900, size=n_seg)
+    sizes[:4] = [0, 1, 64, 65]
+    off = np.zeros(n_seg + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(sizes)
+    tot = int(off[-1])
+    a = np.zeros(tot, dtype=MM128)
+    for s in range(n_seg):
+        b, e = int(off[s]), int(off[s + 1])
+        mode = s % 4
+        if mode == 0:
+            x = rng.integers(0, 1 << 62, size=e - b, dtype=np.uint64)
+        elif mode == 1:
+            x = rng.integers(0, 40, size=e - b, dtype=np.uint64)                      # small scores: many ties
+        elif mode == 2:
+            x = (rng.integers(0, 2, size=e - b, dtype=np.uint64) << np.uint64(63)) | rng.integers(0, 3000, size=e - b, dtype=np.uint64)
+        else:
+            x = rng.integers(0, 6, size=e - b, dtype=np.uint64) << np.uint64(8 * int(rng.integers(0, 8)))
+        a["x"][b:e] = x
+    a["y"] = np.arange(tot, dtype=np.uint64)
+    want = a.copy()
+    assert O.lib().ro_sort128x_batch(n_seg, ptr(want), ptr(off)) == 0
+    got = ctx.sort128x(a, off)
+    assert np.array_equal(got, want)
+    for s in range(n_seg):   # property: it IS a sort
+        seg = got["x"][int(off[s]):int(off[s + 1])]
+        assert np.all(seg[:-1] <= seg[1:])
+
+
+def check_e2e(ctx, wl, reads=None):
+    reads = reads or wl.reads
+    recs = ctx.map_batch(wl.opts, reads)
+    got = [strip_mt(x) for x in paf_lines(wl.index, recs, reads.names, lib=ctx._l)]
+    want = wl.oracle_paf(reads)
+    assert len(got) == len(want) == len(reads)
+    bad = [(g, w) for g, w in zip(got, want) if g != w]
+    assert not bad, f"{len(bad)} PAF lines differ, first: {bad[0]}"
+    return recs

@@ -1,0 +1,47 @@
+"""The C-ABI library loads, exports every symbol include/rawhash_amd.h declares, and has no CPU fallback."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from rawhash_amd import _capi
+from rawhash_amd.api import Context, MapOptions, RhError
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_match_header(product_lib):
+    hdr = open(os.path.join(ROOT, "include", "rawhash_amd.h")).read()
+    declared = set(re.findall(r"RH_API[^;(]*?\b(rh_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 40
+    for name in declared:
+        assert hasattr(product_lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_capi.EXPORTS), "ctypes prototypes and header out of sync"
+
+
+def test_version_and_options(product_lib):
+    assert b"rawhash_amd" in product_lib.rh_version()
+    o = MapOptions("fast")
+    assert o.mo.min_mapq == 5 and o.mo.min_chaining_score == 10 and abs(o.io.fine_range - 0.6) < 1e-6
+    o = MapOptions("faster")
+    assert (o.io.e, o.io.w, o.mo.max_num_chunk) == (11, 3, 5)
+    o = MapOptions("ava")
+    assert o.io.w == 3 and o.mo.bw == 5000 and o.mo.pri_ratio == 0.0
+    with pytest.raises(RhError):
+        MapOptions("no-such-preset")
+
+
+def test_presets_match_oracle_tables(product_lib):
+    import oracle_lib as O
+    for p in [None, "sensitive", "fast", "faster", "viral", "ava", "ava-viral", "ava-sensitive", "ava-large"]:
+        a = MapOptions(p)
+        io, mo = O.preset(p)
+        assert bytes(a.io) == bytes(io) and bytes(a.mo) == bytes(mo), p
+
+
+@pytest.mark.skipif(_capi.lib().rh_device_count() > 0, reason="a GPU is visible")
+def test_no_cpu_fallback(product_lib):
+    """Without a GPU the compute entry points must fail loudly, not fall back."""
+    with pytest.raises(RhError, match="no HIP device"):
+        Context(0)

@@ -1,0 +1,46 @@
+"""CPU-side checks of the KERNEL SOURCES (rh_kernels.hip compiled against the SIMT emulator in tests/emu) against the
+oracle.  These are logic tests of the device code; the real-hardware parity tests are in test_gpu_parity.py."""
+import pytest
+
+import parity_checks as pc
+from rawhash_amd.api import Context
+
+
+@pytest.fixture(scope="module")
+def wl(make_workload, emu_lib):
+    return make_workload(lib=emu_lib, n_reads=24, n_samples=12_000)
+
+
+@pytest.fixture(scope="module")
+def ctx(emu_lib, wl):
+    c = Context(0, lib=emu_lib)
+    c.upload(wl.index)
+    yield c
+    c.close()
+
+
+def test_events_bit_exact(ctx, wl):
+    pc.check_events(ctx, wl, chunks=(0, 2))
+
+
+def test_stage_chain(ctx, wl):
+    n_anchors, n_chained = pc.check_stages(ctx, wl)
+    assert n_anchors > 0 and n_chained > 0
+
+
+def test_exact_sort(ctx):
+    pc.check_sort(ctx, seed=1, n_seg=24)
+
+
+def test_end_to_end_paf(ctx, wl):
+    recs = pc.check_e2e(ctx, wl)
+    assert recs["mapped"].sum() > 0 and (recs["mapped"] == 0).sum() > 0   # both outcomes exercised
+
+
+@pytest.mark.parametrize("preset", ["fast", "faster", "viral"])
+def test_presets(make_workload, emu_lib, preset):
+    w = make_workload(lib=emu_lib, preset=preset, n_reads=16, n_samples=12_000)
+    c = Context(0, lib=emu_lib)
+    c.upload(w.index)
+    pc.check_e2e(c, w)
+    c.close()

@@ -1,0 +1,87 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on a real MI355X."""
+import numpy as np
+import pytest
+
+import parity_checks as pc
+from rawhash_amd.api import Context, paf_lines, strip_mt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wl(make_workload):
+    return make_workload(n_reads=400, n_samples=24_000, chrom_len=600_000)
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu_ctx_factory, wl):
+    c = gpu_ctx_factory()
+    c.upload(wl.index)
+    return c
+
+
+def test_native_library_loaded(product_lib):
+    assert product_lib.rh_device_count() >= 1
+    import os
+    maps = open("/proc/self/maps").read()
+    assert "librawhash_amd.so" in maps
+
+
+def test_events_bit_exact(ctx, wl):
+    pc.check_events(ctx, wl, chunks=(0, 1, 3, 5))
+
+
+def test_stage_chain(ctx, wl):
+    pc.check_stages(ctx, wl)
+
+
+def test_exact_sort(ctx):
+    pc.check_sort(ctx, seed=2, n_seg=400)
+
+
+def test_end_to_end_paf(ctx, wl):
+    recs = pc.check_e2e(ctx, wl)
+    assert recs["mapped"].sum() > 0 and (recs["mapped"] == 0).sum() > 0
+
+
+@pytest.mark.parametrize("preset", ["fast", "faster", "viral"])
+def test_presets(make_workload, gpu_ctx_factory, preset):
+    w = make_workload(preset=preset, n_reads=200, n_samples=24_000, chrom_len=600_000)
+    c = gpu_ctx_factory()
+    c.upload(w.index)
+    pc.check_e2e(c, w)
+
+
+def test_ragged_and_empty_reads(ctx, wl):
+    """empty read, read shorter than one chunk, read shorter than min_events worth of signal, all-filtered read."""
+    from rawhash_amd.api import Reads
+    base = wl.reads
+    parts = [np.zeros(0, np.int16), base.samples[:700].copy(), base.samples[:3999].copy(), base.samples[:4001].copy(),
+             np.full(5000, 30000, np.int16), base.samples[24_000:24_000 + 9000].copy()]
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(p) for p in parts])
+    rd = Reads(np.concatenate(parts), off, [f"edge{i}" for i in range(len(parts))], base.cal_offset[0], base.cal_scale[0])
+    pc.check_e2e(ctx, wl, rd)
+
+
+def test_batch_split_invariance(ctx, wl):
+    """Mapping is per-read independent: any split of the batch gives the same records (property used by sharding)."""
+    full = ctx.map_batch(wl.opts, wl.reads)
+    idx = list(range(len(wl.reads)))
+    a, b = idx[:137], idx[137:]
+    ra = ctx.map_batch(wl.opts, wl.reads.subset(a))
+    rb = ctx.map_batch(wl.opts, wl.reads.subset(b))
+    drop = lambda r: r[[n for n in r.dtype.names if n != "read_idx"]]
+    assert np.array_equal(drop(full[:137]), drop(ra)) and np.array_equal(drop(full[137:]), drop(rb))
+
+
+def test_golden_paf(product_lib, gpu_ctx_factory, tmp_path):
+    """HIP path vs PAF produced by the pinned reference build itself (tests/golden/, made by make_golden.py)."""
+    import golden
+    for case in golden.cases():
+        w = golden.build_case(case, tmp_path / case["name"], product_lib)
+        c = gpu_ctx_factory()
+        c.upload(w.index)
+        recs = c.map_batch(w.opts, w.reads)
+        got = [strip_mt(x) for x in paf_lines(w.index, recs, w.reads.names)]
+        assert got == golden.expected_paf(case)

@@ -1,0 +1,136 @@
+"""The CPU oracle against (a) golden PAF produced by the pinned reference build and (b), where the reference harness is
+present (build container), the reference itself: PAF on fresh workloads, per-stage dumps, and index contents."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden
+import oracle_lib as O
+from rawhash_amd._capi import MM128, ptr
+
+needs_ref = pytest.mark.skipif(not O.have_reference(), reason="oracle/_ref/ref_harness not built (needs /root/reference)")
+
+
+@pytest.mark.parametrize("case", golden.cases(), ids=lambda c: c["name"])
+def test_oracle_matches_golden_paf(case, product_lib, tmp_path):
+    w = golden.build_case(case, tmp_path, product_lib)
+    assert w.oracle_paf() == golden.expected_paf(case)
+
+
+def test_paf_formatters_agree(make_workload, product_lib):
+    """product rh_paf_format == oracle ro_paf_format on the same records"""
+    from rawhash_amd.api import paf_lines
+    w = make_workload(n_reads=40)
+    oix, mo = w.oracle()
+    recs = O.map_batch(oix, mo, w.reads.batch(), n_threads=2)
+    assert paf_lines(w.index, recs, w.reads.names, mt_ms=1.25) == O.paf_lines(oix, recs, w.reads.names, mt_ms=1.25)
+
+
+def test_index_loader_and_builder_agree(make_workload):
+    """product index (built from FASTA, then written as .ind) == what the oracle's loader reads back"""
+    w = make_workload(n_reads=8)
+    oix, mo = w.oracle()
+    hs, cs = oix.listing()
+    assert len(hs) == w.index.n_keys and int(cs.sum()) == w.index.n_positions
+    rng = np.random.default_rng(0)
+    for h in rng.choice(hs, size=300, replace=False):
+        assert np.array_equal(oix.get(h), w.index.get(h))
+    assert mo.mid_occ == w.opts.mo.mid_occ
+    assert oix.names() == [w.index.seq_name(i) for i in range(w.index.n_seq)]
+
+
+def _read_dump(path):
+    recs = {}
+    with open(path, "rb") as f:
+        data = f.read()
+    p = 0
+    while p < len(data):
+        tag, rd, ch, cnt, esz = struct.unpack_from("<5I", data, p)
+        p += 20
+        recs[(tag, rd, ch)] = data[p:p + cnt * esz]
+        p += cnt * esz
+    return recs
+
+
+@needs_ref
+@pytest.mark.parametrize("preset", ["sensitive", "fast", "faster", "viral"])
+def test_oracle_vs_reference_paf_and_index(make_workload, tmp_path, preset):
+    w = make_workload(preset=preset, n_reads=300, n_samples=30_000, chrom_len=500_000, read_seed=21)
+    cfg = w.wl.cfg
+    rhr = str(tmp_path / "reads.rhr")
+    w.reads.write(rhr, cfg.digitisation, cfg.range, cfg.offset)
+    ref_ind = str(tmp_path / "ref.ind")
+    subprocess.run([O.REF_HARNESS, "index", preset, w.fasta, w.model, ref_ind, "4"], check=True, stderr=subprocess.DEVNULL)
+    # (1) the reference maps with ITS index, the oracle with the PRODUCT-built index: identical PAF
+    out = subprocess.run([O.REF_HARNESS, "map", preset, ref_ind, rhr, "4"], check=True, capture_output=True, text=True).stdout
+    assert [O.strip_mt(l) for l in out.splitlines()] == w.oracle_paf()
+    # (2) the reference also maps with the product-written .ind (format compatibility), same PAF
+    out2 = subprocess.run([O.REF_HARNESS, "map", preset, w.ind, rhr, "4"], check=True, capture_output=True, text=True).stdout
+    assert out2.splitlines() and [O.strip_mt(l) for l in out2.splitlines()] == [O.strip_mt(l) for l in out.splitlines()]
+    # (3) index contents: reference-built index dumped by the reference == product-built index
+    dump = str(tmp_path / "idx.bin")
+    subprocess.run([O.REF_HARNESS, "idxdump", ref_ind, dump], check=True, stderr=subprocess.DEVNULL)
+    with open(dump, "rb") as f:
+        hdr = struct.unpack("<9i", f.read(36))
+        nk = struct.unpack("<Q", f.read(8))[0]
+        assert nk == w.index.n_keys and hdr[7] == w.opts.mo.mid_occ
+        for _ in range(2000):
+            h, n = struct.unpack("<QI", f.read(12))
+            pos = np.frombuffer(f.read(8 * n), dtype=np.uint64)
+            assert np.array_equal(pos, w.index.get(h))
+
+
+@needs_ref
+def test_oracle_vs_reference_stage_dumps(make_workload, tmp_path):
+    """events (fp32 bit patterns), seeds, sorted anchors and chains of every chunk of 24 reads"""
+    w = make_workload(n_reads=24, n_samples=20_000, read_seed=22)
+    cfg = w.wl.cfg
+    rhr, dump = str(tmp_path / "reads.rhr"), str(tmp_path / "dump.bin")
+    w.reads.write(rhr, cfg.digitisation, cfg.range, cfg.offset)
+    subprocess.run([O.REF_HARNESS, "dump", "sensitive", w.ind, rhr, dump], check=True, stderr=subprocess.DEVNULL)
+    d = _read_dump(dump)
+    oix, mo = w.oracle()
+    b = w.reads.batch()
+    n = len(w.reads)
+    checked = 0
+    for chunk in range(5):
+        cap = n * 2048
+        ev = np.zeros(cap, dtype=np.float32)
+        eo = np.zeros(n + 1, dtype=np.uint64)
+        assert O.lib().ro_events_batch(C.byref(mo), C.byref(b), chunk, ptr(ev), cap, ptr(eo), None) == 0
+        sd = np.zeros(cap, dtype=MM128)
+        so = np.zeros(n + 1, dtype=np.uint64)
+        assert O.lib().ro_sketch_batch(oix.h, n, ptr(ev), ptr(eo), ptr(sd), cap, ptr(so)) == 0
+        for r in range(n):
+            key = (1, r, chunk)
+            if key not in d:
+                assert eo[r + 1] == eo[r]
+                continue
+            ref_ev = np.frombuffer(d[key], dtype=np.uint32)
+            assert np.array_equal(ref_ev, ev[int(eo[r]):int(eo[r + 1])].view(np.uint32))
+            if (2, r, chunk) in d:
+                ref_sd = np.frombuffer(d[(2, r, chunk)], dtype=MM128)
+                assert np.array_equal(ref_sd, sd[int(so[r]):int(so[r + 1])])
+            checked += 1
+    assert checked > 30
+    # anchors + chains of chunk 0 (no carried anchors yet)
+    ev = np.zeros(n * 2048, dtype=np.float32); eo = np.zeros(n + 1, dtype=np.uint64)
+    O.lib().ro_events_batch(C.byref(mo), C.byref(b), 0, ptr(ev), len(ev), ptr(eo), None)
+    sd = np.zeros(n * 2048, dtype=MM128); so = np.zeros(n + 1, dtype=np.uint64)
+    O.lib().ro_sketch_batch(oix.h, n, ptr(ev), ptr(eo), ptr(sd), len(sd), ptr(so))
+    cap = n * 2048 * 60
+    an = np.zeros(cap, dtype=MM128); ao = np.zeros(n + 1, dtype=np.uint64); rep = np.zeros(n, dtype=np.int32)
+    assert O.lib().ro_seed_batch(oix.h, C.byref(mo), n, ptr(sd), ptr(so), None, None, None, ptr(an), cap, ptr(ao), ptr(rep)) == 0
+    ch = np.zeros(cap, dtype=MM128); co = np.zeros(n + 1, dtype=np.uint64); u = np.zeros(cap, dtype=np.uint64); uo = np.zeros(n + 1, dtype=np.uint64)
+    assert O.lib().ro_chain_batch(oix.h, C.byref(mo), n, ptr(an), ptr(ao), ptr(ch), cap, ptr(co), ptr(u), cap, ptr(uo), None) == 0
+    for r in range(n):
+        if (3, r, 0) not in d:
+            continue
+        assert np.array_equal(np.frombuffer(d[(3, r, 0)], dtype=MM128), an[int(ao[r]):int(ao[r + 1])]), "sorted anchors"
+        assert np.array_equal(np.frombuffer(d[(4, r, 0)], dtype=np.uint64), u[int(uo[r]):int(uo[r + 1])]), "chain u[]"
+        assert np.array_equal(np.frombuffer(d[(5, r, 0)], dtype=MM128), ch[int(co[r]):int(co[r + 1])]), "chained anchors"
+        assert struct.unpack_from("<i", d[(7, r, 0)])[0] == rep[r], "rep_len"
