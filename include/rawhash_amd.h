@@ -134,6 +134,7 @@ RH_API int  rh_index_upload(rh_ctx *ctx, const rh_index *idx);
 /* Multi-GPU replication over RCCL is done by the caller on the raw device blob (torch.distributed broadcast
  * in bench.py / rawhash_amd.dist): rank 0 uploads, every rank allocates `bytes`, broadcasts, then adopts. */
 RH_API int  rh_index_device_blob(rh_ctx *ctx, void **dev_ptr, uint64_t *bytes, void *header_out /* >= 256 B */);
+RH_API int  rh_index_copy_blob(rh_ctx *ctx, void *dst_dev_ptr);   /* device-to-device copy of the resident blob */
 RH_API int  rh_index_adopt_blob(rh_ctx *ctx, const rh_index *idx_meta /* may be NULL */, void *dev_ptr, uint64_t bytes,
                                 const void *header /* from rank 0 */, int take_ownership);
 
@@ -212,6 +213,10 @@ RH_API int  rh_synth_write_fasta(const rh_synth_cfg_t *c, const char *path);
 /* reads [first, first+n): samples must hold n*n_samples int16; names (optional) n*64 chars */
 RH_API int  rh_synth_reads(const rh_synth_cfg_t *c, const char *model_path, uint64_t first, uint32_t n,
                            int16_t *samples, char *names64, int n_threads);
+/* Same reads generated directly into this GPU's HBM (bench: "inputs already resident").  out gets device pointers
+ * (samples_on_device = 1) owned by the context and valid until the next call or rh_ctx_destroy. */
+RH_API int  rh_synth_reads_device(rh_ctx *ctx, const rh_synth_cfg_t *c, const char *model_path, uint64_t first, uint32_t n,
+                                  rh_read_batch_t *out);
 /* true origin of read `idx` (for "maps to origin" sanity checks): chrom, 0-based start base, strand, junk flag */
 RH_API int  rh_synth_origin(const rh_synth_cfg_t *c, uint64_t idx, uint32_t *chrom, uint32_t *pos, uint32_t *strand, uint32_t *junk);
 

@@ -140,6 +140,8 @@ def _declare(lib):
         "rh_synth_cfg_init": (None, [P(SynthCfg)]), "rh_synth_write_model": (i32, [P(SynthCfg), cp]),
         "rh_synth_write_fasta": (i32, [P(SynthCfg), cp]),
         "rh_synth_reads": (i32, [P(SynthCfg), cp, u64, u32, vp, vp, i32]),
+        "rh_synth_reads_device": (i32, [vp, P(SynthCfg), cp, u64, u32, P(ReadBatch)]),
+        "rh_index_copy_blob": (i32, [vp, vp]),
         "rh_synth_origin": (i32, [P(SynthCfg), u64, P(u32), P(u32), P(u32), P(u32)]),
     }
     for name, (res, args) in sig.items():

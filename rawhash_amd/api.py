@@ -184,6 +184,9 @@ class Context:
         _check(self._l.rh_index_device_blob(self.h, C.byref(p), C.byref(n), hdr), self._l)
         return p.value, n.value, hdr.raw
 
+    def copy_blob_to(self, dev_ptr):
+        _check(self._l.rh_index_copy_blob(self.h, C.c_void_p(dev_ptr)), self._l)
+
     def adopt_blob(self, dev_ptr, nbytes, header, take_ownership=False):
         _check(self._l.rh_index_adopt_blob(self.h, None, C.c_void_p(dev_ptr), nbytes, header, int(take_ownership)), self._l)
 
@@ -309,6 +312,12 @@ class SynthWorkload:
         nm = [names.raw[i * 64:(i + 1) * 64].split(b"\0")[0].decode() for i in range(n)] if with_names else [f"r{first + i}" for i in range(n)]
         off = np.arange(n + 1, dtype=np.uint64) * np.uint64(ns)
         return Reads(smp, off, nm, self.cfg.offset, np.float32(self.cfg.range / self.cfg.digitisation))
+
+    def reads_device(self, ctx, model_path, first, n):
+        """Generate the same reads straight into ctx's HBM; returns a ReadBatch of device pointers (owned by ctx)."""
+        b = ReadBatch()
+        _check(self._l.rh_synth_reads_device(ctx.h, C.byref(self.cfg), os.fsencode(model_path), first, n, C.byref(b)), self._l)
+        return b
 
     def origin(self, idx):
         ch, pos, st, jk = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()

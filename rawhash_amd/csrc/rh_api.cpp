@@ -44,6 +44,7 @@ struct rh_ctx_s {
 	DevBuf act[2], n_act_dev;
 	DevBuf ev, n_ev, skip, sx, sy, n_seed, m_val, m_n, m_meta, m_pref, n_match, n_new, rep_len, a_off;
 	DevBuf anc, prev[2], u, n_u, n_v, ws, counters, rec;
+	DevBuf sy_samples, sy_off, sy_cal_off, sy_cal_scale, sy_levels;
 	// timing
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	rh_map_stats_t stats{};
@@ -200,7 +201,7 @@ extern "C" void rh_ctx_destroy(rh_ctx *c)
 	(void)hipStreamSynchronize(c->stream);
 	DevBuf *all[] = {&c->logf_tab, &c->raw, &c->off, &c->cal_off, &c->cal_scale, &c->act[0], &c->act[1], &c->n_act_dev, &c->ev, &c->n_ev, &c->skip, &c->sx, &c->sy,
 	                 &c->n_seed, &c->m_val, &c->m_n, &c->m_meta, &c->m_pref, &c->n_match, &c->n_new, &c->rep_len, &c->a_off, &c->anc, &c->prev[0], &c->prev[1], &c->u,
-	                 &c->n_u, &c->n_v, &c->ws, &c->counters, &c->rec};
+	                 &c->n_u, &c->n_v, &c->ws, &c->counters, &c->rec, &c->sy_samples, &c->sy_off, &c->sy_cal_off, &c->sy_cal_scale, &c->sy_levels};
 	for (DevBuf *b : all) b->release();
 	for (DevBuf &b : c->st) b.release();
 	if (c->blob_owned) c->blob.release();
@@ -265,6 +266,15 @@ extern "C" int rh_index_device_blob(rh_ctx *c, void **dev_ptr, uint64_t *bytes, 
 	BlobHeader h; memcpy(&h, c->header, sizeof(h));
 	*dev_ptr = c->blob.p; *bytes = h.bytes;
 	if (header_out) memcpy(header_out, c->header, 256);
+	return 0;
+}
+
+extern "C" int rh_index_copy_blob(rh_ctx *c, void *dst)
+{
+	if (need_index(c)) return -1;
+	RH_HIP(hipSetDevice(c->device));
+	BlobHeader h; memcpy(&h, c->header, sizeof(h));
+	RH_HIP(hipMemcpy(dst, c->blob.p, h.bytes, hipMemcpyDeviceToDevice));
 	return 0;
 }
 
@@ -560,5 +570,25 @@ extern "C" int rh_sort128x_batch(rh_ctx *c, uint32_t n_seg, rh_mm128_t *a, const
 	RH_HIP(hipStreamSynchronize(c->stream));
 	RH_HIP(hipGetLastError());
 	if (total) RH_HIP(hipMemcpy(a, c->anc.p, total * 16, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// =================================================================================================== synthetic batch in HBM
+extern "C" int rh_synth_reads_device(rh_ctx *c, const rh_synth_cfg_t *cfg, const char *model_path, uint64_t first, uint32_t n, rh_read_batch_t *out)
+{
+	RH_HIP(hipSetDevice(c->device));
+	std::vector<int32_t> level16;
+	if (rh_synth_level_table(cfg, model_path, level16) < 0) return -1;
+	const size_t nn = n ? n : 1;
+	if (c->sy_samples.ensure(nn * cfg->n_samples * 2) || c->sy_off.ensure((nn + 1) * 8) || c->sy_cal_off.ensure(nn * 8) || c->sy_cal_scale.ensure(nn * 4) || c->sy_levels.ensure(level16.size() * 4)) return -1;
+	RH_HIP(hipMemcpy(c->sy_levels.p, level16.data(), level16.size() * 4, hipMemcpyHostToDevice));
+	rhk_synth_reads(c->stream, *cfg, c->sy_levels.as<int32_t>(), first, n, c->sy_samples.as<int16_t>(), c->sy_off.as<uint64_t>(), c->sy_cal_off.as<double>(), c->sy_cal_scale.as<float>());
+	RH_HIP(hipStreamSynchronize(c->stream));
+	RH_HIP(hipGetLastError());
+	memset(out, 0, sizeof(*out));
+	out->n_reads = n;
+	out->samples = c->sy_samples.as<int16_t>(); out->offsets = c->sy_off.as<uint64_t>();
+	out->cal_offset = c->sy_cal_off.as<double>(); out->cal_scale = c->sy_cal_scale.as<float>();
+	out->samples_on_device = 1;
 	return 0;
 }

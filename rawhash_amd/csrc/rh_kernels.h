@@ -4,6 +4,7 @@
 #include "rh_gpu.h"
 #include "rh_core.h"
 #include "rh_index.h"
+#include "rh_synth_core.h"
 
 #define RH_CHUNK_MAX   4096          // samples of one chunk held in LDS by the event kernel
 #define RH_EV_CAP      2048          // events per chunk: peaks are >= 2 samples apart (revent.c:140)
@@ -86,5 +87,6 @@ void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, con
 void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act_in, uint32_t n_in, uint32_t next_chunk,
                         uint32_t *act_out, uint32_t *n_out);
 void rhk_finalize(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, rh_map_record_t *rec);
+void rhk_synth_reads(hipStream_t s, const rh_synth_cfg_t &c, const int32_t *level16, uint64_t first, uint32_t n, int16_t *samples, uint64_t *off, double *cal_off, float *cal_scale);
 // generic segmented exact sort (test entry point rh_sort128x_batch)
 void rhk_sort_segments(hipStream_t s, uint32_t n_seg, rh_mm128_t *a, const uint64_t *off, unsigned char *ws);

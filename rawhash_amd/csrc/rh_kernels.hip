@@ -867,6 +867,19 @@ __global__ void k_finalize(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh_ma
 	rec[r] = q;
 }
 
+// ------------------------------------------------------------------------------------------------ k_synth_reads
+// Bench/test support: the synthetic read generator of rh_synth_core.h, one read per lane, writing straight into HBM.
+__global__ void k_synth_reads(rh_synth_cfg_t c, const int32_t *level16, uint64_t first, uint32_t n, int16_t *samples, uint64_t *off, double *cal_off, float *cal_scale)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i == 0) off[n] = (uint64_t)n * c.n_samples;
+	if (i >= n) return;
+	off[i] = (uint64_t)i * c.n_samples;
+	cal_off[i] = c.offset;
+	cal_scale[i] = (float)(c.range / c.digitisation);
+	rh_sy_generate(c, level16, first + i, samples + (size_t)i * c.n_samples);
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
@@ -883,4 +896,6 @@ void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, con
 void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act_in, uint32_t n_in, uint32_t next_chunk, uint32_t *act_out, uint32_t *n_out)
 { RH_LAUNCH(k_compact_active, 1, 1024, 0, s, o, rd, act_in, n_in, next_chunk, act_out, n_out); }
 void rhk_finalize(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, rh_map_record_t *rec) { if (rd.n_reads) RH_LAUNCH(k_finalize, cdiv(rd.n_reads, 256), 256, 0, s, o, ix, rd, rec); }
+void rhk_synth_reads(hipStream_t s, const rh_synth_cfg_t &c, const int32_t *level16, uint64_t first, uint32_t n, int16_t *samples, uint64_t *off, double *cal_off, float *cal_scale)
+{ if (n) RH_LAUNCH(k_synth_reads, cdiv(n, 64), 64, 0, s, c, level16, first, n, samples, off, cal_off, cal_scale); }
 void rhk_sort_segments(hipStream_t s, uint32_t n_seg, rh_mm128_t *a, const uint64_t *off, unsigned char *ws) { if (n_seg) RH_LAUNCH(k_sort_segments, cdiv(n_seg, 64), 64, 0, s, n_seg, a, off, ws); }

@@ -8,11 +8,12 @@
 //   reads  : uniform start, 50/50 strand, per-base dwell ~ Gamma(2) with mean ~8.9 samples (4000 Hz / 450 bp/s),
 //            additive noise ~ N(0, 1.5 pA), digitised with (digitisation, range, offset) like an R9.4 MinION.
 #include "rh_common.h"
+#include "rh_synth_core.h"
 #include <cmath>
 #include <cstdlib>
 #include <thread>
 
-static const int SY_K = 6;
+static const int SY_K = RH_SY_K;
 
 extern "C" void rh_synth_cfg_init(rh_synth_cfg_t *c)
 {
@@ -25,14 +26,11 @@ extern "C" void rh_synth_cfg_init(rh_synth_cfg_t *c)
 	c->digitisation = 8192.0; c->range = 1402.882; c->offset = 6.0;
 }
 
-static inline uint32_t genome_base(const rh_synth_cfg_t *c, uint32_t chrom, uint32_t pos)
-{
-	return (uint32_t)(rh_rand3(c->genome_seed, chrom, pos >> 5) >> ((pos & 31) * 2)) & 3;
-}
+static inline uint32_t genome_base(const rh_synth_cfg_t *c, uint32_t chrom, uint32_t pos) { return rh_sy_genome_base(c->genome_seed, chrom, pos); }
 
 static double model_level(const rh_synth_cfg_t *c, uint32_t kmer)
 {
-	uint64_t h = rh_rand3(c->model_seed, kmer, 0);
+	uint64_t h = rh_sy_rand3(c->model_seed, kmer, 0);
 	int64_t s = (int64_t)(h & 0xFFFF) + ((h >> 16) & 0xFFFF) + ((h >> 32) & 0xFFFF) + ((h >> 48) & 0xFFFF) - 131070;
 	return 90.0 + 12.0 * (double)s / 37837.2;
 }
@@ -70,26 +68,18 @@ extern "C" int rh_synth_write_fasta(const rh_synth_cfg_t *c, const char *path)
 	return 0;
 }
 
-static inline uint32_t read_span(const rh_synth_cfg_t *c) { return c->n_samples / 4 + 16; }
+static inline uint32_t read_span(const rh_synth_cfg_t *c) { return rh_sy_span(c->n_samples); }
 
 extern "C" int rh_synth_origin(const rh_synth_cfg_t *c, uint64_t idx, uint32_t *chrom, uint32_t *pos, uint32_t *strand, uint32_t *junk)
 {
 	uint32_t span = read_span(c);
 	if (c->chrom_len <= span + 1 || c->n_chrom == 0) { rh_set_error("chrom_len too small for n_samples"); return -1; }
-	uint64_t h = rh_rand3(c->read_seed, idx, 0);
-	if (junk) *junk = (h & 1023) < c->junk_per_1024;
-	if (chrom) *chrom = (uint32_t)((h >> 10) % c->n_chrom);
-	if (strand) *strand = (uint32_t)(h >> 40) & 1;
-	if (pos) *pos = (uint32_t)(rh_rand3(c->read_seed, idx, 1) % (c->chrom_len - span));
+	const rh_sy_origin o = rh_sy_read_origin(*c, idx);
+	if (junk) *junk = o.junk;
+	if (chrom) *chrom = o.chrom;
+	if (strand) *strand = o.strand;
+	if (pos) *pos = o.pos;
 	return 0;
-}
-
-// -log2(u / 65536) in Q8 for u in [1, 65536] (piecewise-linear mantissa), integer only
-static inline uint32_t neg_log2_q8(uint32_t u)
-{
-	int i = 31 - __builtin_clz(u);
-	uint32_t frac = ((u << (16 - i)) & 0xFFFF) >> 8;
-	return (16u << 8) - (((uint32_t)i << 8) + frac);
 }
 
 static int load_model_levels(const char *path, std::vector<float> &lev)
@@ -111,48 +101,30 @@ static int load_model_levels(const char *path, std::vector<float> &lev)
 
 static void synth_one(const rh_synth_cfg_t *c, const int32_t *level16, uint64_t idx, int16_t *out, char *name64)
 {
-	uint32_t chrom, pos, strand, junk, span = read_span(c);
-	rh_synth_origin(c, idx, &chrom, &pos, &strand, &junk);
 	if (name64) {
-		if (junk) snprintf(name64, 64, "r%llu_junk", (unsigned long long)idx);
-		else snprintf(name64, 64, "r%llu_chr%u_%u_%c", (unsigned long long)idx, chrom + 1, pos, strand ? '-' : '+');
+		const rh_sy_origin o = rh_sy_read_origin(*c, idx);
+		if (o.junk) snprintf(name64, 64, "r%llu_junk", (unsigned long long)idx);
+		else snprintf(name64, 64, "r%llu_chr%u_%u_%c", (unsigned long long)idx, o.chrom + 1, o.pos, o.strand ? '-' : '+');
 	}
-	const uint32_t noise_q24 = c->noise_q24 ? c->noise_q24 : 62152u;
-	const uint32_t kmask = (1u << (2 * SY_K)) - 1;
-	uint32_t kmer = 0, s = 0;
-	for (uint32_t j = 0; j < span && s < c->n_samples; ++j) {
-		uint32_t b;
-		if (junk) b = (uint32_t)(rh_rand3(c->read_seed ^ 0x6A756E6BULL, idx, j >> 5) >> ((j & 31) * 2)) & 3;
-		else if (!strand) b = genome_base(c, chrom, pos + j);
-		else b = 3 - genome_base(c, chrom, pos + span - 1 - j);
-		kmer = ((kmer << 2) | b) & kmask;
-		if (j + 1 < (uint32_t)SY_K) continue;
-		uint64_t hd = rh_rand3(c->read_seed + 2, idx, j);
-		uint32_t e = neg_log2_q8((uint32_t)(hd & 0xFFFF) + 1) + neg_log2_q8((uint32_t)((hd >> 16) & 0xFFFF) + 1);
-		uint32_t dwell = (e * 790u + (1u << 15)) >> 16;
-		if (dwell < 1) dwell = 1;
-		if (j + 1 == span) dwell = c->n_samples; // ran out of bases (cannot happen in practice): hold the last level
-		for (uint32_t d = 0; d < dwell && s < c->n_samples; ++d, ++s) {
-			uint64_t hn = rh_rand3(c->read_seed + 3, idx, s);
-			int64_t u = (int64_t)(hn & 0xFFFF) + ((hn >> 16) & 0xFFFF) + ((hn >> 32) & 0xFFFF) + ((hn >> 48) & 0xFFFF) - 131070;
-			int64_t n16 = (u * (int64_t)noise_q24) >> 24;
-			int64_t v = ((int64_t)level16[kmer] + n16 + 8) >> 4;
-			if (v > 32767) v = 32767;
-			if (v < -32768) v = -32768;
-			out[s] = (int16_t)v;
-		}
-	}
+	rh_sy_generate(*c, level16, idx, out);
+}
+
+int rh_synth_level_table(const rh_synth_cfg_t *c, const char *model_path, std::vector<int32_t> &level16)
+{
+	std::vector<float> lev;
+	if (load_model_levels(model_path, lev) < 0) return -1;
+	if (c->chrom_len <= read_span(c) + 1 || c->n_chrom == 0) { rh_set_error("chrom_len too small for n_samples"); return -1; }
+	level16.resize(lev.size());
+	const double scale = c->range / c->digitisation;
+	for (size_t i = 0; i < lev.size(); ++i) level16[i] = (int32_t)floor(((double)lev[i] / scale - c->offset) * 16.0 + 0.5);
+	return 0;
 }
 
 extern "C" int rh_synth_reads(const rh_synth_cfg_t *c, const char *model_path, uint64_t first, uint32_t n,
                               int16_t *samples, char *names64, int n_threads)
 {
-	std::vector<float> lev;
-	if (load_model_levels(model_path, lev) < 0) return -1;
-	if (c->chrom_len <= read_span(c) + 1) { rh_set_error("chrom_len too small for n_samples"); return -1; }
-	std::vector<int32_t> level16(lev.size());
-	const double scale = c->range / c->digitisation;
-	for (size_t i = 0; i < lev.size(); ++i) level16[i] = (int32_t)floor(((double)lev[i] / scale - c->offset) * 16.0 + 0.5);
+	std::vector<int32_t> level16;
+	if (rh_synth_level_table(c, model_path, level16) < 0) return -1;
 	if (n_threads < 1) n_threads = 1;
 	if ((uint32_t)n_threads > n) n_threads = n ? n : 1;
 	std::vector<std::thread> th;
