@@ -42,8 +42,9 @@ struct rh_ctx_s {
 	DevBuf raw, off, cal_off, cal_scale;
 	DevBuf st[24];
 	DevBuf act[2], n_act_dev;
+	DevBuf zbuf, t1buf, t2buf, n_norm, peaks, n_peaks;
 	DevBuf ev, n_ev, skip, sx, sy, n_seed, m_val, m_n, m_meta, m_pref, n_match, n_new, rep_len, a_off;
-	DevBuf anc, prev[2], u, n_u, n_v, ws, counters, rec;
+	DevBuf anc, raw_anc, zs, n_z, need_exact, need_exact2, prev[2], u, n_u, n_v, ws, counters, rec;
 	DevBuf sy_samples, sy_off, sy_cal_off, sy_cal_scale, sy_levels;
 	// timing
 	hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -136,11 +137,17 @@ int stage_reads(rh_ctx *c, const rh_read_batch_t *in, rh_dev_reads *rd)
 int stage_round(rh_ctx *c, uint32_t n_act, rh_dev_round *rr)
 {
 	const size_t n = n_act ? n_act : 1, cap = (size_t)n * RH_EV_CAP;
+	const size_t rowb = (size_t)(n + 64) * (RH_CHUNK_MAX + 64) * 4;   // + 64 rows: the peak kernel reads whole 64-read tiles
+	if (c->zbuf.ensure(rowb) || c->t1buf.ensure(rowb) || c->t2buf.ensure(rowb) || c->n_norm.ensure(n * 4) || c->peaks.ensure(cap * 2) || c->n_peaks.ensure(n * 4)) return -1;
+	rr->zbuf = c->zbuf.as<float>(); rr->t1buf = c->t1buf.as<float>(); rr->t2buf = c->t2buf.as<float>(); rr->n_norm = c->n_norm.as<uint32_t>();
+	rr->peaks = c->peaks.as<uint16_t>(); rr->n_peaks = c->n_peaks.as<uint32_t>();
 	if (c->ev.ensure(cap * 4) || c->n_ev.ensure(n * 4) || c->skip.ensure(n) || c->sx.ensure(cap * 8) || c->sy.ensure(cap * 8) || c->n_seed.ensure(n * 4) ||
 	    c->m_val.ensure(cap * 8) || c->m_n.ensure(cap * 4) || c->m_meta.ensure(cap * 4) || c->m_pref.ensure((size_t)n * (RH_EV_CAP + 1) * 4) ||
 	    c->n_match.ensure(n * 4) || c->n_new.ensure(n * 4) || c->rep_len.ensure(n * 4) || c->a_off.ensure((n + 1) * 8) || c->n_u.ensure(n * 4) || c->n_v.ensure(n * 4) ||
-	    c->counters.ensure(16 * 8)) return -1;
+	    c->counters.ensure(16 * 8) || c->need_exact.ensure(n) || c->need_exact2.ensure(n) || c->n_z.ensure(n * 4)) return -1;
+	rr->n_z = c->n_z.as<uint32_t>();
 	rr->n_act = n_act;
+	rr->need_exact = c->need_exact.as<uint8_t>(); rr->need_exact2 = c->need_exact2.as<uint8_t>();
 	rr->ev = c->ev.as<float>(); rr->n_ev = c->n_ev.as<uint32_t>(); rr->skip = c->skip.as<uint8_t>();
 	rr->sx = c->sx.as<uint64_t>(); rr->sy = c->sy.as<uint64_t>(); rr->n_seed = c->n_seed.as<uint32_t>();
 	rr->m_val = c->m_val.as<uint64_t>(); rr->m_n = c->m_n.as<uint32_t>(); rr->m_meta = c->m_meta.as<uint32_t>(); rr->m_pref = c->m_pref.as<uint32_t>();
@@ -154,8 +161,8 @@ int stage_round(rh_ctx *c, uint32_t n_act, rh_dev_round *rr)
 int stage_anchors(rh_ctx *c, uint64_t total, int which, rh_dev_round *rr)
 {
 	const size_t t = total ? total : 1;
-	if (c->anc.ensure(t * 16) || c->prev[which].ensure(t * 16) || c->u.ensure(t * 8) || c->ws.ensure(t * RH_WS_PER_ANCHOR + 4096)) return -1;
-	rr->anc = c->anc.as<rh_mm128_t>(); rr->prev_out = c->prev[which].as<rh_mm128_t>(); rr->prev_in = c->prev[which ^ 1].as<rh_mm128_t>();
+	if (c->anc.ensure(t * 16) || c->raw_anc.ensure(t * 16) || c->zs.ensure(t * 16) || c->prev[which].ensure(t * 16) || c->u.ensure(t * 8) || c->ws.ensure(t * RH_WS_PER_ANCHOR + 4096)) return -1;
+	rr->anc = c->anc.as<rh_mm128_t>(); rr->raw = c->raw_anc.as<rh_mm128_t>(); rr->zs = c->zs.as<rh_mm128_t>(); rr->prev_out = c->prev[which].as<rh_mm128_t>(); rr->prev_in = c->prev[which ^ 1].as<rh_mm128_t>();
 	rr->u = c->u.as<uint64_t>(); rr->ws = c->ws.as<unsigned char>();
 	return 0;
 }
@@ -199,8 +206,8 @@ extern "C" void rh_ctx_destroy(rh_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
-	DevBuf *all[] = {&c->logf_tab, &c->raw, &c->off, &c->cal_off, &c->cal_scale, &c->act[0], &c->act[1], &c->n_act_dev, &c->ev, &c->n_ev, &c->skip, &c->sx, &c->sy,
-	                 &c->n_seed, &c->m_val, &c->m_n, &c->m_meta, &c->m_pref, &c->n_match, &c->n_new, &c->rep_len, &c->a_off, &c->anc, &c->prev[0], &c->prev[1], &c->u,
+	DevBuf *all[] = {&c->logf_tab, &c->raw, &c->off, &c->cal_off, &c->cal_scale, &c->act[0], &c->act[1], &c->n_act_dev, &c->zbuf, &c->t1buf, &c->t2buf, &c->n_norm, &c->peaks, &c->n_peaks, &c->ev, &c->n_ev, &c->skip, &c->sx, &c->sy,
+	                 &c->n_seed, &c->m_val, &c->m_n, &c->m_meta, &c->m_pref, &c->n_match, &c->n_new, &c->rep_len, &c->a_off, &c->anc, &c->raw_anc, &c->zs, &c->n_z, &c->need_exact, &c->need_exact2, &c->prev[0], &c->prev[1], &c->u,
 	                 &c->n_u, &c->n_v, &c->ws, &c->counters, &c->rec, &c->sy_samples, &c->sy_off, &c->sy_cal_off, &c->sy_cal_scale, &c->sy_levels};
 	for (DevBuf *b : all) b->release();
 	for (DevBuf &b : c->st) b.release();
@@ -562,14 +569,17 @@ extern "C" int rh_chain_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, cons
 
 extern "C" int rh_sort128x_batch(rh_ctx *c, uint32_t n_seg, rh_mm128_t *a, const uint64_t *offsets)
 {
+	// runs the production sort stage (rhk_sort: LDS block sort fast/exact passes + oversized fallback) on free-standing segments
 	RH_HIP(hipSetDevice(c->device));
 	const uint64_t total = n_seg ? offsets[n_seg] : 0;
-	if (c->anc.ensure((total ? total : 1) * 16) || c->a_off.ensure((size_t)(n_seg + 1) * 8) || c->ws.ensure((size_t)(n_seg ? n_seg : 1) * 2048)) return -1;
-	if (h2d(c->anc.p, a, total) || h2d(c->a_off.p, offsets, (size_t)n_seg + 1)) return -1;
-	rhk_sort_segments(c->stream, n_seg, c->anc.as<rh_mm128_t>(), c->a_off.as<uint64_t>(), c->ws.as<unsigned char>());
+	rh_dev_round rr{};
+	if (stage_round(c, n_seg, &rr) || stage_anchors(c, total, 0, &rr)) return -1;
+	std::vector<uint8_t> skip(n_seg ? n_seg : 1, 0);
+	if (h2d(rr.raw, a, total) || h2d(rr.a_off, offsets, (size_t)n_seg + 1) || h2d(rr.skip, skip.data(), n_seg)) return -1;
+	rhk_sort(c->stream, rr);
 	RH_HIP(hipStreamSynchronize(c->stream));
 	RH_HIP(hipGetLastError());
-	if (total) RH_HIP(hipMemcpy(a, c->anc.p, total * 16, hipMemcpyDeviceToHost));
+	if (total) RH_HIP(hipMemcpy(a, rr.anc, total * 16, hipMemcpyDeviceToHost));
 	return 0;
 }
 

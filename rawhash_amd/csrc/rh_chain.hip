@@ -1,0 +1,253 @@
+// Chaining DP stage: mg_lchain_dp's scoring loop (reference lchain.c:439-505), one wavefront per read.
+//
+// Anchors more than max_dist_t apart on the target (or on different targets / strands) never see each other: the window
+// start `st` jumps to i and the max_ii state resets.  The sorted anchor array therefore splits into independent
+// clusters.  Most anchors of a chunk are singletons (f = span, no predecessor) and are finished in one coalesced sweep;
+// the multi-anchor clusters are walked in order, one anchor per iteration, with the up-to-max_iter predecessor window
+// evaluated 64 lanes at a time.  The order-dependent parts of the reference loop are resolved exactly inside the wave:
+//   * "sc > max_f" (strict, descending j)      -> exclusive prefix-max across lanes
+//   * t[] marks ("was j already a predecessor of something seen for this i")  -> LDS marks written by the whole
+//     batch, read after a barrier (marks only ever point below the lane that sets them)
+//   * n_skip counter with floor at 0 and the early break -> scalar walk over the ballot masks of the two event kinds
+// The last RING anchors (coordinates, f, p, v, t) live in an LDS ring; f/p/v go to HBM once.
+#include "rh_kernels.h"
+#include "rh_devutil.h"
+
+#ifndef CH_RING
+#define CH_RING 256
+#endif
+#define CH_MAX_ITER (CH_RING - 1)
+
+#ifndef CH_SMALL
+#define CH_SMALL 12     // clusters of up to this many anchors: the plain loop, one cluster per lane
+#endif
+
+// The reference loop (lchain.c:439-505) on one small cluster [b, b + m), entirely in one lane.
+RH_DEV void chain_small_cluster(const rh_mm128_t *an, int32_t *gf, int32_t *gp, int32_t *gv, int32_t b, int32_t m, int32_t max_dist_t, int32_t max_dist_q,
+                                int32_t bw, int32_t max_iter, int32_t max_skip, float pen_gap, float pen_skip)
+{
+	uint32_t xl[CH_SMALL], yl[CH_SMALL];
+	int32_t f[CH_SMALL], p[CH_SMALL], v[CH_SMALL], t[CH_SMALL], sp[CH_SMALL];
+	const uint32_t D32 = (uint32_t)max_dist_t;
+	for (int32_t k = 0; k < m; ++k) { const rh_mm128_t q = an[b + k]; xl[k] = (uint32_t)q.x; yl[k] = (uint32_t)q.y; sp[k] = (int32_t)((q.y >> 32) & 63); t[k] = -1; }
+	int32_t st = 0, max_ii = -1;
+	for (int32_t i = 0; i < m; ++i) {
+		int32_t max_f = sp[i], max_j = -1, n_skip = 0, j;
+		if (i - st > max_iter) st = i - max_iter;
+		while (st < i && (uint32_t)(xl[i] - xl[st]) > D32) ++st;
+		for (j = i - 1; j >= st; --j) {
+			int32_t sc = rh_pair_score_d((int32_t)yl[i] - (int32_t)yl[j], (int32_t)(xl[i] - xl[j]), sp[j], max_dist_t, max_dist_q, bw, pen_gap, pen_skip);
+			if (sc == RH_SCORE_NONE) continue;
+			sc += f[j];
+			if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
+			else if (t[j] == i) { if (++n_skip > max_skip) break; }
+			if (p[j] >= 0) t[p[j]] = i;
+		}
+		const int32_t end_j = j;
+		if (max_ii < 0 || (uint32_t)(xl[i] - xl[max_ii]) > D32) {
+			int32_t mx = INT32_MIN;
+			max_ii = -1;
+			for (j = i - 1; j >= st; --j) if (mx < f[j]) { mx = f[j]; max_ii = j; }
+		}
+		if (max_ii >= 0 && max_ii < end_j) {
+			const int32_t tmp = rh_pair_score_d((int32_t)yl[i] - (int32_t)yl[max_ii], (int32_t)(xl[i] - xl[max_ii]), sp[max_ii], max_dist_t, max_dist_q, bw, pen_gap, pen_skip);
+			if (tmp != RH_SCORE_NONE && max_f < tmp + f[max_ii]) { max_f = tmp + f[max_ii]; max_j = max_ii; }
+		}
+		f[i] = max_f; p[i] = max_j;
+		v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
+		if (max_ii < 0 || ((uint32_t)(xl[i] - xl[max_ii]) <= D32 && f[max_ii] < f[i])) max_ii = i;
+	}
+	for (int32_t k = 0; k < m; ++k) { gf[b + k] = f[k]; gp[b + k] = p[k] < 0 ? -1 : b + p[k]; gv[b + k] = v[k]; }
+}
+
+struct chain_lds {
+	uint32_t xlo[CH_RING], ylo[CH_RING];
+	int32_t f[CH_RING], p[CH_RING], v[CH_RING], t[CH_RING];
+	uint8_t span[CH_RING];
+};
+
+__global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr)
+{
+	__shared__ chain_lds L;
+	const uint32_t a = blockIdx.x, lane = threadIdx.x;
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const uint64_t base = rr.a_off[a];
+	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
+	if (n == 0) return;
+	const rh_mm128_t *an = rr.anc + base;
+	int32_t *gf = (int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR), *gp = gf + n, *gv = gp + n;
+	int32_t max_dist_t = o.max_dist_t, max_dist_q = o.max_dist_q;
+	const int32_t bw = o.bw, max_iter = o.max_iter, max_skip = o.max_skip;
+	if (max_dist_t < bw) max_dist_t = bw;
+	if (max_dist_q < bw) max_dist_q = bw;
+	const uint64_t D64 = (uint64_t)max_dist_t;
+	const uint32_t D32 = (uint32_t)max_dist_t;
+	for (uint32_t k = lane; k < CH_RING; k += 64) L.t[k] = -1;
+	__syncthreads();
+
+	// Anchors are read once, 64 at a time (coalesced); the sequential walk below only touches registers (shuffles) and LDS.
+	int32_t st = 0, max_ii = -1, f_ii = 0, skip_until = 0;
+	uint32_t xlo_ii = 0;
+	uint64_t x_before = 0;                                         // x of the anchor preceding the tile
+	for (int32_t i0 = 0; i0 < n; i0 += 64) {
+		const int32_t ii = i0 + (int32_t)lane;
+		const bool inb = ii < n;
+		const uint64_t x = inb ? an[ii].x : 0ull, y = inb ? an[ii].y : 0ull;
+		uint64_t xprev = __shfl_up(x, 1);
+		if (lane == 0) xprev = x_before;
+		const bool start = inb && (ii == 0 || (x >> 32) != (xprev >> 32) || x > xprev + D64);
+		const uint64_t smask = __ballot(start);
+		const uint64_t x_last = __shfl(x, 63);
+		bool next_tile_start = true;
+		if (i0 + 64 < n) { const uint64_t xn = an[i0 + 64].x; next_tile_start = (xn >> 32) != (x_last >> 32) || xn > x_last + D64; }
+		const bool nstart = (ii + 1 >= n) ? true : (lane < 63 ? ((smask >> (lane + 1)) & 1ull) != 0 : next_tile_start);
+		const bool single = start && nstart;
+		if (inb && single) { const int32_t sp = (int32_t)((y >> 32) & 63); gf[ii] = sp; gp[ii] = -1; gv[ii] = sp; }
+		// small clusters: their start lane runs the plain loop for the whole cluster (all lanes busy on different clusters)
+		int32_t csz = 0;
+		if (inb && start && !single) {
+			csz = 1;
+			uint64_t xp = x;
+			while (csz <= CH_SMALL && ii + csz < n) {
+				const uint64_t xq = an[ii + csz].x;
+				if ((xq >> 32) != (xp >> 32) || xq > xp + D64) break;
+				xp = xq; ++csz;
+			}
+			if (csz <= CH_SMALL) chain_small_cluster(an, gf, gp, gv, ii, csz, max_dist_t, max_dist_q, bw, max_iter, max_skip, o.pen_gap, o.pen_skip);
+		}
+		const uint64_t small_mask = __ballot(csz > 0 && csz <= CH_SMALL);
+		uint64_t mmask = __ballot(inb && !single);                  // members of multi-anchor clusters, walked in order
+		while (mmask) {
+			const int b = __builtin_ctzll(mmask);
+			mmask &= mmask - 1;
+			const int32_t i = i0 + b;
+			if ((small_mask >> b) & 1ull) skip_until = i + __shfl(csz, b);
+			if (i < skip_until) continue;                            // member of a small cluster, already done
+			const uint64_t xi = __shfl(x, b), yi = __shfl(y, b);
+			if ((smask >> b) & 1ull) { st = i; max_ii = -1; }       // cluster start: window and max_ii state reset
+			const uint32_t xi_lo = (uint32_t)xi, yi_lo = (uint32_t)yi;
+			const int32_t span_i = (int32_t)((yi >> 32) & 63);
+			if (i - st > max_iter) st = i - max_iter;   // clamp first: older ring slots are gone (same result, the test is monotone in st)
+			while (st < i && (uint32_t)(xi_lo - L.xlo[st & (CH_RING - 1)]) > D32) ++st;
+			int32_t max_f = span_i, max_j = -1, n_skip = 0, end_j = st - 1;
+			bool broke = false;
+			for (int32_t jtop = i - 1; jtop >= st && !broke; jtop -= 64) {
+				const int32_t j = jtop - (int32_t)lane;
+				const bool inw = j >= st;
+				const uint32_t slot = (uint32_t)j & (CH_RING - 1);
+				int32_t sc = RH_SCORE_NONE, fj = 0, pj = -1;
+				if (inw) {
+					sc = rh_pair_score_d((int32_t)yi_lo - (int32_t)L.ylo[slot], (int32_t)(xi_lo - L.xlo[slot]), (int32_t)L.span[slot], max_dist_t, max_dist_q, bw, o.pen_gap, o.pen_skip);
+					fj = L.f[slot]; pj = L.p[slot];
+				}
+				const bool valid = inw && sc != RH_SCORE_NONE;
+				if (valid && pj >= st) L.t[(uint32_t)pj & (CH_RING - 1)] = i;
+				__syncthreads();
+				const bool marked = valid && L.t[slot] == i;
+				const int32_t scv = valid ? sc + fj : INT32_MIN;
+				int32_t pm = scv;                                    // inclusive prefix max over lanes (= descending j)
+				for (int d = 1; d < 64; d <<= 1) { const int32_t tv = (int32_t)__shfl_up((uint32_t)pm, d); if (lane >= (uint32_t)d && tv > pm) pm = tv; }
+				int32_t excl = (int32_t)__shfl_up((uint32_t)pm, 1);
+				if (lane == 0) excl = INT32_MIN;
+				if (max_f > excl) excl = max_f;
+				const bool newmax = valid && scv > excl;
+				const uint64_t Dm = __ballot(newmax), Um = __ballot(valid && !newmax && marked);
+				uint64_t ev = Dm | Um;
+				int B = 64;
+				while (ev) {
+					const int e = __builtin_ctzll(ev);
+					ev &= ev - 1;
+					if ((Dm >> e) & 1ull) { if (n_skip > 0) --n_skip; }
+					else if (++n_skip > max_skip) { B = e; break; }
+				}
+				const uint64_t Deff = B < 64 ? (Dm & ((1ull << B) - 1ull)) : Dm;
+				if (Deff) { const int Lm = 63 - __clzll(Deff); max_f = __shfl(scv, Lm); max_j = jtop - Lm; }
+				if (B < 64) { end_j = jtop - B; broke = true; }
+			}
+			// best-scoring anchor still within max_dist_t ("max_ii"), re-derived from the window when it fell out of range
+			if (max_ii < 0 || (uint32_t)(xi_lo - xlo_ii) > D32) {
+				uint64_t best = 0;
+				for (int32_t jtop = i - 1; jtop >= st; jtop -= 64) {
+					const int32_t j = jtop - (int32_t)lane;
+					uint64_t key = j >= st ? ((uint64_t)(uint32_t)L.f[(uint32_t)j & (CH_RING - 1)] << 32 | (uint64_t)(uint32_t)j) : 0ull;
+					for (int d = 32; d > 0; d >>= 1) { const uint64_t ok = __shfl_xor(key, d); if (ok > key) key = ok; }
+					if (key > best) best = key;
+				}
+				if (best) { max_ii = (int32_t)(uint32_t)best; f_ii = (int32_t)(best >> 32); xlo_ii = L.xlo[(uint32_t)max_ii & (CH_RING - 1)]; }
+				else max_ii = -1;
+			}
+			if (max_ii >= 0 && max_ii < end_j) {
+				uint32_t xj, yj; int32_t spj;
+				if (i - max_ii < CH_RING) { const uint32_t sl = (uint32_t)max_ii & (CH_RING - 1); xj = L.xlo[sl]; yj = L.ylo[sl]; spj = (int32_t)L.span[sl]; }
+				else { xj = (uint32_t)an[max_ii].x; yj = (uint32_t)an[max_ii].y; spj = (int32_t)((an[max_ii].y >> 32) & 63); }
+				const int32_t tmp = rh_pair_score_d((int32_t)yi_lo - (int32_t)yj, (int32_t)(xi_lo - xj), spj, max_dist_t, max_dist_q, bw, o.pen_gap, o.pen_skip);
+				if (tmp != RH_SCORE_NONE && max_f < tmp + f_ii) { max_f = tmp + f_ii; max_j = max_ii; }
+			}
+			int32_t vv = max_f;
+			if (max_j >= 0) {
+				const int32_t vmj = (i - max_j < CH_RING) ? L.v[(uint32_t)max_j & (CH_RING - 1)] : __hip_atomic_load(&gv[max_j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (vmj > max_f) vv = vmj;
+			}
+			if (lane == 0) {
+				const uint32_t sl = (uint32_t)i & (CH_RING - 1);
+				gf[i] = max_f; gp[i] = max_j; gv[i] = vv;
+				L.xlo[sl] = xi_lo; L.ylo[sl] = yi_lo; L.span[sl] = (uint8_t)span_i; L.f[sl] = max_f; L.p[sl] = max_j; L.v[sl] = vv;
+			}
+			if (max_ii < 0 || ((uint32_t)(xi_lo - xlo_ii) <= D32 && f_ii < max_f)) { max_ii = i; f_ii = max_f; xlo_ii = xi_lo; }
+			__syncthreads();
+		}
+		x_before = x_last;
+	}
+}
+
+// Fallback for max_chain_iter > CH_MAX_ITER: the plain serial loop, one read per lane.
+__global__ void k_chain_serial(rh_dev_opt o, rh_dev_round rr)
+{
+	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const uint64_t base = rr.a_off[a];
+	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
+	if (n == 0) return;
+	const rh_mm128_t *an = rr.anc + base;
+	int32_t *f = (int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR), *p = f + n, *v = p + n, *t = v + n;
+	int32_t max_dist_t = o.max_dist_t, max_dist_q = o.max_dist_q;
+	const int32_t bw = o.bw;
+	if (max_dist_t < bw) max_dist_t = bw;
+	if (max_dist_q < bw) max_dist_q = bw;
+	for (int32_t i = 0; i < n; ++i) t[i] = 0;
+	int32_t st = 0, max_ii = -1;
+	for (int32_t i = 0; i < n; ++i) {
+		const uint64_t xi = an[i].x, yi = an[i].y;
+		int32_t max_j = -1, max_f = (int32_t)((yi >> 32) & 63), n_skip = 0, j;
+		while (st < i && (xi >> 32 != an[st].x >> 32 || xi > an[st].x + (uint64_t)max_dist_t)) ++st;
+		if (i - st > o.max_iter) st = i - o.max_iter;
+		for (j = i - 1; j >= st; --j) {
+			int32_t sc = rh_pair_score(xi, yi, an[j].x, an[j].y, max_dist_t, max_dist_q, bw, o.pen_gap, o.pen_skip);
+			if (sc == RH_SCORE_NONE) continue;
+			sc += f[j];
+			if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
+			else if (t[j] == i) { if (++n_skip > o.max_skip) break; }
+			if (p[j] >= 0) t[p[j]] = i;
+		}
+		const int32_t end_j = j;
+		if (max_ii < 0 || xi - an[max_ii].x > (uint64_t)(int64_t)max_dist_t) {
+			int32_t mx = INT32_MIN;
+			max_ii = -1;
+			for (j = i - 1; j >= st; --j) if (mx < f[j]) { mx = f[j]; max_ii = j; }
+		}
+		if (max_ii >= 0 && max_ii < end_j) {
+			const int32_t tmp = rh_pair_score(xi, yi, an[max_ii].x, an[max_ii].y, max_dist_t, max_dist_q, bw, o.pen_gap, o.pen_skip);
+			if (tmp != RH_SCORE_NONE && max_f < tmp + f[max_ii]) { max_f = tmp + f[max_ii]; max_j = max_ii; }
+		}
+		f[i] = max_f; p[i] = max_j;
+		v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
+		if (max_ii < 0 || (xi - an[max_ii].x <= (uint64_t)(int64_t)max_dist_t && f[max_ii] < f[i])) max_ii = i;
+	}
+}
+
+void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
+{
+	if (!r.n_act) return;
+	if (o.max_iter <= CH_MAX_ITER) RH_LAUNCH(k_chain_wave, r.n_act, 64, 0, s, o, r);
+	else RH_LAUNCH(k_chain_serial, (r.n_act + 63) / 64, 64, 0, s, o, r);
+}

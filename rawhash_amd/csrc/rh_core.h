@@ -145,19 +145,16 @@ RH_HD inline float rh_log2_approx(float x)
 
 #define RH_SCORE_NONE INT32_MIN
 
-// Score of chaining anchor i after anchor j (reference compute_score lchain.c:297-356).
-// Anchors: x = rev<<63 | rid<<32 | ref_pos, y = flags<<40 | q_span<<32 | q_pos.
-RH_HD inline int32_t rh_pair_score(uint64_t xi, uint64_t yi, uint64_t xj, uint64_t yj, int32_t max_dist_t, int32_t max_dist_q,
-                                   int32_t bw, float pen_gap, float pen_skip)
+// Score of chaining anchor i after anchor j (reference compute_score lchain.c:297-356), on the coordinate differences:
+//   dq = (int32)y_i - (int32)y_j (query), dr = (int32)(x_i - x_j) (target), q_span = span of anchor j.
+RH_HD inline int32_t rh_pair_score_d(int32_t dq, int32_t dr, int32_t q_span, int32_t max_dist_t, int32_t max_dist_q,
+                                     int32_t bw, float pen_gap, float pen_skip)
 {
-	const int32_t dq = (int32_t)yi - (int32_t)yj;
 	if (dq <= 0 || dq > max_dist_q) return RH_SCORE_NONE;
-	const int32_t dr = (int32_t)(xi - xj);
 	if (dr == 0 || dr > max_dist_t) return RH_SCORE_NONE;
 	const int32_t dd = dr > dq ? dr - dq : dq - dr;
 	if (dd > bw || dr > max_dist_q) return RH_SCORE_NONE;
 	const int32_t dg = dr < dq ? dr : dq;
-	const int32_t q_span = (int32_t)((yj >> 32) & 63);
 	int32_t sc = q_span < dg ? q_span : dg;
 	if (dd || dg > q_span) {
 		const float lin = pen_gap * (float)dd + pen_skip * (float)dg;
@@ -165,4 +162,11 @@ RH_HD inline int32_t rh_pair_score(uint64_t xi, uint64_t yi, uint64_t xj, uint64
 		sc -= (int)(lin + .5f * lg);
 	}
 	return sc;
+}
+
+// Same on full anchors: x = rev<<63 | rid<<32 | ref_pos, y = flags<<40 | q_span<<32 | q_pos.
+RH_HD inline int32_t rh_pair_score(uint64_t xi, uint64_t yi, uint64_t xj, uint64_t yj, int32_t max_dist_t, int32_t max_dist_q,
+                                   int32_t bw, float pen_gap, float pen_skip)
+{
+	return rh_pair_score_d((int32_t)yi - (int32_t)yj, (int32_t)(xi - xj), (int32_t)((yj >> 32) & 63), max_dist_t, max_dist_q, bw, pen_gap, pen_skip);
 }

@@ -22,3 +22,5 @@ void rh_set_error(const char *fmt, ...);
 
 // kernel<<<grid, block, lds, stream>>>(args...)
 #define RH_LAUNCH(kernel, grid, block, lds, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, __VA_ARGS__)
+
+#define RH_HIP_VOID(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) rh_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); } while (0)

@@ -9,7 +9,7 @@
 #define RH_CHUNK_MAX   4096          // samples of one chunk held in LDS by the event kernel
 #define RH_EV_CAP      2048          // events per chunk: peaks are >= 2 samples apart (revent.c:140)
 #define RH_MAX_CHUNKS  32            // chunk boundaries kept per read
-#define RH_WS_PER_ANCHOR 96          // bytes of per-anchor scratch shared by sort / DP / backtrack / regions
+#define RH_WS_PER_ANCHOR 128         // bytes of per-anchor scratch shared by sort / DP / backtrack / regions
 #define RH_LOGF_N      (1u << 20)    // host-libm logf() table for integer arguments (MAPQ parity, hit.c:525-533)
 #define RH_DEV_MAXW    16            // largest minimiser window the device sketch supports
 
@@ -58,20 +58,32 @@ struct rh_dev_reads {
 struct rh_dev_round {
 	const uint32_t *act;             // read ids active this round
 	uint32_t n_act; uint32_t chunk;
+	float *zbuf, *t1buf, *t2buf; uint32_t *n_norm;   // n_act rows of (RH_CHUNK_MAX + 64): normalised signal, both t-statistics
+	uint16_t *peaks; uint32_t *n_peaks;              // n_act x RH_EV_CAP peak positions
 	float *ev; uint32_t *n_ev;       // n_act x RH_EV_CAP
 	uint8_t *skip;                   // chunk produced < min_events events (rmap.cpp:232)
 	uint64_t *sx, *sy; uint32_t *n_seed;     // n_act x RH_EV_CAP seeds
 	uint64_t *m_val; uint32_t *m_n, *m_meta, *m_pref; uint32_t *n_match, *n_new; int32_t *rep_len;   // kept seed matches
 	uint64_t *a_off;                 // n_act+1 anchor offsets (exclusive scan of n_new + n_prev)
-	rh_mm128_t *anc;                 // anchors (sorted in place)
+	rh_mm128_t *raw;                 // anchors as expanded (unsorted)
+	rh_mm128_t *anc;                 // anchors in the reference's sorted order
+	uint8_t *need_exact;             // sort: read has equal keys, needs the exact-permutation pass (also reused as a per-read redo flag)
+	uint8_t *need_exact2;
 	rh_mm128_t *chn;                 // chained anchors, chains ordered by target position
 	const rh_mm128_t *prev_in; rh_mm128_t *prev_out;
 	uint64_t *u; uint32_t *n_u, *n_v;        // chains: score<<32 | count
+	rh_mm128_t *zs; uint32_t *n_z;           // backtrack candidates (score, anchor) in radix_sort_128x order
 	unsigned char *ws;               // RH_WS_PER_ANCHOR bytes per anchor
 	uint64_t *counters;              // [0] events [1] seeds [2] hits [3] anchors [4] chained [5] samples used [6] chunks
 };
 
-struct rh_launch_ctx { hipStream_t stream; };
+// a batch of independent 16-byte-record segments to be put into radix_sort_128x order (rh_sort.hip)
+struct rh_sort_job {
+	uint32_t n_seg; const uint8_t *skip; const uint64_t *off; const uint32_t *cnt;   // segment a = [off[a], off[a] + (cnt ? cnt[a] : off[a+1]-off[a]))
+	const rh_mm128_t *src; rh_mm128_t *dst; uint8_t *need_exact;
+	unsigned char *scratch; uint32_t scratch_stride, scratch_skip;   // 2 KB per oversized segment at scratch + off*stride + skip*len
+};
+void rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n);   // segments with <= min_n records are left alone
 
 // kernel launchers (rh_kernels.hip)
 void rhk_prefilter(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd);
@@ -88,5 +100,3 @@ void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &
                         uint32_t *act_out, uint32_t *n_out);
 void rhk_finalize(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, rh_map_record_t *rec);
 void rhk_synth_reads(hipStream_t s, const rh_synth_cfg_t &c, const int32_t *level16, uint64_t first, uint32_t n, int16_t *samples, uint64_t *off, double *cal_off, float *cal_scale);
-// generic segmented exact sort (test entry point rh_sort128x_batch)
-void rhk_sort_segments(hipStream_t s, uint32_t n_seg, rh_mm128_t *a, const uint64_t *off, unsigned char *ws);

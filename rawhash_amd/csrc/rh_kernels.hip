@@ -14,28 +14,7 @@
 // order-dependent stages run one read per lane.  FP is fp32/fp64 exactly where the reference uses them; the file must
 // be compiled with -ffp-contract=off.
 #include "rh_kernels.h"
-
-#define NT 256   // threads of the block-cooperative kernels
-
-// ------------------------------------------------------------------------------------------------ wave / block helpers
-RH_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
-RH_DEV uint32_t wave_id() { return threadIdx.x >> 6; }
-RH_DEV uint32_t lanes_below(uint64_t m) { return (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull)); }
-
-// Order-preserving rank of the calling thread among the threads of the block with pred set; total = their number.
-// s_w: LDS scratch of (blockDim.x / 64) words.  Contains two block barriers.
-RH_DEV uint32_t block_rank(bool pred, uint32_t *s_w, uint32_t &total)
-{
-	const uint64_t m = __ballot(pred);
-	const uint32_t r = lanes_below(m), w = wave_id(), nw = blockDim.x >> 6;
-	if (lane_id() == 0) s_w[w] = (uint32_t)__popcll(m);
-	__syncthreads();
-	uint32_t base = 0;
-	total = 0;
-	for (uint32_t i = 0; i < nw; ++i) { const uint32_t c = s_w[i]; if (i < w) base += c; total += c; }
-	__syncthreads();
-	return base + r;
-}
+#include "rh_devutil.h"
 
 RH_DEV float raw_to_pa(int16_t raw, double cal_off, float cal_scale)
 {
@@ -102,19 +81,22 @@ RH_DEV float tstat_at(const float *ps, const float *pss, uint32_t n, uint32_t w,
 	return fabsf(dm) / sqrtf(var);
 }
 
-struct peak_det { float thr; uint32_t win, masked_to; int32_t pos; float val; int32_t valid; };
+// Event detection runs as three launches so that every lane is busy in each of them:
+//   k_events_norm   (one block per read)      pA filter, fp64 statistics, z-score + compaction, fp32 prefix sums, both
+//                                             t-statistics -> z, t1, t2 rows in HBM
+//   k_events_peaks  (one LANE per read)       the two coupled peak detectors, a 4000-step serial state machine per chunk:
+//                                             64 chunks advance in lock step, their t-stat rows staged through LDS tiles
+//   k_events_means  (one block per read)      per-segment sort + IQR-fenced mean -> events
+#define EV_ROW (RH_CHUNK_MAX + 64)             // row stride (floats) of the z / t1 / t2 staging arrays
 
-// One block per active read: the whole chunk lives in LDS.
-__global__ __launch_bounds__(NT) void k_events(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
+__global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
 {
-	__shared__ float s_z[RH_CHUNK_MAX];          // normalised samples; segments are sorted in place at the end
-	__shared__ float s_a[RH_CHUNK_MAX + 1];      // pA staging -> prefix sums -> short-window t-stat
-	__shared__ float s_b[RH_CHUNK_MAX + 1];      // prefix sums of squares -> long-window t-stat
-	__shared__ uint16_t s_peaks[RH_EV_CAP];
+	__shared__ float s_z[RH_CHUNK_MAX];
+	__shared__ float s_a[RH_CHUNK_MAX + 1];      // pA staging -> prefix sums
+	__shared__ float s_b[RH_CHUNK_MAX + 1];      // prefix sums of squares
 	__shared__ uint32_t s_w[NT / 64];
 	__shared__ double s_red[2 * (NT / 64)];
 	__shared__ double s_stat[2];
-	__shared__ uint32_t s_np;
 
 	const uint32_t a = blockIdx.x, tid = threadIdx.x;
 	if (a >= rr.n_act) return;
@@ -156,6 +138,8 @@ __global__ __launch_bounds__(NT) void k_events(rh_dev_opt o, rh_dev_reads rd, rh
 		const double mean = S / N;
 		s_stat[0] = mean;
 		s_stat[1] = sqrt(S2 / N - mean * mean);
+		atomicAdd((unsigned long long*)&rr.counters[5], (unsigned long long)s_len);
+		atomicAdd((unsigned long long*)&rr.counters[6], 1ull);
 	}
 	__syncthreads();
 	const double mean = s_stat[0], sd = s_stat[1];
@@ -172,10 +156,8 @@ __global__ __launch_bounds__(NT) void k_events(rh_dev_opt o, rh_dev_reads rd, rh
 		n += total;
 	}
 	__syncthreads();
-	if (n == 0) {
-		if (tid == 0) { rr.n_ev[a] = 0; rr.skip[a] = 1; atomicAdd((unsigned long long*)&rr.counters[5], (unsigned long long)s_len); atomicAdd((unsigned long long*)&rr.counters[6], 1ull); }
-		return;
-	}
+	if (tid == 0) rr.n_norm[a] = n;
+	if (n == 0) return;
 
 	// 3. fp32 prefix sums, strictly left to right (order-sensitive: one lane)
 	if (tid == 0) {
@@ -193,35 +175,48 @@ __global__ __launch_bounds__(NT) void k_events(rh_dev_opt o, rh_dev_reads rd, rh
 	}
 	__syncthreads();
 
-	// 4. t-statistics for both windows (all lanes), written back over the prefix sums
-	{
-		float t1[(RH_CHUNK_MAX + NT) / NT], t2[(RH_CHUNK_MAX + NT) / NT];
-		#pragma unroll
-		for (int k = 0; k < (RH_CHUNK_MAX + NT) / NT; ++k) {
-			const uint32_t i = tid + k * NT;
-			t1[k] = i <= n ? tstat_at(s_a, s_b, n, o.w1, i) : 0.0f;
-			t2[k] = i <= n ? tstat_at(s_a, s_b, n, o.w2, i) : 0.0f;
+	// 4. t-statistics of both windows and the normalised signal go to HBM rows (coalesced)
+	float *zrow = rr.zbuf + (size_t)a * EV_ROW, *t1row = rr.t1buf + (size_t)a * EV_ROW, *t2row = rr.t2buf + (size_t)a * EV_ROW;
+	for (uint32_t i = tid; i < n; i += NT) {
+		zrow[i] = s_z[i];
+		t1row[i] = tstat_at(s_a, s_b, n, o.w1, i);
+		t2row[i] = tstat_at(s_a, s_b, n, o.w2, i);
+	}
+}
+
+struct peak_det { float thr; uint32_t win, masked_to; int32_t pos; float val; int32_t valid; };
+
+// One read per lane.  Tiles of 64 steps x 64 reads of t1 / t2 are transposed through LDS (row stride 65: conflict free
+// reads, 2-way writes) so that HBM is read in full 256-byte rows while every lane walks its own chunk.
+#define PK_TILE 64
+__global__ __launch_bounds__(64) void k_events_peaks(rh_dev_opt o, rh_dev_round rr)
+{
+	__shared__ float s_t1[PK_TILE * 65], s_t2[PK_TILE * 65];
+	const uint32_t lane = threadIdx.x, a0 = blockIdx.x * 64, a = a0 + lane;
+	const uint32_t n = a < rr.n_act ? rr.n_norm[a] : 0u;
+	uint32_t nmax = n;
+	for (int d = 32; d > 0; d >>= 1) { const uint32_t t = __shfl_xor(nmax, d); if (t > nmax) nmax = t; }
+	peak_det d0 = { o.thr1, o.w1, 0u, -1, FLT_MAX, 0 }, d1 = { o.thr2, o.w2, 0u, -1, FLT_MAX, 0 };
+	const float ph = o.peak_height;
+	uint32_t np = 0;
+	uint16_t *pk = rr.peaks + (size_t)a * RH_EV_CAP;
+	const uint32_t rows = rr.n_act - a0 < 64u ? rr.n_act - a0 : 64u;
+	for (uint32_t i0 = 0; i0 < nmax; i0 += PK_TILE) {
+		__syncthreads();
+		for (uint32_t row = 0; row < rows; ++row) {
+			const size_t g = (size_t)(a0 + row) * EV_ROW + i0 + lane;     // lane = step inside the tile
+			s_t1[lane * 65 + row] = rr.t1buf[g];
+			s_t2[lane * 65 + row] = rr.t2buf[g];
 		}
 		__syncthreads();
-		#pragma unroll
-		for (int k = 0; k < (RH_CHUNK_MAX + NT) / NT; ++k) {
-			const uint32_t i = tid + k * NT;
-			if (i <= n) { s_a[i] = t1[k]; s_b[i] = t2[k]; }
-		}
-	}
-	__syncthreads();
-
-	// 5. two coupled peak detectors (short masks long): serial finite-state machine
-	if (tid == 0) {
-		peak_det d0 = { o.thr1, o.w1, 0u, -1, FLT_MAX, 0 }, d1 = { o.thr2, o.w2, 0u, -1, FLT_MAX, 0 };
-		const float ph = o.peak_height;
-		uint32_t np = 0;
-		for (uint32_t i = 0; i < n; ++i) {
+		const uint32_t iend = i0 + PK_TILE < n ? i0 + PK_TILE : n;
+		for (uint32_t i = i0; i < iend; ++i) {
+			const uint32_t sl = (i - i0) * 65 + lane;
 			#pragma unroll
 			for (int k = 0; k < 2; ++k) {
 				peak_det &q = k == 0 ? d0 : d1;
 				if (q.masked_to >= i) continue;
-				const float cur = k == 0 ? s_a[i] : s_b[i];
+				const float cur = k == 0 ? s_t1[sl] : s_t2[sl];
 				if (q.pos == -1) {
 					if (cur < q.val) q.val = cur;
 					else if (cur - q.val > ph) { q.val = cur; q.pos = (int32_t)i; }
@@ -230,19 +225,31 @@ __global__ __launch_bounds__(NT) void k_events(rh_dev_opt o, rh_dev_reads rd, rh
 					if (k == 0 && q.val > q.thr) { d1.masked_to = (uint32_t)q.pos + d0.win; d1.pos = -1; d1.val = FLT_MAX; d1.valid = 0; }
 					if (q.val - cur > ph && q.val > q.thr) q.valid = 1;
 					if (q.valid && (i - (uint32_t)q.pos) > q.win / 2) {
-						if (np < RH_EV_CAP) s_peaks[np] = (uint16_t)q.pos;
+						if (np < RH_EV_CAP) pk[np] = (uint16_t)q.pos;
 						++np;
 						q.pos = -1; q.val = cur; q.valid = 0;
 					}
 				}
 			}
 		}
-		s_np = np < RH_EV_CAP ? np : RH_EV_CAP;
 	}
-	__syncthreads();
-	const uint32_t np = s_np;
+	if (a < rr.n_act) rr.n_peaks[a] = np < RH_EV_CAP ? np : RH_EV_CAP;
+}
 
-	// 6. one lane per segment: sort, IQR fence, mean
+__global__ __launch_bounds__(NT) void k_events_means(rh_dev_opt o, rh_dev_round rr)
+{
+	__shared__ float s_z[RH_CHUNK_MAX];
+	__shared__ uint16_t s_peaks[RH_EV_CAP];
+	const uint32_t a = blockIdx.x, tid = threadIdx.x;
+	if (a >= rr.n_act) return;
+	const uint32_t n = rr.n_norm[a];
+	const uint32_t np = n ? rr.n_peaks[a] : 0u;
+	const float *zrow = rr.zbuf + (size_t)a * EV_ROW;
+	const uint16_t *pk = rr.peaks + (size_t)a * RH_EV_CAP;
+	for (uint32_t i = tid; i < n; i += NT) s_z[i] = zrow[i];
+	for (uint32_t i = tid; i < np; i += NT) s_peaks[i] = pk[i];
+	__syncthreads();
+	// one lane per segment: sort, IQR fence, mean
 	float *ev = rr.ev + (size_t)a * RH_EV_CAP;
 	for (uint32_t k = tid; k < np; k += NT) {
 		const uint32_t start = k ? s_peaks[k - 1] : 0u, end = s_peaks[k];
@@ -267,8 +274,6 @@ __global__ __launch_bounds__(NT) void k_events(rh_dev_opt o, rh_dev_reads rd, rh
 		rr.n_ev[a] = np;
 		rr.skip[a] = np < o.min_events ? 1 : 0;
 		atomicAdd((unsigned long long*)&rr.counters[0], (unsigned long long)np);
-		atomicAdd((unsigned long long*)&rr.counters[5], (unsigned long long)s_len);
-		atomicAdd((unsigned long long*)&rr.counters[6], 1ull);
 	}
 }
 
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(NT) void k_expand(rh_dev_opt o, rh_dev_index ix, rh
 	__syncthreads();
 	const uint32_t q_off = rd.ev_off[r];
 	const uint64_t span = (uint64_t)(ix.sp.k + ix.sp.e - 1);
-	rh_mm128_t *anc = rr.anc + base;
+	rh_mm128_t *anc = rr.raw + base;
 	for (uint32_t j = tid; j < nn; j += NT) {
 		uint32_t lo = 0, hi = nm;   // largest s with s_pref[s] <= j
 		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_pref[mid] <= j) lo = mid; else hi = mid; }
@@ -406,405 +411,6 @@ __global__ __launch_bounds__(NT) void k_expand(rh_dev_opt o, rh_dev_index ix, rh
 		anc[j] = p;
 	}
 	for (uint32_t j = tid; j < np; j += NT) anc[nn + j] = pin[j];
-}
-
-// ------------------------------------------------------------------------------------------------ exact radix_sort_128x
-// Serial emulation of klib's in-place MSD radix sort (ksort.h:101-151): insertion sort up to 64 records, otherwise an
-// "American flag" cycle-leader pass per byte from bit 56 down.  The permutation among equal keys is unstable but
-// deterministic and is observed by the chaining DP and the backtracking order, so it is reproduced step by step.
-RH_HD inline void rh_ins_sort128(rh_mm128_t *a, uint32_t beg, uint32_t end)
-{
-	for (uint32_t i = beg + 1; i < end; ++i) {
-		if (a[i].x < a[i - 1].x) {
-			const rh_mm128_t t = a[i];
-			uint32_t j = i;
-			while (j > beg && t.x < a[j - 1].x) { a[j] = a[j - 1]; --j; }
-			a[j] = t;
-		}
-	}
-}
-
-// one American-flag pass over a[beg, end) on byte (s / 8); cw = 512 words of scratch
-RH_HD inline void rh_af_pass(rh_mm128_t *a, uint32_t beg, uint32_t end, int s, uint32_t *cw)
-{
-	uint32_t *head = cw, *tail = cw + 256;
-	for (int c = 0; c < 256; ++c) head[c] = 0;
-	for (uint32_t i = beg; i < end; ++i) ++head[(a[i].x >> s) & 255u];
-	uint32_t p = beg;
-	for (int c = 0; c < 256; ++c) { const uint32_t n = head[c]; head[c] = p; p += n; tail[c] = p; }
-	for (int c = 0; c < 256;) {
-		if (head[c] == tail[c]) { ++c; continue; }
-		uint32_t d = (uint32_t)(a[head[c]].x >> s) & 255u;
-		if (d == (uint32_t)c) { ++head[c]; continue; }
-		rh_mm128_t carry = a[head[c]];
-		do {
-			const uint32_t h = head[d]++;
-			const rh_mm128_t ev = a[h];
-			a[h] = carry;
-			carry = ev;
-			d = (uint32_t)(carry.x >> s) & 255u;
-		} while (d != (uint32_t)c);
-		a[head[c]++] = carry;
-	}
-}
-
-RH_HD inline void rh_radix_sort_128x(rh_mm128_t *a, uint32_t n, uint32_t *cw)
-{
-	if (n <= 64) { rh_ins_sort128(a, 0, n); return; }
-	struct frame { uint32_t beg, end, cur; int s; int passed; } st[9];
-	int sp = 0;
-	st[0].beg = 0; st[0].end = n; st[0].cur = 0; st[0].s = 56; st[0].passed = 0;
-	while (sp >= 0) {
-		frame &f = st[sp];
-		if (!f.passed) {
-			rh_af_pass(a, f.beg, f.end, f.s, cw);
-			f.passed = 1; f.cur = f.beg;
-			if (f.s == 0) { --sp; continue; }
-		}
-		if (f.cur >= f.end) { --sp; continue; }
-		// next sub-bucket = maximal run sharing the byte just sorted on
-		const uint32_t b = f.cur, c = (uint32_t)(a[b].x >> f.s) & 255u;
-		uint32_t e = b + 1;
-		while (e < f.end && ((uint32_t)(a[e].x >> f.s) & 255u) == c) ++e;
-		f.cur = e;
-		const uint32_t sz = e - b;
-		const int ns = f.s > 8 ? f.s - 8 : 0;
-		if (sz > 64) { ++sp; st[sp].beg = b; st[sp].end = e; st[sp].cur = b; st[sp].s = ns; st[sp].passed = 0; }
-		else if (sz > 1) rh_ins_sort128(a, b, e);
-	}
-}
-
-__global__ void k_sort(rh_dev_round rr)
-{
-	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-	if (a >= rr.n_act || rr.skip[a]) return;
-	const uint64_t base = rr.a_off[a];
-	const uint32_t n = (uint32_t)(rr.a_off[a + 1] - base);
-	rh_radix_sort_128x(rr.anc + base, n, (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR));
-}
-
-__global__ void k_sort_segments(uint32_t n_seg, rh_mm128_t *arr, const uint64_t *off, unsigned char *ws)
-{
-	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-	if (s >= n_seg) return;
-	rh_radix_sort_128x(arr + off[s], (uint32_t)(off[s + 1] - off[s]), (uint32_t*)(ws + (size_t)s * 2048));
-}
-
-// ------------------------------------------------------------------------------------------------ k_chain (DP)
-// One read per lane; f/p/v/t live in the read's scratch slice.  Window start, skip counter, t[] marks and the max_ii
-// rescue are order dependent (lchain.c:439-505) and evaluated in the reference's order.
-__global__ void k_chain(rh_dev_opt o, rh_dev_round rr)
-{
-	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-	if (a >= rr.n_act || rr.skip[a]) return;
-	const uint64_t base = rr.a_off[a];
-	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
-	if (n == 0) return;
-	const rh_mm128_t *an = rr.anc + base;
-	int32_t *f = (int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR), *p = f + n, *v = p + n, *t = v + n;
-	int32_t max_dist_t = o.max_dist_t, max_dist_q = o.max_dist_q;
-	const int32_t bw = o.bw;
-	if (max_dist_t < bw) max_dist_t = bw;
-	if (max_dist_q < bw) max_dist_q = bw;
-	for (int32_t i = 0; i < n; ++i) t[i] = 0;
-	int32_t st = 0, max_ii = -1;
-	for (int32_t i = 0; i < n; ++i) {
-		const uint64_t xi = an[i].x, yi = an[i].y;
-		int32_t max_j = -1, max_f = (int32_t)((yi >> 32) & 63), n_skip = 0, j;
-		while (st < i && (xi >> 32 != an[st].x >> 32 || xi > an[st].x + (uint64_t)max_dist_t)) ++st;
-		if (i - st > o.max_iter) st = i - o.max_iter;
-		for (j = i - 1; j >= st; --j) {
-			int32_t sc = rh_pair_score(xi, yi, an[j].x, an[j].y, max_dist_t, max_dist_q, bw, o.pen_gap, o.pen_skip);
-			if (sc == RH_SCORE_NONE) continue;
-			sc += f[j];
-			if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
-			else if (t[j] == i) { if (++n_skip > o.max_skip) break; }
-			if (p[j] >= 0) t[p[j]] = i;
-		}
-		const int32_t end_j = j;
-		if (max_ii < 0 || xi - an[max_ii].x > (uint64_t)(int64_t)max_dist_t) {
-			int32_t mx = INT32_MIN;
-			max_ii = -1;
-			for (j = i - 1; j >= st; --j) if (mx < f[j]) { mx = f[j]; max_ii = j; }
-		}
-		if (max_ii >= 0 && max_ii < end_j) {
-			const int32_t tmp = rh_pair_score(xi, yi, an[max_ii].x, an[max_ii].y, max_dist_t, max_dist_q, bw, o.pen_gap, o.pen_skip);
-			if (tmp != RH_SCORE_NONE && max_f < tmp + f[max_ii]) { max_f = tmp + f[max_ii]; max_j = max_ii; }
-		}
-		f[i] = max_f; p[i] = max_j;
-		v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
-		if (max_ii < 0 || (xi - an[max_ii].x <= (uint64_t)(int64_t)max_dist_t && f[max_ii] < f[i])) max_ii = i;
-	}
-}
-
-// ------------------------------------------------------------------------------------------------ k_backtrack
-// lchain.c:47-75
-RH_DEV int32_t bk_end(int32_t max_drop, const rh_mm128_t *z, const int32_t *f, const int32_t *p, int32_t *t, int32_t k)
-{
-	int32_t i = (int32_t)z[k].y, end_i = -1, max_i = i, max_s = 0;
-	if (i < 0 || t[i] != 0) return i;
-	do {
-		t[i] = 2;
-		end_i = i = p[i];
-		const int32_t s = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[i];
-		if (s > max_s) { max_s = s; max_i = i; }
-		else if (max_s - s > max_drop) break;
-	} while (i >= 0 && t[i] == 0);
-	for (i = (int32_t)z[k].y; i >= 0 && i != end_i; i = p[i]) t[i] = 0;
-	return max_i;
-}
-
-// One read per lane: mg_chain_backtrack (lchain.c:95-194) + compact_a (:214-281).  Outputs: chained anchors (chains
-// ordered by target position) over the front of the anchor slice, their pre-sort copy = the next chunk's carried
-// anchors, and u[] = score << 32 | count.
-__global__ void k_backtrack(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
-{
-	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-	if (a >= rr.n_act || rr.skip[a]) return;
-	const uint32_t r = rr.act[a];
-	const uint64_t base = rr.a_off[a];
-	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
-	rh_mm128_t *an = rr.anc + base;
-	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
-	int32_t *f = (int32_t*)wsr, *p = f + n, *v = p + n, *t = v + n;
-	rh_mm128_t *z = (rh_mm128_t*)(wsr + (size_t)16 * n);
-	uint64_t *u = rr.u + base;
-	rh_mm128_t *pa = rr.prev_out + base;
-	int32_t n_u = 0, n_v = 0, n_z = 0;
-	const int32_t min_sc = o.min_sc, min_cnt = o.min_cnt, max_drop = o.bw;
-	for (int32_t i = 0; i < n; ++i) if (f[i] >= min_sc) { z[n_z].x = (uint64_t)(int64_t)f[i]; z[n_z].y = (uint64_t)i; ++n_z; }
-	if (n_z > 0) {
-		rh_radix_sort_128x(z, (uint32_t)n_z, (uint32_t*)(wsr + (size_t)56 * n));
-		for (int32_t i = 0; i < n; ++i) t[i] = 0;
-		for (int32_t k = n_z - 1; k >= 0; --k) {
-			if (t[z[k].y] != 0) continue;
-			const int32_t n_v0 = n_v;
-			const int32_t end_i = bk_end(max_drop, z, f, p, t, k);
-			int32_t i;
-			for (i = (int32_t)z[k].y; i != end_i; i = p[i]) { v[n_v++] = i; t[i] = 1; }
-			const int32_t sc = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[i];
-			if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint64_t)(uint32_t)(n_v - n_v0);
-			else n_v = n_v0;
-		}
-	}
-	if (n_u == 0) {
-		rr.n_u[a] = 0; rr.n_v[a] = 0;
-		rd.n_prev[r] = 0; rd.prev_off[r] = base;
-		return;
-	}
-	// gather chain members (reverse of backtrack order) into pa; pa is exactly what the next chunk carries
-	int32_t k = 0;
-	for (int32_t i = 0; i < n_u; ++i) {
-		const int32_t k0 = k, ni = (int32_t)u[i];
-		for (int32_t j = 0; j < ni; ++j) pa[k++] = an[v[k0 + (ni - j - 1)]];
-	}
-	// order chains by the target coordinate of their first anchor
-	rh_mm128_t *w = z;                       // z is dead
-	uint64_t *u2 = (uint64_t*)(w + n_u);
-	k = 0;
-	for (int32_t i = 0; i < n_u; ++i) { w[i].x = pa[k].x; w[i].y = (uint64_t)(uint32_t)k << 32 | (uint64_t)(uint32_t)i; k += (int32_t)u[i]; }
-	rh_radix_sort_128x(w, (uint32_t)n_u, (uint32_t*)(wsr + (size_t)56 * n));
-	k = 0;
-	for (int32_t i = 0; i < n_u; ++i) {
-		const int32_t j = (int32_t)w[i].y, cnt = (int32_t)u[j], src = (int32_t)(w[i].y >> 32);
-		u2[i] = u[j];
-		for (int32_t m = 0; m < cnt; ++m) an[k + m] = pa[src + m];
-		k += cnt;
-	}
-	for (int32_t i = 0; i < n_u; ++i) u[i] = u2[i];
-	rr.n_u[a] = (uint32_t)n_u; rr.n_v[a] = (uint32_t)n_v;
-	rd.n_prev[r] = (uint32_t)n_v; rd.prev_off[r] = base;
-	atomicAdd((unsigned long long*)&rr.counters[4], (unsigned long long)n_v);
-}
-
-// ------------------------------------------------------------------------------------------------ k_regions
-struct rh_reg {
-	int32_t id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, n_sub, score0;
-	uint32_t mapq, rev, hash;
-};
-
-RH_DEV float logf_int(int32_t v, const float *tab) { return (v >= 0 && (uint32_t)v < RH_LOGF_N) ? tab[v] : logf((float)v); }
-
-// hit.c:312-336
-RH_DEV void sync_regs(int32_t n, rh_reg *r, int32_t *tmp)
-{
-	if (n <= 0) return;
-	int32_t max_id = -1;
-	for (int32_t i = 0; i < n; ++i) max_id = max_id > r[i].id ? max_id : r[i].id;
-	const int32_t n_tmp = max_id + 1;
-	for (int32_t i = 0; i < n_tmp; ++i) tmp[i] = -1;
-	for (int32_t i = 0; i < n; ++i) if (r[i].id >= 0) tmp[r[i].id] = i;
-	for (int32_t i = 0; i < n; ++i) {
-		rh_reg &q = r[i];
-		q.id = i;
-		if (q.parent == -2) q.parent = i;
-		else if (q.parent >= 0 && tmp[q.parent] >= 0) q.parent = tmp[q.parent];
-		else q.parent = -1;
-	}
-}
-
-// One read per lane: mm_gen_regs (hit.c:100-150), mm_set_parent (:195-263), mm_select_sub (:338-367), mm_set_mapq
-// (:502-539), then the mapping decision of map_worker_for (rmap.cpp:423-500) and the bookkeeping at the end of
-// ri_map_frag (:386).
-__global__ void k_regions(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, const float *logf_tab)
-{
-	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-	if (a >= rr.n_act) return;
-	const uint32_t r = rr.act[a];
-	if (rr.skip[a]) { rd.ls_ncregs[r] = 0; return; }   // creg freed at the top of the iteration, chunk dropped: no regions
-	const uint64_t base = rr.a_off[a];
-	const int32_t n_u = (int32_t)rr.n_u[a];
-	const uint32_t n_events = rr.n_ev[a], offset = rd.ev_off[r];
-	int32_t n_regs = n_u;
-	rh_reg best; best.cnt = 0; best.score = 0; best.mapq = 0; best.qs = best.qe = best.rs = best.re = best.rid = 0; best.rev = 0;
-	int stop = 0;
-	if (n_u > 0) {
-		const rh_mm128_t *an = rr.anc + base;
-		const uint64_t *u = rr.u + base;
-		unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
-		rh_reg *rg = (rh_reg*)wsr;
-		rh_mm128_t *z = (rh_mm128_t*)(wsr + (size_t)64 * n_u);
-		uint64_t *cov = (uint64_t*)(wsr + (size_t)80 * n_u);
-		int32_t *w = (int32_t*)(wsr + (size_t)88 * n_u), *tmp = (int32_t*)(wsr + (size_t)92 * n_u);
-		uint32_t hash = 0;
-		hash ^= rh_wang32(offset + n_events) + rh_wang32(11u);
-		hash = rh_wang32(hash);
-		// --- regions from chains, ordered by (score, hash of first anchor) descending
-		int32_t k = 0;
-		for (int32_t i = 0; i < n_u; ++i) {
-			const uint32_t h = (uint32_t)rh_mix64_nomask((rh_mix64_nomask(an[k].x) + rh_mix64_nomask(an[k].y)) ^ (uint64_t)hash);
-			z[i].x = u[i] ^ (uint64_t)h;
-			z[i].y = (uint64_t)(uint32_t)k << 32 | (uint64_t)(uint32_t)(int32_t)u[i];
-			k += (int32_t)u[i];
-		}
-		rh_radix_sort_128x(z, (uint32_t)n_u, (uint32_t*)wsr);   // regs area is still free here
-		for (int32_t i = 0; i < n_u >> 1; ++i) { const rh_mm128_t tt = z[i]; z[i] = z[n_u - 1 - i]; z[n_u - 1 - i] = tt; }
-		// the sort scratch overlapped rg[]: z must be read before rg[i] is written only for i where areas overlap; z lives
-		// behind the regs area, so there is no overlap
-		for (int32_t i = 0; i < n_u; ++i) {
-			rh_reg q;
-			q.id = i; q.parent = -1; q.subsc = 0; q.n_sub = 0;
-			q.score = q.score0 = (int32_t)(z[i].x >> 32);
-			q.hash = (uint32_t)z[i].x;
-			q.cnt = (int32_t)z[i].y;
-			q.as = (int32_t)(z[i].y >> 32);
-			const int32_t s0 = q.as, s1 = q.as + q.cnt - 1;
-			q.rev = (uint32_t)(an[s0].x >> 63);
-			q.rid = (int32_t)(an[s0].x << 1 >> 33);
-			q.rs = (int32_t)an[s0].x; q.re = (int32_t)an[s1].x + 1;
-			q.qs = (int32_t)an[s0].y; q.qe = (int32_t)an[s1].y + 1;
-			q.mapq = 0;
-			rg[i] = q;
-		}
-		// --- primary / secondary by query overlap
-		{
-			int32_t kk = 1;
-			w[0] = 0; rg[0].parent = 0;
-			const int hard = (o.flag & RH_M_HARD_MLEVEL) != 0;
-			for (int32_t i = 1; i < n_u; ++i) {
-				rh_reg &ri = rg[i];
-				const int32_t si = ri.qs, ei = ri.qe;
-				int32_t n_cov = 0, uncov = 0, j;
-				bool decided_new = false;
-				if (!hard) {
-					for (j = 0; j < kk; ++j) {
-						const rh_reg &rp = rg[w[j]];
-						int32_t sj = rp.qs, ej = rp.qe;
-						if (ej <= si || sj >= ei) continue;
-						if (sj < si) sj = si;
-						if (ej > ei) ej = ei;
-						cov[n_cov++] = (uint64_t)(uint32_t)sj << 32 | (uint64_t)(uint32_t)ej;
-					}
-					if (n_cov == 0) decided_new = true;
-					else {
-						for (int32_t x1 = 1; x1 < n_cov; ++x1) {   // ascending sort of the covered intervals
-							const uint64_t cv = cov[x1]; int32_t y1 = x1;
-							while (y1 > 0 && cov[y1 - 1] > cv) { cov[y1] = cov[y1 - 1]; --y1; }
-							cov[y1] = cv;
-						}
-						int32_t x = si;
-						for (j = 0; j < n_cov; ++j) {
-							if ((int32_t)(cov[j] >> 32) > x) uncov += (int32_t)(cov[j] >> 32) - x;
-							x = (int32_t)cov[j] > x ? (int32_t)cov[j] : x;
-						}
-						if (ei > x) uncov += ei - x;
-					}
-				}
-				j = kk;
-				if (!decided_new) {
-					for (j = 0; j < kk; ++j) {
-						rh_reg &rp = rg[w[j]];
-						const int32_t sj = rp.qs, ej = rp.qe;
-						if (ej <= si || sj >= ei) continue;
-						const int32_t mn = ej - sj < ei - si ? ej - sj : ei - si;
-						const int32_t mx = ej - sj > ei - si ? ej - sj : ei - si;
-						const int32_t ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj) : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
-						if ((float)ol / (float)mn - (float)uncov / (float)mx > o.mask_level && uncov <= o.mask_len) {
-							const int32_t sci = ri.score;
-							ri.parent = rp.parent;
-							rp.subsc = rp.subsc > sci ? rp.subsc : sci;
-							if (ri.cnt >= rp.cnt) ++rp.n_sub;
-							break;
-						}
-					}
-				}
-				if (j == kk) { w[kk++] = i; ri.parent = i; ri.n_sub = 0; }
-			}
-		}
-		// --- drop secondaries (mm_select_sub, check_strand = 1)
-		if (!(o.flag & RH_M_ALL_CHAINS) && o.pri_ratio > 0.0f) {
-			int32_t kk = 0, n_2nd = 0;
-			for (int32_t i = 0; i < n_regs; ++i) {
-				const int32_t pp = rg[i].parent;
-				if (pp == i) rg[kk++] = rg[i];
-				else if (((float)rg[i].score >= (float)rg[pp].score * o.pri_ratio) && n_2nd < o.best_n) {
-					if (!(rg[i].qs == rg[pp].qs && rg[i].qe == rg[pp].qe && rg[i].rid == rg[pp].rid && rg[i].rs == rg[pp].rs && rg[i].re == rg[pp].re)) { rg[kk++] = rg[i]; ++n_2nd; }
-				} else if (n_2nd < o.best_n && rg[i].score > o.min_strand_sc && rg[i].rev != rg[pp].rev) { rg[kk++] = rg[i]; ++n_2nd; }
-			}
-			if (kk != n_regs) sync_regs(kk, rg, tmp);
-			n_regs = kk;
-		}
-		// --- MAPQ
-		{
-			int64_t sum_sc = 0;
-			for (int32_t i = 0; i < n_regs; ++i) if (rg[i].parent == rg[i].id) sum_sc += rg[i].score;
-			const float uniq_ratio = (float)sum_sc / (float)(sum_sc + rr.rep_len[a]);
-			for (int32_t i = 0; i < n_regs; ++i) {
-				rh_reg &q = rg[i];
-				const float pen_s1 = (float)((q.score > 100 ? 1.0 : 0.01 * (double)q.score) * (double)uniq_ratio);
-				float pen_cm = q.cnt > 10 ? 1.0f : 0.1f * (float)q.cnt;
-				pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
-				const int32_t subsc = q.subsc > o.min_sc ? q.subsc : o.min_sc;
-				const float x = (float)subsc / (float)q.score0;
-				int32_t mapq = (int32_t)(pen_cm * 40.0f * (1.0f - x) * logf_int(q.score, logf_tab));
-				mapq -= (int32_t)(4.343f * logf_int(q.n_sub + 1, logf_tab) + .499f);
-				mapq = mapq > 0 ? mapq : 0;
-				q.mapq = (uint32_t)(mapq < 60 ? mapq : 60);
-			}
-		}
-		// --- mapping decision (non-overlap mode: only chain 0 can be reported)
-		if (n_regs == 1 && (int32_t)rg[0].mapq >= o.min_mapq) stop = 1;
-		else if (n_regs >= 1) {
-			float meanC = 0, meanQ = 0;
-			for (int32_t i = 0; i < n_regs; ++i) { meanC += (float)rg[i].score; meanQ += (float)rg[i].mapq; }
-			meanC /= (float)n_regs; meanQ /= (float)n_regs;
-			const float bestQ = (float)rg[0].mapq, bestC = (float)rg[0].score;
-			float r_bestq = (bestQ > 0) ? (bestQ / 30.0f) : 0.0f; if (r_bestq > 1) r_bestq = 1.0f;
-			float r_bestmq = (bestQ > 0) ? (1.0f - (meanQ / bestQ)) : 0.0f; if (r_bestmq < 0) r_bestmq = 0.0f;
-			float r_bestmc = (bestC > 0) ? (1.0f - (meanC / bestC)) : 0.0f; if (r_bestmc < 0) r_bestmc = 0.0f;
-			const float weighted = o.w_bestq * r_bestq + o.w_bestmq * r_bestmq + o.w_bestmc * r_bestmc;
-			if (weighted >= o.w_threshold) stop = 1;
-		}
-		best = rg[0];
-	}
-	rd.ls_ncregs[r] = n_regs;
-	if (n_regs > 0) {
-		rd.ls_cnt[r] = best.cnt; rd.ls_score[r] = best.score; rd.ls_mapq[r] = (int32_t)best.mapq;
-		rd.ls_qs[r] = best.qs; rd.ls_qe[r] = best.qe; rd.ls_rs[r] = best.rs; rd.ls_re[r] = best.re;
-		rd.ls_rid[r] = best.rid; rd.ls_rev[r] = (int32_t)best.rev;
-	}
-	rd.ev_off[r] = offset + n_events;
-	if (stop) { rd.done[r] = 1; rd.stop_chunk[r] = rr.chunk; }
 }
 
 // ------------------------------------------------------------------------------------------------ k_compact_active
@@ -884,18 +490,19 @@ __global__ void k_synth_reads(rh_synth_cfg_t c, const int32_t *level16, uint64_t
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 void rhk_prefilter(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd) { if (rd.n_reads) RH_LAUNCH(k_prefilter, rd.n_reads, NT, 0, s, o, rd); }
-void rhk_events(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events, r.n_act, NT, 0, s, o, rd, r); }
+void rhk_events(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
+{
+	if (!r.n_act) return;
+	RH_LAUNCH(k_events_norm, r.n_act, NT, 0, s, o, rd, r);
+	RH_LAUNCH(k_events_peaks, cdiv(r.n_act, 64), 64, 0, s, o, r);
+	RH_LAUNCH(k_events_means, r.n_act, NT, 0, s, o, r);
+}
 void rhk_sketch(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_sketch, cdiv(r.n_act, 64), 64, 0, s, o, ix, rd, r); }
 void rhk_probe(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_probe, r.n_act, NT, 0, s, o, ix, rd, r); }
 void rhk_scan_anchors(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r) { RH_LAUNCH(k_scan_anchors, 1, 1024, 0, s, rd, r); }
 void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_expand, r.n_act, NT, 0, s, o, ix, rd, r); }
-void rhk_sort(hipStream_t s, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_sort, cdiv(r.n_act, 64), 64, 0, s, r); }
-void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_chain, cdiv(r.n_act, 64), 64, 0, s, o, r); }
-void rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_backtrack, cdiv(r.n_act, 64), 64, 0, s, o, rd, r); }
-void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r, const float *logf_tab) { if (r.n_act) RH_LAUNCH(k_regions, cdiv(r.n_act, 64), 64, 0, s, o, rd, r, logf_tab); }
 void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act_in, uint32_t n_in, uint32_t next_chunk, uint32_t *act_out, uint32_t *n_out)
 { RH_LAUNCH(k_compact_active, 1, 1024, 0, s, o, rd, act_in, n_in, next_chunk, act_out, n_out); }
 void rhk_finalize(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, rh_map_record_t *rec) { if (rd.n_reads) RH_LAUNCH(k_finalize, cdiv(rd.n_reads, 256), 256, 0, s, o, ix, rd, rec); }
 void rhk_synth_reads(hipStream_t s, const rh_synth_cfg_t &c, const int32_t *level16, uint64_t first, uint32_t n, int16_t *samples, uint64_t *off, double *cal_off, float *cal_scale)
 { if (n) RH_LAUNCH(k_synth_reads, cdiv(n, 64), 64, 0, s, c, level16, first, n, samples, off, cal_off, cal_scale); }
-void rhk_sort_segments(hipStream_t s, uint32_t n_seg, rh_mm128_t *a, const uint64_t *off, unsigned char *ws) { if (n_seg) RH_LAUNCH(k_sort_segments, cdiv(n_seg, 64), 64, 0, s, n_seg, a, off, ws); }

@@ -1,0 +1,679 @@
+// Post-DP stages, one read per workgroup with the working set staged in LDS:
+//   k_zbuild      candidates f[i] >= min_sc for backtracking (lchain.c:126-140); they are then put into the reference's
+//                 radix_sort_128x order by the block sorter of rh_sort.hip (scores are full of ties -> exact mode)
+//   k_backtrack   mg_chain_backtrack (lchain.c:95-194, mg_chain_bk_end :47-75) + compact_a (:214-281)
+//   k_regions     mm_gen_regs (hit.c:100-150), mm_set_parent (:195-263), mm_select_sub (:338-367), mm_set_mapq (:502-539),
+//                 the mapping decision of map_worker_for (rmap.cpp:423-500) and the bookkeeping of ri_map_frag (:386)
+// The chain walks and the region bookkeeping are pointer-chasing, order-dependent code: lane 0 runs them on LDS copies
+// (f, p, t marks, sorted candidates; regions, chain heads) while the other lanes do the staging, gathers and copies.
+// Reads whose working set exceeds the LDS caps take the same code paths on HBM scratch (the *_big kernels).
+#include "rh_kernels.h"
+#include "rh_devutil.h"
+
+// ------------------------------------------------------------------------------------------------ k_zbuild
+__global__ __launch_bounds__(64) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
+{
+	const uint32_t a = blockIdx.x, lane = threadIdx.x;
+	if (a >= rr.n_act) return;
+	if (rr.skip[a]) { if (lane == 0) rr.n_z[a] = 0; return; }
+	const uint64_t base = rr.a_off[a];
+	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
+	const int32_t *f = (const int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR);
+	rh_mm128_t *z = rr.raw + base;               // the unsorted anchor copy is dead after the anchor sort
+	uint32_t nz = 0;
+	for (int32_t i0 = 0; i0 < n; i0 += 64) {
+		const int32_t i = i0 + (int32_t)lane;
+		const int32_t fi = i < n ? f[i] : INT32_MIN;
+		const bool ok = i < n && fi >= o.min_sc;
+		const uint64_t m = __ballot(ok);
+		if (ok) { rh_mm128_t e; e.x = (uint64_t)(int64_t)fi; e.y = (uint64_t)(uint32_t)i; z[nz + lanes_below(m)] = e; }
+		nz += (uint32_t)__popcll(m);
+	}
+	if (lane == 0) rr.n_z[a] = nz;
+}
+
+// ------------------------------------------------------------------------------------------------ backtrack
+#ifndef BK_CAP
+#define BK_CAP  5120     // anchors of a read whose f/p/t/candidates fit the LDS copy
+#endif
+#ifndef BK_UCAP
+#define BK_UCAP 1024     // chains whose bookkeeping fits LDS
+#endif
+
+// Walks every candidate from the best score down, emitting chains (lchain.c:148-170).  F/P/T/ZI are LDS or HBM views.
+// Returns n_u; *n_v_out = anchors in chains; v[] = chain members in backtrack order; u[] = score << 32 | count.
+template <class PT>
+RH_DEV int32_t backtrack_walk(const int32_t *F, const PT *P, uint8_t *T, const PT *ZI, int32_t n_z, int32_t min_sc, int32_t min_cnt, int32_t max_drop,
+                              int32_t *v, uint64_t *u, uint32_t *ck0, uint32_t *cn, int32_t *n_v_out)
+{
+	const PT NONE = (PT)~(PT)0;
+	int32_t n_u = 0, n_v = 0;
+	for (int32_t k = n_z - 1; k >= 0; --k) {
+		const int32_t i0 = (int32_t)ZI[k];
+		if (T[i0] != 0) continue;
+		const int32_t zx = F[i0];
+		// mg_chain_bk_end: how far back the chain from i0 may extend before the score drops by more than max_drop
+		int32_t i = i0, end_i = -1, max_i = i0, max_s = 0;
+		do {
+			T[i] = 2;
+			const PT pi = P[i];
+			end_i = i = (pi == NONE) ? -1 : (int32_t)pi;
+			const int32_t s = i < 0 ? zx : zx - F[i];
+			if (s > max_s) { max_s = s; max_i = i; }
+			else if (max_s - s > max_drop) break;
+		} while (i >= 0 && T[i] == 0);
+		for (i = i0; i >= 0 && i != end_i;) { T[i] = 0; const PT pi = P[i]; i = (pi == NONE) ? -1 : (int32_t)pi; }
+		const int32_t stop = max_i, n_v0 = n_v;
+		for (i = i0; i != stop;) { v[n_v++] = i; T[i] = 1; const PT pi = P[i]; i = (pi == NONE) ? -1 : (int32_t)pi; }
+		const int32_t sc = i < 0 ? zx : zx - F[i];
+		if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) {
+			if (n_u < BK_UCAP && ck0) { ck0[n_u] = (uint32_t)n_v0; cn[n_u] = (uint32_t)(n_v - n_v0); }
+			u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint64_t)(uint32_t)(n_v - n_v0);
+		} else n_v = n_v0;
+	}
+	*n_v_out = n_v;
+	return n_u;
+}
+
+static_assert(BK_UCAP * 16 <= BK_CAP * 4 && BK_UCAP * 4 <= BK_CAP * 2 && (BK_UCAP <= 64 || BK_CAP * 2 >= 2048), "LDS aliasing of the chain-order sort");
+
+struct bk_lds {
+	int32_t f[BK_CAP];
+	uint16_t p[BK_CAP], zi[BK_CAP];
+	uint8_t t[BK_CAP];
+	uint32_t ck0[BK_UCAP], cn[BK_UCAP];
+	int32_t n_u, n_v;
+};
+
+__global__ __launch_bounds__(64) void k_backtrack(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, uint32_t n_lo)
+{
+	__shared__ bk_lds L;
+	const uint32_t a = blockIdx.x, lane = threadIdx.x;
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const uint32_t r = rr.act[a];
+	const uint64_t base = rr.a_off[a];
+	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
+	if (n > BK_CAP || n <= (int32_t)n_lo) return;                // others: k_backtrack_big
+	const int32_t n_z = (int32_t)rr.n_z[a];
+	rh_mm128_t *an = rr.anc + base;
+	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
+	const int32_t *gf = (const int32_t*)wsr, *gp = gf + n;
+	int32_t *v = (int32_t*)wsr + 2 * (size_t)n;                  // DP's v[] is dead: reused for the chain members
+	uint64_t *u = rr.u + base;
+	rh_mm128_t *pa = rr.prev_out + base;
+	const rh_mm128_t *zs = rr.zs + base;
+	for (int32_t i = (int32_t)lane; i < n; i += 64) { L.f[i] = gf[i]; const int32_t pi = gp[i]; L.p[i] = pi < 0 ? (uint16_t)0xFFFF : (uint16_t)pi; L.t[i] = 0; }
+	for (int32_t i = (int32_t)lane; i < n_z; i += 64) L.zi[i] = (uint16_t)zs[i].y;
+	__syncthreads();
+	if (lane == 0) { int32_t nv; L.n_u = backtrack_walk<uint16_t>(L.f, L.p, L.t, L.zi, n_z, o.min_sc, o.min_cnt, o.bw, v, u, L.ck0, L.cn, &nv); L.n_v = nv; }
+	__syncthreads();
+	const int32_t n_u = L.n_u, n_v = L.n_v;
+	if (n_u == 0) {
+		if (lane == 0) { rr.n_u[a] = 0; rr.n_v[a] = 0; rd.n_prev[r] = 0; rd.prev_off[r] = base; }
+		return;
+	}
+	// compact_a: gather every chain, reversed into ascending anchor order -> pa (what the next chunk carries, lchain.c:236-239)
+	{
+		uint32_t k0 = 0;
+		for (int32_t i = 0; i < n_u; ++i) {
+			const uint32_t ni = i < BK_UCAP ? L.cn[i] : (uint32_t)u[i];
+			for (uint32_t j = lane; j < ni; j += 64) pa[k0 + j] = an[v[k0 + (ni - j - 1)]];
+			k0 += ni;
+		}
+	}
+	__syncthreads();
+	// chains ordered by the target coordinate of their first anchor (radix_sort_128x on (x, k<<32|i)); LDS regions of the walk are dead
+	if (n_u <= BK_UCAP) {
+		rh_mm128_t *w = (rh_mm128_t*)L.f;
+		uint32_t *cw = (uint32_t*)L.p, *dk = (uint32_t*)L.zi;
+		for (int32_t i = (int32_t)lane; i < n_u; i += 64) { w[i].x = pa[L.ck0[i]].x; w[i].y = (uint64_t)L.ck0[i] << 32 | (uint64_t)(uint32_t)i; }
+		__syncthreads();
+		if (lane == 0) {
+			rh_radix_sort_128x(w, (uint32_t)n_u, cw);
+			uint32_t k = 0;
+			for (int32_t i = 0; i < n_u; ++i) { dk[i] = k; k += L.cn[(uint32_t)w[i].y]; }
+		}
+		__syncthreads();
+		for (int32_t i = 0; i < n_u; ++i) {
+			const uint32_t j = (uint32_t)w[i].y, src = (uint32_t)(w[i].y >> 32), cnt = L.cn[j], d = dk[i];
+			for (uint32_t m = lane; m < cnt; m += 64) an[d + m] = pa[src + m];
+		}
+		uint64_t uu[BK_UCAP / 64];
+		for (int32_t q = 0; q < BK_UCAP / 64; ++q) { const int32_t i = q * 64 + (int32_t)lane; uu[q] = i < n_u ? u[(uint32_t)w[i].y] : 0; }
+		__syncthreads();
+		for (int32_t q = 0; q < BK_UCAP / 64; ++q) { const int32_t i = q * 64 + (int32_t)lane; if (i < n_u) u[i] = uu[q]; }
+	} else if (lane == 0) {	// more chains than the LDS bookkeeping holds: serial tail on HBM scratch
+		rh_mm128_t *w = (rh_mm128_t*)(wsr + (size_t)16 * n);
+		uint64_t *u2 = (uint64_t*)(w + n_u);
+		int32_t k = 0;
+		for (int32_t i = 0; i < n_u; ++i) { w[i].x = pa[k].x; w[i].y = (uint64_t)(uint32_t)k << 32 | (uint64_t)(uint32_t)i; k += (int32_t)u[i]; }
+		rh_radix_sort_128x(w, (uint32_t)n_u, (uint32_t*)(wsr + (size_t)64 * n));
+		k = 0;
+		for (int32_t i = 0; i < n_u; ++i) {
+			const int32_t j = (int32_t)w[i].y, cnt = (int32_t)u[j], src = (int32_t)(w[i].y >> 32);
+			u2[i] = u[j];
+			for (int32_t m = 0; m < cnt; ++m) an[k + m] = pa[src + m];
+			k += cnt;
+		}
+		for (int32_t i = 0; i < n_u; ++i) u[i] = u2[i];
+	}
+	if (lane == 0) {
+		rr.n_u[a] = (uint32_t)n_u; rr.n_v[a] = (uint32_t)n_v;
+		rd.n_prev[r] = (uint32_t)n_v; rd.prev_off[r] = base;
+		atomicAdd((unsigned long long*)&rr.counters[4], (unsigned long long)n_v);
+	}
+}
+
+// reads with more than BK_CAP anchors: the same walk on HBM arrays, one read per lane
+__global__ void k_backtrack_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, uint32_t n_lo)
+{
+	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const uint32_t r = rr.act[a];
+	const uint64_t base = rr.a_off[a];
+	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
+	if (n <= (int32_t)n_lo) return;
+	const int32_t n_z = (int32_t)rr.n_z[a];
+	rh_mm128_t *an = rr.anc + base;
+	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
+	int32_t *f = (int32_t*)wsr, *p = f + n, *v = p + n, *zi = v + n;   // zi: 4n bytes at 12n
+	uint8_t *t = (uint8_t*)(wsr + (size_t)16 * n);
+	const rh_mm128_t *zs = rr.zs + base;
+	uint64_t *u = rr.u + base;
+	rh_mm128_t *pa = rr.prev_out + base;
+	for (int32_t i = 0; i < n; ++i) t[i] = 0;
+	for (int32_t i = 0; i < n_z; ++i) zi[i] = (int32_t)zs[i].y;
+	int32_t n_v = 0;
+	const int32_t n_u = backtrack_walk<uint32_t>(f, (const uint32_t*)p, t, (const uint32_t*)zi, n_z, o.min_sc, o.min_cnt, o.bw, v, u, nullptr, nullptr, &n_v);
+	if (n_u == 0) { rr.n_u[a] = 0; rr.n_v[a] = 0; rd.n_prev[r] = 0; rd.prev_off[r] = base; return; }
+	int32_t k = 0;
+	for (int32_t i = 0; i < n_u; ++i) { const int32_t k0 = k, ni = (int32_t)u[i]; for (int32_t j = 0; j < ni; ++j) pa[k++] = an[v[k0 + (ni - j - 1)]]; }
+	rh_mm128_t *w = (rh_mm128_t*)(wsr + (size_t)32 * n);
+	uint64_t *u2 = (uint64_t*)(w + n_u);
+	k = 0;
+	for (int32_t i = 0; i < n_u; ++i) { w[i].x = pa[k].x; w[i].y = (uint64_t)(uint32_t)k << 32 | (uint64_t)(uint32_t)i; k += (int32_t)u[i]; }
+	rh_radix_sort_128x(w, (uint32_t)n_u, (uint32_t*)(wsr + (size_t)64 * n));
+	k = 0;
+	for (int32_t i = 0; i < n_u; ++i) {
+		const int32_t j = (int32_t)w[i].y, cnt = (int32_t)u[j], src = (int32_t)(w[i].y >> 32);
+		u2[i] = u[j];
+		for (int32_t m = 0; m < cnt; ++m) an[k + m] = pa[src + m];
+		k += cnt;
+	}
+	for (int32_t i = 0; i < n_u; ++i) u[i] = u2[i];
+	rr.n_u[a] = (uint32_t)n_u; rr.n_v[a] = (uint32_t)n_v;
+	rd.n_prev[r] = (uint32_t)n_v; rd.prev_off[r] = base;
+	atomicAdd((unsigned long long*)&rr.counters[4], (unsigned long long)n_v);
+}
+
+// ------------------------------------------------------------------------------------------------ regions
+struct rh_reg {
+	int32_t id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, n_sub, score0;
+	uint32_t mapq, rev, hash;
+};
+struct rh_chain_head { uint64_t x0, y0; int32_t x1, y1, cnt, k; };   // first anchor, low words of the last anchor
+
+RH_DEV float logf_int(int32_t v, const float *tab) { return (v >= 0 && (uint32_t)v < RH_LOGF_N) ? tab[v] : logf((float)v); }
+
+// hit.c:312-336
+RH_DEV void sync_regs(int32_t n, rh_reg *r, int32_t *tmp)
+{
+	if (n <= 0) return;
+	int32_t max_id = -1;
+	for (int32_t i = 0; i < n; ++i) max_id = max_id > r[i].id ? max_id : r[i].id;
+	const int32_t n_tmp = max_id + 1;
+	for (int32_t i = 0; i < n_tmp; ++i) tmp[i] = -1;
+	for (int32_t i = 0; i < n; ++i) if (r[i].id >= 0) tmp[r[i].id] = i;
+	for (int32_t i = 0; i < n; ++i) {
+		rh_reg &q = r[i];
+		q.id = i;
+		if (q.parent == -2) q.parent = i;
+		else if (q.parent >= 0 && tmp[q.parent] >= 0) q.parent = tmp[q.parent];
+		else q.parent = -1;
+	}
+}
+
+// Serial core on whatever memory the arrays live in.  Returns the number of regions kept; *stop = mapping decision.
+RH_DEV int32_t regions_core(const rh_dev_opt &o, int32_t n_u, const uint64_t *u, const rh_chain_head *ch, rh_reg *rg, rh_mm128_t *z, uint64_t *cov,
+                            int32_t *w, int32_t *tmp, uint32_t *cw, int32_t rep_len, uint32_t n_events, uint32_t offset, const float *logf_tab, int *stop)
+{
+	int32_t n_regs = n_u;
+	*stop = 0;
+	uint32_t hash = 0;
+	hash ^= rh_wang32(offset + n_events) + rh_wang32(11u);         // rmap.cpp:346-348
+	hash = rh_wang32(hash);
+	// regions from chains, ordered by (score, hash of first anchor) descending
+	for (int32_t i = 0; i < n_u; ++i) {
+		const uint32_t h = (uint32_t)rh_mix64_nomask((rh_mix64_nomask(ch[i].x0) + rh_mix64_nomask(ch[i].y0)) ^ (uint64_t)hash);
+		z[i].x = u[i] ^ (uint64_t)h;
+		z[i].y = (uint64_t)(uint32_t)i;
+	}
+	rh_radix_sort_128x(z, (uint32_t)n_u, cw);
+	for (int32_t i = 0; i < n_u >> 1; ++i) { const rh_mm128_t tt = z[i]; z[i] = z[n_u - 1 - i]; z[n_u - 1 - i] = tt; }
+	for (int32_t i = 0; i < n_u; ++i) {
+		const rh_chain_head &c = ch[(uint32_t)z[i].y];
+		rh_reg q;
+		q.id = i; q.parent = -1; q.subsc = 0; q.n_sub = 0;
+		q.score = q.score0 = (int32_t)(z[i].x >> 32);
+		q.hash = (uint32_t)z[i].x;
+		q.cnt = c.cnt; q.as = c.k;
+		q.rev = (uint32_t)(c.x0 >> 63);
+		q.rid = (int32_t)(c.x0 << 1 >> 33);
+		q.rs = (int32_t)c.x0; q.re = c.x1 + 1;
+		q.qs = (int32_t)c.y0; q.qe = c.y1 + 1;
+		q.mapq = 0;
+		rg[i] = q;
+	}
+	// primary / secondary by query overlap
+	{
+		int32_t kk = 1;
+		w[0] = 0; rg[0].parent = 0;
+		const int hard = (o.flag & RH_M_HARD_MLEVEL) != 0;
+		for (int32_t i = 1; i < n_u; ++i) {
+			rh_reg &ri = rg[i];
+			const int32_t si = ri.qs, ei = ri.qe;
+			int32_t n_cov = 0, uncov = 0, j;
+			bool decided_new = false;
+			if (!hard) {
+				for (j = 0; j < kk; ++j) {
+					const rh_reg &rp = rg[w[j]];
+					int32_t sj = rp.qs, ej = rp.qe;
+					if (ej <= si || sj >= ei) continue;
+					if (sj < si) sj = si;
+					if (ej > ei) ej = ei;
+					cov[n_cov++] = (uint64_t)(uint32_t)sj << 32 | (uint64_t)(uint32_t)ej;
+				}
+				if (n_cov == 0) decided_new = true;
+				else {
+					for (int32_t x1 = 1; x1 < n_cov; ++x1) {
+						const uint64_t cv = cov[x1]; int32_t y1 = x1;
+						while (y1 > 0 && cov[y1 - 1] > cv) { cov[y1] = cov[y1 - 1]; --y1; }
+						cov[y1] = cv;
+					}
+					int32_t x = si;
+					for (j = 0; j < n_cov; ++j) {
+						if ((int32_t)(cov[j] >> 32) > x) uncov += (int32_t)(cov[j] >> 32) - x;
+						x = (int32_t)cov[j] > x ? (int32_t)cov[j] : x;
+					}
+					if (ei > x) uncov += ei - x;
+				}
+			}
+			j = kk;
+			if (!decided_new) {
+				for (j = 0; j < kk; ++j) {
+					rh_reg &rp = rg[w[j]];
+					const int32_t sj = rp.qs, ej = rp.qe;
+					if (ej <= si || sj >= ei) continue;
+					const int32_t mn = ej - sj < ei - si ? ej - sj : ei - si;
+					const int32_t mx = ej - sj > ei - si ? ej - sj : ei - si;
+					const int32_t ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj) : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
+					if ((float)ol / (float)mn - (float)uncov / (float)mx > o.mask_level && uncov <= o.mask_len) {
+						const int32_t sci = ri.score;
+						ri.parent = rp.parent;
+						rp.subsc = rp.subsc > sci ? rp.subsc : sci;
+						if (ri.cnt >= rp.cnt) ++rp.n_sub;
+						break;
+					}
+				}
+			}
+			if (j == kk) { w[kk++] = i; ri.parent = i; ri.n_sub = 0; }
+		}
+	}
+	// drop secondaries (mm_select_sub, check_strand = 1)
+	if (!(o.flag & RH_M_ALL_CHAINS) && o.pri_ratio > 0.0f) {
+		int32_t kk = 0, n_2nd = 0;
+		for (int32_t i = 0; i < n_regs; ++i) {
+			const int32_t pp = rg[i].parent;
+			if (pp == i) rg[kk++] = rg[i];
+			else if (((float)rg[i].score >= (float)rg[pp].score * o.pri_ratio) && n_2nd < o.best_n) {
+				if (!(rg[i].qs == rg[pp].qs && rg[i].qe == rg[pp].qe && rg[i].rid == rg[pp].rid && rg[i].rs == rg[pp].rs && rg[i].re == rg[pp].re)) { rg[kk++] = rg[i]; ++n_2nd; }
+			} else if (n_2nd < o.best_n && rg[i].score > o.min_strand_sc && rg[i].rev != rg[pp].rev) { rg[kk++] = rg[i]; ++n_2nd; }
+		}
+		if (kk != n_regs) sync_regs(kk, rg, tmp);
+		n_regs = kk;
+	}
+	// MAPQ
+	{
+		int64_t sum_sc = 0;
+		for (int32_t i = 0; i < n_regs; ++i) if (rg[i].parent == rg[i].id) sum_sc += rg[i].score;
+		const float uniq_ratio = (float)sum_sc / (float)(sum_sc + rep_len);
+		for (int32_t i = 0; i < n_regs; ++i) {
+			rh_reg &q = rg[i];
+			const float pen_s1 = (float)((q.score > 100 ? 1.0 : 0.01 * (double)q.score) * (double)uniq_ratio);
+			float pen_cm = q.cnt > 10 ? 1.0f : 0.1f * (float)q.cnt;
+			pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
+			const int32_t subsc = q.subsc > o.min_sc ? q.subsc : o.min_sc;
+			const float x = (float)subsc / (float)q.score0;
+			int32_t mapq = (int32_t)(pen_cm * 40.0f * (1.0f - x) * logf_int(q.score, logf_tab));
+			mapq -= (int32_t)(4.343f * logf_int(q.n_sub + 1, logf_tab) + .499f);
+			mapq = mapq > 0 ? mapq : 0;
+			q.mapq = (uint32_t)(mapq < 60 ? mapq : 60);
+		}
+	}
+	// mapping decision (non-overlap mode: only chain 0 can be reported)
+	if (n_regs == 1 && (int32_t)rg[0].mapq >= o.min_mapq) *stop = 1;
+	else if (n_regs >= 1) {
+		float meanC = 0, meanQ = 0;
+		for (int32_t i = 0; i < n_regs; ++i) { meanC += (float)rg[i].score; meanQ += (float)rg[i].mapq; }
+		meanC /= (float)n_regs; meanQ /= (float)n_regs;
+		const float bestQ = (float)rg[0].mapq, bestC = (float)rg[0].score;
+		float r_bestq = (bestQ > 0) ? (bestQ / 30.0f) : 0.0f; if (r_bestq > 1) r_bestq = 1.0f;
+		float r_bestmq = (bestQ > 0) ? (1.0f - (meanQ / bestQ)) : 0.0f; if (r_bestmq < 0) r_bestmq = 0.0f;
+		float r_bestmc = (bestC > 0) ? (1.0f - (meanC / bestC)) : 0.0f; if (r_bestmc < 0) r_bestmc = 0.0f;
+		const float weighted = o.w_bestq * r_bestq + o.w_bestmq * r_bestmq + o.w_bestmc * r_bestmc;
+		if (weighted >= o.w_threshold) *stop = 1;
+	}
+	return n_regs;
+}
+
+RH_DEV void regions_commit(const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &rr, uint32_t a, uint32_t r, int32_t n_regs, const rh_reg *best, int stop)
+{
+	rd.ls_ncregs[r] = n_regs;
+	if (n_regs > 0) {
+		rd.ls_cnt[r] = best->cnt; rd.ls_score[r] = best->score; rd.ls_mapq[r] = (int32_t)best->mapq;
+		rd.ls_qs[r] = best->qs; rd.ls_qe[r] = best->qe; rd.ls_rs[r] = best->rs; rd.ls_re[r] = best->re;
+		rd.ls_rid[r] = best->rid; rd.ls_rev[r] = (int32_t)best->rev;
+	}
+	rd.ev_off[r] = rd.ev_off[r] + rr.n_ev[a];                    // reg->offset += n_events (rmap.cpp:386)
+	if (stop) { rd.done[r] = 1; rd.stop_chunk[r] = rr.chunk; }
+}
+
+#ifndef RG_CAP
+#define RG_CAP 512
+#endif
+#ifndef RG_SMALL
+#define RG_SMALL 8      // up to this many chains: one read per lane
+#endif
+#ifndef RGW_CAP
+#define RGW_CAP 1536   // chains the wave-cooperative kernel holds in LDS
+#endif
+
+struct rg_lds {
+	rh_reg rg[RG_CAP];
+	rh_chain_head ch[RG_CAP];
+	rh_mm128_t z[RG_CAP];
+	uint64_t cov[RG_CAP], u[RG_CAP];
+	int32_t w[RG_CAP], tmp[RG_CAP];
+	uint32_t cw[512];
+	uint32_t k0[RG_CAP];
+};
+
+__global__ __launch_bounds__(64) void k_regions(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, const float *logf_tab, uint32_t n_lo, int only_flagged)
+{
+	__shared__ rg_lds L;
+	const uint32_t a = blockIdx.x, lane = threadIdx.x;
+	if (a >= rr.n_act) return;
+	const uint32_t r = rr.act[a];
+	if (rr.skip[a]) { if (lane == 0) rd.ls_ncregs[r] = 0; return; }   // chunk dropped: creg stays NULL (rmap.cpp:232-235, :419)
+	const uint64_t base = rr.a_off[a];
+	const int32_t n_u = (int32_t)rr.n_u[a];
+	if (n_u == 0) { if (lane == 0) regions_commit(o, rd, rr, a, r, 0, nullptr, 0); return; }
+	if (n_u > RG_CAP || n_u <= (int32_t)n_lo) return;             // others: k_regions_big
+	if (only_flagged && !rr.need_exact[a]) return;                // done by k_regions_wave
+	const rh_mm128_t *an = rr.anc + base;
+	const uint64_t *u = rr.u + base;
+	for (int32_t i = (int32_t)lane; i < n_u; i += 64) L.u[i] = u[i];
+	__syncthreads();
+	if (lane == 0) { uint32_t k = 0; for (int32_t i = 0; i < n_u; ++i) { L.k0[i] = k; k += (uint32_t)L.u[i]; } }
+	__syncthreads();
+	for (int32_t i = (int32_t)lane; i < n_u; i += 64) {
+		const uint32_t k = L.k0[i], cnt = (uint32_t)L.u[i];
+		const rh_mm128_t f0 = an[k], f1 = an[k + cnt - 1];
+		rh_chain_head h; h.x0 = f0.x; h.y0 = f0.y; h.x1 = (int32_t)f1.x; h.y1 = (int32_t)f1.y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
+		L.ch[i] = h;
+	}
+	__syncthreads();
+	if (lane == 0) {
+		int stop;
+		const int32_t n_regs = regions_core(o, n_u, L.u, L.ch, L.rg, L.z, L.cov, L.w, L.tmp, L.cw, rr.rep_len[a], rr.n_ev[a], rd.ev_off[r], logf_tab, &stop);
+		regions_commit(o, rd, rr, a, r, n_regs, &L.rg[0], stop);
+	}
+}
+
+// reads with more than RG_CAP chains: the same core on HBM scratch, one read per lane
+__global__ void k_regions_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, const float *logf_tab, uint32_t n_lo, uint32_t n_hi, int only_flagged)
+{
+	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const uint32_t r = rr.act[a];
+	const uint64_t base = rr.a_off[a];
+	const int32_t n_u = (int32_t)rr.n_u[a];
+	if (n_u <= (int32_t)n_lo || n_u > (int32_t)n_hi) return;
+	if (only_flagged && n_u <= RGW_CAP && !rr.need_exact[a]) return;
+	const rh_mm128_t *an = rr.anc + base;
+	const uint64_t *u = rr.u + base;
+	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;           // 128 B per anchor >= 128 B per chain
+	rh_reg *rg = (rh_reg*)wsr;
+	rh_chain_head *ch = (rh_chain_head*)(wsr + (size_t)64 * n_u);
+	rh_mm128_t *z = (rh_mm128_t*)(wsr + (size_t)96 * n_u);
+	uint64_t *cov = (uint64_t*)(wsr + (size_t)112 * n_u);
+	int32_t *w = (int32_t*)(wsr + (size_t)120 * n_u), *tmp = (int32_t*)(wsr + (size_t)124 * n_u);
+	uint32_t *cw = (uint32_t*)rg;                                    // the sort runs before rg[] is populated
+	uint32_t k = 0;
+	for (int32_t i = 0; i < n_u; ++i) {
+		const uint32_t cnt = (uint32_t)u[i];
+		rh_chain_head h; h.x0 = an[k].x; h.y0 = an[k].y; h.x1 = (int32_t)an[k + cnt - 1].x; h.y1 = (int32_t)an[k + cnt - 1].y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
+		ch[i] = h;
+		k += cnt;
+	}
+	int stop;
+	const int32_t n_regs = regions_core(o, n_u, u, ch, rg, z, cov, w, tmp, cw, rr.rep_len[a], rr.n_ev[a], rd.ev_off[r], logf_tab, &stop);
+	regions_commit(o, rd, rr, a, r, n_regs, &rg[0], stop);
+}
+
+// ------------------------------------------------------------------------------------------------ regions, wave-cooperative
+// Reads with many chains (unmapped reads accumulate hundreds of short chains over the chunks): mm_set_parent is
+// quadratic in the number of chains, but each of its inner loops over the current primaries is an independent
+// interval test -> 64 primaries per step.  Default selection only (pri_ratio > 0, best_n == 0: secondaries dropped).
+#define RGW_COV 512
+
+// chain heads + sort keys (hit.c:111-120) for reads with more than RG_SMALL chains; heads -> scratch, keys -> rr.raw
+__global__ __launch_bounds__(64) void k_regions_prep(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
+{
+	const uint32_t a = blockIdx.x, lane = threadIdx.x;
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const int32_t n_u = (int32_t)rr.n_u[a];
+	if (n_u <= RG_SMALL) return;
+	const uint32_t r = rr.act[a];
+	const uint64_t base = rr.a_off[a];
+	const rh_mm128_t *an = rr.anc + base;
+	const uint64_t *u = rr.u + base;
+	rh_chain_head *heads = (rh_chain_head*)(rr.ws + base * RH_WS_PER_ANCHOR);
+	rh_mm128_t *z = rr.raw + base;
+	uint32_t hash = 0;
+	hash ^= rh_wang32(rd.ev_off[r] + rr.n_ev[a]) + rh_wang32(11u);
+	hash = rh_wang32(hash);
+	uint32_t carry = 0;
+	for (int32_t i0 = 0; i0 < n_u; i0 += 64) {
+		const int32_t i = i0 + (int32_t)lane;
+		const uint64_t ui = i < n_u ? u[i] : 0ull;
+		const uint32_t cnt = (uint32_t)ui;
+		uint32_t inc = cnt;
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= (uint32_t)d) inc += t; }
+		const uint32_t k = carry + inc - cnt;
+		if (i < n_u) {
+			const rh_mm128_t f0 = an[k], f1 = an[k + cnt - 1];
+			rh_chain_head h; h.x0 = f0.x; h.y0 = f0.y; h.x1 = (int32_t)f1.x; h.y1 = (int32_t)f1.y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
+			heads[i] = h;
+			const uint32_t hh = (uint32_t)rh_mix64_nomask((rh_mix64_nomask(f0.x) + rh_mix64_nomask(f0.y)) ^ (uint64_t)hash);
+			rh_mm128_t e; e.x = ui ^ (uint64_t)hh; e.y = (uint64_t)(uint32_t)i;
+			z[i] = e;
+		}
+		carry += __shfl(inc, 63);
+	}
+}
+
+struct rgw_lds {
+	int32_t qs[RGW_CAP], qe[RGW_CAP], score[RGW_CAP], cnt[RGW_CAP], parent[RGW_CAP], subsc[RGW_CAP], nsub[RGW_CAP];
+	uint16_t w[RGW_CAP];
+	uint64_t cov[RGW_COV];
+	uint16_t covj[RGW_COV];
+	int32_t bc[4];
+};
+
+__global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, const float *logf_tab)
+{
+	__shared__ rgw_lds L;
+	const uint32_t a = blockIdx.x, lane = threadIdx.x;
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const int32_t n_u = (int32_t)rr.n_u[a];
+	if (n_u <= RG_SMALL || n_u > RGW_CAP) return;
+	const uint32_t r = rr.act[a];
+	const uint64_t base = rr.a_off[a];
+	const rh_chain_head *heads = (const rh_chain_head*)(rr.ws + base * RH_WS_PER_ANCHOR);
+	const rh_mm128_t *zs = rr.zs + base;                             // keys in radix_sort_128x order (ascending)
+	for (int32_t i = (int32_t)lane; i < n_u; i += 64) {
+		const rh_mm128_t zi = zs[n_u - 1 - i];                      // descending: larger score first (hit.c:124-126)
+		const rh_chain_head h = heads[(uint32_t)zi.y];
+		L.score[i] = (int32_t)(zi.x >> 32); L.cnt[i] = h.cnt; L.qs[i] = (int32_t)h.y0; L.qe[i] = h.y1 + 1;
+		L.parent[i] = -1; L.subsc[i] = 0; L.nsub[i] = 0;
+	}
+	if (lane == 0) { L.w[0] = 0; L.parent[0] = 0; L.bc[3] = 0; }
+	__syncthreads();
+	const bool hard = (o.flag & RH_M_HARD_MLEVEL) != 0;
+	int32_t kk = 1;
+	bool overflow = false;
+	for (int32_t i = 1; i < n_u && !overflow; ++i) {
+		const int32_t si = L.qs[i], ei = L.qe[i];
+		// overlapping primaries, in list order
+		int32_t n_cov = 0;
+		for (int32_t j0 = 0; j0 < kk; j0 += 64) {
+			const int32_t j = j0 + (int32_t)lane;
+			bool ov = false; int32_t sj = 0, ej = 0;
+			if (j < kk) { const uint32_t rp = L.w[j]; sj = L.qs[rp]; ej = L.qe[rp]; ov = !(ej <= si || sj >= ei); }
+			const uint64_t m = __ballot(ov);
+			if (ov) {
+				const int32_t c = n_cov + (int32_t)lanes_below(m);
+				if (c < RGW_COV) { L.cov[c] = (uint64_t)(uint32_t)(sj < si ? si : sj) << 32 | (uint64_t)(uint32_t)(ej > ei ? ei : ej); L.covj[c] = (uint16_t)j; }
+			}
+			n_cov += (int32_t)__popcll(m);
+		}
+		if (n_cov > RGW_COV) { overflow = true; break; }
+		__syncthreads();
+		int32_t sel = -1, uncov = 0;
+		if (n_cov > 0) {
+			if (!hard) {	// length of [si, ei) not covered by the overlapping primaries
+				if (lane == 0) {
+					for (int32_t x1 = 1; x1 < n_cov; ++x1) { const uint64_t cv = L.cov[x1]; int32_t y1 = x1; while (y1 > 0 && L.cov[y1 - 1] > cv) { L.cov[y1] = L.cov[y1 - 1]; --y1; } L.cov[y1] = cv; }
+					int32_t x = si, un = 0;
+					for (int32_t j = 0; j < n_cov; ++j) { const uint64_t cv = L.cov[j]; if ((int32_t)(cv >> 32) > x) un += (int32_t)(cv >> 32) - x; x = (int32_t)cv > x ? (int32_t)cv : x; }
+					if (ei > x) un += ei - x;
+					L.bc[0] = un;
+				}
+				__syncthreads();
+				uncov = L.bc[0];
+			}
+			// first overlapping primary (list order) that masks region i
+			for (int32_t c0 = 0; c0 < n_cov && sel < 0; c0 += 64) {
+				const int32_t c = c0 + (int32_t)lane;
+				bool hit = false;
+				if (c < n_cov) {
+					const uint32_t rp = L.w[L.covj[c]];
+					const int32_t sj = L.qs[rp], ej = L.qe[rp];
+					const int32_t mn = ej - sj < ei - si ? ej - sj : ei - si;
+					const int32_t mx = ej - sj > ei - si ? ej - sj : ei - si;
+					const int32_t ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj) : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
+					hit = (float)ol / (float)mn - (float)uncov / (float)mx > o.mask_level && uncov <= o.mask_len;
+				}
+				const uint64_t m = __ballot(hit);
+				if (m) sel = (int32_t)L.covj[c0 + __builtin_ctzll(m)];
+			}
+		}
+		if (lane == 0) {
+			if (sel >= 0) {
+				const uint32_t rp = L.w[sel];
+				const int32_t sci = L.score[i];
+				L.parent[i] = L.parent[rp];
+				if (L.subsc[rp] < sci) L.subsc[rp] = sci;
+				if (L.cnt[i] >= L.cnt[rp]) ++L.nsub[rp];
+			} else { L.w[kk] = (uint16_t)i; L.parent[i] = i; L.nsub[i] = 0; }
+		}
+		if (sel < 0) ++kk;
+		__syncthreads();
+	}
+	if (overflow) { if (lane == 0) rr.need_exact[a] = 1; return; }   // re-done by the serial kernel
+	// secondaries dropped (mm_select_sub with best_n = 0): the kept regions are exactly the primaries, in order
+	const int32_t n_regs = kk;
+	int64_t sum_sc = 0;
+	for (int32_t k0 = 0; k0 < n_regs; k0 += 64) { const int32_t k = k0 + (int32_t)lane; int32_t v = k < n_regs ? L.score[L.w[k]] : 0; for (int d = 32; d > 0; d >>= 1) v += (int32_t)__shfl_xor((uint32_t)v, d); sum_sc += v; }
+	const float uniq_ratio = (float)sum_sc / (float)(sum_sc + rr.rep_len[a]);
+	int64_t sumQ = 0;
+	int32_t mapq0 = 0;
+	for (int32_t k0 = 0; k0 < n_regs; k0 += 64) {
+		const int32_t k = k0 + (int32_t)lane;
+		int32_t mq = 0;
+		if (k < n_regs) {
+			const uint32_t i = L.w[k];
+			const int32_t sc = L.score[i], cn = L.cnt[i];
+			const float pen_s1 = (float)((sc > 100 ? 1.0 : 0.01 * (double)sc) * (double)uniq_ratio);
+			float pen_cm = cn > 10 ? 1.0f : 0.1f * (float)cn;
+			pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
+			const int32_t subsc = L.subsc[i] > o.min_sc ? L.subsc[i] : o.min_sc;
+			const float x = (float)subsc / (float)sc;
+			mq = (int32_t)(pen_cm * 40.0f * (1.0f - x) * logf_int(sc, logf_tab));
+			mq -= (int32_t)(4.343f * logf_int(L.nsub[i] + 1, logf_tab) + .499f);
+			mq = mq > 0 ? mq : 0;
+			mq = mq < 60 ? mq : 60;
+		}
+		if (k0 == 0) mapq0 = __shfl(mq, 0);
+		int32_t v = mq;
+		for (int d = 32; d > 0; d >>= 1) v += (int32_t)__shfl_xor((uint32_t)v, d);
+		sumQ += v;
+	}
+	if (lane == 0) {
+		int stop = 0;
+		const int32_t score0 = L.score[0];
+		if (n_regs == 1 && mapq0 >= o.min_mapq) stop = 1;
+		else {
+			float meanC = (float)sum_sc, meanQ = (float)sumQ;        // sums of small integers: exact in fp32 in any order
+			meanC /= (float)n_regs; meanQ /= (float)n_regs;
+			const float bestQ = (float)mapq0, bestC = (float)score0;
+			float r_bestq = (bestQ > 0) ? (bestQ / 30.0f) : 0.0f; if (r_bestq > 1) r_bestq = 1.0f;
+			float r_bestmq = (bestQ > 0) ? (1.0f - (meanQ / bestQ)) : 0.0f; if (r_bestmq < 0) r_bestmq = 0.0f;
+			float r_bestmc = (bestC > 0) ? (1.0f - (meanC / bestC)) : 0.0f; if (r_bestmc < 0) r_bestmc = 0.0f;
+			const float weighted = o.w_bestq * r_bestq + o.w_bestmq * r_bestmq + o.w_bestmc * r_bestmc;
+			if (weighted >= o.w_threshold) stop = 1;
+		}
+		const rh_chain_head h = heads[(uint32_t)zs[n_u - 1].y];
+		rh_reg best;
+		best.cnt = h.cnt; best.score = score0; best.mapq = (uint32_t)mapq0;
+		best.qs = (int32_t)h.y0; best.qe = h.y1 + 1; best.rs = (int32_t)h.x0; best.re = h.x1 + 1;
+		best.rid = (int32_t)(h.x0 << 1 >> 33); best.rev = (uint32_t)(h.x0 >> 63);
+		regions_commit(o, rd, rr, a, r, n_regs, &best, stop);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+void rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
+{
+	if (!r.n_act) return;
+	RH_LAUNCH(k_zbuild, r.n_act, 64, 0, s, o, r);
+	// candidates (score, anchor index) -> reference order; scores are full of ties: exact permutation for every read
+	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_z, r.raw, r.zs, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 64 };
+	rhk_sort_job(s, jb, true, 0u);
+	// The chain walk is pointer chasing: with many reads in flight one read per lane (HBM arrays) hides the latency best;
+	// the LDS workgroup variant is kept for batches too small to fill the machine with lanes.
+	if (r.n_act >= 4096u) RH_LAUNCH(k_backtrack_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, 0u);
+	else {
+		RH_LAUNCH(k_backtrack, r.n_act, 64, 0, s, o, rd, r, 0u);
+		RH_LAUNCH(k_backtrack_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, (uint32_t)BK_CAP);
+	}
+}
+
+void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r, const float *logf_tab)
+{
+	if (!r.n_act) return;
+	const bool wave_ok = o.best_n == 0 && o.pri_ratio > 0.0f && !(o.flag & RH_M_ALL_CHAINS);
+	// need_exact[] doubles as "this read still needs the serial region kernel"
+	RH_HIP_VOID(hipMemsetAsync(r.need_exact, wave_ok ? 0 : 1, r.n_act, s));
+	if (wave_ok) {
+		RH_LAUNCH(k_regions_prep, r.n_act, 64, 0, s, o, rd, r);
+		rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64 };
+		rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL);
+		RH_LAUNCH(k_regions_wave, r.n_act, 64, 0, s, o, rd, r, logf_tab);
+	}
+	// skip / no-chain bookkeeping for every read + LDS serial core for reads the wave kernel could not take
+	RH_LAUNCH(k_regions, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL, wave_ok ? 1 : 0);
+	RH_LAUNCH(k_regions_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, logf_tab, 0u, (uint32_t)RG_SMALL, 0);
+	RH_LAUNCH(k_regions_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_CAP, 0x7FFFFFFFu, wave_ok ? 1 : 0);
+}

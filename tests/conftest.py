@@ -33,6 +33,15 @@ def emu_lib():
     return _capi.load(build_emu.build())
 
 
+@pytest.fixture(scope="session")
+def emu_lib_smallcaps():
+    """Emulator build with tiny LDS caps: forces the oversized-read fallback kernels on small inputs."""
+    from rawhash_amd import _capi
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    return _capi.load(build_emu.build(defines=build_emu.SMALL_CAPS, tag="_smallcaps"))
+
+
 class Workload:
     """Synthetic reference + index + reads, generated from seeds by the product library's host code."""
 

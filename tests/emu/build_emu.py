@@ -10,8 +10,11 @@ CSRC = os.path.join(ROOT, "rawhash_amd", "csrc")
 BUILD = os.path.join(HERE, "_build")
 OUT = os.path.join(BUILD, "librawhash_emu.so")
 
+# small LDS caps so that the oversized-read fallbacks (the *_big kernels) are exercised on small test inputs
+SMALL_CAPS = ("-DBK_CAP=256", "-DBK_UCAP=64", "-DRG_CAP=8", "-DRGW_CAP=48", "-DRH_SORT_CAP1=512", "-DRH_SORT_CAP2=1024")
 
-def build(force=False):
+
+def build(force=False, defines=(), tag=""):
     src_dir = os.path.join(BUILD, "src")
     os.makedirs(src_dir, exist_ok=True)
     srcs = []
@@ -31,12 +34,13 @@ def build(force=False):
         newest = max(newest, os.path.getmtime(os.path.join(HERE, f)))
     srcs.append(os.path.join(src_dir, "emu_runtime.cpp"))
     newest = max(newest, os.path.getmtime(os.path.join(ROOT, "include", "rawhash_amd.h")))
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
-        return OUT
+    out = OUT.replace(".so", tag + ".so")
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
+        return out
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-pthread", "-w",
-           "-I", src_dir, "-I", os.path.join(ROOT, "include"), "-x", "c++"] + srcs + ["-o", OUT, "-lz"]
+           "-I", src_dir, "-I", os.path.join(ROOT, "include"), "-x", "c++"] + list(defines) + srcs + ["-o", out, "-lz"]
     subprocess.run(cmd, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 namespace {
 enum { RUN = 0, AT_BARRIER, AT_WAVE, DONE };
-enum { OP_BALLOT = 1, OP_SHFL_DOWN };
+enum { OP_BALLOT = 1, OP_SHFL_DOWN = 2, OP_SHFL_UP = 3, OP_SHFL_XOR = 4, OP_SHFL_IDX = 5 };
 struct Fiber {
 	ucontext_t ctx; char *stack = nullptr; int state = DONE; unsigned tid = 0;
 	int op = 0; unsigned long long in = 0, out = 0; unsigned par = 0;
@@ -24,7 +24,8 @@ void yield_to_main() { swapcontext(&g_cur->ctx, &g_main); }
 
 void emu_syncthreads() { g_cur->state = AT_BARRIER; yield_to_main(); }
 unsigned long long emu_ballot(int pred) { g_cur->state = AT_WAVE; g_cur->op = OP_BALLOT; g_cur->in = pred ? 1 : 0; yield_to_main(); return g_cur->out; }
-unsigned long long emu_shfl_down_bits(unsigned long long bits, unsigned delta) { g_cur->state = AT_WAVE; g_cur->op = OP_SHFL_DOWN; g_cur->in = bits; g_cur->par = delta; yield_to_main(); return g_cur->out; }
+unsigned long long emu_shfl_bits(unsigned long long bits, int op, unsigned par) { g_cur->state = AT_WAVE; g_cur->op = op; g_cur->in = bits; g_cur->par = par; yield_to_main(); return g_cur->out; }
+unsigned long long emu_shfl_down_bits(unsigned long long bits, unsigned delta) { return emu_shfl_bits(bits, OP_SHFL_DOWN, delta); }
 
 void emu_launch(unsigned grid, unsigned block, const std::function<void()> &body)
 {
@@ -63,7 +64,16 @@ void emu_launch(unsigned grid, unsigned block, const std::function<void()> &body
 					Fiber &f = g_f[t];
 					if (f.state != AT_WAVE) continue;
 					if (f.op == OP_BALLOT) f.out = mask;
-					else { const unsigned src = t + f.par; f.out = (src < w1 && g_f[src].state == AT_WAVE && g_f[src].op == OP_SHFL_DOWN) ? g_f[src].in : f.in; }
+					else {
+						const unsigned l = t - w0;
+						long src = -1;
+						if (f.op == OP_SHFL_DOWN) src = (long)l + f.par;
+						else if (f.op == OP_SHFL_UP) src = (long)l - (long)f.par;
+						else if (f.op == OP_SHFL_XOR) src = (long)(l ^ f.par);
+						else if (f.op == OP_SHFL_IDX) src = (long)(f.par & 63);
+						const long st = src + w0;
+						f.out = (src >= 0 && src < 64 && st < (long)w1 && g_f[st].state == AT_WAVE && g_f[st].op == f.op) ? g_f[st].in : f.in;
+					}
 				}
 				for (unsigned t = w0; t < w1; ++t) if (g_f[t].state == AT_WAVE) { g_f[t].state = RUN; progressed = true; }
 			}

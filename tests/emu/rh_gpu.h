@@ -31,11 +31,27 @@ extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 void emu_syncthreads();
 unsigned long long emu_ballot(int pred);
 unsigned long long emu_shfl_down_bits(unsigned long long bits, unsigned delta);
+unsigned long long emu_shfl_bits(unsigned long long bits, int op, unsigned par);   // op: 2 down, 3 up, 4 xor, 5 idx
 #define __syncthreads() emu_syncthreads()
 #define __ballot(p) emu_ballot((p) ? 1 : 0)
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline double __shfl_down(double v, int d) { unsigned long long b; memcpy(&b, &v, 8); b = emu_shfl_down_bits(b, (unsigned)d); memcpy(&v, &b, 8); return v; }
+static inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
+static inline unsigned __shfl_up(unsigned v, int d) { return (unsigned)emu_shfl_bits(v, 3, (unsigned)d); }
+static inline unsigned __shfl_xor(unsigned v, int d) { return (unsigned)emu_shfl_bits(v, 4, (unsigned)d); }
+static inline unsigned long long __shfl_xor(unsigned long long v, int d) { return emu_shfl_bits(v, 4, (unsigned)d); }
+static inline unsigned long __shfl_xor(unsigned long v, int d) { return (unsigned long)emu_shfl_bits(v, 4, (unsigned)d); }
+static inline unsigned long __shfl_up(unsigned long v, int d) { return (unsigned long)emu_shfl_bits(v, 3, (unsigned)d); }
+static inline unsigned long __shfl(unsigned long v, int lane) { return (unsigned long)emu_shfl_bits(v, 5, (unsigned)lane); }
+static inline unsigned __shfl(unsigned v, int lane) { return (unsigned)emu_shfl_bits(v, 5, (unsigned)lane); }
+static inline int __shfl(int v, int lane) { return (int)emu_shfl_bits((unsigned)v, 5, (unsigned)lane); }
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p += v; return o; }
+static inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p |= v; return o; }
+static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
+
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
 
 // ---- host runtime subset
 typedef int hipError_t;
@@ -72,3 +88,5 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 
 void emu_launch(unsigned grid, unsigned block, const std::function<void()> &body);
 #define RH_LAUNCH(kernel, grid, block, lds, stream, ...) emu_launch((unsigned)(grid), (unsigned)(block), [&]() { kernel(__VA_ARGS__); })
+
+#define RH_HIP_VOID(call) do { (void)(call); } while (0)

@@ -101,15 +101,21 @@ def check_sort(ctx, seed=0, n_seg=40):
     """Exact unstable-permutation emulation of radix_sort_128x, with heavy key ties in every byte position."""
     rng = np.random.default_rng(seed)
     sizes = rng.integers(0, 900, size=n_seg)
-    sizes[:4] = [0, 1, 64, 65]
+    sizes[:8] = [0, 1, 64, 65, 4096, 4097, 3000, 5500]
     off = np.zeros(n_seg + 1, dtype=np.uint64)
     off[1:] = np.cumsum(sizes)
     tot = int(off[-1])
     a = np.zeros(tot, dtype=MM128)
     for s in range(n_seg):
         b, e = int(off[s]), int(off[s + 1])
-        mode = s % 4
-        if mode == 0:
+        mode = s % 6
+        if mode == 4:     # anchor-like keys: strand bit | small rid | 23-bit position, a few duplicated positions
+            x = (rng.integers(0, 2, size=e - b, dtype=np.uint64) << np.uint64(63)) | (rng.integers(0, 3, size=e - b, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, 1 << 23, size=e - b, dtype=np.uint64)
+            if e - b > 10:
+                x[rng.integers(0, e - b, size=(e - b) // 10)] = x[rng.integers(0, e - b, size=(e - b) // 10)]
+        elif mode == 5:   # unique anchor-like keys (fast path result must already be exact)
+            x = (rng.integers(0, 2, size=e - b, dtype=np.uint64) << np.uint64(63)) | rng.permutation(1 << 20)[: e - b].astype(np.uint64) * np.uint64(5)
+        elif mode == 0:
             x = rng.integers(0, 1 << 62, size=e - b, dtype=np.uint64)
         elif mode == 1:
             x = rng.integers(0, 40, size=e - b, dtype=np.uint64)                      # small scores: many ties

@@ -44,3 +44,14 @@ def test_presets(make_workload, emu_lib, preset):
     c.upload(w.index)
     pc.check_e2e(c, w)
     c.close()
+
+
+def test_oversized_read_fallbacks(make_workload, emu_lib_smallcaps):
+    """Same kernels built with tiny LDS caps: reads overflow into the *_big / serial-tail paths and must still match."""
+    w = make_workload(lib=emu_lib_smallcaps, n_reads=12, n_samples=12_000)
+    c = Context(0, lib=emu_lib_smallcaps)
+    c.upload(w.index)
+    pc.check_stages(c, w)
+    pc.check_e2e(c, w)
+    pc.check_sort(c, seed=3, n_seg=16)
+    c.close()

@@ -85,3 +85,16 @@ def test_golden_paf(product_lib, gpu_ctx_factory, tmp_path):
         recs = c.map_batch(w.opts, w.reads)
         got = [strip_mt(x) for x in paf_lines(w.index, recs, w.reads.names)]
         assert got == golden.expected_paf(case)
+
+
+def test_large_batch_paths(make_workload, gpu_ctx_factory):
+    """6000 reads: exercises the many-reads dispatch (one read per lane walks) against the oracle on all host cores."""
+    import os
+    w = make_workload(n_reads=6000, n_samples=20_000, chrom_len=1_500_000, n_chrom=1, junk=120, noise=0, read_seed=31)
+    c = gpu_ctx_factory()
+    c.upload(w.index)
+    recs = c.map_batch(w.opts, w.reads)
+    got = [strip_mt(x) for x in paf_lines(w.index, recs, w.reads.names)]
+    want = w.oracle_paf(n_threads=os.cpu_count() or 8)
+    bad = [(g, x) for g, x in zip(got, want) if g != x]
+    assert not bad, f"{len(bad)} of {len(want)} PAF lines differ, first: {bad[0]}"
