@@ -91,26 +91,8 @@ def main():
     keep = []
     if world > 1:
         # replicate the HBM-resident index: one RCCL broadcast of the flattened blob over xGMI (the only collective)
-        import torch
-        meta = torch.zeros(3, dtype=torch.int64, device=f"cuda:{local_rank}")
-        hdr_t = torch.zeros(256, dtype=torch.uint8, device=f"cuda:{local_rank}")
-        if rank == 0:
-            _, nbytes, hdr = ctx.device_blob()
-            meta[0], meta[1] = nbytes, opts.mo.mid_occ
-            hdr_t.copy_(torch.frombuffer(bytearray(hdr), dtype=torch.uint8))
-        dist.broadcast(meta, 0)
-        dist.broadcast(hdr_t, 0)
-        nbytes = int(meta[0].item())
-        opts.mo.mid_occ = int(meta[1].item())
-        if opts.mo.bw_long < opts.mo.bw:
-            opts.mo.bw_long = opts.mo.bw
-        blob = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
-        if rank == 0:
-            ctx.copy_blob_to(blob.data_ptr())
-        dist.broadcast(blob, 0)
-        torch.cuda.synchronize()
-        ctx.adopt_blob(blob.data_ptr(), nbytes, bytes(hdr_t.cpu().numpy().tobytes()), take_ownership=False)
-        keep.append(blob)
+        from rawhash_amd.dist import replicate_index
+        keep.append(replicate_index(ctx, opts, None, device=f"cuda:{local_rank}"))
         dist.barrier()
     # this rank's shard of the read set, generated straight into HBM
     batch = wl.reads_device(ctx, model, rank * args.reads, args.reads)

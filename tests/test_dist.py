@@ -1,0 +1,79 @@
+"""N > 1 path on CPU: 2 gloo processes shard the reads, broadcast the index blob, map their shard (kernel sources under
+the SIMT emulator) and gather; the result must equal the single-process result and the oracle's PAF."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from rawhash_amd.dist import shard_bounds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, pickle
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, os.path.join(sys.argv[1], "tests", "emu"))
+import numpy as np, torch, torch.distributed as dist
+import build_emu
+from rawhash_amd import _capi
+from rawhash_amd.api import Context, Index, MapOptions, SynthWorkload, paf_lines, strip_mt
+from rawhash_amd.dist import shard_bounds, replicate_index, gather_records
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lib = _capi.load(build_emu.build())
+d = sys.argv[2]
+wl = SynthWorkload(chrom_len=300_000, n_chrom=2, n_samples=12_000, junk_per_1024=150, noise_q24=150_000, lib=lib)
+opts = MapOptions("sensitive", lib=lib)
+ctx = Context(0, lib=lib)
+index = None
+if rank == 0:
+    fasta, model = wl.write_reference(d)
+    index = Index.build(fasta, model, opts, out_ind=os.path.join(d, "ref.ind"), lib=lib)
+    opts.update(index)
+dist.barrier()
+keep = replicate_index(ctx, opts, index, device="cpu")
+n = 21
+lo, hi = shard_bounds(n, rank, world)
+reads = wl.reads(os.path.join(d, "model.txt"), lo, hi - lo)
+recs = ctx.map_batch(opts, reads)
+allr = gather_records(recs, lo)
+if rank == 0:
+    full = wl.reads(os.path.join(d, "model.txt"), 0, n)
+    single = ctx.map_batch(opts, full)
+    assert np.array_equal(allr, single), "sharded result differs from the single-process result"
+    with open(os.path.join(d, "paf.pkl"), "wb") as f:
+        pickle.dump([strip_mt(x) for x in paf_lines(index, allr, full.names, lib=lib)], f)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 100, 101):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gloo_matches_single_process_and_oracle(tmp_path, emu_lib):
+    import pickle
+    import ctypes as C
+    import oracle_lib as O
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29533", str(script), ROOT, str(tmp_path)], check=True, env=env, timeout=600)
+    got = pickle.load(open(tmp_path / "paf.pkl", "rb"))
+    from rawhash_amd.api import SynthWorkload
+    wl = SynthWorkload(chrom_len=300_000, n_chrom=2, n_samples=12_000, junk_per_1024=150, noise_q24=150_000, lib=emu_lib)
+    reads = wl.reads(str(tmp_path / "model.txt"), 0, 21)
+    oix = O.OracleIndex(str(tmp_path / "ref.ind"))
+    _, mo = O.preset("sensitive")
+    O.lib().ro_mapopt_update(C.byref(mo), oix.h)
+    want = [O.strip_mt(x) for x in O.paf_lines(oix, O.map_batch(oix, mo, reads.batch()), reads.names)]
+    assert got == want
