@@ -33,13 +33,17 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # Na anchors (incl. carried), Nc chained anchors, Ne events
 ALGO_BYTES = {
     "prefilter": lambda c: 2 * c["n_samples_raw"],
-    "events": lambda c: 2 * c["n_samples_used"] + 4 * c["n_events"],
+    "events_norm": lambda c: 2 * c["n_samples_used"],                      # int16 in; z/t1/t2 rows are intermediates
+    "events_peaks": lambda c: 8 * c["n_samples_used"] + 2 * c["n_events"],  # interface of the stage: t1,t2 in, peaks out
+    "events_means": lambda c: 4 * c["n_samples_used"] + 6 * c["n_events"],  # z + peaks in, events out
     "sketch": lambda c: 4 * c["n_events"] + 16 * c["n_seeds"],
     "probe": lambda c: 16 * c["n_seeds"] + 16 * c["n_seeds"],
     "expand": lambda c: 8 * c["n_hits"] + 16 * c["n_anchors"],
     "sort": lambda c: 32 * c["n_anchors"],
-    "chain": lambda c: 16 * c["n_anchors"],
-    "backtrack": lambda c: 32 * c["n_chained"],
+    "chain": lambda c: 16 * c["n_anchors"] + 12 * c["n_anchors"],           # anchors in, f/p/v out
+    "zsort": lambda c: 4 * c["n_anchors"] + 32 * c["n_chained"],            # f in; candidates >= chained anchors
+    "backtrack": lambda c: 8 * c["n_anchors"] + 32 * c["n_chained"],        # f,p in; chained anchors out (+ carried copy)
+    "rsort": lambda c: 16 * c["n_chained"],
     "regions": lambda c: 16 * c["n_chained"],
 }
 
@@ -71,8 +75,15 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RH_BENCH_BACKEND=gloo RH_BENCH_ONE_DEVICE=1 lets the multi-rank flow be exercised on a single-GPU box (tests only)
+        backend = os.environ.get("RH_BENCH_BACKEND", "nccl")
+        if os.environ.get("RH_BENCH_ONE_DEVICE"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend=backend)
 
     wl = SynthWorkload(chrom_len=args.genome, n_chrom=1, n_samples=args.samples, junk_per_1024=args.junk)
     opts = MapOptions(args.preset)
@@ -152,7 +163,7 @@ def main():
             "mapped_fraction": round(n_mapped / args.reads, 4),
             "chunks_per_read": round(acc["n_chunks"] / acc["n_reads"], 3),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom, args),
                          "avg_launch_ms": round(stage_ms[dom] / stage_n[dom], 4), "launches": stage_n[dom],
                          "algorithmic_bytes_per_launch": int(dom_bytes / stage_n[dom])},
             "path": {"algorithmic_GB_per_step": round(path_bytes / args.steps / 1e9, 4), "device_ms_per_step": round(dev_ms / args.steps, 3),
@@ -167,6 +178,20 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def pmc_traffic(stage, args):
+    """HBM bytes per launch of the dominant stage from the committed rocprofv3 --pmc passes of this same command
+    (profiles/pmc_traffic.json, made by profiles/collect_pmc.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    if d.get("reads") != args.reads or d.get("samples") != args.samples or d.get("junk") != args.junk:
+        return None
+    e = d.get("stages", {}).get(stage)
+    return None if e is None else int(e["bytes_per_launch"])
 
 
 def cpu_baseline(wl, model, ind, args):

@@ -150,8 +150,8 @@ RH_API int  rh_map_batch(rh_ctx *ctx, const rh_mapopt_t *mo, const rh_read_batch
 typedef struct rh_map_stats_s {
 	uint64_t n_reads, n_chunks, n_samples_raw, n_samples_used, n_events, n_seeds, n_hits, n_anchors, n_chained;
 	double   ms_total;                /* device time of the whole call (hipEvents on the context's stream) */
-	double   ms_kernel[16];           /* per-stage device time, see rh_stage_name() */
-	uint32_t n_launch[16];
+	double   ms_kernel[24];           /* per-stage device time (HIP events on the context's stream), see rh_stage_name() */
+	uint32_t n_launch[24];
 } rh_map_stats_t;
 RH_API int  rh_map_last_stats(rh_ctx *ctx, rh_map_stats_t *out);
 RH_API const char *rh_stage_name(int i);

@@ -1,0 +1,69 @@
+"""Collect HBM traffic per kernel with rocprofv3 PMC counters (separate passes, no tracing domains besides kernel-trace):
+
+    cd /tmp && export TMPDIR=/tmp && python /root/repo/profiles/collect_pmc.py
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream
+(MI355X_MICROARCH.md, HBM section), so read bytes = 2 x FETCH_SIZE x 1024.  k_prefilter is the calibration point: it streams
+exactly 2 B x raw samples.  Output: profiles/pmc_traffic.json (bytes per launch for each bench stage).
+"""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STAGE_OF = {"k_prefilter": "prefilter", "k_events_norm": "events_norm", "k_events_peaks": "events_peaks", "k_events_means": "events_means",
+            "k_sketch": "sketch", "k_probe": "probe", "k_expand": "expand", "k_chain_wave": "chain", "k_backtrack_big": "backtrack",
+            "k_regions_wave": "regions"}
+
+
+def one_pass(counter, out):
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--cpu-sample", "0"]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    f = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)[0]
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        e = acc.setdefault(k, [0, 0.0])
+        e[0] += 1
+        e[1] += float(r["Counter_Value"])
+    return acc
+
+
+def main():
+    fetch = one_pass("FETCH_SIZE", "/tmp/pmc_fetch")
+    write = one_pass("WRITE_SIZE", "/tmp/pmc_write")
+    kernels = {}
+    for k in sorted(set(fetch) | set(write)):
+        n = fetch.get(k, write.get(k))[0]
+        rd = 2.0 * fetch.get(k, [0, 0.0])[1] * 1024.0
+        wr = write.get(k, [0, 0.0])[1] * 1024.0
+        kernels[k] = {"launches": n, "read_bytes": rd, "write_bytes": wr, "bytes_per_launch": (rd + wr) / max(n, 1)}
+    stages = {}
+    for k, v in kernels.items():
+        st = STAGE_OF.get(k) or ("sort" if k.startswith("k_sort") else None)
+        if st is None:
+            continue
+        e = stages.setdefault(st, {"launches": 0, "bytes": 0.0})
+        e["launches"] += v["launches"]
+        e["bytes"] += v["read_bytes"] + v["write_bytes"]
+    for e in stages.values():
+        e["bytes_per_launch"] = e["bytes"] / max(e["launches"], 1)
+    out = {"reads": 100000, "samples": 40000, "junk": 102, "note": "read bytes = 2 x FETCH_SIZE KiB (gfx950), write bytes = WRITE_SIZE KiB",
+           "kernels": kernels, "stages": stages}
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    pf = kernels.get("k_prefilter")
+    if pf:
+        print("calibration: k_prefilter read bytes", pf["read_bytes"], "expected", 2 * 100000 * 40000)
+    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["read_bytes"] - kv[1]["write_bytes"])[:12]:
+        print(f"{k:32s} launches {v['launches']:4d}  read {v['read_bytes']/1e9:8.3f} GB  write {v['write_bytes']/1e9:8.3f} GB")
+
+
+if __name__ == "__main__":
+    main()

@@ -5,11 +5,13 @@
 #include <chrono>
 #include <cmath>
 #include <memory>
+#include <thread>
+#include <cstdlib>
 
 namespace {
 
 struct DevBuf {
-	void *p = nullptr; size_t cap = 0;
+	void *p = nullptr; size_t cap = 0; bool owned = true;
 	int ensure(size_t bytes)
 	{
 		if (bytes <= cap) return 0;
@@ -19,12 +21,12 @@ struct DevBuf {
 		cap = want;
 		return 0;
 	}
-	void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+	void release() { if (p && owned) (void)hipFree(p); p = nullptr; cap = 0; owned = true; }
 	template <class T> T *as() const { return (T*)p; }
 };
 
-enum Stage { ST_H2D = 0, ST_PREFILTER, ST_EVENTS, ST_SKETCH, ST_PROBE, ST_SCAN, ST_EXPAND, ST_SORT, ST_CHAIN, ST_BACKTRACK, ST_REGIONS, ST_COMPACT, ST_FINALIZE, ST_D2H, ST_N };
-const char *kStageName[16] = {"h2d", "prefilter", "events", "sketch", "probe", "scan", "expand", "sort", "chain", "backtrack", "regions", "compact", "finalize", "d2h", "", ""};
+enum Stage { ST_H2D = 0, ST_PREFILTER, ST_EV_NORM, ST_EV_PEAKS, ST_EV_MEANS, ST_SKETCH, ST_PROBE, ST_SCAN, ST_EXPAND, ST_SORT, ST_CHAIN, ST_ZSORT, ST_BACKTRACK, ST_RSORT, ST_REGIONS, ST_COMPACT, ST_FINALIZE, ST_D2H, ST_N };
+const char *kStageName[24] = {"h2d", "prefilter", "events_norm", "events_peaks", "events_means", "sketch", "probe", "scan", "expand", "sort", "chain", "zsort", "backtrack", "rsort", "regions", "compact", "finalize", "d2h", "", "", "", "", "", ""};
 
 } // namespace
 
@@ -49,6 +51,10 @@ struct rh_ctx_s {
 	// timing
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	rh_map_stats_t stats{};
+	// concurrent sub-batches: extra contexts (own stream + arenas) that borrow this context's index and tables
+	std::vector<rh_ctx*> subs;
+	int n_sub = 1;
+	bool is_sub = false;
 };
 
 namespace {
@@ -105,9 +111,9 @@ int stage_reads(rh_ctx *c, const rh_read_batch_t *in, rh_dev_reads *rd)
 		if (!in->cal_offset || !in->cal_scale) { rh_set_error("device batches must carry cal_offset and cal_scale"); return -1; }
 		rd->raw = in->samples; rd->off = in->offsets; rd->cal_off = in->cal_offset; rd->cal_scale = in->cal_scale;
 	} else {
-		const uint64_t total = R ? in->offsets[R] : 0;
+		const uint64_t first = R ? in->offsets[0] : 0, total = R ? in->offsets[R] - first : 0;   // a slice keeps absolute offsets
 		if (c->raw.ensure(total * 2 + 2) || c->off.ensure((size_t)(R + 1) * 8) || c->cal_off.ensure((size_t)(R + 1) * 8) || c->cal_scale.ensure((size_t)(R + 1) * 4)) return -1;
-		if (total) RH_HIP(hipMemcpyAsync(c->raw.p, in->samples, total * 2, hipMemcpyHostToDevice, c->stream));
+		if (total) RH_HIP(hipMemcpyAsync(c->raw.p, in->samples + first, total * 2, hipMemcpyHostToDevice, c->stream));
 		RH_HIP(hipMemcpyAsync(c->off.p, in->offsets, (size_t)(R + 1) * 8, hipMemcpyHostToDevice, c->stream));
 		std::vector<double> co(R, 0.0); std::vector<float> cs(R, 1.0f);
 		if (in->cal_offset) memcpy(co.data(), in->cal_offset, (size_t)R * 8);
@@ -117,7 +123,7 @@ int stage_reads(rh_ctx *c, const rh_read_batch_t *in, rh_dev_reads *rd)
 			RH_HIP(hipMemcpyAsync(c->cal_scale.p, cs.data(), (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
 		}
 		RH_HIP(hipStreamSynchronize(c->stream));   // co/cs are stack-owned
-		rd->raw = c->raw.as<int16_t>(); rd->off = c->off.as<uint64_t>(); rd->cal_off = c->cal_off.as<double>(); rd->cal_scale = c->cal_scale.as<float>();
+		rd->raw = c->raw.as<int16_t>() - first; rd->off = c->off.as<uint64_t>(); rd->cal_off = c->cal_off.as<double>(); rd->cal_scale = c->cal_scale.as<float>();
 	}
 	const size_t n = R ? R : 1;
 	size_t k = 0;
@@ -197,6 +203,7 @@ extern "C" int rh_ctx_create(rh_ctx **out, int device_id)
 	for (uint32_t i = 0; i < RH_LOGF_N; ++i) tab[i] = logf((float)i);
 	if (c->logf_tab.ensure((size_t)RH_LOGF_N * 4)) return -1;
 	RH_HIP(hipMemcpy(c->logf_tab.p, tab.data(), (size_t)RH_LOGF_N * 4, hipMemcpyHostToDevice));
+	if (const char *e = getenv("RH_SUB_BATCHES")) c->n_sub = atoi(e) > 0 ? atoi(e) : 1; else c->n_sub = 1;   // measured on MI355X: 2 sub-batches +5 %, more is slower -> off by default
 	*out = c.release();
 	return 0;
 }
@@ -206,6 +213,8 @@ extern "C" void rh_ctx_destroy(rh_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
+	for (rh_ctx *sc : c->subs) rh_ctx_destroy(sc);
+	c->subs.clear();
 	DevBuf *all[] = {&c->logf_tab, &c->raw, &c->off, &c->cal_off, &c->cal_scale, &c->act[0], &c->act[1], &c->n_act_dev, &c->zbuf, &c->t1buf, &c->t2buf, &c->n_norm, &c->peaks, &c->n_peaks, &c->ev, &c->n_ev, &c->skip, &c->sx, &c->sy,
 	                 &c->n_seed, &c->m_val, &c->m_n, &c->m_meta, &c->m_pref, &c->n_match, &c->n_new, &c->rep_len, &c->a_off, &c->anc, &c->raw_anc, &c->zs, &c->n_z, &c->need_exact, &c->need_exact2, &c->prev[0], &c->prev[1], &c->u,
 	                 &c->n_u, &c->n_v, &c->ws, &c->counters, &c->rec, &c->sy_samples, &c->sy_off, &c->sy_cal_off, &c->sy_cal_scale, &c->sy_levels};
@@ -297,11 +306,13 @@ extern "C" int rh_index_adopt_blob(rh_ctx *c, const rh_index *, void *dev_ptr, u
 // =================================================================================================== the hot path
 extern "C" uint64_t rh_map_max_records(const rh_read_batch_t *in, const rh_mapopt_t *) { return in->n_reads; }
 
-extern "C" const char *rh_stage_name(int i) { return (i >= 0 && i < 16) ? kStageName[i] : ""; }
+extern "C" const char *rh_stage_name(int i) { return (i >= 0 && i < 24) ? kStageName[i] : ""; }
 
 extern "C" int rh_map_last_stats(rh_ctx *c, rh_map_stats_t *out) { *out = c->stats; return 0; }
 
-extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out)
+namespace {
+// the whole path for one (sub-)batch on one context's stream
+int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out)
 {
 	*n_out = 0;
 	if (need_index(c)) return -1;
@@ -330,7 +341,9 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 		if (stage_round(c, n_act, &rr)) return -1;
 		rr.act = c->act[cur].as<uint32_t>(); rr.chunk = chunk;
 		rr.prev_in = c->prev[which ^ 1].as<rh_mm128_t>();
-		{ StageTimer t(c, ST_EVENTS); rhk_events(s, o, rd, rr); }
+		{ StageTimer t(c, ST_EV_NORM); rhk_events_norm(s, o, rd, rr); }
+		{ StageTimer t(c, ST_EV_PEAKS); rhk_events_peaks(s, o, rr); }
+		{ StageTimer t(c, ST_EV_MEANS); rhk_events_means(s, o, rr); }
 		{ StageTimer t(c, ST_SKETCH); rhk_sketch(s, o, c->dix, rd, rr); }
 		{ StageTimer t(c, ST_PROBE); rhk_probe(s, o, c->dix, rd, rr); }
 		uint64_t total = 0;
@@ -340,7 +353,9 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 		{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rr); }
 		{ StageTimer t(c, ST_SORT); rhk_sort(s, rr); }
 		{ StageTimer t(c, ST_CHAIN); rhk_chain(s, o, rr); }
+		{ StageTimer t(c, ST_ZSORT); rhk_zsort(s, o, rr); }
 		{ StageTimer t(c, ST_BACKTRACK); rhk_backtrack(s, o, rd, rr); }
+		{ StageTimer t(c, ST_RSORT); rhk_regions_sort(s, o, rd, rr); }
 		{ StageTimer t(c, ST_REGIONS); rhk_regions(s, o, rd, rr, c->logf_tab.as<float>()); }
 		{ StageTimer t(c, ST_COMPACT); rhk_compact_active(s, o, rd, rr.act, n_act, chunk + 1, c->act[cur ^ 1].as<uint32_t>(), c->n_act_dev.as<uint32_t>()); }
 		RH_HIP(hipMemcpyAsync(&n_act, c->n_act_dev.p, 4, hipMemcpyDeviceToHost, s));
@@ -359,8 +374,73 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 	}
 	RH_HIP(hipGetLastError());
 	c->stats.n_reads = R;
-	c->stats.n_samples_raw = in->samples_on_device ? 0 : in->offsets[R];
+	c->stats.n_samples_raw = in->samples_on_device ? 0 : in->offsets[R] - in->offsets[0];
 	c->stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+	*n_out = R;
+	return 0;
+}
+} // namespace
+
+// Reads are independent, and after the first chunk round only the hard reads remain (latency-bound kernels that cannot
+// fill the GPU).  Large batches are therefore split into contiguous sub-batches that run the identical per-round pipeline
+// concurrently, each on its own HIP stream with its own arenas, so the rounds of different sub-batches overlap.
+extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out)
+{
+	const uint32_t R = in->n_reads;
+	int n_sub = c->n_sub;
+	while (n_sub > 1 && R / (uint32_t)n_sub < 2048u) --n_sub;
+	if (n_sub <= 1 || c->is_sub) return map_batch_single(c, mo, in, out, out_cap, n_out);
+	*n_out = 0;
+	if (need_index(c)) return -1;
+	if (out_cap < R) { rh_set_error("output capacity %llu < %u reads", (unsigned long long)out_cap, R); return -1; }
+	RH_HIP(hipSetDevice(c->device));
+	while ((int)c->subs.size() < n_sub - 1) {
+		std::unique_ptr<rh_ctx> sc(new rh_ctx());
+		sc->device = c->device; sc->is_sub = true; sc->n_sub = 1;
+		RH_HIP(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+		RH_HIP(hipEventCreate(&sc->e0));
+		RH_HIP(hipEventCreate(&sc->e1));
+		c->subs.push_back(sc.release());
+	}
+	for (rh_ctx *sc : c->subs) {	// borrow the resident index and the logf table
+		sc->dix = c->dix; sc->have_index = true; sc->blob_owned = false;
+		sc->logf_tab.p = c->logf_tab.p; sc->logf_tab.cap = c->logf_tab.cap; sc->logf_tab.owned = false;
+	}
+	const auto t_begin = std::chrono::steady_clock::now();
+	std::vector<int> rc(n_sub, 0);
+	std::vector<std::string> err(n_sub);
+	std::vector<std::thread> th;
+	std::vector<uint32_t> lo(n_sub + 1);
+	for (int g = 0; g <= n_sub; ++g) lo[g] = (uint32_t)((uint64_t)R * g / n_sub);
+	for (int g = 0; g < n_sub; ++g)
+		th.emplace_back([&, g]() {
+			rh_ctx *lc = g == 0 ? c : c->subs[g - 1];
+			rh_read_batch_t b = *in;
+			b.n_reads = lo[g + 1] - lo[g];
+			b.offsets = in->offsets + lo[g];
+			if (in->cal_offset) b.cal_offset = in->cal_offset + lo[g];
+			if (in->cal_scale) b.cal_scale = in->cal_scale + lo[g];
+			if (in->name_rank) b.name_rank = in->name_rank + lo[g];
+			uint64_t n = 0;
+			const bool saved = lc->is_sub;
+			lc->is_sub = true;                                      // no further splitting
+			rc[g] = map_batch_single(lc, mo, &b, out + lo[g], b.n_reads, &n);
+			lc->is_sub = saved;
+			if (rc[g]) err[g] = rh_last_error();
+			else for (uint32_t i = 0; i < b.n_reads; ++i) out[lo[g] + i].read_idx += lo[g];
+		});
+	for (auto &t : th) t.join();
+	for (int g = 0; g < n_sub; ++g) if (rc[g]) { rh_set_error("sub-batch %d: %s", g, err[g].c_str()); return -1; }
+	// merge the statistics of the sub-batches into this context's
+	rh_map_stats_t tot = c->stats;
+	for (rh_ctx *sc : c->subs) {
+		const rh_map_stats_t &q = sc->stats;
+		tot.n_reads += q.n_reads; tot.n_chunks += q.n_chunks; tot.n_samples_raw += q.n_samples_raw; tot.n_samples_used += q.n_samples_used;
+		tot.n_events += q.n_events; tot.n_seeds += q.n_seeds; tot.n_hits += q.n_hits; tot.n_anchors += q.n_anchors; tot.n_chained += q.n_chained;
+		for (int i = 0; i < 24; ++i) { tot.ms_kernel[i] += q.ms_kernel[i]; tot.n_launch[i] += q.n_launch[i]; }
+	}
+	tot.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+	c->stats = tot;
 	*n_out = R;
 	return 0;
 }
@@ -549,6 +629,7 @@ extern "C" int rh_chain_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, cons
 	RH_HIP(hipMemset(rr.n_u, 0, (size_t)(R ? R : 1) * 4)); RH_HIP(hipMemset(rr.n_v, 0, (size_t)(R ? R : 1) * 4));
 	hipStream_t s = c->stream;
 	rhk_chain(s, o, rr);
+	rhk_zsort(s, o, rr);
 	rhk_backtrack(s, o, rd, rr);
 	RH_HIP(hipStreamSynchronize(s));
 	RH_HIP(hipGetLastError());

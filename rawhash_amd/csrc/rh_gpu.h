@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdint>
 
 #define RH_HD __host__ __device__
 #define RH_DEV __device__ __forceinline__
@@ -22,5 +23,17 @@ void rh_set_error(const char *fmt, ...);
 
 // kernel<<<grid, block, lds, stream>>>(args...)
 #define RH_LAUNCH(kernel, grid, block, lds, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, __VA_ARGS__)
+
+// wave-uniform register file tricks: lane `l` of a VGPR read / written with a wave-uniform lane index
+// (the amdgcn builtins only exist in the device pass of hipcc; the host pass just needs the declarations to parse)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t rh_readlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint32_t rh_writelane(uint32_t v, uint32_t val, uint32_t l) { return (threadIdx.x & 63u) == l ? val : v; }
+__device__ __forceinline__ uint32_t rh_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+#else
+__device__ uint32_t rh_readlane(uint32_t v, uint32_t l);
+__device__ uint32_t rh_writelane(uint32_t v, uint32_t val, uint32_t l);
+__device__ uint32_t rh_uniform(uint32_t v);
+#endif
 
 #define RH_HIP_VOID(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) rh_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); } while (0)

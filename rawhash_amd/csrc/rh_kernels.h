@@ -87,14 +87,19 @@ void rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t
 
 // kernel launchers (rh_kernels.hip)
 void rhk_prefilter(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd);
-void rhk_events(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
+void rhk_events_norm(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
+void rhk_events_peaks(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
+void rhk_events_means(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
+inline void rhk_events(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r) { rhk_events_norm(s, o, rd, r); rhk_events_peaks(s, o, r); rhk_events_means(s, o, r); }
 void rhk_sketch(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_probe(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_scan_anchors(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_sort(hipStream_t s, const rh_dev_round &r);
 void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
+void rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
 void rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
+void rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r, const float *logf_tab);
 void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act_in, uint32_t n_in, uint32_t next_chunk,
                         uint32_t *act_out, uint32_t *n_out);

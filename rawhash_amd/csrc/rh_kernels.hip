@@ -490,13 +490,9 @@ __global__ void k_synth_reads(rh_synth_cfg_t c, const int32_t *level16, uint64_t
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 void rhk_prefilter(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd) { if (rd.n_reads) RH_LAUNCH(k_prefilter, rd.n_reads, NT, 0, s, o, rd); }
-void rhk_events(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
-{
-	if (!r.n_act) return;
-	RH_LAUNCH(k_events_norm, r.n_act, NT, 0, s, o, rd, r);
-	RH_LAUNCH(k_events_peaks, cdiv(r.n_act, 64), 64, 0, s, o, r);
-	RH_LAUNCH(k_events_means, r.n_act, NT, 0, s, o, r);
-}
+void rhk_events_norm(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_norm, r.n_act, NT, 0, s, o, rd, r); }
+void rhk_events_peaks(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_peaks, cdiv(r.n_act, 64), 64, 0, s, o, r); }
+void rhk_events_means(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_means, r.n_act, NT, 0, s, o, r); }
 void rhk_sketch(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_sketch, cdiv(r.n_act, 64), 64, 0, s, o, ix, rd, r); }
 void rhk_probe(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_probe, r.n_act, NT, 0, s, o, ix, rd, r); }
 void rhk_scan_anchors(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r) { RH_LAUNCH(k_scan_anchors, 1, 1024, 0, s, rd, r); }

@@ -20,6 +20,8 @@ __global__ __launch_bounds__(64) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
 	const int32_t *f = (const int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR);
 	rh_mm128_t *z = rr.raw + base;               // the unsorted anchor copy is dead after the anchor sort
+	uint32_t *t4 = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)16 * n);   // backtrack's "touched" marks (1 B per anchor)
+	for (int32_t i = (int32_t)lane; i < (n + 3) / 4; i += 64) t4[i] = 0u;
 	uint32_t nz = 0;
 	for (int32_t i0 = 0; i0 < n; i0 += 64) {
 		const int32_t i = i0 + (int32_t)lane;
@@ -34,16 +36,21 @@ __global__ __launch_bounds__(64) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 
 // ------------------------------------------------------------------------------------------------ backtrack
 #ifndef BK_CAP
-#define BK_CAP  5120     // anchors of a read whose f/p/t/candidates fit the LDS copy
+#define BK_CAP  4096     // anchors of a read whose f/p/t/candidates fit the first LDS class (2x for the second)
+#endif
+#ifndef BK_CAP2
+#define BK_CAP2 6656     // second LDS class (two workgroups per CU)
 #endif
 #ifndef BK_UCAP
-#define BK_UCAP 1024     // chains whose bookkeeping fits LDS
+#define BK_UCAP 1536     // chains whose bookkeeping fits LDS
 #endif
 
 // Walks every candidate from the best score down, emitting chains (lchain.c:148-170).  F/P/T/ZI are LDS or HBM views.
 // Returns n_u; *n_v_out = anchors in chains; v[] = chain members in backtrack order; u[] = score << 32 | count.
-template <class PT>
-RH_DEV int32_t backtrack_walk(const int32_t *F, const PT *P, uint8_t *T, const PT *ZI, int32_t n_z, int32_t min_sc, int32_t min_cnt, int32_t max_drop,
+struct zi_from_records { const rh_mm128_t *z; __device__ int32_t operator[](int32_t k) const { return (int32_t)z[k].y; } };
+
+template <class PT, class ZT>
+RH_DEV int32_t backtrack_walk(const int32_t *F, const PT *P, uint8_t *T, const ZT ZI, int32_t n_z, int32_t min_sc, int32_t min_cnt, int32_t max_drop,
                               int32_t *v, uint64_t *u, uint32_t *ck0, uint32_t *cn, int32_t *n_v_out)
 {
 	const PT NONE = (PT)~(PT)0;
@@ -75,25 +82,28 @@ RH_DEV int32_t backtrack_walk(const int32_t *F, const PT *P, uint8_t *T, const P
 	return n_u;
 }
 
-static_assert(BK_UCAP * 16 <= BK_CAP * 4 && BK_UCAP * 4 <= BK_CAP * 2 && (BK_UCAP <= 64 || BK_CAP * 2 >= 2048), "LDS aliasing of the chain-order sort");
-
+template <int CAP>
 struct bk_lds {
-	int32_t f[BK_CAP];
-	uint16_t p[BK_CAP], zi[BK_CAP];
-	uint8_t t[BK_CAP];
+	int32_t f[CAP];
+	uint16_t p[CAP], zi[CAP];
+	uint8_t t[CAP];
 	uint32_t ck0[BK_UCAP], cn[BK_UCAP];
 	int32_t n_u, n_v;
 };
 
-__global__ __launch_bounds__(64) void k_backtrack(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, uint32_t n_lo)
+// One workgroup (256 threads) per read.  All threads stage f/p/candidates into LDS and do the gathers/copies; wavefront 0
+// runs the chain walk with uniform control flow (LDS broadcasts), skipping already-claimed candidates 64 at a time.
+template <int CAP>
+__global__ __launch_bounds__(NT) void k_backtrack(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, uint32_t n_lo)
 {
-	__shared__ bk_lds L;
-	const uint32_t a = blockIdx.x, lane = threadIdx.x;
+	__shared__ bk_lds<CAP> L;
+	static_assert(BK_UCAP * 16 <= CAP * 6 && BK_UCAP * 4 <= CAP * 2 && (BK_UCAP <= 64 || BK_UCAP * 4 + 2048 <= CAP * 2), "LDS aliasing of the chain-order sort");
+	const uint32_t a = blockIdx.x, tid = threadIdx.x;
 	if (a >= rr.n_act || rr.skip[a]) return;
 	const uint32_t r = rr.act[a];
 	const uint64_t base = rr.a_off[a];
 	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
-	if (n > BK_CAP || n <= (int32_t)n_lo) return;                // others: k_backtrack_big
+	if (n > CAP || n <= (int32_t)n_lo) return;                   // other size classes / k_backtrack_big
 	const int32_t n_z = (int32_t)rr.n_z[a];
 	rh_mm128_t *an = rr.anc + base;
 	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
@@ -102,22 +112,66 @@ __global__ __launch_bounds__(64) void k_backtrack(rh_dev_opt o, rh_dev_reads rd,
 	uint64_t *u = rr.u + base;
 	rh_mm128_t *pa = rr.prev_out + base;
 	const rh_mm128_t *zs = rr.zs + base;
-	for (int32_t i = (int32_t)lane; i < n; i += 64) { L.f[i] = gf[i]; const int32_t pi = gp[i]; L.p[i] = pi < 0 ? (uint16_t)0xFFFF : (uint16_t)pi; L.t[i] = 0; }
-	for (int32_t i = (int32_t)lane; i < n_z; i += 64) L.zi[i] = (uint16_t)zs[i].y;
+	for (int32_t i = (int32_t)tid; i < n; i += NT) { L.f[i] = gf[i]; const int32_t pi = gp[i]; L.p[i] = pi < 0 ? (uint16_t)0xFFFF : (uint16_t)pi; L.t[i] = 0; }
+	for (int32_t i = (int32_t)tid; i < n_z; i += NT) L.zi[i] = (uint16_t)zs[i].y;
 	__syncthreads();
-	if (lane == 0) { int32_t nv; L.n_u = backtrack_walk<uint16_t>(L.f, L.p, L.t, L.zi, n_z, o.min_sc, o.min_cnt, o.bw, v, u, L.ck0, L.cn, &nv); L.n_v = nv; }
+	if (wave_id() == 0) {
+		const int32_t min_sc = o.min_sc, min_cnt = o.min_cnt, max_drop = o.bw;
+		const uint32_t lane = lane_id();
+		int32_t n_u = 0, n_v = 0;
+		for (int32_t kt = n_z; kt > 0; kt -= 64) {                 // candidates from the best score down (lchain.c:148)
+			const int32_t kl = kt - 1 - (int32_t)lane;
+			uint64_t m = __ballot(kl >= 0 && L.t[L.zi[kl >= 0 ? kl : 0]] == 0);
+			while (m) {
+				const int32_t k = kt - 1 - __builtin_ctzll(m);
+				m &= m - 1;
+				const int32_t i0 = (int32_t)L.zi[k];
+				if (L.t[i0] != 0) continue;                         // claimed by a chain emitted since the ballot
+				const int32_t zx = L.f[i0];
+				int32_t i = i0, end_i = -1, max_i = i0, max_s = 0;
+				do {	// mg_chain_bk_end (lchain.c:47-75)
+					L.t[i] = 2;
+					const uint16_t pi = L.p[i];
+					end_i = i = pi == 0xFFFF ? -1 : (int32_t)pi;
+					const int32_t s = i < 0 ? zx : zx - L.f[i];
+					if (s > max_s) { max_s = s; max_i = i; }
+					else if (max_s - s > max_drop) break;
+				} while (i >= 0 && L.t[i] == 0);
+				for (i = i0; i >= 0 && i != end_i;) { L.t[i] = 0; const uint16_t pi = L.p[i]; i = pi == 0xFFFF ? -1 : (int32_t)pi; }
+				const int32_t stop = max_i, n_v0 = n_v;
+				for (i = i0; i != stop;) { if (lane == 0) v[n_v] = i; ++n_v; L.t[i] = 1; const uint16_t pi = L.p[i]; i = pi == 0xFFFF ? -1 : (int32_t)pi; }
+				const int32_t sc = i < 0 ? zx : zx - L.f[i];
+				if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) {
+					if (lane == 0) {
+						if (n_u < BK_UCAP) { L.ck0[n_u] = (uint32_t)n_v0; L.cn[n_u] = (uint32_t)(n_v - n_v0); }
+						u[n_u] = (uint64_t)(uint32_t)sc << 32 | (uint64_t)(uint32_t)(n_v - n_v0);
+					}
+					++n_u;
+				} else n_v = n_v0;
+			}
+		}
+		if (lane == 0) { L.n_u = n_u; L.n_v = n_v; }
+	}
 	__syncthreads();
 	const int32_t n_u = L.n_u, n_v = L.n_v;
 	if (n_u == 0) {
-		if (lane == 0) { rr.n_u[a] = 0; rr.n_v[a] = 0; rd.n_prev[r] = 0; rd.prev_off[r] = base; }
+		if (tid == 0) { rr.n_u[a] = 0; rr.n_v[a] = 0; rd.n_prev[r] = 0; rd.prev_off[r] = base; }
 		return;
 	}
 	// compact_a: gather every chain, reversed into ascending anchor order -> pa (what the next chunk carries, lchain.c:236-239)
-	{
+	if (n_u <= BK_UCAP) {
+		// one pass over all chained anchors: output slot q belongs to the chain whose [ck0, ck0+cn) contains it
+		for (int32_t q = (int32_t)tid; q < n_v; q += NT) {
+			int32_t lo = 0, hi = n_u;                                // largest chain c with ck0[c] <= q
+			while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if ((int32_t)L.ck0[mid] <= q) lo = mid; else hi = mid; }
+			const int32_t k0 = (int32_t)L.ck0[lo], ni = (int32_t)L.cn[lo], j = q - k0;
+			pa[q] = an[v[k0 + (ni - j - 1)]];
+		}
+	} else {
 		uint32_t k0 = 0;
 		for (int32_t i = 0; i < n_u; ++i) {
-			const uint32_t ni = i < BK_UCAP ? L.cn[i] : (uint32_t)u[i];
-			for (uint32_t j = lane; j < ni; j += 64) pa[k0 + j] = an[v[k0 + (ni - j - 1)]];
+			const uint32_t ni = (uint32_t)u[i];
+			for (uint32_t j = tid; j < ni; j += NT) pa[k0 + j] = an[v[k0 + (ni - j - 1)]];
 			k0 += ni;
 		}
 	}
@@ -125,24 +179,26 @@ __global__ __launch_bounds__(64) void k_backtrack(rh_dev_opt o, rh_dev_reads rd,
 	// chains ordered by the target coordinate of their first anchor (radix_sort_128x on (x, k<<32|i)); LDS regions of the walk are dead
 	if (n_u <= BK_UCAP) {
 		rh_mm128_t *w = (rh_mm128_t*)L.f;
-		uint32_t *cw = (uint32_t*)L.p, *dk = (uint32_t*)L.zi;
-		for (int32_t i = (int32_t)lane; i < n_u; i += 64) { w[i].x = pa[L.ck0[i]].x; w[i].y = (uint64_t)L.ck0[i] << 32 | (uint64_t)(uint32_t)i; }
+		uint32_t *dk = (uint32_t*)L.zi, *cw = dk + BK_UCAP;      // w spans f[] + p[] (contiguous), dk + sort scratch span zi[]
+		for (int32_t i = (int32_t)tid; i < n_u; i += NT) { w[i].x = pa[L.ck0[i]].x; w[i].y = (uint64_t)L.ck0[i] << 32 | (uint64_t)(uint32_t)i; }
 		__syncthreads();
-		if (lane == 0) {
+		if (tid == 0) {
 			rh_radix_sort_128x(w, (uint32_t)n_u, cw);
 			uint32_t k = 0;
 			for (int32_t i = 0; i < n_u; ++i) { dk[i] = k; k += L.cn[(uint32_t)w[i].y]; }
 		}
 		__syncthreads();
-		for (int32_t i = 0; i < n_u; ++i) {
-			const uint32_t j = (uint32_t)w[i].y, src = (uint32_t)(w[i].y >> 32), cnt = L.cn[j], d = dk[i];
-			for (uint32_t m = lane; m < cnt; m += 64) an[d + m] = pa[src + m];
+		for (int32_t q = (int32_t)tid; q < n_v; q += NT) {        // destination slot q -> sorted chain c -> source
+			int32_t lo = 0, hi = n_u;
+			while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if ((int32_t)dk[mid] <= q) lo = mid; else hi = mid; }
+			const uint32_t src = (uint32_t)(w[lo].y >> 32);
+			an[q] = pa[src + ((uint32_t)q - dk[lo])];
 		}
-		uint64_t uu[BK_UCAP / 64];
-		for (int32_t q = 0; q < BK_UCAP / 64; ++q) { const int32_t i = q * 64 + (int32_t)lane; uu[q] = i < n_u ? u[(uint32_t)w[i].y] : 0; }
+		uint64_t uu[(BK_UCAP + NT - 1) / NT];
+		for (int32_t qq = 0; qq < (BK_UCAP + NT - 1) / NT; ++qq) { const int32_t i = qq * NT + (int32_t)tid; uu[qq] = i < n_u ? u[(uint32_t)w[i].y] : 0; }
 		__syncthreads();
-		for (int32_t q = 0; q < BK_UCAP / 64; ++q) { const int32_t i = q * 64 + (int32_t)lane; if (i < n_u) u[i] = uu[q]; }
-	} else if (lane == 0) {	// more chains than the LDS bookkeeping holds: serial tail on HBM scratch
+		for (int32_t qq = 0; qq < (BK_UCAP + NT - 1) / NT; ++qq) { const int32_t i = qq * NT + (int32_t)tid; if (i < n_u) u[i] = uu[qq]; }
+	} else if (tid == 0) {	// more chains than the LDS bookkeeping holds: serial tail on HBM scratch
 		rh_mm128_t *w = (rh_mm128_t*)(wsr + (size_t)16 * n);
 		uint64_t *u2 = (uint64_t*)(w + n_u);
 		int32_t k = 0;
@@ -157,7 +213,7 @@ __global__ __launch_bounds__(64) void k_backtrack(rh_dev_opt o, rh_dev_reads rd,
 		}
 		for (int32_t i = 0; i < n_u; ++i) u[i] = u2[i];
 	}
-	if (lane == 0) {
+	if (tid == 0) {
 		rr.n_u[a] = (uint32_t)n_u; rr.n_v[a] = (uint32_t)n_v;
 		rd.n_prev[r] = (uint32_t)n_v; rd.prev_off[r] = base;
 		atomicAdd((unsigned long long*)&rr.counters[4], (unsigned long long)n_v);
@@ -176,15 +232,14 @@ __global__ void k_backtrack_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, 
 	const int32_t n_z = (int32_t)rr.n_z[a];
 	rh_mm128_t *an = rr.anc + base;
 	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
-	int32_t *f = (int32_t*)wsr, *p = f + n, *v = p + n, *zi = v + n;   // zi: 4n bytes at 12n
-	uint8_t *t = (uint8_t*)(wsr + (size_t)16 * n);
+	int32_t *f = (int32_t*)wsr, *p = f + n, *v = p + n;
+	uint8_t *t = (uint8_t*)(wsr + (size_t)16 * n);                  // zeroed (coalesced) by k_zbuild
 	const rh_mm128_t *zs = rr.zs + base;
 	uint64_t *u = rr.u + base;
 	rh_mm128_t *pa = rr.prev_out + base;
-	for (int32_t i = 0; i < n; ++i) t[i] = 0;
-	for (int32_t i = 0; i < n_z; ++i) zi[i] = (int32_t)zs[i].y;
 	int32_t n_v = 0;
-	const int32_t n_u = backtrack_walk<uint32_t>(f, (const uint32_t*)p, t, (const uint32_t*)zi, n_z, o.min_sc, o.min_cnt, o.bw, v, u, nullptr, nullptr, &n_v);
+	const zi_from_records zi = { zs };
+	const int32_t n_u = backtrack_walk<uint32_t, zi_from_records>(f, (const uint32_t*)p, t, zi, n_z, o.min_sc, o.min_cnt, o.bw, v, u, nullptr, nullptr, &n_v);
 	if (n_u == 0) { rr.n_u[a] = 0; rr.n_v[a] = 0; rd.n_prev[r] = 0; rd.prev_off[r] = base; return; }
 	int32_t k = 0;
 	for (int32_t i = 0; i < n_u; ++i) { const int32_t k0 = k, ni = (int32_t)u[i]; for (int32_t j = 0; j < ni; ++j) pa[k++] = an[v[k0 + (ni - j - 1)]]; }
@@ -644,34 +699,47 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-void rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
+void rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 {
 	if (!r.n_act) return;
 	RH_LAUNCH(k_zbuild, r.n_act, 64, 0, s, o, r);
 	// candidates (score, anchor index) -> reference order; scores are full of ties: exact permutation for every read
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_z, r.raw, r.zs, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 64 };
 	rhk_sort_job(s, jb, true, 0u);
-	// The chain walk is pointer chasing: with many reads in flight one read per lane (HBM arrays) hides the latency best;
-	// the LDS workgroup variant is kept for batches too small to fill the machine with lanes.
-	if (r.n_act >= 4096u) RH_LAUNCH(k_backtrack_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, 0u);
+}
+
+void rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
+{
+	if (!r.n_act) return;
+	// The chain walk is pointer chasing.  Measured on MI355X: with thousands of reads in flight, one read per lane on HBM
+	// arrays (latency hidden by sheer lane count) beats the LDS workgroup variant, whose concurrency is capped by LDS;
+	// the workgroup variant serves small batches.
+	if (r.n_act >= 2048u) RH_LAUNCH(k_backtrack_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, 0u);
 	else {
-		RH_LAUNCH(k_backtrack, r.n_act, 64, 0, s, o, rd, r, 0u);
-		RH_LAUNCH(k_backtrack_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, (uint32_t)BK_CAP);
+		RH_LAUNCH(k_backtrack<BK_CAP>, r.n_act, NT, 0, s, o, rd, r, 0u);
+		RH_LAUNCH(k_backtrack<BK_CAP2>, r.n_act, NT, 0, s, o, rd, r, (uint32_t)BK_CAP);
+		RH_LAUNCH(k_backtrack_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, (uint32_t)BK_CAP2);
 	}
+}
+
+static bool regions_wave_ok(const rh_dev_opt &o) { return o.best_n == 0 && o.pri_ratio > 0.0f && !(o.flag & RH_M_ALL_CHAINS); }
+
+// chain heads + hashed keys of reads with many chains, put into the reference's order (hit.c:111-126)
+void rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
+{
+	if (!r.n_act || !regions_wave_ok(o)) return;
+	RH_LAUNCH(k_regions_prep, r.n_act, 64, 0, s, o, rd, r);
+	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64 };
+	rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL);
 }
 
 void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r, const float *logf_tab)
 {
 	if (!r.n_act) return;
-	const bool wave_ok = o.best_n == 0 && o.pri_ratio > 0.0f && !(o.flag & RH_M_ALL_CHAINS);
+	const bool wave_ok = regions_wave_ok(o);
 	// need_exact[] doubles as "this read still needs the serial region kernel"
 	RH_HIP_VOID(hipMemsetAsync(r.need_exact, wave_ok ? 0 : 1, r.n_act, s));
-	if (wave_ok) {
-		RH_LAUNCH(k_regions_prep, r.n_act, 64, 0, s, o, rd, r);
-		rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64 };
-		rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL);
-		RH_LAUNCH(k_regions_wave, r.n_act, 64, 0, s, o, rd, r, logf_tab);
-	}
+	if (wave_ok) RH_LAUNCH(k_regions_wave, r.n_act, 64, 0, s, o, rd, r, logf_tab);
 	// skip / no-chain bookkeeping for every read + LDS serial core for reads the wave kernel could not take
 	RH_LAUNCH(k_regions, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL, wave_ok ? 1 : 0);
 	RH_LAUNCH(k_regions_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, logf_tab, 0u, (uint32_t)RG_SMALL, 0);

@@ -197,18 +197,26 @@ __global__ void k_sort_big(rh_sort_job jb, uint32_t n_lo)
 #define RH_SORT_CAP2 8192     // ~141 KB of LDS: one workgroup per CU (reads that carry many chained anchors)
 #endif
 
+#ifndef RH_SORT_CAP0
+#define RH_SORT_CAP0 512      // ~12 KB of LDS: candidate / chain-key sorts and short anchor lists
+#endif
+
+template <int CAP>
+static void launch_class(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t lo, uint32_t hi)
+{
+	if (all_exact) RH_LAUNCH(k_sort_block<CAP>, jb.n_seg, NT, 0, s, jb, lo, hi, 2);
+	else {
+		RH_LAUNCH(k_sort_block<CAP>, jb.n_seg, NT, 0, s, jb, lo, hi, 0);
+		RH_LAUNCH(k_sort_block<CAP>, jb.n_seg, NT, 0, s, jb, lo, hi, 1);
+	}
+}
+
 void rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n)
 {
 	if (!jb.n_seg) return;
-	if (all_exact) {
-		RH_LAUNCH(k_sort_block<RH_SORT_CAP1>, jb.n_seg, NT, 0, s, jb, min_n, (uint32_t)RH_SORT_CAP1, 2);
-		RH_LAUNCH(k_sort_block<RH_SORT_CAP2>, jb.n_seg, NT, 0, s, jb, (uint32_t)RH_SORT_CAP1, (uint32_t)RH_SORT_CAP2, 2);
-	} else {
-		RH_LAUNCH(k_sort_block<RH_SORT_CAP1>, jb.n_seg, NT, 0, s, jb, min_n, (uint32_t)RH_SORT_CAP1, 0);
-		RH_LAUNCH(k_sort_block<RH_SORT_CAP1>, jb.n_seg, NT, 0, s, jb, min_n, (uint32_t)RH_SORT_CAP1, 1);
-		RH_LAUNCH(k_sort_block<RH_SORT_CAP2>, jb.n_seg, NT, 0, s, jb, (uint32_t)RH_SORT_CAP1, (uint32_t)RH_SORT_CAP2, 0);
-		RH_LAUNCH(k_sort_block<RH_SORT_CAP2>, jb.n_seg, NT, 0, s, jb, (uint32_t)RH_SORT_CAP1, (uint32_t)RH_SORT_CAP2, 1);
-	}
+	launch_class<RH_SORT_CAP0>(s, jb, all_exact, min_n, (uint32_t)RH_SORT_CAP0);
+	launch_class<RH_SORT_CAP1>(s, jb, all_exact, (uint32_t)RH_SORT_CAP0, (uint32_t)RH_SORT_CAP1);
+	launch_class<RH_SORT_CAP2>(s, jb, all_exact, (uint32_t)RH_SORT_CAP1, (uint32_t)RH_SORT_CAP2);
 	RH_LAUNCH(k_sort_big, (jb.n_seg + 63) / 64, 64, 0, s, jb, (uint32_t)RH_SORT_CAP2);
 }
 

@@ -98,3 +98,30 @@ def test_large_batch_paths(make_workload, gpu_ctx_factory):
     want = w.oracle_paf(n_threads=os.cpu_count() or 8)
     bad = [(g, x) for g, x in zip(got, want) if g != x]
     assert not bad, f"{len(bad)} of {len(want)} PAF lines differ, first: {bad[0]}"
+
+
+def test_large_genome_many_anchors(make_workload, gpu_ctx_factory):
+    """48 Mbp index: ~10 k anchors per chunk, beyond the LDS size classes of sort / backtrack (HBM fallbacks), several targets."""
+    import os
+    w = make_workload(n_reads=96, n_samples=16_000, chrom_len=24_000_000, n_chrom=2, junk=100, noise=100_000, read_seed=41)
+    c = gpu_ctx_factory()
+    c.upload(w.index)
+    recs = c.map_batch(w.opts, w.reads)
+    got = [strip_mt(x) for x in paf_lines(w.index, recs, w.reads.names)]
+    want = w.oracle_paf(n_threads=os.cpu_count() or 8)
+    assert got == want
+    assert c.stats()["n_anchors"] / max(c.stats()["n_chunks"], 1) > 6000
+
+
+def test_sub_batches_give_identical_records(make_workload, product_lib, monkeypatch):
+    """RH_SUB_BATCHES=2: concurrent sub-batches on two streams return exactly the records of the single-stream run."""
+    from rawhash_amd.api import Context
+    w = make_workload(n_reads=6000, n_samples=20_000, chrom_len=1_500_000, n_chrom=1, junk=120, noise=0, read_seed=31)
+    c1 = Context(0, lib=product_lib); c1.upload(w.index)
+    a = c1.map_batch(w.opts, w.reads)
+    c1.close()
+    monkeypatch.setenv("RH_SUB_BATCHES", "2")
+    c2 = Context(0, lib=product_lib); c2.upload(w.index)
+    b = c2.map_batch(w.opts, w.reads)
+    c2.close()
+    assert np.array_equal(a, b)
