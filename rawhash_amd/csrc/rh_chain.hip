@@ -23,7 +23,7 @@
 #endif
 
 // The reference loop (lchain.c:439-505) on one small cluster [b, b + m), entirely in one lane.
-RH_DEV void chain_small_cluster(const rh_mm128_t *an, int32_t *gf, int32_t *gp, int32_t *gv, int32_t b, int32_t m, int32_t max_dist_t, int32_t max_dist_q,
+RH_DEV void chain_small_cluster(const rh_mm128_t *an, int32_t *gfp, int32_t *gv, int32_t b, int32_t m, int32_t max_dist_t, int32_t max_dist_q,
                                 int32_t bw, int32_t max_iter, int32_t max_skip, float pen_gap, float pen_skip)
 {
 	uint32_t xl[CH_SMALL], yl[CH_SMALL];
@@ -57,7 +57,7 @@ RH_DEV void chain_small_cluster(const rh_mm128_t *an, int32_t *gf, int32_t *gp, 
 		v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
 		if (max_ii < 0 || ((uint32_t)(xl[i] - xl[max_ii]) <= D32 && f[max_ii] < f[i])) max_ii = i;
 	}
-	for (int32_t k = 0; k < m; ++k) { gf[b + k] = f[k]; gp[b + k] = p[k] < 0 ? -1 : b + p[k]; gv[b + k] = v[k]; }
+	for (int32_t k = 0; k < m; ++k) { gfp[2 * (b + k)] = f[k]; gfp[2 * (b + k) + 1] = p[k] < 0 ? -1 : b + p[k]; gv[b + k] = v[k]; }
 }
 
 struct chain_lds {
@@ -75,7 +75,8 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
 	if (n == 0) return;
 	const rh_mm128_t *an = rr.anc + base;
-	int32_t *gf = (int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR), *gp = gf + n, *gv = gp + n;
+	// DP output per anchor: {f, p} interleaved (one 8-byte record: the backtrack walk needs both per step), then v[]
+	int32_t *gfp = (int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR), *gv = gfp + 2 * (size_t)n;
 	int32_t max_dist_t = o.max_dist_t, max_dist_q = o.max_dist_q;
 	const int32_t bw = o.bw, max_iter = o.max_iter, max_skip = o.max_skip;
 	if (max_dist_t < bw) max_dist_t = bw;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 		if (i0 + 64 < n) { const uint64_t xn = an[i0 + 64].x; next_tile_start = (xn >> 32) != (x_last >> 32) || xn > x_last + D64; }
 		const bool nstart = (ii + 1 >= n) ? true : (lane < 63 ? ((smask >> (lane + 1)) & 1ull) != 0 : next_tile_start);
 		const bool single = start && nstart;
-		if (inb && single) { const int32_t sp = (int32_t)((y >> 32) & 63); gf[ii] = sp; gp[ii] = -1; gv[ii] = sp; }
+		if (inb && single) { const int32_t sp = (int32_t)((y >> 32) & 63); gfp[2 * ii] = sp; gfp[2 * ii + 1] = -1; gv[ii] = sp; }
 		// small clusters: their start lane runs the plain loop for the whole cluster (all lanes busy on different clusters)
 		int32_t csz = 0;
 		if (inb && start && !single) {
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 				if ((xq >> 32) != (xp >> 32) || xq > xp + D64) break;
 				xp = xq; ++csz;
 			}
-			if (csz <= CH_SMALL) chain_small_cluster(an, gf, gp, gv, ii, csz, max_dist_t, max_dist_q, bw, max_iter, max_skip, o.pen_gap, o.pen_skip);
+			if (csz <= CH_SMALL) chain_small_cluster(an, gfp, gv, ii, csz, max_dist_t, max_dist_q, bw, max_iter, max_skip, o.pen_gap, o.pen_skip);
 		}
 		const uint64_t small_mask = __ballot(csz > 0 && csz <= CH_SMALL);
 		uint64_t mmask = __ballot(inb && !single);                  // members of multi-anchor clusters, walked in order
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 			}
 			if (lane == 0) {
 				const uint32_t sl = (uint32_t)i & (CH_RING - 1);
-				gf[i] = max_f; gp[i] = max_j; gv[i] = vv;
+				gfp[2 * i] = max_f; gfp[2 * i + 1] = max_j; gv[i] = vv;
 				L.xlo[sl] = xi_lo; L.ylo[sl] = yi_lo; L.span[sl] = (uint8_t)span_i; L.f[sl] = max_f; L.p[sl] = max_j; L.v[sl] = vv;
 			}
 			if (max_ii < 0 || ((uint32_t)(xi_lo - xlo_ii) <= D32 && f_ii < max_f)) { max_ii = i; f_ii = max_f; xlo_ii = xi_lo; }
@@ -209,7 +210,9 @@ __global__ void k_chain_serial(rh_dev_opt o, rh_dev_round rr)
 	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
 	if (n == 0) return;
 	const rh_mm128_t *an = rr.anc + base;
-	int32_t *f = (int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR), *p = f + n, *v = p + n, *t = v + n;
+	int32_t *fp = (int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR), *v = fp + 2 * (size_t)n, *t = v + n;   // {f,p} interleaved
+	#define F_(i) fp[2 * (i)]
+	#define P_(i) fp[2 * (i) + 1]
 	int32_t max_dist_t = o.max_dist_t, max_dist_q = o.max_dist_q;
 	const int32_t bw = o.bw;
 	if (max_dist_t < bw) max_dist_t = bw;
@@ -224,25 +227,27 @@ __global__ void k_chain_serial(rh_dev_opt o, rh_dev_round rr)
 		for (j = i - 1; j >= st; --j) {
 			int32_t sc = rh_pair_score(xi, yi, an[j].x, an[j].y, max_dist_t, max_dist_q, bw, o.pen_gap, o.pen_skip);
 			if (sc == RH_SCORE_NONE) continue;
-			sc += f[j];
+			sc += F_(j);
 			if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
 			else if (t[j] == i) { if (++n_skip > o.max_skip) break; }
-			if (p[j] >= 0) t[p[j]] = i;
+			if (P_(j) >= 0) t[P_(j)] = i;
 		}
 		const int32_t end_j = j;
 		if (max_ii < 0 || xi - an[max_ii].x > (uint64_t)(int64_t)max_dist_t) {
 			int32_t mx = INT32_MIN;
 			max_ii = -1;
-			for (j = i - 1; j >= st; --j) if (mx < f[j]) { mx = f[j]; max_ii = j; }
+			for (j = i - 1; j >= st; --j) if (mx < F_(j)) { mx = F_(j); max_ii = j; }
 		}
 		if (max_ii >= 0 && max_ii < end_j) {
 			const int32_t tmp = rh_pair_score(xi, yi, an[max_ii].x, an[max_ii].y, max_dist_t, max_dist_q, bw, o.pen_gap, o.pen_skip);
-			if (tmp != RH_SCORE_NONE && max_f < tmp + f[max_ii]) { max_f = tmp + f[max_ii]; max_j = max_ii; }
+			if (tmp != RH_SCORE_NONE && max_f < tmp + F_(max_ii)) { max_f = tmp + F_(max_ii); max_j = max_ii; }
 		}
-		f[i] = max_f; p[i] = max_j;
+		F_(i) = max_f; P_(i) = max_j;
 		v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
-		if (max_ii < 0 || (xi - an[max_ii].x <= (uint64_t)(int64_t)max_dist_t && f[max_ii] < f[i])) max_ii = i;
+		if (max_ii < 0 || (xi - an[max_ii].x <= (uint64_t)(int64_t)max_dist_t && F_(max_ii) < F_(i))) max_ii = i;
 	}
+	#undef F_
+	#undef P_
 }
 
 void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)

@@ -303,6 +303,8 @@ __global__ __launch_bounds__(NT) void k_probe(rh_dev_opt o, rh_dev_index ix, rh_
 {
 	__shared__ uint32_t s_n[RH_EV_CAP];
 	__shared__ uint64_t s_val[RH_EV_CAP];
+	__shared__ uint32_t s_flt[RH_EV_CAP];       // over-frequent seeds: q_pos | q_span << 26
+	__shared__ uint32_t s_w[NT / 64];
 	const uint32_t a = blockIdx.x, tid = threadIdx.x;
 	if (a >= rr.n_act) return;
 	const uint32_t ns = rr.skip[a] ? 0u : rr.n_seed[a];
@@ -323,28 +325,41 @@ __global__ __launch_bounds__(NT) void k_probe(rh_dev_opt o, rh_dev_index ix, rh_
 		}
 	}
 	__syncthreads();
-	if (tid == 0) {
-		uint64_t *m_val = rr.m_val + (size_t)a * RH_EV_CAP;
-		uint32_t *m_n = rr.m_n + (size_t)a * RH_EV_CAP, *m_meta = rr.m_meta + (size_t)a * RH_EV_CAP, *m_pref = rr.m_pref + (size_t)a * (RH_EV_CAP + 1);
-		uint32_t nm = 0, pref = 0;
-		int32_t rep_st = 0, rep_en = 0, rep_len = 0;
-		uint64_t hprev = 0, hcur = ns ? sx[0] >> 6 : 0, hnext;
-		for (uint32_t i = 0; i < ns; ++i) {
-			hnext = i + 1 < ns ? sx[i + 1] >> 6 : 0;
-			const uint32_t cnt = s_n[i];
+	// Bookkeeping of ri_collect_matches (rseed.c:105-154), order preserving and parallel: tandem flag from the neighbouring
+	// hashes, mid_occ filter, compaction of the kept matches with the running prefix of their occurrence counts; only the
+	// interval merge of the (few) over-frequent seeds is left to one lane.
+	uint64_t *m_val = rr.m_val + (size_t)a * RH_EV_CAP;
+	uint32_t *m_n = rr.m_n + (size_t)a * RH_EV_CAP, *m_meta = rr.m_meta + (size_t)a * RH_EV_CAP, *m_pref = rr.m_pref + (size_t)a * (RH_EV_CAP + 1);
+	uint32_t nm = 0, pref = 0, n_flt = 0;
+	for (uint32_t base = 0; base < ns; base += NT) {
+		const uint32_t i = base + tid;
+		bool kept = false, flt = false;
+		uint32_t cnt = 0, q_pos = 0, tandem = 0;
+		if (i < ns) {
+			cnt = s_n[i];
 			if (cnt != 0) {
-				const uint32_t q_pos = (uint32_t)sy[i], q_span = (uint32_t)(sx[i] & 63u);
-				const uint32_t tandem = ((i > 0 && hcur == hprev) || (i + 1 < ns && hcur == hnext)) ? 1u : 0u;
-				if (cnt > (uint32_t)o.mid_occ) {
-					const int32_t st = (int32_t)(q_pos >> 1) + 1, en = st + (int32_t)q_span + 1;
-					if (st > rep_en) { rep_len += rep_en - rep_st; rep_st = st; rep_en = en; }
-					else rep_en = en;
-				} else {
-					m_val[nm] = s_val[i]; m_n[nm] = cnt; m_meta[nm] = (q_pos >> 1) | (tandem << 31); m_pref[nm] = pref;
-					pref += cnt; ++nm;
-				}
+				const uint64_t h = sx[i] >> 6;
+				q_pos = (uint32_t)sy[i];
+				tandem = ((i > 0 && (sx[i - 1] >> 6) == h) || (i + 1 < ns && (sx[i + 1] >> 6) == h)) ? 1u : 0u;
+				flt = cnt > (uint32_t)o.mid_occ;
+				kept = !flt;
 			}
-			hprev = hcur; hcur = hnext;
+		}
+		uint32_t tot_k, tot_c, tot_f;
+		const uint32_t rk = block_rank(kept, s_w, tot_k);
+		const uint32_t pc = block_excl_scan(kept ? cnt : 0u, s_w, tot_c);
+		const uint32_t rf = block_rank(flt, s_w, tot_f);
+		if (kept) { m_val[nm + rk] = s_val[i]; m_n[nm + rk] = cnt; m_meta[nm + rk] = (q_pos >> 1) | (tandem << 31); m_pref[nm + rk] = pref + pc; }
+		if (flt && n_flt + rf < RH_EV_CAP) s_flt[n_flt + rf] = (q_pos >> 1) | ((uint32_t)(sx[i] & 63u) << 26);
+		nm += tot_k; pref += tot_c; n_flt += tot_f;
+	}
+	__syncthreads();
+	if (tid == 0) {
+		int32_t rep_st = 0, rep_en = 0, rep_len = 0;
+		for (uint32_t k = 0; k < n_flt; ++k) {
+			const int32_t st = (int32_t)(s_flt[k] & 0x3FFFFFFu) + 1, en = st + (int32_t)(s_flt[k] >> 26) + 1;
+			if (st > rep_en) { rep_len += rep_en - rep_st; rep_st = st; rep_en = en; }
+			else rep_en = en;
 		}
 		rep_len += rep_en - rep_st;
 		m_pref[nm] = pref;

@@ -18,14 +18,14 @@ __global__ __launch_bounds__(64) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 	if (rr.skip[a]) { if (lane == 0) rr.n_z[a] = 0; return; }
 	const uint64_t base = rr.a_off[a];
 	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
-	const int32_t *f = (const int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR);
+	const int32_t *fp = (const int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR);   // {f, p} interleaved
 	rh_mm128_t *z = rr.raw + base;               // the unsorted anchor copy is dead after the anchor sort
 	uint32_t *t4 = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)16 * n);   // backtrack's "touched" marks (1 B per anchor)
 	for (int32_t i = (int32_t)lane; i < (n + 3) / 4; i += 64) t4[i] = 0u;
 	uint32_t nz = 0;
 	for (int32_t i0 = 0; i0 < n; i0 += 64) {
 		const int32_t i = i0 + (int32_t)lane;
-		const int32_t fi = i < n ? f[i] : INT32_MIN;
+		const int32_t fi = i < n ? fp[2 * i] : INT32_MIN;
 		const bool ok = i < n && fi >= o.min_sc;
 		const uint64_t m = __ballot(ok);
 		if (ok) { rh_mm128_t e; e.x = (uint64_t)(int64_t)fi; e.y = (uint64_t)(uint32_t)i; z[nz + lanes_below(m)] = e; }
@@ -40,6 +40,9 @@ __global__ __launch_bounds__(64) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 #endif
 #ifndef BK_CAP2
 #define BK_CAP2 6656     // second LDS class (two workgroups per CU)
+#endif
+#ifndef RH_BK_LANE_MIN
+#define RH_BK_LANE_MIN 2048u   // active reads from which the walk runs one read per lane
 #endif
 #ifndef BK_UCAP
 #define BK_UCAP 1536     // chains whose bookkeeping fits LDS
@@ -107,12 +110,12 @@ __global__ __launch_bounds__(NT) void k_backtrack(rh_dev_opt o, rh_dev_reads rd,
 	const int32_t n_z = (int32_t)rr.n_z[a];
 	rh_mm128_t *an = rr.anc + base;
 	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
-	const int32_t *gf = (const int32_t*)wsr, *gp = gf + n;
+	const int32_t *gfp = (const int32_t*)wsr;                    // {f, p} interleaved
 	int32_t *v = (int32_t*)wsr + 2 * (size_t)n;                  // DP's v[] is dead: reused for the chain members
 	uint64_t *u = rr.u + base;
 	rh_mm128_t *pa = rr.prev_out + base;
 	const rh_mm128_t *zs = rr.zs + base;
-	for (int32_t i = (int32_t)tid; i < n; i += NT) { L.f[i] = gf[i]; const int32_t pi = gp[i]; L.p[i] = pi < 0 ? (uint16_t)0xFFFF : (uint16_t)pi; L.t[i] = 0; }
+	for (int32_t i = (int32_t)tid; i < n; i += NT) { L.f[i] = gfp[2 * i]; const int32_t pi = gfp[2 * i + 1]; L.p[i] = pi < 0 ? (uint16_t)0xFFFF : (uint16_t)pi; L.t[i] = 0; }
 	for (int32_t i = (int32_t)tid; i < n_z; i += NT) L.zi[i] = (uint16_t)zs[i].y;
 	__syncthreads();
 	if (wave_id() == 0) {
@@ -220,11 +223,15 @@ __global__ __launch_bounds__(NT) void k_backtrack(rh_dev_opt o, rh_dev_reads rd,
 	}
 }
 
-// reads with more than BK_CAP anchors: the same walk on HBM arrays, one read per lane
-__global__ void k_backtrack_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, uint32_t n_lo)
+// One read per lane on HBM arrays (large batches, and reads too big for the LDS classes).  The walk is pointer chasing;
+// per step it needs f and p of one anchor -> the DP stores them as one 8-byte record, and the "touched" byte is loaded
+// alongside, so a step costs one memory round trip.  Candidates are examined four at a time (independent loads), and the
+// reset + emit passes of the reference (lchain.c:69, :160) are merged into one pass over the visited prefix.
+__global__ void k_backtrack_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, uint32_t n_lo, int walk_only)
 {
 	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-	if (a >= rr.n_act || rr.skip[a]) return;
+	if (a >= rr.n_act) return;
+	if (rr.skip[a]) { if (walk_only) { rr.n_u[a] = 0; rr.n_v[a] = 0; } return; }
 	const uint32_t r = rr.act[a];
 	const uint64_t base = rr.a_off[a];
 	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
@@ -232,15 +239,50 @@ __global__ void k_backtrack_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, 
 	const int32_t n_z = (int32_t)rr.n_z[a];
 	rh_mm128_t *an = rr.anc + base;
 	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
-	int32_t *f = (int32_t*)wsr, *p = f + n, *v = p + n;
+	const int2 *fp = (const int2*)wsr;                              // .x = f, .y = p
+	int32_t *v = (int32_t*)wsr + 2 * (size_t)n;
 	uint8_t *t = (uint8_t*)(wsr + (size_t)16 * n);                  // zeroed (coalesced) by k_zbuild
 	const rh_mm128_t *zs = rr.zs + base;
 	uint64_t *u = rr.u + base;
 	rh_mm128_t *pa = rr.prev_out + base;
-	int32_t n_v = 0;
-	const zi_from_records zi = { zs };
-	const int32_t n_u = backtrack_walk<uint32_t, zi_from_records>(f, (const uint32_t*)p, t, zi, n_z, o.min_sc, o.min_cnt, o.bw, v, u, nullptr, nullptr, &n_v);
+	const int32_t min_sc = o.min_sc, min_cnt = o.min_cnt, max_drop = o.bw;
+	int32_t n_u = 0, n_v = 0;
+	for (int32_t k = n_z - 1; k >= 0;) {
+		// four candidates per trip: indices, then their marks (independent loads)
+		int32_t ci[4]; uint8_t ct[4];
+		const int32_t nb = k >= 3 ? 4 : k + 1;
+		for (int32_t q = 0; q < nb; ++q) ci[q] = (int32_t)zs[k - q].y;
+		for (int32_t q = 0; q < nb; ++q) ct[q] = t[ci[q]];
+		bool emitted = false;
+		for (int32_t q = 0; q < nb; ++q) {
+			const int32_t i0 = ci[q];
+			if (emitted ? t[i0] != 0 : ct[q] != 0) continue;          // marks may have changed once a chain was emitted
+			int2 rec = fp[i0];
+			const int32_t zx = rec.x;
+			// mg_chain_bk_end: extend back until a touched anchor, the start, or a score drop > max_drop
+			int32_t i = i0, max_i = i0, max_s = 0;                     // (the transient mark 2 of the reference is unobservable: p decreases)
+			for (;;) {
+				i = rec.y;
+				int32_t s = zx;
+				uint8_t ti = 0;
+				if (i >= 0) { rec = fp[i]; ti = t[i]; s = zx - rec.x; }
+				if (s > max_s) { max_s = s; max_i = i; }
+				else if (max_s - s > max_drop) break;
+				if (i < 0 || ti != 0) break;
+			}
+			// anchors i0 .. (exclusive) max_i form the chain; the rest of the visited prefix keeps mark 0
+			const int32_t n_v0 = n_v;
+			rec = fp[i0];
+			for (i = i0; i != max_i; ) { v[n_v++] = i; t[i] = 1; i = rec.y; if (i >= 0 && i != max_i) rec = fp[i]; }
+			const int32_t sc = i < 0 ? zx : zx - fp[i].x;
+			if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint64_t)(uint32_t)(n_v - n_v0);
+			else n_v = n_v0;                                        // the marks stay, as in the reference
+			emitted = true;
+		}
+		k -= nb;
+	}
 	if (n_u == 0) { rr.n_u[a] = 0; rr.n_v[a] = 0; rd.n_prev[r] = 0; rd.prev_off[r] = base; return; }
+	if (walk_only) { rr.n_u[a] = (uint32_t)n_u; rr.n_v[a] = (uint32_t)n_v; return; }   // compact_a runs as workgroup kernels
 	int32_t k = 0;
 	for (int32_t i = 0; i < n_u; ++i) { const int32_t k0 = k, ni = (int32_t)u[i]; for (int32_t j = 0; j < ni; ++j) pa[k++] = an[v[k0 + (ni - j - 1)]]; }
 	rh_mm128_t *w = (rh_mm128_t*)(wsr + (size_t)32 * n);
@@ -259,6 +301,84 @@ __global__ void k_backtrack_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, 
 	rr.n_u[a] = (uint32_t)n_u; rr.n_v[a] = (uint32_t)n_v;
 	rd.n_prev[r] = (uint32_t)n_v; rd.prev_off[r] = base;
 	atomicAdd((unsigned long long*)&rr.counters[4], (unsigned long long)n_v);
+}
+
+// compact_a (lchain.c:214-281) as two workgroup kernels around the block sorter, for the one-read-per-lane walk:
+//   k_chain_gather : chain start offsets (scan of the counts), chain members reversed into ascending order -> pa (= what the
+//                    next chunk carries), sort keys (first-anchor x, start << 32 | chain) -> rr.raw
+//   [rhk_sort_job  : chains into the reference's order of their first anchor]
+//   k_chain_reorder: destination offsets (scan in sorted order), chains copied back over the anchor slice, u[] permuted
+__global__ __launch_bounds__(NT) void k_chain_gather(rh_dev_round rr)
+{
+	__shared__ uint32_t s_w[NT / 64];
+	const uint32_t a = blockIdx.x, tid = threadIdx.x;
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const uint32_t n_u = rr.n_u[a], n_v = rr.n_v[a];
+	if (n_u == 0) return;
+	const uint64_t base = rr.a_off[a];
+	const uint32_t n = (uint32_t)(rr.a_off[a + 1] - base);
+	const rh_mm128_t *an = rr.anc + base;
+	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
+	const int32_t *v = (const int32_t*)wsr + 2 * (size_t)n;
+	uint32_t *ck0 = (uint32_t*)(wsr + (size_t)32 * n);               // n_u <= n start offsets
+	const uint64_t *u = rr.u + base;
+	rh_mm128_t *pa = rr.prev_out + base, *w = rr.raw + base;
+	uint32_t run = 0;
+	for (uint32_t i0 = 0; i0 < n_u; i0 += NT) {
+		const uint32_t i = i0 + tid, cnt = i < n_u ? (uint32_t)u[i] : 0u;
+		uint32_t tot;
+		const uint32_t ex = block_excl_scan(cnt, s_w, tot);
+		if (i < n_u) ck0[i] = run + ex;
+		run += tot;
+	}
+	__syncthreads();
+	for (uint32_t q = tid; q < n_v; q += NT) {
+		uint32_t lo = 0, hi = n_u;                                   // chain whose [ck0, ck0 + cnt) holds slot q
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ck0[mid] <= q) lo = mid; else hi = mid; }
+		const uint32_t k0 = ck0[lo], ni = (uint32_t)u[lo];
+		pa[q] = an[v[k0 + (ni - (q - k0) - 1)]];
+	}
+	__syncthreads();
+	for (uint32_t i = tid; i < n_u; i += NT) { rh_mm128_t e; e.x = pa[ck0[i]].x; e.y = (uint64_t)ck0[i] << 32 | (uint64_t)i; w[i] = e; }
+}
+
+__global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_round rr)
+{
+	__shared__ uint32_t s_w[NT / 64];
+	const uint32_t a = blockIdx.x, tid = threadIdx.x;
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const uint32_t r = rr.act[a];
+	const uint64_t base = rr.a_off[a];
+	const uint32_t n_u = rr.n_u[a], n_v = rr.n_v[a];
+	if (n_u == 0) { if (tid == 0) { rd.n_prev[r] = 0; rd.prev_off[r] = base; } return; }
+	const uint32_t n = (uint32_t)(rr.a_off[a + 1] - base);
+	rh_mm128_t *an = rr.anc + base;
+	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
+	uint32_t *dk = (uint32_t*)(wsr + (size_t)36 * n);                // destination offsets in sorted order
+	uint64_t *u2 = (uint64_t*)(wsr + (size_t)40 * n);
+	uint64_t *u = rr.u + base;
+	const rh_mm128_t *pa = rr.prev_out + base, *w = rr.zs + base;   // w: sorted keys
+	uint32_t run = 0;
+	for (uint32_t i0 = 0; i0 < n_u; i0 += NT) {
+		const uint32_t i = i0 + tid;
+		uint64_t ui = 0;
+		if (i < n_u) { ui = u[(uint32_t)w[i].y]; u2[i] = ui; }
+		uint32_t tot;
+		const uint32_t ex = block_excl_scan((uint32_t)ui, s_w, tot);
+		if (i < n_u) dk[i] = run + ex;
+		run += tot;
+	}
+	__syncthreads();
+	for (uint32_t q = tid; q < n_v; q += NT) {
+		uint32_t lo = 0, hi = n_u;
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (dk[mid] <= q) lo = mid; else hi = mid; }
+		an[q] = pa[(uint32_t)(w[lo].y >> 32) + (q - dk[lo])];
+	}
+	for (uint32_t i = tid; i < n_u; i += NT) u[i] = u2[i];
+	if (tid == 0) {
+		rd.n_prev[r] = n_v; rd.prev_off[r] = base;
+		atomicAdd((unsigned long long*)&rr.counters[4], (unsigned long long)n_v);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------ regions
@@ -440,7 +560,10 @@ RH_DEV void regions_commit(const rh_dev_opt &o, const rh_dev_reads &rd, const rh
 #define RG_SMALL 8      // up to this many chains: one read per lane
 #endif
 #ifndef RGW_CAP
-#define RGW_CAP 1536   // chains the wave-cooperative kernel holds in LDS
+#define RGW_CAP 1536   // chains the wave-cooperative kernel holds in LDS (large class)
+#endif
+#ifndef RGW_CAP0
+#define RGW_CAP0 256   // ... small class
 #endif
 
 struct rg_lds {
@@ -558,32 +681,42 @@ __global__ __launch_bounds__(64) void k_regions_prep(rh_dev_opt o, rh_dev_reads 
 	}
 }
 
+template <int CAP>
 struct rgw_lds {
-	int32_t qs[RGW_CAP], qe[RGW_CAP], score[RGW_CAP], cnt[RGW_CAP], parent[RGW_CAP], subsc[RGW_CAP], nsub[RGW_CAP];
-	uint16_t w[RGW_CAP];
-	uint64_t cov[RGW_COV];
-	uint16_t covj[RGW_COV];
+	int32_t qs[CAP], qe[CAP];                    // per region (sorted order): query interval
+	uint32_t sc[CAP];                            // per region: score | cnt << 20
+	int32_t pqs[CAP], pqe[CAP], psub[CAP], pns[CAP];   // per primary (dense, list order): interval, subsc, n_sub
+	uint16_t w[CAP];                             // per primary: region index
+	uint64_t cov[RGW_COV < CAP ? RGW_COV : CAP];
+	uint16_t covj[RGW_COV < CAP ? RGW_COV : CAP];
 	int32_t bc[4];
 };
 
-__global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, const float *logf_tab)
+// size classes: (n_lo, CAP] chains per read; the small class keeps many reads per CU in flight
+template <int CAP>
+__global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, const float *logf_tab, uint32_t n_lo)
 {
-	__shared__ rgw_lds L;
+	__shared__ rgw_lds<CAP> L;
+	constexpr int RGW_COVC = RGW_COV < CAP ? RGW_COV : CAP;
 	const uint32_t a = blockIdx.x, lane = threadIdx.x;
 	if (a >= rr.n_act || rr.skip[a]) return;
 	const int32_t n_u = (int32_t)rr.n_u[a];
-	if (n_u <= RG_SMALL || n_u > RGW_CAP) return;
+	if (n_u <= (int32_t)n_lo || n_u > CAP) return;
 	const uint32_t r = rr.act[a];
 	const uint64_t base = rr.a_off[a];
 	const rh_chain_head *heads = (const rh_chain_head*)(rr.ws + base * RH_WS_PER_ANCHOR);
 	const rh_mm128_t *zs = rr.zs + base;                             // keys in radix_sort_128x order (ascending)
+	bool unfit = false;
 	for (int32_t i = (int32_t)lane; i < n_u; i += 64) {
 		const rh_mm128_t zi = zs[n_u - 1 - i];                      // descending: larger score first (hit.c:124-126)
 		const rh_chain_head h = heads[(uint32_t)zi.y];
-		L.score[i] = (int32_t)(zi.x >> 32); L.cnt[i] = h.cnt; L.qs[i] = (int32_t)h.y0; L.qe[i] = h.y1 + 1;
-		L.parent[i] = -1; L.subsc[i] = 0; L.nsub[i] = 0;
+		const uint32_t score = (uint32_t)(zi.x >> 32);
+		if (score >= (1u << 20) || (uint32_t)h.cnt >= (1u << 12)) unfit = true;
+		L.sc[i] = score | (uint32_t)h.cnt << 20; L.qs[i] = (int32_t)h.y0; L.qe[i] = h.y1 + 1;
 	}
-	if (lane == 0) { L.w[0] = 0; L.parent[0] = 0; L.bc[3] = 0; }
+	if (__ballot(unfit)) { if (lane == 0) rr.need_exact[a] = 1; return; }   // does not fit the packed layout: serial kernel
+	__syncthreads();
+	if (lane == 0) { L.w[0] = 0; L.pqs[0] = L.qs[0]; L.pqe[0] = L.qe[0]; L.psub[0] = 0; L.pns[0] = 0; }
 	__syncthreads();
 	const bool hard = (o.flag & RH_M_HARD_MLEVEL) != 0;
 	int32_t kk = 1;
@@ -595,18 +728,18 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 		for (int32_t j0 = 0; j0 < kk; j0 += 64) {
 			const int32_t j = j0 + (int32_t)lane;
 			bool ov = false; int32_t sj = 0, ej = 0;
-			if (j < kk) { const uint32_t rp = L.w[j]; sj = L.qs[rp]; ej = L.qe[rp]; ov = !(ej <= si || sj >= ei); }
+			if (j < kk) { sj = L.pqs[j]; ej = L.pqe[j]; ov = !(ej <= si || sj >= ei); }
 			const uint64_t m = __ballot(ov);
 			if (ov) {
 				const int32_t c = n_cov + (int32_t)lanes_below(m);
-				if (c < RGW_COV) { L.cov[c] = (uint64_t)(uint32_t)(sj < si ? si : sj) << 32 | (uint64_t)(uint32_t)(ej > ei ? ei : ej); L.covj[c] = (uint16_t)j; }
+				if (c < RGW_COVC) { L.cov[c] = (uint64_t)(uint32_t)(sj < si ? si : sj) << 32 | (uint64_t)(uint32_t)(ej > ei ? ei : ej); L.covj[c] = (uint16_t)j; }
 			}
 			n_cov += (int32_t)__popcll(m);
 		}
-		if (n_cov > RGW_COV) { overflow = true; break; }
-		__syncthreads();
+		if (n_cov > RGW_COVC) { overflow = true; break; }
 		int32_t sel = -1, uncov = 0;
 		if (n_cov > 0) {
+			__syncthreads();
 			if (!hard) {	// length of [si, ei) not covered by the overlapping primaries
 				if (lane == 0) {
 					for (int32_t x1 = 1; x1 < n_cov; ++x1) { const uint64_t cv = L.cov[x1]; int32_t y1 = x1; while (y1 > 0 && L.cov[y1 - 1] > cv) { L.cov[y1] = L.cov[y1 - 1]; --y1; } L.cov[y1] = cv; }
@@ -623,8 +756,8 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 				const int32_t c = c0 + (int32_t)lane;
 				bool hit = false;
 				if (c < n_cov) {
-					const uint32_t rp = L.w[L.covj[c]];
-					const int32_t sj = L.qs[rp], ej = L.qe[rp];
+					const uint32_t j = L.covj[c];
+					const int32_t sj = L.pqs[j], ej = L.pqe[j];
 					const int32_t mn = ej - sj < ei - si ? ej - sj : ei - si;
 					const int32_t mx = ej - sj > ei - si ? ej - sj : ei - si;
 					const int32_t ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj) : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
@@ -636,12 +769,10 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 		}
 		if (lane == 0) {
 			if (sel >= 0) {
-				const uint32_t rp = L.w[sel];
-				const int32_t sci = L.score[i];
-				L.parent[i] = L.parent[rp];
-				if (L.subsc[rp] < sci) L.subsc[rp] = sci;
-				if (L.cnt[i] >= L.cnt[rp]) ++L.nsub[rp];
-			} else { L.w[kk] = (uint16_t)i; L.parent[i] = i; L.nsub[i] = 0; }
+				const int32_t sci = (int32_t)(L.sc[i] & 0xFFFFFu);
+				if (L.psub[sel] < sci) L.psub[sel] = sci;
+				if ((L.sc[i] >> 20) >= (L.sc[L.w[sel]] >> 20)) ++L.pns[sel];
+			} else { L.w[kk] = (uint16_t)i; L.pqs[kk] = si; L.pqe[kk] = ei; L.psub[kk] = 0; L.pns[kk] = 0; }
 		}
 		if (sel < 0) ++kk;
 		__syncthreads();
@@ -650,7 +781,7 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 	// secondaries dropped (mm_select_sub with best_n = 0): the kept regions are exactly the primaries, in order
 	const int32_t n_regs = kk;
 	int64_t sum_sc = 0;
-	for (int32_t k0 = 0; k0 < n_regs; k0 += 64) { const int32_t k = k0 + (int32_t)lane; int32_t v = k < n_regs ? L.score[L.w[k]] : 0; for (int d = 32; d > 0; d >>= 1) v += (int32_t)__shfl_xor((uint32_t)v, d); sum_sc += v; }
+	for (int32_t k0 = 0; k0 < n_regs; k0 += 64) { const int32_t k = k0 + (int32_t)lane; int32_t v = k < n_regs ? (int32_t)(L.sc[L.w[k]] & 0xFFFFFu) : 0; for (int d = 32; d > 0; d >>= 1) v += (int32_t)__shfl_xor((uint32_t)v, d); sum_sc += v; }
 	const float uniq_ratio = (float)sum_sc / (float)(sum_sc + rr.rep_len[a]);
 	int64_t sumQ = 0;
 	int32_t mapq0 = 0;
@@ -658,15 +789,15 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 		const int32_t k = k0 + (int32_t)lane;
 		int32_t mq = 0;
 		if (k < n_regs) {
-			const uint32_t i = L.w[k];
-			const int32_t sc = L.score[i], cn = L.cnt[i];
+			const uint32_t pk = L.sc[L.w[k]];
+			const int32_t sc = (int32_t)(pk & 0xFFFFFu), cn = (int32_t)(pk >> 20);
 			const float pen_s1 = (float)((sc > 100 ? 1.0 : 0.01 * (double)sc) * (double)uniq_ratio);
 			float pen_cm = cn > 10 ? 1.0f : 0.1f * (float)cn;
 			pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
-			const int32_t subsc = L.subsc[i] > o.min_sc ? L.subsc[i] : o.min_sc;
+			const int32_t subsc = L.psub[k] > o.min_sc ? L.psub[k] : o.min_sc;
 			const float x = (float)subsc / (float)sc;
 			mq = (int32_t)(pen_cm * 40.0f * (1.0f - x) * logf_int(sc, logf_tab));
-			mq -= (int32_t)(4.343f * logf_int(L.nsub[i] + 1, logf_tab) + .499f);
+			mq -= (int32_t)(4.343f * logf_int(L.pns[k] + 1, logf_tab) + .499f);
 			mq = mq > 0 ? mq : 0;
 			mq = mq < 60 ? mq : 60;
 		}
@@ -677,7 +808,7 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 	}
 	if (lane == 0) {
 		int stop = 0;
-		const int32_t score0 = L.score[0];
+		const int32_t score0 = (int32_t)(L.sc[0] & 0xFFFFFu);
 		if (n_regs == 1 && mapq0 >= o.min_mapq) stop = 1;
 		else {
 			float meanC = (float)sum_sc, meanQ = (float)sumQ;        // sums of small integers: exact in fp32 in any order
@@ -714,11 +845,16 @@ void rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, c
 	// The chain walk is pointer chasing.  Measured on MI355X: with thousands of reads in flight, one read per lane on HBM
 	// arrays (latency hidden by sheer lane count) beats the LDS workgroup variant, whose concurrency is capped by LDS;
 	// the workgroup variant serves small batches.
-	if (r.n_act >= 2048u) RH_LAUNCH(k_backtrack_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, 0u);
-	else {
+	if (r.n_act >= RH_BK_LANE_MIN) {
+		RH_LAUNCH(k_backtrack_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, 0u, 1);
+		RH_LAUNCH(k_chain_gather, r.n_act, NT, 0, s, r);
+		rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64 };
+		rhk_sort_job(s, jb, false, 0u);
+		RH_LAUNCH(k_chain_reorder, r.n_act, NT, 0, s, rd, r);
+	} else {
 		RH_LAUNCH(k_backtrack<BK_CAP>, r.n_act, NT, 0, s, o, rd, r, 0u);
 		RH_LAUNCH(k_backtrack<BK_CAP2>, r.n_act, NT, 0, s, o, rd, r, (uint32_t)BK_CAP);
-		RH_LAUNCH(k_backtrack_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, (uint32_t)BK_CAP2);
+		RH_LAUNCH(k_backtrack_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, (uint32_t)BK_CAP2, 0);
 	}
 }
 
@@ -739,7 +875,10 @@ void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, con
 	const bool wave_ok = regions_wave_ok(o);
 	// need_exact[] doubles as "this read still needs the serial region kernel"
 	RH_HIP_VOID(hipMemsetAsync(r.need_exact, wave_ok ? 0 : 1, r.n_act, s));
-	if (wave_ok) RH_LAUNCH(k_regions_wave, r.n_act, 64, 0, s, o, rd, r, logf_tab);
+	if (wave_ok) {
+		RH_LAUNCH(k_regions_wave<RGW_CAP0>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL);
+		RH_LAUNCH(k_regions_wave<RGW_CAP>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RGW_CAP0);
+	}
 	// skip / no-chain bookkeeping for every read + LDS serial core for reads the wave kernel could not take
 	RH_LAUNCH(k_regions, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL, wave_ok ? 1 : 0);
 	RH_LAUNCH(k_regions_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, logf_tab, 0u, (uint32_t)RG_SMALL, 0);

@@ -154,17 +154,24 @@ __global__ __launch_bounds__(NT) void k_sort_block(rh_sort_job jb, uint32_t n_lo
 		if (tid == 0) L.n_rng[cur] = 0;
 		__syncthreads();
 	}
-	// stable insertion sort of every small range, one lane each
+	// Ranges of <= 64 records get klib's insertion sort, i.e. any STABLE sort: one wavefront per range computes each
+	// record's rank (smaller keys + equal keys that come earlier) with broadcast LDS reads and scatters in one step.
 	const uint32_t ns = L.n_small;
-	for (uint32_t q = tid; q < ns; q += NT) {
-		const uint32_t b = L.small[q] & 0xFFFFu, e = L.small[q] >> 16;
-		for (uint32_t i = b + 1; i < e; ++i) {
-			const uint16_t idx = L.ia[i];
-			const uint64_t k = L.key[idx];
-			uint32_t j = i;
-			while (j > b && k < L.key[L.ia[j - 1]]) { L.ia[j] = L.ia[j - 1]; --j; }
-			L.ia[j] = idx;
+	for (uint32_t q = wave_id(); q < ns; q += NT / 64) {
+		const uint32_t b = L.small[q] & 0xFFFFu, m = (L.small[q] >> 16) - b, l = lane_id();
+		const uint16_t idx = l < m ? L.ia[b + l] : (uint16_t)0;
+		const uint64_t k = L.key[idx];
+		uint32_t rank = 0;
+		for (uint32_t j = 0; j < m; ++j) {
+			const uint64_t kj = L.key[L.ia[b + j]];
+			rank += (kj < k || (kj == k && j < l)) ? 1u : 0u;
 		}
+		if (l < m) L.ib[b + rank] = idx;
+	}
+	__syncthreads();
+	for (uint32_t q = wave_id(); q < ns; q += NT / 64) {
+		const uint32_t b = L.small[q] & 0xFFFFu, m = (L.small[q] >> 16) - b, l = lane_id();
+		if (l < m) L.ia[b + l] = L.ib[b + l];
 	}
 	__syncthreads();
 	if (!exact) {
