@@ -122,9 +122,10 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 			const int b = __builtin_ctzll(mmask);
 			mmask &= mmask - 1;
 			const int32_t i = i0 + b;
-			if ((small_mask >> b) & 1ull) skip_until = i + __shfl(csz, b);
+			if ((small_mask >> b) & 1ull) skip_until = i + (int32_t)rh_readlane((uint32_t)csz, (uint32_t)b);
 			if (i < skip_until) continue;                            // member of a small cluster, already done
-			const uint64_t xi = __shfl(x, b), yi = __shfl(y, b);
+			const uint64_t xi = (uint64_t)rh_readlane((uint32_t)(x >> 32), (uint32_t)b) << 32 | rh_readlane((uint32_t)x, (uint32_t)b);
+			const uint64_t yi = (uint64_t)rh_readlane((uint32_t)(y >> 32), (uint32_t)b) << 32 | rh_readlane((uint32_t)y, (uint32_t)b);
 			if ((smask >> b) & 1ull) { st = i; max_ii = -1; }       // cluster start: window and max_ii state reset
 			const uint32_t xi_lo = (uint32_t)xi, yi_lo = (uint32_t)yi;
 			const int32_t span_i = (int32_t)((yi >> 32) & 63);
@@ -146,13 +147,21 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 				__syncthreads();
 				const bool marked = valid && L.t[slot] == i;
 				const int32_t scv = valid ? sc + fj : INT32_MIN;
-				int32_t pm = scv;                                    // inclusive prefix max over lanes (= descending j)
-				for (int d = 1; d < 64; d <<= 1) { const int32_t tv = (int32_t)__shfl_up((uint32_t)pm, d); if (lane >= (uint32_t)d && tv > pm) pm = tv; }
-				int32_t excl = (int32_t)__shfl_up((uint32_t)pm, 1);
-				if (lane == 0) excl = INT32_MIN;
-				if (max_f > excl) excl = max_f;
-				const bool newmax = valid && scv > excl;
-				const uint64_t Dm = __ballot(newmax), Um = __ballot(valid && !newmax && marked);
+				// "sc > max_f" in descending-j order = the record highs of scv along the lanes, starting from max_f.  There are
+				// only a few per batch: find them one by one with a ballot + readlane instead of a 6-step shuffle scan.
+				uint64_t Dm = 0, rem = ~0ull;
+				int32_t cur = max_f;
+				for (;;) {
+					const uint64_t m = __ballot(valid && scv > cur) & rem;
+					if (!m) break;
+					const int l = __builtin_ctzll(m);
+					Dm |= 1ull << l;
+					cur = (int32_t)rh_readlane((uint32_t)scv, (uint32_t)l);
+					if (l == 63) break;
+					rem = ~((2ull << l) - 1ull);
+				}
+				const bool newmax = ((Dm >> lane) & 1ull) != 0;
+				const uint64_t Um = __ballot(valid && !newmax && marked);
 				uint64_t ev = Dm | Um;
 				int B = 64;
 				while (ev) {
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 					else if (++n_skip > max_skip) { B = e; break; }
 				}
 				const uint64_t Deff = B < 64 ? (Dm & ((1ull << B) - 1ull)) : Dm;
-				if (Deff) { const int Lm = 63 - __clzll(Deff); max_f = __shfl(scv, Lm); max_j = jtop - Lm; }
+				if (Deff) { const int Lm = 63 - __clzll(Deff); max_f = (int32_t)rh_readlane((uint32_t)scv, (uint32_t)Lm); max_j = jtop - Lm; }
 				if (B < 64) { end_j = jtop - B; broke = true; }
 			}
 			// best-scoring anchor still within max_dist_t ("max_ii"), re-derived from the window when it fell out of range
