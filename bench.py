@@ -163,11 +163,12 @@ def main():
             "mapped_fraction": round(n_mapped / args.reads, 4),
             "chunks_per_read": round(acc["n_chunks"] / acc["n_reads"], 3),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom, args),
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom, args, stage_n[dom] / args.steps),
                          "avg_launch_ms": round(stage_ms[dom] / stage_n[dom], 4), "launches": stage_n[dom],
                          "algorithmic_bytes_per_launch": int(dom_bytes / stage_n[dom])},
-            "path": {"algorithmic_GB_per_step": round(path_bytes / args.steps / 1e9, 4), "device_ms_per_step": round(dev_ms / args.steps, 3),
-                     "achieved_GBs": round(path_bytes / (dev_ms * 1e-3) / 1e9, 3)},
+            "path": {"algorithmic_GB_per_step": round(path_bytes / args.steps / 1e9, 4), "device_ms_per_step": round(dev_ms / args.steps, 3),   # sum over concurrent sub-batch streams
+                    
+                     "achieved_GBs": round(path_bytes / elapsed / 1e9, 3)},
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items() if stage_n.get(k)},
             "setup_s": round(t_setup, 2),
         }
@@ -180,7 +181,7 @@ def main():
     ctx.close()
 
 
-def pmc_traffic(stage, args):
+def pmc_traffic(stage, args, launches_per_step):
     """HBM bytes per launch of the dominant stage from the committed rocprofv3 --pmc passes of this same command
     (profiles/pmc_traffic.json, made by profiles/collect_pmc.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -191,7 +192,7 @@ def pmc_traffic(stage, args):
     if d.get("reads") != args.reads or d.get("samples") != args.samples or d.get("junk") != args.junk:
         return None
     e = d.get("stages", {}).get(stage)
-    return None if e is None else int(e["bytes_per_launch"])
+    return None if e is None or "bytes_per_step" not in e else int(e["bytes_per_step"] / max(launches_per_step, 1))
 
 
 def cpu_baseline(wl, model, ind, args):

@@ -14,22 +14,31 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGE_OF = {"k_prefilter": "prefilter", "k_events_norm": "events_norm", "k_events_peaks": "events_peaks", "k_events_means": "events_means",
+STAGE_OF = {"k_chain_reorder": "backtrack", "k_regions_wave<1536>": "regions", "k_regions_wave<256>": "regions", "k_prefilter": "prefilter", "k_events_norm": "events_norm", "k_events_peaks": "events_peaks", "k_events_means": "events_means",
             "k_sketch": "sketch", "k_probe": "probe", "k_expand": "expand", "k_chain_wave": "chain", "k_backtrack_big": "backtrack",
             "k_regions_wave": "regions"}
 
 
+# k_sort_block / k_sort_big serve four stages; which one a dispatch belongs to follows from the kernel that precedes the
+# group of sort launches (single-stream run, so dispatch order = program order)
+SORT_OWNER = {"k_expand": "sort", "k_zbuild": "zsort", "k_chain_gather": "backtrack", "k_regions_prep": "rsort"}
+
+
 def one_pass(counter, out):
+    env = dict(os.environ, RH_SUB_BATCHES="1")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--cpu-sample", "0"]
-    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
     f = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)[0]
-    acc = {}
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != counter:
-            continue
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    acc, owner = {}, "sort"
+    for r in rows:
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        e = acc.setdefault(k, [0, 0.0])
+        if k in SORT_OWNER:
+            owner = SORT_OWNER[k]
+        key = k if not k.startswith("k_sort") else k + "@" + owner
+        e = acc.setdefault(key, [0, 0.0])
         e[0] += 1
         e[1] += float(r["Counter_Value"])
     return acc
@@ -46,14 +55,14 @@ def main():
         kernels[k] = {"launches": n, "read_bytes": rd, "write_bytes": wr, "bytes_per_launch": (rd + wr) / max(n, 1)}
     stages = {}
     for k, v in kernels.items():
-        st = STAGE_OF.get(k) or ("sort" if k.startswith("k_sort") else None)
+        st = STAGE_OF.get(k) or (k.split("@")[1] if k.startswith("k_sort") else None)
         if st is None:
             continue
         e = stages.setdefault(st, {"launches": 0, "bytes": 0.0})
         e["launches"] += v["launches"]
         e["bytes"] += v["read_bytes"] + v["write_bytes"]
     for e in stages.values():
-        e["bytes_per_launch"] = e["bytes"] / max(e["launches"], 1)
+        e["bytes_per_step"] = e["bytes"]          # the profiled command runs exactly one step
     out = {"reads": 100000, "samples": 40000, "junk": 102, "note": "read bytes = 2 x FETCH_SIZE KiB (gfx950), write bytes = WRITE_SIZE KiB",
            "kernels": kernels, "stages": stages}
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
