@@ -33,7 +33,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJ, s + ".o")
         objs.append(obj)
         if force or _newer(src, obj) or os.path.getmtime(obj) < hdr_time:
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + os.environ.get("RH_HIPCC_EXTRA", "").split() + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))

@@ -311,6 +311,42 @@ extern "C" const char *rh_stage_name(int i) { return (i >= 0 && i < 24) ? kStage
 extern "C" int rh_map_last_stats(rh_ctx *c, rh_map_stats_t *out) { *out = c->stats; return 0; }
 
 namespace {
+// RH_DEBUG_ROUNDS=1: per chunk round, the anchor-count distribution of the active reads and how many needed the exact sort
+bool debug_rounds() { static const bool on = getenv("RH_DEBUG_ROUNDS") != nullptr; return on; }
+void dump_round(rh_ctx *c, uint32_t chunk, uint32_t n_act, const rh_dev_round &rr)
+{
+	std::vector<uint64_t> off((size_t)n_act + 1);
+	std::vector<uint8_t> ex(n_act);
+	(void)hipStreamSynchronize(c->stream);
+	(void)hipMemcpy(off.data(), rr.a_off, off.size() * 8, hipMemcpyDeviceToHost);
+	(void)hipMemcpy(ex.data(), rr.need_exact, n_act, hipMemcpyDeviceToHost);
+	const uint32_t edges[] = {0, 1, 64, 512, 1024, 2048, 3072, 4096, 6144, 8192, 1u << 30};
+	uint32_t h[10] = {0}, hx[10] = {0};
+	for (uint32_t a = 0; a < n_act; ++a) {
+		const uint64_t n = off[a + 1] - off[a];
+		for (int b = 0; b < 10; ++b) if (n >= edges[b] && n < edges[b + 1]) { ++h[b]; hx[b] += ex[a]; }
+	}
+	fprintf(stderr, "[round %u] n_act %u anchors %llu :", chunk, n_act, (unsigned long long)off[n_act]);
+	for (int b = 0; b < 10; ++b) fprintf(stderr, " <%u:%u(%u)", edges[b + 1], h[b], hx[b]);
+	fprintf(stderr, "\n");
+}
+
+void dump_round2(rh_ctx *c, uint32_t chunk, uint32_t n_act, const rh_dev_round &rr)
+{
+	std::vector<uint32_t> nu(n_act), nz(n_act), nv(n_act);
+	(void)hipStreamSynchronize(c->stream);
+	(void)hipMemcpy(nu.data(), rr.n_u, (size_t)n_act * 4, hipMemcpyDeviceToHost);
+	(void)hipMemcpy(nz.data(), rr.n_z, (size_t)n_act * 4, hipMemcpyDeviceToHost);
+	(void)hipMemcpy(nv.data(), rr.n_v, (size_t)n_act * 4, hipMemcpyDeviceToHost);
+	const uint32_t edges[] = {0, 1, 8, 64, 256, 512, 768, 1024, 1536, 1u << 30};
+	uint32_t h[9] = {0};
+	uint64_t su = 0, sz = 0, sv = 0;
+	for (uint32_t a = 0; a < n_act; ++a) { su += nu[a]; sz += nz[a]; sv += nv[a]; for (int b = 0; b < 9; ++b) if (nu[a] >= edges[b] && nu[a] < edges[b + 1]) ++h[b]; }
+	fprintf(stderr, "[round %u] chains: mean n_u %.1f n_z %.1f n_v %.1f :", chunk, (double)su / n_act, (double)sz / n_act, (double)sv / n_act);
+	for (int b = 0; b < 9; ++b) fprintf(stderr, " <%u:%u", edges[b + 1], h[b]);
+	fprintf(stderr, "\n");
+}
+
 // the whole path for one (sub-)batch on one context's stream
 int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out)
 {
@@ -352,11 +388,13 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 		if (stage_anchors(c, total, which, &rr)) return -1;
 		{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rr); }
 		{ StageTimer t(c, ST_SORT); rhk_sort(s, rr); }
+		if (debug_rounds()) dump_round(c, chunk, n_act, rr);
 		{ StageTimer t(c, ST_CHAIN); rhk_chain(s, o, rr); }
 		{ StageTimer t(c, ST_ZSORT); rhk_zsort(s, o, rr); }
 		{ StageTimer t(c, ST_BACKTRACK); rhk_backtrack(s, o, rd, rr); }
 		{ StageTimer t(c, ST_RSORT); rhk_regions_sort(s, o, rd, rr); }
 		{ StageTimer t(c, ST_REGIONS); rhk_regions(s, o, rd, rr, c->logf_tab.as<float>()); }
+		if (debug_rounds()) dump_round2(c, chunk, n_act, rr);
 		{ StageTimer t(c, ST_COMPACT); rhk_compact_active(s, o, rd, rr.act, n_act, chunk + 1, c->act[cur ^ 1].as<uint32_t>(), c->n_act_dev.as<uint32_t>()); }
 		RH_HIP(hipMemcpyAsync(&n_act, c->n_act_dev.p, 4, hipMemcpyDeviceToHost, s));
 		RH_HIP(hipStreamSynchronize(s));

@@ -36,4 +36,7 @@ __device__ uint32_t rh_writelane(uint32_t v, uint32_t val, uint32_t l);
 __device__ uint32_t rh_uniform(uint32_t v);
 #endif
 
+// all lanes of the wavefront have executed everything above (lock step on the GPU: only a compiler-level barrier)
+#define RH_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+
 #define RH_HIP_VOID(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) rh_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); } while (0)

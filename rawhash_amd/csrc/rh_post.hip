@@ -10,6 +10,23 @@
 #include "rh_kernels.h"
 #include "rh_devutil.h"
 
+#ifdef RH_KPROF
+__device__ unsigned long long rh_kprof_post[32];
+#define KPROF_DECL unsigned long long kp_t0 = clock64()
+#define KPROF(slot) do { if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); atomicAdd(&rh_kprof_post[slot], t_ - kp_t0); kp_t0 = t_; } } while (0)
+#define KPROF_ADD(slot, v) do { if (threadIdx.x == 0) atomicAdd(&rh_kprof_post[slot], (unsigned long long)(v)); } while (0)
+extern "C" __attribute__((visibility("default"))) int rh_debug_kprof_post(unsigned long long *out, int reset)
+{
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rh_kprof_post), sizeof(rh_kprof_post)) != hipSuccess) return -1;
+	if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rh_kprof_post), z, sizeof(z)) != hipSuccess) return -1; }
+	return 0;
+}
+#else
+#define KPROF_DECL
+#define KPROF(slot)
+#define KPROF_ADD(slot, v)
+#endif
+
 // ------------------------------------------------------------------------------------------------ k_zbuild
 __global__ __launch_bounds__(64) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 {
@@ -617,7 +634,7 @@ __global__ void k_regions_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, co
 	const uint64_t base = rr.a_off[a];
 	const int32_t n_u = (int32_t)rr.n_u[a];
 	if (n_u <= (int32_t)n_lo || n_u > (int32_t)n_hi) return;
-	if (only_flagged && n_u <= RGW_CAP && !rr.need_exact[a]) return;
+	if (only_flagged && !rr.need_exact[a]) return;
 	const rh_mm128_t *an = rr.anc + base;
 	const uint64_t *u = rr.u + base;
 	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;           // 128 B per anchor >= 128 B per chain
@@ -702,11 +719,13 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 	if (a >= rr.n_act || rr.skip[a]) return;
 	const int32_t n_u = (int32_t)rr.n_u[a];
 	if (n_u <= (int32_t)n_lo || n_u > CAP) return;
+	if (!rr.need_exact[a]) return;                                   // done by k_regions_reg
 	const uint32_t r = rr.act[a];
 	const uint64_t base = rr.a_off[a];
 	const rh_chain_head *heads = (const rh_chain_head*)(rr.ws + base * RH_WS_PER_ANCHOR);
 	const rh_mm128_t *zs = rr.zs + base;                             // keys in radix_sort_128x order (ascending)
 	bool unfit = false;
+	KPROF_DECL;
 	for (int32_t i = (int32_t)lane; i < n_u; i += 64) {
 		const rh_mm128_t zi = zs[n_u - 1 - i];                      // descending: larger score first (hit.c:124-126)
 		const rh_chain_head h = heads[(uint32_t)zi.y];
@@ -719,6 +738,7 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 	if (lane == 0) { L.w[0] = 0; L.pqs[0] = L.qs[0]; L.pqe[0] = L.qe[0]; L.psub[0] = 0; L.pns[0] = 0; }
 	__syncthreads();
 	const bool hard = (o.flag & RH_M_HARD_MLEVEL) != 0;
+	KPROF(1);
 	int32_t kk = 1;
 	bool overflow = false;
 	for (int32_t i = 1; i < n_u && !overflow; ++i) {
@@ -737,6 +757,7 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 			n_cov += (int32_t)__popcll(m);
 		}
 		if (n_cov > RGW_COVC) { overflow = true; break; }
+		KPROF(2); KPROF_ADD(10, n_cov); KPROF_ADD(11, 1); KPROF_ADD(12, kk);
 		int32_t sel = -1, uncov = 0;
 		if (n_cov > 0) {
 			__syncthreads();
@@ -751,6 +772,7 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 				__syncthreads();
 				uncov = L.bc[0];
 			}
+			KPROF(3);
 			// first overlapping primary (list order) that masks region i
 			for (int32_t c0 = 0; c0 < n_cov && sel < 0; c0 += 64) {
 				const int32_t c = c0 + (int32_t)lane;
@@ -766,6 +788,7 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 				const uint64_t m = __ballot(hit);
 				if (m) sel = (int32_t)L.covj[c0 + __builtin_ctzll(m)];
 			}
+			KPROF(4);
 		}
 		if (lane == 0) {
 			if (sel >= 0) {
@@ -776,6 +799,7 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 		}
 		if (sel < 0) ++kk;
 		__syncthreads();
+		KPROF(5);
 	}
 	if (overflow) { if (lane == 0) rr.need_exact[a] = 1; return; }   // re-done by the serial kernel
 	// secondaries dropped (mm_select_sub with best_n = 0): the kept regions are exactly the primaries, in order
@@ -809,6 +833,186 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 	if (lane == 0) {
 		int stop = 0;
 		const int32_t score0 = (int32_t)(L.sc[0] & 0xFFFFFu);
+		if (n_regs == 1 && mapq0 >= o.min_mapq) stop = 1;
+		else {
+			float meanC = (float)sum_sc, meanQ = (float)sumQ;        // sums of small integers: exact in fp32 in any order
+			meanC /= (float)n_regs; meanQ /= (float)n_regs;
+			const float bestQ = (float)mapq0, bestC = (float)score0;
+			float r_bestq = (bestQ > 0) ? (bestQ / 30.0f) : 0.0f; if (r_bestq > 1) r_bestq = 1.0f;
+			float r_bestmq = (bestQ > 0) ? (1.0f - (meanQ / bestQ)) : 0.0f; if (r_bestmq < 0) r_bestmq = 0.0f;
+			float r_bestmc = (bestC > 0) ? (1.0f - (meanC / bestC)) : 0.0f; if (r_bestmc < 0) r_bestmc = 0.0f;
+			const float weighted = o.w_bestq * r_bestq + o.w_bestmq * r_bestmq + o.w_bestmc * r_bestmc;
+			if (weighted >= o.w_threshold) stop = 1;
+		}
+		const rh_chain_head h = heads[(uint32_t)zs[n_u - 1].y];
+		rh_reg best;
+		best.cnt = h.cnt; best.score = score0; best.mapq = (uint32_t)mapq0;
+		best.qs = (int32_t)h.y0; best.qe = h.y1 + 1; best.rs = (int32_t)h.x0; best.re = h.x1 + 1;
+		best.rid = (int32_t)(h.x0 << 1 >> 33); best.rev = (uint32_t)(h.x0 >> 63);
+		regions_commit(o, rd, rr, a, r, n_regs, &best, stop);
+		rr.need_exact[a] = 0;
+	}
+	KPROF(6);
+}
+
+// ------------------------------------------------------------------------------------------------ regions, primaries in registers
+// Measured on unmapped reads (hundreds of chains, carried over every chunk): only a handful of chains are primaries and a
+// chain overlaps one or two of them, so mm_set_parent (hit.c:136-195) is bound by the latency of its per-chain step, not
+// by interval tests.  Here primary j lives in the VGPRs of lane (j & 63), slot (j >> 6); the chains are streamed through
+// registers 64 at a time and broadcast with v_readlane; overlap / mask tests are one ballot; the parent's sub-score and
+// n_sub update is a masked register write.  No LDS, no barrier.  Reads with more primaries than fit fall back to
+// k_regions_wave.  Default selection only (pri_ratio > 0, best_n == 0: secondaries dropped).
+#ifndef RGR_SLOTS
+#define RGR_SLOTS 2
+#endif
+#ifndef RGR_PRIM_CAP
+#define RGR_PRIM_CAP (64 * RGR_SLOTS)
+#endif
+
+__global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, const float *logf_tab, uint32_t n_lo)
+{
+	constexpr int P = RGR_SLOTS;
+	const uint32_t a = blockIdx.x, lane = threadIdx.x;
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const int32_t n_u = (int32_t)rr.n_u[a];
+	if (n_u <= (int32_t)n_lo) return;
+	const uint32_t r = rr.act[a];
+	const uint64_t base = rr.a_off[a];
+	const rh_chain_head *heads = (const rh_chain_head*)(rr.ws + base * RH_WS_PER_ANCHOR);
+	const rh_mm128_t *zs = rr.zs + base;                             // keys in radix_sort_128x order (ascending)
+	const bool hard = (o.flag & RH_M_HARD_MLEVEL) != 0;
+	int32_t pqs[P], pqe[P], psc[P], pcn[P], psub[P], pns[P];
+#pragma unroll
+	for (int p = 0; p < P; ++p) { pqs[p] = 0; pqe[p] = 0; psc[p] = 0; pcn[p] = 0; psub[p] = 0; pns[p] = 0; }
+	uint32_t kk = 0;
+	bool overflow = false;
+	// region i (descending score: larger first, hit.c:124-126) of the current tile sits in lane i - i0
+	int32_t nqs = 0, nqe = 0, nsc = 0, ncn = 0;
+	if ((int32_t)lane < n_u) {
+		const rh_mm128_t zi = zs[n_u - 1 - (int32_t)lane];
+		const rh_chain_head *h = heads + (uint32_t)zi.y;
+		nsc = (int32_t)(zi.x >> 32); nqs = (int32_t)h->y0; nqe = h->y1 + 1; ncn = h->cnt;
+	}
+	for (int32_t i0 = 0; i0 < n_u && !overflow; i0 += 64) {
+		const int32_t tqs = nqs, tqe = nqe, tsc = nsc, tcn = ncn;
+		const int32_t inext = i0 + 64 + (int32_t)lane;
+		if (inext < n_u) {	// next tile's loads fly while this tile is processed
+			const rh_mm128_t zi = zs[n_u - 1 - inext];
+			const rh_chain_head *h = heads + (uint32_t)zi.y;
+			nsc = (int32_t)(zi.x >> 32); nqs = (int32_t)h->y0; nqe = h->y1 + 1; ncn = h->cnt;
+		}
+		const uint32_t nt = (uint32_t)(n_u - i0 < 64 ? n_u - i0 : 64);
+		for (uint32_t t = 0; t < nt; ++t) {
+			const int32_t si = (int32_t)rh_readlane((uint32_t)tqs, t), ei = (int32_t)rh_readlane((uint32_t)tqe, t);
+			const int32_t sci = (int32_t)rh_readlane((uint32_t)tsc, t), cni = (int32_t)rh_readlane((uint32_t)tcn, t);
+			// primaries overlapping [si, ei)
+			uint64_t m[P];
+			bool ov[P];
+			uint32_t n_cov = 0;
+#pragma unroll
+			for (int p = 0; p < P; ++p) {
+				ov[p] = (uint32_t)p * 64u + lane < kk && !(pqe[p] <= si || pqs[p] >= ei);
+				m[p] = __ballot(ov[p]);
+				n_cov += (uint32_t)__popcll(m[p]);
+			}
+			int32_t sel = -1;
+			if (n_cov > 0) {
+				int32_t uncov = 0;
+				if (!hard) {
+					// length of [si, ei) not covered by the overlapping primaries = (ei - si) - |union of the clipped intervals|;
+					// in sweep order (start, end, list index) an interval adds what lies beyond everything before it
+					int32_t cs[P], ce[P], reach[P];
+#pragma unroll
+					for (int p = 0; p < P; ++p) { cs[p] = pqs[p] < si ? si : pqs[p]; ce[p] = pqe[p] > ei ? ei : pqe[p]; reach[p] = si; }
+					if (n_cov > 1) {
+#pragma unroll
+						for (int q = 0; q < P; ++q) {
+							uint64_t mm = m[q];
+							while (mm) {
+								const uint32_t l2 = (uint32_t)__builtin_ctzll(mm);
+								mm &= mm - 1;
+								const int32_t s2 = (int32_t)rh_readlane((uint32_t)cs[q], l2), e2 = (int32_t)rh_readlane((uint32_t)ce[q], l2);
+								const uint32_t j2 = (uint32_t)q * 64u + l2;
+#pragma unroll
+								for (int p = 0; p < P; ++p) {
+									const uint32_t j = (uint32_t)p * 64u + lane;
+									const bool before = s2 < cs[p] || (s2 == cs[p] && (e2 < ce[p] || (e2 == ce[p] && j2 < j)));
+									if (before && e2 > reach[p]) reach[p] = e2;
+								}
+							}
+						}
+					}
+					int32_t uni = 0;
+#pragma unroll
+					for (int p = 0; p < P; ++p) {
+						const int32_t from = cs[p] > reach[p] ? cs[p] : reach[p];
+						const int32_t add = ov[p] && ce[p] > from ? ce[p] - from : 0;
+						uint64_t mm = m[p];
+						while (mm) { const uint32_t l2 = (uint32_t)__builtin_ctzll(mm); mm &= mm - 1; uni += (int32_t)rh_readlane((uint32_t)add, l2); }
+					}
+					uncov = (ei - si) - uni;
+				}
+				// first overlapping primary (list order) that masks region i
+#pragma unroll
+				for (int p = 0; p < P; ++p) {
+					bool hit = false;
+					if (ov[p]) {
+						const int32_t sj = pqs[p], ej = pqe[p];
+						const int32_t mn = ej - sj < ei - si ? ej - sj : ei - si;
+						const int32_t mx = ej - sj > ei - si ? ej - sj : ei - si;
+						const int32_t ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj) : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
+						hit = (float)ol / (float)mn - (float)uncov / (float)mx > o.mask_level && uncov <= o.mask_len;
+					}
+					const uint64_t hm = __ballot(hit);
+					if (sel < 0 && hm) sel = p * 64 + (int32_t)__builtin_ctzll(hm);
+				}
+			}
+			if (i0 == 0 && t == 0) sel = -1;                       // the best chain opens the list
+			if (sel >= 0) {
+#pragma unroll
+				for (int p = 0; p < P; ++p)
+					if ((uint32_t)sel == (uint32_t)p * 64u + lane) { if (psub[p] < sci) psub[p] = sci; if (cni >= pcn[p]) ++pns[p]; }
+			} else {
+				if (kk >= (uint32_t)RGR_PRIM_CAP) { overflow = true; break; }
+#pragma unroll
+				for (int p = 0; p < P; ++p)
+					if (kk == (uint32_t)p * 64u + lane) { pqs[p] = si; pqe[p] = ei; psc[p] = sci; pcn[p] = cni; psub[p] = 0; pns[p] = 0; }
+				++kk;
+			}
+		}
+	}
+	if (overflow) { if (lane == 0) rr.need_exact[a] = 1; return; }   // re-done by k_regions_wave / the serial kernel
+	// secondaries dropped (mm_select_sub with best_n = 0): the kept regions are exactly the primaries, in order
+	const int32_t n_regs = (int32_t)kk;
+	int64_t sum_sc = 0;
+#pragma unroll
+	for (int p = 0; p < P; ++p) { int32_t v = (uint32_t)p * 64u + lane < kk ? psc[p] : 0; for (int d = 32; d > 0; d >>= 1) v += (int32_t)__shfl_xor((uint32_t)v, d); sum_sc += v; }
+	const float uniq_ratio = (float)sum_sc / (float)(sum_sc + rr.rep_len[a]);
+	int64_t sumQ = 0;
+	int32_t mapq0 = 0;
+#pragma unroll
+	for (int p = 0; p < P; ++p) {
+		int32_t mq = 0;
+		if ((uint32_t)p * 64u + lane < kk) {
+			const int32_t sc = psc[p], cn = pcn[p];
+			const float pen_s1 = (float)((sc > 100 ? 1.0 : 0.01 * (double)sc) * (double)uniq_ratio);
+			float pen_cm = cn > 10 ? 1.0f : 0.1f * (float)cn;
+			pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
+			const int32_t subsc = psub[p] > o.min_sc ? psub[p] : o.min_sc;
+			const float x = (float)subsc / (float)sc;
+			mq = (int32_t)(pen_cm * 40.0f * (1.0f - x) * logf_int(sc, logf_tab));
+			mq -= (int32_t)(4.343f * logf_int(pns[p] + 1, logf_tab) + .499f);
+			mq = mq > 0 ? mq : 0;
+			mq = mq < 60 ? mq : 60;
+		}
+		if (p == 0) mapq0 = (int32_t)rh_readlane((uint32_t)mq, 0);
+		int32_t v = mq;
+		for (int d = 32; d > 0; d >>= 1) v += (int32_t)__shfl_xor((uint32_t)v, d);
+		sumQ += v;
+	}
+	if (lane == 0) {
+		int stop = 0;
+		const int32_t score0 = psc[0];
 		if (n_regs == 1 && mapq0 >= o.min_mapq) stop = 1;
 		else {
 			float meanC = (float)sum_sc, meanQ = (float)sumQ;        // sums of small integers: exact in fp32 in any order
@@ -876,6 +1080,7 @@ void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, con
 	// need_exact[] doubles as "this read still needs the serial region kernel"
 	RH_HIP_VOID(hipMemsetAsync(r.need_exact, wave_ok ? 0 : 1, r.n_act, s));
 	if (wave_ok) {
+		RH_LAUNCH(k_regions_reg, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL);
 		RH_LAUNCH(k_regions_wave<RGW_CAP0>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL);
 		RH_LAUNCH(k_regions_wave<RGW_CAP>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RGW_CAP0);
 	}

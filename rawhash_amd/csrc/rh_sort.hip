@@ -5,142 +5,250 @@
 // ranges <= 64).  It is unstable, and the order it leaves equal keys in is observed by the chaining DP, so the result
 // must be the reference's exact permutation.  Structure used here:
 //   * ranges whose keys agree on a byte are untouched by that pass -> jump straight to the highest differing byte;
-//   * the final insertion sorts (ranges <= 64) are stable and independent -> one lane per range, in parallel;
+//   * the final insertion sorts (ranges <= 64) are stable and independent -> one wavefront per range, in parallel;
 //   * a pass over >= 2 buckets is a permutation that only matters for EQUAL keys:
-//       fast mode : digit scatter with LDS atomics (order inside a bucket arbitrary), then check the sorted result for
-//                   adjacent equal keys; a read without ties has a unique sorted order, so it is already exact;
-//       exact mode: (reads flagged by the fast pass, ~5 % on an E. coli-scale index) the reference's cycle-leader
-//                   permutation: closed form for two buckets (prefix ranks), one lane walking the cycles otherwise.
-// Keys live in LDS by original index (8 B); the permutation is carried as 16-bit indices.  Records (16 B) are gathered
-// from / written to HBM once.
+//       fast pass : digit scatter with LDS atomics (order inside a bucket arbitrary), then the sorted result is checked
+//                   for adjacent equal keys; a read without ties has a unique sorted order, so it is already exact;
+//       exact pass: (same launch, reads with ties only) the sort is redone from the input order, and every range that
+//                   holds a tied key gets the reference's cycle-leader permutation - closed form for two buckets
+//                   (prefix ranks), otherwise one wavefront replays the cycle walk with the range's digits and the
+//                   bucket heads held in VGPRs (v_readlane + s_set_gpr_idx, no memory on the dependency chain);
+//                   tie-free ranges keep the atomic scatter.
+// LDS per record: 8 B key (by original index) + 2 B permutation + 2 B scratch map; permutations are applied through
+// registers.  Records (16 B) are gathered from / written to HBM once.
 #include "rh_kernels.h"
 #include "rh_devutil.h"
+
+// -DRH_KPROF: development aid, shader-clock cycles spent per phase of k_sort_block summed over workgroups (thread 0)
+#ifdef RH_KPROF
+__device__ unsigned long long rh_kprof_acc[32];
+#define KPROF_DECL unsigned long long kp_t0 = clock64()
+#define KPROF(slot) do { if (threadIdx.x == 0 && L.prof != 0) { const unsigned long long t_ = clock64(); atomicAdd(&rh_kprof_acc[slot], t_ - kp_t0); kp_t0 = t_; } } while (0)
+extern "C" __attribute__((visibility("default"))) int rh_debug_kprof(unsigned long long *out, int reset)
+{
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rh_kprof_acc), sizeof(rh_kprof_acc)) != hipSuccess) return -1;
+	if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rh_kprof_acc), z, sizeof(z)) != hipSuccess) return -1; }
+	return 0;
+}
+#else
+#define KPROF_DECL
+#define KPROF(slot)
+#endif
 
 template <int CAP>
 struct sort_lds {
 	uint64_t key[CAP];
-	uint16_t ia[CAP], ib[CAP], tmp[CAP];
-	uint8_t db[CAP];
-	uint32_t small[CAP / 2 + 2];               // ranges <= 64 awaiting the stable insertion sort: beg | end << 16
+	uint16_t ia[CAP];                          // current arrangement: position -> original index
+	uint16_t xm[CAP];                          // scratch of a pass: gather map (position -> source position) or rank lists
+	uint32_t sbit[CAP / 32 + 3], ebit[CAP / 32 + 3];   // ranges <= 64 awaiting the stable insertion sort: first / last position marks
+	uint32_t tbit[CAP / 32 + 3];               // original indices whose key occurs more than once
 	uint32_t rng[2][CAP / 64 + 4];             // ranges > 64 still to be split: beg | end << 16
 	uint8_t rsh[2][CAP / 64 + 4];              // ... and the byte shift they are to be split on next
-	uint32_t cnt[256], head[256], tail[256];
+	uint32_t cnt[256], head[256];
 	uint32_t w[NT / 64];
 	uint64_t r64[NT / 64];
-	uint32_t n_rng[2], n_small, tie, misc[4];
+	uint32_t n_rng[2], tie, misc[4], prof;
 };
 
+enum { SORT_FAST = 0, SORT_EXACT_TIED = 1, SORT_EXACT_ALL = 2 };
+
 template <int CAP>
-RH_DEV void sort_split_range(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int shift, int nxt, int exact)
+RH_DEV uint32_t sort_digit(const sort_lds<CAP> &L, uint32_t i, int s) { return (uint32_t)(L.key[L.ia[i]] >> s) & 255u; }
+
+// ia[j] = ia[xm[j]] for j in [beg, end), through registers
+template <int CAP>
+RH_DEV void sort_apply_gather(sort_lds<CAP> &L, uint32_t beg, uint32_t end)
+{
+	constexpr int K = (CAP + NT - 1) / NT;
+	uint16_t v[K];
+#pragma unroll
+	for (int k = 0; k < K; ++k) {
+		if (beg + (uint32_t)k * NT >= end) break;
+		const uint32_t j = beg + (uint32_t)k * NT + threadIdx.x;
+		v[k] = j < end ? L.ia[L.xm[j]] : (uint16_t)0;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < K; ++k) {
+		if (beg + (uint32_t)k * NT >= end) break;
+		const uint32_t j = beg + (uint32_t)k * NT + threadIdx.x;
+		if (j < end) L.ia[j] = v[k];
+	}
+	__syncthreads();
+}
+
+// Two buckets A < B.  Cycle-leader result in closed form: the k-th misplaced element of region A trades places with the
+// k-th misplaced element of region B, except that in B every run of in-place elements between two misplaced ones is
+// shifted right by one slot and the arrival lands in front of the run.
+template <int CAP>
+RH_DEV void sort_two_buckets(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s, uint32_t cA, uint32_t cB, uint32_t startB)
+{
+	constexpr int K = (CAP + NT - 1) / NT;
+	const uint32_t tid = threadIdx.x;
+	uint32_t code[K];                                       // kind | rank << 2; kind: 0 A in place, 1 A misplaced, 2 B misplaced, 3 B in place
+	uint32_t nA = 0, nB = 0;                                // misplaced elements seen so far in A / in B
+#pragma unroll
+	for (int k = 0; k < K; ++k) {
+		if (beg + (uint32_t)k * NT >= end) break;
+		const uint32_t i = beg + (uint32_t)k * NT + tid;
+		const bool in = i < end;
+		const uint32_t d = in ? sort_digit(L, i, s) : 0u;
+		const bool fa = in && i < startB && d == cB, fb = in && i >= startB && d == cA;
+		const uint64_t mA = __ballot(fa), mB = __ballot(fb);
+		if (lane_id() == 0) L.w[wave_id()] = (uint32_t)__popcll(mA) | (uint32_t)__popcll(mB) << 16;
+		__syncthreads();
+		uint32_t base = 0, tot = 0;
+		for (uint32_t q = 0; q < NT / 64; ++q) { const uint32_t c = L.w[q]; if (q < wave_id()) base += c; tot += c; }
+		__syncthreads();
+		const uint32_t ra = nA + (base & 0xFFFFu) + lanes_below(mA), rb = nB + (base >> 16) + lanes_below(mB);
+		if (fa) L.xm[beg + ra] = (uint16_t)i;              // positions of A's misplaced elements, ascending
+		if (fb) L.xm[end - 1 - rb] = (uint16_t)i;          // positions of B's misplaced elements, stored from the back
+		code[k] = in ? ((fa ? 1u : fb ? 2u : i < startB ? 0u : 3u) | (fa ? ra : rb) << 2) : ~0u;
+		nA += tot & 0xFFFFu; nB += tot >> 16;
+	}
+	__syncthreads();
+	const uint32_t m = nA;
+	uint16_t val[K];
+#pragma unroll
+	for (int k = 0; k < K; ++k) {
+		if (beg + (uint32_t)k * NT >= end) break;
+		const uint32_t i = beg + (uint32_t)k * NT + tid, c = code[k];
+		if (c == ~0u) continue;
+		const uint32_t kind = c & 3u, r = c >> 2;
+		uint32_t dest;
+		if (kind == 0) dest = i;
+		else if (kind == 1) dest = r == 0 ? startB : (uint32_t)L.xm[end - r] + 1u;
+		else if (kind == 2) dest = L.xm[beg + r];
+		else dest = r < m ? i + 1 : i;
+		code[k] = dest;
+		val[k] = L.ia[i];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < K; ++k) {
+		if (beg + (uint32_t)k * NT >= end) break;
+		if (code[k] != ~0u) L.ia[code[k]] = val[k];
+	}
+	__syncthreads();
+}
+
+// The reference's cycle walk over >= 3 buckets, replayed by ONE wavefront (all lanes in lock step on wave-uniform
+// values).  State lives in registers: the digit of relative position p is byte (p & 3) of VGPR [p >> 8] in lane
+// ((p >> 2) & 63); lane (c & 63) holds the head / tail of bucket c in VGPR [c >> 6].  Each step is a couple of
+// v_readlane; the only memory operation is the fire-and-forget LDS store of the gather map xm[dest] = source.
+template <int CAP>
+RH_DEV void sort_cycle_walk(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s)
+{
+	constexpr int NR = (CAP + 255) / 256;
+	const uint32_t lane = lane_id(), n = end - beg;
+	uint32_t dg[NR];
+#pragma unroll
+	for (int q = 0; q < NR; ++q) {
+		uint32_t w = 0;
+		const uint32_t p0 = ((uint32_t)q * 64u + lane) * 4u;
+		if (p0 < n) {
+			for (uint32_t b = 0; b < 4; ++b) if (p0 + b < n) w |= sort_digit(L, beg + p0 + b, s) << (8 * b);
+		}
+		dg[q] = w;
+	}
+	uint32_t hd[4], tl[4];
+#pragma unroll
+	for (int q = 0; q < 4; ++q) { hd[q] = L.head[q * 64 + lane] - beg; tl[q] = hd[q] + L.cnt[q * 64 + lane]; }
+	for (uint32_t c = 0; c < 256; ++c) {
+		const uint32_t tlc = rh_readlane(tl[c >> 6], c & 63u);
+		uint32_t h = rh_readlane(hd[c >> 6], c & 63u);
+		while (h != tlc) {
+			uint32_t src = h;
+			uint32_t d = (rh_readlane(dg[h >> 8], (h >> 2) & 63u) >> ((h & 3u) * 8u)) & 255u;
+			while (d != c) {
+				const uint32_t q = rh_readlane(hd[d >> 6], d & 63u);
+				if (lane == (d & 63u)) hd[d >> 6] = q + 1;
+				L.xm[beg + q] = (uint16_t)(beg + src);
+				src = q;
+				d = (rh_readlane(dg[q >> 8], (q >> 2) & 63u) >> ((q & 3u) * 8u)) & 255u;
+			}
+			L.xm[beg + h] = (uint16_t)(beg + src);
+			++h;
+		}
+	}
+}
+
+template <int CAP>
+RH_DEV void sort_split_range(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int shift, int nxt, int pass)
 {
 	const uint32_t tid = threadIdx.x;
-	// highest byte on which the range's keys differ (passes above it are identities in the reference)
+	KPROF_DECL;
+	// highest byte on which the range's keys differ (passes above it are identities in the reference); does it hold ties?
 	const uint64_t k0 = L.key[L.ia[beg]];
 	uint64_t diff = 0;
-	for (uint32_t i = beg + tid; i < end; i += NT) diff |= L.key[L.ia[i]] ^ k0;
-	diff = block_or64(diff, L.r64);
+	bool tied = false;
+	for (uint32_t i = beg + tid; i < end; i += NT) {
+		const uint32_t idx = L.ia[i];
+		diff |= L.key[idx] ^ k0;
+		if (pass == SORT_EXACT_TIED) tied |= (L.tbit[idx >> 5] >> (idx & 31u) & 1u) != 0;
+	}
+	const uint64_t tm = __ballot(tied);
+	if (lane_id() == 0) L.w[wave_id()] = tm != 0;
+	diff = block_or64(diff, L.r64);                           // (barriers inside publish L.w as well)
+	KPROF(1);
 	if (diff == 0) return;                                   // all keys equal: every remaining pass is an identity
+	const bool exact = pass == SORT_EXACT_ALL || (pass == SORT_EXACT_TIED && (L.w[0] | L.w[1] | L.w[2] | L.w[3]) != 0);
 	int s = (63 - __clzll(diff)) & ~7;
 	if (s > shift) s = shift;
 	// digit histogram
 	L.cnt[tid] = 0;
 	__syncthreads();
-	for (uint32_t i = beg + tid; i < end; i += NT) { const uint32_t d = (uint32_t)(L.key[L.ia[i]] >> s) & 255u; L.db[i] = (uint8_t)d; atomicAdd(&L.cnt[d], 1u); }
+	for (uint32_t i = beg + tid; i < end; i += NT) atomicAdd(&L.cnt[sort_digit(L, i, s)], 1u);
 	__syncthreads();
 	const uint32_t my_cnt = L.cnt[tid];
 	uint32_t total;
 	const uint32_t my_start = beg + block_excl_scan(my_cnt, L.w, total);
-	L.head[tid] = my_start; L.tail[tid] = my_start + my_cnt;
+	L.head[tid] = my_start;
 	uint32_t nbk;
 	(void)block_rank(my_cnt != 0, L.w, nbk);
-	// permutation of the pass: ia[beg,end) -> ib[beg,end)
+	KPROF(2);
+	// permutation of the pass
 	if (!exact) {
-		for (uint32_t i = beg + tid; i < end; i += NT) { const uint32_t pos = atomicAdd(&L.head[L.db[i]], 1u); L.ib[pos] = L.ia[i]; }
+		for (uint32_t i = beg + tid; i < end; i += NT) { const uint32_t pos = atomicAdd(&L.head[sort_digit(L, i, s)], 1u); L.xm[pos] = (uint16_t)i; }
+		__syncthreads();
+		KPROF(3);
+		sort_apply_gather<CAP>(L, beg, end);
+		KPROF(4);
 	} else if (nbk == 2) {
-		// Two buckets A < B.  Cycle-leader result in closed form: the k-th misplaced element of region A trades places
-		// with the k-th misplaced element of region B, except that in B every run of in-place elements between two
-		// misplaced ones is shifted right by one slot and the arrival lands in front of the run.
 		if (my_cnt != 0) { const uint32_t which = my_start == beg ? 0u : 1u; L.misc[which] = tid; L.misc[2 + which] = my_start; }
 		__syncthreads();
-		const uint32_t cA = L.misc[0], cB = L.misc[1], startB = L.misc[3];
-		uint32_t m = 0;                                        // misplaced elements seen so far in A
-		for (uint32_t base = beg; base < startB; base += NT) {
-			const uint32_t i = base + tid;
-			const bool foreign = i < startB && L.db[i] == cB;
-			uint32_t tot;
-			const uint32_t rk = block_rank(foreign, L.w, tot);
-			if (i < startB) { if (foreign) L.tmp[m + rk] = (uint16_t)i; else L.ib[i] = L.ia[i]; }
-			m += tot;
-		}
-		uint32_t fb = 0;                                       // misplaced elements seen so far in B
-		for (uint32_t base = startB; base < end; base += NT) {
-			const uint32_t i = base + tid;
-			const bool foreign = i < end && L.db[i] == cA;
-			uint32_t tot;
-			const uint32_t rk = block_rank(foreign, L.w, tot);
-			if (i < end) {
-				const uint32_t r = fb + rk;                      // misplaced elements of B before slot i
-				if (foreign) { L.ib[L.tmp[r]] = L.ia[i]; L.tmp[m + r] = (uint16_t)i; }
-				else L.ib[r < m ? i + 1 : i] = L.ia[i];
-			}
-			fb += tot;
-		}
-		__syncthreads();
-		for (uint32_t k = tid; k < m; k += NT) L.ib[k == 0 ? startB : (uint32_t)L.tmp[m + k - 1] + 1u] = L.ia[L.tmp[k]];
+		sort_two_buckets<CAP>(L, beg, end, s, L.misc[0], L.misc[1], L.misc[3]);
+		KPROF(5);
 	} else {
 		__syncthreads();
-		if (tid == 0) {	// the reference's cycle walk, on (digit, index) pairs
-			for (uint32_t c = 0; c < 256; ++c) {
-				const uint32_t tl = L.tail[c];
-				uint32_t h = L.head[c];
-				while (h != tl) {
-					uint32_t carry = L.ia[h], d = L.db[h];
-					if (d != c) {
-						do {
-							const uint32_t hh = L.head[d];
-							L.head[d] = hh + 1;
-							const uint32_t ev = L.ia[hh], dn = L.db[hh];
-							L.ib[hh] = (uint16_t)carry;
-							carry = ev; d = dn;
-						} while (d != c);
-					}
-					L.ib[h++] = (uint16_t)carry;
-				}
-				L.head[c] = h;
-			}
-		}
+		if (wave_id() == 0) sort_cycle_walk<CAP>(L, beg, end, s);
+		__syncthreads();
+		KPROF(6);
+		sort_apply_gather<CAP>(L, beg, end);
+		KPROF(4);
 	}
-	__syncthreads();
-	for (uint32_t i = beg + tid; i < end; i += NT) L.ia[i] = L.ib[i];
 	// children: one bucket per thread
 	if (s > 0 && my_cnt > 1) {
 		if (my_cnt > 64) { const uint32_t k = atomicAdd(&L.n_rng[nxt], 1u); L.rng[nxt][k] = my_start | (my_start + my_cnt) << 16; L.rsh[nxt][k] = (uint8_t)(s - 8); }
-		else { const uint32_t k = atomicAdd(&L.n_small, 1u); L.small[k] = my_start | (my_start + my_cnt) << 16; }
+		else { const uint32_t e = my_start + my_cnt - 1; atomicOr(&L.sbit[my_start >> 5], 1u << (my_start & 31u)); atomicOr(&L.ebit[e >> 5], 1u << (e & 31u)); }
 	}
 	__syncthreads();
+	KPROF(7);
 }
 
-// mode 0: fast pass over every read of the size class, sets flag[a] (1 = has equal keys, output not written)
-// mode 1: exact pass over the flagged reads
-// mode 2: exact pass over every segment (keys known to be full of ties, e.g. chain scores)
+// the whole radix sort of the n keys in L.key, from the input order, into L.ia
 template <int CAP>
-__global__ __launch_bounds__(NT) void k_sort_block(rh_sort_job jb, uint32_t n_lo, uint32_t n_hi, int mode)
+RH_DEV void sort_run(sort_lds<CAP> &L, uint32_t n, int pass)
 {
-	__shared__ sort_lds<CAP> L;
-	const uint32_t a = blockIdx.x, tid = threadIdx.x;
-	const int exact = mode != 0;
-	if (a >= jb.n_seg || (jb.skip && jb.skip[a])) return;
-	const uint64_t base = jb.off[a];
-	const uint32_t n = jb.cnt ? jb.cnt[a] : (uint32_t)(jb.off[a + 1] - base);
-	if (n <= n_lo || n > n_hi) return;
-	if (mode == 1 && !jb.need_exact[a]) return;
-	const rh_mm128_t *src = jb.src + base;
-	rh_mm128_t *dst = jb.dst + base;
-	for (uint32_t i = tid; i < n; i += NT) { L.key[i] = src[i].x; L.ia[i] = (uint16_t)i; }
+	const uint32_t tid = threadIdx.x;
+	KPROF_DECL;
+	for (uint32_t i = tid; i < n; i += NT) L.ia[i] = (uint16_t)i;
+	for (uint32_t i = tid; i < CAP / 32 + 3; i += NT) { L.sbit[i] = 0; L.ebit[i] = 0; }
+	__syncthreads();
 	if (tid == 0) {
-		L.n_rng[0] = 0; L.n_rng[1] = 0; L.n_small = 0; L.tie = 0;
+		L.n_rng[0] = 0; L.n_rng[1] = 0;
 		if (n > 64) { L.rng[0][0] = 0u | n << 16; L.rsh[0][0] = 56; L.n_rng[0] = 1; }
-		else if (n > 1) { L.small[0] = 0u | n << 16; L.n_small = 1; }
+		else if (n > 1) { L.sbit[0] = 1u; L.ebit[(n - 1) >> 5] = 1u << ((n - 1) & 31u); }
 	}
 	__syncthreads();
 	for (int cur = 0;; cur ^= 1) {
@@ -148,7 +256,7 @@ __global__ __launch_bounds__(NT) void k_sort_block(rh_sort_job jb, uint32_t n_lo
 		if (nr == 0) break;
 		for (uint32_t ri = 0; ri < nr; ++ri) {
 			const uint32_t be = L.rng[cur][ri];
-			sort_split_range<CAP>(L, be & 0xFFFFu, be >> 16, (int)L.rsh[cur][ri], cur ^ 1, exact);
+			sort_split_range<CAP>(L, be & 0xFFFFu, be >> 16, (int)L.rsh[cur][ri], cur ^ 1, pass);
 		}
 		__syncthreads();
 		if (tid == 0) L.n_rng[cur] = 0;
@@ -156,33 +264,82 @@ __global__ __launch_bounds__(NT) void k_sort_block(rh_sort_job jb, uint32_t n_lo
 	}
 	// Ranges of <= 64 records get klib's insertion sort, i.e. any STABLE sort: one wavefront per range computes each
 	// record's rank (smaller keys + equal keys that come earlier) with broadcast LDS reads and scatters in one step.
-	const uint32_t ns = L.n_small;
-	for (uint32_t q = wave_id(); q < ns; q += NT / 64) {
-		const uint32_t b = L.small[q] & 0xFFFFu, m = (L.small[q] >> 16) - b, l = lane_id();
-		const uint16_t idx = l < m ? L.ia[b + l] : (uint16_t)0;
-		const uint64_t k = L.key[idx];
-		uint32_t rank = 0;
-		for (uint32_t j = 0; j < m; ++j) {
-			const uint64_t kj = L.key[L.ia[b + j]];
-			rank += (kj < k || (kj == k && j < l)) ? 1u : 0u;
+	KPROF(8);
+	const uint32_t nw32 = (n + 31) / 32;
+	for (uint32_t wi = wave_id(); wi < nw32; wi += NT / 64) {
+		uint32_t sb = rh_uniform(L.sbit[wi]);
+		while (sb) {
+			const uint32_t bit = (uint32_t)__builtin_ctz(sb);
+			sb &= sb - 1;
+			const uint32_t b = wi * 32 + bit;
+			uint32_t ew = rh_uniform(L.ebit[wi]) >> bit, e = b;
+			if (ew) e = b + (uint32_t)__builtin_ctz(ew);
+			else { uint32_t x = wi + 1; while ((ew = rh_uniform(L.ebit[x])) == 0) ++x; e = x * 32 + (uint32_t)__builtin_ctz(ew); }
+			const uint32_t m = e - b + 1, l = lane_id();
+			const uint16_t idx = L.ia[b + (l < m ? l : 0u)];
+			const uint64_t k = L.key[idx];
+			const uint32_t klo = (uint32_t)k, khi = (uint32_t)(k >> 32);
+			uint32_t rank = 0;
+			// the other records' keys come from their lanes' registers (v_readlane with the wave-uniform j), not from LDS
+			if (__ballot(khi != rh_readlane(khi, 0)) == 0) {
+				for (uint32_t j = 0; j < m; ++j) { const uint32_t kj = rh_readlane(klo, j); rank += (kj < klo || (kj == klo && j < l)) ? 1u : 0u; }
+			} else {
+				for (uint32_t j = 0; j < m; ++j) {
+					const uint64_t kj = (uint64_t)rh_readlane(khi, j) << 32 | rh_readlane(klo, j);
+					rank += (kj < k || (kj == k && j < l)) ? 1u : 0u;
+				}
+			}
+			RH_WAVE_SYNC();                                    // every lane has read the range before it is rewritten
+			if (l < m) L.ia[b + rank] = idx;
 		}
-		if (l < m) L.ib[b + rank] = idx;
 	}
 	__syncthreads();
-	for (uint32_t q = wave_id(); q < ns; q += NT / 64) {
-		const uint32_t b = L.small[q] & 0xFFFFu, m = (L.small[q] >> 16) - b, l = lane_id();
-		if (l < m) L.ia[b + l] = L.ib[b + l];
-	}
+	KPROF(9);
+}
+
+// mode 0: fast pass; reads whose sorted keys show ties are redone with the exact permutation on the tied ranges
+// mode 2: exact pass on every range (keys known to be full of ties, e.g. chain scores)
+template <int CAP>
+__global__ __launch_bounds__(NT) void k_sort_block(rh_sort_job jb, uint32_t n_lo, uint32_t n_hi, int mode)
+{
+	__shared__ sort_lds<CAP> L;
+	const uint32_t a = blockIdx.x, tid = threadIdx.x;
+	if (a >= jb.n_seg || (jb.skip && jb.skip[a])) return;
+	const uint64_t base = jb.off[a];
+	const uint32_t n = jb.cnt ? jb.cnt[a] : (uint32_t)(jb.off[a + 1] - base);
+	if (n <= n_lo || n > n_hi) return;
+	const rh_mm128_t *src = jb.src + base;
+	rh_mm128_t *dst = jb.dst + base;
+	KPROF_DECL;
+#ifdef RH_KPROF
+	if (tid == 0) L.prof = jb.scratch_skip == 0 ? 1u : 0u;      // profile the anchor sort only
 	__syncthreads();
-	if (!exact) {
-		uint32_t tie = 0;
-		for (uint32_t i = tid + 1; i < n; i += NT) if (L.key[L.ia[i]] == L.key[L.ia[i - 1]]) tie = 1;
-		if (tie) L.tie = 1;
+#endif
+	for (uint32_t i = tid; i < n; i += NT) L.key[i] = src[i].x;
+	for (uint32_t i = tid; i < CAP / 32 + 3; i += NT) L.tbit[i] = 0;
+	if (tid == 0) L.tie = 0;
+	__syncthreads();
+	KPROF(10);
+	sort_run<CAP>(L, n, mode == 0 ? SORT_FAST : SORT_EXACT_ALL);
+#ifdef RH_KPROF
+	kp_t0 = clock64();
+#endif
+	if (mode == 0) {
+		for (uint32_t i = tid + 1; i < n; i += NT) {
+			const uint32_t p = L.ia[i - 1], q = L.ia[i];
+			if (L.key[p] == L.key[q]) { atomicOr(&L.tbit[p >> 5], 1u << (p & 31u)); atomicOr(&L.tbit[q >> 5], 1u << (q & 31u)); L.tie = 1; }
+		}
 		__syncthreads();
-		if (tid == 0) jb.need_exact[a] = (uint8_t)L.tie;
-		if (L.tie) return;
+		const uint32_t tie = L.tie;
+		if (tid == 0 && jb.need_exact) jb.need_exact[a] = (uint8_t)tie;
+		KPROF(11);
+		if (tie) sort_run<CAP>(L, n, SORT_EXACT_TIED);
+#ifdef RH_KPROF
+		kp_t0 = clock64();
+#endif
 	}
 	for (uint32_t i = tid; i < n; i += NT) dst[i] = src[L.ia[i]];
+	KPROF(12);
 }
 
 // reads too large for LDS: copy, then the serial in-place emulation (one read per lane)
@@ -198,10 +355,13 @@ __global__ void k_sort_big(rh_sort_job jb, uint32_t n_lo)
 }
 
 #ifndef RH_SORT_CAP1
-#define RH_SORT_CAP1 4096     // ~72 KB of LDS: two workgroups per CU
+#define RH_SORT_CAP1 4096     // ~52 KB of LDS: three workgroups per CU
 #endif
 #ifndef RH_SORT_CAP2
-#define RH_SORT_CAP2 8192     // ~141 KB of LDS: one workgroup per CU (reads that carry many chained anchors)
+#define RH_SORT_CAP2 6144     // ~77 KB of LDS: two workgroups per CU (unmapped reads accumulate carried anchors)
+#endif
+#ifndef RH_SORT_CAP3
+#define RH_SORT_CAP3 8192     // ~102 KB of LDS: one workgroup per CU
 #endif
 
 #ifndef RH_SORT_CAP0
@@ -211,11 +371,7 @@ __global__ void k_sort_big(rh_sort_job jb, uint32_t n_lo)
 template <int CAP>
 static void launch_class(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t lo, uint32_t hi)
 {
-	if (all_exact) RH_LAUNCH(k_sort_block<CAP>, jb.n_seg, NT, 0, s, jb, lo, hi, 2);
-	else {
-		RH_LAUNCH(k_sort_block<CAP>, jb.n_seg, NT, 0, s, jb, lo, hi, 0);
-		RH_LAUNCH(k_sort_block<CAP>, jb.n_seg, NT, 0, s, jb, lo, hi, 1);
-	}
+	RH_LAUNCH(k_sort_block<CAP>, jb.n_seg, NT, 0, s, jb, lo, hi, all_exact ? 2 : 0);
 }
 
 void rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n)
@@ -224,7 +380,8 @@ void rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t
 	launch_class<RH_SORT_CAP0>(s, jb, all_exact, min_n, (uint32_t)RH_SORT_CAP0);
 	launch_class<RH_SORT_CAP1>(s, jb, all_exact, (uint32_t)RH_SORT_CAP0, (uint32_t)RH_SORT_CAP1);
 	launch_class<RH_SORT_CAP2>(s, jb, all_exact, (uint32_t)RH_SORT_CAP1, (uint32_t)RH_SORT_CAP2);
-	RH_LAUNCH(k_sort_big, (jb.n_seg + 63) / 64, 64, 0, s, jb, (uint32_t)RH_SORT_CAP2);
+	launch_class<RH_SORT_CAP3>(s, jb, all_exact, (uint32_t)RH_SORT_CAP2, (uint32_t)RH_SORT_CAP3);
+	RH_LAUNCH(k_sort_big, (jb.n_seg + 63) / 64, 64, 0, s, jb, (uint32_t)RH_SORT_CAP3);
 }
 
 // anchor sort of a chunk round: unsorted expand output -> reference order

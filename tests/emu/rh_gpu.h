@@ -54,6 +54,7 @@ static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if 
 static inline unsigned rh_readlane(unsigned v, unsigned l) { return (unsigned)emu_shfl_bits(v, 5, l); }
 static inline unsigned rh_writelane(unsigned v, unsigned val, unsigned l) { return (threadIdx.x & 63u) == l ? val : v; }
 static inline unsigned rh_uniform(unsigned v) { return v; }
+#define RH_WAVE_SYNC() ((void)emu_ballot(1))
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) (*(p))
 
