@@ -50,6 +50,8 @@ struct rh_ctx_s {
 	DevBuf sy_samples, sy_off, sy_cal_off, sy_cal_scale, sy_levels;
 	// timing
 	hipEvent_t e0 = nullptr, e1 = nullptr;
+	std::vector<hipEvent_t> ev_pool; std::vector<int> ev_stage; size_t ev_used = 0;   // stage timers of the batch in flight
+	uint64_t *pin = nullptr;                                       // pinned host words for the per-round read-backs
 	rh_map_stats_t stats{};
 	// concurrent sub-batches: extra contexts (own stream + arenas) that borrow this context's index and tables
 	std::vector<rh_ctx*> subs;
@@ -59,19 +61,29 @@ struct rh_ctx_s {
 
 namespace {
 
+// Stage timing without stalling the stream: start/stop events come from a per-context pool, are only recorded here, and
+// are read back by stage_timers_collect() after the batch's final synchronisation.
 struct StageTimer {
-	rh_ctx *c; int stage;
-	StageTimer(rh_ctx *ctx, int st) : c(ctx), stage(st) { (void)hipEventRecord(c->e0, c->stream); }
-	~StageTimer()
+	rh_ctx *c; int stage; size_t slot;
+	StageTimer(rh_ctx *ctx, int st) : c(ctx), stage(st)
 	{
-		(void)hipEventRecord(c->e1, c->stream);
-		(void)hipEventSynchronize(c->e1);
-		float ms = 0;
-		(void)hipEventElapsedTime(&ms, c->e0, c->e1);
-		c->stats.ms_kernel[stage] += ms;
-		c->stats.n_launch[stage] += 1;
+		slot = c->ev_used;
+		while (c->ev_pool.size() < slot + 2) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) break; c->ev_pool.push_back(e); }
+		if (c->ev_pool.size() >= slot + 2) { c->ev_used += 2; c->ev_stage.push_back(stage); (void)hipEventRecord(c->ev_pool[slot], c->stream); }
+		else slot = (size_t)-1;
 	}
+	~StageTimer() { if (slot != (size_t)-1) (void)hipEventRecord(c->ev_pool[slot + 1], c->stream); }
 };
+
+void stage_timers_collect(rh_ctx *c)
+{
+	for (size_t k = 0; k < c->ev_stage.size(); ++k) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, c->ev_pool[2 * k], c->ev_pool[2 * k + 1]) == hipSuccess) c->stats.ms_kernel[c->ev_stage[k]] += ms;
+		c->stats.n_launch[c->ev_stage[k]] += 1;
+	}
+	c->ev_used = 0; c->ev_stage.clear();
+}
 
 int fill_dev_opt(const rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
 {
@@ -221,6 +233,8 @@ extern "C" void rh_ctx_destroy(rh_ctx *c)
 	for (DevBuf *b : all) b->release();
 	for (DevBuf &b : c->st) b.release();
 	if (c->blob_owned) c->blob.release();
+	for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+	if (c->pin) (void)hipHostFree(c->pin);
 	if (c->e0) (void)hipEventDestroy(c->e0);
 	if (c->e1) (void)hipEventDestroy(c->e1);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -359,6 +373,7 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 	if (out_cap < R) { rh_set_error("output capacity %llu < %u reads", (unsigned long long)out_cap, R); return -1; }
 	if (R == 0) return 0;
 	memset(&c->stats, 0, sizeof(c->stats));
+	c->ev_used = 0; c->ev_stage.clear();
 	const auto t_begin = std::chrono::steady_clock::now();
 	hipStream_t s = c->stream;
 	rh_dev_reads rd;
@@ -368,9 +383,11 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 	{ StageTimer t(c, ST_PREFILTER); rhk_prefilter(s, o, rd); }
 	int cur = 0;
 	{ StageTimer t(c, ST_COMPACT); rhk_compact_active(s, o, rd, nullptr, R, 0, c->act[cur].as<uint32_t>(), c->n_act_dev.as<uint32_t>()); }
+	if (!c->pin) RH_HIP(hipHostMalloc((void**)&c->pin, 64, 0));
 	uint32_t n_act = 0;
-	RH_HIP(hipMemcpyAsync(&n_act, c->n_act_dev.p, 4, hipMemcpyDeviceToHost, s));
+	RH_HIP(hipMemcpyAsync(c->pin, c->n_act_dev.p, 4, hipMemcpyDeviceToHost, s));
 	RH_HIP(hipStreamSynchronize(s));
+	n_act = (uint32_t)c->pin[0];
 	int which = 0;
 	for (uint32_t chunk = 0; chunk < mo->max_num_chunk && n_act > 0; ++chunk) {
 		rh_dev_round rr{};
@@ -383,8 +400,9 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 		{ StageTimer t(c, ST_SKETCH); rhk_sketch(s, o, c->dix, rd, rr); }
 		{ StageTimer t(c, ST_PROBE); rhk_probe(s, o, c->dix, rd, rr); }
 		uint64_t total = 0;
-		{ StageTimer t(c, ST_SCAN); rhk_scan_anchors(s, rd, rr); RH_HIP(hipMemcpyAsync(&total, rr.a_off + n_act, 8, hipMemcpyDeviceToHost, s)); }
+		{ StageTimer t(c, ST_SCAN); rhk_scan_anchors(s, rd, rr); RH_HIP(hipMemcpyAsync(c->pin + 1, rr.a_off + n_act, 8, hipMemcpyDeviceToHost, s)); }
 		RH_HIP(hipStreamSynchronize(s));
+		total = c->pin[1];
 		if (stage_anchors(c, total, which, &rr)) return -1;
 		{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rr); }
 		{ StageTimer t(c, ST_SORT); rhk_sort(s, rr); }
@@ -396,8 +414,9 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 		{ StageTimer t(c, ST_REGIONS); rhk_regions(s, o, rd, rr, c->logf_tab.as<float>()); }
 		if (debug_rounds()) dump_round2(c, chunk, n_act, rr);
 		{ StageTimer t(c, ST_COMPACT); rhk_compact_active(s, o, rd, rr.act, n_act, chunk + 1, c->act[cur ^ 1].as<uint32_t>(), c->n_act_dev.as<uint32_t>()); }
-		RH_HIP(hipMemcpyAsync(&n_act, c->n_act_dev.p, 4, hipMemcpyDeviceToHost, s));
+		RH_HIP(hipMemcpyAsync(c->pin, c->n_act_dev.p, 4, hipMemcpyDeviceToHost, s));
 		RH_HIP(hipStreamSynchronize(s));
+		n_act = (uint32_t)c->pin[0];
 		cur ^= 1; which ^= 1;
 	}
 	{ StageTimer t(c, ST_FINALIZE); rhk_finalize(s, o, c->dix, rd, c->rec.as<rh_map_record_t>()); }
@@ -410,6 +429,8 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 		c->stats.n_events = cnt[0]; c->stats.n_seeds = cnt[1]; c->stats.n_hits = cnt[2]; c->stats.n_anchors = cnt[3]; c->stats.n_chained = cnt[4];
 		c->stats.n_samples_used = cnt[5]; c->stats.n_chunks = cnt[6];
 	}
+	RH_HIP(hipStreamSynchronize(s));                                // the last stop event
+	stage_timers_collect(c);
 	RH_HIP(hipGetLastError());
 	c->stats.n_reads = R;
 	c->stats.n_samples_raw = in->samples_on_device ? 0 : in->offsets[R] - in->offsets[0];
