@@ -22,42 +22,64 @@
 #define CH_SMALL 12     // clusters of up to this many anchors: the plain loop, one cluster per lane
 #endif
 
-// The reference loop (lchain.c:439-505) on one small cluster [b, b + m), entirely in one lane.
+// The reference loop (lchain.c:439-505) on one small cluster [b, b + m) per lane (m == 0: lane has none), with every
+// array index a compile-time constant: the loops over i and j are fully unrolled and predicated, so the per-lane state
+// stays in plain VGPRs (a lane-dependent index into a register array would cost a waterfall loop per access).  The t[]
+// marks of the reference become a bit mask per i; the state of max_ii is carried as values, not as an index.
 RH_DEV void chain_small_cluster(const rh_mm128_t *an, int32_t *gfp, int32_t *gv, int32_t b, int32_t m, int32_t max_dist_t, int32_t max_dist_q,
                                 int32_t bw, int32_t max_iter, int32_t max_skip, float pen_gap, float pen_skip)
 {
 	uint32_t xl[CH_SMALL], yl[CH_SMALL];
-	int32_t f[CH_SMALL], p[CH_SMALL], v[CH_SMALL], t[CH_SMALL], sp[CH_SMALL];
+	int32_t f[CH_SMALL], p[CH_SMALL], v[CH_SMALL], sp[CH_SMALL];
 	const uint32_t D32 = (uint32_t)max_dist_t;
-	for (int32_t k = 0; k < m; ++k) { const rh_mm128_t q = an[b + k]; xl[k] = (uint32_t)q.x; yl[k] = (uint32_t)q.y; sp[k] = (int32_t)((q.y >> 32) & 63); t[k] = -1; }
-	int32_t st = 0, max_ii = -1;
-	for (int32_t i = 0; i < m; ++i) {
-		int32_t max_f = sp[i], max_j = -1, n_skip = 0, j;
-		if (i - st > max_iter) st = i - max_iter;
-		while (st < i && (uint32_t)(xl[i] - xl[st]) > D32) ++st;
-		for (j = i - 1; j >= st; --j) {
-			int32_t sc = rh_pair_score_d((int32_t)yl[i] - (int32_t)yl[j], (int32_t)(xl[i] - xl[j]), sp[j], max_dist_t, max_dist_q, bw, pen_gap, pen_skip);
-			if (sc == RH_SCORE_NONE) continue;
-			sc += f[j];
-			if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
-			else if (t[j] == i) { if (++n_skip > max_skip) break; }
-			if (p[j] >= 0) t[p[j]] = i;
-		}
-		const int32_t end_j = j;
-		if (max_ii < 0 || (uint32_t)(xl[i] - xl[max_ii]) > D32) {
-			int32_t mx = INT32_MIN;
-			max_ii = -1;
-			for (j = i - 1; j >= st; --j) if (mx < f[j]) { mx = f[j]; max_ii = j; }
-		}
-		if (max_ii >= 0 && max_ii < end_j) {
-			const int32_t tmp = rh_pair_score_d((int32_t)yl[i] - (int32_t)yl[max_ii], (int32_t)(xl[i] - xl[max_ii]), sp[max_ii], max_dist_t, max_dist_q, bw, pen_gap, pen_skip);
-			if (tmp != RH_SCORE_NONE && max_f < tmp + f[max_ii]) { max_f = tmp + f[max_ii]; max_j = max_ii; }
-		}
-		f[i] = max_f; p[i] = max_j;
-		v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
-		if (max_ii < 0 || ((uint32_t)(xl[i] - xl[max_ii]) <= D32 && f[max_ii] < f[i])) max_ii = i;
+#pragma unroll
+	for (int k = 0; k < CH_SMALL; ++k) {
+		xl[k] = 0; yl[k] = 0; sp[k] = 0; f[k] = 0; p[k] = -1; v[k] = 0;
+		if (k < m) { const rh_mm128_t q = an[b + k]; xl[k] = (uint32_t)q.x; yl[k] = (uint32_t)q.y; sp[k] = (int32_t)((q.y >> 32) & 63); }
 	}
-	for (int32_t k = 0; k < m; ++k) { gfp[2 * (b + k)] = f[k]; gfp[2 * (b + k) + 1] = p[k] < 0 ? -1 : b + p[k]; gv[b + k] = v[k]; }
+	int32_t st = 0, mi = -1, f_ii = 0, sp_ii = 0, v_ii = 0;
+	uint32_t x_ii = 0, y_ii = 0;
+#pragma unroll
+	for (int i = 0; i < CH_SMALL; ++i) {
+		if (__ballot(i < m) == 0) break;
+		if (i < m) {
+			const uint32_t xi = xl[i], yi = yl[i];
+			int32_t max_f = sp[i], max_j = -1, v_mj = 0, n_skip = 0, end_j = 0;
+			uint32_t tm = 0;                                       // bit j: t[j] == i in the reference's terms
+			bool broke = false;
+			if (i - st > max_iter) st = i - max_iter;
+#pragma unroll
+			for (int k = 0; k < i; ++k) if (st == k && (uint32_t)(xi - xl[k]) > D32) st = k + 1;
+#pragma unroll
+			for (int j = i - 1; j >= 0; --j) {
+				if (!broke && j >= st) {
+					int32_t sc = rh_pair_score_d((int32_t)yi - (int32_t)yl[j], (int32_t)(xi - xl[j]), sp[j], max_dist_t, max_dist_q, bw, pen_gap, pen_skip);
+					if (sc != RH_SCORE_NONE) {
+						sc += f[j];
+						if (sc > max_f) { max_f = sc; max_j = j; v_mj = v[j]; if (n_skip > 0) --n_skip; }
+						else if ((tm >> j) & 1u) { if (++n_skip > max_skip) { broke = true; end_j = j; } }
+						if (!broke && p[j] >= 0) tm |= 1u << p[j];
+					}
+				}
+			}
+			if (!broke) end_j = st - 1;
+			if (mi < 0 || (uint32_t)(xi - x_ii) > D32) {
+				int32_t mx = INT32_MIN;
+				mi = -1;
+#pragma unroll
+				for (int j = i - 1; j >= 0; --j) if (j >= st && mx < f[j]) { mx = f[j]; mi = j; x_ii = xl[j]; y_ii = yl[j]; sp_ii = sp[j]; v_ii = v[j]; }
+				f_ii = mx;
+			}
+			if (mi >= 0 && mi < end_j) {
+				const int32_t tmp = rh_pair_score_d((int32_t)yi - (int32_t)y_ii, (int32_t)(xi - x_ii), sp_ii, max_dist_t, max_dist_q, bw, pen_gap, pen_skip);
+				if (tmp != RH_SCORE_NONE && max_f < tmp + f_ii) { max_f = tmp + f_ii; max_j = mi; v_mj = v_ii; }
+			}
+			const int32_t vv = (max_j >= 0 && v_mj > max_f) ? v_mj : max_f;
+			f[i] = max_f; p[i] = max_j; v[i] = vv;
+			gfp[2 * (b + i)] = max_f; gfp[2 * (b + i) + 1] = max_j < 0 ? -1 : b + max_j; gv[b + i] = vv;
+			if (mi < 0 || ((uint32_t)(xi - x_ii) <= D32 && f_ii < max_f)) { mi = i; f_ii = max_f; x_ii = xi; y_ii = yi; sp_ii = sp[i]; v_ii = vv; }
+		}
+	}
 }
 
 struct chain_lds {
@@ -114,9 +136,9 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 				if ((xq >> 32) != (xp >> 32) || xq > xp + D64) break;
 				xp = xq; ++csz;
 			}
-			if (csz <= CH_SMALL) chain_small_cluster(an, gfp, gv, ii, csz, max_dist_t, max_dist_q, bw, max_iter, max_skip, o.pen_gap, o.pen_skip);
 		}
 		const uint64_t small_mask = __ballot(csz > 0 && csz <= CH_SMALL);
+		if (small_mask) chain_small_cluster(an, gfp, gv, ii, (csz > 0 && csz <= CH_SMALL) ? csz : 0, max_dist_t, max_dist_q, bw, max_iter, max_skip, o.pen_gap, o.pen_skip);
 		uint64_t mmask = __ballot(inb && !single);                  // members of multi-anchor clusters, walked in order
 		while (mmask) {
 			const int b = __builtin_ctzll(mmask);
