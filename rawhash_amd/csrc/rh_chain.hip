@@ -112,30 +112,34 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 	int32_t st = 0, max_ii = -1, f_ii = 0, skip_until = 0;
 	uint32_t xlo_ii = 0;
 	uint64_t x_before = 0;                                         // x of the anchor preceding the tile
+	// software pipeline over the tiles: A = current, B = next (needed to size a cluster that runs over the tile edge), C in flight
+	uint64_t xB = 0, yB = 0, xC = 0, yC = 0;
+	if ((int32_t)lane < n) { xB = an[lane].x; yB = an[lane].y; }
+	if (64 + (int32_t)lane < n) { xC = an[64 + lane].x; yC = an[64 + lane].y; }
 	for (int32_t i0 = 0; i0 < n; i0 += 64) {
 		const int32_t ii = i0 + (int32_t)lane;
 		const bool inb = ii < n;
-		const uint64_t x = inb ? an[ii].x : 0ull, y = inb ? an[ii].y : 0ull;
+		const uint64_t x = xB, y = yB;
+		xB = xC; yB = yC;
+		if (ii + 128 < n) { xC = an[ii + 128].x; yC = an[ii + 128].y; } else { xC = 0; yC = 0; }
 		uint64_t xprev = __shfl_up(x, 1);
 		if (lane == 0) xprev = x_before;
 		const bool start = inb && (ii == 0 || (x >> 32) != (xprev >> 32) || x > xprev + D64);
 		const uint64_t smask = __ballot(start);
+		const uint64_t bmask = __ballot(start || !inb);               // cluster boundaries, the end of the array included
 		const uint64_t x_last = __shfl(x, 63);
-		bool next_tile_start = true;
-		if (i0 + 64 < n) { const uint64_t xn = an[i0 + 64].x; next_tile_start = (xn >> 32) != (x_last >> 32) || xn > x_last + D64; }
-		const bool nstart = (ii + 1 >= n) ? true : (lane < 63 ? ((smask >> (lane + 1)) & 1ull) != 0 : next_tile_start);
+		uint64_t xprevB = __shfl_up(xB, 1);
+		if (lane == 0) xprevB = x_last;
+		const uint64_t bmaskB = __ballot(ii + 64 >= n || (xB >> 32) != (xprevB >> 32) || xB > xprevB + D64);   // same for the next tile
+		const bool nstart = lane < 63 ? ((bmask >> (lane + 1)) & 1ull) != 0 : (bmaskB & 1ull) != 0;
 		const bool single = start && nstart;
 		if (inb && single) { const int32_t sp = (int32_t)((y >> 32) & 63); gfp[2 * ii] = sp; gfp[2 * ii + 1] = -1; gv[ii] = sp; }
 		// small clusters: their start lane runs the plain loop for the whole cluster (all lanes busy on different clusters)
 		int32_t csz = 0;
 		if (inb && start && !single) {
-			csz = 1;
-			uint64_t xp = x;
-			while (csz <= CH_SMALL && ii + csz < n) {
-				const uint64_t xq = an[ii + csz].x;
-				if ((xq >> 32) != (xp >> 32) || xq > xp + D64) break;
-				xp = xq; ++csz;
-			}
+			const uint64_t after = lane < 63 ? bmask >> (lane + 1) : 0ull;
+			if (after) csz = 1 + __builtin_ctzll(after);
+			else csz = (64 - (int32_t)lane) + (bmaskB ? __builtin_ctzll(bmaskB) : CH_SMALL + 1);
 		}
 		const uint64_t small_mask = __ballot(csz > 0 && csz <= CH_SMALL);
 		if (small_mask) chain_small_cluster(an, gfp, gv, ii, (csz > 0 && csz <= CH_SMALL) ? csz : 0, max_dist_t, max_dist_q, bw, max_iter, max_skip, o.pen_gap, o.pen_skip);
