@@ -192,7 +192,9 @@ RH_DEV void sort_split_range(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s
 	diff = block_or64(diff, L.r64);                           // (barriers inside publish L.w as well)
 	KPROF(1);
 	if (diff == 0) return;                                   // all keys equal: every remaining pass is an identity
-	const bool exact = pass == SORT_EXACT_ALL || (pass == SORT_EXACT_TIED && (L.w[0] | L.w[1] | L.w[2] | L.w[3]) != 0);
+	// redo pass: a range without tied keys already has its (unique) final order from the fast pass -> nothing to do
+	if (pass == SORT_EXACT_TIED && (L.w[0] | L.w[1] | L.w[2] | L.w[3]) == 0) return;
+	const bool exact = pass != SORT_FAST;
 	int s = (63 - __clzll(diff)) & ~7;
 	if (s > shift) s = shift;
 	// digit histogram
@@ -265,8 +267,8 @@ RH_DEV void sort_run(sort_lds<CAP> &L, uint32_t n, int pass)
 	// Ranges of <= 64 records get klib's insertion sort, i.e. any STABLE sort: one wavefront per range computes each
 	// record's rank (smaller keys + equal keys that come earlier) with broadcast LDS reads and scatters in one step.
 	KPROF(8);
-	const uint32_t nw32 = (n + 31) / 32;
-	for (uint32_t wi = wave_id(); wi < nw32; wi += NT / 64) {
+	const uint32_t nw32 = (n + 31) / 32, wv = rh_uniform(wave_id());
+	for (uint32_t wi = wv; wi < nw32; wi += NT / 64) {
 		uint32_t sb = rh_uniform(L.sbit[wi]);
 		while (sb) {
 			const uint32_t bit = (uint32_t)__builtin_ctz(sb);
@@ -277,12 +279,16 @@ RH_DEV void sort_run(sort_lds<CAP> &L, uint32_t n, int pass)
 			else { uint32_t x = wi + 1; while ((ew = rh_uniform(L.ebit[x])) == 0) ++x; e = x * 32 + (uint32_t)__builtin_ctz(ew); }
 			const uint32_t m = e - b + 1, l = lane_id();
 			const uint16_t idx = L.ia[b + (l < m ? l : 0u)];
+			if (pass == SORT_EXACT_TIED && __ballot((L.tbit[idx >> 5] >> (idx & 31u)) & 1u) == 0) continue;   // final since the fast pass
 			const uint64_t k = L.key[idx];
 			const uint32_t klo = (uint32_t)k, khi = (uint32_t)(k >> 32);
 			uint32_t rank = 0;
 			// the other records' keys come from their lanes' registers (v_readlane with the wave-uniform j), not from LDS
-			if (__ballot(khi != rh_readlane(khi, 0)) == 0) {
-				for (uint32_t j = 0; j < m; ++j) { const uint32_t kj = rh_readlane(klo, j); rank += (kj < klo || (kj == klo && j < l)) ? 1u : 0u; }
+			const uint32_t khi0 = rh_readlane(khi, 0), klo0 = rh_readlane(klo, 0);
+			if (__ballot(khi != khi0 || ((klo ^ klo0) >> 26) != 0) == 0) {
+				// the keys differ in their low 26 bits only: (key bits, position) in one word makes the stable order a plain '<'
+				const uint32_t c = klo << 6 | l;
+				for (uint32_t j = 0; j < m; ++j) rank += rh_readlane(c, j) < c ? 1u : 0u;
 			} else {
 				for (uint32_t j = 0; j < m; ++j) {
 					const uint64_t kj = (uint64_t)rh_readlane(khi, j) << 32 | rh_readlane(klo, j);
@@ -324,22 +330,23 @@ __global__ __launch_bounds__(NT) void k_sort_block(rh_sort_job jb, uint32_t n_lo
 #ifdef RH_KPROF
 	kp_t0 = clock64();
 #endif
-	if (mode == 0) {
-		for (uint32_t i = tid + 1; i < n; i += NT) {
-			const uint32_t p = L.ia[i - 1], q = L.ia[i];
-			if (L.key[p] == L.key[q]) { atomicOr(&L.tbit[p >> 5], 1u << (p & 31u)); atomicOr(&L.tbit[q >> 5], 1u << (q & 31u)); L.tie = 1; }
-		}
-		__syncthreads();
-		const uint32_t tie = L.tie;
-		if (tid == 0 && jb.need_exact) jb.need_exact[a] = (uint8_t)tie;
-		KPROF(11);
-		if (tie) sort_run<CAP>(L, n, SORT_EXACT_TIED);
-#ifdef RH_KPROF
-		kp_t0 = clock64();
-#endif
-	}
 	for (uint32_t i = tid; i < n; i += NT) dst[i] = src[L.ia[i]];
 	KPROF(12);
+	if (mode != 0) return;
+	for (uint32_t i = tid + 1; i < n; i += NT) {
+		const uint32_t p = L.ia[i - 1], q = L.ia[i];
+		if (L.key[p] == L.key[q]) { atomicOr(&L.tbit[p >> 5], 1u << (p & 31u)); atomicOr(&L.tbit[q >> 5], 1u << (q & 31u)); L.tie = 1; }
+	}
+	__syncthreads();
+	const uint32_t tie = L.tie;
+	if (tid == 0 && jb.need_exact) jb.need_exact[a] = (uint8_t)tie;
+	KPROF(11);
+	if (!tie) return;
+	// Equal keys: their order is the reference's cycle-leader permutation.  Redo the sort from the input order on the ranges
+	// that hold tied keys only; every other record already sits at its final place, and so does each group of equal keys
+	// as a whole - only the records inside the groups are rewritten.
+	sort_run<CAP>(L, n, SORT_EXACT_TIED);
+	for (uint32_t i = tid; i < n; i += NT) { const uint32_t idx = L.ia[i]; if ((L.tbit[idx >> 5] >> (idx & 31u)) & 1u) dst[i] = src[idx]; }
 }
 
 // reads too large for LDS: copy, then the serial in-place emulation (one read per lane)
