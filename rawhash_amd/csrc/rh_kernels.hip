@@ -91,9 +91,9 @@ RH_DEV float tstat_at(const float *ps, const float *pss, uint32_t n, uint32_t w,
 
 __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
 {
-	__shared__ float s_z[RH_CHUNK_MAX];
-	__shared__ float s_a[RH_CHUNK_MAX + 1];      // pA staging -> prefix sums
-	__shared__ float s_b[RH_CHUNK_MAX + 1];      // prefix sums of squares
+	__shared__ __attribute__((aligned(16))) float s_z[RH_CHUNK_MAX];
+	__shared__ __attribute__((aligned(16))) float s_a[RH_CHUNK_MAX + 4];      // pA staging -> prefix sums (at +3)
+	__shared__ __attribute__((aligned(16))) float s_b[RH_CHUNK_MAX + 4];      // prefix sums of squares (at +3)
 	__shared__ uint32_t s_w[NT / 64];
 	__shared__ double s_red[2 * (NT / 64)];
 	__shared__ double s_stat[2];
@@ -159,19 +159,30 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 	if (tid == 0) rr.n_norm[a] = n;
 	if (n == 0) return;
 
-	// 3. fp32 prefix sums, strictly left to right (order-sensitive: one lane)
-	if (tid == 0) {
-		float ps = 0.0f, pss = 0.0f;
-		s_a[0] = 0.0f; s_b[0] = 0.0f;
+	// 3. fp32 prefix sums, strictly left to right (order-sensitive).  The two sums are independent chains: one lane of
+	//    wave 0 accumulates z, one lane of wave 1 accumulates z*z, concurrently.  The prefix arrays are stored shifted by
+	//    3 floats so that entries 4k+1 .. 4k+4 form one aligned 16-byte LDS store.
+	float *pa = s_a + 3, *pb = s_b + 3;
+	if (tid == 0 || tid == 64) {
+		const bool sq = tid == 64;
+		float *dst = sq ? pb : pa;
+		float acc = 0.0f;
+		dst[0] = 0.0f;
 		uint32_t i = 0;
 		for (; i + 8 <= n; i += 8) {
-			float z[8];
-			#pragma unroll
-			for (int k = 0; k < 8; ++k) z[k] = s_z[i + k];
-			#pragma unroll
-			for (int k = 0; k < 8; ++k) { ps = ps + z[k]; pss = pss + z[k] * z[k]; s_a[i + k + 1] = ps; s_b[i + k + 1] = pss; }
+			const float4 z0 = *reinterpret_cast<const float4*>(&s_z[i]), z1 = *reinterpret_cast<const float4*>(&s_z[i + 4]);
+			float4 r0, r1;
+			if (sq) {
+				r0.x = acc = acc + z0.x * z0.x; r0.y = acc = acc + z0.y * z0.y; r0.z = acc = acc + z0.z * z0.z; r0.w = acc = acc + z0.w * z0.w;
+				r1.x = acc = acc + z1.x * z1.x; r1.y = acc = acc + z1.y * z1.y; r1.z = acc = acc + z1.z * z1.z; r1.w = acc = acc + z1.w * z1.w;
+			} else {
+				r0.x = acc = acc + z0.x; r0.y = acc = acc + z0.y; r0.z = acc = acc + z0.z; r0.w = acc = acc + z0.w;
+				r1.x = acc = acc + z1.x; r1.y = acc = acc + z1.y; r1.z = acc = acc + z1.z; r1.w = acc = acc + z1.w;
+			}
+			*reinterpret_cast<float4*>(&dst[i + 1]) = r0;
+			*reinterpret_cast<float4*>(&dst[i + 5]) = r1;
 		}
-		for (; i < n; ++i) { const float z = s_z[i]; ps = ps + z; pss = pss + z * z; s_a[i + 1] = ps; s_b[i + 1] = pss; }
+		for (; i < n; ++i) { const float z = s_z[i]; acc = acc + (sq ? z * z : z); dst[i + 1] = acc; }
 	}
 	__syncthreads();
 
@@ -179,8 +190,8 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 	float *zrow = rr.zbuf + (size_t)a * EV_ROW, *t1row = rr.t1buf + (size_t)a * EV_ROW, *t2row = rr.t2buf + (size_t)a * EV_ROW;
 	for (uint32_t i = tid; i < n; i += NT) {
 		zrow[i] = s_z[i];
-		t1row[i] = tstat_at(s_a, s_b, n, o.w1, i);
-		t2row[i] = tstat_at(s_a, s_b, n, o.w2, i);
+		t1row[i] = tstat_at(pa, pb, n, o.w1, i);
+		t2row[i] = tstat_at(pa, pb, n, o.w2, i);
 	}
 }
 
