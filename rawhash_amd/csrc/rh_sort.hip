@@ -45,6 +45,7 @@ struct sort_lds {
 	uint32_t rng[2][CAP / 64 + 4];             // ranges > 64 still to be split: beg | end << 16
 	uint8_t rsh[2][CAP / 64 + 4];              // ... and the byte shift they are to be split on next
 	uint32_t cnt[256], head[256];
+	uint8_t dmap[256], inv[256];                 // digit -> rank among the non-empty buckets, and back
 	uint32_t w[NT / 64];
 	uint64_t r64[NT / 64];
 	uint32_t n_rng[2], tie, misc[4], prof;
@@ -133,11 +134,13 @@ RH_DEV void sort_two_buckets(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s
 }
 
 // The reference's cycle walk over >= 3 buckets, replayed by ONE wavefront (all lanes in lock step on wave-uniform
-// values).  State lives in registers: the digit of relative position p is byte (p & 3) of VGPR [p >> 8] in lane
-// ((p >> 2) & 63); lane (c & 63) holds the head / tail of bucket c in VGPR [c >> 6].  Each step is a couple of
-// v_readlane; the only memory operation is the fire-and-forget LDS store of the gather map xm[dest] = source.
-template <int CAP>
-RH_DEV void sort_cycle_walk(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s)
+// values).  A single wavefront issues roughly one instruction every 5 cycles, so the walk is as fast as its step is
+// short.  State lives in registers: the non-empty buckets are renumbered 0 .. nbk-1 in digit order; the dense digit of
+// relative position p is byte (p & 3) of VGPR [p >> 8] in lane ((p >> 2) & 63); lane (c & 63) holds the head / tail of
+// dense bucket c in VGPR [c >> 6] (HB = 1, 2 or 4 of them, picked by nbk).  Each step is a couple of v_readlane; the only
+// memory operation is the fire-and-forget LDS store of the gather map xm[dest] = source.
+template <int CAP, int HB>
+RH_DEV void sort_cycle_walk_hb(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s, uint32_t nbk)
 {
 	constexpr int NR = (CAP + 255) / 256;
 	const uint32_t lane = lane_id(), n = end - beg;
@@ -147,30 +150,47 @@ RH_DEV void sort_cycle_walk(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s)
 		uint32_t w = 0;
 		const uint32_t p0 = ((uint32_t)q * 64u + lane) * 4u;
 		if (p0 < n) {
-			for (uint32_t b = 0; b < 4; ++b) if (p0 + b < n) w |= sort_digit(L, beg + p0 + b, s) << (8 * b);
+			for (uint32_t b = 0; b < 4; ++b) if (p0 + b < n) w |= (uint32_t)L.dmap[sort_digit(L, beg + p0 + b, s)] << (8 * b);
 		}
 		dg[q] = w;
 	}
-	uint32_t hd[4], tl[4];
+	uint32_t hd[HB], tl[HB];
 #pragma unroll
-	for (int q = 0; q < 4; ++q) { hd[q] = L.head[q * 64 + lane] - beg; tl[q] = hd[q] + L.cnt[q * 64 + lane]; }
-	for (uint32_t c = 0; c < 256; ++c) {
-		const uint32_t tlc = rh_readlane(tl[c >> 6], c & 63u);
-		uint32_t h = rh_readlane(hd[c >> 6], c & 63u);
+	for (int q = 0; q < HB; ++q) {
+		const uint32_t id = (uint32_t)q * 64u + lane;
+		hd[q] = 0; tl[q] = 0;
+		if (id < nbk) { const uint32_t dgt = L.inv[id]; hd[q] = L.head[dgt] - beg; tl[q] = hd[q] + L.cnt[dgt]; }
+	}
+	const uint32_t ubeg = rh_uniform(beg);
+	for (uint32_t c = 0; c < nbk; ++c) {
+		uint32_t tlc = rh_readlane(tl[0], c & 63u), h = rh_readlane(hd[0], c & 63u);
+#pragma unroll
+		for (int q = 1; q < HB; ++q) { const uint32_t t2 = rh_readlane(tl[q], c & 63u), h2 = rh_readlane(hd[q], c & 63u); if ((c >> 6) == (uint32_t)q) { tlc = t2; h = h2; } }
 		while (h != tlc) {
 			uint32_t src = h;
 			uint32_t d = (rh_readlane(dg[h >> 8], (h >> 2) & 63u) >> ((h & 3u) * 8u)) & 255u;
 			while (d != c) {
-				const uint32_t q = rh_readlane(hd[d >> 6], d & 63u);
-				if (lane == (d & 63u)) hd[d >> 6] = q + 1;
-				L.xm[beg + q] = (uint16_t)(beg + src);
+				uint32_t q = rh_readlane(hd[0], d & 63u);
+#pragma unroll
+				for (int k = 1; k < HB; ++k) { const uint32_t q2 = rh_readlane(hd[k], d & 63u); q = (d >> 6) == (uint32_t)k ? q2 : q; }
+#pragma unroll
+				for (int k = 0; k < HB; ++k) hd[k] = (lane == (d & 63u) && (HB == 1 || (d >> 6) == (uint32_t)k)) ? q + 1 : hd[k];
+				L.xm[ubeg + q] = (uint16_t)(ubeg + src);
 				src = q;
 				d = (rh_readlane(dg[q >> 8], (q >> 2) & 63u) >> ((q & 3u) * 8u)) & 255u;
 			}
-			L.xm[beg + h] = (uint16_t)(beg + src);
+			L.xm[ubeg + h] = (uint16_t)(ubeg + src);
 			++h;
 		}
 	}
+}
+
+template <int CAP>
+RH_DEV void sort_cycle_walk(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s, uint32_t nbk)
+{
+	if (nbk <= 64) sort_cycle_walk_hb<CAP, 1>(L, beg, end, s, nbk);
+	else if (nbk <= 128) sort_cycle_walk_hb<CAP, 2>(L, beg, end, s, nbk);
+	else sort_cycle_walk_hb<CAP, 4>(L, beg, end, s, nbk);
 }
 
 template <int CAP>
@@ -207,7 +227,8 @@ RH_DEV void sort_split_range(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s
 	const uint32_t my_start = beg + block_excl_scan(my_cnt, L.w, total);
 	L.head[tid] = my_start;
 	uint32_t nbk;
-	(void)block_rank(my_cnt != 0, L.w, nbk);
+	const uint32_t dense = block_rank(my_cnt != 0, L.w, nbk);
+	if (exact && my_cnt != 0) { L.dmap[tid] = (uint8_t)dense; L.inv[dense] = (uint8_t)tid; }
 	KPROF(2);
 	// permutation of the pass
 	if (!exact) {
@@ -223,7 +244,7 @@ RH_DEV void sort_split_range(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s
 		KPROF(5);
 	} else {
 		__syncthreads();
-		if (wave_id() == 0) sort_cycle_walk<CAP>(L, beg, end, s);
+		if (wave_id() == 0) sort_cycle_walk<CAP>(L, beg, end, s, nbk);
 		__syncthreads();
 		KPROF(6);
 		sort_apply_gather<CAP>(L, beg, end);
@@ -361,18 +382,22 @@ __global__ void k_sort_big(rh_sort_job jb, uint32_t n_lo)
 	rh_radix_sort_128x(jb.dst + base, n, (uint32_t*)(jb.scratch + base * jb.scratch_stride + jb.scratch_skip * (jb.off[a + 1] - base)));
 }
 
+// Size classes = LDS footprints (12 B per record + ~4.5 KB) chosen for whole workgroups per CU; the allocation granularity
+// means a class must stay clearly below 160 KB / k to get k workgroups resident (measured: 54.0 KB gives 2, 52.4 KB gives 3).
+#ifndef RH_SORT_CAP0
+#define RH_SORT_CAP0 512      // ~10 KB: candidate / chain-key sorts and short anchor lists
+#endif
 #ifndef RH_SORT_CAP1
-#define RH_SORT_CAP1 4096     // ~52 KB of LDS: three workgroups per CU
+#define RH_SORT_CAP1 2816     // ~38 KB: four workgroups per CU (a typical chunk's anchors)
 #endif
 #ifndef RH_SORT_CAP2
-#define RH_SORT_CAP2 6144     // ~77 KB of LDS: two workgroups per CU (unmapped reads accumulate carried anchors)
+#define RH_SORT_CAP2 3968     // ~52 KB: three
 #endif
 #ifndef RH_SORT_CAP3
-#define RH_SORT_CAP3 8192     // ~102 KB of LDS: one workgroup per CU
+#define RH_SORT_CAP3 6144     // ~78 KB: two (unmapped reads accumulate carried anchors)
 #endif
-
-#ifndef RH_SORT_CAP0
-#define RH_SORT_CAP0 512      // ~12 KB of LDS: candidate / chain-key sorts and short anchor lists
+#ifndef RH_SORT_CAP4
+#define RH_SORT_CAP4 8192     // ~103 KB: one
 #endif
 
 template <int CAP>
@@ -388,7 +413,8 @@ void rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t
 	launch_class<RH_SORT_CAP1>(s, jb, all_exact, (uint32_t)RH_SORT_CAP0, (uint32_t)RH_SORT_CAP1);
 	launch_class<RH_SORT_CAP2>(s, jb, all_exact, (uint32_t)RH_SORT_CAP1, (uint32_t)RH_SORT_CAP2);
 	launch_class<RH_SORT_CAP3>(s, jb, all_exact, (uint32_t)RH_SORT_CAP2, (uint32_t)RH_SORT_CAP3);
-	RH_LAUNCH(k_sort_big, (jb.n_seg + 63) / 64, 64, 0, s, jb, (uint32_t)RH_SORT_CAP3);
+	launch_class<RH_SORT_CAP4>(s, jb, all_exact, (uint32_t)RH_SORT_CAP3, (uint32_t)RH_SORT_CAP4);
+	RH_LAUNCH(k_sort_big, (jb.n_seg + 63) / 64, 64, 0, s, jb, (uint32_t)RH_SORT_CAP4);
 }
 
 // anchor sort of a chunk round: unsorted expand output -> reference order

@@ -13,10 +13,3 @@ names = {1: "diff/tie reduce", 2: "hist+scan", 3: "fast scatter", 4: "apply gath
 tot = sum(out[i] for i in names if i != 8)
 for i, nm in names.items(): print(f"{nm:24s} {out[i]/1e6:12.1f} Mcyc {100*out[i]/max(tot,1):5.1f}%")
 
-out = (ctypes.c_ulonglong * 32)()
-lib.rh_debug_kprof_post.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
-print("kprof_post rc", lib.rh_debug_kprof_post(out, 1))
-names = {1: "load heads", 2: "overlap scan", 3: "coverage (lane 0)", 4: "select scan", 5: "commit+sync", 6: "mapq/decision"}
-tot = sum(out[i] for i in names)
-for i, nm in names.items(): print(f"{nm:24s} {out[i]/1e6:12.1f} Mcyc {100*out[i]/max(tot,1):5.1f}%")
-print("iterations", out[11], "mean n_cov", out[10]/max(out[11],1), "mean kk", out[12]/max(out[11],1))
