@@ -28,7 +28,9 @@ void rh_set_error(const char *fmt, ...);
 // (the amdgcn builtins only exist in the device pass of hipcc; the host pass just needs the declarations to parse)
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint32_t rh_readlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
-__device__ __forceinline__ uint32_t rh_writelane(uint32_t v, uint32_t val, uint32_t l) { return (threadIdx.x & 63u) == l ? val : v; }
+// v with lane l := val; val and l must be wave-uniform values produced by scalar instructions (the s_and / s_add of the
+// callers), which keeps clear of the "VALU-written SGPR as lane select" hazard the assembler cannot see inside asm
+__device__ __forceinline__ uint32_t rh_writelane(uint32_t v, uint32_t val, uint32_t l) { asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(l) : "m0"); return v; }   // (one SGPR + M0: constant-bus limit)
 __device__ __forceinline__ uint32_t rh_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 #else
 __device__ uint32_t rh_readlane(uint32_t v, uint32_t l);

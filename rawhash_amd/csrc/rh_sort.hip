@@ -162,6 +162,7 @@ RH_DEV void sort_cycle_walk_hb(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int
 		if (id < nbk) { const uint32_t dgt = L.inv[id]; hd[q] = L.head[dgt] - beg; tl[q] = hd[q] + L.cnt[dgt]; }
 	}
 	const uint32_t ubeg = rh_uniform(beg);
+	uint16_t *xmr = L.xm + ubeg;
 	for (uint32_t c = 0; c < nbk; ++c) {
 		uint32_t tlc = rh_readlane(tl[0], c & 63u), h = rh_readlane(hd[0], c & 63u);
 #pragma unroll
@@ -170,16 +171,19 @@ RH_DEV void sort_cycle_walk_hb(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int
 			uint32_t src = h;
 			uint32_t d = (rh_readlane(dg[h >> 8], (h >> 2) & 63u) >> ((h & 3u) * 8u)) & 255u;
 			while (d != c) {
-				uint32_t q = rh_readlane(hd[0], d & 63u);
+				uint32_t r[HB];
 #pragma unroll
-				for (int k = 1; k < HB; ++k) { const uint32_t q2 = rh_readlane(hd[k], d & 63u); q = (d >> 6) == (uint32_t)k ? q2 : q; }
+				for (int k = 0; k < HB; ++k) r[k] = rh_readlane(hd[k], d & 63u);
+				uint32_t q = r[0];
 #pragma unroll
-				for (int k = 0; k < HB; ++k) hd[k] = (lane == (d & 63u) && (HB == 1 || (d >> 6) == (uint32_t)k)) ? q + 1 : hd[k];
-				L.xm[ubeg + q] = (uint16_t)(ubeg + src);
+				for (int k = 1; k < HB; ++k) q = (d >> 6) == (uint32_t)k ? r[k] : q;
+#pragma unroll
+				for (int k = 0; k < HB; ++k) hd[k] = rh_writelane(hd[k], (HB == 1 || (d >> 6) == (uint32_t)k) ? q + 1 : r[k], d & 63u);
+				xmr[q] = (uint16_t)(ubeg + src);
 				src = q;
 				d = (rh_readlane(dg[q >> 8], (q >> 2) & 63u) >> ((q & 3u) * 8u)) & 255u;
 			}
-			L.xm[ubeg + h] = (uint16_t)(ubeg + src);
+			xmr[h] = (uint16_t)(ubeg + src);
 			++h;
 		}
 	}
