@@ -41,4 +41,7 @@ __device__ uint32_t rh_uniform(uint32_t v);
 // all lanes of the wavefront have executed everything above (lock step on the GPU: only a compiler-level barrier)
 #define RH_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 
+// order this wavefront's / workgroup's memory operations without touching the caches (a device-scope fence writes the L2 back)
+#define RH_WG_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+
 #define RH_HIP_VOID(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) rh_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); } while (0)

@@ -39,6 +39,8 @@ __global__ __launch_bounds__(64) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 	rh_mm128_t *z = rr.raw + base;               // the unsorted anchor copy is dead after the anchor sort
 	uint32_t *t4 = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)16 * n);   // backtrack's "touched" marks (1 B per anchor)
 	for (int32_t i = (int32_t)lane; i < (n + 3) / 4; i += 64) t4[i] = 0u;
+	uint32_t *claim = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)20 * n);   // k_backtrack_spec's per-anchor claim stamps
+	for (int32_t i = (int32_t)lane; i < n; i += 64) claim[i] = 0u;
 	uint32_t nz = 0;
 	for (int32_t i0 = 0; i0 < n; i0 += 64) {
 		const int32_t i = i0 + (int32_t)lane;
@@ -318,6 +320,109 @@ __global__ void k_backtrack_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, 
 	rr.n_u[a] = (uint32_t)n_u; rr.n_v[a] = (uint32_t)n_v;
 	rd.n_prev[r] = (uint32_t)n_v; rd.prev_off[r] = base;
 	atomicAdd((unsigned long long*)&rr.counters[4], (unsigned long long)n_v);
+}
+
+// One read per wavefront, 64 candidates at a time - the walk of mg_chain_backtrack (lchain.c:148-170) made parallel without
+// changing its result.  A candidate's outcome depends on the candidates before it only through the "used" marks of the
+// anchors its own mg_chain_bk_end walk reads (its path; a used anchor that ends the walk stays used and needs no watching), and a candidate only ever marks anchors of
+// its own path.  So, per
+// batch of 64 candidates (lane 0 = best score), rounds of:
+//   1. every pending lane walks its path under the current marks and stamps each anchor of it with (round, priority)
+//      through atomicMax;
+//   2. a lane whose path carries no stamp of a better lane of this round cannot be influenced by any pending lane (a later
+//      re-walk of those only shortens their paths): it commits - marks its chain, fixes score and count;
+//   3. the others walk again next round, now seeing the new marks.  The best pending lane always commits.
+// When the batch is settled the accepted chains get their slots in u[] / v[] by a prefix sum in candidate order.  The
+// dependent loads of 64 walks are in flight together, where the serial walk paid one memory round trip per step.
+__global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
+{
+	const uint32_t a = blockIdx.x, lane = threadIdx.x;
+	if (a >= rr.n_act) return;
+	if (rr.skip[a]) { if (lane == 0) { rr.n_u[a] = 0; rr.n_v[a] = 0; } return; }
+	const uint32_t r = rr.act[a];
+	const uint64_t base = rr.a_off[a];
+	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
+	const int32_t n_z = (int32_t)rr.n_z[a];
+	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
+	const int2 *fp = (const int2*)wsr;                              // .x = f, .y = p
+	int32_t *v = (int32_t*)wsr + 2 * (size_t)n;
+	uint8_t *t = (uint8_t*)(wsr + (size_t)16 * n);                  // "used" marks, zeroed by k_zbuild
+	uint32_t *claim = (uint32_t*)(wsr + (size_t)20 * n);            // stamps, zeroed by k_zbuild
+	const rh_mm128_t *zs = rr.zs + base;
+	uint64_t *u = rr.u + base;
+	const int32_t min_sc = o.min_sc, min_cnt = o.min_cnt, max_drop = o.bw;
+	int32_t n_u = 0, n_v = 0;
+	uint32_t epoch = 0;
+	for (int32_t kt = n_z; kt > 0; kt -= 64) {                     // candidates from the best score down (lchain.c:148)
+		const int32_t k = kt - 1 - (int32_t)lane;
+		const int32_t i0 = k >= 0 ? (int32_t)zs[k].y : 0;
+		bool pending = k >= 0, accepted = false;
+		int32_t r_cnt = 0, r_sc = 0;
+		while (__ballot(pending)) {
+			++epoch;
+			const uint32_t stamp = epoch << 6 | (63u - lane);
+			bool walked = false;
+			int32_t max_i = i0, zx = 0, path = 0;                     // path = anchors reached after i0
+			if (pending && t[i0] == 0) {
+				walked = true;
+				int2 rec = fp[i0];
+				zx = rec.x;
+				atomicMax(&claim[i0], stamp);
+				int32_t max_s = 0;
+				for (;;) {	// mg_chain_bk_end (lchain.c:47-75): back until a used anchor, the start, or a score drop > max_drop
+					const int32_t i = rec.y;
+					int32_t sdrop = zx;
+					uint8_t ti = 0;
+					if (i >= 0) {
+						rec = fp[i]; ti = t[i]; sdrop = zx - rec.x;
+						if (ti == 0) { atomicMax(&claim[i], stamp); ++path; }    // a used anchor ends every walk that reaches it: nobody's to take
+					}
+					if (sdrop > max_s) { max_s = sdrop; max_i = i; }
+					else if (max_s - sdrop > max_drop) break;
+					if (i < 0 || ti != 0) break;
+				}
+			}
+			RH_WG_FENCE();
+			__syncthreads();                                          // every stamp of the round is in
+			bool conflict = false;
+			if (walked) {
+				int32_t x = i0;
+				for (int32_t j = 0; ; ++j) {
+					if (atomicMax(&claim[x], stamp) != stamp) { conflict = true; break; }   // read at L2, where the stamps were combined
+					if (j == path) break;
+					x = fp[x].y;
+				}
+			}
+			if (pending && !conflict) {
+				if (walked) {	// anchors i0 .. (exclusive) max_i form the chain; the marks stay even if it is rejected, as in the reference
+					int32_t cnt = 0, x = i0;
+					while (x != max_i) { t[x] = 1; ++cnt; x = fp[x].y; }
+					const int32_t sc = max_i < 0 ? zx : zx - fp[max_i].x;
+					accepted = sc >= min_sc && cnt > 0 && cnt >= min_cnt;
+					r_cnt = cnt; r_sc = sc;
+				}
+				pending = false;
+			}
+			RH_WG_FENCE();
+			__syncthreads();                                          // the new marks are in before anybody walks again (one CU, one L1)
+		}
+		// slots in candidate order
+		const uint64_t am = __ballot(accepted);
+		uint32_t inc = accepted ? (uint32_t)r_cnt : 0u;
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(inc, d); if (lane >= (uint32_t)d) inc += up; }
+		const uint32_t total = __shfl(inc, 63);
+		if (accepted) {
+			u[n_u + (int32_t)lanes_below(am)] = (uint64_t)(uint32_t)r_sc << 32 | (uint64_t)(uint32_t)r_cnt;
+			int32_t off = n_v + (int32_t)(inc - (uint32_t)r_cnt), x = i0;
+			for (int32_t j = 0; j < r_cnt; ++j) { v[off + j] = x; x = fp[x].y; }
+		}
+		n_u += (int32_t)__popcll(am);
+		n_v += (int32_t)total;
+	}
+	if (lane == 0) {
+		rr.n_u[a] = (uint32_t)n_u; rr.n_v[a] = (uint32_t)n_v;
+		if (n_u == 0) { rd.n_prev[r] = 0; rd.prev_off[r] = base; }
+	}
 }
 
 // compact_a (lchain.c:214-281) as two workgroup kernels around the block sorter, for the one-read-per-lane walk:
@@ -1050,7 +1155,7 @@ void rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, c
 	// arrays (latency hidden by sheer lane count) beats the LDS workgroup variant, whose concurrency is capped by LDS;
 	// the workgroup variant serves small batches.
 	if (r.n_act >= RH_BK_LANE_MIN) {
-		RH_LAUNCH(k_backtrack_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, 0u, 1);
+		RH_LAUNCH(k_backtrack_spec, r.n_act, 64, 0, s, o, rd, r);
 		RH_LAUNCH(k_chain_gather, r.n_act, NT, 0, s, r);
 		rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64 };
 		rhk_sort_job(s, jb, false, 0u);

@@ -35,6 +35,8 @@ unsigned long long emu_ballot(int pred);
 unsigned long long emu_shfl_down_bits(unsigned long long bits, unsigned delta);
 unsigned long long emu_shfl_bits(unsigned long long bits, int op, unsigned par);   // op: 2 down, 3 up, 4 xor, 5 idx
 #define __syncthreads() emu_syncthreads()
+static inline void __threadfence() {}
+#define RH_WG_FENCE() ((void)0)
 #define __ballot(p) emu_ballot((p) ? 1 : 0)
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline double __shfl_down(double v, int d) { unsigned long long b; memcpy(&b, &v, 8); b = emu_shfl_down_bits(b, (unsigned)d); memcpy(&v, &b, 8); return v; }
@@ -58,6 +60,8 @@ static inline unsigned rh_uniform(unsigned v) { return v; }
 #define RH_WAVE_SYNC() ((void)emu_ballot(1))
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __ATOMIC_RELAXED_DEFINED 1
 
 // ---- host runtime subset
 typedef int hipError_t;
