@@ -97,6 +97,47 @@ def check_stages(ctx, wl):
     return len(oan), len(och)
 
 
+def check_chain_synthetic(ctx, wl, seed=0, n_reads=64, max_n=700):
+    """DP + backtrack + compact_a on adversarial anchor sets: collinear runs (long chains, every member a backtrack
+    candidate), bundles of anchors competing for the same predecessor (fan-in), random clutter, equal target positions."""
+    rng = np.random.default_rng(seed)
+    segs, off = [], [0]
+    for r in range(n_reads):
+        n = int(rng.integers(0, max_n)) if r % 7 else int(rng.integers(0, 6))
+        xs, ys = [], []
+        while len(xs) < n:
+            kind = rng.integers(0, 4)
+            rev = int(rng.integers(0, 2)); rid = int(rng.integers(0, 2))
+            r0 = int(rng.integers(1000, 60000)); q0 = int(rng.integers(0, 1500))
+            if kind == 0:      # collinear run with jitter
+                m = int(rng.integers(2, 120)); st = int(rng.integers(3, 40))
+                for t in range(m):
+                    xs.append((rev << 63) | (rid << 32) | (r0 + t * st + int(rng.integers(0, 3)))); ys.append(q0 + t * st + int(rng.integers(0, 3)))
+            elif kind == 1:    # fan-in: many successors of one anchor
+                xs.append((rev << 63) | (rid << 32) | r0); ys.append(q0)
+                for t in range(int(rng.integers(2, 30))):
+                    d = int(rng.integers(5, 60)); xs.append((rev << 63) | (rid << 32) | (r0 + d)); ys.append(q0 + d + int(rng.integers(-2, 3)))
+            elif kind == 2:    # clutter
+                for t in range(int(rng.integers(1, 40))):
+                    xs.append((rev << 63) | (rid << 32) | int(rng.integers(1000, 60000))); ys.append(int(rng.integers(0, 3000)))
+            else:              # two interleaved diagonals sharing target positions
+                m = int(rng.integers(2, 40))
+                for t in range(m):
+                    xs.append((rev << 63) | (rid << 32) | (r0 + t * 11)); ys.append(q0 + t * 11)
+                    xs.append((rev << 63) | (rid << 32) | (r0 + t * 11)); ys.append(q0 + 400 + t * 11)
+        x = np.array(xs[:n], dtype=np.uint64); y = np.array(ys[:n], dtype=np.int64).clip(0, 1 << 20).astype(np.uint64) | (np.uint64(10 + r % 9) << np.uint64(32))
+        order = np.argsort(x, kind="stable")
+        seg = np.zeros(n, dtype=MM128); seg["x"] = x[order]; seg["y"] = y[order]
+        segs.append(seg); off.append(off[-1] + n)
+    an = np.concatenate(segs) if segs else np.zeros(0, dtype=MM128)
+    ao = np.array(off, dtype=np.uint64)
+    och, oco, ou, ouo, opv = oracle_chains(wl, an, ao)
+    ch, co, u, uo, pv = ctx.chain(wl.opts, an, ao)
+    assert np.array_equal(co, oco) and np.array_equal(uo, ouo), "chain counts differ"
+    assert np.array_equal(u, ou) and np.array_equal(ch, och) and np.array_equal(pv, opv), "chains differ"
+    return len(an), len(och), len(ou)
+
+
 def check_sort(ctx, seed=0, n_seg=40):
     """Exact unstable-permutation emulation of radix_sort_128x, with heavy key ties in every byte position."""
     rng = np.random.default_rng(seed)

@@ -32,6 +32,11 @@ def test_exact_sort(ctx):
     pc.check_sort(ctx, seed=1, n_seg=24)
 
 
+def test_chain_adversarial(ctx, wl):
+    n_an, n_ch, n_u = pc.check_chain_synthetic(ctx, wl, seed=2, n_reads=24, max_n=600)
+    assert n_ch > 0 and n_u > 0
+
+
 def test_end_to_end_paf(ctx, wl):
     recs = pc.check_e2e(ctx, wl)
     assert recs["mapped"].sum() > 0 and (recs["mapped"] == 0).sum() > 0   # both outcomes exercised
@@ -54,4 +59,5 @@ def test_oversized_read_fallbacks(make_workload, emu_lib_smallcaps):
     pc.check_stages(c, w)
     pc.check_e2e(c, w)
     pc.check_sort(c, seed=3, n_seg=16)
+    pc.check_chain_synthetic(c, w, seed=5, n_reads=40, max_n=500)
     c.close()

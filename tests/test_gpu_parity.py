@@ -39,6 +39,13 @@ def test_exact_sort(ctx):
     pc.check_sort(ctx, seed=2, n_seg=400)
 
 
+def test_chain_adversarial(ctx, wl):
+    """few reads -> workgroup walk in LDS; thousands -> the 64-candidates-per-round wave kernel"""
+    for n_reads, max_n, seed in ((48, 900, 1), (2300, 260, 2), (2100, 60, 3)):
+        n_an, n_ch, n_u = pc.check_chain_synthetic(ctx, wl, seed=seed, n_reads=n_reads, max_n=max_n)
+        assert n_ch > 0 and n_u > 0
+
+
 def test_end_to_end_paf(ctx, wl):
     recs = pc.check_e2e(ctx, wl)
     assert recs["mapped"].sum() > 0 and (recs["mapped"] == 0).sum() > 0
