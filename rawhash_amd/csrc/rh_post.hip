@@ -1,12 +1,13 @@
-// Post-DP stages, one read per workgroup with the working set staged in LDS:
-//   k_zbuild      candidates f[i] >= min_sc for backtracking (lchain.c:126-140); they are then put into the reference's
-//                 radix_sort_128x order by the block sorter of rh_sort.hip (scores are full of ties -> exact mode)
-//   k_backtrack   mg_chain_backtrack (lchain.c:95-194, mg_chain_bk_end :47-75) + compact_a (:214-281)
-//   k_regions     mm_gen_regs (hit.c:100-150), mm_set_parent (:195-263), mm_select_sub (:338-367), mm_set_mapq (:502-539),
-//                 the mapping decision of map_worker_for (rmap.cpp:423-500) and the bookkeeping of ri_map_frag (:386)
-// The chain walks and the region bookkeeping are pointer-chasing, order-dependent code: lane 0 runs them on LDS copies
-// (f, p, t marks, sorted candidates; regions, chain heads) while the other lanes do the staging, gathers and copies.
-// Reads whose working set exceeds the LDS caps take the same code paths on HBM scratch (the *_big kernels).
+// Post-DP stages:
+//   k_zbuild          candidates f[i] >= min_sc for backtracking (lchain.c:126-140); they are then put into the reference's
+//                     radix_sort_128x order by the block sorter of rh_sort.hip (scores are full of ties -> exact mode)
+//   k_backtrack_spec  mg_chain_backtrack (lchain.c:95-194, mg_chain_bk_end :47-75): one wavefront per read, 64 candidates
+//                     walked in parallel per round, conflicts re-walked
+//   k_chain_gather, k_chain_reorder (+ block sorter)   compact_a (lchain.c:214-281)
+//   k_regions_*       mm_gen_regs (hit.c:100-150), mm_set_parent (:195-263), mm_select_sub (:338-367), mm_set_mapq (:502-539),
+//                     the mapping decision of map_worker_for (rmap.cpp:423-500) and the bookkeeping of ri_map_frag (:386):
+//                     k_regions_reg keeps the primaries in registers; k_regions_wave (LDS), k_regions / k_regions_big
+//                     (serial core) take the reads and option sets it cannot
 #include "rh_kernels.h"
 #include "rh_devutil.h"
 
@@ -54,274 +55,6 @@ __global__ __launch_bounds__(64) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 }
 
 // ------------------------------------------------------------------------------------------------ backtrack
-#ifndef BK_CAP
-#define BK_CAP  4096     // anchors of a read whose f/p/t/candidates fit the first LDS class (2x for the second)
-#endif
-#ifndef BK_CAP2
-#define BK_CAP2 6656     // second LDS class (two workgroups per CU)
-#endif
-#ifndef RH_BK_LANE_MIN
-#define RH_BK_LANE_MIN 2048u   // active reads from which the walk runs one read per lane
-#endif
-#ifndef BK_UCAP
-#define BK_UCAP 1536     // chains whose bookkeeping fits LDS
-#endif
-
-// Walks every candidate from the best score down, emitting chains (lchain.c:148-170).  F/P/T/ZI are LDS or HBM views.
-// Returns n_u; *n_v_out = anchors in chains; v[] = chain members in backtrack order; u[] = score << 32 | count.
-struct zi_from_records { const rh_mm128_t *z; __device__ int32_t operator[](int32_t k) const { return (int32_t)z[k].y; } };
-
-template <class PT, class ZT>
-RH_DEV int32_t backtrack_walk(const int32_t *F, const PT *P, uint8_t *T, const ZT ZI, int32_t n_z, int32_t min_sc, int32_t min_cnt, int32_t max_drop,
-                              int32_t *v, uint64_t *u, uint32_t *ck0, uint32_t *cn, int32_t *n_v_out)
-{
-	const PT NONE = (PT)~(PT)0;
-	int32_t n_u = 0, n_v = 0;
-	for (int32_t k = n_z - 1; k >= 0; --k) {
-		const int32_t i0 = (int32_t)ZI[k];
-		if (T[i0] != 0) continue;
-		const int32_t zx = F[i0];
-		// mg_chain_bk_end: how far back the chain from i0 may extend before the score drops by more than max_drop
-		int32_t i = i0, end_i = -1, max_i = i0, max_s = 0;
-		do {
-			T[i] = 2;
-			const PT pi = P[i];
-			end_i = i = (pi == NONE) ? -1 : (int32_t)pi;
-			const int32_t s = i < 0 ? zx : zx - F[i];
-			if (s > max_s) { max_s = s; max_i = i; }
-			else if (max_s - s > max_drop) break;
-		} while (i >= 0 && T[i] == 0);
-		for (i = i0; i >= 0 && i != end_i;) { T[i] = 0; const PT pi = P[i]; i = (pi == NONE) ? -1 : (int32_t)pi; }
-		const int32_t stop = max_i, n_v0 = n_v;
-		for (i = i0; i != stop;) { v[n_v++] = i; T[i] = 1; const PT pi = P[i]; i = (pi == NONE) ? -1 : (int32_t)pi; }
-		const int32_t sc = i < 0 ? zx : zx - F[i];
-		if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) {
-			if (n_u < BK_UCAP && ck0) { ck0[n_u] = (uint32_t)n_v0; cn[n_u] = (uint32_t)(n_v - n_v0); }
-			u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint64_t)(uint32_t)(n_v - n_v0);
-		} else n_v = n_v0;
-	}
-	*n_v_out = n_v;
-	return n_u;
-}
-
-template <int CAP>
-struct bk_lds {
-	int32_t f[CAP];
-	uint16_t p[CAP], zi[CAP];
-	uint8_t t[CAP];
-	uint32_t ck0[BK_UCAP], cn[BK_UCAP];
-	int32_t n_u, n_v;
-};
-
-// One workgroup (256 threads) per read.  All threads stage f/p/candidates into LDS and do the gathers/copies; wavefront 0
-// runs the chain walk with uniform control flow (LDS broadcasts), skipping already-claimed candidates 64 at a time.
-template <int CAP>
-__global__ __launch_bounds__(NT) void k_backtrack(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, uint32_t n_lo)
-{
-	__shared__ bk_lds<CAP> L;
-	static_assert(BK_UCAP * 16 <= CAP * 6 && BK_UCAP * 4 <= CAP * 2 && (BK_UCAP <= 64 || BK_UCAP * 4 + 2048 <= CAP * 2), "LDS aliasing of the chain-order sort");
-	const uint32_t a = blockIdx.x, tid = threadIdx.x;
-	if (a >= rr.n_act || rr.skip[a]) return;
-	const uint32_t r = rr.act[a];
-	const uint64_t base = rr.a_off[a];
-	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
-	if (n > CAP || n <= (int32_t)n_lo) return;                   // other size classes / k_backtrack_big
-	const int32_t n_z = (int32_t)rr.n_z[a];
-	rh_mm128_t *an = rr.anc + base;
-	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
-	const int32_t *gfp = (const int32_t*)wsr;                    // {f, p} interleaved
-	int32_t *v = (int32_t*)wsr + 2 * (size_t)n;                  // DP's v[] is dead: reused for the chain members
-	uint64_t *u = rr.u + base;
-	rh_mm128_t *pa = rr.prev_out + base;
-	const rh_mm128_t *zs = rr.zs + base;
-	for (int32_t i = (int32_t)tid; i < n; i += NT) { L.f[i] = gfp[2 * i]; const int32_t pi = gfp[2 * i + 1]; L.p[i] = pi < 0 ? (uint16_t)0xFFFF : (uint16_t)pi; L.t[i] = 0; }
-	for (int32_t i = (int32_t)tid; i < n_z; i += NT) L.zi[i] = (uint16_t)zs[i].y;
-	__syncthreads();
-	if (wave_id() == 0) {
-		const int32_t min_sc = o.min_sc, min_cnt = o.min_cnt, max_drop = o.bw;
-		const uint32_t lane = lane_id();
-		int32_t n_u = 0, n_v = 0;
-		for (int32_t kt = n_z; kt > 0; kt -= 64) {                 // candidates from the best score down (lchain.c:148)
-			const int32_t kl = kt - 1 - (int32_t)lane;
-			uint64_t m = __ballot(kl >= 0 && L.t[L.zi[kl >= 0 ? kl : 0]] == 0);
-			while (m) {
-				const int32_t k = kt - 1 - __builtin_ctzll(m);
-				m &= m - 1;
-				const int32_t i0 = (int32_t)L.zi[k];
-				if (L.t[i0] != 0) continue;                         // claimed by a chain emitted since the ballot
-				const int32_t zx = L.f[i0];
-				int32_t i = i0, end_i = -1, max_i = i0, max_s = 0;
-				do {	// mg_chain_bk_end (lchain.c:47-75)
-					L.t[i] = 2;
-					const uint16_t pi = L.p[i];
-					end_i = i = pi == 0xFFFF ? -1 : (int32_t)pi;
-					const int32_t s = i < 0 ? zx : zx - L.f[i];
-					if (s > max_s) { max_s = s; max_i = i; }
-					else if (max_s - s > max_drop) break;
-				} while (i >= 0 && L.t[i] == 0);
-				for (i = i0; i >= 0 && i != end_i;) { L.t[i] = 0; const uint16_t pi = L.p[i]; i = pi == 0xFFFF ? -1 : (int32_t)pi; }
-				const int32_t stop = max_i, n_v0 = n_v;
-				for (i = i0; i != stop;) { if (lane == 0) v[n_v] = i; ++n_v; L.t[i] = 1; const uint16_t pi = L.p[i]; i = pi == 0xFFFF ? -1 : (int32_t)pi; }
-				const int32_t sc = i < 0 ? zx : zx - L.f[i];
-				if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) {
-					if (lane == 0) {
-						if (n_u < BK_UCAP) { L.ck0[n_u] = (uint32_t)n_v0; L.cn[n_u] = (uint32_t)(n_v - n_v0); }
-						u[n_u] = (uint64_t)(uint32_t)sc << 32 | (uint64_t)(uint32_t)(n_v - n_v0);
-					}
-					++n_u;
-				} else n_v = n_v0;
-			}
-		}
-		if (lane == 0) { L.n_u = n_u; L.n_v = n_v; }
-	}
-	__syncthreads();
-	const int32_t n_u = L.n_u, n_v = L.n_v;
-	if (n_u == 0) {
-		if (tid == 0) { rr.n_u[a] = 0; rr.n_v[a] = 0; rd.n_prev[r] = 0; rd.prev_off[r] = base; }
-		return;
-	}
-	// compact_a: gather every chain, reversed into ascending anchor order -> pa (what the next chunk carries, lchain.c:236-239)
-	if (n_u <= BK_UCAP) {
-		// one pass over all chained anchors: output slot q belongs to the chain whose [ck0, ck0+cn) contains it
-		for (int32_t q = (int32_t)tid; q < n_v; q += NT) {
-			int32_t lo = 0, hi = n_u;                                // largest chain c with ck0[c] <= q
-			while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if ((int32_t)L.ck0[mid] <= q) lo = mid; else hi = mid; }
-			const int32_t k0 = (int32_t)L.ck0[lo], ni = (int32_t)L.cn[lo], j = q - k0;
-			pa[q] = an[v[k0 + (ni - j - 1)]];
-		}
-	} else {
-		uint32_t k0 = 0;
-		for (int32_t i = 0; i < n_u; ++i) {
-			const uint32_t ni = (uint32_t)u[i];
-			for (uint32_t j = tid; j < ni; j += NT) pa[k0 + j] = an[v[k0 + (ni - j - 1)]];
-			k0 += ni;
-		}
-	}
-	__syncthreads();
-	// chains ordered by the target coordinate of their first anchor (radix_sort_128x on (x, k<<32|i)); LDS regions of the walk are dead
-	if (n_u <= BK_UCAP) {
-		rh_mm128_t *w = (rh_mm128_t*)L.f;
-		uint32_t *dk = (uint32_t*)L.zi, *cw = dk + BK_UCAP;      // w spans f[] + p[] (contiguous), dk + sort scratch span zi[]
-		for (int32_t i = (int32_t)tid; i < n_u; i += NT) { w[i].x = pa[L.ck0[i]].x; w[i].y = (uint64_t)L.ck0[i] << 32 | (uint64_t)(uint32_t)i; }
-		__syncthreads();
-		if (tid == 0) {
-			rh_radix_sort_128x(w, (uint32_t)n_u, cw);
-			uint32_t k = 0;
-			for (int32_t i = 0; i < n_u; ++i) { dk[i] = k; k += L.cn[(uint32_t)w[i].y]; }
-		}
-		__syncthreads();
-		for (int32_t q = (int32_t)tid; q < n_v; q += NT) {        // destination slot q -> sorted chain c -> source
-			int32_t lo = 0, hi = n_u;
-			while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if ((int32_t)dk[mid] <= q) lo = mid; else hi = mid; }
-			const uint32_t src = (uint32_t)(w[lo].y >> 32);
-			an[q] = pa[src + ((uint32_t)q - dk[lo])];
-		}
-		uint64_t uu[(BK_UCAP + NT - 1) / NT];
-		for (int32_t qq = 0; qq < (BK_UCAP + NT - 1) / NT; ++qq) { const int32_t i = qq * NT + (int32_t)tid; uu[qq] = i < n_u ? u[(uint32_t)w[i].y] : 0; }
-		__syncthreads();
-		for (int32_t qq = 0; qq < (BK_UCAP + NT - 1) / NT; ++qq) { const int32_t i = qq * NT + (int32_t)tid; if (i < n_u) u[i] = uu[qq]; }
-	} else if (tid == 0) {	// more chains than the LDS bookkeeping holds: serial tail on HBM scratch
-		rh_mm128_t *w = (rh_mm128_t*)(wsr + (size_t)16 * n);
-		uint64_t *u2 = (uint64_t*)(w + n_u);
-		int32_t k = 0;
-		for (int32_t i = 0; i < n_u; ++i) { w[i].x = pa[k].x; w[i].y = (uint64_t)(uint32_t)k << 32 | (uint64_t)(uint32_t)i; k += (int32_t)u[i]; }
-		rh_radix_sort_128x(w, (uint32_t)n_u, (uint32_t*)(wsr + (size_t)64 * n));
-		k = 0;
-		for (int32_t i = 0; i < n_u; ++i) {
-			const int32_t j = (int32_t)w[i].y, cnt = (int32_t)u[j], src = (int32_t)(w[i].y >> 32);
-			u2[i] = u[j];
-			for (int32_t m = 0; m < cnt; ++m) an[k + m] = pa[src + m];
-			k += cnt;
-		}
-		for (int32_t i = 0; i < n_u; ++i) u[i] = u2[i];
-	}
-	if (tid == 0) {
-		rr.n_u[a] = (uint32_t)n_u; rr.n_v[a] = (uint32_t)n_v;
-		rd.n_prev[r] = (uint32_t)n_v; rd.prev_off[r] = base;
-		atomicAdd((unsigned long long*)&rr.counters[4], (unsigned long long)n_v);
-	}
-}
-
-// One read per lane on HBM arrays (large batches, and reads too big for the LDS classes).  The walk is pointer chasing;
-// per step it needs f and p of one anchor -> the DP stores them as one 8-byte record, and the "touched" byte is loaded
-// alongside, so a step costs one memory round trip.  Candidates are examined four at a time (independent loads), and the
-// reset + emit passes of the reference (lchain.c:69, :160) are merged into one pass over the visited prefix.
-__global__ void k_backtrack_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, uint32_t n_lo, int walk_only)
-{
-	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-	if (a >= rr.n_act) return;
-	if (rr.skip[a]) { if (walk_only) { rr.n_u[a] = 0; rr.n_v[a] = 0; } return; }
-	const uint32_t r = rr.act[a];
-	const uint64_t base = rr.a_off[a];
-	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
-	if (n <= (int32_t)n_lo) return;
-	const int32_t n_z = (int32_t)rr.n_z[a];
-	rh_mm128_t *an = rr.anc + base;
-	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
-	const int2 *fp = (const int2*)wsr;                              // .x = f, .y = p
-	int32_t *v = (int32_t*)wsr + 2 * (size_t)n;
-	uint8_t *t = (uint8_t*)(wsr + (size_t)16 * n);                  // zeroed (coalesced) by k_zbuild
-	const rh_mm128_t *zs = rr.zs + base;
-	uint64_t *u = rr.u + base;
-	rh_mm128_t *pa = rr.prev_out + base;
-	const int32_t min_sc = o.min_sc, min_cnt = o.min_cnt, max_drop = o.bw;
-	int32_t n_u = 0, n_v = 0;
-	for (int32_t k = n_z - 1; k >= 0;) {
-		// four candidates per trip: indices, then their marks (independent loads)
-		int32_t ci[4]; uint8_t ct[4];
-		const int32_t nb = k >= 3 ? 4 : k + 1;
-		for (int32_t q = 0; q < nb; ++q) ci[q] = (int32_t)zs[k - q].y;
-		for (int32_t q = 0; q < nb; ++q) ct[q] = t[ci[q]];
-		bool emitted = false;
-		for (int32_t q = 0; q < nb; ++q) {
-			const int32_t i0 = ci[q];
-			if (emitted ? t[i0] != 0 : ct[q] != 0) continue;          // marks may have changed once a chain was emitted
-			int2 rec = fp[i0];
-			const int32_t zx = rec.x;
-			// mg_chain_bk_end: extend back until a touched anchor, the start, or a score drop > max_drop
-			int32_t i = i0, max_i = i0, max_s = 0;                     // (the transient mark 2 of the reference is unobservable: p decreases)
-			for (;;) {
-				i = rec.y;
-				int32_t s = zx;
-				uint8_t ti = 0;
-				if (i >= 0) { rec = fp[i]; ti = t[i]; s = zx - rec.x; }
-				if (s > max_s) { max_s = s; max_i = i; }
-				else if (max_s - s > max_drop) break;
-				if (i < 0 || ti != 0) break;
-			}
-			// anchors i0 .. (exclusive) max_i form the chain; the rest of the visited prefix keeps mark 0
-			const int32_t n_v0 = n_v;
-			rec = fp[i0];
-			for (i = i0; i != max_i; ) { v[n_v++] = i; t[i] = 1; i = rec.y; if (i >= 0 && i != max_i) rec = fp[i]; }
-			const int32_t sc = i < 0 ? zx : zx - fp[i].x;
-			if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint64_t)(uint32_t)(n_v - n_v0);
-			else n_v = n_v0;                                        // the marks stay, as in the reference
-			emitted = true;
-		}
-		k -= nb;
-	}
-	if (n_u == 0) { rr.n_u[a] = 0; rr.n_v[a] = 0; rd.n_prev[r] = 0; rd.prev_off[r] = base; return; }
-	if (walk_only) { rr.n_u[a] = (uint32_t)n_u; rr.n_v[a] = (uint32_t)n_v; return; }   // compact_a runs as workgroup kernels
-	int32_t k = 0;
-	for (int32_t i = 0; i < n_u; ++i) { const int32_t k0 = k, ni = (int32_t)u[i]; for (int32_t j = 0; j < ni; ++j) pa[k++] = an[v[k0 + (ni - j - 1)]]; }
-	rh_mm128_t *w = (rh_mm128_t*)(wsr + (size_t)32 * n);
-	uint64_t *u2 = (uint64_t*)(w + n_u);
-	k = 0;
-	for (int32_t i = 0; i < n_u; ++i) { w[i].x = pa[k].x; w[i].y = (uint64_t)(uint32_t)k << 32 | (uint64_t)(uint32_t)i; k += (int32_t)u[i]; }
-	rh_radix_sort_128x(w, (uint32_t)n_u, (uint32_t*)(wsr + (size_t)64 * n));
-	k = 0;
-	for (int32_t i = 0; i < n_u; ++i) {
-		const int32_t j = (int32_t)w[i].y, cnt = (int32_t)u[j], src = (int32_t)(w[i].y >> 32);
-		u2[i] = u[j];
-		for (int32_t m = 0; m < cnt; ++m) an[k + m] = pa[src + m];
-		k += cnt;
-	}
-	for (int32_t i = 0; i < n_u; ++i) u[i] = u2[i];
-	rr.n_u[a] = (uint32_t)n_u; rr.n_v[a] = (uint32_t)n_v;
-	rd.n_prev[r] = (uint32_t)n_v; rd.prev_off[r] = base;
-	atomicAdd((unsigned long long*)&rr.counters[4], (unsigned long long)n_v);
-}
-
 // One read per wavefront, 64 candidates at a time - the walk of mg_chain_backtrack (lchain.c:148-170) made parallel without
 // changing its result.  A candidate's outcome depends on the candidates before it only through the "used" marks of the
 // anchors its own mg_chain_bk_end walk reads (its path; a used anchor that ends the walk stays used and needs no watching), and a candidate only ever marks anchors of
@@ -425,7 +158,7 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 	}
 }
 
-// compact_a (lchain.c:214-281) as two workgroup kernels around the block sorter, for the one-read-per-lane walk:
+// compact_a (lchain.c:214-281) as two workgroup kernels around the block sorter:
 //   k_chain_gather : chain start offsets (scan of the counts), chain members reversed into ascending order -> pa (= what the
 //                    next chunk carries), sort keys (first-anchor x, start << 32 | chain) -> rr.raw
 //   [rhk_sort_job  : chains into the reference's order of their first anchor]
@@ -1151,20 +884,12 @@ void rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 void rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
 {
 	if (!r.n_act) return;
-	// The chain walk is pointer chasing.  Measured on MI355X: with thousands of reads in flight, one read per lane on HBM
-	// arrays (latency hidden by sheer lane count) beats the LDS workgroup variant, whose concurrency is capped by LDS;
-	// the workgroup variant serves small batches.
-	if (r.n_act >= RH_BK_LANE_MIN) {
-		RH_LAUNCH(k_backtrack_spec, r.n_act, 64, 0, s, o, rd, r);
-		RH_LAUNCH(k_chain_gather, r.n_act, NT, 0, s, r);
-		rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64 };
-		rhk_sort_job(s, jb, false, 0u);
-		RH_LAUNCH(k_chain_reorder, r.n_act, NT, 0, s, rd, r);
-	} else {
-		RH_LAUNCH(k_backtrack<BK_CAP>, r.n_act, NT, 0, s, o, rd, r, 0u);
-		RH_LAUNCH(k_backtrack<BK_CAP2>, r.n_act, NT, 0, s, o, rd, r, (uint32_t)BK_CAP);
-		RH_LAUNCH(k_backtrack_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, (uint32_t)BK_CAP2, 0);
-	}
+	RH_LAUNCH(k_backtrack_spec, r.n_act, 64, 0, s, o, rd, r);
+	// compact_a: chains gathered, put into the reference's order of their first anchor, written back
+	RH_LAUNCH(k_chain_gather, r.n_act, NT, 0, s, r);
+	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64 };
+	rhk_sort_job(s, jb, false, 0u);
+	RH_LAUNCH(k_chain_reorder, r.n_act, NT, 0, s, rd, r);
 }
 
 static bool regions_wave_ok(const rh_dev_opt &o) { return o.best_n == 0 && o.pri_ratio > 0.0f && !(o.flag & RH_M_ALL_CHAINS); }
