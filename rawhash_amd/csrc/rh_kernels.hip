@@ -23,11 +23,20 @@ RH_DEV float raw_to_pa(int16_t raw, double cal_off, float cal_scale)
 
 // ------------------------------------------------------------------------------------------------ k_prefilter
 // One block per read: count samples surviving the pA filter and record, for every chunk boundary, the raw index of the
-// first surviving sample of that chunk.  Signal bytes are read once, coalesced (2 B/sample).
+// first surviving sample of that chunk.  Each wavefront owns a contiguous quarter of the read and works on tiles of 256
+// samples (four coalesced 128-byte rows) with ballots only: pass 1 counts, one barrier turns the four counts into
+// offsets, pass 2 re-reads the quarter (L2) and ranks just the tiles that hold a chunk boundary.
+RH_DEV uint64_t pa_tile_ballot(const int16_t *raw, uint32_t i, uint32_t end, double coff, float cscale)
+{
+	bool valid = false;
+	if (i < end) { const float pa = raw_to_pa(raw[i], coff, cscale); valid = pa > 30.0f && pa < 200.0f; }
+	return __ballot(valid);
+}
+
 __global__ __launch_bounds__(NT) void k_prefilter(rh_dev_opt o, rh_dev_reads rd)
 {
-	__shared__ uint32_t s_w[NT / 64];
-	const uint32_t r = blockIdx.x, tid = threadIdx.x;
+	__shared__ uint32_t s_tot[NT / 64];
+	const uint32_t r = blockIdx.x, tid = threadIdx.x, w = wave_id(), l = lane_id();
 	const uint64_t o0 = rd.off[r], n64 = rd.off[r + 1] - o0;
 	const uint32_t n = (uint32_t)n64;
 	const int16_t *raw = rd.raw + o0;
@@ -35,23 +44,39 @@ __global__ __launch_bounds__(NT) void k_prefilter(rh_dev_opt o, rh_dev_reads rd)
 	const float cscale = rd.cal_scale[r];
 	uint32_t *cs = rd.chunk_start + (size_t)r * (RH_MAX_CHUNKS + 1);
 	for (uint32_t k = tid; k <= RH_MAX_CHUNKS; k += NT) cs[k] = n;
-	__syncthreads();
 	const uint32_t C = o.chunk_size;
-	uint32_t count = 0;
-	for (uint32_t base = 0; base < n; base += NT) {
-		const uint32_t i = base + tid;
-		bool valid = false;
-		if (i < n) { const float pa = raw_to_pa(raw[i], coff, cscale); valid = pa > 30.0f && pa < 200.0f; }
-		uint32_t total;
-		const uint32_t rank = block_rank(valid, s_w, total);
-		if (valid) {
-			const uint32_t fi = count + rank;
-			if (fi % C == 0) { const uint32_t k = fi / C; if (k <= RH_MAX_CHUNKS) cs[k] = i; }
+	const uint32_t per = ((n + (NT / 64) * 256u - 1) / ((NT / 64) * 256u)) * 256u;   // samples per wavefront, whole tiles
+	const uint32_t beg = w * per < n ? w * per : n, end = beg + per < n ? beg + per : n;
+	uint32_t cnt = 0;
+	for (uint32_t base = beg; base < end; base += 256) {
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k) cnt += (uint32_t)__popcll(pa_tile_ballot(raw, base + k * 64 + l, end, coff, cscale));
+	}
+	if (l == 0) s_tot[w] = cnt;
+	__syncthreads();                                              // (also orders the cs[] defaults before the boundary writes)
+	uint32_t run = 0, total = 0;
+	for (uint32_t q = 0; q < NT / 64; ++q) { const uint32_t c = s_tot[q]; if (q < w) run += c; total += c; }
+	for (uint32_t base = beg; base < end; base += 256) {
+		uint64_t B[4];
+		uint32_t tc = 0;
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k) { B[k] = pa_tile_ballot(raw, base + k * 64 + l, end, coff, cscale); tc += (uint32_t)__popcll(B[k]); }
+		const uint32_t nb = ((run + C - 1) / C) * C;               // first chunk boundary at or after this tile's first survivor
+		if (nb < run + tc) {
+			uint32_t before = run;
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) {
+				if ((B[k] >> l) & 1ull) {
+					const uint32_t fi = before + lanes_below(B[k]);
+					if (fi % C == 0) { const uint32_t kk = fi / C; if (kk <= RH_MAX_CHUNKS) cs[kk] = base + k * 64 + l; }
+				}
+				before += (uint32_t)__popcll(B[k]);
+			}
 		}
-		count += total;
+		run += tc;
 	}
 	if (tid == 0) {
-		rd.l_sig[r] = count;
+		rd.l_sig[r] = total;
 		rd.sum[r] = 0.0; rd.sum2[r] = 0.0; rd.n_sum[r] = 0; rd.ev_off[r] = 0; rd.n_prev[r] = 0; rd.prev_off[r] = 0;
 		rd.done[r] = 0; rd.stop_chunk[r] = 0; rd.ls_ncregs[r] = 0;
 	}
@@ -109,30 +134,50 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 	const uint32_t cs0 = cs[c], cs1 = cs[c + 1];
 	const uint32_t C = o.chunk_size;
 
-	// 1. load, convert, filter, compact (order preserving) + fp64 partial sums (exact for 30<pA<200, any order)
-	uint32_t count = 0;
+	// 1. load, convert, filter, compact (order preserving) + fp64 partial sums (exact for 30<pA<200, any order).
+	//    Each wavefront owns a contiguous quarter of the chunk's raw samples, in tiles of 256 (four coalesced rows); ranks
+	//    come from ballots, and the only barrier is the one that turns the four counts into offsets.
+	const uint32_t w = wave_id(), l = lane_id();
+	uint32_t s_len;
 	double dsum = 0.0, dsum2 = 0.0;
-	for (uint32_t base = cs0; base < cs1; base += NT) {
-		const uint32_t i = base + tid;
-		bool valid = false; float pa = 0.0f;
-		if (i < cs1) { pa = raw_to_pa(raw[i], coff, cscale); valid = pa > 30.0f && pa < 200.0f; }
-		uint32_t total;
-		const uint32_t rank = block_rank(valid, s_w, total);
-		if (valid && count + rank < C) {
-			s_a[count + rank] = pa;
-			dsum += (double)pa;
-			const float sq = pa * pa;
-			dsum2 += (double)sq;
+	{
+		const uint32_t span = cs1 - cs0;
+		const uint32_t per = ((span + (NT / 64) * 256u - 1) / ((NT / 64) * 256u)) * 256u;
+		const uint32_t beg = cs0 + (w * per < span ? w * per : span), end = beg + per < cs1 ? beg + per : cs1;
+		uint32_t cnt = 0;
+		for (uint32_t base = beg; base < end; base += 256) {
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) cnt += (uint32_t)__popcll(pa_tile_ballot(raw, base + k * 64 + l, end, coff, cscale));
 		}
-		count += total;
+		if (l == 0) s_w[w] = cnt;
+		__syncthreads();
+		uint32_t run = 0, count = 0;
+		for (uint32_t q = 0; q < NT / 64; ++q) { const uint32_t c2 = s_w[q]; if (q < w) run += c2; count += c2; }
+		for (uint32_t base = beg; base < end && run < C; base += 256) {
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) {
+				const uint32_t i = base + k * 64 + l;
+				bool valid = false; float pa = 0.0f;
+				if (i < end) { pa = raw_to_pa(raw[i], coff, cscale); valid = pa > 30.0f && pa < 200.0f; }
+				const uint64_t B = __ballot(valid);
+				const uint32_t pos = run + lanes_below(B);
+				if (valid && pos < C) {
+					s_a[pos] = pa;
+					dsum += (double)pa;
+					const float sq = pa * pa;
+					dsum2 += (double)sq;
+				}
+				run += (uint32_t)__popcll(B);
+			}
+		}
+		s_len = count < C ? count : C;
 	}
-	const uint32_t s_len = count < C ? count : C;
 	for (int d = 32; d > 0; d >>= 1) { dsum += __shfl_down(dsum, d); dsum2 += __shfl_down(dsum2, d); }
 	if (lane_id() == 0) { s_red[2 * wave_id()] = dsum; s_red[2 * wave_id() + 1] = dsum2; }
 	__syncthreads();
 	if (tid == 0) {
 		double S = rd.sum[r], S2 = rd.sum2[r];
-		for (uint32_t w = 0; w < NT / 64; ++w) { S += s_red[2 * w]; S2 += s_red[2 * w + 1]; }
+		for (uint32_t q = 0; q < NT / 64; ++q) { S += s_red[2 * q]; S2 += s_red[2 * q + 1]; }
 		const uint32_t N = rd.n_sum[r] + s_len;
 		rd.sum[r] = S; rd.sum2[r] = S2; rd.n_sum[r] = N;
 		const double mean = S / N;
@@ -144,16 +189,37 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 	__syncthreads();
 	const double mean = s_stat[0], sd = s_stat[1];
 
-	// 2. z-score, drop |z| >= 3, compact
-	uint32_t n = 0;
-	for (uint32_t base = 0; base < s_len; base += NT) {
-		const uint32_t i = base + tid;
-		bool keep = false; float v = 0.0f;
-		if (i < s_len) { v = (float)(((double)s_a[i] - mean) / sd); keep = v < 3.0f && v > -3.0f; }
-		uint32_t total;
-		const uint32_t rank = block_rank(keep, s_w, total);
-		if (keep) s_z[n + rank] = v;
-		n += total;
+	// 2. z-score, drop |z| >= 3, compact: same scheme; the z values of pass 1 wait in s_b for their slots
+	uint32_t n;
+	{
+		const uint32_t per = ((s_len + (NT / 64) * 256u - 1) / ((NT / 64) * 256u)) * 256u;
+		const uint32_t beg = w * per < s_len ? w * per : s_len, end = beg + per < s_len ? beg + per : s_len;
+		uint32_t cnt = 0;
+		for (uint32_t base = beg; base < end; base += 256) {
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) {
+				const uint32_t i = base + k * 64 + l;
+				bool keep = false;
+				if (i < end) { const float v = (float)(((double)s_a[i] - mean) / sd); s_b[i] = v; keep = v < 3.0f && v > -3.0f; }
+				cnt += (uint32_t)__popcll(__ballot(keep));
+			}
+		}
+		if (l == 0) s_w[w] = cnt;
+		__syncthreads();
+		uint32_t run = 0;
+		n = 0;
+		for (uint32_t q = 0; q < NT / 64; ++q) { const uint32_t c2 = s_w[q]; if (q < w) run += c2; n += c2; }
+		for (uint32_t base = beg; base < end; base += 256) {
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) {
+				const uint32_t i = base + k * 64 + l;
+				bool keep = false; float v = 0.0f;
+				if (i < end) { v = s_b[i]; keep = v < 3.0f && v > -3.0f; }
+				const uint64_t B = __ballot(keep);
+				if (keep) s_z[run + lanes_below(B)] = v;
+				run += (uint32_t)__popcll(B);
+			}
+		}
 	}
 	__syncthreads();
 	if (tid == 0) rr.n_norm[a] = n;
