@@ -68,12 +68,23 @@ RH_HD inline uint32_t rh_quantise(float s, float fine_min, float fine_max, float
 	return (uint32_t)(qz * (n_buckets - 1));
 }
 
+// Working storage of the sketch loop, by policy: plain arrays on the host; on the device an LDS slice per lane (a
+// lane-dependent index into a register array would be spilled to scratch memory).
+template <int MAXW>
+struct rh_sketch_store_local {
+	uint32_t r[16];
+	uint64_t x[MAXW > 0 ? MAXW : 1], y[MAXW > 0 ? MAXW : 1];
+	RH_HD uint32_t &ring(int i) { return r[i]; }
+	RH_HD uint64_t &bx(int i) { return x[i]; }
+	RH_HD uint64_t &by(int i) { return y[i]; }
+};
+
 // Sketch of one event array (reference ri_sketch rsketch.c:271 -> ri_sketch_reg :143-204 for w == 0,
 // ri_sketch_min :55-141 for w > 0).  `emit(x, y)` receives every seed in output order:
 //   x = hash << 6 | span,  y = id << 32 | first_event_pos << 1 | strand.
 // MAXW bounds the minimiser window the caller is prepared to hold (256 on the host, small on the device).
-template <int MAXW, class Emit>
-RH_HD inline void rh_sketch_events(const float *ev, uint32_t len, uint32_t id, int strand, const rh_sketch_par &sp, Emit &emit)
+template <int MAXW, class Emit, class Store>
+RH_HD inline void rh_sketch_events(const float *ev, uint32_t len, uint32_t id, int strand, const rh_sketch_par &sp, Emit &emit, Store &st)
 {
 	const int e = sp.e, w = sp.w;
 	const uint32_t qb = (uint32_t)sp.q, n_buckets = 1u << qb;
@@ -81,19 +92,17 @@ RH_HD inline void rh_sketch_events(const float *ev, uint32_t len, uint32_t id, i
 	const uint64_t id_shift = (uint64_t)id << 32;
 	const uint64_t mask_events = (qb * e >= 64) ? ~0ULL : ((1ULL << (qb * e)) - 1);
 	const uint64_t mask_q = (1ULL << qb) - 1;
-	// ring of the last e kept events: slot r holds the position (y) of the event that STARTS the e-mer whose
-	// hash (x) is written e-1 kept events later
-	uint64_t ring_y[16];
+	// ring of the last e kept events: slot r holds the position of the event that STARTS the e-mer whose hash (x) is
+	// written e-1 kept events later
 	if (len == 0 || e > 16) return;
-	for (int i = 0; i < 16; ++i) ring_y[i] = 0;
+	for (int i = 0; i < 16; ++i) st.ring(i) = 0;
 	int rp = 0, full = 0;
 	uint32_t last = 0, n_kept = 0;
 	uint64_t qv = 0;
 	// minimiser state (w > 0)
-	uint64_t buf_x[MAXW > 0 ? MAXW : 1], buf_y[MAXW > 0 ? MAXW : 1];
 	uint64_t min_x = ~0ULL, min_y = ~0ULL;
 	int buf_pos = 0, min_pos = 0;
-	if (w > 0) { if (w > MAXW) return; for (int i = 0; i < w; ++i) buf_x[i] = buf_y[i] = ~0ULL; }
+	if (w > 0) { if (w > MAXW) return; for (int i = 0; i < w; ++i) st.bx(i) = st.by(i) = ~0ULL; }
 
 	for (uint32_t f = 0; f < len; ++f) {
 		if (f > 0) { float d = ev[f] - ev[last]; if ((d < 0 ? -d : d) < sp.diff) continue; }
@@ -101,17 +110,17 @@ RH_HD inline void rh_sketch_events(const float *ev, uint32_t len, uint32_t id, i
 		++n_kept;
 		const uint64_t code = rh_quantise(ev[f], sp.fine_min, sp.fine_max, sp.fine_range, n_buckets) & mask_q;
 		qv = ((qv << qb) | code) & mask_events;
-		ring_y[rp] = id_shift | (uint64_t)(uint32_t)(f << 1) | (uint64_t)(uint32_t)strand;
+		st.ring(rp) = f;
 		if (++rp == e) { full = 1; rp = 0; }
 		if (!full) continue;
-		const uint64_t x = (rh_seed_hash32(qv) << 6) | span, y = ring_y[rp];
+		const uint64_t x = (rh_seed_hash32(qv) << 6) | span, y = id_shift | (uint64_t)(uint32_t)(st.ring(rp) << 1) | (uint64_t)(uint32_t)strand;
 		if (w == 0) { emit(x, y); continue; }
 		// ---- minimiser selection over windows of w consecutive e-mers (duplicates of the minimum are kept)
 		const uint32_t l = n_kept;
-		buf_x[buf_pos] = x; buf_y[buf_pos] = y;
+		st.bx(buf_pos) = x; st.by(buf_pos) = y;
 		if (l == (uint32_t)(w + e - 1) && min_x != ~0ULL) {
-			for (int j = buf_pos + 1; j < w; ++j) if (min_x == buf_x[j] && buf_y[j] != min_y) emit(buf_x[j], buf_y[j]);
-			for (int j = 0; j < buf_pos; ++j) if (min_x == buf_x[j] && buf_y[j] != min_y) emit(buf_x[j], buf_y[j]);
+			for (int j = buf_pos + 1; j < w; ++j) if (min_x == st.bx(j) && st.by(j) != min_y) emit(st.bx(j), st.by(j));
+			for (int j = 0; j < buf_pos; ++j) if (min_x == st.bx(j) && st.by(j) != min_y) emit(st.bx(j), st.by(j));
 		}
 		if (x <= min_x) {
 			if (l >= (uint32_t)(w + e) && min_x != ~0ULL) emit(min_x, min_y);
@@ -119,11 +128,11 @@ RH_HD inline void rh_sketch_events(const float *ev, uint32_t len, uint32_t id, i
 		} else if (buf_pos == min_pos) {
 			if (l >= (uint32_t)(w + e - 1) && min_x != ~0ULL) emit(min_x, min_y);
 			min_x = ~0ULL;
-			for (int j = buf_pos + 1; j < w; ++j) if (min_x >= buf_x[j]) { min_x = buf_x[j]; min_y = buf_y[j]; min_pos = j; }
-			for (int j = 0; j <= buf_pos; ++j) if (min_x >= buf_x[j]) { min_x = buf_x[j]; min_y = buf_y[j]; min_pos = j; }
+			for (int j = buf_pos + 1; j < w; ++j) if (min_x >= st.bx(j)) { min_x = st.bx(j); min_y = st.by(j); min_pos = j; }
+			for (int j = 0; j <= buf_pos; ++j) if (min_x >= st.bx(j)) { min_x = st.bx(j); min_y = st.by(j); min_pos = j; }
 			if (l >= (uint32_t)(w + e - 1) && min_x != ~0ULL) {
-				for (int j = buf_pos + 1; j < w; ++j) if (min_x == buf_x[j] && min_y != buf_y[j]) emit(buf_x[j], buf_y[j]);
-				for (int j = 0; j <= buf_pos; ++j) if (min_x == buf_x[j] && min_y != buf_y[j]) emit(buf_x[j], buf_y[j]);
+				for (int j = buf_pos + 1; j < w; ++j) if (min_x == st.bx(j) && min_y != st.by(j)) emit(st.bx(j), st.by(j));
+				for (int j = 0; j <= buf_pos; ++j) if (min_x == st.bx(j) && min_y != st.by(j)) emit(st.bx(j), st.by(j));
 			}
 		}
 		if (++buf_pos == w) buf_pos = 0;

@@ -306,7 +306,7 @@ extern "C" rh_index *rh_index_build(const char *fasta_path, const char *pore_mod
 				seq_to_levels(seqs[si], ix->pore_vals, io->k, strand, lv);
 				if (lv.empty()) continue;
 				SeedSink sink{&part[task]};
-				rh_sketch_events<256>(lv.data(), (uint32_t)lv.size(), (uint32_t)si, strand, sp, sink);
+				{ rh_sketch_store_local<256> st; rh_sketch_events<256>(lv.data(), (uint32_t)lv.size(), (uint32_t)si, strand, sp, sink, st); }
 			}
 		});
 	for (auto &t : th) t.join();

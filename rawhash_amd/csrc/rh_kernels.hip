@@ -360,13 +360,26 @@ struct seed_emit {
 	RH_HD void operator()(uint64_t x, uint64_t y) { if (n < cap) { sx[n] = x; sy[n] = y; } ++n; }
 };
 
-__global__ void k_sketch(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh_dev_round rr)
+// per-lane slices of LDS, slot-major: lane l of the wavefront owns column l (conflict-free whatever slot each lane indexes)
+template <bool MINIMISERS>
+struct sketch_store_lds {
+	uint32_t *r; uint64_t *x, *y;
+	__device__ uint32_t &ring(int i) { return r[i * 64]; }
+	__device__ uint64_t &bx(int i) { return x[MINIMISERS ? i * 64 : 0]; }
+	__device__ uint64_t &by(int i) { return y[MINIMISERS ? i * 64 : 0]; }
+};
+
+template <bool MINIMISERS>
+__global__ __launch_bounds__(64) void k_sketch(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh_dev_round rr)
 {
+	__shared__ uint32_t s_ring[16 * 64];
+	__shared__ uint64_t s_bx[MINIMISERS ? RH_DEV_MAXW * 64 : 64], s_by[MINIMISERS ? RH_DEV_MAXW * 64 : 64];
 	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
 	if (a >= rr.n_act) return;
 	if (rr.skip[a]) { rr.n_seed[a] = 0; return; }
 	seed_emit em = { rr.sx + (size_t)a * RH_EV_CAP, rr.sy + (size_t)a * RH_EV_CAP, 0u, RH_EV_CAP };
-	rh_sketch_events<RH_DEV_MAXW>(rr.ev + (size_t)a * RH_EV_CAP, rr.n_ev[a], 0u, 0, ix.sp, em);
+	sketch_store_lds<MINIMISERS> st = { s_ring + threadIdx.x, s_bx + threadIdx.x, s_by + threadIdx.x };
+	rh_sketch_events<RH_DEV_MAXW>(rr.ev + (size_t)a * RH_EV_CAP, rr.n_ev[a], 0u, 0, ix.sp, em, st);
 	const uint32_t ns = em.n < RH_EV_CAP ? em.n : RH_EV_CAP;
 	rr.n_seed[a] = ns;
 	atomicAdd((unsigned long long*)&rr.counters[1], (unsigned long long)ns);
@@ -585,7 +598,11 @@ void rhk_prefilter(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd) {
 void rhk_events_norm(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_norm, r.n_act, NT, 0, s, o, rd, r); }
 void rhk_events_peaks(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_peaks, cdiv(r.n_act, 64), 64, 0, s, o, r); }
 void rhk_events_means(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_means, r.n_act, NT, 0, s, o, r); }
-void rhk_sketch(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_sketch, cdiv(r.n_act, 64), 64, 0, s, o, ix, rd, r); }
+void rhk_sketch(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) {
+	if (!r.n_act) return;
+	if (ix.sp.w > 0) RH_LAUNCH(k_sketch<true>, cdiv(r.n_act, 64), 64, 0, s, o, ix, rd, r);
+	else RH_LAUNCH(k_sketch<false>, cdiv(r.n_act, 64), 64, 0, s, o, ix, rd, r);
+}
 void rhk_probe(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_probe, r.n_act, NT, 0, s, o, ix, rd, r); }
 void rhk_scan_anchors(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r) { RH_LAUNCH(k_scan_anchors, 1, 1024, 0, s, rd, r); }
 void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_expand, r.n_act, NT, 0, s, o, ix, rd, r); }
