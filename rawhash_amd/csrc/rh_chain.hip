@@ -22,71 +22,17 @@
 #define CH_SMALL 12     // clusters of up to this many anchors: the plain loop, one cluster per lane
 #endif
 
-// The reference loop (lchain.c:439-505) on one small cluster [b, b + m) per lane (m == 0: lane has none), with every
-// array index a compile-time constant: the loops over i and j are fully unrolled and predicated, so the per-lane state
-// stays in plain VGPRs (a lane-dependent index into a register array would cost a waterfall loop per access).  The t[]
-// marks of the reference become a bit mask per i; the state of max_ii is carried as values, not as an index.
-RH_DEV void chain_small_cluster(const rh_mm128_t *an, int32_t *gfp, int32_t *gv, int32_t b, int32_t m, int32_t max_dist_t, int32_t max_dist_q,
-                                int32_t bw, int32_t max_iter, int32_t max_skip, float pen_gap, float pen_skip)
-{
-	uint32_t xl[CH_SMALL], yl[CH_SMALL];
-	int32_t f[CH_SMALL], p[CH_SMALL], v[CH_SMALL], sp[CH_SMALL];
-	const uint32_t D32 = (uint32_t)max_dist_t;
-#pragma unroll
-	for (int k = 0; k < CH_SMALL; ++k) {
-		xl[k] = 0; yl[k] = 0; sp[k] = 0; f[k] = 0; p[k] = -1; v[k] = 0;
-		if (k < m) { const rh_mm128_t q = an[b + k]; xl[k] = (uint32_t)q.x; yl[k] = (uint32_t)q.y; sp[k] = (int32_t)((q.y >> 32) & 63); }
-	}
-	int32_t st = 0, mi = -1, f_ii = 0, sp_ii = 0, v_ii = 0;
-	uint32_t x_ii = 0, y_ii = 0;
-#pragma unroll
-	for (int i = 0; i < CH_SMALL; ++i) {
-		if (__ballot(i < m) == 0) break;
-		if (i < m) {
-			const uint32_t xi = xl[i], yi = yl[i];
-			int32_t max_f = sp[i], max_j = -1, v_mj = 0, n_skip = 0, end_j = 0;
-			uint32_t tm = 0;                                       // bit j: t[j] == i in the reference's terms
-			bool broke = false;
-			if (i - st > max_iter) st = i - max_iter;
-#pragma unroll
-			for (int k = 0; k < i; ++k) if (st == k && (uint32_t)(xi - xl[k]) > D32) st = k + 1;
-#pragma unroll
-			for (int j = i - 1; j >= 0; --j) {
-				if (!broke && j >= st) {
-					int32_t sc = rh_pair_score_d((int32_t)yi - (int32_t)yl[j], (int32_t)(xi - xl[j]), sp[j], max_dist_t, max_dist_q, bw, pen_gap, pen_skip);
-					if (sc != RH_SCORE_NONE) {
-						sc += f[j];
-						if (sc > max_f) { max_f = sc; max_j = j; v_mj = v[j]; if (n_skip > 0) --n_skip; }
-						else if ((tm >> j) & 1u) { if (++n_skip > max_skip) { broke = true; end_j = j; } }
-						if (!broke && p[j] >= 0) tm |= 1u << p[j];
-					}
-				}
-			}
-			if (!broke) end_j = st - 1;
-			if (mi < 0 || (uint32_t)(xi - x_ii) > D32) {
-				int32_t mx = INT32_MIN;
-				mi = -1;
-#pragma unroll
-				for (int j = i - 1; j >= 0; --j) if (j >= st && mx < f[j]) { mx = f[j]; mi = j; x_ii = xl[j]; y_ii = yl[j]; sp_ii = sp[j]; v_ii = v[j]; }
-				f_ii = mx;
-			}
-			if (mi >= 0 && mi < end_j) {
-				const int32_t tmp = rh_pair_score_d((int32_t)yi - (int32_t)y_ii, (int32_t)(xi - x_ii), sp_ii, max_dist_t, max_dist_q, bw, pen_gap, pen_skip);
-				if (tmp != RH_SCORE_NONE && max_f < tmp + f_ii) { max_f = tmp + f_ii; max_j = mi; v_mj = v_ii; }
-			}
-			const int32_t vv = (max_j >= 0 && v_mj > max_f) ? v_mj : max_f;
-			f[i] = max_f; p[i] = max_j; v[i] = vv;
-			gfp[2 * (b + i)] = max_f; gfp[2 * (b + i) + 1] = max_j < 0 ? -1 : b + max_j; gv[b + i] = vv;
-			if (mi < 0 || ((uint32_t)(xi - x_ii) <= D32 && f_ii < max_f)) { mi = i; f_ii = max_f; x_ii = xi; y_ii = yi; sp_ii = sp[i]; v_ii = vv; }
-		}
-	}
-}
-
 struct chain_lds {
 	uint32_t xlo[CH_RING], ylo[CH_RING];
 	int32_t f[CH_RING], p[CH_RING], v[CH_RING], t[CH_RING];
 	uint8_t span[CH_RING];
+	// small clusters: coordinates of the last two tiles and the max_ii state after each of their anchors
+	uint32_t s_xlo[128], s_ylo[128];
+	int32_t s_mi[128];
+	uint8_t s_span[128];
 };
+
+#define CH_FAR (INT32_MIN + 1)   // pair further apart than max_dist_t on the target: ends the predecessor window
 
 __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr)
 {
@@ -109,7 +55,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 	__syncthreads();
 
 	// Anchors are read once, 64 at a time (coalesced); the sequential walk below only touches registers (shuffles) and LDS.
-	int32_t st = 0, max_ii = -1, f_ii = 0, skip_until = 0;
+	int32_t st = 0, max_ii = -1, f_ii = 0, open_start = 0;
 	uint32_t xlo_ii = 0;
 	uint64_t x_before = 0;                                         // x of the anchor preceding the tile
 	// software pipeline over the tiles: A = current, B = next (needed to size a cluster that runs over the tile edge), C in flight
@@ -134,22 +80,24 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 		const bool nstart = lane < 63 ? ((bmask >> (lane + 1)) & 1ull) != 0 : (bmaskB & 1ull) != 0;
 		const bool single = start && nstart;
 		if (inb && single) { const int32_t sp = (int32_t)((y >> 32) & 63); gfp[2 * ii] = sp; gfp[2 * ii + 1] = -1; gv[ii] = sp; }
-		// small clusters: their start lane runs the plain loop for the whole cluster (all lanes busy on different clusters)
-		int32_t csz = 0;
-		if (inb && start && !single) {
+		// the cluster [cs_g, ce_g] (global indices) of every anchor of the tile, from the boundary masks
+		int32_t cs_g, ce_g;
+		{
+			const uint64_t sm = smask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+			cs_g = sm ? i0 + 63 - (int32_t)__clzll(sm) : open_start;
 			const uint64_t after = lane < 63 ? bmask >> (lane + 1) : 0ull;
-			if (after) csz = 1 + __builtin_ctzll(after);
-			else csz = (64 - (int32_t)lane) + (bmaskB ? __builtin_ctzll(bmaskB) : CH_SMALL + 1);
+			if (after) ce_g = ii + (int32_t)__builtin_ctzll(after);
+			else if (bmaskB) ce_g = i0 + 63 + (int32_t)__builtin_ctzll(bmaskB);
+			else ce_g = 0x3FFFFFFF;
 		}
-		const uint64_t small_mask = __ballot(csz > 0 && csz <= CH_SMALL);
-		if (small_mask) chain_small_cluster(an, gfp, gv, ii, (csz > 0 && csz <= CH_SMALL) ? csz : 0, max_dist_t, max_dist_q, bw, max_iter, max_skip, o.pen_gap, o.pen_skip);
-		uint64_t mmask = __ballot(inb && !single);                  // members of multi-anchor clusters, walked in order
+		const bool small = inb && !single && ce_g - cs_g < CH_SMALL;
+		const int32_t pos = ii - cs_g;
+		if (!(bmaskB & 1ull) && smask) open_start = i0 + 63 - (int32_t)__clzll(smask);   // cluster still open at the tile's end
+		uint64_t mmask = __ballot(inb && !single && !small);       // members of the larger clusters, walked in order
 		while (mmask) {
 			const int b = __builtin_ctzll(mmask);
 			mmask &= mmask - 1;
 			const int32_t i = i0 + b;
-			if ((small_mask >> b) & 1ull) skip_until = i + (int32_t)rh_readlane((uint32_t)csz, (uint32_t)b);
-			if (i < skip_until) continue;                            // member of a small cluster, already done
 			const uint64_t xi = (uint64_t)rh_readlane((uint32_t)(x >> 32), (uint32_t)b) << 32 | rh_readlane((uint32_t)x, (uint32_t)b);
 			const uint64_t yi = (uint64_t)rh_readlane((uint32_t)(y >> 32), (uint32_t)b) << 32 | rh_readlane((uint32_t)y, (uint32_t)b);
 			if ((smask >> b) & 1ull) { st = i; max_ii = -1; }       // cluster start: window and max_ii state reset
@@ -231,6 +179,81 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 			}
 			if (max_ii < 0 || ((uint32_t)(xi_lo - xlo_ii) <= D32 && f_ii < max_f)) { max_ii = i; f_ii = max_f; xlo_ii = xi_lo; }
 			__syncthreads();
+		}
+		// Small clusters (up to CH_SMALL anchors: the bulk of a chunk's anchors), one anchor per lane.  The pair scores - the
+		// expensive, DP-independent part of lchain.c:439-505 - are computed for all anchors of the tile at once (predecessor
+		// r back, r = 1, 2, ...); the DP itself then runs in steps over the position inside the cluster: step s settles the
+		// s-th anchor of every cluster of the tile together, from f / p of its predecessors in the LDS ring.  Every index
+		// is a compile-time constant after unrolling, so the per-lane scores stay in VGPRs.
+		if (__ballot(small)) {
+			const uint32_t xi = (uint32_t)x, yi = (uint32_t)y;
+			const int32_t span_i = (int32_t)((y >> 32) & 63);
+			if (inb) { const uint32_t sl = (uint32_t)ii & 127u; L.s_xlo[sl] = xi; L.s_ylo[sl] = yi; L.s_span[sl] = (uint8_t)span_i; }
+			__syncthreads();
+			int32_t sc[CH_SMALL];
+#pragma unroll
+			for (int r = 1; r < CH_SMALL; ++r) {
+				sc[r] = RH_SCORE_NONE;
+				if (__ballot(small && pos >= r) == 0) break;
+				if (small && pos >= r) {
+					const uint32_t sl = (uint32_t)(ii - r) & 127u;
+					const uint32_t xj = L.s_xlo[sl], yj = L.s_ylo[sl];
+					sc[r] = (uint32_t)(xi - xj) > D32 ? CH_FAR
+					        : rh_pair_score_d((int32_t)yi - (int32_t)yj, (int32_t)(xi - xj), (int32_t)L.s_span[sl], max_dist_t, max_dist_q, bw, o.pen_gap, o.pen_skip);
+				}
+			}
+#pragma unroll
+			for (int sidx = 0; sidx < CH_SMALL; ++sidx) {
+				if (__ballot(small && pos >= sidx) == 0) break;
+				if (small && pos == sidx) {
+					int32_t max_f = span_i, max_j = -1, n_skip = 0, end_j = 0, nwin = 0;
+					uint32_t tm = 0;                                   // bit k: the cluster's k-th anchor carries t[] == i
+					bool broke = false, far = false;
+					int32_t fr[CH_SMALL];
+#pragma unroll
+					for (int r = 1; r <= sidx; ++r) {
+						fr[r] = 0;
+						if (far || sc[r] == CH_FAR || r > max_iter) far = true;
+						else {
+							nwin = r;
+							const uint32_t sl = (uint32_t)(ii - r) & (CH_RING - 1);
+							const int32_t fj = L.f[sl], pj = L.p[sl];
+							fr[r] = fj;
+							if (!broke && sc[r] != RH_SCORE_NONE) {
+								const int32_t cand = sc[r] + fj;
+								if (cand > max_f) { max_f = cand; max_j = ii - r; if (n_skip > 0) --n_skip; }
+								else if ((tm >> (sidx - r)) & 1u) { if (++n_skip > max_skip) { broke = true; end_j = ii - r; } }
+								if (!broke && pj >= 0) tm |= 1u << (pj - cs_g);
+							}
+						}
+					}
+					if (!broke) end_j = ii - nwin - 1;
+					// max_ii: state left by the previous anchor of the cluster; re-derived from the window when out of reach
+					int32_t mi = sidx == 0 ? -1 : L.s_mi[(uint32_t)(ii - 1) & 127u], fmi = 0;
+					uint32_t xmi = 0;
+					if (mi >= 0) { xmi = L.s_xlo[(uint32_t)mi & 127u]; fmi = L.f[(uint32_t)mi & (CH_RING - 1)]; }
+					if (mi < 0 || (uint32_t)(xi - xmi) > D32) {
+						int32_t mx = INT32_MIN;
+						mi = -1;
+#pragma unroll
+						for (int r = 1; r <= sidx; ++r) if (r <= nwin && mx < fr[r]) { mx = fr[r]; mi = ii - r; }
+						if (mi >= 0) { fmi = mx; xmi = L.s_xlo[(uint32_t)mi & 127u]; }
+					}
+					if (mi >= 0 && mi < end_j) {
+						const uint32_t sl = (uint32_t)mi & 127u;
+						const int32_t tmp = rh_pair_score_d((int32_t)yi - (int32_t)L.s_ylo[sl], (int32_t)(xi - xmi), (int32_t)L.s_span[sl], max_dist_t, max_dist_q, bw, o.pen_gap, o.pen_skip);
+						if (tmp != RH_SCORE_NONE && max_f < tmp + fmi) { max_f = tmp + fmi; max_j = mi; }
+					}
+					int32_t vv = max_f;
+					if (max_j >= 0) { const int32_t vmj = L.v[(uint32_t)max_j & (CH_RING - 1)]; if (vmj > max_f) vv = vmj; }
+					const uint32_t sl = (uint32_t)ii & (CH_RING - 1);
+					L.f[sl] = max_f; L.p[sl] = max_j; L.v[sl] = vv;
+					gfp[2 * ii] = max_f; gfp[2 * ii + 1] = max_j; gv[ii] = vv;
+					if (mi < 0 || ((uint32_t)(xi - xmi) <= D32 && fmi < max_f)) mi = ii;
+					L.s_mi[(uint32_t)ii & 127u] = mi;
+				}
+				__syncthreads();                                     // the step's f / p / v / max_ii are in the ring
+			}
 		}
 		x_before = x_last;
 	}
