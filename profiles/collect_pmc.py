@@ -55,7 +55,7 @@ def main():
         kernels[k] = {"launches": n, "read_bytes": rd, "write_bytes": wr, "bytes_per_launch": (rd + wr) / max(n, 1)}
     stages = {}
     for k, v in kernels.items():
-        st = STAGE_OF.get(k) or (k.split("@")[1] if k.startswith("k_sort") else None)
+        st = STAGE_OF.get(k) or STAGE_OF.get(k.split("<")[0]) or (k.split("@")[1] if k.startswith("k_sort") else None)
         if st is None:
             continue
         e = stages.setdefault(st, {"launches": 0, "bytes": 0.0})
