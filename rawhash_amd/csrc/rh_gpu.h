@@ -32,7 +32,12 @@ __device__ __forceinline__ uint32_t rh_readlane(uint32_t v, uint32_t l) { return
 // callers), which keeps clear of the "VALU-written SGPR as lane select" hazard the assembler cannot see inside asm
 __device__ __forceinline__ uint32_t rh_writelane(uint32_t v, uint32_t val, uint32_t l) { asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(l) : "m0"); return v; }   // (one SGPR + M0: constant-bus limit)
 __device__ __forceinline__ uint32_t rh_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// value of lane (l & ~1) / (l | 1) of each lane pair (DPP quad permutes: VALU speed, no LDS)
+__device__ __forceinline__ int32_t rh_quad_perm_0022(int32_t v) { return __builtin_amdgcn_mov_dpp(v, 0xA0, 0xF, 0xF, true); }
+__device__ __forceinline__ int32_t rh_quad_perm_1133(int32_t v) { return __builtin_amdgcn_mov_dpp(v, 0xF5, 0xF, 0xF, true); }
 #else
+__device__ int32_t rh_quad_perm_0022(int32_t v);
+__device__ int32_t rh_quad_perm_1133(int32_t v);
 __device__ uint32_t rh_readlane(uint32_t v, uint32_t l);
 __device__ uint32_t rh_writelane(uint32_t v, uint32_t val, uint32_t l);
 __device__ uint32_t rh_uniform(uint32_t v);

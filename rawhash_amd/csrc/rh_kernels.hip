@@ -261,56 +261,71 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 	}
 }
 
-struct peak_det { float thr; uint32_t win, masked_to; int32_t pos; float val; int32_t valid; };
-
-// One read per lane.  Tiles of 64 steps x 64 reads of t1 / t2 are transposed through LDS (row stride 65: conflict free
-// reads, 2-way writes) so that HBM is read in full 256-byte rows while every lane walks its own chunk.
+// Two lanes per chunk, one per peak detector (short / long window), 32 chunks per wavefront.  Within a step the reference
+// runs the short detector first, and only it acts on the other (it masks the long one while it rides a strong peak);
+// so the long detector's lane simply lags one step behind and receives the short one's masking event of that step
+// through a DPP quad permute before it starts.  One generic detector body per iteration instead of two in sequence.
+// Tiles of 64 steps x 32 chunks of t1 and t2 are transposed through LDS (row stride 33: conflict-free reads) so that
+// HBM is read in full 256-byte rows.
 #define PK_TILE 64
+#define PK_CHUNKS 32
 __global__ __launch_bounds__(64) void k_events_peaks(rh_dev_opt o, rh_dev_round rr)
 {
-	__shared__ float s_t1[PK_TILE * 65], s_t2[PK_TILE * 65];
-	const uint32_t lane = threadIdx.x, a0 = blockIdx.x * 64, a = a0 + lane;
+	__shared__ float s_t[2][PK_TILE * (PK_CHUNKS + 1)];
+	const uint32_t lane = threadIdx.x, c = lane >> 1, k = lane & 1u, a0 = blockIdx.x * PK_CHUNKS, a = a0 + c;
 	const uint32_t n = a < rr.n_act ? rr.n_norm[a] : 0u;
 	uint32_t nmax = n;
 	for (int d = 32; d > 0; d >>= 1) { const uint32_t t = __shfl_xor(nmax, d); if (t > nmax) nmax = t; }
-	peak_det d0 = { o.thr1, o.w1, 0u, -1, FLT_MAX, 0 }, d1 = { o.thr2, o.w2, 0u, -1, FLT_MAX, 0 };
-	const float ph = o.peak_height;
-	uint32_t np = 0;
+	const float thr = k == 0 ? o.thr1 : o.thr2, ph = o.peak_height;
+	const uint32_t win = k == 0 ? o.w1 : o.w2;
+	uint32_t masked_to = 0, np = 0;
+	int32_t pos = -1, valid = 0;
+	float val = FLT_MAX, held = 0.0f;                               // held: the long detector's sample of the step it is about to process
+	uint32_t ev_in = 0;                                             // masking event of that step: 1u << 31 | masked_to
 	uint16_t *pk = rr.peaks + (size_t)a * RH_EV_CAP;
-	const uint32_t rows = rr.n_act - a0 < 64u ? rr.n_act - a0 : 64u;
-	for (uint32_t i0 = 0; i0 < nmax; i0 += PK_TILE) {
+	const uint32_t rows = rr.n_act - a0 < PK_CHUNKS ? rr.n_act - a0 : PK_CHUNKS;
+	for (uint32_t i0 = 0; i0 <= nmax; i0 += PK_TILE) {               // (<=: one more iteration for the lagging lanes)
 		__syncthreads();
 		for (uint32_t row = 0; row < rows; ++row) {
 			const size_t g = (size_t)(a0 + row) * EV_ROW + i0 + lane;     // lane = step inside the tile
-			s_t1[lane * 65 + row] = rr.t1buf[g];
-			s_t2[lane * 65 + row] = rr.t2buf[g];
+			s_t[0][lane * (PK_CHUNKS + 1) + row] = rr.t1buf[g];
+			s_t[1][lane * (PK_CHUNKS + 1) + row] = rr.t2buf[g];
 		}
 		__syncthreads();
-		const uint32_t iend = i0 + PK_TILE < n ? i0 + PK_TILE : n;
-		for (uint32_t i = i0; i < iend; ++i) {
-			const uint32_t sl = (i - i0) * 65 + lane;
-			#pragma unroll
-			for (int k = 0; k < 2; ++k) {
-				peak_det &q = k == 0 ? d0 : d1;
-				if (q.masked_to >= i) continue;
-				const float cur = k == 0 ? s_t1[sl] : s_t2[sl];
-				if (q.pos == -1) {
-					if (cur < q.val) q.val = cur;
-					else if (cur - q.val > ph) { q.val = cur; q.pos = (int32_t)i; }
-				} else {
-					if (cur > q.val) { q.val = cur; q.pos = (int32_t)i; }
-					if (k == 0 && q.val > q.thr) { d1.masked_to = (uint32_t)q.pos + d0.win; d1.pos = -1; d1.val = FLT_MAX; d1.valid = 0; }
-					if (q.val - cur > ph && q.val > q.thr) q.valid = 1;
-					if (q.valid && (i - (uint32_t)q.pos) > q.win / 2) {
-						if (np < RH_EV_CAP) pk[np] = (uint16_t)q.pos;
-						++np;
-						q.pos = -1; q.val = cur; q.valid = 0;
+		const uint32_t tend = i0 + PK_TILE < nmax + 1 ? i0 + PK_TILE : nmax + 1;
+		for (uint32_t t = i0; t < tend; ++t) {
+			const float cur_t = s_t[k][(t - i0) * (PK_CHUNKS + 1) + c];   // sample of step t of this lane's statistic
+			const uint32_t i = t - k;                                   // the step this lane processes now
+			const bool act = k == 0 ? t < n : (t >= 1 && t <= n);
+			const float cur = k == 0 ? cur_t : held;
+			held = cur_t;
+			uint32_t ev_out = 0;
+			int32_t emit = -1;
+			if (act) {
+				if (ev_in >> 31) { masked_to = ev_in & 0x7FFFFFFFu; pos = -1; val = FLT_MAX; valid = 0; }
+				if (!(masked_to >= i)) {
+					if (pos == -1) {
+						if (cur < val) val = cur;
+						else if (cur - val > ph) { val = cur; pos = (int32_t)i; }
+					} else {
+						if (cur > val) { val = cur; pos = (int32_t)i; }
+						if (k == 0 && val > thr) ev_out = 1u << 31 | ((uint32_t)pos + win);
+						if (val - cur > ph && val > thr) valid = 1;
+						if (valid && (i - (uint32_t)pos) > win / 2) { emit = pos; pos = -1; val = cur; valid = 0; }
 					}
 				}
 			}
+			// partner exchange: the long lane takes the short lane's event (for the step it processes next); both learn
+			// whether the other emitted.  Order inside the iteration as in the reference: (step t-1, long) then (step t, short).
+			ev_in = (uint32_t)rh_quad_perm_0022((int32_t)ev_out);
+			if (k == 0) ev_in = 0;
+			const int32_t e_mine = emit >= 0 ? 1 : 0;
+			const int32_t e_short = rh_quad_perm_0022(e_mine), e_long = rh_quad_perm_1133(e_mine);
+			if (emit >= 0) { const uint32_t at = np + (k == 0 ? (uint32_t)e_long : 0u); if (at < RH_EV_CAP) pk[at] = (uint16_t)emit; }
+			np += (uint32_t)(e_short + e_long);
 		}
 	}
-	if (a < rr.n_act) rr.n_peaks[a] = np < RH_EV_CAP ? np : RH_EV_CAP;
+	if (a < rr.n_act && k == 0) rr.n_peaks[a] = np < RH_EV_CAP ? np : RH_EV_CAP;
 }
 
 __global__ __launch_bounds__(NT) void k_events_means(rh_dev_opt o, rh_dev_round rr)
@@ -596,7 +611,7 @@ static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 void rhk_prefilter(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd) { if (rd.n_reads) RH_LAUNCH(k_prefilter, rd.n_reads, NT, 0, s, o, rd); }
 void rhk_events_norm(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_norm, r.n_act, NT, 0, s, o, rd, r); }
-void rhk_events_peaks(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_peaks, cdiv(r.n_act, 64), 64, 0, s, o, r); }
+void rhk_events_peaks(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_peaks, cdiv(r.n_act, PK_CHUNKS), 64, 0, s, o, r); }
 void rhk_events_means(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_means, r.n_act, NT, 0, s, o, r); }
 void rhk_sketch(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) {
 	if (!r.n_act) return;

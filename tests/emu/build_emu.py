@@ -15,31 +15,33 @@ SMALL_CAPS = ("-DRG_CAP=8", "-DRGW_CAP=48", "-DRGW_CAP0=16", "-DRGR_PRIM_CAP=5",
 
 
 def build(force=False, defines=(), tag=""):
+    import fcntl
     src_dir = os.path.join(BUILD, "src")
     os.makedirs(src_dir, exist_ok=True)
-    srcs = []
-    newest = 0.0
-    for f in sorted(os.listdir(CSRC)):
-        if f == "rh_gpu.h" or not f.endswith((".h", ".cpp", ".hip")):
-            continue
-        dst = os.path.join(src_dir, f)
-        if os.path.lexists(dst):
-            os.remove(dst)
-        os.symlink(os.path.join(CSRC, f), dst)       # same files, but rh_gpu.h now resolves to the emulator's
-        newest = max(newest, os.path.getmtime(os.path.join(CSRC, f)))
-        if f.endswith((".cpp", ".hip")):
-            srcs.append(dst)
-    for f in ("rh_gpu.h", "emu_runtime.cpp"):
-        shutil.copy(os.path.join(HERE, f), os.path.join(src_dir, f))
-        newest = max(newest, os.path.getmtime(os.path.join(HERE, f)))
-    srcs.append(os.path.join(src_dir, "emu_runtime.cpp"))
-    newest = max(newest, os.path.getmtime(os.path.join(ROOT, "include", "rawhash_amd.h")))
+    names = [f for f in sorted(os.listdir(CSRC)) if f != "rh_gpu.h" and f.endswith((".h", ".cpp", ".hip"))]
+    newest = max([os.path.getmtime(os.path.join(CSRC, f)) for f in names] +
+                 [os.path.getmtime(os.path.join(HERE, f)) for f in ("rh_gpu.h", "emu_runtime.cpp")] +
+                 [os.path.getmtime(os.path.join(ROOT, "include", "rawhash_amd.h"))])
     out = OUT.replace(".so", tag + ".so")
-    if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
-        return out
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-pthread", "-w",
-           "-I", src_dir, "-I", os.path.join(ROOT, "include"), "-x", "c++"] + list(defines) + srcs + ["-o", out, "-lz"]
-    subprocess.run(cmd, check=True)
+    with open(os.path.join(BUILD, ".lock"), "w") as lock:       # several test processes (2-rank gloo test) may get here together
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
+            return out
+        srcs = []
+        for f in names:
+            dst = os.path.join(src_dir, f)
+            if os.path.lexists(dst):
+                os.remove(dst)
+            os.symlink(os.path.join(CSRC, f), dst)       # same files, but rh_gpu.h now resolves to the emulator's
+            if f.endswith((".cpp", ".hip")):
+                srcs.append(dst)
+        for f in ("rh_gpu.h", "emu_runtime.cpp"):
+            shutil.copy(os.path.join(HERE, f), os.path.join(src_dir, f))
+        srcs.append(os.path.join(src_dir, "emu_runtime.cpp"))
+        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-pthread", "-w",
+               "-I", src_dir, "-I", os.path.join(ROOT, "include"), "-x", "c++"] + list(defines) + srcs + ["-o", out + ".tmp", "-lz"]
+        subprocess.run(cmd, check=True)
+        os.replace(out + ".tmp", out)
     return out
 
 

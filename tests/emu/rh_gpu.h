@@ -57,6 +57,8 @@ static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if 
 static inline unsigned rh_readlane(unsigned v, unsigned l) { return (unsigned)emu_shfl_bits(v, 5, l); }
 static inline unsigned rh_writelane(unsigned v, unsigned val, unsigned l) { return (threadIdx.x & 63u) == l ? val : v; }
 static inline unsigned rh_uniform(unsigned v) { return v; }
+static inline int rh_quad_perm_0022(int v) { return (int)emu_shfl_bits((unsigned)v, 5, (threadIdx.x & 63u) & ~1u); }
+static inline int rh_quad_perm_1133(int v) { return (int)emu_shfl_bits((unsigned)v, 5, (threadIdx.x & 63u) | 1u); }
 #define RH_WAVE_SYNC() ((void)emu_ballot(1))
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) (*(p))
