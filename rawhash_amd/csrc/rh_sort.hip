@@ -374,6 +374,253 @@ __global__ __launch_bounds__(NT) void k_sort_block(rh_sort_job jb, uint32_t n_lo
 	for (uint32_t i = tid; i < n; i += NT) { const uint32_t idx = L.ia[i]; if ((L.tbit[idx >> 5] >> (idx & 31u)) & 1u) dst[i] = src[idx]; }
 }
 
+// ------------------------------------------------------------------------------------------------ segments beyond the LDS classes
+// Same algorithm, one workgroup per segment, with the permutation arrays in HBM scratch (they stay in L2: 12 B per
+// record) and the keys read in place from the records: larger genomes put tens of thousands of anchors into one chunk.
+// Only the histogram / bucket heads and, for the exact cycle walk, the digits of the range being walked live in LDS.
+#ifndef RH_SORT_GCAP
+#define RH_SORT_GCAP (1u << 20)    // records per segment; beyond: the serial emulation
+#endif
+#ifndef RH_SORTG_DB
+#define RH_SORTG_DB 49152          // records of a range whose digits the exact walk caches in LDS
+#endif
+
+struct sortg_lds {
+	uint32_t cnt[256], head[256];
+	uint8_t dmap[256], inv[256];
+	uint32_t w[NT / 64];
+	uint64_t r64[NT / 64];
+	uint32_t n_rng[2], tie, misc[4];
+	uint8_t db[RH_SORTG_DB];
+};
+struct sortg_mem {
+	const rh_mm128_t *src;
+	uint32_t *ia, *ib, *tm;            // arrangement, pass output, scratch (rank lists / gather map)
+	uint32_t *sbit, *ebit, *tbit;
+	uint64_t *rng[2];                  // ranges > 64 still to be split: beg | end << 32
+	uint8_t *rsh[2];
+};
+
+RH_DEV uint64_t sortg_key(const sortg_mem &G, uint32_t i) { return G.src[G.ia[i]].x; }
+RH_DEV uint32_t sortg_digit(const sortg_mem &G, uint32_t i, int s) { return (uint32_t)(sortg_key(G, i) >> s) & 255u; }
+
+// one wavefront: the reference's cycle walk over >= 3 buckets (see sort_cycle_walk_hb); digits from the LDS cache when the
+// range fits it, else recomputed from the keys; gather map -> G.tm
+RH_DEV void sortg_cycle_walk(sortg_lds &L, const sortg_mem &G, uint32_t beg, uint32_t end, int s, uint32_t nbk, bool cached)
+{
+	const uint32_t lane = lane_id();
+	uint32_t hd[4], tl[4];
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		const uint32_t id = (uint32_t)q * 64u + lane;
+		hd[q] = 0; tl[q] = 0;
+		if (id < nbk) { const uint32_t dgt = L.inv[id]; hd[q] = L.head[dgt] - beg; tl[q] = hd[q] + L.cnt[dgt]; }
+	}
+	const uint32_t ubeg = rh_uniform(beg);
+	uint32_t *tmr = G.tm + ubeg;
+	#define SG_DIGIT(p) rh_uniform(cached ? (uint32_t)L.db[(p)] : (uint32_t)L.dmap[sortg_digit(G, ubeg + (p), s)])
+	for (uint32_t c = 0; c < nbk; ++c) {
+		uint32_t tlc = rh_readlane(tl[0], c & 63u), h = rh_readlane(hd[0], c & 63u);
+#pragma unroll
+		for (int q = 1; q < 4; ++q) { const uint32_t t2 = rh_readlane(tl[q], c & 63u), h2 = rh_readlane(hd[q], c & 63u); if ((c >> 6) == (uint32_t)q) { tlc = t2; h = h2; } }
+		while (h != tlc) {
+			uint32_t src = h;
+			uint32_t d = SG_DIGIT(h);
+			while (d != c) {
+				uint32_t r[4];
+#pragma unroll
+				for (int k = 0; k < 4; ++k) r[k] = rh_readlane(hd[k], d & 63u);
+				uint32_t q = r[0];
+#pragma unroll
+				for (int k = 1; k < 4; ++k) q = (d >> 6) == (uint32_t)k ? r[k] : q;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) hd[k] = rh_writelane(hd[k], (d >> 6) == (uint32_t)k ? q + 1 : r[k], d & 63u);
+				tmr[q] = ubeg + src;
+				src = q;
+				d = SG_DIGIT(q);
+			}
+			tmr[h] = ubeg + src;
+			++h;
+		}
+	}
+	#undef SG_DIGIT
+}
+
+RH_DEV void sortg_split_range(sortg_lds &L, const sortg_mem &G, uint32_t beg, uint32_t end, int shift, int nxt, int pass)
+{
+	const uint32_t tid = threadIdx.x;
+	const uint64_t k0 = sortg_key(G, beg);
+	uint64_t diff = 0;
+	bool tied = false;
+	for (uint32_t i = beg + tid; i < end; i += NT) {
+		const uint32_t idx = G.ia[i];
+		diff |= G.src[idx].x ^ k0;
+		if (pass == SORT_EXACT_TIED) tied |= (G.tbit[idx >> 5] >> (idx & 31u) & 1u) != 0;
+	}
+	const uint64_t tmk = __ballot(tied);
+	if (lane_id() == 0) L.w[wave_id()] = tmk != 0;
+	diff = block_or64(diff, L.r64);
+	if (diff == 0) return;
+	if (pass == SORT_EXACT_TIED && (L.w[0] | L.w[1] | L.w[2] | L.w[3]) == 0) return;
+	const bool exact = pass != SORT_FAST;
+	int s = (63 - __clzll(diff)) & ~7;
+	if (s > shift) s = shift;
+	L.cnt[tid] = 0;
+	__syncthreads();
+	for (uint32_t i = beg + tid; i < end; i += NT) atomicAdd(&L.cnt[sortg_digit(G, i, s)], 1u);
+	__syncthreads();
+	const uint32_t my_cnt = L.cnt[tid];
+	uint32_t total;
+	const uint32_t my_start = beg + block_excl_scan(my_cnt, L.w, total);
+	L.head[tid] = my_start;
+	uint32_t nbk;
+	const uint32_t dense = block_rank(my_cnt != 0, L.w, nbk);
+	if (exact && my_cnt != 0) { L.dmap[tid] = (uint8_t)dense; L.inv[dense] = (uint8_t)tid; }
+	// permutation of the pass: ia[beg, end) -> ib[beg, end)
+	if (!exact) {
+		for (uint32_t i = beg + tid; i < end; i += NT) { const uint32_t pos = atomicAdd(&L.head[sortg_digit(G, i, s)], 1u); G.ib[pos] = G.ia[i]; }
+	} else if (nbk == 2) {
+		// two buckets A < B: closed form of the cycle-leader result (see sort_two_buckets), rank lists in G.tm
+		if (my_cnt != 0) { const uint32_t which = my_start == beg ? 0u : 1u; L.misc[which] = tid; L.misc[2 + which] = my_start; }
+		__syncthreads();
+		const uint32_t cA = L.misc[0], cB = L.misc[1], startB = L.misc[3];
+		uint32_t m = 0;
+		for (uint32_t base = beg; base < startB; base += NT) {
+			const uint32_t i = base + tid;
+			const bool foreign = i < startB && sortg_digit(G, i, s) == cB;
+			uint32_t tot;
+			const uint32_t rk = block_rank(foreign, L.w, tot);
+			if (i < startB) { if (foreign) G.tm[beg + m + rk] = i; else G.ib[i] = G.ia[i]; }
+			m += tot;
+		}
+		__syncthreads();
+		uint32_t fb = 0;
+		for (uint32_t base = startB; base < end; base += NT) {
+			const uint32_t i = base + tid;
+			const bool foreign = i < end && sortg_digit(G, i, s) == cA;
+			uint32_t tot;
+			const uint32_t rk = block_rank(foreign, L.w, tot);
+			if (i < end) {
+				const uint32_t r = fb + rk;
+				if (foreign) { G.ib[G.tm[beg + r]] = G.ia[i]; G.tm[end - 1 - r] = i; }
+				else G.ib[r < m ? i + 1 : i] = G.ia[i];
+			}
+			fb += tot;
+		}
+		__syncthreads();
+		for (uint32_t k = tid; k < m; k += NT) G.ib[k == 0 ? startB : G.tm[end - k] + 1u] = G.ia[G.tm[beg + k]];
+	} else {
+		const bool cached = end - beg <= (uint32_t)RH_SORTG_DB;
+		__syncthreads();
+		if (cached) for (uint32_t i = beg + tid; i < end; i += NT) L.db[i - beg] = L.dmap[sortg_digit(G, i, s)];
+		__syncthreads();
+		if (wave_id() == 0) sortg_cycle_walk(L, G, beg, end, s, nbk, cached);
+		__syncthreads();
+		for (uint32_t i = beg + tid; i < end; i += NT) G.ib[i] = G.ia[G.tm[i]];
+	}
+	__syncthreads();
+	for (uint32_t i = beg + tid; i < end; i += NT) G.ia[i] = G.ib[i];
+	if (s > 0 && my_cnt > 1) {
+		if (my_cnt > 64) { const uint32_t k = atomicAdd(&L.n_rng[nxt], 1u); G.rng[nxt][k] = (uint64_t)my_start | (uint64_t)(my_start + my_cnt) << 32; G.rsh[nxt][k] = (uint8_t)(s - 8); }
+		else { const uint32_t e = my_start + my_cnt - 1; atomicOr(&G.sbit[my_start >> 5], 1u << (my_start & 31u)); atomicOr(&G.ebit[e >> 5], 1u << (e & 31u)); }
+	}
+	__syncthreads();
+}
+
+RH_DEV void sortg_run(sortg_lds &L, const sortg_mem &G, uint32_t n, int pass)
+{
+	const uint32_t tid = threadIdx.x;
+	for (uint32_t i = tid; i < n; i += NT) G.ia[i] = i;
+	for (uint32_t i = tid; i < n / 32 + 3; i += NT) { G.sbit[i] = 0; G.ebit[i] = 0; }
+	__syncthreads();
+	if (tid == 0) {
+		L.n_rng[0] = 0; L.n_rng[1] = 0;
+		if (n > 64) { G.rng[0][0] = (uint64_t)n << 32; G.rsh[0][0] = 56; L.n_rng[0] = 1; }
+		else if (n > 1) { G.sbit[0] = 1u; G.ebit[(n - 1) >> 5] = 1u << ((n - 1) & 31u); }
+	}
+	__syncthreads();
+	for (int cur = 0;; cur ^= 1) {
+		const uint32_t nr = L.n_rng[cur];
+		if (nr == 0) break;
+		for (uint32_t ri = 0; ri < nr; ++ri) {
+			const uint64_t be = G.rng[cur][ri];
+			sortg_split_range(L, G, (uint32_t)be, (uint32_t)(be >> 32), (int)G.rsh[cur][ri], cur ^ 1, pass);
+		}
+		__syncthreads();
+		if (tid == 0) L.n_rng[cur] = 0;
+		__syncthreads();
+	}
+	// ranges of <= 64 records: stable rank sort by one wavefront each, keys from registers (as in sort_run)
+	const uint32_t nw32 = (n + 31) / 32, wv = rh_uniform(wave_id());
+	for (uint32_t wi = wv; wi < nw32; wi += NT / 64) {
+		uint32_t sb = rh_uniform(G.sbit[wi]);
+		while (sb) {
+			const uint32_t bit = (uint32_t)__builtin_ctz(sb);
+			sb &= sb - 1;
+			const uint32_t b = wi * 32 + bit;
+			uint32_t ew = rh_uniform(G.ebit[wi]) >> bit, e = b;
+			if (ew) e = b + (uint32_t)__builtin_ctz(ew);
+			else { uint32_t x = wi + 1; while ((ew = rh_uniform(G.ebit[x])) == 0) ++x; e = x * 32 + (uint32_t)__builtin_ctz(ew); }
+			const uint32_t m = e - b + 1, l = lane_id();
+			const uint32_t idx = G.ia[b + (l < m ? l : 0u)];
+			if (pass == SORT_EXACT_TIED && __ballot((G.tbit[idx >> 5] >> (idx & 31u)) & 1u) == 0) continue;
+			const uint64_t k = G.src[idx].x;
+			const uint32_t klo = (uint32_t)k, khi = (uint32_t)(k >> 32);
+			uint32_t rank = 0;
+			const uint32_t khi0 = rh_readlane(khi, 0), klo0 = rh_readlane(klo, 0);
+			if (__ballot(khi != khi0 || ((klo ^ klo0) >> 26) != 0) == 0) {
+				const uint32_t c = klo << 6 | l;
+				for (uint32_t j = 0; j < m; ++j) rank += rh_readlane(c, j) < c ? 1u : 0u;
+			} else {
+				for (uint32_t j = 0; j < m; ++j) {
+					const uint64_t kj = (uint64_t)rh_readlane(khi, j) << 32 | rh_readlane(klo, j);
+					rank += (kj < k || (kj == k && j < l)) ? 1u : 0u;
+				}
+			}
+			RH_WAVE_SYNC();
+			if (l < m) G.ia[b + rank] = idx;
+		}
+	}
+	__syncthreads();
+}
+
+__global__ __launch_bounds__(NT) void k_sort_gmem(rh_sort_job jb, uint32_t n_lo, uint32_t n_hi, int mode)
+{
+	__shared__ sortg_lds L;
+	const uint32_t a = blockIdx.x, tid = threadIdx.x;
+	if (a >= jb.n_seg || (jb.skip && jb.skip[a])) return;
+	const uint64_t base = jb.off[a];
+	const uint32_t n = jb.cnt ? jb.cnt[a] : (uint32_t)(jb.off[a + 1] - base);
+	if (n <= n_lo || n > n_hi) return;
+	const rh_mm128_t *src = jb.src + base;
+	rh_mm128_t *dst = jb.dst + base;
+	// scratch of the segment: (stride - skip) bytes per record of the owning read, >= 64
+	unsigned char *S = jb.scratch + base * jb.scratch_stride + (uint64_t)jb.scratch_skip * (jb.off[a + 1] - base);
+	const uint32_t n4 = (n + 3u) & ~3u, W = n / 32 + 3, R = n / 64 + 4;
+	sortg_mem G;
+	G.src = src;
+	G.ia = (uint32_t*)S; G.ib = G.ia + n4; G.tm = G.ib + n4;
+	G.sbit = G.tm + n4; G.ebit = G.sbit + W; G.tbit = G.ebit + W;
+	G.rng[0] = (uint64_t*)(((uintptr_t)(G.tbit + W) + 7) & ~(uintptr_t)7); G.rng[1] = G.rng[0] + R;
+	G.rsh[0] = (uint8_t*)(G.rng[1] + R); G.rsh[1] = G.rsh[0] + R;
+	for (uint32_t i = tid; i < W; i += NT) G.tbit[i] = 0;
+	if (tid == 0) L.tie = 0;
+	__syncthreads();
+	sortg_run(L, G, n, mode == 0 ? SORT_FAST : SORT_EXACT_ALL);
+	for (uint32_t i = tid; i < n; i += NT) dst[i] = src[G.ia[i]];
+	if (mode != 0) return;
+	for (uint32_t i = tid + 1; i < n; i += NT) {
+		const uint32_t p = G.ia[i - 1], q = G.ia[i];
+		if (src[p].x == src[q].x) { atomicOr(&G.tbit[p >> 5], 1u << (p & 31u)); atomicOr(&G.tbit[q >> 5], 1u << (q & 31u)); L.tie = 1; }
+	}
+	__syncthreads();
+	const uint32_t tie = L.tie;
+	if (tid == 0 && jb.need_exact) jb.need_exact[a] = (uint8_t)tie;
+	if (!tie) return;
+	sortg_run(L, G, n, SORT_EXACT_TIED);
+	for (uint32_t i = tid; i < n; i += NT) { const uint32_t idx = G.ia[i]; if ((G.tbit[idx >> 5] >> (idx & 31u)) & 1u) dst[i] = src[idx]; }
+}
+
 // reads too large for LDS: copy, then the serial in-place emulation (one read per lane)
 __global__ void k_sort_big(rh_sort_job jb, uint32_t n_lo)
 {
@@ -418,7 +665,8 @@ void rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t
 	launch_class<RH_SORT_CAP2>(s, jb, all_exact, (uint32_t)RH_SORT_CAP1, (uint32_t)RH_SORT_CAP2);
 	launch_class<RH_SORT_CAP3>(s, jb, all_exact, (uint32_t)RH_SORT_CAP2, (uint32_t)RH_SORT_CAP3);
 	launch_class<RH_SORT_CAP4>(s, jb, all_exact, (uint32_t)RH_SORT_CAP3, (uint32_t)RH_SORT_CAP4);
-	RH_LAUNCH(k_sort_big, (jb.n_seg + 63) / 64, 64, 0, s, jb, (uint32_t)RH_SORT_CAP4);
+	RH_LAUNCH(k_sort_gmem, jb.n_seg, NT, 0, s, jb, (uint32_t)RH_SORT_CAP4, (uint32_t)RH_SORT_GCAP, all_exact ? 2 : 0);
+	RH_LAUNCH(k_sort_big, (jb.n_seg + 63) / 64, 64, 0, s, jb, (uint32_t)RH_SORT_GCAP);
 }
 
 // anchor sort of a chunk round: unsorted expand output -> reference order

@@ -138,11 +138,13 @@ def check_chain_synthetic(ctx, wl, seed=0, n_reads=64, max_n=700):
     return len(an), len(och), len(ou)
 
 
-def check_sort(ctx, seed=0, n_seg=40):
+def check_sort(ctx, seed=0, n_seg=40, big=()):
     """Exact unstable-permutation emulation of radix_sort_128x, with heavy key ties in every byte position."""
     rng = np.random.default_rng(seed)
     sizes = rng.integers(0, 900, size=n_seg)
     sizes[:8] = [0, 1, 64, 65, 4096, 4097, 3000, 5500]
+    if len(big):
+        sizes[8:8 + len(big)] = big             # beyond the LDS classes: the workgroup sorter on HBM scratch, all key kinds
     off = np.zeros(n_seg + 1, dtype=np.uint64)
     off[1:] = np.cumsum(sizes)
     tot = int(off[-1])

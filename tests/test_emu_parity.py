@@ -59,5 +59,6 @@ def test_oversized_read_fallbacks(make_workload, emu_lib_smallcaps):
     pc.check_stages(c, w)
     pc.check_e2e(c, w)
     pc.check_sort(c, seed=3, n_seg=16)
+    pc.check_sort(c, seed=4, n_seg=20, big=(1025, 2000, 3500, 4096, 1600, 2049))
     pc.check_chain_synthetic(c, w, seed=5, n_reads=40, max_n=500)
     c.close()
