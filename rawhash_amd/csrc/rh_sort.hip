@@ -49,7 +49,13 @@ struct sort_lds {
 	uint32_t w[NT / 64];
 	uint64_t r64[NT / 64];
 	uint32_t n_rng[2], tie, misc[4], prof;
+	// records with equal keys (at most SORT_TG per segment for the short cut below): original index, first sorted position
+	// of their group, final position once settled; records of the range being walked, in pop order
+	uint16_t tg_idx[32], tg_pos[32], tg_fin[32], tlist[32];
+	uint8_t tg_rng[32];
+	uint32_t n_tg, n_tl;
 };
+#define SORT_TG 32
 
 enum { SORT_FAST = 0, SORT_EXACT_TIED = 1, SORT_EXACT_ALL = 2 };
 
@@ -189,6 +195,65 @@ RH_DEV void sort_cycle_walk_hb(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int
 	}
 }
 
+// Short cut for the usual case - a few pairs of equal keys whose bucket in this pass is final (<= 64 records, sorted
+// stably afterwards): inside a bucket the records end up in the order in which the walk pops them, so the order of two
+// equal keys is settled the moment the first of them is popped.  The walk therefore stops after all but one of the
+// range's tied records have been popped (a third of the way for one pair) and writes no gather map at all: everything
+// else in the range already has its final place from the fast pass.  Bit 7 of a cached digit = "tied record".
+template <int CAP, int HB>
+RH_DEV void sort_cycle_walk_early(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s, uint32_t nbk, uint32_t stop)
+{
+	constexpr int NR = (CAP + 255) / 256;
+	const uint32_t lane = lane_id(), n = end - beg;
+	uint32_t dg[NR];
+#pragma unroll
+	for (int q = 0; q < NR; ++q) {
+		uint32_t w = 0;
+		const uint32_t p0 = ((uint32_t)q * 64u + lane) * 4u;
+		if (p0 < n) {
+			for (uint32_t b = 0; b < 4; ++b) if (p0 + b < n) {
+				const uint32_t idx = L.ia[beg + p0 + b];
+				w |= ((uint32_t)L.dmap[(uint32_t)(L.key[idx] >> s) & 255u] | ((L.tbit[idx >> 5] >> (idx & 31u)) & 1u) << 7) << (8 * b);
+			}
+		}
+		dg[q] = w;
+	}
+	uint32_t hd[HB], tl[HB];
+#pragma unroll
+	for (int q = 0; q < HB; ++q) {
+		const uint32_t id = (uint32_t)q * 64u + lane;
+		hd[q] = 0; tl[q] = 0;
+		if (id < nbk) { const uint32_t dgt = L.inv[id]; hd[q] = L.head[dgt] - beg; tl[q] = hd[q] + L.cnt[dgt]; }
+	}
+	const uint32_t ubeg = rh_uniform(beg);
+	uint32_t ntl = 0;
+	for (uint32_t c = 0; c < nbk && ntl < stop; ++c) {
+		uint32_t tlc = rh_readlane(tl[0], c & 63u), h = rh_readlane(hd[0], c & 63u);
+#pragma unroll
+		for (int q = 1; q < HB; ++q) { const uint32_t t2 = rh_readlane(tl[q], c & 63u), h2 = rh_readlane(hd[q], c & 63u); if ((c >> 6) == (uint32_t)q) { tlc = t2; h = h2; } }
+		while (h != tlc && ntl < stop) {
+			uint32_t db = (rh_readlane(dg[h >> 8], (h >> 2) & 63u) >> ((h & 3u) * 8u)) & 255u;
+			if (db >> 7) L.tlist[ntl++] = (uint16_t)(ubeg + h);
+			uint32_t d = db & 127u;
+			while (d != c && ntl < stop) {
+				uint32_t r[HB];
+#pragma unroll
+				for (int k = 0; k < HB; ++k) r[k] = rh_readlane(hd[k], d & 63u);
+				uint32_t q = r[0];
+#pragma unroll
+				for (int k = 1; k < HB; ++k) q = (d >> 6) == (uint32_t)k ? r[k] : q;
+#pragma unroll
+				for (int k = 0; k < HB; ++k) hd[k] = rh_writelane(hd[k], (HB == 1 || (d >> 6) == (uint32_t)k) ? q + 1 : r[k], d & 63u);
+				db = (rh_readlane(dg[q >> 8], (q >> 2) & 63u) >> ((q & 3u) * 8u)) & 255u;
+				if (db >> 7) L.tlist[ntl++] = (uint16_t)(ubeg + q);
+				d = db & 127u;
+			}
+			++h;
+		}
+	}
+	if (lane == 0) L.n_tl = ntl;
+}
+
 template <int CAP>
 RH_DEV void sort_cycle_walk(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s, uint32_t nbk)
 {
@@ -248,6 +313,45 @@ RH_DEV void sort_split_range(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s
 		KPROF(5);
 	} else {
 		__syncthreads();
+		if (pass == SORT_EXACT_TIED && nbk <= 128 && L.n_tg <= SORT_TG) {
+			// can the order of the tied records be settled by pop order alone?  (their buckets must be final after this pass)
+			if (tid < SORT_TG) L.tg_rng[tid] = 0;
+			if (tid == 0) L.misc[0] = 0;
+			__syncthreads();
+			bool bad = false;
+			const uint32_t ntg = L.n_tg;
+			for (uint32_t i = beg + tid; i < end; i += NT) {
+				const uint32_t idx = L.ia[i];
+				if ((L.tbit[idx >> 5] >> (idx & 31u)) & 1u) {
+					if (s > 0 && L.cnt[(uint32_t)(L.key[idx] >> s) & 255u] > 64u) bad = true;
+					for (uint32_t e = 0; e < ntg; ++e) if (L.tg_idx[e] == idx) L.tg_rng[e] = 1;
+					atomicAdd(&L.misc[0], 1u);
+				}
+			}
+			const uint64_t bm = __ballot(bad);
+			if (lane_id() == 0) L.w[wave_id()] = bm != 0;
+			__syncthreads();
+			if ((L.w[0] | L.w[1] | L.w[2] | L.w[3]) == 0) {
+				const uint32_t stop = L.misc[0] - 1;
+				if (wave_id() == 0) { if (nbk <= 64) sort_cycle_walk_early<CAP, 1>(L, beg, end, s, nbk, stop); else sort_cycle_walk_early<CAP, 2>(L, beg, end, s, nbk, stop); }
+				__syncthreads();
+				KPROF(6);
+				if (tid < ntg && L.tg_rng[tid]) {	// my place in my group: pop order; the record never popped comes last
+					const uint32_t idx = L.tg_idx[tid], gs = L.tg_pos[tid], ntl = L.n_tl;
+					uint32_t in_group = 0, mine = 0xFFFFu;
+					for (uint32_t r = 0; r < ntl; ++r) {
+						const uint32_t qi = L.ia[L.tlist[r]];
+						uint32_t g2 = 0xFFFFu;
+						for (uint32_t e = 0; e < ntg; ++e) if (L.tg_idx[e] == qi) g2 = L.tg_pos[e];
+						if (g2 == gs) { if (qi == idx) mine = in_group; ++in_group; }
+					}
+					L.tg_fin[tid] = (uint16_t)(gs + (mine != 0xFFFFu ? mine : in_group));
+					atomicAnd(&L.tbit[idx >> 5], ~(1u << (idx & 31u)));      // settled: not for the final rewrite of tied records
+				}
+				__syncthreads();
+				return;
+			}
+		}
 		if (wave_id() == 0) sort_cycle_walk<CAP>(L, beg, end, s, nbk);
 		__syncthreads();
 		KPROF(6);
@@ -348,7 +452,7 @@ __global__ __launch_bounds__(NT) void k_sort_block(rh_sort_job jb, uint32_t n_lo
 #endif
 	for (uint32_t i = tid; i < n; i += NT) L.key[i] = src[i].x;
 	for (uint32_t i = tid; i < CAP / 32 + 3; i += NT) L.tbit[i] = 0;
-	if (tid == 0) L.tie = 0;
+	if (tid == 0) { L.tie = 0; L.n_tg = 0; }
 	__syncthreads();
 	KPROF(10);
 	sort_run<CAP>(L, n, mode == 0 ? SORT_FAST : SORT_EXACT_ALL);
@@ -358,9 +462,17 @@ __global__ __launch_bounds__(NT) void k_sort_block(rh_sort_job jb, uint32_t n_lo
 	for (uint32_t i = tid; i < n; i += NT) dst[i] = src[L.ia[i]];
 	KPROF(12);
 	if (mode != 0) return;
-	for (uint32_t i = tid + 1; i < n; i += NT) {
-		const uint32_t p = L.ia[i - 1], q = L.ia[i];
-		if (L.key[p] == L.key[q]) { atomicOr(&L.tbit[p >> 5], 1u << (p & 31u)); atomicOr(&L.tbit[q >> 5], 1u << (q & 31u)); L.tie = 1; }
+	for (uint32_t i = tid; i < n; i += NT) {
+		const uint32_t idx = L.ia[i];
+		const uint64_t k = L.key[idx];
+		if ((i > 0 && L.key[L.ia[i - 1]] == k) || (i + 1 < n && L.key[L.ia[i + 1]] == k)) {
+			atomicOr(&L.tbit[idx >> 5], 1u << (idx & 31u));
+			L.tie = 1;
+			uint32_t gs = i;
+			while (gs > 0 && L.key[L.ia[gs - 1]] == k) --gs;
+			const uint32_t slot = atomicAdd(&L.n_tg, 1u);
+			if (slot < SORT_TG) { L.tg_idx[slot] = (uint16_t)idx; L.tg_pos[slot] = (uint16_t)gs; L.tg_fin[slot] = 0xFFFFu; }
+		}
 	}
 	__syncthreads();
 	const uint32_t tie = L.tie;
@@ -372,6 +484,7 @@ __global__ __launch_bounds__(NT) void k_sort_block(rh_sort_job jb, uint32_t n_lo
 	// as a whole - only the records inside the groups are rewritten.
 	sort_run<CAP>(L, n, SORT_EXACT_TIED);
 	for (uint32_t i = tid; i < n; i += NT) { const uint32_t idx = L.ia[i]; if ((L.tbit[idx >> 5] >> (idx & 31u)) & 1u) dst[i] = src[idx]; }
+	if (tid < SORT_TG && tid < L.n_tg && L.tg_fin[tid] != 0xFFFFu) dst[L.tg_fin[tid]] = src[L.tg_idx[tid]];   // settled by pop order
 }
 
 // ------------------------------------------------------------------------------------------------ segments beyond the LDS classes

@@ -151,8 +151,14 @@ def check_sort(ctx, seed=0, n_seg=40, big=()):
     a = np.zeros(tot, dtype=MM128)
     for s in range(n_seg):
         b, e = int(off[s]), int(off[s + 1])
-        mode = s % 6
-        if mode == 4:     # anchor-like keys: strand bit | small rid | 23-bit position, a few duplicated positions
+        mode = s % 7
+        if mode == 6:     # anchor-like keys with one to four pairs / triples of equal positions (the pop-order short cut of the sorter)
+            x = (rng.integers(0, 2, size=e - b, dtype=np.uint64) << np.uint64(63)) | rng.integers(0, 1 << 23, size=e - b, dtype=np.uint64)
+            if e - b > 10:
+                for _ in range(int(rng.integers(1, 5))):
+                    j = rng.integers(0, e - b, size=int(rng.integers(2, 4)))
+                    x[j] = x[j[0]]
+        elif mode == 4:     # anchor-like keys: strand bit | small rid | 23-bit position, a few duplicated positions
             x = (rng.integers(0, 2, size=e - b, dtype=np.uint64) << np.uint64(63)) | (rng.integers(0, 3, size=e - b, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, 1 << 23, size=e - b, dtype=np.uint64)
             if e - b > 10:
                 x[rng.integers(0, e - b, size=(e - b) // 10)] = x[rng.integers(0, e - b, size=(e - b) // 10)]
