@@ -10,14 +10,35 @@
 
 namespace {
 
+thread_local bool g_oom = false;   // the last failure on this thread was a device allocation that did not fit
+
 struct DevBuf {
 	void *p = nullptr; size_t cap = 0; bool owned = true;
 	int ensure(size_t bytes)
 	{
 		if (bytes <= cap) return 0;
 		if (p) { RH_HIP(hipFree(p)); p = nullptr; cap = 0; }
-		const size_t want = bytes + bytes / 4 + 256;
-		RH_HIP(hipMalloc(&p, want));
+		size_t want = bytes + bytes / 4 + 256;
+		// keep head-room on the device: the runtime itself allocates at dispatch time (kernel scratch, queues) and aborts the
+		// process when that fails, so an arena that would eat the last gigabytes is refused here like a failed hipMalloc
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+			const size_t reserve = total_b / 32 > ((size_t)2 << 30) ? total_b / 32 : ((size_t)2 << 30);
+			if (want + reserve > free_b) want = bytes + 256;
+			if (want + reserve > free_b) {
+				g_oom = true;
+				rh_set_error("%s:%d: device arena of %zu bytes does not fit (%zu free, %zu kept in reserve)", __FILE__, __LINE__, want, free_b, reserve);
+				return -1;
+			}
+		}
+		hipError_t e = hipMalloc(&p, want);
+		if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); want = bytes + 256; e = hipMalloc(&p, want); }   // without the growth margin
+		if (e != hipSuccess) {
+			p = nullptr;
+			if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); g_oom = true; }
+			rh_set_error("%s:%d: hipMalloc of %zu bytes failed: %s", __FILE__, __LINE__, want, hipGetErrorString(e));
+			return -1;
+		}
 		cap = want;
 		return 0;
 	}
@@ -57,6 +78,7 @@ struct rh_ctx_s {
 	std::vector<rh_ctx*> subs;
 	int n_sub = 1;
 	bool is_sub = false;
+	uint32_t slice_hint = 0;                                       // reads per slice that fitted the device last time (0 = whole batches fit)
 };
 
 namespace {
@@ -179,6 +201,12 @@ int stage_round(rh_ctx *c, uint32_t n_act, rh_dev_round *rr)
 int stage_anchors(rh_ctx *c, uint64_t total, int which, rh_dev_round *rr)
 {
 	const size_t t = total ? total : 1;
+	const char *cap_env = getenv("RH_ARENA_MAX_BYTES");              // optional cap on the per-anchor scratch arena (shared devices, tests)
+	if (cap_env && t * RH_WS_PER_ANCHOR > (size_t)strtoull(cap_env, nullptr, 10)) {
+		g_oom = true;
+		rh_set_error("per-anchor arena of %zu bytes exceeds RH_ARENA_MAX_BYTES=%s", t * RH_WS_PER_ANCHOR, cap_env);
+		return -1;
+	}
 	if (c->anc.ensure(t * 16) || c->raw_anc.ensure(t * 16) || c->zs.ensure(t * 16) || c->prev[which].ensure(t * 16) || c->u.ensure(t * 8) || c->ws.ensure(t * RH_WS_PER_ANCHOR + 4096)) return -1;
 	rr->anc = c->anc.as<rh_mm128_t>(); rr->raw = c->raw_anc.as<rh_mm128_t>(); rr->zs = c->zs.as<rh_mm128_t>(); rr->prev_out = c->prev[which].as<rh_mm128_t>(); rr->prev_in = c->prev[which ^ 1].as<rh_mm128_t>();
 	rr->u = c->u.as<uint64_t>(); rr->ws = c->ws.as<unsigned char>();
@@ -362,7 +390,7 @@ void dump_round2(rh_ctx *c, uint32_t chunk, uint32_t n_act, const rh_dev_round &
 }
 
 // the whole path for one (sub-)batch on one context's stream
-int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out)
+int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out)
 {
 	*n_out = 0;
 	if (need_index(c)) return -1;
@@ -438,6 +466,60 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 	*n_out = R;
 	return 0;
 }
+void add_stats(rh_map_stats_t &tot, const rh_map_stats_t &q)
+{
+	tot.n_reads += q.n_reads; tot.n_chunks += q.n_chunks; tot.n_samples_raw += q.n_samples_raw; tot.n_samples_used += q.n_samples_used;
+	tot.n_events += q.n_events; tot.n_seeds += q.n_seeds; tot.n_hits += q.n_hits; tot.n_anchors += q.n_anchors; tot.n_chained += q.n_chained;
+	tot.ms_total += q.ms_total;
+	for (int i = 0; i < 24; ++i) { tot.ms_kernel[i] += q.ms_kernel[i]; tot.n_launch[i] += q.n_launch[i]; }
+}
+
+// One (sub-)batch on one context.  The per-anchor arenas are sized by what the reads turn out to need (tens of thousands
+// of anchors per chunk on a large index); when they do not fit the device, the batch is mapped in consecutive slices,
+// halving the slice until it fits.  Reads are independent, so the records are the same.
+int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out)
+{
+	const uint32_t R = in->n_reads;
+	*n_out = 0;
+	if (out_cap < R) { rh_set_error("output capacity %llu < %u reads", (unsigned long long)out_cap, R); return -1; }
+	g_oom = false;
+	uint64_t n = 0;
+	uint32_t slice = R / 2, done = 0;
+	if (c->slice_hint == 0 || R <= c->slice_hint) {
+		if (map_batch_once(c, mo, in, out, out_cap, &n) == 0) { *n_out = n; return 0; }
+		if (!g_oom || R < 2) return -1;
+		DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev[0], &c->prev[1], &c->u, &c->ws};
+		(void)hipStreamSynchronize(c->stream);
+		for (DevBuf *d : big) d->release();
+	} else slice = c->slice_hint;
+	rh_map_stats_t tot{};
+	while (done < R) {
+		const uint32_t m = R - done < slice ? R - done : slice;
+		rh_read_batch_t b = *in;
+		b.n_reads = m;
+		b.offsets = in->offsets + done;
+		if (in->cal_offset) b.cal_offset = in->cal_offset + done;
+		if (in->cal_scale) b.cal_scale = in->cal_scale + done;
+		if (in->name_rank) b.name_rank = in->name_rank + done;
+		g_oom = false;
+		if (map_batch_once(c, mo, &b, out + done, m, &n)) {
+			if (!g_oom || slice < 2) return -1;
+			slice /= 2;                                             // try smaller, from empty per-anchor arenas
+			DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev[0], &c->prev[1], &c->u, &c->ws};
+			(void)hipStreamSynchronize(c->stream);
+			for (DevBuf *d : big) d->release();
+			continue;
+		}
+		for (uint32_t i = 0; i < m; ++i) out[done + i].read_idx += done;
+		add_stats(tot, c->stats);
+		done += m;
+	}
+	c->slice_hint = slice;
+	c->stats = tot;
+	*n_out = R;
+	return 0;
+}
+
 } // namespace
 
 // Reads are independent, and after the first chunk round only the hard reads remain (latency-bound kernels that cannot

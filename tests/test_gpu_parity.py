@@ -133,3 +133,20 @@ def test_sub_batches_give_identical_records(make_workload, product_lib, monkeypa
     b = c2.map_batch(w.opts, w.reads)
     c2.close()
     assert np.array_equal(a, b)
+
+
+def test_batch_sliced_when_arenas_do_not_fit(make_workload, product_lib, monkeypatch):
+    """RH_ARENA_MAX_BYTES far below what the batch needs: rh_map_batch maps it in halving slices and returns the same records."""
+    w = make_workload(n_reads=48)
+    monkeypatch.setenv("RH_SUB_BATCHES", "1")
+    c = Context(0, lib=product_lib)
+    c.upload(w.index)
+    whole = [strip_mt(x) for x in paf_lines(w.index, c.map_batch(w.opts, w.reads), w.reads.names)]
+    c.close()
+    monkeypatch.setenv("RH_ARENA_MAX_BYTES", str(3 << 20))       # the 128 B/anchor scratch of 48 reads x ~3 k anchors is ~18 MB
+    c = Context(0, lib=product_lib)
+    c.upload(w.index)
+    sliced = [strip_mt(x) for x in paf_lines(w.index, c.map_batch(w.opts, w.reads), w.reads.names)]
+    again = [strip_mt(x) for x in paf_lines(w.index, c.map_batch(w.opts, w.reads), w.reads.names)]   # second call starts from the remembered slice size
+    c.close()
+    assert sliced == whole and again == whole and len(whole) == 48
