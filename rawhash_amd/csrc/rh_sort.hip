@@ -504,6 +504,9 @@ struct sortg_lds {
 	uint32_t w[NT / 64];
 	uint64_t r64[NT / 64];
 	uint32_t n_rng[2], tie, misc[4];
+	uint32_t tg_idx[SORT_TG], tg_pos[SORT_TG], tg_fin[SORT_TG], tlist[SORT_TG];   // tied records, as in sort_lds
+	uint8_t tg_rng[SORT_TG];
+	uint32_t n_tg, n_tl;
 	uint8_t db[RH_SORTG_DB];
 };
 struct sortg_mem {
@@ -559,6 +562,41 @@ RH_DEV void sortg_cycle_walk(sortg_lds &L, const sortg_mem &G, uint32_t beg, uin
 	#undef SG_DIGIT
 }
 
+// the pop-order short cut of sort_cycle_walk_early on the LDS digit cache (bit 7 of a cached digit = tied record)
+RH_DEV void sortg_cycle_walk_early(sortg_lds &L, uint32_t beg, uint32_t nbk, uint32_t stop)
+{
+	const uint32_t lane = lane_id();
+	uint32_t hd[2], tl[2];
+#pragma unroll
+	for (int q = 0; q < 2; ++q) {
+		const uint32_t id = (uint32_t)q * 64u + lane;
+		hd[q] = 0; tl[q] = 0;
+		if (id < nbk) { const uint32_t dgt = L.inv[id]; hd[q] = L.head[dgt] - beg; tl[q] = hd[q] + L.cnt[dgt]; }
+	}
+	const uint32_t ubeg = rh_uniform(beg);
+	uint32_t ntl = 0;
+	for (uint32_t c = 0; c < nbk && ntl < stop; ++c) {
+		uint32_t tlc = rh_readlane(tl[0], c & 63u), h = rh_readlane(hd[0], c & 63u);
+		{ const uint32_t t2 = rh_readlane(tl[1], c & 63u), h2 = rh_readlane(hd[1], c & 63u); if ((c >> 6) == 1u) { tlc = t2; h = h2; } }
+		while (h != tlc && ntl < stop) {
+			uint32_t db = rh_uniform((uint32_t)L.db[h]);
+			if (db >> 7) L.tlist[ntl++] = ubeg + h;
+			uint32_t d = db & 127u;
+			while (d != c && ntl < stop) {
+				const uint32_t r0 = rh_readlane(hd[0], d & 63u), r1 = rh_readlane(hd[1], d & 63u);
+				const uint32_t q = (d >> 6) == 1u ? r1 : r0;
+				hd[0] = rh_writelane(hd[0], (d >> 6) == 0u ? q + 1 : r0, d & 63u);
+				hd[1] = rh_writelane(hd[1], (d >> 6) == 1u ? q + 1 : r1, d & 63u);
+				db = rh_uniform((uint32_t)L.db[q]);
+				if (db >> 7) L.tlist[ntl++] = ubeg + q;
+				d = db & 127u;
+			}
+			++h;
+		}
+	}
+	if (lane == 0) L.n_tl = ntl;
+}
+
 RH_DEV void sortg_split_range(sortg_lds &L, const sortg_mem &G, uint32_t beg, uint32_t end, int shift, int nxt, int pass)
 {
 	const uint32_t tid = threadIdx.x;
@@ -597,34 +635,83 @@ RH_DEV void sortg_split_range(sortg_lds &L, const sortg_mem &G, uint32_t beg, ui
 		if (my_cnt != 0) { const uint32_t which = my_start == beg ? 0u : 1u; L.misc[which] = tid; L.misc[2 + which] = my_start; }
 		__syncthreads();
 		const uint32_t cA = L.misc[0], cB = L.misc[1], startB = L.misc[3];
-		uint32_t m = 0;
-		for (uint32_t base = beg; base < startB; base += NT) {
-			const uint32_t i = base + tid;
-			const bool foreign = i < startB && sortg_digit(G, i, s) == cB;
-			uint32_t tot;
-			const uint32_t rk = block_rank(foreign, L.w, tot);
-			if (i < startB) { if (foreign) G.tm[beg + m + rk] = i; else G.ib[i] = G.ia[i]; }
-			m += tot;
+		// ranks of the misplaced records inside A and inside B: each wavefront owns a contiguous quarter of either region
+		// (tiles of 64, ballots only); one barrier turns the per-wavefront counts into offsets
+		const uint32_t w = wave_id(), l = lane_id();
+		const uint32_t lenA = startB - beg, lenB = end - startB;
+		const uint32_t perA = ((lenA + NT - 1) / NT) * 64u, perB = ((lenB + NT - 1) / NT) * 64u;
+		const uint32_t a0 = beg + (w * perA < lenA ? w * perA : lenA), a1 = a0 + perA < startB ? a0 + perA : startB;
+		const uint32_t b0 = startB + (w * perB < lenB ? w * perB : lenB), b1 = b0 + perB < end ? b0 + perB : end;
+		uint32_t ca = 0, cb = 0;
+		for (uint32_t base = a0; base < a1; base += 64) { const uint32_t i = base + l; ca += (uint32_t)__popcll(__ballot(i < a1 && sortg_digit(G, i, s) == cB)); }
+		for (uint32_t base = b0; base < b1; base += 64) { const uint32_t i = base + l; cb += (uint32_t)__popcll(__ballot(i < b1 && sortg_digit(G, i, s) == cA)); }
+		if (l == 0) L.r64[w] = (uint64_t)ca | (uint64_t)cb << 32;
+		__syncthreads();
+		uint32_t ra = 0, rb = 0, m = 0;
+		for (uint32_t q = 0; q < NT / 64; ++q) { const uint64_t c2 = L.r64[q]; if (q < w) { ra += (uint32_t)c2; rb += (uint32_t)(c2 >> 32); } m += (uint32_t)c2; }
+		for (uint32_t base = a0; base < a1; base += 64) {
+			const uint32_t i = base + l;
+			const bool foreign = i < a1 && sortg_digit(G, i, s) == cB;
+			const uint64_t B = __ballot(foreign);
+			if (i < a1) { if (foreign) G.tm[beg + ra + lanes_below(B)] = i; else G.ib[i] = G.ia[i]; }
+			ra += (uint32_t)__popcll(B);
 		}
 		__syncthreads();
-		uint32_t fb = 0;
-		for (uint32_t base = startB; base < end; base += NT) {
-			const uint32_t i = base + tid;
-			const bool foreign = i < end && sortg_digit(G, i, s) == cA;
-			uint32_t tot;
-			const uint32_t rk = block_rank(foreign, L.w, tot);
-			if (i < end) {
-				const uint32_t r = fb + rk;
+		for (uint32_t base = b0; base < b1; base += 64) {
+			const uint32_t i = base + l;
+			const bool foreign = i < b1 && sortg_digit(G, i, s) == cA;
+			const uint64_t B = __ballot(foreign);
+			if (i < b1) {
+				const uint32_t r = rb + lanes_below(B);                 // misplaced records of B before slot i
 				if (foreign) { G.ib[G.tm[beg + r]] = G.ia[i]; G.tm[end - 1 - r] = i; }
 				else G.ib[r < m ? i + 1 : i] = G.ia[i];
 			}
-			fb += tot;
+			rb += (uint32_t)__popcll(B);
 		}
 		__syncthreads();
 		for (uint32_t k = tid; k < m; k += NT) G.ib[k == 0 ? startB : G.tm[end - k] + 1u] = G.ia[G.tm[beg + k]];
 	} else {
 		const bool cached = end - beg <= (uint32_t)RH_SORTG_DB;
 		__syncthreads();
+		if (pass == SORT_EXACT_TIED && cached && nbk <= 128 && L.n_tg <= SORT_TG) {
+			// the order of a few tied records whose buckets are final after this pass: pop order (see sort_split_range)
+			if (tid < SORT_TG) L.tg_rng[tid] = 0;
+			if (tid == 0) L.misc[0] = 0;
+			__syncthreads();
+			bool bad = false;
+			const uint32_t ntg = L.n_tg;
+			for (uint32_t i = beg + tid; i < end; i += NT) {
+				const uint32_t idx = G.ia[i];
+				const uint32_t dgt = (uint32_t)(G.src[idx].x >> s) & 255u, tb = (G.tbit[idx >> 5] >> (idx & 31u)) & 1u;
+				L.db[i - beg] = (uint8_t)(L.dmap[dgt] | tb << 7);
+				if (tb) {
+					if (s > 0 && L.cnt[dgt] > 64u) bad = true;
+					for (uint32_t e = 0; e < ntg; ++e) if (L.tg_idx[e] == idx) L.tg_rng[e] = 1;
+					atomicAdd(&L.misc[0], 1u);
+				}
+			}
+			const uint64_t bm = __ballot(bad);
+			if (lane_id() == 0) L.w[wave_id()] = bm != 0;
+			__syncthreads();
+			if ((L.w[0] | L.w[1] | L.w[2] | L.w[3]) == 0) {
+				if (wave_id() == 0) sortg_cycle_walk_early(L, beg, nbk, L.misc[0] - 1);
+				__syncthreads();
+				if (tid < ntg && L.tg_rng[tid]) {
+					const uint32_t idx = L.tg_idx[tid], gs = L.tg_pos[tid], ntl = L.n_tl;
+					uint32_t in_group = 0, mine = ~0u;
+					for (uint32_t r = 0; r < ntl; ++r) {
+						const uint32_t qi = G.ia[L.tlist[r]];
+						uint32_t g2 = ~0u;
+						for (uint32_t e = 0; e < ntg; ++e) if (L.tg_idx[e] == qi) g2 = L.tg_pos[e];
+						if (g2 == gs) { if (qi == idx) mine = in_group; ++in_group; }
+					}
+					L.tg_fin[tid] = gs + (mine != ~0u ? mine : in_group);
+					atomicAnd(&G.tbit[idx >> 5], ~(1u << (idx & 31u)));
+				}
+				__syncthreads();
+				return;
+			}
+		}
 		if (cached) for (uint32_t i = beg + tid; i < end; i += NT) L.db[i - beg] = L.dmap[sortg_digit(G, i, s)];
 		__syncthreads();
 		if (wave_id() == 0) sortg_cycle_walk(L, G, beg, end, s, nbk, cached);
@@ -663,37 +750,66 @@ RH_DEV void sortg_run(sortg_lds &L, const sortg_mem &G, uint32_t n, int pass)
 		if (tid == 0) L.n_rng[cur] = 0;
 		__syncthreads();
 	}
-	// ranges of <= 64 records: stable rank sort by one wavefront each, keys from registers (as in sort_run)
-	const uint32_t nw32 = (n + 31) / 32, wv = rh_uniform(wave_id());
-	for (uint32_t wi = wv; wi < nw32; wi += NT / 64) {
-		uint32_t sb = rh_uniform(G.sbit[wi]);
-		while (sb) {
-			const uint32_t bit = (uint32_t)__builtin_ctz(sb);
-			sb &= sb - 1;
-			const uint32_t b = wi * 32 + bit;
-			uint32_t ew = rh_uniform(G.ebit[wi]) >> bit, e = b;
-			if (ew) e = b + (uint32_t)__builtin_ctz(ew);
-			else { uint32_t x = wi + 1; while ((ew = rh_uniform(G.ebit[x])) == 0) ++x; e = x * 32 + (uint32_t)__builtin_ctz(ew); }
-			const uint32_t m = e - b + 1, l = lane_id();
-			const uint32_t idx = G.ia[b + (l < m ? l : 0u)];
-			if (pass == SORT_EXACT_TIED && __ballot((G.tbit[idx >> 5] >> (idx & 31u)) & 1u) == 0) continue;
-			const uint64_t k = G.src[idx].x;
-			const uint32_t klo = (uint32_t)k, khi = (uint32_t)(k >> 32);
-			uint32_t rank = 0;
-			const uint32_t khi0 = rh_readlane(khi, 0), klo0 = rh_readlane(klo, 0);
-			if (__ballot(khi != khi0 || ((klo ^ klo0) >> 26) != 0) == 0) {
-				const uint32_t c = klo << 6 | l;
-				for (uint32_t j = 0; j < m; ++j) rank += rh_readlane(c, j) < c ? 1u : 0u;
-			} else {
-				for (uint32_t j = 0; j < m; ++j) {
-					const uint64_t kj = (uint64_t)rh_readlane(khi, j) << 32 | rh_readlane(klo, j);
-					rank += (kj < k || (kj == k && j < l)) ? 1u : 0u;
+	// Ranges of <= 64 records (with 256 buckets per pass there are thousands of them, a handful of records each): one
+	// THREAD per record - it finds its range in the start / end bit masks, ranks its key among the range's keys and moves
+	// its record there.  Every load is independent of the other threads', so the L2 latency is paid 256-fold in parallel
+	// (a wavefront per range paid it once per range, in sequence).
+	for (uint32_t i0 = 0; i0 < n; i0 += NT) {
+		const uint32_t i = i0 + tid;
+		uint32_t dest = ~0u;
+		if (i < n) {
+			// 64-bit windows of the masks: bit k of lo* = position i - 63 + k (k = 63 is i itself), bit k of hi = position i + k
+			uint64_t los = 0, loe = 0, hie = 0;
+			{
+				const int64_t p0 = (int64_t)i - 63;
+				for (int q = 0; q < 3; ++q) {
+					const int64_t wi = (p0 >> 5) + q;                 // words covering [i - 63, i]
+					if (wi < 0) continue;
+					const uint64_t ws = G.sbit[wi], we = G.ebit[wi];
+					const int64_t sh = wi * 32 - p0;                   // position of the word's bit 0 inside the window
+					los |= sh >= 0 ? (sh < 64 ? ws << sh : 0) : ws >> -sh;
+					loe |= sh >= 0 ? (sh < 64 ? we << sh : 0) : we >> -sh;
+				}
+				for (int q = 0; q < 3; ++q) {
+					const uint32_t wi = (i >> 5) + (uint32_t)q;
+					if (wi >= n / 32 + 3) break;
+					const uint64_t we = G.ebit[wi];
+					const int32_t sh = (int32_t)(wi * 32) - (int32_t)i;
+					hie |= sh >= 0 ? (sh < 64 ? we << sh : 0) : we >> -sh;
 				}
 			}
-			RH_WAVE_SYNC();
-			if (l < m) G.ia[b + rank] = idx;
+			if (los && hie) {
+				const uint32_t kb = 63u - (uint32_t)__clzll(los);          // window bit of the nearest start at or before i
+				const uint64_t between = kb < 63 ? (loe >> kb) & ((1ull << (63 - kb)) - 1ull) : 0ull;   // ends in [start, i)
+				if (between == 0) {
+					const uint32_t b = i - (63u - kb), e = i + (uint32_t)__builtin_ctzll(hie);
+					if (e - b < 64) {
+						const uint32_t idx = G.ia[i];
+						const uint64_t k = G.src[idx].x;
+						uint32_t rank = 0, tiedr = 0;
+						for (uint32_t j0 = b; j0 <= e; j0 += 8) {	// eight independent index loads, then eight independent key loads
+							uint32_t jx[8]; uint64_t kj[8];
+#pragma unroll
+							for (uint32_t q = 0; q < 8; ++q) jx[q] = G.ia[j0 + q <= e ? j0 + q : e];
+#pragma unroll
+							for (uint32_t q = 0; q < 8; ++q) kj[q] = G.src[jx[q]].x;
+#pragma unroll
+							for (uint32_t q = 0; q < 8; ++q) if (j0 + q <= e) {
+								rank += (kj[q] < k || (kj[q] == k && j0 + q < i)) ? 1u : 0u;
+								if (pass == SORT_EXACT_TIED) tiedr |= (G.tbit[jx[q] >> 5] >> (jx[q] & 31u)) & 1u;
+							}
+						}
+						if (pass != SORT_EXACT_TIED || tiedr) dest = b + rank;
+					}
+				}
+			}
 		}
+		if (i < n) G.tm[i] = dest;
 	}
+	__syncthreads();
+	for (uint32_t i = tid; i < n; i += NT) { const uint32_t d = G.tm[i]; if (d != ~0u) G.ib[d] = G.ia[i]; }
+	__syncthreads();
+	for (uint32_t i = tid; i < n; i += NT) if (G.tm[i] != ~0u) G.ia[i] = G.ib[i];
 	__syncthreads();
 }
 
@@ -717,14 +833,22 @@ __global__ __launch_bounds__(NT) void k_sort_gmem(rh_sort_job jb, uint32_t n_lo,
 	G.rng[0] = (uint64_t*)(((uintptr_t)(G.tbit + W) + 7) & ~(uintptr_t)7); G.rng[1] = G.rng[0] + R;
 	G.rsh[0] = (uint8_t*)(G.rng[1] + R); G.rsh[1] = G.rsh[0] + R;
 	for (uint32_t i = tid; i < W; i += NT) G.tbit[i] = 0;
-	if (tid == 0) L.tie = 0;
+	if (tid == 0) { L.tie = 0; L.n_tg = 0; }
 	__syncthreads();
 	sortg_run(L, G, n, mode == 0 ? SORT_FAST : SORT_EXACT_ALL);
 	for (uint32_t i = tid; i < n; i += NT) dst[i] = src[G.ia[i]];
 	if (mode != 0) return;
-	for (uint32_t i = tid + 1; i < n; i += NT) {
-		const uint32_t p = G.ia[i - 1], q = G.ia[i];
-		if (src[p].x == src[q].x) { atomicOr(&G.tbit[p >> 5], 1u << (p & 31u)); atomicOr(&G.tbit[q >> 5], 1u << (q & 31u)); L.tie = 1; }
+	for (uint32_t i = tid; i < n; i += NT) {
+		const uint32_t idx = G.ia[i];
+		const uint64_t k = src[idx].x;
+		if ((i > 0 && src[G.ia[i - 1]].x == k) || (i + 1 < n && src[G.ia[i + 1]].x == k)) {
+			atomicOr(&G.tbit[idx >> 5], 1u << (idx & 31u));
+			L.tie = 1;
+			uint32_t gs = i;
+			while (gs > 0 && src[G.ia[gs - 1]].x == k) --gs;
+			const uint32_t slot = atomicAdd(&L.n_tg, 1u);
+			if (slot < SORT_TG) { L.tg_idx[slot] = idx; L.tg_pos[slot] = gs; L.tg_fin[slot] = ~0u; }
+		}
 	}
 	__syncthreads();
 	const uint32_t tie = L.tie;
@@ -732,6 +856,7 @@ __global__ __launch_bounds__(NT) void k_sort_gmem(rh_sort_job jb, uint32_t n_lo,
 	if (!tie) return;
 	sortg_run(L, G, n, SORT_EXACT_TIED);
 	for (uint32_t i = tid; i < n; i += NT) { const uint32_t idx = G.ia[i]; if ((G.tbit[idx >> 5] >> (idx & 31u)) & 1u) dst[i] = src[idx]; }
+	if (tid < SORT_TG && tid < L.n_tg && L.tg_fin[tid] != ~0u) dst[L.tg_fin[tid]] = src[L.tg_idx[tid]];   // settled by pop order
 }
 
 // reads too large for LDS: copy, then the serial in-place emulation (one read per lane)
