@@ -488,8 +488,8 @@ __global__ __launch_bounds__(NT) void k_sort_block(rh_sort_job jb, uint32_t n_lo
 }
 
 // ------------------------------------------------------------------------------------------------ segments beyond the LDS classes
-// Same algorithm, one workgroup per segment, with the permutation arrays in HBM scratch (they stay in L2: 12 B per
-// record) and the keys read in place from the records: larger genomes put tens of thousands of anchors into one chunk.
+// Same algorithm, one workgroup per segment, with the arrangement and a copy of the keys in arrangement order in HBM
+// scratch (L2-resident, 28 B per record; every pass moves index and key together, so key reads are coalesced): larger genomes put tens of thousands of anchors into one chunk.
 // Only the histogram / bucket heads and, for the exact cycle walk, the digits of the range being walked live in LDS.
 #ifndef RH_SORT_GCAP
 #define RH_SORT_GCAP (1u << 20)    // records per segment; beyond: the serial emulation
@@ -512,12 +512,13 @@ struct sortg_lds {
 struct sortg_mem {
 	const rh_mm128_t *src;
 	uint32_t *ia, *ib, *tm;            // arrangement, pass output, scratch (rank lists / gather map)
+	uint64_t *kp, *kb;                 // the keys in arrangement order (moved with every pass: all key reads are coalesced), pass output
 	uint32_t *sbit, *ebit, *tbit;
 	uint64_t *rng[2];                  // ranges > 64 still to be split: beg | end << 32
 	uint8_t *rsh[2];
 };
 
-RH_DEV uint64_t sortg_key(const sortg_mem &G, uint32_t i) { return G.src[G.ia[i]].x; }
+RH_DEV uint64_t sortg_key(const sortg_mem &G, uint32_t i) { return G.kp[i]; }
 RH_DEV uint32_t sortg_digit(const sortg_mem &G, uint32_t i, int s) { return (uint32_t)(sortg_key(G, i) >> s) & 255u; }
 
 // one wavefront: the reference's cycle walk over >= 3 buckets (see sort_cycle_walk_hb); digits from the LDS cache when the
@@ -604,9 +605,8 @@ RH_DEV void sortg_split_range(sortg_lds &L, const sortg_mem &G, uint32_t beg, ui
 	uint64_t diff = 0;
 	bool tied = false;
 	for (uint32_t i = beg + tid; i < end; i += NT) {
-		const uint32_t idx = G.ia[i];
-		diff |= G.src[idx].x ^ k0;
-		if (pass == SORT_EXACT_TIED) tied |= (G.tbit[idx >> 5] >> (idx & 31u) & 1u) != 0;
+		diff |= G.kp[i] ^ k0;
+		if (pass == SORT_EXACT_TIED) { const uint32_t idx = G.ia[i]; tied |= (G.tbit[idx >> 5] >> (idx & 31u) & 1u) != 0; }
 	}
 	const uint64_t tmk = __ballot(tied);
 	if (lane_id() == 0) L.w[wave_id()] = tmk != 0;
@@ -629,7 +629,7 @@ RH_DEV void sortg_split_range(sortg_lds &L, const sortg_mem &G, uint32_t beg, ui
 	if (exact && my_cnt != 0) { L.dmap[tid] = (uint8_t)dense; L.inv[dense] = (uint8_t)tid; }
 	// permutation of the pass: ia[beg, end) -> ib[beg, end)
 	if (!exact) {
-		for (uint32_t i = beg + tid; i < end; i += NT) { const uint32_t pos = atomicAdd(&L.head[sortg_digit(G, i, s)], 1u); G.ib[pos] = G.ia[i]; }
+		for (uint32_t i = beg + tid; i < end; i += NT) { const uint64_t k = G.kp[i]; const uint32_t pos = atomicAdd(&L.head[(uint32_t)(k >> s) & 255u], 1u); G.ib[pos] = G.ia[i]; G.kb[pos] = k; }
 	} else if (nbk == 2) {
 		// two buckets A < B: closed form of the cycle-leader result (see sort_two_buckets), rank lists in G.tm
 		if (my_cnt != 0) { const uint32_t which = my_start == beg ? 0u : 1u; L.misc[which] = tid; L.misc[2 + which] = my_start; }
@@ -653,7 +653,7 @@ RH_DEV void sortg_split_range(sortg_lds &L, const sortg_mem &G, uint32_t beg, ui
 			const uint32_t i = base + l;
 			const bool foreign = i < a1 && sortg_digit(G, i, s) == cB;
 			const uint64_t B = __ballot(foreign);
-			if (i < a1) { if (foreign) G.tm[beg + ra + lanes_below(B)] = i; else G.ib[i] = G.ia[i]; }
+			if (i < a1) { if (foreign) G.tm[beg + ra + lanes_below(B)] = i; else { G.ib[i] = G.ia[i]; G.kb[i] = G.kp[i]; } }
 			ra += (uint32_t)__popcll(B);
 		}
 		__syncthreads();
@@ -663,13 +663,13 @@ RH_DEV void sortg_split_range(sortg_lds &L, const sortg_mem &G, uint32_t beg, ui
 			const uint64_t B = __ballot(foreign);
 			if (i < b1) {
 				const uint32_t r = rb + lanes_below(B);                 // misplaced records of B before slot i
-				if (foreign) { G.ib[G.tm[beg + r]] = G.ia[i]; G.tm[end - 1 - r] = i; }
-				else G.ib[r < m ? i + 1 : i] = G.ia[i];
+				if (foreign) { const uint32_t d = G.tm[beg + r]; G.ib[d] = G.ia[i]; G.kb[d] = G.kp[i]; G.tm[end - 1 - r] = i; }
+				else { const uint32_t d = r < m ? i + 1 : i; G.ib[d] = G.ia[i]; G.kb[d] = G.kp[i]; }
 			}
 			rb += (uint32_t)__popcll(B);
 		}
 		__syncthreads();
-		for (uint32_t k = tid; k < m; k += NT) G.ib[k == 0 ? startB : G.tm[end - k] + 1u] = G.ia[G.tm[beg + k]];
+		for (uint32_t k = tid; k < m; k += NT) { const uint32_t d = k == 0 ? startB : G.tm[end - k] + 1u, sp = G.tm[beg + k]; G.ib[d] = G.ia[sp]; G.kb[d] = G.kp[sp]; }
 	} else {
 		const bool cached = end - beg <= (uint32_t)RH_SORTG_DB;
 		__syncthreads();
@@ -682,7 +682,7 @@ RH_DEV void sortg_split_range(sortg_lds &L, const sortg_mem &G, uint32_t beg, ui
 			const uint32_t ntg = L.n_tg;
 			for (uint32_t i = beg + tid; i < end; i += NT) {
 				const uint32_t idx = G.ia[i];
-				const uint32_t dgt = (uint32_t)(G.src[idx].x >> s) & 255u, tb = (G.tbit[idx >> 5] >> (idx & 31u)) & 1u;
+				const uint32_t dgt = (uint32_t)(G.kp[i] >> s) & 255u, tb = (G.tbit[idx >> 5] >> (idx & 31u)) & 1u;
 				L.db[i - beg] = (uint8_t)(L.dmap[dgt] | tb << 7);
 				if (tb) {
 					if (s > 0 && L.cnt[dgt] > 64u) bad = true;
@@ -716,10 +716,10 @@ RH_DEV void sortg_split_range(sortg_lds &L, const sortg_mem &G, uint32_t beg, ui
 		__syncthreads();
 		if (wave_id() == 0) sortg_cycle_walk(L, G, beg, end, s, nbk, cached);
 		__syncthreads();
-		for (uint32_t i = beg + tid; i < end; i += NT) G.ib[i] = G.ia[G.tm[i]];
+		for (uint32_t i = beg + tid; i < end; i += NT) { const uint32_t sp = G.tm[i]; G.ib[i] = G.ia[sp]; G.kb[i] = G.kp[sp]; }
 	}
 	__syncthreads();
-	for (uint32_t i = beg + tid; i < end; i += NT) G.ia[i] = G.ib[i];
+	for (uint32_t i = beg + tid; i < end; i += NT) { G.ia[i] = G.ib[i]; G.kp[i] = G.kb[i]; }
 	if (s > 0 && my_cnt > 1) {
 		if (my_cnt > 64) { const uint32_t k = atomicAdd(&L.n_rng[nxt], 1u); G.rng[nxt][k] = (uint64_t)my_start | (uint64_t)(my_start + my_cnt) << 32; G.rsh[nxt][k] = (uint8_t)(s - 8); }
 		else { const uint32_t e = my_start + my_cnt - 1; atomicOr(&G.sbit[my_start >> 5], 1u << (my_start & 31u)); atomicOr(&G.ebit[e >> 5], 1u << (e & 31u)); }
@@ -730,7 +730,7 @@ RH_DEV void sortg_split_range(sortg_lds &L, const sortg_mem &G, uint32_t beg, ui
 RH_DEV void sortg_run(sortg_lds &L, const sortg_mem &G, uint32_t n, int pass)
 {
 	const uint32_t tid = threadIdx.x;
-	for (uint32_t i = tid; i < n; i += NT) G.ia[i] = i;
+	for (uint32_t i = tid; i < n; i += NT) { G.ia[i] = i; G.kp[i] = G.src[i].x; }
 	for (uint32_t i = tid; i < n / 32 + 3; i += NT) { G.sbit[i] = 0; G.ebit[i] = 0; }
 	__syncthreads();
 	if (tid == 0) {
@@ -784,21 +784,16 @@ RH_DEV void sortg_run(sortg_lds &L, const sortg_mem &G, uint32_t n, int pass)
 				if (between == 0) {
 					const uint32_t b = i - (63u - kb), e = i + (uint32_t)__builtin_ctzll(hie);
 					if (e - b < 64) {
-						const uint32_t idx = G.ia[i];
-						const uint64_t k = G.src[idx].x;
+						const uint64_t k = G.kp[i];
 						uint32_t rank = 0, tiedr = 0;
-						for (uint32_t j0 = b; j0 <= e; j0 += 8) {	// eight independent index loads, then eight independent key loads
-							uint32_t jx[8]; uint64_t kj[8];
+						for (uint32_t j0 = b; j0 <= e; j0 += 8) {	// eight independent (coalesced-ish) key loads at a time
+							uint64_t kj[8];
 #pragma unroll
-							for (uint32_t q = 0; q < 8; ++q) jx[q] = G.ia[j0 + q <= e ? j0 + q : e];
+							for (uint32_t q = 0; q < 8; ++q) kj[q] = G.kp[j0 + q <= e ? j0 + q : e];
 #pragma unroll
-							for (uint32_t q = 0; q < 8; ++q) kj[q] = G.src[jx[q]].x;
-#pragma unroll
-							for (uint32_t q = 0; q < 8; ++q) if (j0 + q <= e) {
-								rank += (kj[q] < k || (kj[q] == k && j0 + q < i)) ? 1u : 0u;
-								if (pass == SORT_EXACT_TIED) tiedr |= (G.tbit[jx[q] >> 5] >> (jx[q] & 31u)) & 1u;
-							}
+							for (uint32_t q = 0; q < 8; ++q) if (j0 + q <= e) rank += (kj[q] < k || (kj[q] == k && j0 + q < i)) ? 1u : 0u;
 						}
+						if (pass == SORT_EXACT_TIED) for (uint32_t j = b; j <= e; ++j) { const uint32_t jx = G.ia[j]; tiedr |= (G.tbit[jx >> 5] >> (jx & 31u)) & 1u; }
 						if (pass != SORT_EXACT_TIED || tiedr) dest = b + rank;
 					}
 				}
@@ -807,9 +802,9 @@ RH_DEV void sortg_run(sortg_lds &L, const sortg_mem &G, uint32_t n, int pass)
 		if (i < n) G.tm[i] = dest;
 	}
 	__syncthreads();
-	for (uint32_t i = tid; i < n; i += NT) { const uint32_t d = G.tm[i]; if (d != ~0u) G.ib[d] = G.ia[i]; }
+	for (uint32_t i = tid; i < n; i += NT) { const uint32_t d = G.tm[i]; if (d != ~0u) { G.ib[d] = G.ia[i]; G.kb[d] = G.kp[i]; } }
 	__syncthreads();
-	for (uint32_t i = tid; i < n; i += NT) if (G.tm[i] != ~0u) G.ia[i] = G.ib[i];
+	for (uint32_t i = tid; i < n; i += NT) if (G.tm[i] != ~0u) { G.ia[i] = G.ib[i]; G.kp[i] = G.kb[i]; }
 	__syncthreads();
 }
 
@@ -828,7 +823,8 @@ __global__ __launch_bounds__(NT) void k_sort_gmem(rh_sort_job jb, uint32_t n_lo,
 	const uint32_t n4 = (n + 3u) & ~3u, W = n / 32 + 3, R = n / 64 + 4;
 	sortg_mem G;
 	G.src = src;
-	G.ia = (uint32_t*)S; G.ib = G.ia + n4; G.tm = G.ib + n4;
+	G.kp = (uint64_t*)S; G.kb = G.kp + n4;
+	G.ia = (uint32_t*)(G.kb + n4); G.ib = G.ia + n4; G.tm = G.ib + n4;
 	G.sbit = G.tm + n4; G.ebit = G.sbit + W; G.tbit = G.ebit + W;
 	G.rng[0] = (uint64_t*)(((uintptr_t)(G.tbit + W) + 7) & ~(uintptr_t)7); G.rng[1] = G.rng[0] + R;
 	G.rsh[0] = (uint8_t*)(G.rng[1] + R); G.rsh[1] = G.rsh[0] + R;
@@ -839,13 +835,13 @@ __global__ __launch_bounds__(NT) void k_sort_gmem(rh_sort_job jb, uint32_t n_lo,
 	for (uint32_t i = tid; i < n; i += NT) dst[i] = src[G.ia[i]];
 	if (mode != 0) return;
 	for (uint32_t i = tid; i < n; i += NT) {
-		const uint32_t idx = G.ia[i];
-		const uint64_t k = src[idx].x;
-		if ((i > 0 && src[G.ia[i - 1]].x == k) || (i + 1 < n && src[G.ia[i + 1]].x == k)) {
+		const uint64_t k = G.kp[i];
+		if ((i > 0 && G.kp[i - 1] == k) || (i + 1 < n && G.kp[i + 1] == k)) {
+			const uint32_t idx = G.ia[i];
 			atomicOr(&G.tbit[idx >> 5], 1u << (idx & 31u));
 			L.tie = 1;
 			uint32_t gs = i;
-			while (gs > 0 && src[G.ia[gs - 1]].x == k) --gs;
+			while (gs > 0 && G.kp[gs - 1] == k) --gs;
 			const uint32_t slot = atomicAdd(&L.n_tg, 1u);
 			if (slot < SORT_TG) { L.tg_idx[slot] = idx; L.tg_pos[slot] = gs; L.tg_fin[slot] = ~0u; }
 		}
