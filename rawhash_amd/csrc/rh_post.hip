@@ -163,9 +163,13 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 //                    next chunk carries), sort keys (first-anchor x, start << 32 | chain) -> rr.raw
 //   [rhk_sort_job  : chains into the reference's order of their first anchor]
 //   k_chain_reorder: destination offsets (scan in sorted order), chains copied back over the anchor slice, u[] permuted
+#ifndef CG_CAP
+#define CG_CAP 2048
+#endif
 __global__ __launch_bounds__(NT) void k_chain_gather(rh_dev_round rr)
 {
 	__shared__ uint32_t s_w[NT / 64];
+	__shared__ uint32_t s_off[CG_CAP];
 	const uint32_t a = blockIdx.x, tid = threadIdx.x;
 	if (a >= rr.n_act || rr.skip[a]) return;
 	const uint32_t n_u = rr.n_u[a], n_v = rr.n_v[a];
@@ -187,10 +191,14 @@ __global__ __launch_bounds__(NT) void k_chain_gather(rh_dev_round rr)
 		run += tot;
 	}
 	__syncthreads();
+	// slot -> chain by binary search in the start offsets; up to CG_CAP of them are searched in LDS (ten dependent probes
+	// of an L2 array per slot otherwise)
+	const uint32_t *tab = ck0;
+	if (n_u <= CG_CAP) { for (uint32_t i = tid; i < n_u; i += NT) s_off[i] = ck0[i]; tab = s_off; __syncthreads(); }
 	for (uint32_t q = tid; q < n_v; q += NT) {
 		uint32_t lo = 0, hi = n_u;                                   // chain whose [ck0, ck0 + cnt) holds slot q
-		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ck0[mid] <= q) lo = mid; else hi = mid; }
-		const uint32_t k0 = ck0[lo], ni = (uint32_t)u[lo];
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tab[mid] <= q) lo = mid; else hi = mid; }
+		const uint32_t k0 = tab[lo], ni = (uint32_t)u[lo];
 		pa[q] = an[v[k0 + (ni - (q - k0) - 1)]];
 	}
 	__syncthreads();
@@ -200,6 +208,7 @@ __global__ __launch_bounds__(NT) void k_chain_gather(rh_dev_round rr)
 __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_round rr)
 {
 	__shared__ uint32_t s_w[NT / 64];
+	__shared__ uint32_t s_off[CG_CAP];
 	const uint32_t a = blockIdx.x, tid = threadIdx.x;
 	if (a >= rr.n_act || rr.skip[a]) return;
 	const uint32_t r = rr.act[a];
@@ -224,10 +233,12 @@ __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_ro
 		run += tot;
 	}
 	__syncthreads();
+	const uint32_t *tab = dk;
+	if (n_u <= CG_CAP) { for (uint32_t i = tid; i < n_u; i += NT) s_off[i] = dk[i]; tab = s_off; __syncthreads(); }
 	for (uint32_t q = tid; q < n_v; q += NT) {
 		uint32_t lo = 0, hi = n_u;
-		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (dk[mid] <= q) lo = mid; else hi = mid; }
-		an[q] = pa[(uint32_t)(w[lo].y >> 32) + (q - dk[lo])];
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tab[mid] <= q) lo = mid; else hi = mid; }
+		an[q] = pa[(uint32_t)(w[lo].y >> 32) + (q - tab[lo])];
 	}
 	for (uint32_t i = tid; i < n_u; i += NT) u[i] = u2[i];
 	if (tid == 0) {
