@@ -91,26 +91,30 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 		const int32_t i0 = k >= 0 ? (int32_t)zs[k].y : 0;
 		bool pending = k >= 0, accepted = false;
 		int32_t r_cnt = 0, r_sc = 0;
+		int32_t pn1 = 0, pn2 = 0, pn3 = 0;                             // the first anchors of the path after i0 (most chains are this short)
 		while (__ballot(pending)) {
 			++epoch;
 			const uint32_t stamp = epoch << 6 | (63u - lane);
 			bool walked = false;
-			int32_t max_i = i0, zx = 0, path = 0;                     // path = anchors reached after i0
+			int32_t zx = 0, path = 0, max_s = 0, emit = 0;             // path = unused anchors reached after i0; emit = anchors i0 .. before max_i
 			if (pending && t[i0] == 0) {
 				walked = true;
 				int2 rec = fp[i0];
 				zx = rec.x;
 				atomicMax(&claim[i0], stamp);
-				int32_t max_s = 0;
 				for (;;) {	// mg_chain_bk_end (lchain.c:47-75): back until a used anchor, the start, or a score drop > max_drop
 					const int32_t i = rec.y;
 					int32_t sdrop = zx;
 					uint8_t ti = 0;
 					if (i >= 0) {
 						rec = fp[i]; ti = t[i]; sdrop = zx - rec.x;
-						if (ti == 0) { atomicMax(&claim[i], stamp); ++path; }    // a used anchor ends every walk that reaches it: nobody's to take
+						if (ti == 0) {	// (a used anchor ends every walk that reaches it: nobody's to take, nothing to stamp)
+							atomicMax(&claim[i], stamp);
+							++path;
+							if (path == 1) pn1 = i; else if (path == 2) pn2 = i; else if (path == 3) pn3 = i;
+						}
 					}
-					if (sdrop > max_s) { max_s = sdrop; max_i = i; }
+					if (sdrop > max_s) { max_s = sdrop; emit = (i >= 0 && ti == 0) ? path : path + 1; }   // max_i = i: the chain ends before it
 					else if (max_s - sdrop > max_drop) break;
 					if (i < 0 || ti != 0) break;
 				}
@@ -118,21 +122,25 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 			RH_WG_FENCE();
 			__syncthreads();                                          // every stamp of the round is in
 			bool conflict = false;
-			if (walked) {
-				int32_t x = i0;
-				for (int32_t j = 0; ; ++j) {
-					if (atomicMax(&claim[x], stamp) != stamp) { conflict = true; break; }   // read at L2, where the stamps were combined
-					if (j == path) break;
-					x = fp[x].y;
-				}
+			if (walked) {	// read at L2, where the stamps were combined; the cached anchors' reads are independent of each other
+				const uint32_t c0 = atomicMax(&claim[i0], stamp);
+				const uint32_t c1 = path >= 1 ? atomicMax(&claim[pn1], stamp) : stamp;
+				const uint32_t c2 = path >= 2 ? atomicMax(&claim[pn2], stamp) : stamp;
+				const uint32_t c3 = path >= 3 ? atomicMax(&claim[pn3], stamp) : stamp;
+				conflict = c0 != stamp || c1 != stamp || c2 != stamp || c3 != stamp;
+				int32_t x = pn3;
+				for (int32_t j = 3; j < path && !conflict; ++j) { x = fp[x].y; if (atomicMax(&claim[x], stamp) != stamp) conflict = true; }
 			}
 			if (pending && !conflict) {
 				if (walked) {	// anchors i0 .. (exclusive) max_i form the chain; the marks stay even if it is rejected, as in the reference
-					int32_t cnt = 0, x = i0;
-					while (x != max_i) { t[x] = 1; ++cnt; x = fp[x].y; }
-					const int32_t sc = max_i < 0 ? zx : zx - fp[max_i].x;
-					accepted = sc >= min_sc && cnt > 0 && cnt >= min_cnt;
-					r_cnt = cnt; r_sc = sc;
+					if (emit >= 1) t[i0] = 1;
+					if (emit >= 2) t[pn1] = 1;
+					if (emit >= 3) t[pn2] = 1;
+					if (emit >= 4) t[pn3] = 1;
+					int32_t x = pn3;
+					for (int32_t j = 4; j < emit; ++j) { x = fp[x].y; t[x] = 1; }
+					accepted = max_s >= min_sc && emit > 0 && emit >= min_cnt;   // (score of the chain = the best drop seen = max_s)
+					r_cnt = emit; r_sc = max_s;
 				}
 				pending = false;
 			}
@@ -146,8 +154,13 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 		const uint32_t total = __shfl(inc, 63);
 		if (accepted) {
 			u[n_u + (int32_t)lanes_below(am)] = (uint64_t)(uint32_t)r_sc << 32 | (uint64_t)(uint32_t)r_cnt;
-			int32_t off = n_v + (int32_t)(inc - (uint32_t)r_cnt), x = i0;
-			for (int32_t j = 0; j < r_cnt; ++j) { v[off + j] = x; x = fp[x].y; }
+			const int32_t off = n_v + (int32_t)(inc - (uint32_t)r_cnt);
+			v[off] = i0;
+			if (r_cnt >= 2) v[off + 1] = pn1;
+			if (r_cnt >= 3) v[off + 2] = pn2;
+			if (r_cnt >= 4) v[off + 3] = pn3;
+			int32_t x = pn3;
+			for (int32_t j = 4; j < r_cnt; ++j) { x = fp[x].y; v[off + j] = x; }
 		}
 		n_u += (int32_t)__popcll(am);
 		n_v += (int32_t)total;
