@@ -33,9 +33,13 @@ RH_DEV uint64_t pa_tile_ballot(const int16_t *raw, uint32_t i, uint32_t end, dou
 	return __ballot(valid);
 }
 
+#ifndef PF_TILES
+#define PF_TILES 2048          // tiles of 256 samples whose counts fit LDS (reads up to 512 k samples)
+#endif
 __global__ __launch_bounds__(NT) void k_prefilter(rh_dev_opt o, rh_dev_reads rd)
 {
 	__shared__ uint32_t s_tot[NT / 64];
+	__shared__ uint16_t s_tc[PF_TILES];
 	const uint32_t r = blockIdx.x, tid = threadIdx.x, w = wave_id(), l = lane_id();
 	const uint64_t o0 = rd.off[r], n64 = rd.off[r + 1] - o0;
 	const uint32_t n = (uint32_t)n64;
@@ -47,30 +51,37 @@ __global__ __launch_bounds__(NT) void k_prefilter(rh_dev_opt o, rh_dev_reads rd)
 	const uint32_t C = o.chunk_size;
 	const uint32_t per = ((n + (NT / 64) * 256u - 1) / ((NT / 64) * 256u)) * 256u;   // samples per wavefront, whole tiles
 	const uint32_t beg = w * per < n ? w * per : n, end = beg + per < n ? beg + per : n;
+	const bool keep = (n + 255) / 256 <= PF_TILES;                // per-tile counts of pass 1 kept in LDS: pass 2 re-reads boundary tiles only
 	uint32_t cnt = 0;
 	for (uint32_t base = beg; base < end; base += 256) {
+		uint32_t tc = 0;
 #pragma unroll
-		for (uint32_t k = 0; k < 4; ++k) cnt += (uint32_t)__popcll(pa_tile_ballot(raw, base + k * 64 + l, end, coff, cscale));
+		for (uint32_t k = 0; k < 4; ++k) tc += (uint32_t)__popcll(pa_tile_ballot(raw, base + k * 64 + l, end, coff, cscale));
+		if (keep && l == 0) s_tc[base >> 8] = (uint16_t)tc;
+		cnt += tc;
 	}
 	if (l == 0) s_tot[w] = cnt;
 	__syncthreads();                                              // (also orders the cs[] defaults before the boundary writes)
 	uint32_t run = 0, total = 0;
 	for (uint32_t q = 0; q < NT / 64; ++q) { const uint32_t c = s_tot[q]; if (q < w) run += c; total += c; }
 	for (uint32_t base = beg; base < end; base += 256) {
-		uint64_t B[4];
-		uint32_t tc = 0;
-#pragma unroll
-		for (uint32_t k = 0; k < 4; ++k) { B[k] = pa_tile_ballot(raw, base + k * 64 + l, end, coff, cscale); tc += (uint32_t)__popcll(B[k]); }
+		uint32_t tc = keep ? (uint32_t)s_tc[base >> 8] : 0u;
 		const uint32_t nb = ((run + C - 1) / C) * C;               // first chunk boundary at or after this tile's first survivor
-		if (nb < run + tc) {
-			uint32_t before = run;
+		if (!keep || nb < run + tc) {
+			uint64_t B[4];
+			tc = 0;
 #pragma unroll
-			for (uint32_t k = 0; k < 4; ++k) {
-				if ((B[k] >> l) & 1ull) {
-					const uint32_t fi = before + lanes_below(B[k]);
-					if (fi % C == 0) { const uint32_t kk = fi / C; if (kk <= RH_MAX_CHUNKS) cs[kk] = base + k * 64 + l; }
+			for (uint32_t k = 0; k < 4; ++k) { B[k] = pa_tile_ballot(raw, base + k * 64 + l, end, coff, cscale); tc += (uint32_t)__popcll(B[k]); }
+			if (nb < run + tc) {
+				uint32_t before = run;
+#pragma unroll
+				for (uint32_t k = 0; k < 4; ++k) {
+					if ((B[k] >> l) & 1ull) {
+						const uint32_t fi = before + lanes_below(B[k]);
+						if (fi % C == 0) { const uint32_t kk = fi / C; if (kk <= RH_MAX_CHUNKS) cs[kk] = base + k * 64 + l; }
+					}
+					before += (uint32_t)__popcll(B[k]);
 				}
-				before += (uint32_t)__popcll(B[k]);
 			}
 		}
 		run += tc;
