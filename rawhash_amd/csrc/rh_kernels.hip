@@ -125,6 +125,38 @@ RH_DEV float tstat_at(const float *ps, const float *pss, uint32_t n, uint32_t w,
 //   k_events_means  (one block per read)      per-segment sort + IQR-fenced mean -> events
 #define EV_ROW (RH_CHUNK_MAX + 64)             // row stride (floats) of the z / t1 / t2 staging arrays
 
+// dst[0] = 0, dst[i + 1] = dst[i] + (SQ ? z[i] * z[i] : z[i]) in fp32, strictly left to right, by ONE lane.  The chain of
+// dependent adds is the floor (a lone wavefront gets a dependent VALU result every ~8 cycles); everything else is kept
+// off it: the samples arrive 16 ahead in 16-byte LDS reads, the results leave in aligned 16-byte LDS writes.
+template <bool SQ>
+RH_DEV void serial_prefix(const float *z, float *dst, uint32_t n)
+{
+	float acc = 0.0f;
+	dst[0] = 0.0f;
+	uint32_t i = 0;
+	#define SP_STEP(r, a) do { if (SQ) { r.x = acc = acc + a.x * a.x; r.y = acc = acc + a.y * a.y; r.z = acc = acc + a.z * a.z; r.w = acc = acc + a.w * a.w; } \
+	                           else { r.x = acc = acc + a.x; r.y = acc = acc + a.y; r.z = acc = acc + a.z; r.w = acc = acc + a.w; } } while (0)
+	if (n >= 16) {
+		const float4 *z4 = reinterpret_cast<const float4*>(z);
+		float4 a0 = z4[0], a1 = z4[1], a2 = z4[2], a3 = z4[3];
+		for (; i + 32 <= n; i += 16) {	// the next 16 samples are requested before the 16 dependent adds of this round
+			const float4 b0 = z4[i / 4 + 4], b1 = z4[i / 4 + 5], b2 = z4[i / 4 + 6], b3 = z4[i / 4 + 7];
+			float4 r0, r1, r2, r3;
+			SP_STEP(r0, a0); SP_STEP(r1, a1); SP_STEP(r2, a2); SP_STEP(r3, a3);
+			*reinterpret_cast<float4*>(&dst[i + 1]) = r0; *reinterpret_cast<float4*>(&dst[i + 5]) = r1;
+			*reinterpret_cast<float4*>(&dst[i + 9]) = r2; *reinterpret_cast<float4*>(&dst[i + 13]) = r3;
+			a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+		}
+		float4 r0, r1, r2, r3;
+		SP_STEP(r0, a0); SP_STEP(r1, a1); SP_STEP(r2, a2); SP_STEP(r3, a3);
+		*reinterpret_cast<float4*>(&dst[i + 1]) = r0; *reinterpret_cast<float4*>(&dst[i + 5]) = r1;
+		*reinterpret_cast<float4*>(&dst[i + 9]) = r2; *reinterpret_cast<float4*>(&dst[i + 13]) = r3;
+		i += 16;
+	}
+	#undef SP_STEP
+	for (; i < n; ++i) { const float v = z[i]; acc = acc + (SQ ? v * v : v); dst[i + 1] = acc; }
+}
+
 __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
 {
 	__shared__ __attribute__((aligned(16))) float s_z[RH_CHUNK_MAX];
@@ -240,27 +272,8 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 	//    wave 0 accumulates z, one lane of wave 1 accumulates z*z, concurrently.  The prefix arrays are stored shifted by
 	//    3 floats so that entries 4k+1 .. 4k+4 form one aligned 16-byte LDS store.
 	float *pa = s_a + 3, *pb = s_b + 3;
-	if (tid == 0 || tid == 64) {
-		const bool sq = tid == 64;
-		float *dst = sq ? pb : pa;
-		float acc = 0.0f;
-		dst[0] = 0.0f;
-		uint32_t i = 0;
-		for (; i + 8 <= n; i += 8) {
-			const float4 z0 = *reinterpret_cast<const float4*>(&s_z[i]), z1 = *reinterpret_cast<const float4*>(&s_z[i + 4]);
-			float4 r0, r1;
-			if (sq) {
-				r0.x = acc = acc + z0.x * z0.x; r0.y = acc = acc + z0.y * z0.y; r0.z = acc = acc + z0.z * z0.z; r0.w = acc = acc + z0.w * z0.w;
-				r1.x = acc = acc + z1.x * z1.x; r1.y = acc = acc + z1.y * z1.y; r1.z = acc = acc + z1.z * z1.z; r1.w = acc = acc + z1.w * z1.w;
-			} else {
-				r0.x = acc = acc + z0.x; r0.y = acc = acc + z0.y; r0.z = acc = acc + z0.z; r0.w = acc = acc + z0.w;
-				r1.x = acc = acc + z1.x; r1.y = acc = acc + z1.y; r1.z = acc = acc + z1.z; r1.w = acc = acc + z1.w;
-			}
-			*reinterpret_cast<float4*>(&dst[i + 1]) = r0;
-			*reinterpret_cast<float4*>(&dst[i + 5]) = r1;
-		}
-		for (; i < n; ++i) { const float z = s_z[i]; acc = acc + (sq ? z * z : z); dst[i + 1] = acc; }
-	}
+	if (tid == 0) serial_prefix<false>(s_z, pa, n);
+	else if (tid == 64) serial_prefix<true>(s_z, pb, n);
 	__syncthreads();
 
 	// 4. t-statistics of both windows and the normalised signal go to HBM rows (coalesced)
