@@ -352,10 +352,56 @@ __global__ __launch_bounds__(64) void k_events_peaks(rh_dev_opt o, rh_dev_round 
 	if (a < rr.n_act && k == 0) rr.n_peaks[a] = np < RH_EV_CAP ? np : RH_EV_CAP;
 }
 
+// IQR-fenced mean of one sorted segment (revent.c:158-180): fp32 sum in ascending order
+RH_DEV float fenced_mean_lds(const float *seg, uint32_t len)
+{
+	const float q1 = seg[len / 4], q3 = seg[3 * len / 4], iqr = q3 - q1, lo = q1 - iqr, hi = q3 + iqr;
+	float sum = 0.0f; uint32_t cnt = 0;
+	for (uint32_t i = 0; i < len; ++i) if (seg[i] >= lo && seg[i] <= hi) { sum += seg[i]; ++cnt; }
+	return cnt > 0 ? sum / (float)cnt : 0.0f;
+}
+
+// One lane per segment, the segment in REGISTERS: 88 % of the segments have <= 16 samples, 99 % <= 32, but an in-LDS
+// insertion sort makes every lane wait for the longest segment of its wavefront (quadratic, one bank-conflicted LDS round
+// trip per shift).  A bitonic network on 32 (or 16) registers is data-independent: a few hundred min / max, no memory.
+// The sorted values are unique as a sequence, so any correct sort gives the reference's qsort result.
+template <int N>
+RH_DEV float sort_mean_regs(const float *seg, uint32_t len)
+{
+	float v[N];
+#pragma unroll
+	for (int i = 0; i < N; ++i) v[i] = (uint32_t)i < len ? seg[i] : FLT_MAX;
+#pragma unroll
+	for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+		for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+			for (int i = 0; i < N; ++i) {
+				const int l = i ^ j;
+				if (l > i) {
+					const float lo = fminf(v[i], v[l]), hi = fmaxf(v[i], v[l]);
+					if ((i & k) == 0) { v[i] = lo; v[l] = hi; } else { v[i] = hi; v[l] = lo; }
+				}
+			}
+		}
+	}
+	float q1 = 0.0f, q3 = 0.0f;
+#pragma unroll
+	for (int i = 0; i < N; ++i) { if ((uint32_t)i == len / 4) q1 = v[i]; if ((uint32_t)i == 3 * len / 4) q3 = v[i]; }
+	const float iqr = q3 - q1, lo = q1 - iqr, hi = q3 + iqr;
+	float sum = 0.0f; uint32_t cnt = 0;
+#pragma unroll
+	for (int i = 0; i < N; ++i) if ((uint32_t)i < len && v[i] >= lo && v[i] <= hi) { sum += v[i]; ++cnt; }
+	return cnt > 0 ? sum / (float)cnt : 0.0f;
+}
+
+#define EM_LONG 128          // segments the lanes hand over to a whole wavefront
 __global__ __launch_bounds__(NT) void k_events_means(rh_dev_opt o, rh_dev_round rr)
 {
 	__shared__ float s_z[RH_CHUNK_MAX];
 	__shared__ uint16_t s_peaks[RH_EV_CAP];
+	__shared__ uint16_t s_long[EM_LONG];
+	__shared__ uint32_t s_nlong;
 	const uint32_t a = blockIdx.x, tid = threadIdx.x;
 	if (a >= rr.n_act) return;
 	const uint32_t n = rr.n_norm[a];
@@ -364,27 +410,58 @@ __global__ __launch_bounds__(NT) void k_events_means(rh_dev_opt o, rh_dev_round 
 	const uint16_t *pk = rr.peaks + (size_t)a * RH_EV_CAP;
 	for (uint32_t i = tid; i < n; i += NT) s_z[i] = zrow[i];
 	for (uint32_t i = tid; i < np; i += NT) s_peaks[i] = pk[i];
+	if (tid == 0) s_nlong = 0;
 	__syncthreads();
-	// one lane per segment: sort, IQR fence, mean
 	float *ev = rr.ev + (size_t)a * RH_EV_CAP;
-	for (uint32_t k = tid; k < np; k += NT) {
-		const uint32_t start = k ? s_peaks[k - 1] : 0u, end = s_peaks[k];
-		const uint32_t len = end > start ? end - start : 0u;
-		float *seg = s_z + start;
-		for (uint32_t i = 1; i < len; ++i) {
-			const float v = seg[i];
-			uint32_t j = i;
-			while (j > 0 && seg[j - 1] > v) { seg[j] = seg[j - 1]; --j; }
-			seg[j] = v;
-		}
+	for (uint32_t k0 = 0; k0 < np; k0 += NT) {
+		const uint32_t k = k0 + tid;
+		uint32_t start = 0, len = 0;
+		if (k < np) { start = k ? s_peaks[k - 1] : 0u; const uint32_t end = s_peaks[k]; len = end > start ? end - start : 0u; }
+		const bool small = k < np && len <= 32;
+		if (k < np && !small) { const uint32_t q = atomicAdd(&s_nlong, 1u); if (q < EM_LONG) s_long[q] = (uint16_t)k; }
 		float res = 0.0f;
-		if (len > 0) {
-			const float q1 = seg[len / 4], q3 = seg[3 * len / 4], iqr = q3 - q1, lo = q1 - iqr, hi = q3 + iqr;
-			float sum = 0.0f; uint32_t cnt = 0;
-			for (uint32_t i = 0; i < len; ++i) if (seg[i] >= lo && seg[i] <= hi) { sum += seg[i]; ++cnt; }
-			res = cnt > 0 ? sum / (float)cnt : 0.0f;
+		if (__ballot(small && len > 16)) { if (small && len > 0) res = sort_mean_regs<32>(s_z + start, len); }
+		else if (small && len > 0) res = sort_mean_regs<16>(s_z + start, len);
+		if (small) ev[k] = res;
+	}
+	__syncthreads();
+	// the rare long segments: one wavefront each ranks the samples (broadcast LDS reads), scatters them, and one lane sums
+	const uint32_t nl = s_nlong < EM_LONG ? s_nlong : EM_LONG;
+	for (uint32_t q = wave_id(); q < nl; q += NT / 64) {
+		const uint32_t k = s_long[q], start = k ? s_peaks[k - 1] : 0u, len = s_peaks[k] - start, l = lane_id();
+		float *seg = s_z + start;
+		if (len <= 256) {
+			float v[4]; uint32_t rk[4];
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				const uint32_t e = (uint32_t)t * 64u + l;
+				v[t] = e < len ? seg[e] : 0.0f; rk[t] = 0;
+			}
+			for (uint32_t j = 0; j < len; ++j) {
+				const float sj = seg[j];
+#pragma unroll
+				for (int t = 0; t < 4; ++t) rk[t] += (sj < v[t] || (sj == v[t] && j < (uint32_t)t * 64u + l)) ? 1u : 0u;
+			}
+			RH_WAVE_SYNC();
+#pragma unroll
+			for (int t = 0; t < 4; ++t) if ((uint32_t)t * 64u + l < len) seg[rk[t]] = v[t];
+			RH_WAVE_SYNC();
+		} else if (l == 0) {
+			for (uint32_t i = 1; i < len; ++i) { const float x = seg[i]; uint32_t j = i; while (j > 0 && seg[j - 1] > x) { seg[j] = seg[j - 1]; --j; } seg[j] = x; }
 		}
-		ev[k] = res;
+		if (l == 0) ev[k] = fenced_mean_lds(seg, len);
+	}
+	if (s_nlong > EM_LONG && tid == 0) {	// more long segments than the list holds (pathological signal): the plain serial way
+		for (uint32_t k = 0; k < np; ++k) {
+			const uint32_t start = k ? s_peaks[k - 1] : 0u, end = s_peaks[k], len = end > start ? end - start : 0u;
+			if (len <= 32) continue;
+			bool listed = false;
+			for (uint32_t q = 0; q < EM_LONG; ++q) listed |= s_long[q] == k;
+			if (listed) continue;
+			float *seg = s_z + start;
+			for (uint32_t i = 1; i < len; ++i) { const float x = seg[i]; uint32_t j = i; while (j > 0 && seg[j - 1] > x) { seg[j] = seg[j - 1]; --j; } seg[j] = x; }
+			ev[k] = fenced_mean_lds(seg, len);
+		}
 	}
 	if (tid == 0) {
 		rr.n_ev[a] = np;
