@@ -26,6 +26,38 @@ def check_events(ctx, wl, chunks=(0, 1, 2)):
     return ev, off
 
 
+class _ReadsOnly:
+    """what check_events needs of a workload: options + reads"""
+    def __init__(self, opts, reads):
+        self.opts, self.reads = opts, reads
+
+
+def check_events_odd_signals(ctx, wl, seed=0):
+    """Event detection on signals with long dwells (segments of hundreds of samples: the whole-wavefront / serial branches of
+    the segment sort), flat stretches, out-of-range samples (pA filter) and very short reads."""
+    from rawhash_amd.api import Reads
+    rng = np.random.default_rng(seed)
+    dig, rng_pa, off = 8192.0, 1402.882, 6.0
+    scale = rng_pa / dig
+    sigs = []
+    for r in range(24):
+        n = int(rng.integers(200, 12000)) if r % 6 else int(rng.integers(0, 60))
+        pa = np.empty(n, dtype=np.float64)
+        i = 0
+        while i < n:
+            kind = rng.integers(0, 5)
+            dwell = int(rng.integers(3, 20)) if kind < 3 else int(rng.integers(40, 900)) if kind == 3 else int(rng.integers(1, 4))
+            level = rng.uniform(60, 130) if kind != 4 else rng.choice([10.0, 250.0])      # kind 4: outside (30, 200) pA
+            m = min(dwell, n - i)
+            pa[i:i + m] = level + rng.normal(0, 1.5 if r % 3 else 0.2, size=m)
+            i += m
+        sigs.append(np.round(pa / scale - off).clip(-32768, 32767).astype(np.int16))
+    offs = np.zeros(len(sigs) + 1, dtype=np.uint64); offs[1:] = np.cumsum([len(x) for x in sigs])
+    reads = Reads(np.concatenate(sigs), offs, [f"odd{r}" for r in range(len(sigs))],
+                  np.full(len(sigs), off, dtype=np.float64), np.full(len(sigs), scale, dtype=np.float32))
+    return check_events(ctx, _ReadsOnly(wl.opts, reads), chunks=(0, 1, 2))
+
+
 def oracle_events(wl, chunk=0):
     b = wl.reads.batch()
     n = len(wl.reads)

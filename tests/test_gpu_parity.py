@@ -29,6 +29,8 @@ def test_native_library_loaded(product_lib):
 
 def test_events_bit_exact(ctx, wl):
     pc.check_events(ctx, wl, chunks=(0, 1, 3, 5))
+    for seed in (1, 2, 3):
+        pc.check_events_odd_signals(ctx, wl, seed=seed)
 
 
 def test_stage_chain(ctx, wl):
