@@ -393,40 +393,108 @@ RH_DEV void sort_run(sort_lds<CAP> &L, uint32_t n, int pass)
 		if (tid == 0) L.n_rng[cur] = 0;
 		__syncthreads();
 	}
-	// Ranges of <= 64 records get klib's insertion sort, i.e. any STABLE sort: one wavefront per range computes each
-	// record's rank (smaller keys + equal keys that come earlier) with broadcast LDS reads and scatters in one step.
+	// Ranges of <= 64 records get klib's insertion sort, i.e. any STABLE sort.  Most hold a dozen or two records whose keys
+	// differ in their low bits only: ONE LANE per range then sorts the words (key bits << 5 | position) in registers with a
+	// bitonic network - data-independent, no memory, and the position in the low bits makes it stable.  The others (33..64
+	// records, keys differing high up) are ranked by a whole wavefront from its lanes' registers.
 	KPROF(8);
-	const uint32_t nw32 = (n + 31) / 32, wv = rh_uniform(wave_id());
-	for (uint32_t wi = wv; wi < nw32; wi += NT / 64) {
-		uint32_t sb = rh_uniform(L.sbit[wi]);
+	if (tid == 0) L.misc[0] = 0;
+	__syncthreads();
+	const uint32_t nw32 = (n + 31) / 32;
+	for (uint32_t wi = tid; wi < nw32; wi += NT) {	// list of the ranges: first position, length (xm is free between passes)
+		uint32_t sb = L.sbit[wi];
 		while (sb) {
 			const uint32_t bit = (uint32_t)__builtin_ctz(sb);
 			sb &= sb - 1;
 			const uint32_t b = wi * 32 + bit;
-			uint32_t ew = rh_uniform(L.ebit[wi]) >> bit, e = b;
+			uint32_t ew = L.ebit[wi] >> bit, e = b;
 			if (ew) e = b + (uint32_t)__builtin_ctz(ew);
-			else { uint32_t x = wi + 1; while ((ew = rh_uniform(L.ebit[x])) == 0) ++x; e = x * 32 + (uint32_t)__builtin_ctz(ew); }
-			const uint32_t m = e - b + 1, l = lane_id();
-			const uint16_t idx = L.ia[b + (l < m ? l : 0u)];
-			if (pass == SORT_EXACT_TIED && __ballot((L.tbit[idx >> 5] >> (idx & 31u)) & 1u) == 0) continue;   // final since the fast pass
-			const uint64_t k = L.key[idx];
-			const uint32_t klo = (uint32_t)k, khi = (uint32_t)(k >> 32);
-			uint32_t rank = 0;
-			// the other records' keys come from their lanes' registers (v_readlane with the wave-uniform j), not from LDS
-			const uint32_t khi0 = rh_readlane(khi, 0), klo0 = rh_readlane(klo, 0);
-			if (__ballot(khi != khi0 || ((klo ^ klo0) >> 26) != 0) == 0) {
-				// the keys differ in their low 26 bits only: (key bits, position) in one word makes the stable order a plain '<'
-				const uint32_t c = klo << 6 | l;
-				for (uint32_t j = 0; j < m; ++j) rank += rh_readlane(c, j) < c ? 1u : 0u;
-			} else {
-				for (uint32_t j = 0; j < m; ++j) {
-					const uint64_t kj = (uint64_t)rh_readlane(khi, j) << 32 | rh_readlane(klo, j);
-					rank += (kj < k || (kj == k && j < l)) ? 1u : 0u;
-				}
-			}
-			RH_WAVE_SYNC();                                    // every lane has read the range before it is rewritten
-			if (l < m) L.ia[b + rank] = idx;
+			else { uint32_t x = wi + 1; while ((ew = L.ebit[x]) == 0) ++x; e = x * 32 + (uint32_t)__builtin_ctz(ew); }
+			const uint32_t q = atomicAdd(&L.misc[0], 1u);
+			L.xm[2 * q] = (uint16_t)b; L.xm[2 * q + 1] = (uint16_t)(e - b + 1);
 		}
+	}
+	__syncthreads();
+	const uint32_t ns = L.misc[0];
+	for (uint32_t q0 = 0; q0 < ns; q0 += NT) {
+		const uint32_t q = q0 + tid;
+		uint32_t b = 0, m = 0;
+		if (q < ns) { b = L.xm[2 * q]; m = L.xm[2 * q + 1]; }
+		bool mine = q < ns && m <= 32;
+		if (mine && ((L.key[L.ia[b]] ^ L.key[L.ia[b + m - 1]]) >> 27) != 0) mine = false;   // cheap look before loading the range
+		if (__ballot(mine) == 0) continue;
+		uint32_t c[32];
+		uint64_t dif = 0, k0 = 0;
+		uint32_t tiedr = 0;
+#pragma unroll
+		for (int j = 0; j < 32; ++j) {
+			c[j] = 0xFFFFFFFFu;
+			if (mine && (uint32_t)j < m) {
+				const uint32_t idx = L.ia[b + j];
+				const uint64_t k = L.key[idx];
+				if (j == 0) k0 = k;
+				dif |= k ^ k0;
+				tiedr |= (L.tbit[idx >> 5] >> (idx & 31u)) & 1u;
+				c[j] = (uint32_t)k << 5 | (uint32_t)j;
+			}
+		}
+		if (mine && (dif >> 27) != 0) mine = false;               // keys differ above bit 26: the wavefront path
+		const bool skip = mine && pass == SORT_EXACT_TIED && !tiedr;   // final since the fast pass
+		if (mine) L.xm[2 * q + 1] = (uint16_t)(m | 0x8000u);          // settled here
+		if (__ballot(mine && !skip) == 0) continue;
+		if (__ballot(mine && !skip && m > 16)) {
+#pragma unroll
+			for (int kk = 2; kk <= 32; kk <<= 1)
+#pragma unroll
+				for (int jj = kk >> 1; jj > 0; jj >>= 1)
+#pragma unroll
+					for (int i = 0; i < 32; ++i) {
+						const int l2 = i ^ jj;
+						if (l2 > i) { const uint32_t lo = c[i] < c[l2] ? c[i] : c[l2], hi = c[i] < c[l2] ? c[l2] : c[i]; if ((i & kk) == 0) { c[i] = lo; c[l2] = hi; } else { c[i] = hi; c[l2] = lo; } }
+					}
+		} else {
+#pragma unroll
+			for (int kk = 2; kk <= 16; kk <<= 1)
+#pragma unroll
+				for (int jj = kk >> 1; jj > 0; jj >>= 1)
+#pragma unroll
+					for (int i = 0; i < 16; ++i) {
+						const int l2 = i ^ jj;
+						if (l2 > i) { const uint32_t lo = c[i] < c[l2] ? c[i] : c[l2], hi = c[i] < c[l2] ? c[l2] : c[i]; if ((i & kk) == 0) { c[i] = lo; c[l2] = hi; } else { c[i] = hi; c[l2] = lo; } }
+					}
+		}
+		if (mine && !skip) {	// the record that was at position (word & 31) moves to the word's rank; all reads before the first write
+			uint16_t nx[32];
+#pragma unroll
+			for (int j = 0; j < 32; ++j) nx[j] = (uint32_t)j < m ? L.ia[b + (c[j] & 31u)] : (uint16_t)0;
+#pragma unroll
+			for (int j = 0; j < 32; ++j) if ((uint32_t)j < m) L.ia[b + j] = nx[j];
+		}
+	}
+	__syncthreads();
+	const uint32_t wv = rh_uniform(wave_id());
+	for (uint32_t q = wv; q < ns; q += NT / 64) {
+		const uint32_t mm = rh_uniform((uint32_t)L.xm[2 * q + 1]);
+		if (mm & 0x8000u) continue;
+		const uint32_t b = rh_uniform((uint32_t)L.xm[2 * q]), m = mm, l = lane_id();
+		const uint16_t idx = L.ia[b + (l < m ? l : 0u)];
+		if (pass == SORT_EXACT_TIED && __ballot((L.tbit[idx >> 5] >> (idx & 31u)) & 1u) == 0) continue;   // final since the fast pass
+		const uint64_t k = L.key[idx];
+		const uint32_t klo = (uint32_t)k, khi = (uint32_t)(k >> 32);
+		uint32_t rank = 0;
+		// the other records' keys come from their lanes' registers (v_readlane with the wave-uniform j), not from LDS
+		const uint32_t khi0 = rh_readlane(khi, 0), klo0 = rh_readlane(klo, 0);
+		if (__ballot(khi != khi0 || ((klo ^ klo0) >> 26) != 0) == 0) {
+			const uint32_t cw = klo << 6 | l;                       // (key bits, position) in one word makes the stable order a plain '<'
+			for (uint32_t j = 0; j < m; ++j) rank += rh_readlane(cw, j) < cw ? 1u : 0u;
+		} else {
+			for (uint32_t j = 0; j < m; ++j) {
+				const uint64_t kj = (uint64_t)rh_readlane(khi, j) << 32 | rh_readlane(klo, j);
+				rank += (kj < k || (kj == k && j < l)) ? 1u : 0u;
+			}
+		}
+		RH_WAVE_SYNC();                                        // every lane has read the range before it is rewritten
+		if (l < m) L.ia[b + rank] = idx;
 	}
 	__syncthreads();
 	KPROF(9);
