@@ -58,6 +58,7 @@ struct rh_ctx_s {
 	DevBuf blob; bool blob_owned = true;
 	rh_dev_index dix{};
 	bool have_index = false;
+	bool akey_on = false; uint8_t akey_lo = 0, akey_mid = 0;      // dimensions of the anchor keys of the resident index
 	unsigned char header[256] = {0};
 	// logf table
 	DevBuf logf_tab;
@@ -277,6 +278,7 @@ struct BlobHeader {
 	uint64_t magic, bytes, table_off, pos_off, len_off, n_pos;
 	int32_t lg_buckets; uint32_t n_seq; int32_t flag;
 	rh_sketch_par sp;
+	uint32_t max_len;
 };
 const uint64_t kBlobMagic = 0x3130424958444952ULL;   // "RIDXIB01"
 
@@ -287,6 +289,12 @@ int bind_blob(rh_ctx *c, const BlobHeader &h)
 	c->dix.pos = (const uint64_t*)(base + h.pos_off);
 	c->dix.seq_len = (const uint32_t*)(base + h.len_off);
 	c->dix.lg_buckets = h.lg_buckets; c->dix.n_seq = h.n_seq; c->dix.flag = h.flag; c->dix.sp = h.sp;
+	// anchor keys fit 32 bits when strand + target id + position do (they do up to a few hundred Mbp in a few targets)
+	uint32_t lo = 0, mid = 0;
+	while (lo < 32 && (1ull << lo) <= (uint64_t)h.max_len) ++lo;
+	while (mid < 32 && (1ull << mid) < (uint64_t)(h.n_seq ? h.n_seq : 1)) ++mid;
+	c->akey_on = h.max_len > 0 && lo <= 30 && mid <= 24 && lo + mid + 1 <= 32;
+	c->akey_lo = (uint8_t)lo; c->akey_mid = (uint8_t)mid;
 	memset(c->header, 0, sizeof(c->header));
 	memcpy(c->header, &h, sizeof(h));
 	c->have_index = true;
@@ -308,6 +316,8 @@ extern "C" int rh_index_upload(rh_ctx *c, const rh_index *ix)
 	h.len_off = h.pos_off + (h.n_pos ? h.n_pos : 1) * 8;
 	h.bytes = h.len_off + (ix->lens.size() ? ix->lens.size() : 1) * 4;
 	h.lg_buckets = lg; h.n_seq = (uint32_t)ix->lens.size(); h.flag = ix->flag;
+	h.max_len = 0;
+	for (uint32_t L : ix->lens) if (L > h.max_len) h.max_len = L;
 	h.sp = rh_sketch_par{ix->e, ix->w, ix->q, ix->k, ix->diff, ix->fine_min, ix->fine_max, ix->fine_range};
 	if (!c->blob_owned) { c->blob.p = nullptr; c->blob.cap = 0; c->blob_owned = true; }
 	if (c->blob.ensure(h.bytes)) return -1;
@@ -421,6 +431,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 		rh_dev_round rr{};
 		if (stage_round(c, n_act, &rr)) return -1;
 		rr.act = c->act[cur].as<uint32_t>(); rr.chunk = chunk;
+		rr.akey_on = c->akey_on ? 1 : 0; rr.akey_lo = c->akey_lo; rr.akey_mid = c->akey_mid;
 		rr.prev_in = c->prev[which ^ 1].as<rh_mm128_t>();
 		{ StageTimer t(c, ST_EV_NORM); rhk_events_norm(s, o, rd, rr); }
 		{ StageTimer t(c, ST_EV_PEAKS); rhk_events_peaks(s, o, rr); }
@@ -545,6 +556,7 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 	}
 	for (rh_ctx *sc : c->subs) {	// borrow the resident index and the logf table
 		sc->dix = c->dix; sc->have_index = true; sc->blob_owned = false;
+		sc->akey_on = c->akey_on; sc->akey_lo = c->akey_lo; sc->akey_mid = c->akey_mid;
 		sc->logf_tab.p = c->logf_tab.p; sc->logf_tab.cap = c->logf_tab.cap; sc->logf_tab.owned = false;
 	}
 	const auto t_begin = std::chrono::steady_clock::now();

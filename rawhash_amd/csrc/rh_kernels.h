@@ -56,6 +56,7 @@ struct rh_dev_reads {
 
 // per-round work arrays indexed by active slot a in [0, n_act)
 struct rh_dev_round {
+	uint8_t akey_on, akey_lo, akey_mid;      // anchor x = rev << 63 | rid << 32 | pos with pos < 2^akey_lo, rid < 2^akey_mid (0 = unknown)
 	const uint32_t *act;             // read ids active this round
 	uint32_t n_act; uint32_t chunk;
 	float *zbuf, *t1buf, *t2buf; uint32_t *n_norm;   // n_act rows of (RH_CHUNK_MAX + 64): normalised signal, both t-statistics
@@ -82,6 +83,9 @@ struct rh_sort_job {
 	uint32_t n_seg; const uint8_t *skip; const uint64_t *off; const uint32_t *cnt;   // segment a = [off[a], off[a] + (cnt ? cnt[a] : off[a+1]-off[a]))
 	const rh_mm128_t *src; rh_mm128_t *dst; uint8_t *need_exact;
 	unsigned char *scratch; uint32_t scratch_stride, scratch_skip;   // 2 KB per oversized segment at scratch + off*stride + skip*len
+	// keys known to be  hi << 63 | mid << 32 | lo  with lo < 2^kc_lo, mid < 2^kc_mid (kc_lo + kc_mid + kc_hi <= 32, kc_on set):
+	// the LDS sorter keeps them as 32-bit words (8 instead of 12 bytes of LDS per record -> more workgroups per CU)
+	uint8_t kc_on, kc_lo, kc_mid, kc_hi;
 };
 void rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n);   // segments with <= min_n records are left alone
 

@@ -35,9 +35,12 @@ extern "C" __attribute__((visibility("default"))) int rh_debug_kprof(unsigned lo
 #define KPROF(slot)
 #endif
 
-template <int CAP>
+// how a 64-bit key  hi << 63 | mid << 32 | lo  is kept in a 32-bit word (all zero: kept whole)
+struct sort_kc { uint32_t lo_bits, mid_bits, hi_bits; };
+
+template <int CAP, class KT>
 struct sort_lds {
-	uint64_t key[CAP];
+	KT key[CAP];                               // by original index; 32-bit words when the job says its keys fit (sort_kc)
 	uint16_t ia[CAP];                          // current arrangement: position -> original index
 	uint16_t xm[CAP];                          // scratch of a pass: gather map (position -> source position) or rank lists
 	uint32_t sbit[CAP / 32 + 3], ebit[CAP / 32 + 3];   // ranges <= 64 awaiting the stable insertion sort: first / last position marks
@@ -54,17 +57,36 @@ struct sort_lds {
 	uint16_t tg_idx[32], tg_pos[32], tg_fin[32], tlist[32];
 	uint8_t tg_rng[32];
 	uint32_t n_tg, n_tl;
+	sort_kc kc;
 };
 #define SORT_TG 32
 
 enum { SORT_FAST = 0, SORT_EXACT_TIED = 1, SORT_EXACT_ALL = 2 };
 
-template <int CAP>
-RH_DEV uint32_t sort_digit(const sort_lds<CAP> &L, uint32_t i, int s) { return (uint32_t)(L.key[L.ia[i]] >> s) & 255u; }
+// digit (byte s / 8 of the ORIGINAL 64-bit key) of a stored key
+template <int CAP, class KT>
+RH_DEV uint32_t sort_key_digit(const sort_lds<CAP, KT> &L, KT k, int s)
+{
+	if (sizeof(KT) == 8) return (uint32_t)((uint64_t)k >> s) & 255u;
+	const uint32_t ck = (uint32_t)k, lo = L.kc.lo_bits, mid = L.kc.mid_bits;
+	if (s < 32) return (uint32_t)(((uint64_t)ck & ((1ull << lo) - 1ull)) >> s) & 255u;
+	if (s < 56) return (((ck >> lo) & ((1u << mid) - 1u)) >> (s - 32)) & 255u;          // (mid < 2^24: byte 7 holds the top bit only)
+	return L.kc.hi_bits ? ((ck >> (lo + mid)) & 1u) << 7 : 0u;
+}
+// a XOR of stored keys, back at the original bit positions
+template <int CAP, class KT>
+RH_DEV uint64_t sort_key_spread(const sort_lds<CAP, KT> &L, uint64_t d)
+{
+	if (sizeof(KT) == 8) return d;
+	const uint32_t lo = L.kc.lo_bits, mid = L.kc.mid_bits;
+	return (d & ((1ull << lo) - 1ull)) | ((d >> lo) & ((1ull << mid) - 1ull)) << 32 | (L.kc.hi_bits ? (d >> (lo + mid)) & 1ull : 0ull) << 63;
+}
+template <int CAP, class KT>
+RH_DEV uint32_t sort_digit(const sort_lds<CAP, KT> &L, uint32_t i, int s) { return sort_key_digit(L, L.key[L.ia[i]], s); }
 
 // ia[j] = ia[xm[j]] for j in [beg, end), through registers
-template <int CAP>
-RH_DEV void sort_apply_gather(sort_lds<CAP> &L, uint32_t beg, uint32_t end)
+template <int CAP, class KT>
+RH_DEV void sort_apply_gather(sort_lds<CAP, KT> &L, uint32_t beg, uint32_t end)
 {
 	constexpr int K = (CAP + NT - 1) / NT;
 	uint16_t v[K];
@@ -87,8 +109,8 @@ RH_DEV void sort_apply_gather(sort_lds<CAP> &L, uint32_t beg, uint32_t end)
 // Two buckets A < B.  Cycle-leader result in closed form: the k-th misplaced element of region A trades places with the
 // k-th misplaced element of region B, except that in B every run of in-place elements between two misplaced ones is
 // shifted right by one slot and the arrival lands in front of the run.
-template <int CAP>
-RH_DEV void sort_two_buckets(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s, uint32_t cA, uint32_t cB, uint32_t startB)
+template <int CAP, class KT>
+RH_DEV void sort_two_buckets(sort_lds<CAP, KT> &L, uint32_t beg, uint32_t end, int s, uint32_t cA, uint32_t cB, uint32_t startB)
 {
 	constexpr int K = (CAP + NT - 1) / NT;
 	const uint32_t tid = threadIdx.x;
@@ -145,8 +167,8 @@ RH_DEV void sort_two_buckets(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s
 // relative position p is byte (p & 3) of VGPR [p >> 8] in lane ((p >> 2) & 63); lane (c & 63) holds the head / tail of
 // dense bucket c in VGPR [c >> 6] (HB = 1, 2 or 4 of them, picked by nbk).  Each step is a couple of v_readlane; the only
 // memory operation is the fire-and-forget LDS store of the gather map xm[dest] = source.
-template <int CAP, int HB>
-RH_DEV void sort_cycle_walk_hb(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s, uint32_t nbk)
+template <int CAP, class KT, int HB>
+RH_DEV void sort_cycle_walk_hb(sort_lds<CAP, KT> &L, uint32_t beg, uint32_t end, int s, uint32_t nbk)
 {
 	constexpr int NR = (CAP + 255) / 256;
 	const uint32_t lane = lane_id(), n = end - beg;
@@ -200,8 +222,8 @@ RH_DEV void sort_cycle_walk_hb(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int
 // equal keys is settled the moment the first of them is popped.  The walk therefore stops after all but one of the
 // range's tied records have been popped (a third of the way for one pair) and writes no gather map at all: everything
 // else in the range already has its final place from the fast pass.  Bit 7 of a cached digit = "tied record".
-template <int CAP, int HB>
-RH_DEV void sort_cycle_walk_early(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s, uint32_t nbk, uint32_t stop)
+template <int CAP, class KT, int HB>
+RH_DEV void sort_cycle_walk_early(sort_lds<CAP, KT> &L, uint32_t beg, uint32_t end, int s, uint32_t nbk, uint32_t stop)
 {
 	constexpr int NR = (CAP + 255) / 256;
 	const uint32_t lane = lane_id(), n = end - beg;
@@ -213,7 +235,7 @@ RH_DEV void sort_cycle_walk_early(sort_lds<CAP> &L, uint32_t beg, uint32_t end, 
 		if (p0 < n) {
 			for (uint32_t b = 0; b < 4; ++b) if (p0 + b < n) {
 				const uint32_t idx = L.ia[beg + p0 + b];
-				w |= ((uint32_t)L.dmap[(uint32_t)(L.key[idx] >> s) & 255u] | ((L.tbit[idx >> 5] >> (idx & 31u)) & 1u) << 7) << (8 * b);
+				w |= ((uint32_t)L.dmap[sort_key_digit(L, L.key[idx], s)] | ((L.tbit[idx >> 5] >> (idx & 31u)) & 1u) << 7) << (8 * b);
 			}
 		}
 		dg[q] = w;
@@ -254,31 +276,31 @@ RH_DEV void sort_cycle_walk_early(sort_lds<CAP> &L, uint32_t beg, uint32_t end, 
 	if (lane == 0) L.n_tl = ntl;
 }
 
-template <int CAP>
-RH_DEV void sort_cycle_walk(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s, uint32_t nbk)
+template <int CAP, class KT>
+RH_DEV void sort_cycle_walk(sort_lds<CAP, KT> &L, uint32_t beg, uint32_t end, int s, uint32_t nbk)
 {
-	if (nbk <= 64) sort_cycle_walk_hb<CAP, 1>(L, beg, end, s, nbk);
-	else if (nbk <= 128) sort_cycle_walk_hb<CAP, 2>(L, beg, end, s, nbk);
-	else sort_cycle_walk_hb<CAP, 4>(L, beg, end, s, nbk);
+	if (nbk <= 64) sort_cycle_walk_hb<CAP, KT, 1>(L, beg, end, s, nbk);
+	else if (nbk <= 128) sort_cycle_walk_hb<CAP, KT, 2>(L, beg, end, s, nbk);
+	else sort_cycle_walk_hb<CAP, KT, 4>(L, beg, end, s, nbk);
 }
 
-template <int CAP>
-RH_DEV void sort_split_range(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int shift, int nxt, int pass)
+template <int CAP, class KT>
+RH_DEV void sort_split_range(sort_lds<CAP, KT> &L, uint32_t beg, uint32_t end, int shift, int nxt, int pass)
 {
 	const uint32_t tid = threadIdx.x;
 	KPROF_DECL;
 	// highest byte on which the range's keys differ (passes above it are identities in the reference); does it hold ties?
-	const uint64_t k0 = L.key[L.ia[beg]];
+	const uint64_t k0 = (uint64_t)L.key[L.ia[beg]];
 	uint64_t diff = 0;
 	bool tied = false;
 	for (uint32_t i = beg + tid; i < end; i += NT) {
 		const uint32_t idx = L.ia[i];
-		diff |= L.key[idx] ^ k0;
+		diff |= (uint64_t)L.key[idx] ^ k0;
 		if (pass == SORT_EXACT_TIED) tied |= (L.tbit[idx >> 5] >> (idx & 31u) & 1u) != 0;
 	}
 	const uint64_t tm = __ballot(tied);
 	if (lane_id() == 0) L.w[wave_id()] = tm != 0;
-	diff = block_or64(diff, L.r64);                           // (barriers inside publish L.w as well)
+	diff = sort_key_spread(L, block_or64(diff, L.r64));       // (barriers inside publish L.w as well)
 	KPROF(1);
 	if (diff == 0) return;                                   // all keys equal: every remaining pass is an identity
 	// redo pass: a range without tied keys already has its (unique) final order from the fast pass -> nothing to do
@@ -304,12 +326,12 @@ RH_DEV void sort_split_range(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s
 		for (uint32_t i = beg + tid; i < end; i += NT) { const uint32_t pos = atomicAdd(&L.head[sort_digit(L, i, s)], 1u); L.xm[pos] = (uint16_t)i; }
 		__syncthreads();
 		KPROF(3);
-		sort_apply_gather<CAP>(L, beg, end);
+		sort_apply_gather<CAP, KT>(L, beg, end);
 		KPROF(4);
 	} else if (nbk == 2) {
 		if (my_cnt != 0) { const uint32_t which = my_start == beg ? 0u : 1u; L.misc[which] = tid; L.misc[2 + which] = my_start; }
 		__syncthreads();
-		sort_two_buckets<CAP>(L, beg, end, s, L.misc[0], L.misc[1], L.misc[3]);
+		sort_two_buckets<CAP, KT>(L, beg, end, s, L.misc[0], L.misc[1], L.misc[3]);
 		KPROF(5);
 	} else {
 		__syncthreads();
@@ -323,7 +345,7 @@ RH_DEV void sort_split_range(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s
 			for (uint32_t i = beg + tid; i < end; i += NT) {
 				const uint32_t idx = L.ia[i];
 				if ((L.tbit[idx >> 5] >> (idx & 31u)) & 1u) {
-					if (s > 0 && L.cnt[(uint32_t)(L.key[idx] >> s) & 255u] > 64u) bad = true;
+					if (s > 0 && L.cnt[sort_key_digit(L, L.key[idx], s)] > 64u) bad = true;
 					for (uint32_t e = 0; e < ntg; ++e) if (L.tg_idx[e] == idx) L.tg_rng[e] = 1;
 					atomicAdd(&L.misc[0], 1u);
 				}
@@ -333,7 +355,7 @@ RH_DEV void sort_split_range(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s
 			__syncthreads();
 			if ((L.w[0] | L.w[1] | L.w[2] | L.w[3]) == 0) {
 				const uint32_t stop = L.misc[0] - 1;
-				if (wave_id() == 0) { if (nbk <= 64) sort_cycle_walk_early<CAP, 1>(L, beg, end, s, nbk, stop); else sort_cycle_walk_early<CAP, 2>(L, beg, end, s, nbk, stop); }
+				if (wave_id() == 0) { if (nbk <= 64) sort_cycle_walk_early<CAP, KT, 1>(L, beg, end, s, nbk, stop); else sort_cycle_walk_early<CAP, KT, 2>(L, beg, end, s, nbk, stop); }
 				__syncthreads();
 				KPROF(6);
 				if (tid < ntg && L.tg_rng[tid]) {	// my place in my group: pop order; the record never popped comes last
@@ -352,10 +374,10 @@ RH_DEV void sort_split_range(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s
 				return;
 			}
 		}
-		if (wave_id() == 0) sort_cycle_walk<CAP>(L, beg, end, s, nbk);
+		if (wave_id() == 0) sort_cycle_walk<CAP, KT>(L, beg, end, s, nbk);
 		__syncthreads();
 		KPROF(6);
-		sort_apply_gather<CAP>(L, beg, end);
+		sort_apply_gather<CAP, KT>(L, beg, end);
 		KPROF(4);
 	}
 	// children: one bucket per thread
@@ -368,8 +390,8 @@ RH_DEV void sort_split_range(sort_lds<CAP> &L, uint32_t beg, uint32_t end, int s
 }
 
 // the whole radix sort of the n keys in L.key, from the input order, into L.ia
-template <int CAP>
-RH_DEV void sort_run(sort_lds<CAP> &L, uint32_t n, int pass)
+template <int CAP, class KT>
+RH_DEV void sort_run(sort_lds<CAP, KT> &L, uint32_t n, int pass)
 {
 	const uint32_t tid = threadIdx.x;
 	KPROF_DECL;
@@ -387,7 +409,7 @@ RH_DEV void sort_run(sort_lds<CAP> &L, uint32_t n, int pass)
 		if (nr == 0) break;
 		for (uint32_t ri = 0; ri < nr; ++ri) {
 			const uint32_t be = L.rng[cur][ri];
-			sort_split_range<CAP>(L, be & 0xFFFFu, be >> 16, (int)L.rsh[cur][ri], cur ^ 1, pass);
+			sort_split_range<CAP, KT>(L, be & 0xFFFFu, be >> 16, (int)L.rsh[cur][ri], cur ^ 1, pass);
 		}
 		__syncthreads();
 		if (tid == 0) L.n_rng[cur] = 0;
@@ -421,7 +443,7 @@ RH_DEV void sort_run(sort_lds<CAP> &L, uint32_t n, int pass)
 		uint32_t b = 0, m = 0;
 		if (q < ns) { b = L.xm[2 * q]; m = L.xm[2 * q + 1]; }
 		bool mine = q < ns && m <= 32;
-		if (mine && ((L.key[L.ia[b]] ^ L.key[L.ia[b + m - 1]]) >> 27) != 0) mine = false;   // cheap look before loading the range
+		if (mine && (((uint64_t)L.key[L.ia[b]] ^ (uint64_t)L.key[L.ia[b + m - 1]]) >> 27) != 0) mine = false;   // cheap look before loading the range
 		if (__ballot(mine) == 0) continue;
 		uint32_t c[32];
 		uint64_t dif = 0, k0 = 0;
@@ -431,7 +453,7 @@ RH_DEV void sort_run(sort_lds<CAP> &L, uint32_t n, int pass)
 			c[j] = 0xFFFFFFFFu;
 			if (mine && (uint32_t)j < m) {
 				const uint32_t idx = L.ia[b + j];
-				const uint64_t k = L.key[idx];
+				const uint64_t k = (uint64_t)L.key[idx];
 				if (j == 0) k0 = k;
 				dif |= k ^ k0;
 				tiedr |= (L.tbit[idx >> 5] >> (idx & 31u)) & 1u;
@@ -479,7 +501,7 @@ RH_DEV void sort_run(sort_lds<CAP> &L, uint32_t n, int pass)
 		const uint32_t b = rh_uniform((uint32_t)L.xm[2 * q]), m = mm, l = lane_id();
 		const uint16_t idx = L.ia[b + (l < m ? l : 0u)];
 		if (pass == SORT_EXACT_TIED && __ballot((L.tbit[idx >> 5] >> (idx & 31u)) & 1u) == 0) continue;   // final since the fast pass
-		const uint64_t k = L.key[idx];
+		const uint64_t k = (uint64_t)L.key[idx];
 		const uint32_t klo = (uint32_t)k, khi = (uint32_t)(k >> 32);
 		uint32_t rank = 0;
 		// the other records' keys come from their lanes' registers (v_readlane with the wave-uniform j), not from LDS
@@ -502,10 +524,15 @@ RH_DEV void sort_run(sort_lds<CAP> &L, uint32_t n, int pass)
 
 // mode 0: fast pass; reads whose sorted keys show ties are redone with the exact permutation on the tied ranges
 // mode 2: exact pass on every range (keys known to be full of ties, e.g. chain scores)
-template <int CAP>
-__global__ __launch_bounds__(NT) void k_sort_block(rh_sort_job jb, uint32_t n_lo, uint32_t n_hi, int mode)
+// workgroups of a class that fit the 160 KB of LDS of a CU (1 KB allocation granules) = wavefronts per SIMD the compiler
+// has to leave registers for (4 wavefronts per workgroup, 4 SIMDs per CU)
+template <int CAP, class KT>
+constexpr int sort_wg_per_cu() { return (int)((160u * 1024u) / ((sizeof(sort_lds<CAP, KT>) + 1023u) / 1024u * 1024u)) < 4 ? (int)((160u * 1024u) / ((sizeof(sort_lds<CAP, KT>) + 1023u) / 1024u * 1024u)) : 4; }
+
+template <int CAP, class KT>
+__global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(rh_sort_job jb, uint32_t n_lo, uint32_t n_hi, int mode)
 {
-	__shared__ sort_lds<CAP> L;
+	__shared__ sort_lds<CAP, KT> L;
 	const uint32_t a = blockIdx.x, tid = threadIdx.x;
 	if (a >= jb.n_seg || (jb.skip && jb.skip[a])) return;
 	const uint64_t base = jb.off[a];
@@ -518,12 +545,18 @@ __global__ __launch_bounds__(NT) void k_sort_block(rh_sort_job jb, uint32_t n_lo
 	if (tid == 0) L.prof = jb.scratch_skip == 0 ? 1u : 0u;      // profile the anchor sort only
 	__syncthreads();
 #endif
-	for (uint32_t i = tid; i < n; i += NT) L.key[i] = src[i].x;
+	const sort_kc kc = { jb.kc_lo, jb.kc_mid, jb.kc_hi };
+	if (tid == 0) L.kc = kc;
+	for (uint32_t i = tid; i < n; i += NT) {
+		const uint64_t x = src[i].x;
+		if (sizeof(KT) == 8) L.key[i] = (KT)x;
+		else L.key[i] = (KT)((x & ((1ull << kc.lo_bits) - 1ull)) | ((x >> 32) & ((1ull << kc.mid_bits) - 1ull)) << kc.lo_bits | (kc.hi_bits ? x >> 63 : 0ull) << (kc.lo_bits + kc.mid_bits));
+	}
 	for (uint32_t i = tid; i < CAP / 32 + 3; i += NT) L.tbit[i] = 0;
 	if (tid == 0) { L.tie = 0; L.n_tg = 0; }
 	__syncthreads();
 	KPROF(10);
-	sort_run<CAP>(L, n, mode == 0 ? SORT_FAST : SORT_EXACT_ALL);
+	sort_run<CAP, KT>(L, n, mode == 0 ? SORT_FAST : SORT_EXACT_ALL);
 #ifdef RH_KPROF
 	kp_t0 = clock64();
 #endif
@@ -532,7 +565,7 @@ __global__ __launch_bounds__(NT) void k_sort_block(rh_sort_job jb, uint32_t n_lo
 	if (mode != 0) return;
 	for (uint32_t i = tid; i < n; i += NT) {
 		const uint32_t idx = L.ia[i];
-		const uint64_t k = L.key[idx];
+		const KT k = L.key[idx];
 		if ((i > 0 && L.key[L.ia[i - 1]] == k) || (i + 1 < n && L.key[L.ia[i + 1]] == k)) {
 			atomicOr(&L.tbit[idx >> 5], 1u << (idx & 31u));
 			L.tie = 1;
@@ -550,7 +583,7 @@ __global__ __launch_bounds__(NT) void k_sort_block(rh_sort_job jb, uint32_t n_lo
 	// Equal keys: their order is the reference's cycle-leader permutation.  Redo the sort from the input order on the ranges
 	// that hold tied keys only; every other record already sits at its final place, and so does each group of equal keys
 	// as a whole - only the records inside the groups are rewritten.
-	sort_run<CAP>(L, n, SORT_EXACT_TIED);
+	sort_run<CAP, KT>(L, n, SORT_EXACT_TIED);
 	for (uint32_t i = tid; i < n; i += NT) { const uint32_t idx = L.ia[i]; if ((L.tbit[idx >> 5] >> (idx & 31u)) & 1u) dst[i] = src[idx]; }
 	if (tid < SORT_TG && tid < L.n_tg && L.tg_fin[tid] != 0xFFFFu) dst[L.tg_fin[tid]] = src[L.tg_idx[tid]];   // settled by pop order
 }
@@ -953,27 +986,48 @@ __global__ void k_sort_big(rh_sort_job jb, uint32_t n_lo)
 #define RH_SORT_CAP4 8192     // ~103 KB: one
 #endif
 
-template <int CAP>
+template <int CAP, class KT>
 static void launch_class(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t lo, uint32_t hi)
 {
-	RH_LAUNCH(k_sort_block<CAP>, jb.n_seg, NT, 0, s, jb, lo, hi, all_exact ? 2 : 0);
+	RH_LAUNCH((k_sort_block<CAP, KT>), jb.n_seg, NT, 0, s, jb, lo, hi, all_exact ? 2 : 0);
 }
+
+// the same classes when the job's keys fit 32-bit words: 8 B of LDS per record
+#ifndef RH_SORT32_CAP1
+#define RH_SORT32_CAP1 4096     // ~38 KB: four workgroups per CU
+#endif
+#ifndef RH_SORT32_CAP2
+#define RH_SORT32_CAP2 5632     // ~51 KB: three
+#endif
+#ifndef RH_SORT32_CAP3
+#define RH_SORT32_CAP3 8192     // ~73 KB: two
+#endif
 
 void rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n)
 {
 	if (!jb.n_seg) return;
-	launch_class<RH_SORT_CAP0>(s, jb, all_exact, min_n, (uint32_t)RH_SORT_CAP0);
-	launch_class<RH_SORT_CAP1>(s, jb, all_exact, (uint32_t)RH_SORT_CAP0, (uint32_t)RH_SORT_CAP1);
-	launch_class<RH_SORT_CAP2>(s, jb, all_exact, (uint32_t)RH_SORT_CAP1, (uint32_t)RH_SORT_CAP2);
-	launch_class<RH_SORT_CAP3>(s, jb, all_exact, (uint32_t)RH_SORT_CAP2, (uint32_t)RH_SORT_CAP3);
-	launch_class<RH_SORT_CAP4>(s, jb, all_exact, (uint32_t)RH_SORT_CAP3, (uint32_t)RH_SORT_CAP4);
-	RH_LAUNCH(k_sort_gmem, jb.n_seg, NT, 0, s, jb, (uint32_t)RH_SORT_CAP4, (uint32_t)RH_SORT_GCAP, all_exact ? 2 : 0);
+	uint32_t top;
+	if (jb.kc_on && (uint32_t)jb.kc_lo + jb.kc_mid + jb.kc_hi <= 32u && jb.kc_mid <= 24u) {
+		launch_class<RH_SORT_CAP0, uint32_t>(s, jb, all_exact, min_n, (uint32_t)RH_SORT_CAP0);
+		launch_class<RH_SORT32_CAP1, uint32_t>(s, jb, all_exact, (uint32_t)RH_SORT_CAP0, (uint32_t)RH_SORT32_CAP1);
+		launch_class<RH_SORT32_CAP2, uint32_t>(s, jb, all_exact, (uint32_t)RH_SORT32_CAP1, (uint32_t)RH_SORT32_CAP2);
+		launch_class<RH_SORT32_CAP3, uint32_t>(s, jb, all_exact, (uint32_t)RH_SORT32_CAP2, (uint32_t)RH_SORT32_CAP3);
+		top = (uint32_t)RH_SORT32_CAP3;
+	} else {
+		launch_class<RH_SORT_CAP0, uint64_t>(s, jb, all_exact, min_n, (uint32_t)RH_SORT_CAP0);
+		launch_class<RH_SORT_CAP1, uint64_t>(s, jb, all_exact, (uint32_t)RH_SORT_CAP0, (uint32_t)RH_SORT_CAP1);
+		launch_class<RH_SORT_CAP2, uint64_t>(s, jb, all_exact, (uint32_t)RH_SORT_CAP1, (uint32_t)RH_SORT_CAP2);
+		launch_class<RH_SORT_CAP3, uint64_t>(s, jb, all_exact, (uint32_t)RH_SORT_CAP2, (uint32_t)RH_SORT_CAP3);
+		launch_class<RH_SORT_CAP4, uint64_t>(s, jb, all_exact, (uint32_t)RH_SORT_CAP3, (uint32_t)RH_SORT_CAP4);
+		top = (uint32_t)RH_SORT_CAP4;
+	}
+	RH_LAUNCH(k_sort_gmem, jb.n_seg, NT, 0, s, jb, top, (uint32_t)RH_SORT_GCAP, all_exact ? 2 : 0);
 	RH_LAUNCH(k_sort_big, (jb.n_seg + 63) / 64, 64, 0, s, jb, (uint32_t)RH_SORT_GCAP);
 }
 
 // anchor sort of a chunk round: unsorted expand output -> reference order
 void rhk_sort(hipStream_t s, const rh_dev_round &r)
 {
-	rh_sort_job jb = { r.n_act, r.skip, r.a_off, nullptr, r.raw, r.anc, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 0 };
+	rh_sort_job jb = { r.n_act, r.skip, r.a_off, nullptr, r.raw, r.anc, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 0, r.akey_on, r.akey_lo, r.akey_mid, 1 };
 	rhk_sort_job(s, jb, false, 0u);
 }
