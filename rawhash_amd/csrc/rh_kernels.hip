@@ -310,10 +310,15 @@ __global__ __launch_bounds__(64) void k_events_peaks(rh_dev_opt o, rh_dev_round 
 	const uint32_t rows = rr.n_act - a0 < PK_CHUNKS ? rr.n_act - a0 : PK_CHUNKS;
 	for (uint32_t i0 = 0; i0 <= nmax; i0 += PK_TILE) {               // (<=: one more iteration for the lagging lanes)
 		__syncthreads();
-		for (uint32_t row = 0; row < rows; ++row) {
-			const size_t g = (size_t)(a0 + row) * EV_ROW + i0 + lane;     // lane = step inside the tile
-			s_t[0][lane * (PK_CHUNKS + 1) + row] = rr.t1buf[g];
-			s_t[1][lane * (PK_CHUNKS + 1) + row] = rr.t2buf[g];
+		{	// all the row loads of the tile are issued before the first LDS store waits for one (lane = step inside the tile)
+			float r1[PK_CHUNKS], r2[PK_CHUNKS];
+#pragma unroll
+			for (uint32_t row = 0; row < PK_CHUNKS; ++row) {
+				const size_t g = (size_t)(a0 + (row < rows ? row : 0u)) * EV_ROW + i0 + lane;
+				r1[row] = rr.t1buf[g]; r2[row] = rr.t2buf[g];
+			}
+#pragma unroll
+			for (uint32_t row = 0; row < PK_CHUNKS; ++row) { s_t[0][lane * (PK_CHUNKS + 1) + row] = r1[row]; s_t[1][lane * (PK_CHUNKS + 1) + row] = r2[row]; }
 		}
 		__syncthreads();
 		const uint32_t tend = i0 + PK_TILE < nmax + 1 ? i0 + PK_TILE : nmax + 1;
@@ -323,21 +328,28 @@ __global__ __launch_bounds__(64) void k_events_peaks(rh_dev_opt o, rh_dev_round 
 			const bool act = k == 0 ? t < n : (t >= 1 && t <= n);
 			const float cur = k == 0 ? cur_t : held;
 			held = cur_t;
-			uint32_t ev_out = 0;
-			int32_t emit = -1;
-			if (act) {
-				if (ev_in >> 31) { masked_to = ev_in & 0x7FFFFFFFu; pos = -1; val = FLT_MAX; valid = 0; }
-				if (!(masked_to >= i)) {
-					if (pos == -1) {
-						if (cur < val) val = cur;
-						else if (cur - val > ph) { val = cur; pos = (int32_t)i; }
-					} else {
-						if (cur > val) { val = cur; pos = (int32_t)i; }
-						if (k == 0 && val > thr) ev_out = 1u << 31 | ((uint32_t)pos + win);
-						if (val - cur > ph && val > thr) valid = 1;
-						if (valid && (i - (uint32_t)pos) > win / 2) { emit = pos; pos = -1; val = cur; valid = 0; }
-					}
-				}
+			// one step of the detector (revent.c:91-150), written with selects: a dozen divergent branch regions per step cost
+			// more than evaluating both states
+			if (act && (ev_in >> 31)) { masked_to = ev_in & 0x7FFFFFFFu; pos = -1; val = FLT_MAX; valid = 0; }
+			const bool go = act && !(masked_to >= i);
+			const bool searching = pos == -1;
+			// no peak open: follow the minimum; a rise of more than peak_height above it opens a peak
+			const bool a_rise = !(cur < val) && (cur - val > ph);
+			const float a_val = (cur < val || a_rise) ? cur : val;
+			const int32_t a_pos = a_rise ? (int32_t)i : -1;
+			// peak open: raise it; strong enough -> valid (and, short detector, mask the long one); past the window -> emit
+			const bool b_up = cur > val;
+			const float b_val = b_up ? cur : val;
+			const int32_t b_pos = b_up ? (int32_t)i : pos;
+			const bool b_strong = b_val > thr;
+			const int32_t b_valid = (valid != 0 || (b_val - cur > ph && b_strong)) ? 1 : 0;
+			const bool b_emit = b_valid != 0 && (i - (uint32_t)b_pos) > win / 2;
+			const uint32_t ev_out = (go && !searching && k == 0 && b_strong) ? (1u << 31 | ((uint32_t)b_pos + win)) : 0u;
+			const int32_t emit = (go && !searching && b_emit) ? b_pos : -1;
+			if (go) {
+				val = searching ? a_val : (b_emit ? cur : b_val);
+				pos = searching ? a_pos : (b_emit ? -1 : b_pos);
+				valid = searching ? valid : (b_emit ? 0 : b_valid);
 			}
 			// partner exchange: the long lane takes the short lane's event (for the step it processes next); both learn
 			// whether the other emitted.  Order inside the iteration as in the reference: (step t-1, long) then (step t, short).
