@@ -817,6 +817,7 @@ __global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads r
 				// first overlapping primary (list order) that masks region i
 #pragma unroll
 				for (int p = 0; p < P; ++p) {
+					if (m[p] == 0) continue;                                 // (wave-uniform: no primary of this slot overlaps)
 					bool hit = false;
 					if (ov[p]) {
 						const int32_t sj = pqs[p], ej = pqe[p];
