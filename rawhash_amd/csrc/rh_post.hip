@@ -723,7 +723,7 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 // by interval tests.  Here primary j lives in the VGPRs of lane (j & 63), slot (j >> 6); the chains are streamed through
 // registers 64 at a time and broadcast with v_readlane; overlap / mask tests are one ballot; the parent's sub-score and
 // n_sub update is a masked register write.  No LDS, no barrier.  Reads with more primaries than fit fall back to
-// k_regions_wave.  Default selection only (pri_ratio > 0, best_n == 0: secondaries dropped).
+// k_regions_wave.  Instantiated for one slot (half the vector work per chain) and for all of them.  Default selection only (pri_ratio > 0, best_n == 0: secondaries dropped).
 #ifndef RGR_SLOTS
 #define RGR_SLOTS 2
 #endif
@@ -731,13 +731,15 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 #define RGR_PRIM_CAP (64 * RGR_SLOTS)
 #endif
 
-__global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, const float *logf_tab, uint32_t n_lo)
+template <int P>
+__global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, const float *logf_tab, uint32_t n_lo, int only_flagged)
 {
-	constexpr int P = RGR_SLOTS;
+	constexpr uint32_t PRIM_CAP = 64u * P < (uint32_t)RGR_PRIM_CAP ? 64u * P : (uint32_t)RGR_PRIM_CAP;
 	const uint32_t a = blockIdx.x, lane = threadIdx.x;
 	if (a >= rr.n_act || rr.skip[a]) return;
 	const int32_t n_u = (int32_t)rr.n_u[a];
 	if (n_u <= (int32_t)n_lo) return;
+	if (only_flagged && !rr.need_exact[a]) return;                   // settled by the narrower instance
 	const uint32_t r = rr.act[a];
 	const uint64_t base = rr.a_off[a];
 	const rh_chain_head *heads = (const rh_chain_head*)(rr.ws + base * RH_WS_PER_ANCHOR);
@@ -836,7 +838,7 @@ __global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads r
 				for (int p = 0; p < P; ++p)
 					if ((uint32_t)sel == (uint32_t)p * 64u + lane) { if (psub[p] < sci) psub[p] = sci; if (cni >= pcn[p]) ++pns[p]; }
 			} else {
-				if (kk >= (uint32_t)RGR_PRIM_CAP) { overflow = true; break; }
+				if (kk >= PRIM_CAP) { overflow = true; break; }
 #pragma unroll
 				for (int p = 0; p < P; ++p)
 					if (kk == (uint32_t)p * 64u + lane) { pqs[p] = si; pqe[p] = ei; psc[p] = sci; pcn[p] = cni; psub[p] = 0; pns[p] = 0; }
@@ -893,6 +895,7 @@ __global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads r
 		best.qs = (int32_t)h.y0; best.qe = h.y1 + 1; best.rs = (int32_t)h.x0; best.re = h.x1 + 1;
 		best.rid = (int32_t)(h.x0 << 1 >> 33); best.rev = (uint32_t)(h.x0 >> 63);
 		regions_commit(o, rd, rr, a, r, n_regs, &best, stop);
+		rr.need_exact[a] = 0;
 	}
 }
 
@@ -935,7 +938,9 @@ void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, con
 	// need_exact[] doubles as "this read still needs the serial region kernel"
 	RH_HIP_VOID(hipMemsetAsync(r.need_exact, wave_ok ? 0 : 1, r.n_act, s));
 	if (wave_ok) {
-		RH_LAUNCH(k_regions_reg, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL);
+		// one register slot (<= 64 primaries: nearly every read) first; the reads that overflow it again with all slots
+		RH_LAUNCH(k_regions_reg<1>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL, 0);
+		if (RGR_SLOTS > 1) RH_LAUNCH(k_regions_reg<RGR_SLOTS>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL, 1);
 		RH_LAUNCH(k_regions_wave<RGW_CAP0>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL);
 		RH_LAUNCH(k_regions_wave<RGW_CAP>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RGW_CAP0);
 	}
