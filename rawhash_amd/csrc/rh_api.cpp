@@ -184,7 +184,7 @@ int stage_round(rh_ctx *c, uint32_t n_act, rh_dev_round *rr)
 	rr->peaks = c->peaks.as<uint16_t>(); rr->n_peaks = c->n_peaks.as<uint32_t>();
 	if (c->ev.ensure(cap * 4) || c->n_ev.ensure(n * 4) || c->skip.ensure(n) || c->sx.ensure(cap * 8) || c->sy.ensure(cap * 8) || c->n_seed.ensure(n * 4) ||
 	    c->m_val.ensure(cap * 8) || c->m_n.ensure(cap * 4) || c->m_meta.ensure(cap * 4) || c->m_pref.ensure((size_t)n * (RH_EV_CAP + 1) * 4) ||
-	    c->n_match.ensure(n * 4) || c->n_new.ensure(n * 4) || c->rep_len.ensure(n * 4) || c->a_off.ensure((n + 1) * 8) || c->n_u.ensure(n * 4) || c->n_v.ensure(n * 4) ||
+	    c->n_match.ensure(n * 4) || c->n_new.ensure(n * 4) || c->rep_len.ensure(n * 4) || c->a_off.ensure((n + 2) * 8) || c->n_u.ensure(n * 4) || c->n_v.ensure(n * 4) ||
 	    c->counters.ensure(16 * 8) || c->need_exact.ensure(n) || c->need_exact2.ensure(n) || c->n_z.ensure(n * 4)) return -1;
 	rr->n_z = c->n_z.as<uint32_t>();
 	rr->n_act = n_act;
@@ -439,9 +439,10 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 		{ StageTimer t(c, ST_SKETCH); rhk_sketch(s, o, c->dix, rd, rr); }
 		{ StageTimer t(c, ST_PROBE); rhk_probe(s, o, c->dix, rd, rr); }
 		uint64_t total = 0;
-		{ StageTimer t(c, ST_SCAN); rhk_scan_anchors(s, rd, rr); RH_HIP(hipMemcpyAsync(c->pin + 1, rr.a_off + n_act, 8, hipMemcpyDeviceToHost, s)); }
+		{ StageTimer t(c, ST_SCAN); rhk_scan_anchors(s, rd, rr); RH_HIP(hipMemcpyAsync(c->pin + 1, rr.a_off + n_act, 16, hipMemcpyDeviceToHost, s)); }
 		RH_HIP(hipStreamSynchronize(s));
 		total = c->pin[1];
+		rr.max_anchors = (uint32_t)c->pin[2];
 		if (stage_anchors(c, total, which, &rr)) return -1;
 		{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rr); }
 		{ StageTimer t(c, ST_SORT); rhk_sort(s, rr); }

@@ -56,6 +56,7 @@ struct rh_dev_reads {
 
 // per-round work arrays indexed by active slot a in [0, n_act)
 struct rh_dev_round {
+	uint32_t max_anchors;                    // anchors of the largest active read this round (0 = unknown)
 	uint8_t akey_on, akey_lo, akey_mid;      // anchor x = rev << 63 | rid << 32 | pos with pos < 2^akey_lo, rid < 2^akey_mid (0 = unknown)
 	const uint32_t *act;             // read ids active this round
 	uint32_t n_act; uint32_t chunk;
@@ -86,6 +87,7 @@ struct rh_sort_job {
 	// keys known to be  hi << 63 | mid << 32 | lo  with lo < 2^kc_lo, mid < 2^kc_mid (kc_lo + kc_mid + kc_hi <= 32, kc_on set):
 	// the LDS sorter keeps them as 32-bit words (8 instead of 12 bytes of LDS per record -> more workgroups per CU)
 	uint8_t kc_on, kc_lo, kc_mid, kc_hi;
+	uint32_t n_max;                          // no segment is longer than this (0 = unknown): size classes above it are not launched
 };
 void rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n);   // segments with <= min_n records are left alone
 

@@ -587,18 +587,27 @@ __global__ __launch_bounds__(NT) void k_probe(rh_dev_opt o, rh_dev_index ix, rh_
 }
 
 // ------------------------------------------------------------------------------------------------ k_scan_anchors
-// a_off = exclusive scan of (new hits + carried anchors) over the active reads; a_off[n_act] = total.  One block.
+// a_off = exclusive scan of (new hits + carried anchors) over the active reads; a_off[n_act] = total, [n_act + 1] = the
+// largest count.  One block.
 __global__ __launch_bounds__(1024) void k_scan_anchors(rh_dev_reads rd, rh_dev_round rr)
 {
 	__shared__ uint64_t s_part[1024];
+	__shared__ uint32_t s_max[1024];
 	const uint32_t tid = threadIdx.x, nt = blockDim.x, n = rr.n_act;
 	const uint32_t per = (n + nt - 1) / nt;
 	const uint32_t b = tid * per, e = b + per < n ? b + per : n;
 	uint64_t s = 0;
-	for (uint32_t i = b; i < e; ++i) s += (uint64_t)rr.n_new[i] + rd.n_prev[rr.act[i]];
-	s_part[tid] = s;
+	uint32_t mx = 0;
+	for (uint32_t i = b; i < e; ++i) { const uint32_t c = rr.n_new[i] + rd.n_prev[rr.act[i]]; s += c; mx = c > mx ? c : mx; }
+	s_part[tid] = s; s_max[tid] = mx;
 	__syncthreads();
-	if (tid == 0) { uint64_t run = 0; for (uint32_t i = 0; i < nt; ++i) { const uint64_t v = s_part[i]; s_part[i] = run; run += v; } rr.a_off[n] = run; atomicAdd((unsigned long long*)&rr.counters[3], (unsigned long long)run); }
+	if (tid == 0) {
+		uint64_t run = 0;
+		uint32_t m = 0;
+		for (uint32_t i = 0; i < nt; ++i) { const uint64_t v = s_part[i]; s_part[i] = run; run += v; m = s_max[i] > m ? s_max[i] : m; }
+		rr.a_off[n] = run; rr.a_off[n + 1] = m;                     // total, and the largest read (lets the host skip empty size classes)
+		atomicAdd((unsigned long long*)&rr.counters[3], (unsigned long long)run);
+	}
 	__syncthreads();
 	uint64_t run = s_part[tid];
 	for (uint32_t i = b; i < e; ++i) { rr.a_off[i] = run; run += (uint64_t)rr.n_new[i] + rd.n_prev[rr.act[i]]; }

@@ -905,7 +905,7 @@ void rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 	if (!r.n_act) return;
 	RH_LAUNCH(k_zbuild, r.n_act, 64, 0, s, o, r);
 	// candidates (score, anchor index) -> reference order; scores are full of ties: exact permutation for every read
-	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_z, r.raw, r.zs, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 64, (uint8_t)(o.min_sc >= 0), 32, 0, 0 };   // keys = scores >= min_sc: non-negative int32
+	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_z, r.raw, r.zs, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 64, (uint8_t)(o.min_sc >= 0), 32, 0, 0, r.max_anchors };   // keys = scores >= min_sc: non-negative int32
 	rhk_sort_job(s, jb, true, 0u);
 }
 
@@ -915,7 +915,7 @@ void rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, c
 	RH_LAUNCH(k_backtrack_spec, r.n_act, 64, 0, s, o, rd, r);
 	// compact_a: chains gathered, put into the reference's order of their first anchor, written back
 	RH_LAUNCH(k_chain_gather, r.n_act, NT, 0, s, r);
-	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, r.akey_on, r.akey_lo, r.akey_mid, 1 };   // keys = first anchors
+	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };   // keys = first anchors
 	rhk_sort_job(s, jb, false, 0u);
 	RH_LAUNCH(k_chain_reorder, r.n_act, NT, 0, s, rd, r);
 }
@@ -927,7 +927,7 @@ void rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd
 {
 	if (!r.n_act || !regions_wave_ok(o)) return;
 	RH_LAUNCH(k_regions_prep, r.n_act, 64, 0, s, o, rd, r);
-	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, 0, 0, 0, 0 };   // keys = hashed: full 64 bits
+	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, 0, 0, 0, 0, r.max_anchors };   // keys = hashed: full 64 bits
 	rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL);
 }
 

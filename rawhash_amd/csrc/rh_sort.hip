@@ -989,6 +989,7 @@ __global__ void k_sort_big(rh_sort_job jb, uint32_t n_lo)
 template <int CAP, class KT>
 static void launch_class(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t lo, uint32_t hi)
 {
+	if (jb.n_max && lo >= jb.n_max) return;                       // no segment reaches this class
 	RH_LAUNCH((k_sort_block<CAP, KT>), jb.n_seg, NT, 0, s, jb, lo, hi, all_exact ? 2 : 0);
 }
 
@@ -1021,13 +1022,13 @@ void rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t
 		launch_class<RH_SORT_CAP4, uint64_t>(s, jb, all_exact, (uint32_t)RH_SORT_CAP3, (uint32_t)RH_SORT_CAP4);
 		top = (uint32_t)RH_SORT_CAP4;
 	}
-	RH_LAUNCH(k_sort_gmem, jb.n_seg, NT, 0, s, jb, top, (uint32_t)RH_SORT_GCAP, all_exact ? 2 : 0);
-	RH_LAUNCH(k_sort_big, (jb.n_seg + 63) / 64, 64, 0, s, jb, (uint32_t)RH_SORT_GCAP);
+	if (!jb.n_max || top < jb.n_max) RH_LAUNCH(k_sort_gmem, jb.n_seg, NT, 0, s, jb, top, (uint32_t)RH_SORT_GCAP, all_exact ? 2 : 0);
+	if (!jb.n_max || (uint32_t)RH_SORT_GCAP < jb.n_max) RH_LAUNCH(k_sort_big, (jb.n_seg + 63) / 64, 64, 0, s, jb, (uint32_t)RH_SORT_GCAP);
 }
 
 // anchor sort of a chunk round: unsorted expand output -> reference order
 void rhk_sort(hipStream_t s, const rh_dev_round &r)
 {
-	rh_sort_job jb = { r.n_act, r.skip, r.a_off, nullptr, r.raw, r.anc, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 0, r.akey_on, r.akey_lo, r.akey_mid, 1 };
+	rh_sort_job jb = { r.n_act, r.skip, r.a_off, nullptr, r.raw, r.anc, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 0, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };
 	rhk_sort_job(s, jb, false, 0u);
 }
