@@ -92,7 +92,10 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 		bool pending = k >= 0, accepted = false;
 		int32_t r_cnt = 0, r_sc = 0;
 		int32_t pn1 = 0, pn2 = 0, pn3 = 0;                             // the first anchors of the path after i0 (most chains are this short)
-		while (__ballot(pending)) {
+		for (;;) {
+			const uint64_t pend = __ballot(pending);
+			if (!pend) break;
+			const bool solo = (pend & (pend - 1)) == 0;               // a single pending lane has nobody to collide with
 			++epoch;
 			const uint32_t stamp = epoch << 6 | (63u - lane);
 			bool walked = false;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 				walked = true;
 				int2 rec = fp[i0];
 				zx = rec.x;
-				atomicMax(&claim[i0], stamp);
+				if (!solo) atomicMax(&claim[i0], stamp);
 				for (;;) {	// mg_chain_bk_end (lchain.c:47-75): back until a used anchor, the start, or a score drop > max_drop
 					const int32_t i = rec.y;
 					int32_t sdrop = zx;
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 					if (i >= 0) {
 						rec = fp[i]; ti = t[i]; sdrop = zx - rec.x;
 						if (ti == 0) {	// (a used anchor ends every walk that reaches it: nobody's to take, nothing to stamp)
-							atomicMax(&claim[i], stamp);
+							if (!solo) atomicMax(&claim[i], stamp);
 							++path;
 							if (path == 1) pn1 = i; else if (path == 2) pn2 = i; else if (path == 3) pn3 = i;
 						}
@@ -122,14 +125,16 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 			RH_WG_FENCE();
 			__syncthreads();                                          // every stamp of the round is in
 			bool conflict = false;
-			if (walked) {	// read at L2, where the stamps were combined; the cached anchors' reads are independent of each other
-				const uint32_t c0 = atomicMax(&claim[i0], stamp);
-				const uint32_t c1 = path >= 1 ? atomicMax(&claim[pn1], stamp) : stamp;
-				const uint32_t c2 = path >= 2 ? atomicMax(&claim[pn2], stamp) : stamp;
-				const uint32_t c3 = path >= 3 ? atomicMax(&claim[pn3], stamp) : stamp;
+			if (walked && !solo) {	// read at L2, where the stamps were combined; the cached anchors' reads are independent of each other
+				#define BK_CLAIM(i) __hip_atomic_load(&claim[(i)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)   /* an L2 read, no read-modify-write */
+				const uint32_t c0 = BK_CLAIM(i0);
+				const uint32_t c1 = path >= 1 ? BK_CLAIM(pn1) : stamp;
+				const uint32_t c2 = path >= 2 ? BK_CLAIM(pn2) : stamp;
+				const uint32_t c3 = path >= 3 ? BK_CLAIM(pn3) : stamp;
 				conflict = c0 != stamp || c1 != stamp || c2 != stamp || c3 != stamp;
 				int32_t x = pn3;
-				for (int32_t j = 3; j < path && !conflict; ++j) { x = fp[x].y; if (atomicMax(&claim[x], stamp) != stamp) conflict = true; }
+				for (int32_t j = 3; j < path && !conflict; ++j) { x = fp[x].y; if (BK_CLAIM(x) != stamp) conflict = true; }
+				#undef BK_CLAIM
 			}
 			if (pending && !conflict) {
 				if (walked) {	// anchors i0 .. (exclusive) max_i form the chain; the marks stay even if it is rejected, as in the reference
