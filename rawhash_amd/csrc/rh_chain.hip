@@ -68,14 +68,12 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 		const uint64_t x = xB, y = yB;
 		xB = xC; yB = yC;
 		if (ii + 128 < n) { xC = an[ii + 128].x; yC = an[ii + 128].y; } else { xC = 0; yC = 0; }
-		uint64_t xprev = __shfl_up(x, 1);
-		if (lane == 0) xprev = x_before;
+		const uint64_t xprev = (uint64_t)rh_wave_shr1((uint32_t)(x >> 32), (uint32_t)(x_before >> 32)) << 32 | rh_wave_shr1((uint32_t)x, (uint32_t)x_before);
 		const bool start = inb && (ii == 0 || (x >> 32) != (xprev >> 32) || x > xprev + D64);
 		const uint64_t smask = __ballot(start);
 		const uint64_t bmask = __ballot(start || !inb);               // cluster boundaries, the end of the array included
-		const uint64_t x_last = __shfl(x, 63);
-		uint64_t xprevB = __shfl_up(xB, 1);
-		if (lane == 0) xprevB = x_last;
+		const uint64_t x_last = (uint64_t)rh_readlane((uint32_t)(x >> 32), 63u) << 32 | rh_readlane((uint32_t)x, 63u);
+		const uint64_t xprevB = (uint64_t)rh_wave_shr1((uint32_t)(xB >> 32), (uint32_t)(x_last >> 32)) << 32 | rh_wave_shr1((uint32_t)xB, (uint32_t)x_last);
 		const uint64_t bmaskB = __ballot(ii + 64 >= n || (xB >> 32) != (xprevB >> 32) || xB > xprevB + D64);   // same for the next tile
 		const bool nstart = lane < 63 ? ((bmask >> (lane + 1)) & 1ull) != 0 : (bmaskB & 1ull) != 0;
 		const bool single = start && nstart;

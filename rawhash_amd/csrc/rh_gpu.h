@@ -35,7 +35,10 @@ __device__ __forceinline__ uint32_t rh_uniform(uint32_t v) { return (uint32_t)__
 // value of lane (l & ~1) / (l | 1) of each lane pair (DPP quad permutes: VALU speed, no LDS)
 __device__ __forceinline__ int32_t rh_quad_perm_0022(int32_t v) { return __builtin_amdgcn_mov_dpp(v, 0xA0, 0xF, 0xF, true); }
 __device__ __forceinline__ int32_t rh_quad_perm_1133(int32_t v) { return __builtin_amdgcn_mov_dpp(v, 0xF5, 0xF, 0xF, true); }
+// value of the lane below (lane 0 keeps `first`): a DPP whole-wave shift, VALU speed (a shuffle goes through the LDS crossbar)
+__device__ __forceinline__ uint32_t rh_wave_shr1(uint32_t v, uint32_t first) { return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xF, 0xF, false); }
 #else
+__device__ uint32_t rh_wave_shr1(uint32_t v, uint32_t first);
 __device__ int32_t rh_quad_perm_0022(int32_t v);
 __device__ int32_t rh_quad_perm_1133(int32_t v);
 __device__ uint32_t rh_readlane(uint32_t v, uint32_t l);

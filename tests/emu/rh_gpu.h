@@ -58,6 +58,7 @@ static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if 
 static inline unsigned rh_readlane(unsigned v, unsigned l) { return (unsigned)emu_shfl_bits(v, 5, l); }
 static inline unsigned rh_writelane(unsigned v, unsigned val, unsigned l) { return (threadIdx.x & 63u) == l ? val : v; }
 static inline unsigned rh_uniform(unsigned v) { return v; }
+static inline unsigned rh_wave_shr1(unsigned v, unsigned first) { const unsigned up = (unsigned)emu_shfl_bits(v, 3, 1u); return (threadIdx.x & 63u) == 0 ? first : up; }
 static inline int rh_quad_perm_0022(int v) { return (int)emu_shfl_bits((unsigned)v, 5, (threadIdx.x & 63u) & ~1u); }
 static inline int rh_quad_perm_1133(int v) { return (int)emu_shfl_bits((unsigned)v, 5, (threadIdx.x & 63u) | 1u); }
 #define RH_WAVE_SYNC() ((void)emu_ballot(1))
