@@ -117,9 +117,11 @@ RH_DEV float tstat_at(const float *ps, const float *pss, uint32_t n, uint32_t w,
 	return fabsf(dm) / sqrtf(var);
 }
 
-// Event detection runs as three launches so that every lane is busy in each of them:
-//   k_events_norm   (one block per read)      pA filter, fp64 statistics, z-score + compaction, fp32 prefix sums, both
-//                                             t-statistics -> z, t1, t2 rows in HBM
+// Event detection runs as four launches so that every lane is busy in each of them:
+//   k_events_norm   (one block per read)      pA filter, fp64 statistics, z-score + compaction -> z rows in HBM
+//   k_events_tstat  (one LANE per read for the order-sensitive fp32 prefix sums, 64 chunks in lock step; the whole block
+//                    for the t-statistics of the tile those sums just covered)  -> t1, t2 rows in HBM
+//                   (windows wider than TS_WMAX: k_events_norm<true> does both in the one-block-per-read layout)
 //   k_events_peaks  (one LANE per read)       the two coupled peak detectors, a 4000-step serial state machine per chunk:
 //                                             64 chunks advance in lock step, their t-stat rows staged through LDS tiles
 //   k_events_means  (one block per read)      per-segment sort + IQR-fenced mean -> events
@@ -157,9 +159,10 @@ RH_DEV void serial_prefix(const float *z, float *dst, uint32_t n)
 	for (; i < n; ++i) { const float v = z[i]; acc = acc + (SQ ? v * v : v); dst[i + 1] = acc; }
 }
 
+template <bool FULL>
 __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
 {
-	__shared__ __attribute__((aligned(16))) float s_z[RH_CHUNK_MAX];
+	__shared__ __attribute__((aligned(16))) float s_z[FULL ? RH_CHUNK_MAX : 4];
 	__shared__ __attribute__((aligned(16))) float s_a[RH_CHUNK_MAX + 4];      // pA staging -> prefix sums (at +3)
 	__shared__ __attribute__((aligned(16))) float s_b[RH_CHUNK_MAX + 4];      // prefix sums of squares (at +3)
 	__shared__ uint32_t s_w[NT / 64];
@@ -232,7 +235,9 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 	__syncthreads();
 	const double mean = s_stat[0], sd = s_stat[1];
 
-	// 2. z-score, drop |z| >= 3, compact: same scheme; the z values of pass 1 wait in s_b for their slots
+	// 2. z-score, drop |z| >= 3, compact: same scheme; the z values of pass 1 wait in s_b for their slots (which are
+	//    in the HBM row directly when the prefix sums are another launch's business)
+	float *zrow = rr.zbuf + (size_t)a * EV_ROW;
 	uint32_t n;
 	{
 		const uint32_t per = ((s_len + (NT / 64) * 256u - 1) / ((NT / 64) * 256u)) * 256u;
@@ -259,11 +264,12 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 				bool keep = false; float v = 0.0f;
 				if (i < end) { v = s_b[i]; keep = v < 3.0f && v > -3.0f; }
 				const uint64_t B = __ballot(keep);
-				if (keep) s_z[run + lanes_below(B)] = v;
+				if (keep) { if (FULL) s_z[run + lanes_below(B)] = v; else zrow[run + lanes_below(B)] = v; }
 				run += (uint32_t)__popcll(B);
 			}
 		}
 	}
+	if (!FULL) { if (tid == 0) rr.n_norm[a] = n; return; }
 	__syncthreads();
 	if (tid == 0) rr.n_norm[a] = n;
 	if (n == 0) return;
@@ -277,11 +283,149 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 	__syncthreads();
 
 	// 4. t-statistics of both windows and the normalised signal go to HBM rows (coalesced)
-	float *zrow = rr.zbuf + (size_t)a * EV_ROW, *t1row = rr.t1buf + (size_t)a * EV_ROW, *t2row = rr.t2buf + (size_t)a * EV_ROW;
+	float *t1row = rr.t1buf + (size_t)a * EV_ROW, *t2row = rr.t2buf + (size_t)a * EV_ROW;
 	for (uint32_t i = tid; i < n; i += NT) {
 		zrow[i] = s_z[i];
 		t1row[i] = tstat_at(pa, pb, n, o.w1, i);
 		t2row[i] = tstat_at(pa, pb, n, o.w2, i);
+	}
+}
+
+// The fp32 prefix sums of z and z*z must be accumulated strictly left to right (comp_prefix_prefixsq, revent.c:23-36), a
+// chain of 4000 dependent adds per chunk.  Here each lane of wave 0 owns the chain of one chunk, 64 chunks per block, and
+// the chunks advance together in tiles of TS_TILE samples: the block loads the tile of z transposed into LDS (row stride
+// 65: lane-per-chunk and lane-per-sample accesses are both conflict free), wave 0 extends the 64 chains, and then all
+// four waves turn the new prefix values into t-statistics, lanes across positions, half a wave per window.  A window of
+// width w can be evaluated TS_TILE samples at a time lagging w behind the chains, so the prefix sums only ever live in
+// a ring of TS_RING entries per chunk and never touch HBM.
+#define TS_TILE 32
+#define TS_RING 64
+#define TS_WMAX 15                              // TS_TILE + 2 * w + 1 <= TS_RING
+#define TS_STRIDE 65
+// x / fw for the small integer window widths: product with the rounded reciprocal plus one exact-remainder correction
+// (Markstein); compared with the correctly rounded quotient over all 2^32 inputs for every w in 2..TS_WMAX it differs
+// only for x = -0, which takes the plain product (tests: rh_debug_div_const_check).  3 VALU ops instead of ~11.
+RH_DEV float div_by_const(float x, float fw, float r)
+{
+	const float q0 = x * r;
+	const float e = __builtin_fmaf(-q0, fw, x);
+	const float q1 = __builtin_fmaf(e, r, q0);
+	return x == 0.0f ? q0 : q1;
+}
+
+__global__ void k_div_const_check(float fw, unsigned long long *out)
+{
+	const float r = 1.0f / fw;
+	unsigned long long bad = 0, bad_reach = 0;
+	for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32); b += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t u = (uint32_t)b;
+		if ((u & 0x7f800000u) == 0x7f800000u) continue;
+		const float x = __uint_as_float(u);
+		const float qt = x / fw, qf = div_by_const(x, fw, r);
+		if (__float_as_uint(qt) != __float_as_uint(qf)) { ++bad; const float ax = fabsf(x); if (ax == 0.0f || (ax > 1e-30f && ax < 1e30f)) ++bad_reach; }
+	}
+	if (bad) atomicAdd(&out[0], bad);
+	if (bad_reach) atomicAdd(&out[1], bad_reach);
+}
+
+// test hook (not part of the interface): out[0] = inputs where div_by_const differs from x / w, out[1] = those among
+// zero and 1e-30 < |x| < 1e30 (the prefix sums of |z| < 3 samples live far inside that range)
+extern "C" __attribute__((visibility("default"))) int rh_debug_div_const_check(int w, unsigned long long *out)
+{
+	unsigned long long *d = nullptr;
+	if (hipMalloc(&d, 16) != hipSuccess) return -1;
+	int rc = -1;
+	if (hipMemset(d, 0, 16) == hipSuccess) {
+		RH_LAUNCH(k_div_const_check, 4096, 256, 0, 0, (float)w, d);
+		if (hipMemcpy(out, d, 16, hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
+	}
+	(void)hipFree(d);
+	return rc;
+}
+
+// every index is a valid ring slot, so the arithmetic runs unconditionally (independent rows interleave) and the border
+// rule of comp_tstat (revent.c:38-74) is a select at the end
+RH_DEV float tstat_ring(const float *ps, const float *pss, uint32_t c, uint32_t n, uint32_t w, float fw, float rw, uint32_t i)
+{
+	#define TS_AT(arr, idx) arr[((idx) & (TS_RING - 1u)) * TS_STRIDE + c]
+	const float p0 = TS_AT(ps, i), r0 = TS_AT(pss, i);
+	const float pm = TS_AT(ps, i - w), rm = TS_AT(pss, i - w);
+	const float s1 = i > w ? p0 - pm : p0, q1 = i > w ? r0 - rm : r0;
+	const float s2 = TS_AT(ps, i + w) - p0, q2 = TS_AT(pss, i + w) - r0;
+	#undef TS_AT
+	const float m1 = div_by_const(s1, fw, rw), m2 = div_by_const(s2, fw, rw);
+	float var = div_by_const(div_by_const(q1, fw, rw) - m1 * m1 + div_by_const(q2, fw, rw) - m2 * m2, fw, rw);
+	var = fmaxf(var, FLT_MIN);
+	const float dm = m2 - m1;
+	const float t = fabsf(dm) / sqrtf(var);
+	return (n < 2 * w || w < 2 || i < w || i > n - w) ? 0.0f : t;
+}
+
+// CB chunks per block (64, or fewer when a round has too few chunks to fill the chip with blocks of 64)
+template <uint32_t CB>
+__global__ __launch_bounds__(NT) void k_events_tstat(rh_dev_opt o, rh_dev_round rr)
+{
+	constexpr uint32_t RW = CB / 4;                                     // rows (chunks) per wave
+	__shared__ float s_zt[TS_TILE * TS_STRIDE];
+	__shared__ float s_pa[TS_RING * TS_STRIDE], s_pb[TS_RING * TS_STRIDE];
+	__shared__ uint32_t s_n[64];
+	const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63u, a0 = blockIdx.x * CB;
+	if (tid < 64) {
+		s_n[tid] = tid < CB && a0 + tid < rr.n_act ? rr.n_norm[a0 + tid] : 0u;
+		s_pa[tid] = 0.0f; s_pb[tid] = 0.0f;                         // prefix entry 0
+	}
+	__syncthreads();
+	uint32_t nmax = s_n[l];
+	for (int d = 32; d > 0; d >>= 1) { const uint32_t t = __shfl_xor(nmax, d); if (t > nmax) nmax = t; }
+	const uint32_t n_tiles = (nmax + TS_TILE - 1) / TS_TILE;
+
+	// loads: thread (w, l) fetches sample (l & 31) of the chunks w * RW + 2 * k + (l >> 5): two 128-byte row pieces per request
+	const uint32_t ls = l & 31u, lc0 = w * RW + (l >> 5);
+	uint32_t ln[RW / 2];
+	const float *lrow[RW / 2];
+#pragma unroll
+	for (uint32_t k = 0; k < RW / 2; ++k) { ln[k] = s_n[lc0 + 2 * k]; lrow[k] = rr.zbuf + (size_t)(a0 + lc0 + 2 * k) * EV_ROW + ls; }
+	float zr[RW / 2];
+#pragma unroll
+	for (uint32_t k = 0; k < RW / 2; ++k) zr[k] = ls < ln[k] ? lrow[k][0] : 0.0f;
+
+	float acc = 0.0f, acc2 = 0.0f;                                     // wave 0: the two chains of chunk l
+	const uint32_t win = l < 32 ? o.w1 : o.w2;                         // t-statistics: lanes 0..31 the short window, 32..63 the long one
+	const float fwin = (float)win, rwin = 1.0f / fwin;
+	float *const tbuf = (l < 32 ? rr.t1buf : rr.t2buf) + (size_t)(a0 + w * RW) * EV_ROW;
+	uint32_t rn[RW];
+#pragma unroll
+	for (uint32_t k = 0; k < RW; ++k) rn[k] = s_n[w * RW + k];
+	for (uint32_t t = 0; t <= n_tiles; ++t) {                          // the last round only finishes the lagging t-statistics
+		const uint32_t base = t * TS_TILE;
+		if (t < n_tiles) {
+#pragma unroll
+			for (uint32_t k = 0; k < RW / 2; ++k) s_zt[ls * TS_STRIDE + lc0 + 2 * k] = zr[k];
+		}
+		__syncthreads();                                               // tile staged; everyone is done with the ring of the previous round
+		if (t + 1 < n_tiles) {
+#pragma unroll
+			for (uint32_t k = 0; k < RW / 2; ++k) zr[k] = base + TS_TILE + ls < ln[k] ? lrow[k][base + TS_TILE] : 0.0f;
+		}
+		if (w == 0 && t < n_tiles) {
+			float z[TS_TILE];
+#pragma unroll
+			for (uint32_t s2 = 0; s2 < TS_TILE; ++s2) z[s2] = s_zt[s2 * TS_STRIDE + l];
+#pragma unroll
+			for (uint32_t s2 = 0; s2 < TS_TILE; ++s2) {                 // past the end of a chunk the chain runs on zeros into entries nobody reads
+				acc = acc + z[s2];
+				acc2 = acc2 + z[s2] * z[s2];
+				const uint32_t slot = ((base + s2 + 1) & (TS_RING - 1u)) * TS_STRIDE + l;
+				s_pa[slot] = acc; s_pb[slot] = acc2;
+			}
+		}
+		__syncthreads();                                               // prefix entries <= base + TS_TILE are in the ring
+		const uint32_t i0 = base + ls - win;                           // this lane's position in every row (wraps below zero: fails i0 < n)
+#pragma unroll
+		for (uint32_t k = 0; k < RW; ++k) {
+			const float v = tstat_ring(s_pa, s_pb, w * RW + k, rn[k], win, fwin, rwin, i0);
+			if (i0 < rn[k]) tbuf[(size_t)k * EV_ROW + i0] = v;
+		}
 	}
 }
 
@@ -732,7 +876,17 @@ __global__ void k_synth_reads(rh_synth_cfg_t c, const int32_t *level16, uint64_t
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 void rhk_prefilter(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd) { if (rd.n_reads) RH_LAUNCH(k_prefilter, rd.n_reads, NT, 0, s, o, rd); }
-void rhk_events_norm(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_norm, r.n_act, NT, 0, s, o, rd, r); }
+void rhk_events_norm(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
+{
+	if (!r.n_act) return;
+	if (o.w1 > TS_WMAX || o.w2 > TS_WMAX) { RH_LAUNCH(k_events_norm<true>, r.n_act, NT, 0, s, o, rd, r); return; }
+	RH_LAUNCH(k_events_norm<false>, r.n_act, NT, 0, s, o, rd, r);
+	const char *force = getenv("RH_TSTAT_CB");                      // tests: pin the chunks-per-block variant
+	const uint32_t cb = force ? (uint32_t)atoi(force) : r.n_act >= 64u * 768u ? 64u : r.n_act >= 16u * 768u ? 16u : 8u;
+	if (cb >= 64) RH_LAUNCH(k_events_tstat<64>, cdiv(r.n_act, 64), NT, 0, s, o, r);
+	else if (cb >= 16) RH_LAUNCH(k_events_tstat<16>, cdiv(r.n_act, 16), NT, 0, s, o, r);
+	else RH_LAUNCH(k_events_tstat<8>, cdiv(r.n_act, 8), NT, 0, s, o, r);
+}
 void rhk_events_peaks(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_peaks, cdiv(r.n_act, PK_CHUNKS), 64, 0, s, o, r); }
 void rhk_events_means(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_means, r.n_act, NT, 0, s, o, r); }
 void rhk_sketch(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) {

@@ -304,7 +304,10 @@ RH_DEV void sort_split_range(sort_lds<CAP, KT> &L, uint32_t beg, uint32_t end, i
 	KPROF(1);
 	if (diff == 0) return;                                   // all keys equal: every remaining pass is an identity
 	// redo pass: a range without tied keys already has its (unique) final order from the fast pass -> nothing to do
-	if (pass == SORT_EXACT_TIED && (L.w[0] | L.w[1] | L.w[2] | L.w[3]) == 0) return;
+	if (pass == SORT_EXACT_TIED && (L.w[0] | L.w[1] | L.w[2] | L.w[3]) == 0) {
+		__syncthreads();                                     // every wave has read the flags before the next range's call rewrites them
+		return;
+	}
 	const bool exact = pass != SORT_FAST;
 	int s = (63 - __clzll(diff)) & ~7;
 	if (s > shift) s = shift;
@@ -713,7 +716,10 @@ RH_DEV void sortg_split_range(sortg_lds &L, const sortg_mem &G, uint32_t beg, ui
 	if (lane_id() == 0) L.w[wave_id()] = tmk != 0;
 	diff = block_or64(diff, L.r64);
 	if (diff == 0) return;
-	if (pass == SORT_EXACT_TIED && (L.w[0] | L.w[1] | L.w[2] | L.w[3]) == 0) return;
+	if (pass == SORT_EXACT_TIED && (L.w[0] | L.w[1] | L.w[2] | L.w[3]) == 0) {
+		__syncthreads();                                     // (as in sort_split_range: the next call rewrites the flags)
+		return;
+	}
 	const bool exact = pass != SORT_FAST;
 	int s = (63 - __clzll(diff)) & ~7;
 	if (s > shift) s = shift;

@@ -26,6 +26,22 @@ def check_events(ctx, wl, chunks=(0, 1, 2)):
     return ev, off
 
 
+def check_events_variants(ctx, wl, chunks=(0, 2)):
+    """Every chunks-per-block variant of the prefix-sum / t-statistic kernel (the launcher picks by round size; RH_TSTAT_CB pins
+    it), then windows too wide for that kernel's ring (the one-block-per-chunk layout computes them)."""
+    import copy, os
+    try:
+        for cb in ("64", "16", "8"):
+            os.environ["RH_TSTAT_CB"] = cb
+            check_events(ctx, wl, chunks=chunks)
+    finally:
+        os.environ.pop("RH_TSTAT_CB", None)
+    wide = copy.copy(wl.opts)
+    wide.mo = type(wl.opts.mo).from_buffer_copy(wl.opts.mo)
+    wide.mo.window_length1, wide.mo.window_length2 = 5, 20
+    check_events(ctx, _ReadsOnly(wide, wl.reads), chunks=chunks[:1])
+
+
 class _ReadsOnly:
     """what check_events needs of a workload: options + reads"""
     def __init__(self, opts, reads):

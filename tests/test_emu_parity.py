@@ -21,6 +21,7 @@ def ctx(emu_lib, wl):
 
 def test_events_bit_exact(ctx, wl):
     pc.check_events(ctx, wl, chunks=(0, 2))
+    pc.check_events_variants(ctx, wl, chunks=(1,))
 
 
 def test_stage_chain(ctx, wl):

@@ -29,8 +29,21 @@ def test_native_library_loaded(product_lib):
 
 def test_events_bit_exact(ctx, wl):
     pc.check_events(ctx, wl, chunks=(0, 1, 3, 5))
+    pc.check_events_variants(ctx, wl, chunks=(0, 4))
     for seed in (1, 2, 3):
         pc.check_events_odd_signals(ctx, wl, seed=seed)
+
+
+def test_window_division_shortcut(ctx):
+    """The t-statistic kernel divides by the window width with a reciprocal product + one remainder correction; on this GPU
+    that must equal the IEEE quotient for every fp32 input the prefix sums can produce (all 2^32 patterns are tried)."""
+    import ctypes, os, rawhash_amd
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(rawhash_amd.__file__), "librawhash_amd.so"))
+    lib.rh_debug_div_const_check.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_ulonglong)]
+    for w in range(2, 16):
+        out = (ctypes.c_ulonglong * 2)()
+        assert lib.rh_debug_div_const_check(w, out) == 0
+        assert out[1] == 0, f"w={w}: {out[1]} reachable inputs differ ({out[0]} overall)"
 
 
 def test_stage_chain(ctx, wl):
