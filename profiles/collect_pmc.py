@@ -14,7 +14,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGE_OF = {"k_regions_reg": "regions", "k_chain_reorder": "backtrack", "k_regions_wave<1536>": "regions", "k_regions_wave<256>": "regions", "k_prefilter": "prefilter", "k_events_norm": "events_norm", "k_events_peaks": "events_peaks", "k_events_means": "events_means",
+STAGE_OF = {"k_regions_reg": "regions", "k_chain_reorder": "backtrack", "k_regions_wave<1536>": "regions", "k_regions_wave<256>": "regions", "k_prefilter": "prefilter", "k_events_norm": "events_norm", "k_events_tstat": "events_norm", "k_events_peaks": "events_peaks", "k_events_means": "events_means",
             "k_sketch": "sketch", "k_probe": "probe", "k_expand": "expand", "k_chain_wave": "chain", "k_backtrack_big": "backtrack",
             "k_regions_wave": "regions"}
 

@@ -150,6 +150,29 @@ def test_sub_batches_give_identical_records(make_workload, product_lib, monkeypa
     assert np.array_equal(a, b)
 
 
+@pytest.mark.timeout(600)
+def test_concurrent_sub_batches_repeatable(product_lib, monkeypatch, tmp_path):
+    """The bench's shape at a third of its size, 3 sub-batches on 3 streams, 12 calls: every call returns the same records
+    (a barrier missing in the sorter once made roughly one call in thirty spin forever under exactly this load)."""
+    import os
+    from rawhash_amd import Context, Index, MapOptions, SynthWorkload
+    monkeypatch.setenv("RH_SUB_BATCHES", "3")
+    wl = SynthWorkload(chrom_len=4_600_000, n_chrom=1, n_samples=40_000, junk_per_1024=102)
+    opts = MapOptions("sensitive")
+    wl.write_reference(str(tmp_path))
+    fasta, model = os.path.join(str(tmp_path), "ref.fa"), os.path.join(str(tmp_path), "model.txt")
+    index = Index.build(fasta, model, opts, out_ind=None, n_threads=os.cpu_count() or 8)
+    opts.update(index)
+    c = Context(0, lib=product_lib)
+    c.upload(index)
+    batch = wl.reads_device(c, model, 0, 36_000)
+    first = c.map_batch(opts, batch).copy()
+    assert int(first["mapped"].sum()) > 30_000
+    for _ in range(11):
+        assert np.array_equal(first, c.map_batch(opts, batch))
+    c.close()
+
+
 def test_batch_sliced_when_arenas_do_not_fit(make_workload, product_lib, monkeypatch):
     """RH_ARENA_MAX_BYTES far below what the batch needs: rh_map_batch maps it in halving slices and returns the same records."""
     w = make_workload(n_reads=48)
