@@ -54,9 +54,17 @@ __global__ __launch_bounds__(NT) void k_prefilter(rh_dev_opt o, rh_dev_reads rd)
 	const bool keep = (n + 255) / 256 <= PF_TILES;                // per-tile counts of pass 1 kept in LDS: pass 2 re-reads boundary tiles only
 	uint32_t cnt = 0;
 	for (uint32_t base = beg; base < end; base += 256) {
+		// counting needs no order: each lane takes 4 consecutive samples of the tile in one 8-byte load (512 B per request)
+		const uint32_t i0 = base + 4u * l;
+		int16_t v[4] = {0, 0, 0, 0};
+		if (i0 + 4u <= end) __builtin_memcpy(v, raw + i0, 8);
+		else { for (uint32_t k = 0; k < 4; ++k) if (i0 + k < end) v[k] = raw[i0 + k]; }
 		uint32_t tc = 0;
 #pragma unroll
-		for (uint32_t k = 0; k < 4; ++k) tc += (uint32_t)__popcll(pa_tile_ballot(raw, base + k * 64 + l, end, coff, cscale));
+		for (uint32_t k = 0; k < 4; ++k) {
+			const float pa = raw_to_pa(v[k], coff, cscale);
+			tc += (uint32_t)__popcll(__ballot(i0 + k < end && pa > 30.0f && pa < 200.0f));
+		}
 		if (keep && l == 0) s_tc[base >> 8] = (uint16_t)tc;
 		cnt += tc;
 	}
