@@ -33,6 +33,23 @@ RH_DEV uint64_t pa_tile_ballot(const int16_t *raw, uint32_t i, uint32_t end, dou
 	return __ballot(valid);
 }
 
+// survivors of the pA filter among the 256 samples from `base` (clipped at end).  Counting needs no order: each lane takes
+// 4 consecutive samples in one 8-byte load (512 B per request instead of 128)
+RH_DEV uint32_t pa_tile_count(const int16_t *raw, uint32_t base, uint32_t end, double coff, float cscale)
+{
+	const uint32_t i0 = base + 4u * lane_id();
+	int16_t v[4] = {0, 0, 0, 0};
+	if (i0 + 4u <= end) __builtin_memcpy(v, raw + i0, 8);
+	else { for (uint32_t k = 0; k < 4; ++k) if (i0 + k < end) v[k] = raw[i0 + k]; }
+	uint32_t tc = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < 4; ++k) {
+		const float pa = raw_to_pa(v[k], coff, cscale);
+		tc += (uint32_t)__popcll(__ballot(i0 + k < end && pa > 30.0f && pa < 200.0f));
+	}
+	return tc;
+}
+
 #ifndef PF_TILES
 #define PF_TILES 2048          // tiles of 256 samples whose counts fit LDS (reads up to 512 k samples)
 #endif
@@ -54,17 +71,7 @@ __global__ __launch_bounds__(NT) void k_prefilter(rh_dev_opt o, rh_dev_reads rd)
 	const bool keep = (n + 255) / 256 <= PF_TILES;                // per-tile counts of pass 1 kept in LDS: pass 2 re-reads boundary tiles only
 	uint32_t cnt = 0;
 	for (uint32_t base = beg; base < end; base += 256) {
-		// counting needs no order: each lane takes 4 consecutive samples of the tile in one 8-byte load (512 B per request)
-		const uint32_t i0 = base + 4u * l;
-		int16_t v[4] = {0, 0, 0, 0};
-		if (i0 + 4u <= end) __builtin_memcpy(v, raw + i0, 8);
-		else { for (uint32_t k = 0; k < 4; ++k) if (i0 + k < end) v[k] = raw[i0 + k]; }
-		uint32_t tc = 0;
-#pragma unroll
-		for (uint32_t k = 0; k < 4; ++k) {
-			const float pa = raw_to_pa(v[k], coff, cscale);
-			tc += (uint32_t)__popcll(__ballot(i0 + k < end && pa > 30.0f && pa < 200.0f));
-		}
+		const uint32_t tc = pa_tile_count(raw, base, end, coff, cscale);
 		if (keep && l == 0) s_tc[base >> 8] = (uint16_t)tc;
 		cnt += tc;
 	}
@@ -199,10 +206,7 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 		const uint32_t per = ((span + (NT / 64) * 256u - 1) / ((NT / 64) * 256u)) * 256u;
 		const uint32_t beg = cs0 + (w * per < span ? w * per : span), end = beg + per < cs1 ? beg + per : cs1;
 		uint32_t cnt = 0;
-		for (uint32_t base = beg; base < end; base += 256) {
-#pragma unroll
-			for (uint32_t k = 0; k < 4; ++k) cnt += (uint32_t)__popcll(pa_tile_ballot(raw, base + k * 64 + l, end, coff, cscale));
-		}
+		for (uint32_t base = beg; base < end; base += 256) cnt += pa_tile_count(raw, base, end, coff, cscale);
 		if (l == 0) s_w[w] = cnt;
 		__syncthreads();
 		uint32_t run = 0, count = 0;
