@@ -166,7 +166,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom, args, stage_n[dom] / args.steps),
                          "avg_launch_ms": round(stage_ms[dom] / stage_n[dom], 4), "launches": stage_n[dom],
-                         "algorithmic_bytes_per_launch": int(dom_bytes / stage_n[dom])},
+                         "algorithmic_bytes_per_launch": int(dom_bytes / stage_n[dom]),
+                         "concurrent_streams": int(os.environ.get("RH_SUB_BATCHES", "3")),
+                         "note": "launch durations are HIP-event times on each sub-batch's own stream; with >1 concurrent streams a launch shares the "
+                                 "chip with the other streams' kernels, so frac understates the kernel alone (RH_SUB_BATCHES=1: profiles/r01_final_bench_1stream.json)"},
             "path": {"algorithmic_GB_per_step": round(path_bytes / args.steps / 1e9, 4), "device_ms_per_step": round(dev_ms / args.steps, 3),   # sum over concurrent sub-batch streams
                     
                      "achieved_GBs": round(path_bytes / elapsed / 1e9, 3)},

@@ -244,7 +244,7 @@ extern "C" int rh_ctx_create(rh_ctx **out, int device_id)
 	for (uint32_t i = 0; i < RH_LOGF_N; ++i) tab[i] = logf((float)i);
 	if (c->logf_tab.ensure((size_t)RH_LOGF_N * 4)) return -1;
 	RH_HIP(hipMemcpy(c->logf_tab.p, tab.data(), (size_t)RH_LOGF_N * 4, hipMemcpyHostToDevice));
-	if (const char *e = getenv("RH_SUB_BATCHES")) c->n_sub = atoi(e) > 0 ? atoi(e) : 1; else c->n_sub = 3;   // measured on MI355X (100 k reads): 1: 211 k, 2: 226 k, 3: 235 k, 4: 191 k, >= 5: ~120 k reads/s
+	if (const char *e = getenv("RH_SUB_BATCHES")) c->n_sub = atoi(e) > 0 ? atoi(e) : 1; else c->n_sub = 3;   // measured on MI355X (100 k reads): 1: 585 k, 2: 656 k, 3: 690 k, 4: 517 k (636 k with GPU_MAX_HW_QUEUES=8: HIP multiplexes streams onto 4 hardware queues by default), 6: 544 k (653 k) reads/s
 	*out = c.release();
 	return 0;
 }
