@@ -69,6 +69,7 @@ struct rh_ctx_s {
 	DevBuf zbuf, t1buf, t2buf, n_norm, peaks, n_peaks;
 	DevBuf ev, n_ev, skip, sx, sy, n_seed, m_val, m_n, m_meta, m_pref, n_match, n_new, rep_len, a_off;
 	DevBuf anc, raw_anc, zs, n_z, need_exact, need_exact2, prev[2], u, n_u, n_v, ws, counters, rec;
+	DevBuf sort_alt, sort_ws;                                     // multi-workgroup segment sorter: second record array + tables (only when a read exceeds the LDS classes)
 	DevBuf sy_samples, sy_off, sy_cal_off, sy_cal_scale, sy_levels;
 	// timing
 	hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -211,6 +212,13 @@ int stage_anchors(rh_ctx *c, uint64_t total, int which, rh_dev_round *rr)
 	if (c->anc.ensure(t * 16) || c->raw_anc.ensure(t * 16) || c->zs.ensure(t * 16) || c->prev[which].ensure(t * 16) || c->u.ensure(t * 8) || c->ws.ensure(t * RH_WS_PER_ANCHOR + 4096)) return -1;
 	rr->anc = c->anc.as<rh_mm128_t>(); rr->raw = c->raw_anc.as<rh_mm128_t>(); rr->zs = c->zs.as<rh_mm128_t>(); rr->prev_out = c->prev[which].as<rh_mm128_t>(); rr->prev_in = c->prev[which ^ 1].as<rh_mm128_t>();
 	rr->u = c->u.as<uint64_t>(); rr->ws = c->ws.as<unsigned char>();
+	// segments longer than the LDS sort classes (large indexes): scratch of the multi-workgroup sorter
+	if (rr->max_anchors == 0 || rr->max_anchors > (uint32_t)RH_SORT_LDS_MIN_TOP) {
+		const size_t wsb = rhk_bigsort_ws_bytes(t, (uint32_t)RH_SORT_LDS_MIN_TOP);
+		if (c->sort_alt.ensure(t * 16) || c->sort_ws.ensure(wsb)) return -1;
+		if (!c->pin) RH_HIP(hipHostMalloc((void**)&c->pin, 256, 0));
+		rr->sort_alt = c->sort_alt.as<rh_mm128_t>(); rr->sort_ws = c->sort_ws.as<unsigned char>(); rr->sort_ws_bytes = c->sort_ws.cap; rr->sort_pin = c->pin + 16; rr->sort_total = t;
+	}
 	return 0;
 }
 
@@ -258,7 +266,7 @@ extern "C" void rh_ctx_destroy(rh_ctx *c)
 	c->subs.clear();
 	DevBuf *all[] = {&c->logf_tab, &c->raw, &c->off, &c->cal_off, &c->cal_scale, &c->act[0], &c->act[1], &c->n_act_dev, &c->zbuf, &c->t1buf, &c->t2buf, &c->n_norm, &c->peaks, &c->n_peaks, &c->ev, &c->n_ev, &c->skip, &c->sx, &c->sy,
 	                 &c->n_seed, &c->m_val, &c->m_n, &c->m_meta, &c->m_pref, &c->n_match, &c->n_new, &c->rep_len, &c->a_off, &c->anc, &c->raw_anc, &c->zs, &c->n_z, &c->need_exact, &c->need_exact2, &c->prev[0], &c->prev[1], &c->u,
-	                 &c->n_u, &c->n_v, &c->ws, &c->counters, &c->rec, &c->sy_samples, &c->sy_off, &c->sy_cal_off, &c->sy_cal_scale, &c->sy_levels};
+	                 &c->n_u, &c->n_v, &c->ws, &c->sort_alt, &c->sort_ws, &c->counters, &c->rec, &c->sy_samples, &c->sy_off, &c->sy_cal_off, &c->sy_cal_scale, &c->sy_levels};
 	for (DevBuf *b : all) b->release();
 	for (DevBuf &b : c->st) b.release();
 	if (c->blob_owned) c->blob.release();
@@ -421,7 +429,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 	{ StageTimer t(c, ST_PREFILTER); rhk_prefilter(s, o, rd); }
 	int cur = 0;
 	{ StageTimer t(c, ST_COMPACT); rhk_compact_active(s, o, rd, nullptr, R, 0, c->act[cur].as<uint32_t>(), c->n_act_dev.as<uint32_t>()); }
-	if (!c->pin) RH_HIP(hipHostMalloc((void**)&c->pin, 64, 0));
+	if (!c->pin) RH_HIP(hipHostMalloc((void**)&c->pin, 256, 0));
 	uint32_t n_act = 0;
 	RH_HIP(hipMemcpyAsync(c->pin, c->n_act_dev.p, 4, hipMemcpyDeviceToHost, s));
 	RH_HIP(hipStreamSynchronize(s));
@@ -445,12 +453,12 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 		rr.max_anchors = (uint32_t)c->pin[2];
 		if (stage_anchors(c, total, which, &rr)) return -1;
 		{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rr); }
-		{ StageTimer t(c, ST_SORT); rhk_sort(s, rr); }
+		{ StageTimer t(c, ST_SORT); if (rhk_sort(s, rr)) return -1; }
 		if (debug_rounds()) dump_round(c, chunk, n_act, rr);
 		{ StageTimer t(c, ST_CHAIN); rhk_chain(s, o, rr); }
-		{ StageTimer t(c, ST_ZSORT); rhk_zsort(s, o, rr); }
-		{ StageTimer t(c, ST_BACKTRACK); rhk_backtrack(s, o, rd, rr); }
-		{ StageTimer t(c, ST_RSORT); rhk_regions_sort(s, o, rd, rr); }
+		{ StageTimer t(c, ST_ZSORT); if (rhk_zsort(s, o, rr)) return -1; }
+		{ StageTimer t(c, ST_BACKTRACK); if (rhk_backtrack(s, o, rd, rr)) return -1; }
+		{ StageTimer t(c, ST_RSORT); if (rhk_regions_sort(s, o, rd, rr)) return -1; }
 		{ StageTimer t(c, ST_REGIONS); rhk_regions(s, o, rd, rr, c->logf_tab.as<float>()); }
 		if (debug_rounds()) dump_round2(c, chunk, n_act, rr);
 		{ StageTimer t(c, ST_COMPACT); rhk_compact_active(s, o, rd, rr.act, n_act, chunk + 1, c->act[cur ^ 1].as<uint32_t>(), c->n_act_dev.as<uint32_t>()); }
@@ -500,7 +508,7 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 	if (c->slice_hint == 0 || R <= c->slice_hint) {
 		if (map_batch_once(c, mo, in, out, out_cap, &n) == 0) { *n_out = n; return 0; }
 		if (!g_oom || R < 2) return -1;
-		DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev[0], &c->prev[1], &c->u, &c->ws};
+		DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev[0], &c->prev[1], &c->u, &c->ws, &c->sort_alt, &c->sort_ws};
 		(void)hipStreamSynchronize(c->stream);
 		for (DevBuf *d : big) d->release();
 	} else slice = c->slice_hint;
@@ -517,7 +525,7 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 		if (map_batch_once(c, mo, &b, out + done, m, &n)) {
 			if (!g_oom || slice < 2) return -1;
 			slice /= 2;                                             // try smaller, from empty per-anchor arenas
-			DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev[0], &c->prev[1], &c->u, &c->ws};
+			DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev[0], &c->prev[1], &c->u, &c->ws, &c->sort_alt, &c->sort_ws};
 			(void)hipStreamSynchronize(c->stream);
 			for (DevBuf *d : big) d->release();
 			continue;
@@ -752,7 +760,7 @@ extern "C" int rh_seed_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, const
 	if (stage_anchors(c, total, 0, &rr)) return -1;
 	rr.prev_in = c->prev[1].as<rh_mm128_t>();
 	rhk_expand(s, o, c->dix, rd, rr);
-	rhk_sort(s, rr);
+	if (rhk_sort(s, rr)) return -1;
 	RH_HIP(hipStreamSynchronize(s));
 	RH_HIP(hipGetLastError());
 	if (total > anchors_cap) { rh_set_error("anchor buffer too small (%llu needed)", (unsigned long long)total); return -1; }
@@ -776,6 +784,7 @@ extern "C" int rh_chain_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, cons
 	if (stage_round(c, R, &rr) || make_identity(c, R, 0)) return -1;
 	rr.act = c->act[0].as<uint32_t>();
 	const uint64_t total = anchor_offsets[R];
+	for (uint32_t r = 0; r < R; ++r) { const uint64_t m = anchor_offsets[r + 1] - anchor_offsets[r]; if (m > rr.max_anchors) rr.max_anchors = (uint32_t)m; }
 	if (stage_anchors(c, total, 0, &rr)) return -1;
 	std::vector<uint8_t> skip(R ? R : 1, 0);
 	if (h2d(rr.a_off, anchor_offsets, (size_t)R + 1) || h2d(rr.anc, anchors, total) || h2d(rr.skip, skip.data(), R)) return -1;
@@ -783,8 +792,7 @@ extern "C" int rh_chain_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, cons
 	RH_HIP(hipMemset(rr.n_u, 0, (size_t)(R ? R : 1) * 4)); RH_HIP(hipMemset(rr.n_v, 0, (size_t)(R ? R : 1) * 4));
 	hipStream_t s = c->stream;
 	rhk_chain(s, o, rr);
-	rhk_zsort(s, o, rr);
-	rhk_backtrack(s, o, rd, rr);
+	if (rhk_zsort(s, o, rr) || rhk_backtrack(s, o, rd, rr)) return -1;
 	RH_HIP(hipStreamSynchronize(s));
 	RH_HIP(hipGetLastError());
 	std::vector<uint32_t> nu, nv; std::vector<rh_mm128_t> an, pv; std::vector<uint64_t> uu;
@@ -811,7 +819,7 @@ extern "C" int rh_sort128x_batch(rh_ctx *c, uint32_t n_seg, rh_mm128_t *a, const
 	if (stage_round(c, n_seg, &rr) || stage_anchors(c, total, 0, &rr)) return -1;
 	std::vector<uint8_t> skip(n_seg ? n_seg : 1, 0);
 	if (h2d(rr.raw, a, total) || h2d(rr.a_off, offsets, (size_t)n_seg + 1) || h2d(rr.skip, skip.data(), n_seg)) return -1;
-	rhk_sort(c->stream, rr);
+	if (rhk_sort(c->stream, rr)) return -1;
 	RH_HIP(hipStreamSynchronize(c->stream));
 	RH_HIP(hipGetLastError());
 	if (total) RH_HIP(hipMemcpy(a, rr.anc, total * 16, hipMemcpyDeviceToHost));

@@ -1,0 +1,544 @@
+// Segments beyond the LDS classes of rh_sort.hip (tens of thousands to millions of records: large indexes put that many
+// anchors into one chunk): the reference's radix_sort_128x (ksort.h:101-151) level by level with MANY workgroups per
+// segment, still producing its exact - unstable - permutation.
+//
+// One level of rs_sort on a range = an in-place American-flag pass on one byte of the key.  What it does to a range
+// follows from two facts ("Exact unstable sort"):
+//   * Split the range into the buckets' regions.  A record sitting in its own region is "in place", every other position
+//     is a "hole".  The cycle walk only ever reads the holes of a region in position order: it is a token that moves
+//     between regions, each visit consuming the region's next hole and continuing with the bucket of the record found
+//     there.  So the walk needs nothing but one byte per hole (the digit of its record), region by region, and it is
+//     the only serial part: one lane walks the byte streams (staged through LDS windows) and notes, for the record of
+//     every hole, which hole of its own region it lands in (`dest`).
+//   * Where the j-th arrival of a region ends up, and what happens to the in-place records, is closed form: while an
+//     earlier bucket is being filled ("phase 1", the first J arrivals) an arrival is written at the region's head and
+//     pushes the run of in-place records before the next hole one slot to the right; once the walk works on the region
+//     itself ("phase 2") arrivals drop straight into the holes and nothing shifts.
+// Everything except the token walk is data parallel over fixed tiles of a range: OR / AND of the keys (highest differing
+// byte: levels on which all keys agree are identities), digit histogram, hole compaction (digits + positions in
+// position order), final placement.  Ranges of one level are independent; a range's buckets become the next level's
+// ranges (still too large), segments for the LDS block sorter (<= its largest class; they finish there, insertion
+// sorts of <= 64 records included), or are final.  Records move once per level between two scratch copies (the
+// job's own source array and `alt`); finished buckets go straight to the destination array.
+#include "rh_kernels.h"
+#include "rh_devutil.h"
+
+#ifndef BS_TILE_IT
+#define BS_TILE_IT 8                      // records per thread of a tile
+#endif
+#define BS_TILE (NT * BS_TILE_IT)
+#ifndef BS_WIN_BYTES
+#define BS_WIN_BYTES 32768                // LDS of the token walk's stream windows
+#endif
+
+struct bs_range {
+	uint64_t beg;                         // absolute record offset of the range in the job's arrays
+	uint32_t n;
+	uint32_t tile0;                       // first tile of the range in this level's tile numbering
+	uint8_t buf;                          // which copy holds it: 0 = job source, 1 = alt
+	uint8_t shift;                        // highest byte shift this level may split on
+	uint8_t pad[6];
+};
+
+// per-range tables of a level
+struct bs_meta {
+	uint64_t k_or, k_and;
+	uint32_t cnt[256];                    // digit histogram
+	uint32_t start[257];                  // exclusive scan
+	uint32_t inpl[256];                   // records already in their region
+	uint32_t hst[257];                    // holes before each region (= index of the region's first hole)
+	uint32_t J[256];                      // arrivals of a region before the walk turns to it
+	uint8_t fate[256];                    // 0 empty, 1 final, 2 block sorter, 3 next level
+	int32_t s;                            // byte shift of this level (-1: all keys equal)
+	uint32_t pad;
+};
+enum { BS_EMPTY = 0, BS_FINAL = 1, BS_SMALL = 2, BS_BIG = 3 };
+
+struct bs_ctx {
+	rh_mm128_t *buf[2];                   // 0 = job source (overwritten), 1 = alt
+	rh_mm128_t *dst;
+	bs_range *rng[2];                     // this level's ranges / next level's
+	bs_meta *meta;
+	uint32_t *tile_h;                     // per tile: holes -> (after the scan) holes of the range before the tile
+	uint8_t *dg, *hd;                     // per record: digit; per hole: digit of its record
+	uint32_t *hp, *dest;                  // per hole: position in the range; hole (of the record's own region) it moves to
+	uint64_t *small_off[2]; uint32_t *small_cnt[2];   // segments for the block sorter, by the copy that holds them
+	uint32_t *hdr;                        // [0] ranges of this level [1] tiles [2],[3] block-sorter segments per copy [4] next level's ranges [5] error
+	uint32_t small_cap, rng_cap, n_lo;
+};
+
+RH_DEV uint32_t bs_find_range(const bs_ctx &C, uint32_t tile, uint32_t n_rng, uint32_t *s_r)
+{
+	if (threadIdx.x == 0) {
+		uint32_t lo = 0, hi = n_rng;      // largest r with tile0[r] <= tile
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (C.rng[0][mid].tile0 <= tile) lo = mid; else hi = mid; }
+		*s_r = lo;
+	}
+	__syncthreads();
+	return *s_r;
+}
+
+// ------------------------------------------------------------------------------------------------ level set-up
+// level 0: one range per segment longer than n_lo
+__global__ __launch_bounds__(NT) void k_bs_init(rh_sort_job jb, bs_ctx C)
+{
+	__shared__ uint32_t s_w[NT / 64];
+	__shared__ uint32_t s_run[2];
+	const uint32_t tid = threadIdx.x;
+	if (tid == 0) { s_run[0] = 0; s_run[1] = 0; }
+	__syncthreads();
+	for (uint32_t a0 = 0; a0 < jb.n_seg; a0 += NT) {
+		const uint32_t a = a0 + tid;
+		uint32_t n = 0;
+		if (a < jb.n_seg && !(jb.skip && jb.skip[a])) n = jb.cnt ? jb.cnt[a] : (uint32_t)(jb.off[a + 1] - jb.off[a]);
+		const bool big = n > C.n_lo;
+		uint32_t tot_r, tot_t;
+		const uint32_t rk = block_rank(big, s_w, tot_r);
+		const uint32_t tk = block_excl_scan(big ? (n + BS_TILE - 1) / BS_TILE : 0u, s_w, tot_t);
+		if (big) {
+			bs_range q;
+			q.beg = jb.off[a]; q.n = n; q.tile0 = s_run[1] + tk; q.buf = 0; q.shift = 56;
+			for (int i = 0; i < 6; ++i) q.pad[i] = 0;
+			if (s_run[0] + rk < C.rng_cap) C.rng[0][s_run[0] + rk] = q;
+		}
+		__syncthreads();
+		if (tid == 0) { s_run[0] += tot_r; s_run[1] += tot_t; }
+		__syncthreads();
+	}
+	if (tid == 0) { C.hdr[0] = s_run[0]; C.hdr[1] = s_run[1]; C.hdr[2] = 0; C.hdr[3] = 0; C.hdr[4] = 0; C.hdr[5] = s_run[0] > C.rng_cap ? 1u : 0u; }
+}
+
+__global__ __launch_bounds__(NT) void k_bs_clear(bs_ctx C)
+{
+	const uint32_t r = blockIdx.x, tid = threadIdx.x;
+	if (r >= C.hdr[0]) return;
+	bs_meta &M = C.meta[r];
+	M.cnt[tid] = 0; M.inpl[tid] = 0;
+	if (tid == 0) { M.k_or = 0; M.k_and = ~0ull; }
+}
+
+// ------------------------------------------------------------------------------------------------ K1: OR / AND of the keys
+__global__ __launch_bounds__(NT) void k_bs_diff(bs_ctx C)
+{
+	__shared__ uint32_t s_r;
+	__shared__ uint64_t s_red[2 * (NT / 64)];
+	const uint32_t n_rng = C.hdr[0], tid = threadIdx.x;
+	if (blockIdx.x >= C.hdr[1]) return;
+	const uint32_t r = bs_find_range(C, blockIdx.x, n_rng, &s_r);
+	const bs_range R = C.rng[0][r];
+	const uint32_t t0 = (blockIdx.x - R.tile0) * BS_TILE;
+	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
+	uint64_t vo = 0, va = ~0ull;
+#pragma unroll
+	for (int it = 0; it < BS_TILE_IT; ++it) {
+		const uint32_t p = t0 + (uint32_t)it * NT + tid;
+		if (p < R.n) { const uint64_t k = src[p].x; vo |= k; va &= k; }
+	}
+	for (int d = 32; d > 0; d >>= 1) { vo |= __shfl_xor(vo, d); va &= __shfl_xor(va, d); }
+	if (lane_id() == 0) { s_red[2 * wave_id()] = vo; s_red[2 * wave_id() + 1] = va; }
+	__syncthreads();
+	if (tid == 0) {
+		for (uint32_t q = 1; q < NT / 64; ++q) { vo |= s_red[2 * q]; va &= s_red[2 * q + 1]; }
+		atomicOr((unsigned long long*)&C.meta[r].k_or, (unsigned long long)vo);
+		atomicAnd((unsigned long long*)&C.meta[r].k_and, (unsigned long long)va);
+	}
+}
+
+RH_DEV int bs_level_shift(const bs_meta &M, uint32_t shift_max)
+{
+	const uint64_t diff = M.k_or & ~M.k_and;
+	if (diff == 0) return -1;
+	int s = (63 - __clzll(diff)) & ~7;
+	if (s > (int)shift_max) s = (int)shift_max;                   // (cannot happen: the bytes above agree; kept as the reference's bound)
+	return s;
+}
+
+// ------------------------------------------------------------------------------------------------ K2: digits + histogram
+__global__ __launch_bounds__(NT) void k_bs_hist(bs_ctx C)
+{
+	__shared__ uint32_t s_r;
+	__shared__ uint32_t s_cnt[256];
+	const uint32_t n_rng = C.hdr[0], tid = threadIdx.x;
+	if (blockIdx.x >= C.hdr[1]) return;
+	const uint32_t r = bs_find_range(C, blockIdx.x, n_rng, &s_r);
+	const bs_range R = C.rng[0][r];
+	const int s = bs_level_shift(C.meta[r], R.shift);
+	const uint32_t t0 = (blockIdx.x - R.tile0) * BS_TILE;
+	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
+	uint8_t *dg = C.dg + R.beg;
+	s_cnt[tid] = 0;
+	__syncthreads();
+#pragma unroll
+	for (int it = 0; it < BS_TILE_IT; ++it) {
+		const uint32_t p = t0 + (uint32_t)it * NT + tid;
+		if (p < R.n) {
+			const uint32_t d = s < 0 ? 0u : (uint32_t)(src[p].x >> s) & 255u;
+			dg[p] = (uint8_t)d;
+			atomicAdd(&s_cnt[d], 1u);
+		}
+	}
+	__syncthreads();
+	if (s_cnt[tid]) atomicAdd(&C.meta[r].cnt[tid], s_cnt[tid]);
+}
+
+// ------------------------------------------------------------------------------------------------ K3: regions, fates, children
+__global__ __launch_bounds__(NT) void k_bs_plan(bs_ctx C)
+{
+	__shared__ uint32_t s_w[NT / 64];
+	const uint32_t r = blockIdx.x, tid = threadIdx.x;
+	if (r >= C.hdr[0]) return;
+	const bs_range R = C.rng[0][r];
+	bs_meta &M = C.meta[r];
+	const int s = bs_level_shift(M, R.shift);
+	const uint32_t c = M.cnt[tid];
+	uint32_t total;
+	const uint32_t st = block_excl_scan(c, s_w, total);
+	M.start[tid] = st;
+	if (tid == 0) { M.start[256] = total; M.s = s; }
+	uint8_t fate = BS_EMPTY;
+	if (c) {
+		if (s <= 0 || c == 1) fate = BS_FINAL;                    // all keys equal, last byte done, or a single record
+		else if (c <= C.n_lo) fate = BS_SMALL;
+		else fate = BS_BIG;
+	}
+	const uint8_t alt = R.buf ^ 1;
+	if (fate == BS_SMALL) {
+		const uint32_t k = atomicAdd(&C.hdr[2 + alt], 1u);
+		if (k < C.small_cap) { C.small_off[alt][k] = R.beg + st; C.small_cnt[alt][k] = c; }
+		else C.hdr[5] = 1;
+	} else if (fate == BS_BIG) {
+		const uint32_t k = atomicAdd(&C.hdr[4], 1u);
+		if (k < C.rng_cap) {
+			bs_range q;
+			q.beg = R.beg + st; q.n = c; q.tile0 = 0; q.buf = alt; q.shift = (uint8_t)(s - 8);
+			for (int i = 0; i < 6; ++i) q.pad[i] = 0;
+			C.rng[1][k] = q;
+		} else C.hdr[5] = 1;
+	}
+	M.fate[tid] = fate;
+}
+
+// ------------------------------------------------------------------------------------------------ tiles: classification
+// region of position p: largest b with start[b] <= p (empty buckets share their start with the next one)
+RH_DEV uint32_t bs_region(const uint32_t *start, uint32_t p)
+{
+	uint32_t lo = 0, hi = 256;
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (start[mid] <= p) lo = mid; else hi = mid; }
+	return lo;
+}
+
+// For the thread's BS_TILE_IT records of the tile (record `it` at position t0 + it * NT + tid): digit, region, and the
+// number of holes of the tile before it (position order).  s_cw: BS_TILE_IT * (NT / 64) words.  Returns the tile's holes.
+struct bs_cls { uint32_t d[BS_TILE_IT], b[BS_TILE_IT], hb[BS_TILE_IT]; };
+RH_DEV uint32_t bs_classify(const uint8_t *dg, const uint32_t *s_start, uint32_t t0, uint32_t n, uint32_t *s_cw, bs_cls &q)
+{
+	const uint32_t tid = threadIdx.x, w = wave_id();
+	uint64_t bal[BS_TILE_IT];
+#pragma unroll
+	for (int it = 0; it < BS_TILE_IT; ++it) {
+		const uint32_t p = t0 + (uint32_t)it * NT + tid;
+		bool hole = false;
+		q.d[it] = 0; q.b[it] = 0;
+		if (p < n) { q.d[it] = dg[p]; q.b[it] = bs_region(s_start, p); hole = q.d[it] != q.b[it]; }
+		bal[it] = __ballot(hole);
+		if (lane_id() == 0) s_cw[it * (NT / 64) + w] = (uint32_t)__popcll(bal[it]);
+	}
+	__syncthreads();
+	uint32_t run = 0, total = 0;
+#pragma unroll
+	for (int it = 0; it < BS_TILE_IT; ++it) {
+		for (uint32_t ww = 0; ww < NT / 64; ++ww) {
+			const uint32_t c = s_cw[it * (NT / 64) + ww];
+			if (ww == w) q.hb[it] = total + lanes_below(bal[it]);
+			total += c;
+		}
+	}
+	(void)run;
+	__syncthreads();
+	return total;
+}
+
+// K4: holes per tile, in-place records per bucket
+__global__ __launch_bounds__(NT) void k_bs_count(bs_ctx C)
+{
+	__shared__ uint32_t s_r;
+	__shared__ uint32_t s_start[257], s_inpl[256], s_cw[BS_TILE_IT * (NT / 64)];
+	const uint32_t n_rng = C.hdr[0], tid = threadIdx.x;
+	if (blockIdx.x >= C.hdr[1]) return;
+	const uint32_t r = bs_find_range(C, blockIdx.x, n_rng, &s_r);
+	const bs_range R = C.rng[0][r];
+	const bs_meta &M = C.meta[r];
+	s_start[tid] = M.start[tid]; s_inpl[tid] = 0;
+	if (tid == 0) s_start[256] = M.start[256];
+	__syncthreads();
+	const uint32_t t0 = (blockIdx.x - R.tile0) * BS_TILE;
+	bs_cls q;
+	const uint32_t holes = bs_classify(C.dg + R.beg, s_start, t0, R.n, s_cw, q);
+#pragma unroll
+	for (int it = 0; it < BS_TILE_IT; ++it) {
+		const uint32_t p = t0 + (uint32_t)it * NT + tid;
+		if (p < R.n && q.d[it] == q.b[it]) atomicAdd(&s_inpl[q.d[it]], 1u);
+	}
+	__syncthreads();
+	if (s_inpl[tid]) atomicAdd(&C.meta[r].inpl[tid], s_inpl[tid]);
+	if (tid == 0) C.tile_h[blockIdx.x] = holes;
+}
+
+// K5: per range - holes before each tile, holes before each region
+__global__ __launch_bounds__(NT) void k_bs_scan(bs_ctx C)
+{
+	__shared__ uint32_t s_w[NT / 64];
+	const uint32_t r = blockIdx.x, tid = threadIdx.x;
+	if (r >= C.hdr[0]) return;
+	const bs_range R = C.rng[0][r];
+	bs_meta &M = C.meta[r];
+	const uint32_t nt = (R.n + BS_TILE - 1) / BS_TILE;
+	uint32_t run = 0;
+	for (uint32_t i0 = 0; i0 < nt; i0 += NT) {
+		const uint32_t i = i0 + tid;
+		const uint32_t v = i < nt ? C.tile_h[R.tile0 + i] : 0u;
+		uint32_t tot;
+		const uint32_t ex = block_excl_scan(v, s_w, tot);
+		if (i < nt) C.tile_h[R.tile0 + i] = run + ex;
+		run += tot;
+	}
+	uint32_t total;
+	const uint32_t m = M.cnt[tid] - M.inpl[tid];
+	const uint32_t hs = block_excl_scan(m, s_w, total);
+	M.hst[tid] = hs;
+	if (tid == 0) M.hst[256] = total;
+}
+
+// K6: the holes in position order: digit of the record, position
+__global__ __launch_bounds__(NT) void k_bs_holes(bs_ctx C)
+{
+	__shared__ uint32_t s_r;
+	__shared__ uint32_t s_start[257], s_cw[BS_TILE_IT * (NT / 64)];
+	const uint32_t n_rng = C.hdr[0], tid = threadIdx.x;
+	if (blockIdx.x >= C.hdr[1]) return;
+	const uint32_t r = bs_find_range(C, blockIdx.x, n_rng, &s_r);
+	const bs_range R = C.rng[0][r];
+	const bs_meta &M = C.meta[r];
+	s_start[tid] = M.start[tid];
+	if (tid == 0) s_start[256] = M.start[256];
+	__syncthreads();
+	const uint32_t t0 = (blockIdx.x - R.tile0) * BS_TILE, hbase = C.tile_h[blockIdx.x];
+	bs_cls q;
+	bs_classify(C.dg + R.beg, s_start, t0, R.n, s_cw, q);
+	uint8_t *hd = C.hd + R.beg;
+	uint32_t *hp = C.hp + R.beg;
+#pragma unroll
+	for (int it = 0; it < BS_TILE_IT; ++it) {
+		const uint32_t p = t0 + (uint32_t)it * NT + tid;
+		if (p < R.n && q.d[it] != q.b[it]) { const uint32_t g = hbase + q.hb[it]; hd[g] = (uint8_t)q.d[it]; hp[g] = p; }
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ K7: the token walk
+// One wavefront per range.  Lane 0 walks; the hole-digit streams of the regions are staged through LDS windows (ring
+// per region, refilled by all lanes when the walker runs into the end of one).  Two regions with holes: closed form
+// (the i-th hole of the lower region trades with the i-th of the upper one), all lanes.
+struct bs_walk_state { uint32_t k, i0, i, d, inchase, need, done; };
+
+__global__ __launch_bounds__(64) void k_bs_walk(bs_ctx C)
+{
+	__shared__ uint8_t s_win[BS_WIN_BYTES];
+	__shared__ uint32_t s_ptr[256], s_lim[256], s_end[256], s_h0[256], s_wb[256];
+	__shared__ uint8_t s_act[256];
+	__shared__ uint32_t s_nh;
+	__shared__ bs_walk_state S;
+	const uint32_t r = blockIdx.x, lane = threadIdx.x;
+	if (r >= C.hdr[0]) return;
+	const bs_range R = C.rng[0][r];
+	bs_meta &M = C.meta[r];
+	for (uint32_t d = lane; d < 256; d += 64) { s_ptr[d] = M.hst[d]; s_h0[d] = M.hst[d]; s_end[d] = M.hst[d + 1]; s_lim[d] = M.hst[d]; M.J[d] = 0; }
+	__syncthreads();
+	if (lane == 0) { uint32_t nh = 0; for (uint32_t d = 0; d < 256; ++d) if (s_end[d] > s_ptr[d]) s_act[nh++] = (uint8_t)d; s_nh = nh; }
+	__syncthreads();
+	const uint32_t nh = s_nh;
+	if (nh == 0) return;
+	const uint8_t *hd = C.hd + R.beg;
+	uint32_t *dest = C.dest + R.beg;
+	if (nh == 2) {
+		const uint32_t A = s_act[0], B = s_act[1], hA = s_h0[A], hB = s_h0[B], m = s_end[A] - hA;
+		for (uint32_t i = lane; i < m; i += 64) { dest[hA + i] = hB + i; dest[hB + i] = hA + i; }
+		if (lane == 0) M.J[B] = m;
+		return;
+	}
+	uint32_t W = 1;                                                // window entries per region: a power of two, nh * W <= BS_WIN_BYTES (>= 256)
+	while (W * 2 * nh <= (uint32_t)BS_WIN_BYTES && W < (1u << 20)) W *= 2;
+	const uint32_t Wm = W - 1, Wlow = W / 2 ? W / 2 : 1u;
+	if (lane == 0) {
+		for (uint32_t q = 0; q < nh; ++q) s_wb[s_act[q]] = q * W;
+		S.k = 0; S.i0 = 0; S.i = 0; S.d = 0; S.inchase = 0; S.need = 1; S.done = 0;
+	}
+	__syncthreads();
+	for (;;) {
+		// refill: every region whose window is more than half used gets it topped up to W entries ahead of its pointer
+		for (uint32_t q = 0; q < nh; ++q) {
+			const uint32_t d = s_act[q], pt = s_ptr[d], lim = s_lim[d], en = s_end[d];
+			if (lim >= en || lim - pt >= Wlow) continue;
+			const uint32_t nl = pt + W < en ? pt + W : en;
+			for (uint32_t g = lim + lane; g < nl; g += 64) s_win[s_wb[d] + (g & Wm)] = hd[g];
+		}
+		__syncthreads();
+		if (lane == 0) {
+			for (uint32_t q = 0; q < nh; ++q) {
+				const uint32_t d = s_act[q], pt = s_ptr[d], lim = s_lim[d], en = s_end[d];
+				if (lim >= en || lim - pt >= Wlow) continue;
+				s_lim[d] = pt + W < en ? pt + W : en;
+			}
+			// the walk (ksort.h:124-138), until it is finished or needs a record beyond a window
+			uint32_t k = S.k, i0 = S.i0, i = S.i, d = S.d;
+			bool inchase = S.inchase != 0, need = false;
+			while (k < 256) {
+				if (!inchase) {
+					const uint32_t pk = s_ptr[k];
+					if (pk >= s_end[k]) { ++k; if (k < 256 && s_end[k] > s_h0[k]) M.J[k] = s_ptr[k] - s_h0[k]; continue; }
+					if (pk >= s_lim[k]) { need = true; break; }
+					d = s_win[s_wb[k] + (pk & Wm)];
+					s_ptr[k] = pk + 1;
+					i0 = i = pk;
+					inchase = true;
+				}
+				while (d != k) {
+					const uint32_t j = s_ptr[d];
+					if (j >= s_lim[d]) { need = true; break; }
+					const uint32_t nd = s_win[s_wb[d] + (j & Wm)];
+					s_ptr[d] = j + 1;
+					dest[i] = j;
+					i = j; d = nd;
+				}
+				if (need) break;
+				dest[i] = i0;
+				inchase = false;
+			}
+			S.k = k; S.i0 = i0; S.i = i; S.d = d; S.inchase = inchase ? 1u : 0u; S.done = need ? 0u : 1u;
+		}
+		__syncthreads();
+		if (S.done) break;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ K8: placement
+__global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
+{
+	__shared__ uint32_t s_r;
+	__shared__ uint32_t s_start[257], s_hst[257], s_J[256], s_cw[BS_TILE_IT * (NT / 64)];
+	__shared__ uint8_t s_fate[256];
+	const uint32_t n_rng = C.hdr[0], tid = threadIdx.x;
+	if (blockIdx.x >= C.hdr[1]) return;
+	const uint32_t r = bs_find_range(C, blockIdx.x, n_rng, &s_r);
+	const bs_range R = C.rng[0][r];
+	const bs_meta &M = C.meta[r];
+	s_start[tid] = M.start[tid]; s_hst[tid] = M.hst[tid]; s_J[tid] = M.J[tid]; s_fate[tid] = M.fate[tid];
+	if (tid == 0) { s_start[256] = M.start[256]; s_hst[256] = M.hst[256]; }
+	__syncthreads();
+	const uint32_t t0 = (blockIdx.x - R.tile0) * BS_TILE, hbase = C.tile_h[blockIdx.x];
+	bs_cls q;
+	bs_classify(C.dg + R.beg, s_start, t0, R.n, s_cw, q);
+	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
+	rh_mm128_t *out_alt = C.buf[R.buf ^ 1] + R.beg, *out_fin = C.dst + R.beg;
+	const uint32_t *hp = C.hp + R.beg, *dest = C.dest + R.beg;
+#pragma unroll
+	for (int it = 0; it < BS_TILE_IT; ++it) {
+		const uint32_t p = t0 + (uint32_t)it * NT + tid;
+		if (p >= R.n) continue;
+		const uint32_t d = q.d[it], b = q.b[it], hb = hbase + q.hb[it];
+		uint32_t np;
+		if (d == b) np = p + ((hb - s_hst[b]) < s_J[b] ? 1u : 0u);
+		else {
+			const uint32_t j = dest[hb], jj = j - s_hst[d];
+			if (jj < s_J[d]) np = jj == 0 ? s_start[d] : hp[j - 1] + 1u;
+			else np = hp[j];
+		}
+		const rh_mm128_t rec = src[p];
+		if (s_fate[d] == BS_FINAL) out_fin[np] = rec; else out_alt[np] = rec;
+	}
+}
+
+// K9: the next level's ranges get their tile numbers; they become "this level"
+__global__ __launch_bounds__(NT) void k_bs_next(bs_ctx C)
+{
+	__shared__ uint32_t s_w[NT / 64];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t n = C.hdr[4] < C.rng_cap ? C.hdr[4] : C.rng_cap;
+	uint32_t run = 0;
+	for (uint32_t i0 = 0; i0 < n; i0 += NT) {
+		const uint32_t i = i0 + tid;
+		const uint32_t v = i < n ? (C.rng[1][i].n + BS_TILE - 1) / BS_TILE : 0u;
+		uint32_t tot;
+		const uint32_t ex = block_excl_scan(v, s_w, tot);
+		if (i < n) C.rng[1][i].tile0 = run + ex;
+		run += tot;
+	}
+	__syncthreads();
+	if (tid == 0) { C.hdr[0] = n; C.hdr[1] = run; C.hdr[4] = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+size_t rhk_bigsort_ws_bytes(uint64_t total, uint32_t n_lo)
+{
+	const uint64_t t = total ? total : 1, lo = n_lo ? n_lo : 1;
+	const uint64_t rng_cap = t / (lo + 1) + 2, small_cap = t / 4 + 256, tiles = t / BS_TILE + rng_cap + 2;
+	size_t b = 256;                                                // hdr
+	b += 2 * ((rng_cap * sizeof(bs_range) + 255) & ~(size_t)255);
+	b += (rng_cap * sizeof(bs_meta) + 255) & ~(size_t)255;
+	b += (tiles * 4 + 255) & ~(size_t)255;
+	b += 2 * ((t + 255) & ~(size_t)255);                           // dg, hd
+	b += 2 * ((t * 4 + 255) & ~(size_t)255);                       // hp, dest
+	b += 2 * ((small_cap * 8 + 255) & ~(size_t)255) + 2 * ((small_cap * 4 + 255) & ~(size_t)255);
+	return b;
+}
+
+int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n_lo)
+{
+	if (!jb.n_seg || !jb.big_alt || !jb.big_ws || !jb.big_pin) { rh_set_error("segment sorter: no scratch for segments beyond the LDS classes"); return -1; }
+	const uint64_t t = jb.big_total ? jb.big_total : 1, lo = n_lo ? n_lo : 1;
+	bs_ctx C{};
+	C.buf[0] = const_cast<rh_mm128_t*>(jb.src); C.buf[1] = jb.big_alt; C.dst = jb.dst;
+	C.n_lo = n_lo;
+	C.rng_cap = (uint32_t)(t / (lo + 1) + 2); C.small_cap = (uint32_t)(t / 4 + 256);
+	const uint64_t tiles_cap = t / BS_TILE + C.rng_cap + 2;
+	unsigned char *p = jb.big_ws;
+	auto take = [&](size_t bytes) { unsigned char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
+	C.hdr = (uint32_t*)take(256);
+	C.rng[0] = (bs_range*)take((size_t)C.rng_cap * sizeof(bs_range)); C.rng[1] = (bs_range*)take((size_t)C.rng_cap * sizeof(bs_range));
+	C.meta = (bs_meta*)take((size_t)C.rng_cap * sizeof(bs_meta));
+	C.tile_h = (uint32_t*)take(tiles_cap * 4);
+	C.dg = (uint8_t*)take(t); C.hd = (uint8_t*)take(t);
+	C.hp = (uint32_t*)take(t * 4); C.dest = (uint32_t*)take(t * 4);
+	for (int q = 0; q < 2; ++q) { C.small_off[q] = (uint64_t*)take((size_t)C.small_cap * 8); C.small_cnt[q] = (uint32_t*)take((size_t)C.small_cap * 4); }
+	if ((size_t)(p - jb.big_ws) > jb.big_ws_bytes) { rh_set_error("segment sorter: scratch of %zu bytes is too small (%zu needed)", jb.big_ws_bytes, (size_t)(p - jb.big_ws)); return -1; }
+	RH_LAUNCH(k_bs_init, 1, NT, 0, s, jb, C);
+	uint32_t *pin = (uint32_t*)jb.big_pin;
+	for (int level = 0; level < 9; ++level) {
+		RH_HIP(hipMemcpyAsync(pin, C.hdr, 32, hipMemcpyDeviceToHost, s));
+		RH_HIP(hipStreamSynchronize(s));
+		const uint32_t n_rng = pin[0], n_tiles = pin[1];
+		if (pin[5]) { rh_set_error("segment sorter: range / segment list overflow"); return -1; }
+		if (n_rng == 0) break;
+		RH_LAUNCH(k_bs_clear, n_rng, NT, 0, s, C);
+		RH_LAUNCH(k_bs_diff, n_tiles, NT, 0, s, C);
+		RH_LAUNCH(k_bs_hist, n_tiles, NT, 0, s, C);
+		RH_LAUNCH(k_bs_plan, n_rng, NT, 0, s, C);
+		RH_LAUNCH(k_bs_count, n_tiles, NT, 0, s, C);
+		RH_LAUNCH(k_bs_scan, n_rng, NT, 0, s, C);
+		RH_LAUNCH(k_bs_holes, n_tiles, NT, 0, s, C);
+		RH_LAUNCH(k_bs_walk, n_rng, 64, 0, s, C);
+		RH_LAUNCH(k_bs_scatter, n_tiles, NT, 0, s, C);
+		RH_LAUNCH(k_bs_next, 1, NT, 0, s, C);
+		bs_range *tmp = C.rng[0]; C.rng[0] = C.rng[1]; C.rng[1] = tmp;
+	}
+	// the buckets that fit the LDS classes finish in the block sorter, from the copy that holds them
+	for (int q = 0; q < 2; ++q) {
+		const uint32_t ns = pin[2 + q];
+		if (!ns) continue;
+		rh_sort_job sj = jb;
+		sj.n_seg = ns; sj.skip = nullptr; sj.off = C.small_off[q]; sj.cnt = C.small_cnt[q];
+		sj.src = C.buf[q]; sj.dst = jb.dst; sj.need_exact = nullptr; sj.n_max = n_lo;
+		sj.big_alt = nullptr; sj.big_ws = nullptr;
+		rhk_sort_job(s, sj, all_exact, 1u);
+	}
+	return 0;
+}

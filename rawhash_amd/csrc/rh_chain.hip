@@ -34,14 +34,25 @@ struct chain_lds {
 
 #define CH_FAR (INT32_MIN + 1)   // pair further apart than max_dist_t on the target: ends the predecessor window
 
-__global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr)
+#ifndef CH_TILE
+#define CH_TILE 4096             // anchors per wavefront when a read's anchors are split (multiple of 64)
+#endif
+
+// A read with many anchors (large indexes: tens of thousands per chunk) is split over several wavefronts: the clusters are
+// independent, so wavefront `tix` takes the clusters that START in [tix * tile_len, (tix + 1) * tile_len) - it skips the
+// tail of a cluster that began before its slice and runs past the end of the slice until the next cluster starts.
+__global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr, uint32_t tiles_per_read, uint32_t tile_len)
 {
 	__shared__ chain_lds L;
-	const uint32_t a = blockIdx.x, lane = threadIdx.x;
+	const uint32_t a = blockIdx.x / tiles_per_read, tix = blockIdx.x % tiles_per_read, lane = threadIdx.x;
 	if (a >= rr.n_act || rr.skip[a]) return;
 	const uint64_t base = rr.a_off[a];
 	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
 	if (n == 0) return;
+	const int32_t T0 = (int32_t)(tix * tile_len);
+	if (T0 >= n) return;
+	const int32_t T1 = tile_len && T0 + (int32_t)tile_len < n ? T0 + (int32_t)tile_len : n;
+	bool begun = T0 == 0;
 	const rh_mm128_t *an = rr.anc + base;
 	// DP output per anchor: {f, p} interleaved (one 8-byte record: the backtrack walk needs both per step), then v[]
 	int32_t *gfp = (int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR), *gv = gfp + 2 * (size_t)n;
@@ -57,22 +68,35 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 	// Anchors are read once, 64 at a time (coalesced); the sequential walk below only touches registers (shuffles) and LDS.
 	int32_t st = 0, max_ii = -1, f_ii = 0, open_start = 0;
 	uint32_t xlo_ii = 0;
-	uint64_t x_before = 0;                                         // x of the anchor preceding the tile
+	uint64_t x_before = T0 > 0 ? an[T0 - 1].x : 0ull;              // x of the anchor preceding the tile
 	// software pipeline over the tiles: A = current, B = next (needed to size a cluster that runs over the tile edge), C in flight
 	uint64_t xB = 0, yB = 0, xC = 0, yC = 0;
-	if ((int32_t)lane < n) { xB = an[lane].x; yB = an[lane].y; }
-	if (64 + (int32_t)lane < n) { xC = an[64 + lane].x; yC = an[64 + lane].y; }
-	for (int32_t i0 = 0; i0 < n; i0 += 64) {
+	if (T0 + (int32_t)lane < n) { xB = an[T0 + lane].x; yB = an[T0 + lane].y; }
+	if (T0 + 64 + (int32_t)lane < n) { xC = an[T0 + 64 + lane].x; yC = an[T0 + 64 + lane].y; }
+	for (int32_t i0 = T0; i0 < n; i0 += 64) {
 		const int32_t ii = i0 + (int32_t)lane;
-		const bool inb = ii < n;
+		const bool inb_r = ii < n;
 		const uint64_t x = xB, y = yB;
 		xB = xC; yB = yC;
 		if (ii + 128 < n) { xC = an[ii + 128].x; yC = an[ii + 128].y; } else { xC = 0; yC = 0; }
 		const uint64_t xprev = (uint64_t)rh_wave_shr1((uint32_t)(x >> 32), (uint32_t)(x_before >> 32)) << 32 | rh_wave_shr1((uint32_t)x, (uint32_t)x_before);
-		const bool start = inb && (ii == 0 || (x >> 32) != (xprev >> 32) || x > xprev + D64);
+		const bool start_r = inb_r && (ii == 0 || (x >> 32) != (xprev >> 32) || x > xprev + D64);
+		const uint64_t x_last = (uint64_t)rh_readlane((uint32_t)(x >> 32), 63u) << 32 | rh_readlane((uint32_t)x, 63u);
+		// this wavefront's share: from the first cluster start at or after T0 up to (not including) the first one at or after T1
+		const uint64_t sreal = __ballot(start_r);
+		bool incl = true, last_tile = false;
+		if (!begun) {
+			if (sreal) { begun = true; incl = lane >= (uint32_t)__builtin_ctzll(sreal); }
+			else incl = false;
+		}
+		if (T1 < n && i0 + 64 > T1) {
+			const uint64_t m = sreal & (T1 > i0 ? ~((1ull << (T1 - i0)) - 1ull) : ~0ull);
+			if (m) { incl = incl && lane < (uint32_t)__builtin_ctzll(m); last_tile = true; }
+		}
+		if (__ballot(incl && inb_r) == 0) { x_before = x_last; if (last_tile) break; continue; }
+		const bool inb = inb_r && incl, start = start_r && incl;
 		const uint64_t smask = __ballot(start);
 		const uint64_t bmask = __ballot(start || !inb);               // cluster boundaries, the end of the array included
-		const uint64_t x_last = (uint64_t)rh_readlane((uint32_t)(x >> 32), 63u) << 32 | rh_readlane((uint32_t)x, 63u);
 		const uint64_t xprevB = (uint64_t)rh_wave_shr1((uint32_t)(xB >> 32), (uint32_t)(x_last >> 32)) << 32 | rh_wave_shr1((uint32_t)xB, (uint32_t)x_last);
 		const uint64_t bmaskB = __ballot(ii + 64 >= n || (xB >> 32) != (xprevB >> 32) || xB > xprevB + D64);   // same for the next tile
 		const bool nstart = lane < 63 ? ((bmask >> (lane + 1)) & 1ull) != 0 : (bmaskB & 1ull) != 0;
@@ -254,6 +278,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 			}
 		}
 		x_before = x_last;
+		if (last_tile) break;
 	}
 }
 
@@ -309,6 +334,9 @@ __global__ void k_chain_serial(rh_dev_opt o, rh_dev_round rr)
 void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 {
 	if (!r.n_act) return;
-	if (o.max_iter <= CH_MAX_ITER) RH_LAUNCH(k_chain_wave, r.n_act, 64, 0, s, o, r);
+	if (o.max_iter <= CH_MAX_ITER) {
+		const uint32_t tiles = r.max_anchors > (uint32_t)CH_TILE ? (r.max_anchors + CH_TILE - 1) / CH_TILE : 1u;
+		RH_LAUNCH(k_chain_wave, r.n_act * tiles, 64, 0, s, o, r, tiles, tiles > 1 ? (uint32_t)CH_TILE : 0u);
+	}
 	else RH_LAUNCH(k_chain_serial, (r.n_act + 63) / 64, 64, 0, s, o, r);
 }

@@ -76,8 +76,41 @@ struct rh_dev_round {
 	uint64_t *u; uint32_t *n_u, *n_v;        // chains: score<<32 | count
 	rh_mm128_t *zs; uint32_t *n_z;           // backtrack candidates (score, anchor) in radix_sort_128x order
 	unsigned char *ws;               // RH_WS_PER_ANCHOR bytes per anchor
+	rh_mm128_t *sort_alt; unsigned char *sort_ws; size_t sort_ws_bytes; void *sort_pin; uint64_t sort_total;   // scratch of the multi-workgroup segment sorter (rh_bigsort.hip)
 	uint64_t *counters;              // [0] events [1] seeds [2] hits [3] anchors [4] chained [5] samples used [6] chunks
 };
+
+// ---- LDS size classes of the block sorter (rh_sort.hip)
+// Size classes = LDS footprints (12 B per record + ~4.5 KB) chosen for whole workgroups per CU; the allocation granularity
+// means a class must stay clearly below 160 KB / k to get k workgroups resident (measured: 54.0 KB gives 2, 52.4 KB gives 3).
+#ifndef RH_SORT_CAP0
+#define RH_SORT_CAP0 512      // ~10 KB: candidate / chain-key sorts and short anchor lists
+#endif
+#ifndef RH_SORT_CAP1
+#define RH_SORT_CAP1 2816     // ~38 KB: four workgroups per CU (a typical chunk's anchors)
+#endif
+#ifndef RH_SORT_CAP2
+#define RH_SORT_CAP2 3968     // ~52 KB: three
+#endif
+#ifndef RH_SORT_CAP3
+#define RH_SORT_CAP3 6144     // ~78 KB: two (unmapped reads accumulate carried anchors)
+#endif
+#ifndef RH_SORT_CAP4
+#define RH_SORT_CAP4 8192     // ~103 KB: one
+#endif
+
+// the same classes when the job's keys fit 32-bit words: 8 B of LDS per record
+#ifndef RH_SORT32_CAP1
+#define RH_SORT32_CAP1 4096     // ~38 KB: four workgroups per CU
+#endif
+#ifndef RH_SORT32_CAP2
+#define RH_SORT32_CAP2 5632     // ~51 KB: three
+#endif
+#ifndef RH_SORT32_CAP3
+#define RH_SORT32_CAP3 8192     // ~73 KB: two
+#endif
+
+#define RH_SORT_LDS_MIN_TOP (RH_SORT32_CAP3 < RH_SORT_CAP4 ? RH_SORT32_CAP3 : RH_SORT_CAP4)   // segments longer than this may need rh_bigsort.hip
 
 // a batch of independent 16-byte-record segments to be put into radix_sort_128x order (rh_sort.hip)
 struct rh_sort_job {
@@ -88,8 +121,14 @@ struct rh_sort_job {
 	// the LDS sorter keeps them as 32-bit words (8 instead of 12 bytes of LDS per record -> more workgroups per CU)
 	uint8_t kc_on, kc_lo, kc_mid, kc_hi;
 	uint32_t n_max;                          // no segment is longer than this (0 = unknown): size classes above it are not launched
+	// segments beyond the LDS classes (rh_bigsort.hip): a second record array the size of src (src itself is overwritten),
+	// scratch of rhk_bigsort_ws_bytes(big_total, ...) bytes, 32 pinned host bytes for the per-level read-backs
+	rh_mm128_t *big_alt; unsigned char *big_ws; size_t big_ws_bytes; void *big_pin; uint64_t big_total;
 };
-void rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n);   // segments with <= min_n records are left alone
+int rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n);   // segments with <= min_n records are left alone
+uint32_t rhk_sort_lds_max(const rh_sort_job &jb);                        // longest segment the LDS classes take for this job's keys
+size_t rhk_bigsort_ws_bytes(uint64_t total, uint32_t n_lo);
+int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n_lo);
 
 // kernel launchers (rh_kernels.hip)
 void rhk_prefilter(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd);
@@ -101,11 +140,11 @@ void rhk_sketch(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, cons
 void rhk_probe(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_scan_anchors(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
-void rhk_sort(hipStream_t s, const rh_dev_round &r);
+int rhk_sort(hipStream_t s, const rh_dev_round &r);
 void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
-void rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
-void rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
-void rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
+int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
+int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
+int rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r, const float *logf_tab);
 void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act_in, uint32_t n_in, uint32_t next_chunk,
                         uint32_t *act_out, uint32_t *n_out);

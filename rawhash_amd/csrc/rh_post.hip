@@ -905,35 +905,41 @@ __global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads r
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-void rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
+static void sort_scratch(rh_sort_job &jb, const rh_dev_round &r) { jb.big_alt = r.sort_alt; jb.big_ws = r.sort_ws; jb.big_ws_bytes = r.sort_ws_bytes; jb.big_pin = r.sort_pin; jb.big_total = r.sort_total; }
+
+int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 {
-	if (!r.n_act) return;
+	if (!r.n_act) return 0;
 	RH_LAUNCH(k_zbuild, r.n_act, 64, 0, s, o, r);
 	// candidates (score, anchor index) -> reference order; scores are full of ties: exact permutation for every read
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_z, r.raw, r.zs, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 64, (uint8_t)(o.min_sc >= 0), 32, 0, 0, r.max_anchors };   // keys = scores >= min_sc: non-negative int32
-	rhk_sort_job(s, jb, true, 0u);
+	sort_scratch(jb, r);
+	return rhk_sort_job(s, jb, true, 0u);
 }
 
-void rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
+int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
 {
-	if (!r.n_act) return;
+	if (!r.n_act) return 0;
 	RH_LAUNCH(k_backtrack_spec, r.n_act, 64, 0, s, o, rd, r);
 	// compact_a: chains gathered, put into the reference's order of their first anchor, written back
 	RH_LAUNCH(k_chain_gather, r.n_act, NT, 0, s, r);
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };   // keys = first anchors
-	rhk_sort_job(s, jb, false, 0u);
+	sort_scratch(jb, r);
+	if (rhk_sort_job(s, jb, false, 0u)) return -1;
 	RH_LAUNCH(k_chain_reorder, r.n_act, NT, 0, s, rd, r);
+	return 0;
 }
 
 static bool regions_wave_ok(const rh_dev_opt &o) { return o.best_n == 0 && o.pri_ratio > 0.0f && !(o.flag & RH_M_ALL_CHAINS); }
 
 // chain heads + hashed keys of reads with many chains, put into the reference's order (hit.c:111-126)
-void rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
+int rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
 {
-	if (!r.n_act || !regions_wave_ok(o)) return;
+	if (!r.n_act || !regions_wave_ok(o)) return 0;
 	RH_LAUNCH(k_regions_prep, r.n_act, 64, 0, s, o, rd, r);
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, 0, 0, 0, 0, r.max_anchors };   // keys = hashed: full 64 bits
-	rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL);
+	sort_scratch(jb, r);
+	return rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL);
 }
 
 void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r, const float *logf_tab)

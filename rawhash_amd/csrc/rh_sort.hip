@@ -591,407 +591,6 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 	if (tid < SORT_TG && tid < L.n_tg && L.tg_fin[tid] != 0xFFFFu) dst[L.tg_fin[tid]] = src[L.tg_idx[tid]];   // settled by pop order
 }
 
-// ------------------------------------------------------------------------------------------------ segments beyond the LDS classes
-// Same algorithm, one workgroup per segment, with the arrangement and a copy of the keys in arrangement order in HBM
-// scratch (L2-resident, 28 B per record; every pass moves index and key together, so key reads are coalesced): larger genomes put tens of thousands of anchors into one chunk.
-// Only the histogram / bucket heads and, for the exact cycle walk, the digits of the range being walked live in LDS.
-#ifndef RH_SORT_GCAP
-#define RH_SORT_GCAP (1u << 20)    // records per segment; beyond: the serial emulation
-#endif
-#ifndef RH_SORTG_DB
-#define RH_SORTG_DB 49152          // records of a range whose digits the exact walk caches in LDS
-#endif
-
-struct sortg_lds {
-	uint32_t cnt[256], head[256];
-	uint8_t dmap[256], inv[256];
-	uint32_t w[NT / 64];
-	uint64_t r64[NT / 64];
-	uint32_t n_rng[2], tie, misc[4];
-	uint32_t tg_idx[SORT_TG], tg_pos[SORT_TG], tg_fin[SORT_TG], tlist[SORT_TG];   // tied records, as in sort_lds
-	uint8_t tg_rng[SORT_TG];
-	uint32_t n_tg, n_tl;
-	uint8_t db[RH_SORTG_DB];
-};
-struct sortg_mem {
-	const rh_mm128_t *src;
-	uint32_t *ia, *ib, *tm;            // arrangement, pass output, scratch (rank lists / gather map)
-	uint64_t *kp, *kb;                 // the keys in arrangement order (moved with every pass: all key reads are coalesced), pass output
-	uint32_t *sbit, *ebit, *tbit;
-	uint64_t *rng[2];                  // ranges > 64 still to be split: beg | end << 32
-	uint8_t *rsh[2];
-};
-
-RH_DEV uint64_t sortg_key(const sortg_mem &G, uint32_t i) { return G.kp[i]; }
-RH_DEV uint32_t sortg_digit(const sortg_mem &G, uint32_t i, int s) { return (uint32_t)(sortg_key(G, i) >> s) & 255u; }
-
-// one wavefront: the reference's cycle walk over >= 3 buckets (see sort_cycle_walk_hb); digits from the LDS cache when the
-// range fits it, else recomputed from the keys; gather map -> G.tm
-RH_DEV void sortg_cycle_walk(sortg_lds &L, const sortg_mem &G, uint32_t beg, uint32_t end, int s, uint32_t nbk, bool cached)
-{
-	const uint32_t lane = lane_id();
-	uint32_t hd[4], tl[4];
-#pragma unroll
-	for (int q = 0; q < 4; ++q) {
-		const uint32_t id = (uint32_t)q * 64u + lane;
-		hd[q] = 0; tl[q] = 0;
-		if (id < nbk) { const uint32_t dgt = L.inv[id]; hd[q] = L.head[dgt] - beg; tl[q] = hd[q] + L.cnt[dgt]; }
-	}
-	const uint32_t ubeg = rh_uniform(beg);
-	uint32_t *tmr = G.tm + ubeg;
-	#define SG_DIGIT(p) rh_uniform(cached ? (uint32_t)L.db[(p)] : (uint32_t)L.dmap[sortg_digit(G, ubeg + (p), s)])
-	for (uint32_t c = 0; c < nbk; ++c) {
-		uint32_t tlc = rh_readlane(tl[0], c & 63u), h = rh_readlane(hd[0], c & 63u);
-#pragma unroll
-		for (int q = 1; q < 4; ++q) { const uint32_t t2 = rh_readlane(tl[q], c & 63u), h2 = rh_readlane(hd[q], c & 63u); if ((c >> 6) == (uint32_t)q) { tlc = t2; h = h2; } }
-		while (h != tlc) {
-			uint32_t src = h;
-			uint32_t d = SG_DIGIT(h);
-			while (d != c) {
-				uint32_t r[4];
-#pragma unroll
-				for (int k = 0; k < 4; ++k) r[k] = rh_readlane(hd[k], d & 63u);
-				uint32_t q = r[0];
-#pragma unroll
-				for (int k = 1; k < 4; ++k) q = (d >> 6) == (uint32_t)k ? r[k] : q;
-#pragma unroll
-				for (int k = 0; k < 4; ++k) hd[k] = rh_writelane(hd[k], (d >> 6) == (uint32_t)k ? q + 1 : r[k], d & 63u);
-				tmr[q] = ubeg + src;
-				src = q;
-				d = SG_DIGIT(q);
-			}
-			tmr[h] = ubeg + src;
-			++h;
-		}
-	}
-	#undef SG_DIGIT
-}
-
-// the pop-order short cut of sort_cycle_walk_early on the LDS digit cache (bit 7 of a cached digit = tied record)
-RH_DEV void sortg_cycle_walk_early(sortg_lds &L, uint32_t beg, uint32_t nbk, uint32_t stop)
-{
-	const uint32_t lane = lane_id();
-	uint32_t hd[2], tl[2];
-#pragma unroll
-	for (int q = 0; q < 2; ++q) {
-		const uint32_t id = (uint32_t)q * 64u + lane;
-		hd[q] = 0; tl[q] = 0;
-		if (id < nbk) { const uint32_t dgt = L.inv[id]; hd[q] = L.head[dgt] - beg; tl[q] = hd[q] + L.cnt[dgt]; }
-	}
-	const uint32_t ubeg = rh_uniform(beg);
-	uint32_t ntl = 0;
-	for (uint32_t c = 0; c < nbk && ntl < stop; ++c) {
-		uint32_t tlc = rh_readlane(tl[0], c & 63u), h = rh_readlane(hd[0], c & 63u);
-		{ const uint32_t t2 = rh_readlane(tl[1], c & 63u), h2 = rh_readlane(hd[1], c & 63u); if ((c >> 6) == 1u) { tlc = t2; h = h2; } }
-		while (h != tlc && ntl < stop) {
-			uint32_t db = rh_uniform((uint32_t)L.db[h]);
-			if (db >> 7) L.tlist[ntl++] = ubeg + h;
-			uint32_t d = db & 127u;
-			while (d != c && ntl < stop) {
-				const uint32_t r0 = rh_readlane(hd[0], d & 63u), r1 = rh_readlane(hd[1], d & 63u);
-				const uint32_t q = (d >> 6) == 1u ? r1 : r0;
-				hd[0] = rh_writelane(hd[0], (d >> 6) == 0u ? q + 1 : r0, d & 63u);
-				hd[1] = rh_writelane(hd[1], (d >> 6) == 1u ? q + 1 : r1, d & 63u);
-				db = rh_uniform((uint32_t)L.db[q]);
-				if (db >> 7) L.tlist[ntl++] = ubeg + q;
-				d = db & 127u;
-			}
-			++h;
-		}
-	}
-	if (lane == 0) L.n_tl = ntl;
-}
-
-RH_DEV void sortg_split_range(sortg_lds &L, const sortg_mem &G, uint32_t beg, uint32_t end, int shift, int nxt, int pass)
-{
-	const uint32_t tid = threadIdx.x;
-	const uint64_t k0 = sortg_key(G, beg);
-	uint64_t diff = 0;
-	bool tied = false;
-	for (uint32_t i = beg + tid; i < end; i += NT) {
-		diff |= G.kp[i] ^ k0;
-		if (pass == SORT_EXACT_TIED) { const uint32_t idx = G.ia[i]; tied |= (G.tbit[idx >> 5] >> (idx & 31u) & 1u) != 0; }
-	}
-	const uint64_t tmk = __ballot(tied);
-	if (lane_id() == 0) L.w[wave_id()] = tmk != 0;
-	diff = block_or64(diff, L.r64);
-	if (diff == 0) return;
-	if (pass == SORT_EXACT_TIED && (L.w[0] | L.w[1] | L.w[2] | L.w[3]) == 0) {
-		__syncthreads();                                     // (as in sort_split_range: the next call rewrites the flags)
-		return;
-	}
-	const bool exact = pass != SORT_FAST;
-	int s = (63 - __clzll(diff)) & ~7;
-	if (s > shift) s = shift;
-	L.cnt[tid] = 0;
-	__syncthreads();
-	for (uint32_t i = beg + tid; i < end; i += NT) atomicAdd(&L.cnt[sortg_digit(G, i, s)], 1u);
-	__syncthreads();
-	const uint32_t my_cnt = L.cnt[tid];
-	uint32_t total;
-	const uint32_t my_start = beg + block_excl_scan(my_cnt, L.w, total);
-	L.head[tid] = my_start;
-	uint32_t nbk;
-	const uint32_t dense = block_rank(my_cnt != 0, L.w, nbk);
-	if (exact && my_cnt != 0) { L.dmap[tid] = (uint8_t)dense; L.inv[dense] = (uint8_t)tid; }
-	// permutation of the pass: ia[beg, end) -> ib[beg, end)
-	if (!exact) {
-		for (uint32_t i = beg + tid; i < end; i += NT) { const uint64_t k = G.kp[i]; const uint32_t pos = atomicAdd(&L.head[(uint32_t)(k >> s) & 255u], 1u); G.ib[pos] = G.ia[i]; G.kb[pos] = k; }
-	} else if (nbk == 2) {
-		// two buckets A < B: closed form of the cycle-leader result (see sort_two_buckets), rank lists in G.tm
-		if (my_cnt != 0) { const uint32_t which = my_start == beg ? 0u : 1u; L.misc[which] = tid; L.misc[2 + which] = my_start; }
-		__syncthreads();
-		const uint32_t cA = L.misc[0], cB = L.misc[1], startB = L.misc[3];
-		// ranks of the misplaced records inside A and inside B: each wavefront owns a contiguous quarter of either region
-		// (tiles of 64, ballots only); one barrier turns the per-wavefront counts into offsets
-		const uint32_t w = wave_id(), l = lane_id();
-		const uint32_t lenA = startB - beg, lenB = end - startB;
-		const uint32_t perA = ((lenA + NT - 1) / NT) * 64u, perB = ((lenB + NT - 1) / NT) * 64u;
-		const uint32_t a0 = beg + (w * perA < lenA ? w * perA : lenA), a1 = a0 + perA < startB ? a0 + perA : startB;
-		const uint32_t b0 = startB + (w * perB < lenB ? w * perB : lenB), b1 = b0 + perB < end ? b0 + perB : end;
-		uint32_t ca = 0, cb = 0;
-		for (uint32_t base = a0; base < a1; base += 64) { const uint32_t i = base + l; ca += (uint32_t)__popcll(__ballot(i < a1 && sortg_digit(G, i, s) == cB)); }
-		for (uint32_t base = b0; base < b1; base += 64) { const uint32_t i = base + l; cb += (uint32_t)__popcll(__ballot(i < b1 && sortg_digit(G, i, s) == cA)); }
-		if (l == 0) L.r64[w] = (uint64_t)ca | (uint64_t)cb << 32;
-		__syncthreads();
-		uint32_t ra = 0, rb = 0, m = 0;
-		for (uint32_t q = 0; q < NT / 64; ++q) { const uint64_t c2 = L.r64[q]; if (q < w) { ra += (uint32_t)c2; rb += (uint32_t)(c2 >> 32); } m += (uint32_t)c2; }
-		for (uint32_t base = a0; base < a1; base += 64) {
-			const uint32_t i = base + l;
-			const bool foreign = i < a1 && sortg_digit(G, i, s) == cB;
-			const uint64_t B = __ballot(foreign);
-			if (i < a1) { if (foreign) G.tm[beg + ra + lanes_below(B)] = i; else { G.ib[i] = G.ia[i]; G.kb[i] = G.kp[i]; } }
-			ra += (uint32_t)__popcll(B);
-		}
-		__syncthreads();
-		for (uint32_t base = b0; base < b1; base += 64) {
-			const uint32_t i = base + l;
-			const bool foreign = i < b1 && sortg_digit(G, i, s) == cA;
-			const uint64_t B = __ballot(foreign);
-			if (i < b1) {
-				const uint32_t r = rb + lanes_below(B);                 // misplaced records of B before slot i
-				if (foreign) { const uint32_t d = G.tm[beg + r]; G.ib[d] = G.ia[i]; G.kb[d] = G.kp[i]; G.tm[end - 1 - r] = i; }
-				else { const uint32_t d = r < m ? i + 1 : i; G.ib[d] = G.ia[i]; G.kb[d] = G.kp[i]; }
-			}
-			rb += (uint32_t)__popcll(B);
-		}
-		__syncthreads();
-		for (uint32_t k = tid; k < m; k += NT) { const uint32_t d = k == 0 ? startB : G.tm[end - k] + 1u, sp = G.tm[beg + k]; G.ib[d] = G.ia[sp]; G.kb[d] = G.kp[sp]; }
-	} else {
-		const bool cached = end - beg <= (uint32_t)RH_SORTG_DB;
-		__syncthreads();
-		if (pass == SORT_EXACT_TIED && cached && nbk <= 128 && L.n_tg <= SORT_TG) {
-			// the order of a few tied records whose buckets are final after this pass: pop order (see sort_split_range)
-			if (tid < SORT_TG) L.tg_rng[tid] = 0;
-			if (tid == 0) L.misc[0] = 0;
-			__syncthreads();
-			bool bad = false;
-			const uint32_t ntg = L.n_tg;
-			for (uint32_t i = beg + tid; i < end; i += NT) {
-				const uint32_t idx = G.ia[i];
-				const uint32_t dgt = (uint32_t)(G.kp[i] >> s) & 255u, tb = (G.tbit[idx >> 5] >> (idx & 31u)) & 1u;
-				L.db[i - beg] = (uint8_t)(L.dmap[dgt] | tb << 7);
-				if (tb) {
-					if (s > 0 && L.cnt[dgt] > 64u) bad = true;
-					for (uint32_t e = 0; e < ntg; ++e) if (L.tg_idx[e] == idx) L.tg_rng[e] = 1;
-					atomicAdd(&L.misc[0], 1u);
-				}
-			}
-			const uint64_t bm = __ballot(bad);
-			if (lane_id() == 0) L.w[wave_id()] = bm != 0;
-			__syncthreads();
-			if ((L.w[0] | L.w[1] | L.w[2] | L.w[3]) == 0) {
-				if (wave_id() == 0) sortg_cycle_walk_early(L, beg, nbk, L.misc[0] - 1);
-				__syncthreads();
-				if (tid < ntg && L.tg_rng[tid]) {
-					const uint32_t idx = L.tg_idx[tid], gs = L.tg_pos[tid], ntl = L.n_tl;
-					uint32_t in_group = 0, mine = ~0u;
-					for (uint32_t r = 0; r < ntl; ++r) {
-						const uint32_t qi = G.ia[L.tlist[r]];
-						uint32_t g2 = ~0u;
-						for (uint32_t e = 0; e < ntg; ++e) if (L.tg_idx[e] == qi) g2 = L.tg_pos[e];
-						if (g2 == gs) { if (qi == idx) mine = in_group; ++in_group; }
-					}
-					L.tg_fin[tid] = gs + (mine != ~0u ? mine : in_group);
-					atomicAnd(&G.tbit[idx >> 5], ~(1u << (idx & 31u)));
-				}
-				__syncthreads();
-				return;
-			}
-		}
-		if (cached) for (uint32_t i = beg + tid; i < end; i += NT) L.db[i - beg] = L.dmap[sortg_digit(G, i, s)];
-		__syncthreads();
-		if (wave_id() == 0) sortg_cycle_walk(L, G, beg, end, s, nbk, cached);
-		__syncthreads();
-		for (uint32_t i = beg + tid; i < end; i += NT) { const uint32_t sp = G.tm[i]; G.ib[i] = G.ia[sp]; G.kb[i] = G.kp[sp]; }
-	}
-	__syncthreads();
-	for (uint32_t i = beg + tid; i < end; i += NT) { G.ia[i] = G.ib[i]; G.kp[i] = G.kb[i]; }
-	if (s > 0 && my_cnt > 1) {
-		if (my_cnt > 64) { const uint32_t k = atomicAdd(&L.n_rng[nxt], 1u); G.rng[nxt][k] = (uint64_t)my_start | (uint64_t)(my_start + my_cnt) << 32; G.rsh[nxt][k] = (uint8_t)(s - 8); }
-		else { const uint32_t e = my_start + my_cnt - 1; atomicOr(&G.sbit[my_start >> 5], 1u << (my_start & 31u)); atomicOr(&G.ebit[e >> 5], 1u << (e & 31u)); }
-	}
-	__syncthreads();
-}
-
-RH_DEV void sortg_run(sortg_lds &L, const sortg_mem &G, uint32_t n, int pass)
-{
-	const uint32_t tid = threadIdx.x;
-	for (uint32_t i = tid; i < n; i += NT) { G.ia[i] = i; G.kp[i] = G.src[i].x; }
-	for (uint32_t i = tid; i < n / 32 + 3; i += NT) { G.sbit[i] = 0; G.ebit[i] = 0; }
-	__syncthreads();
-	if (tid == 0) {
-		L.n_rng[0] = 0; L.n_rng[1] = 0;
-		if (n > 64) { G.rng[0][0] = (uint64_t)n << 32; G.rsh[0][0] = 56; L.n_rng[0] = 1; }
-		else if (n > 1) { G.sbit[0] = 1u; G.ebit[(n - 1) >> 5] = 1u << ((n - 1) & 31u); }
-	}
-	__syncthreads();
-	for (int cur = 0;; cur ^= 1) {
-		const uint32_t nr = L.n_rng[cur];
-		if (nr == 0) break;
-		for (uint32_t ri = 0; ri < nr; ++ri) {
-			const uint64_t be = G.rng[cur][ri];
-			sortg_split_range(L, G, (uint32_t)be, (uint32_t)(be >> 32), (int)G.rsh[cur][ri], cur ^ 1, pass);
-		}
-		__syncthreads();
-		if (tid == 0) L.n_rng[cur] = 0;
-		__syncthreads();
-	}
-	// Ranges of <= 64 records (with 256 buckets per pass there are thousands of them, a handful of records each): one
-	// THREAD per record - it finds its range in the start / end bit masks, ranks its key among the range's keys and moves
-	// its record there.  Every load is independent of the other threads', so the L2 latency is paid 256-fold in parallel
-	// (a wavefront per range paid it once per range, in sequence).
-	for (uint32_t i0 = 0; i0 < n; i0 += NT) {
-		const uint32_t i = i0 + tid;
-		uint32_t dest = ~0u;
-		if (i < n) {
-			// 64-bit windows of the masks: bit k of lo* = position i - 63 + k (k = 63 is i itself), bit k of hi = position i + k
-			uint64_t los = 0, loe = 0, hie = 0;
-			{
-				const int64_t p0 = (int64_t)i - 63;
-				for (int q = 0; q < 3; ++q) {
-					const int64_t wi = (p0 >> 5) + q;                 // words covering [i - 63, i]
-					if (wi < 0) continue;
-					const uint64_t ws = G.sbit[wi], we = G.ebit[wi];
-					const int64_t sh = wi * 32 - p0;                   // position of the word's bit 0 inside the window
-					los |= sh >= 0 ? (sh < 64 ? ws << sh : 0) : ws >> -sh;
-					loe |= sh >= 0 ? (sh < 64 ? we << sh : 0) : we >> -sh;
-				}
-				for (int q = 0; q < 3; ++q) {
-					const uint32_t wi = (i >> 5) + (uint32_t)q;
-					if (wi >= n / 32 + 3) break;
-					const uint64_t we = G.ebit[wi];
-					const int32_t sh = (int32_t)(wi * 32) - (int32_t)i;
-					hie |= sh >= 0 ? (sh < 64 ? we << sh : 0) : we >> -sh;
-				}
-			}
-			if (los && hie) {
-				const uint32_t kb = 63u - (uint32_t)__clzll(los);          // window bit of the nearest start at or before i
-				const uint64_t between = kb < 63 ? (loe >> kb) & ((1ull << (63 - kb)) - 1ull) : 0ull;   // ends in [start, i)
-				if (between == 0) {
-					const uint32_t b = i - (63u - kb), e = i + (uint32_t)__builtin_ctzll(hie);
-					if (e - b < 64) {
-						const uint64_t k = G.kp[i];
-						uint32_t rank = 0, tiedr = 0;
-						for (uint32_t j0 = b; j0 <= e; j0 += 8) {	// eight independent (coalesced-ish) key loads at a time
-							uint64_t kj[8];
-#pragma unroll
-							for (uint32_t q = 0; q < 8; ++q) kj[q] = G.kp[j0 + q <= e ? j0 + q : e];
-#pragma unroll
-							for (uint32_t q = 0; q < 8; ++q) if (j0 + q <= e) rank += (kj[q] < k || (kj[q] == k && j0 + q < i)) ? 1u : 0u;
-						}
-						if (pass == SORT_EXACT_TIED) for (uint32_t j = b; j <= e; ++j) { const uint32_t jx = G.ia[j]; tiedr |= (G.tbit[jx >> 5] >> (jx & 31u)) & 1u; }
-						if (pass != SORT_EXACT_TIED || tiedr) dest = b + rank;
-					}
-				}
-			}
-		}
-		if (i < n) G.tm[i] = dest;
-	}
-	__syncthreads();
-	for (uint32_t i = tid; i < n; i += NT) { const uint32_t d = G.tm[i]; if (d != ~0u) { G.ib[d] = G.ia[i]; G.kb[d] = G.kp[i]; } }
-	__syncthreads();
-	for (uint32_t i = tid; i < n; i += NT) if (G.tm[i] != ~0u) { G.ia[i] = G.ib[i]; G.kp[i] = G.kb[i]; }
-	__syncthreads();
-}
-
-__global__ __launch_bounds__(NT) void k_sort_gmem(rh_sort_job jb, uint32_t n_lo, uint32_t n_hi, int mode)
-{
-	__shared__ sortg_lds L;
-	const uint32_t a = blockIdx.x, tid = threadIdx.x;
-	if (a >= jb.n_seg || (jb.skip && jb.skip[a])) return;
-	const uint64_t base = jb.off[a];
-	const uint32_t n = jb.cnt ? jb.cnt[a] : (uint32_t)(jb.off[a + 1] - base);
-	if (n <= n_lo || n > n_hi) return;
-	const rh_mm128_t *src = jb.src + base;
-	rh_mm128_t *dst = jb.dst + base;
-	// scratch of the segment: (stride - skip) bytes per record of the owning read, >= 64
-	unsigned char *S = jb.scratch + base * jb.scratch_stride + (uint64_t)jb.scratch_skip * (jb.off[a + 1] - base);
-	const uint32_t n4 = (n + 3u) & ~3u, W = n / 32 + 3, R = n / 64 + 4;
-	sortg_mem G;
-	G.src = src;
-	G.kp = (uint64_t*)S; G.kb = G.kp + n4;
-	G.ia = (uint32_t*)(G.kb + n4); G.ib = G.ia + n4; G.tm = G.ib + n4;
-	G.sbit = G.tm + n4; G.ebit = G.sbit + W; G.tbit = G.ebit + W;
-	G.rng[0] = (uint64_t*)(((uintptr_t)(G.tbit + W) + 7) & ~(uintptr_t)7); G.rng[1] = G.rng[0] + R;
-	G.rsh[0] = (uint8_t*)(G.rng[1] + R); G.rsh[1] = G.rsh[0] + R;
-	for (uint32_t i = tid; i < W; i += NT) G.tbit[i] = 0;
-	if (tid == 0) { L.tie = 0; L.n_tg = 0; }
-	__syncthreads();
-	sortg_run(L, G, n, mode == 0 ? SORT_FAST : SORT_EXACT_ALL);
-	for (uint32_t i = tid; i < n; i += NT) dst[i] = src[G.ia[i]];
-	if (mode != 0) return;
-	for (uint32_t i = tid; i < n; i += NT) {
-		const uint64_t k = G.kp[i];
-		if ((i > 0 && G.kp[i - 1] == k) || (i + 1 < n && G.kp[i + 1] == k)) {
-			const uint32_t idx = G.ia[i];
-			atomicOr(&G.tbit[idx >> 5], 1u << (idx & 31u));
-			L.tie = 1;
-			uint32_t gs = i;
-			while (gs > 0 && G.kp[gs - 1] == k) --gs;
-			const uint32_t slot = atomicAdd(&L.n_tg, 1u);
-			if (slot < SORT_TG) { L.tg_idx[slot] = idx; L.tg_pos[slot] = gs; L.tg_fin[slot] = ~0u; }
-		}
-	}
-	__syncthreads();
-	const uint32_t tie = L.tie;
-	if (tid == 0 && jb.need_exact) jb.need_exact[a] = (uint8_t)tie;
-	if (!tie) return;
-	sortg_run(L, G, n, SORT_EXACT_TIED);
-	for (uint32_t i = tid; i < n; i += NT) { const uint32_t idx = G.ia[i]; if ((G.tbit[idx >> 5] >> (idx & 31u)) & 1u) dst[i] = src[idx]; }
-	if (tid < SORT_TG && tid < L.n_tg && L.tg_fin[tid] != ~0u) dst[L.tg_fin[tid]] = src[L.tg_idx[tid]];   // settled by pop order
-}
-
-// reads too large for LDS: copy, then the serial in-place emulation (one read per lane)
-__global__ void k_sort_big(rh_sort_job jb, uint32_t n_lo)
-{
-	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-	if (a >= jb.n_seg || (jb.skip && jb.skip[a])) return;
-	const uint64_t base = jb.off[a];
-	const uint32_t n = jb.cnt ? jb.cnt[a] : (uint32_t)(jb.off[a + 1] - base);
-	if (n <= n_lo) return;
-	for (uint32_t i = 0; i < n; ++i) jb.dst[base + i] = jb.src[base + i];
-	rh_radix_sort_128x(jb.dst + base, n, (uint32_t*)(jb.scratch + base * jb.scratch_stride + jb.scratch_skip * (jb.off[a + 1] - base)));
-}
-
-// Size classes = LDS footprints (12 B per record + ~4.5 KB) chosen for whole workgroups per CU; the allocation granularity
-// means a class must stay clearly below 160 KB / k to get k workgroups resident (measured: 54.0 KB gives 2, 52.4 KB gives 3).
-#ifndef RH_SORT_CAP0
-#define RH_SORT_CAP0 512      // ~10 KB: candidate / chain-key sorts and short anchor lists
-#endif
-#ifndef RH_SORT_CAP1
-#define RH_SORT_CAP1 2816     // ~38 KB: four workgroups per CU (a typical chunk's anchors)
-#endif
-#ifndef RH_SORT_CAP2
-#define RH_SORT_CAP2 3968     // ~52 KB: three
-#endif
-#ifndef RH_SORT_CAP3
-#define RH_SORT_CAP3 6144     // ~78 KB: two (unmapped reads accumulate carried anchors)
-#endif
-#ifndef RH_SORT_CAP4
-#define RH_SORT_CAP4 8192     // ~103 KB: one
-#endif
-
 template <int CAP, class KT>
 static void launch_class(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t lo, uint32_t hi)
 {
@@ -999,22 +598,15 @@ static void launch_class(hipStream_t s, const rh_sort_job &jb, bool all_exact, u
 	RH_LAUNCH((k_sort_block<CAP, KT>), jb.n_seg, NT, 0, s, jb, lo, hi, all_exact ? 2 : 0);
 }
 
-// the same classes when the job's keys fit 32-bit words: 8 B of LDS per record
-#ifndef RH_SORT32_CAP1
-#define RH_SORT32_CAP1 4096     // ~38 KB: four workgroups per CU
-#endif
-#ifndef RH_SORT32_CAP2
-#define RH_SORT32_CAP2 5632     // ~51 KB: three
-#endif
-#ifndef RH_SORT32_CAP3
-#define RH_SORT32_CAP3 8192     // ~73 KB: two
-#endif
+static bool sort_keys32(const rh_sort_job &jb) { return jb.kc_on && (uint32_t)jb.kc_lo + jb.kc_mid + jb.kc_hi <= 32u && jb.kc_mid <= 24u; }
 
-void rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n)
+uint32_t rhk_sort_lds_max(const rh_sort_job &jb) { return sort_keys32(jb) ? (uint32_t)RH_SORT32_CAP3 : (uint32_t)RH_SORT_CAP4; }
+
+int rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n)
 {
-	if (!jb.n_seg) return;
+	if (!jb.n_seg) return 0;
 	uint32_t top;
-	if (jb.kc_on && (uint32_t)jb.kc_lo + jb.kc_mid + jb.kc_hi <= 32u && jb.kc_mid <= 24u) {
+	if (sort_keys32(jb)) {
 		launch_class<RH_SORT_CAP0, uint32_t>(s, jb, all_exact, min_n, (uint32_t)RH_SORT_CAP0);
 		launch_class<RH_SORT32_CAP1, uint32_t>(s, jb, all_exact, (uint32_t)RH_SORT_CAP0, (uint32_t)RH_SORT32_CAP1);
 		launch_class<RH_SORT32_CAP2, uint32_t>(s, jb, all_exact, (uint32_t)RH_SORT32_CAP1, (uint32_t)RH_SORT32_CAP2);
@@ -1028,13 +620,17 @@ void rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t
 		launch_class<RH_SORT_CAP4, uint64_t>(s, jb, all_exact, (uint32_t)RH_SORT_CAP3, (uint32_t)RH_SORT_CAP4);
 		top = (uint32_t)RH_SORT_CAP4;
 	}
-	if (!jb.n_max || top < jb.n_max) RH_LAUNCH(k_sort_gmem, jb.n_seg, NT, 0, s, jb, top, (uint32_t)RH_SORT_GCAP, all_exact ? 2 : 0);
-	if (!jb.n_max || (uint32_t)RH_SORT_GCAP < jb.n_max) RH_LAUNCH(k_sort_big, (jb.n_seg + 63) / 64, 64, 0, s, jb, (uint32_t)RH_SORT_GCAP);
+	// longer segments: many workgroups per segment, level by level (rh_bigsort.hip)
+	if (!jb.n_max || top < jb.n_max) return rhk_bigsort(s, jb, all_exact, top);
+	return 0;
 }
 
+static void sort_scratch(rh_sort_job &jb, const rh_dev_round &r) { jb.big_alt = r.sort_alt; jb.big_ws = r.sort_ws; jb.big_ws_bytes = r.sort_ws_bytes; jb.big_pin = r.sort_pin; jb.big_total = r.sort_total; }
+
 // anchor sort of a chunk round: unsorted expand output -> reference order
-void rhk_sort(hipStream_t s, const rh_dev_round &r)
+int rhk_sort(hipStream_t s, const rh_dev_round &r)
 {
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, nullptr, r.raw, r.anc, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 0, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };
-	rhk_sort_job(s, jb, false, 0u);
+	sort_scratch(jb, r);
+	return rhk_sort_job(s, jb, false, 0u);
 }

@@ -51,6 +51,8 @@ static inline unsigned __shfl(unsigned v, int lane) { return (unsigned)emu_shfl_
 static inline int __shfl(int v, int lane) { return (int)emu_shfl_bits((unsigned)v, 5, (unsigned)lane); }
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p += v; return o; }
+static inline unsigned long long atomicOr(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p |= v; return o; }
+static inline unsigned long long atomicAnd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p &= v; return o; }
 static inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p |= v; return o; }
 static inline unsigned atomicAnd(unsigned *p, unsigned v) { unsigned o = *p; *p &= v; return o; }
 static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }

@@ -231,6 +231,41 @@ def check_sort(ctx, seed=0, n_seg=40, big=()):
         assert np.all(seg[:-1] <= seg[1:])
 
 
+def check_sort_big(ctx, seed=0, sizes=(20000, 33000, 9000), kinds=(0, 1, 2, 3, 4)):
+    """Segments beyond the LDS classes (the multi-workgroup level-by-level sorter): anchor-like keys over many targets with
+    duplicated positions, chain-score keys with one dominant value, random 64-bit keys, one hot byte, all keys equal."""
+    rng = np.random.default_rng(seed)
+    segs = []
+    for i, n in enumerate(sizes):
+        kind = kinds[i % len(kinds)]
+        if kind == 0:      # strand | 24 targets | position, 5 % duplicated keys (a seed repeated inside the chunk)
+            x = (rng.integers(0, 2, size=n, dtype=np.uint64) << np.uint64(63)) | (rng.integers(0, 24, size=n, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, 1 << 27, size=n, dtype=np.uint64)
+            j = rng.integers(0, n, size=n // 20)
+            x[rng.integers(0, n, size=n // 20)] = x[j]
+        elif kind == 1:    # backtrack candidates: scores, nearly all equal to the span
+            x = np.full(n, 13, dtype=np.uint64)
+            j = rng.integers(0, n, size=n // 12)
+            x[j] = rng.integers(14, 400, size=len(j), dtype=np.uint64)
+        elif kind == 2:
+            x = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+        elif kind == 3:    # three values of one byte, the rest equal
+            x = (rng.integers(0, 3, size=n, dtype=np.uint64) << np.uint64(8 * int(rng.integers(1, 8)))) | np.uint64(7)
+        else:
+            x = np.full(n, 0x0123456789ABCDEF, dtype=np.uint64)
+        segs.append(x)
+    off = np.zeros(len(sizes) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in segs])
+    a = np.zeros(int(off[-1]), dtype=MM128)
+    a["x"] = np.concatenate(segs)
+    a["y"] = np.arange(len(a), dtype=np.uint64)
+    want = a.copy()
+    assert O.lib().ro_sort128x_batch(len(sizes), ptr(want), ptr(off)) == 0
+    got = ctx.sort128x(a, off)
+    assert np.array_equal(got["x"], want["x"]), "not sorted like the reference"
+    bad = np.nonzero(got["y"] != want["y"])[0]
+    assert len(bad) == 0, f"{len(bad)} records out of the reference's order, first at {bad[:5]}"
+
+
 def check_e2e(ctx, wl, reads=None):
     reads = reads or wl.reads
     recs = ctx.map_batch(wl.opts, reads)

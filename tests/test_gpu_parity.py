@@ -55,6 +55,15 @@ def test_exact_sort(ctx):
     pc.check_sort(ctx, seed=5, n_seg=40, big=(8193, 9000, 20000, 70000, 30000, 12345, 100000, 16384, 50000, 65537, 33333, 9999))
 
 
+def test_exact_sort_multi_workgroup(ctx):
+    """Segments beyond the LDS classes (rh_bigsort.hip): every key kind, several levels, one segment of more than 2^20
+    records, and many segments at once (thousands of ranges per level)."""
+    pc.check_sort_big(ctx, seed=11, sizes=(30000, 70000, 9000, 8193, 250000, 40000, 100000, 16385))
+    pc.check_sort_big(ctx, seed=12, sizes=(1_200_000, 300_000), kinds=(0, 1))
+    pc.check_sort_big(ctx, seed=13, sizes=(1_100_000,), kinds=(2,))
+    pc.check_sort_big(ctx, seed=14, sizes=tuple([30000 + 17 * i for i in range(300)]), kinds=(0, 1, 0, 0, 3))
+
+
 def test_chain_adversarial(ctx, wl):
     """few reads -> workgroup walk in LDS; thousands -> the 64-candidates-per-round wave kernel"""
     for n_reads, max_n, seed in ((48, 900, 1), (2300, 260, 2), (2100, 60, 3)):
