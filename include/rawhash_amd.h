@@ -138,6 +138,19 @@ RH_API int  rh_index_copy_blob(rh_ctx *ctx, void *dst_dev_ptr);   /* device-to-d
 RH_API int  rh_index_adopt_blob(rh_ctx *ctx, const rh_index *idx_meta /* may be NULL */, void *dev_ptr, uint64_t bytes,
                                 const void *header /* from rank 0 */, int take_ownership);
 
+/* ri_idx_gen rindex.c:900 on the GPU: sketches the targets, sorts and groups the seeds and fills the
+ * HBM-resident table of this context directly (as rh_index_upload would), in seconds for a human-sized reference.
+ * seqs[i] = the bases of target i in host memory (ACGTU in either case; anything else is an ambiguous base,
+ * ri_seq_to_sig rsig.c:13-41), lens[i] < 2^31.  Minimiser indexes (w > 0) and signal-target indexes are built by
+ * rh_index_build on the host.  The returned host object carries the header, target names/lengths and the occupancy
+ * statistics rh_mapopt_update needs; rh_index_download fetches keys and positions (for rh_index_get or to write a .ind
+ * with rh_index_write). */
+RH_API rh_index *rh_index_build_device(rh_ctx *ctx, uint32_t n_seq, const char *const *names, const char *const *seqs, const uint32_t *lens,
+                                       const char *pore_model_path, const rh_idxopt_t *io, int n_threads);
+RH_API rh_index *rh_index_build_device_fasta(rh_ctx *ctx, const char *fasta_path, const char *pore_model_path, const rh_idxopt_t *io, int n_threads);
+RH_API int  rh_index_download(rh_ctx *ctx, rh_index *idx, int n_threads);
+RH_API int  rh_index_write(const rh_index *idx, const char *out_ind);          /* ri_idx_dump rindex.c:545 */
+
 /* ------------------------------------------------------------------------------------------- the hot path */
 /* = kt_for(n_threads, map_worker_for, step, n_sig)  rmap.cpp:700 / map_worker_for rmap.cpp:389.
  * out must hold at least rh_map_max_records(batch, mo) records; *n_out receives the count.  Records are ordered by
@@ -210,6 +223,8 @@ typedef struct rh_synth_cfg_s {
 RH_API void rh_synth_cfg_init(rh_synth_cfg_t *c);
 RH_API int  rh_synth_write_model(const rh_synth_cfg_t *c, const char *path);
 RH_API int  rh_synth_write_fasta(const rh_synth_cfg_t *c, const char *path);
+/* bases of chromosome `chrom` ("chr<chrom+1>") into out[0 .. chrom_len): the same sequence rh_synth_write_fasta writes */
+RH_API int  rh_synth_genome(const rh_synth_cfg_t *c, uint32_t chrom, char *out, int n_threads);
 /* reads [first, first+n): samples must hold n*n_samples int16; names (optional) n*64 chars */
 RH_API int  rh_synth_reads(const rh_synth_cfg_t *c, const char *model_path, uint64_t first, uint32_t n,
                            int16_t *samples, char *names64, int n_threads);

@@ -123,6 +123,10 @@ def _declare(lib):
         "rh_index_get": (vp, [vp, u64, P(C.c_int)]),
         "rh_ctx_create": (i32, [P(vp), i32]), "rh_ctx_destroy": (None, [vp]),
         "rh_index_upload": (i32, [vp, vp]),
+        "rh_index_build_device": (vp, [vp, u32, P(cp), P(cp), vp, cp, P(IdxOpt), i32]),
+        "rh_index_build_device_fasta": (vp, [vp, cp, cp, P(IdxOpt), i32]),
+        "rh_index_download": (i32, [vp, vp, i32]), "rh_index_write": (i32, [vp, cp]),
+        "rh_synth_genome": (i32, [P(SynthCfg), u32, vp, i32]),
         "rh_index_device_blob": (i32, [vp, P(vp), P(u64), vp]),
         "rh_index_adopt_blob": (i32, [vp, vp, vp, u64, vp, i32]),
         "rh_map_max_records": (u64, [P(ReadBatch), P(MapOpt)]),

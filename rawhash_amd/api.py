@@ -61,6 +61,37 @@ class Index:
             raise RhError(_capi.last_error(l))
         return cls(h, l)
 
+    @classmethod
+    def build_device(cls, ctx, fasta, pore_model, opts, n_threads=8):
+        """ri_idx_gen on the GPU: the table is left resident in `ctx` (no upload needed); FASTA read on the host."""
+        l = ctx._l
+        h = l.rh_index_build_device_fasta(ctx.h, os.fsencode(fasta), os.fsencode(pore_model), C.byref(opts.io), n_threads)
+        if not h:
+            raise RhError(_capi.last_error(l))
+        return cls(h, l)
+
+    @classmethod
+    def build_device_seqs(cls, ctx, names, seqs, pore_model, opts, n_threads=8):
+        """Same from sequences already in host memory: seqs = list of uint8 numpy arrays (ASCII bases)."""
+        l = ctx._l
+        n = len(seqs)
+        keep = [np.ascontiguousarray(s, dtype=np.uint8) for s in seqs]
+        np_arr = (C.c_char_p * n)(*[x.encode() for x in names])
+        sp_arr = (C.c_char_p * n)(*[C.cast(k.ctypes.data, C.c_char_p) for k in keep])
+        lens = np.array([len(k) for k in keep], dtype=np.uint32)
+        h = l.rh_index_build_device(ctx.h, n, np_arr, sp_arr, ptr(lens), os.fsencode(pore_model), C.byref(opts.io), n_threads)
+        if not h:
+            raise RhError(_capi.last_error(l))
+        return cls(h, l)
+
+    def download(self, ctx, n_threads=8):
+        """Fetch keys + positions of a device-built index into this host object (for get() / write())."""
+        _check(self._l.rh_index_download(ctx.h, self.h, n_threads), self._l)
+        return self
+
+    def write(self, path):
+        _check(self._l.rh_index_write(self.h, os.fsencode(path)), self._l)
+
     def close(self):
         if self.h:
             self._l.rh_index_destroy(self.h)
@@ -303,6 +334,12 @@ class SynthWorkload:
         _check(self._l.rh_synth_write_model(C.byref(self.cfg), os.fsencode(model)), self._l)
         _check(self._l.rh_synth_write_fasta(C.byref(self.cfg), os.fsencode(fasta)), self._l)
         return fasta, model
+
+    def genome(self, chrom, n_threads=8):
+        """Bases of one chromosome as a uint8 array (what write_reference puts into the FASTA)."""
+        out = np.empty(self.cfg.chrom_len, dtype=np.uint8)
+        _check(self._l.rh_synth_genome(C.byref(self.cfg), chrom, ptr(out), n_threads), self._l)
+        return out
 
     def reads(self, model_path, first, n, n_threads=8, with_names=True):
         ns = self.cfg.n_samples

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librawhash_amd.so")
 OBJ = os.path.join(HERE, "_obj")
-SOURCES = ["rh_common.cpp", "rh_options.cpp", "rh_reads.cpp", "rh_synth.cpp", "rh_index.cpp", "rh_paf.cpp", "rh_api.cpp", "rh_kernels.hip", "rh_sort.hip", "rh_bigsort.hip", "rh_chain.hip", "rh_post.hip"]
+SOURCES = ["rh_common.cpp", "rh_options.cpp", "rh_reads.cpp", "rh_synth.cpp", "rh_index.cpp", "rh_paf.cpp", "rh_api.cpp", "rh_kernels.hip", "rh_sort.hip", "rh_bigsort.hip", "rh_index_device.hip", "rh_chain.hip", "rh_post.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result", "-x", "hip", "-I", os.path.join(HERE, "..", "include")]
 

@@ -282,13 +282,8 @@ extern "C" void rh_ctx_destroy(rh_ctx *c)
 // Blob layout: [table: nb*8 slots of 16 B][pos: n_pos u64][seq_len: n_seq u32]; the 256-byte header describes it so
 // that another rank can adopt a broadcast copy.
 namespace {
-struct BlobHeader {
-	uint64_t magic, bytes, table_off, pos_off, len_off, n_pos;
-	int32_t lg_buckets; uint32_t n_seq; int32_t flag;
-	rh_sketch_par sp;
-	uint32_t max_len;
-};
-const uint64_t kBlobMagic = 0x3130424958444952ULL;   // "RIDXIB01"
+typedef rh_blob_header BlobHeader;
+const uint64_t kBlobMagic = RH_BLOB_MAGIC;
 
 int bind_blob(rh_ctx *c, const BlobHeader &h)
 {
@@ -361,6 +356,77 @@ extern "C" int rh_index_adopt_blob(rh_ctx *c, const rh_index *, void *dev_ptr, u
 	if (c->blob_owned) c->blob.release();
 	c->blob.p = dev_ptr; c->blob.cap = bytes; c->blob_owned = take_ownership != 0;
 	return bind_blob(c, h);
+}
+
+// =================================================================================================== index built on the device
+extern "C" rh_index *rh_index_build_device(rh_ctx *c, uint32_t n_seq, const char *const *names, const char *const *seqs, const uint32_t *lens,
+                                           const char *pore_model_path, const rh_idxopt_t *io, int n_threads)
+{
+	if (hipSetDevice(c->device) != hipSuccess) { rh_set_error("hipSetDevice failed"); return nullptr; }
+	if (io->flag & RH_I_SIG_TARGET) { rh_set_error("signal-target (Rawsamble) indexes are built by rh_index_build_signals"); return nullptr; }
+	if (io->w != 0) { rh_set_error("minimiser indexes (w = %d) are built on the host: rh_index_build", io->w); return nullptr; }
+	if (io->e < 1 || io->e > 16 || io->q < 1 || io->q * io->e > 64 || io->k < 1 || io->k > 12) { rh_set_error("unsupported index parameters e=%d q=%d k=%d", io->e, io->q, io->k); return nullptr; }
+	std::unique_ptr<rh_index_s> ix(new rh_index_s());
+	ix->w = io->w; ix->e = io->e; ix->n = io->n; ix->q = io->q; ix->k = io->k; ix->flag = io->flag;
+	ix->diff = io->diff; ix->fine_min = io->fine_min; ix->fine_max = io->fine_max; ix->fine_range = io->fine_range;
+	if (!rh_load_model(pore_model_path, io->k, io->lev_col, ix->pore_vals)) return nullptr;
+	ix->n_pore_vals = (uint32_t)ix->pore_vals.size(); ix->pore_k = (int16_t)io->k;
+	rh_make_pore_inds(ix->pore_vals, io->k, ix->pore_inds);
+	for (uint32_t i = 0; i < n_seq; ++i) { ix->names.push_back(names && names[i] ? names[i] : ""); ix->lens.push_back(lens[i]); }
+	// the resident index of this context is replaced
+	if (c->blob_owned) c->blob.release(); else { c->blob.p = nullptr; c->blob.cap = 0; }
+	c->have_index = false;
+	BlobHeader h{};
+	void *blob = nullptr;
+	uint64_t n_keys = 0;
+	if (rhk_index_build_device(c->stream, n_seq, seqs, lens, ix->pore_vals, io, &h, &blob, ix->occ_hist, &n_keys, n_threads)) return nullptr;
+	c->blob.p = blob; c->blob.cap = h.bytes; c->blob.owned = true; c->blob_owned = true;
+	if (bind_blob(c, h)) return nullptr;
+	ix->dev_n_keys = n_keys; ix->dev_n_pos = h.n_pos;
+	return ix.release();
+}
+
+extern "C" rh_index *rh_index_build_device_fasta(rh_ctx *c, const char *fasta_path, const char *pore_model_path, const rh_idxopt_t *io, int n_threads)
+{
+	std::vector<std::string> names, seqs;
+	if (!rh_read_fasta(fasta_path, names, seqs)) return nullptr;
+	std::vector<const char*> np, sp; std::vector<uint32_t> ln;
+	for (size_t i = 0; i < seqs.size(); ++i) {
+		if (seqs[i].size() >= (1ull << 31)) { rh_set_error("%s: sequence %s is too long", fasta_path, names[i].c_str()); return nullptr; }
+		np.push_back(names[i].c_str()); sp.push_back(seqs[i].data()); ln.push_back((uint32_t)seqs[i].size());
+	}
+	return rh_index_build_device(c, (uint32_t)seqs.size(), np.data(), sp.data(), ln.data(), pore_model_path, io, n_threads);
+}
+
+// keys and positions of the resident index back into the host object (hash order), for rh_index_get / rh_index_write
+extern "C" int rh_index_download(rh_ctx *c, rh_index *ix, int n_threads)
+{
+	if (need_index(c)) return -1;
+	RH_HIP(hipSetDevice(c->device));
+	BlobHeader h; memcpy(&h, c->header, sizeof(h));
+	const uint64_t n_slots = (uint64_t)RH_TB_SLOTS << h.lg_buckets;
+	std::vector<rh_tslot> slots(n_slots);
+	RH_HIP(hipMemcpy(slots.data(), c->blob.as<unsigned char>() + h.table_off, n_slots * sizeof(rh_tslot), hipMemcpyDeviceToHost));
+	ix->pos.resize(h.n_pos);
+	if (h.n_pos) RH_HIP(hipMemcpy(ix->pos.data(), c->blob.as<unsigned char>() + h.pos_off, h.n_pos * 8, hipMemcpyDeviceToHost));
+	// non-empty slots by the top byte of the hash, each range sorted concurrently
+	if (n_threads < 1) n_threads = 1;
+	std::vector<uint64_t> cnt(257, 0);
+	for (const rh_tslot &sl : slots) if (sl.n) ++cnt[(sl.hash >> 24) + 1];
+	for (int i = 0; i < 256; ++i) cnt[i + 1] += cnt[i];
+	std::vector<rh_tslot> ent(cnt[256]);
+	{ std::vector<uint64_t> w(cnt.begin(), cnt.end() - 1); for (const rh_tslot &sl : slots) if (sl.n) ent[w[sl.hash >> 24]++] = sl; }
+	std::vector<rh_tslot>().swap(slots);
+	{
+		std::vector<std::thread> th;
+		for (int t = 0; t < n_threads; ++t)
+			th.emplace_back([&, t]() { for (int b = t; b < 256; b += n_threads) std::sort(ent.begin() + cnt[b], ent.begin() + cnt[b + 1], [](const rh_tslot &a, const rh_tslot &b2) { return a.hash < b2.hash; }); });
+		for (auto &t : th) t.join();
+	}
+	const size_t nk = ent.size();
+	ix->key_hash.resize(nk); ix->key_n.resize(nk); ix->key_val.resize(nk);
+	for (size_t i = 0; i < nk; ++i) { ix->key_hash[i] = ent[i].hash; ix->key_n[i] = ent[i].n; ix->key_val[i] = ent[i].val; }
+	return 0;
 }
 
 // =================================================================================================== the hot path

@@ -28,7 +28,7 @@
 #endif
 #define BS_TILE (NT * BS_TILE_IT)
 #ifndef BS_WIN_BYTES
-#define BS_WIN_BYTES 32768                // LDS of the token walk's stream windows
+#define BS_WIN_BYTES 4096                 // LDS of the token walk's stream windows (>= 512: two entries for each of 256 regions)
 #endif
 
 struct bs_range {
@@ -49,8 +49,9 @@ struct bs_meta {
 	uint32_t hst[257];                    // holes before each region (= index of the region's first hole)
 	uint32_t J[256];                      // arrivals of a region before the walk turns to it
 	uint8_t fate[256];                    // 0 empty, 1 final, 2 block sorter, 3 next level
+	uint8_t act[256], dmap[256];          // regions with holes, renumbered 0 .. nh-1 in digit order: dense -> digit, digit -> dense
 	int32_t s;                            // byte shift of this level (-1: all keys equal)
-	uint32_t pad;
+	uint32_t nh;
 };
 enum { BS_EMPTY = 0, BS_FINAL = 1, BS_SMALL = 2, BS_BIG = 3 };
 
@@ -302,11 +303,15 @@ __global__ __launch_bounds__(NT) void k_bs_scan(bs_ctx C)
 		if (i < nt) C.tile_h[R.tile0 + i] = run + ex;
 		run += tot;
 	}
-	uint32_t total;
+	uint32_t total, nh;
 	const uint32_t m = M.cnt[tid] - M.inpl[tid];
 	const uint32_t hs = block_excl_scan(m, s_w, total);
 	M.hst[tid] = hs;
-	if (tid == 0) M.hst[256] = total;
+	const uint32_t q = block_rank(m != 0, s_w, nh);
+	M.dmap[tid] = (uint8_t)q;
+	if (m != 0) M.act[q] = (uint8_t)tid;
+	M.J[tid] = 0;
+	if (tid == 0) { M.hst[256] = total; M.nh = nh; }
 }
 
 // K6: the holes in position order: digit of the record, position
@@ -319,7 +324,8 @@ __global__ __launch_bounds__(NT) void k_bs_holes(bs_ctx C)
 	const uint32_t r = bs_find_range(C, blockIdx.x, n_rng, &s_r);
 	const bs_range R = C.rng[0][r];
 	const bs_meta &M = C.meta[r];
-	s_start[tid] = M.start[tid];
+	__shared__ uint8_t s_dmap[256];
+	s_start[tid] = M.start[tid]; s_dmap[tid] = M.dmap[tid];
 	if (tid == 0) s_start[256] = M.start[256];
 	__syncthreads();
 	const uint32_t t0 = (blockIdx.x - R.tile0) * BS_TILE, hbase = C.tile_h[blockIdx.x];
@@ -330,89 +336,151 @@ __global__ __launch_bounds__(NT) void k_bs_holes(bs_ctx C)
 #pragma unroll
 	for (int it = 0; it < BS_TILE_IT; ++it) {
 		const uint32_t p = t0 + (uint32_t)it * NT + tid;
-		if (p < R.n && q.d[it] != q.b[it]) { const uint32_t g = hbase + q.hb[it]; hd[g] = (uint8_t)q.d[it]; hp[g] = p; }
+		if (p < R.n && q.d[it] != q.b[it]) { const uint32_t g = hbase + q.hb[it]; hd[g] = s_dmap[q.d[it]]; hp[g] = p; }   // (a misplaced record's own region has a hole for it)
 	}
 }
 
 // ------------------------------------------------------------------------------------------------ K7: the token walk
-// One wavefront per range.  Lane 0 walks; the hole-digit streams of the regions are staged through LDS windows (ring
-// per region, refilled by all lanes when the walker runs into the end of one).  Two regions with holes: closed form
-// (the i-th hole of the lower region trades with the i-th of the upper one), all lanes.
-struct bs_walk_state { uint32_t k, i0, i, d, inchase, need, done; };
+// The regions with holes are renumbered 0 .. nh-1 (digit order); the hole streams hold these dense numbers.
+//
+// k_bs_walk_lanes: ONE LANE per range (3 <= nh <= BS_LANE_NH).  A step is one dependent pair of loads (the region's
+// pointer from the lane's LDS column, the digit waiting there from the stream in HBM/L2); a wavefront advances 64 walks
+// per instruction, and the chip holds thousands of wavefronts: with tens of thousands of ranges per level (two per read)
+// the serial walks run at memory-system throughput instead of one walk's latency.
+// k_bs_walk_wave: one WAVEFRONT per range for the rest - nh == 2 is closed form (the i-th hole of the lower region
+// trades with the i-th of the upper one; all lanes), nh > BS_LANE_NH walks on lane 0 with the streams staged through
+// LDS windows (a ring per region, filled in aligned half-window blocks by all lanes) and one LDS read on the
+// dependency chain per step (s_head[region] = pointer + the digit waiting there + the region's window slot).
+#ifndef BS_LANE_NH
+#define BS_LANE_NH 32
+#endif
+#ifndef BS_LANES_MIN_RANGES
+#define BS_LANES_MIN_RANGES 256           // ranges of a level from which the one-lane-per-range walker is used
+#endif
 
-__global__ __launch_bounds__(64) void k_bs_walk(bs_ctx C)
+__global__ __launch_bounds__(64) void k_bs_walk_lanes(bs_ctx C)
+{
+	__shared__ uint32_t s_ptr[BS_LANE_NH * 64];
+	const uint32_t lane = threadIdx.x, r = blockIdx.x * 64 + lane, n_rng = C.hdr[0];
+	const bool mine = r < n_rng && C.meta[r].nh >= 3 && C.meta[r].nh <= (uint32_t)BS_LANE_NH;
+	if (__ballot(mine) == 0) return;
+	const bs_range R = C.rng[0][mine ? r : 0];
+	bs_meta &M = C.meta[mine ? r : 0];
+	const uint32_t nh = mine ? M.nh : 0u;
+	for (uint32_t q = 0; q < nh; ++q) s_ptr[q * 64 + lane] = M.hst[M.act[q]];
+	const uint8_t *hd = C.hd + R.beg;
+	uint32_t *dest = C.dest + R.beg;
+	uint32_t k = 0, pk = 0, ek = 0, i0 = 0, i = 0, d = 0;
+	bool inchase = false, live = mine;
+	if (live) { pk = M.hst[M.act[0]]; ek = M.hst[M.act[0] + 1u]; }
+	while (__ballot(live)) {
+		if (live) {
+			uint32_t j;
+			if (!inchase) {
+				while (pk >= ek) {	// region k is complete: the walk turns to the next one (arrivals so far = its J)
+					if (++k >= nh) { live = false; break; }
+					const uint32_t dk = M.act[k], h0 = M.hst[dk];
+					pk = s_ptr[k * 64 + lane]; ek = M.hst[dk + 1u];
+					M.J[dk] = pk - h0;
+				}
+				if (live) { j = pk++; i0 = j; }
+			} else {
+				j = s_ptr[d * 64 + lane];
+				s_ptr[d * 64 + lane] = j + 1u;
+				dest[i] = j;
+			}
+			if (live) {
+				i = j;
+				d = hd[j];
+				inchase = d != k;
+				if (!inchase) dest[i] = i0;
+			}
+		}
+	}
+}
+
+#define BS_INVALID (1u << 31)
+struct bs_walk_state { uint32_t k, i0, i, d, inchase, done; };
+
+__global__ __launch_bounds__(64) void k_bs_walk_wave(bs_ctx C, int all)
 {
 	__shared__ uint8_t s_win[BS_WIN_BYTES];
-	__shared__ uint32_t s_ptr[256], s_lim[256], s_end[256], s_h0[256], s_wb[256];
-	__shared__ uint8_t s_act[256];
-	__shared__ uint32_t s_nh;
+	__shared__ uint64_t s_head[256];                               // ptr | (digit | invalid << 31) << 32, by dense region
+	__shared__ uint32_t s_lim[256], s_end[256], s_h0[256];
 	__shared__ bs_walk_state S;
 	const uint32_t r = blockIdx.x, lane = threadIdx.x;
 	if (r >= C.hdr[0]) return;
 	const bs_range R = C.rng[0][r];
 	bs_meta &M = C.meta[r];
-	for (uint32_t d = lane; d < 256; d += 64) { s_ptr[d] = M.hst[d]; s_h0[d] = M.hst[d]; s_end[d] = M.hst[d + 1]; s_lim[d] = M.hst[d]; M.J[d] = 0; }
+	const uint32_t nh = M.nh;
+	if (nh == 0 || (!all && nh >= 3 && nh <= (uint32_t)BS_LANE_NH)) return;
+	for (uint32_t q = lane; q < nh; q += 64) { const uint32_t dk = M.act[q]; s_h0[q] = M.hst[dk]; s_end[q] = M.hst[dk + 1u]; }
 	__syncthreads();
-	if (lane == 0) { uint32_t nh = 0; for (uint32_t d = 0; d < 256; ++d) if (s_end[d] > s_ptr[d]) s_act[nh++] = (uint8_t)d; s_nh = nh; }
-	__syncthreads();
-	const uint32_t nh = s_nh;
-	if (nh == 0) return;
 	const uint8_t *hd = C.hd + R.beg;
 	uint32_t *dest = C.dest + R.beg;
 	if (nh == 2) {
-		const uint32_t A = s_act[0], B = s_act[1], hA = s_h0[A], hB = s_h0[B], m = s_end[A] - hA;
+		const uint32_t hA = s_h0[0], hB = s_h0[1], m = s_end[0] - hA;
 		for (uint32_t i = lane; i < m; i += 64) { dest[hA + i] = hB + i; dest[hB + i] = hA + i; }
-		if (lane == 0) M.J[B] = m;
+		if (lane == 0) M.J[M.act[1]] = m;
 		return;
 	}
-	uint32_t W = 1;                                                // window entries per region: a power of two, nh * W <= BS_WIN_BYTES (>= 256)
-	while (W * 2 * nh <= (uint32_t)BS_WIN_BYTES && W < (1u << 20)) W *= 2;
-	const uint32_t Wm = W - 1, Wlow = W / 2 ? W / 2 : 1u;
-	if (lane == 0) {
-		for (uint32_t q = 0; q < nh; ++q) s_wb[s_act[q]] = q * W;
-		S.k = 0; S.i0 = 0; S.i = 0; S.d = 0; S.inchase = 0; S.need = 1; S.done = 0;
-	}
+	uint32_t logW = 1;                                             // window entries per region: 2^logW, nh << logW <= BS_WIN_BYTES (>= 512)
+	while ((nh << (logW + 1)) <= (uint32_t)BS_WIN_BYTES && logW < 16) ++logW;
+	const uint32_t Wm = (1u << logW) - 1, logH = logW - 1, Hm = (1u << logH) - 1;
+	// a region's loaded stretch ends at s_lim (a multiple of the half window; it may lie beyond the region's end: nothing
+	// past the end is ever popped); blocks (ptr >> logH) and the one after it fit the ring
+	for (uint32_t q = lane; q < nh; q += 64) { s_head[q] = (uint64_t)s_h0[q] | (uint64_t)BS_INVALID << 32; s_lim[q] = (s_h0[q] >> logH) << logH; }
+	if (lane == 0) { S.k = 0; S.i0 = 0; S.i = 0; S.d = 0; S.inchase = 0; S.done = 0; }
 	__syncthreads();
 	for (;;) {
-		// refill: every region whose window is more than half used gets it topped up to W entries ahead of its pointer
 		for (uint32_t q = 0; q < nh; ++q) {
-			const uint32_t d = s_act[q], pt = s_ptr[d], lim = s_lim[d], en = s_end[d];
-			if (lim >= en || lim - pt >= Wlow) continue;
-			const uint32_t nl = pt + W < en ? pt + W : en;
-			for (uint32_t g = lim + lane; g < nl; g += 64) s_win[s_wb[d] + (g & Wm)] = hd[g];
+			const uint32_t pt = (uint32_t)s_head[q], lim = s_lim[q], en = s_end[q];
+			const uint32_t tgt = ((pt >> logH) + 2u) << logH;
+			if (pt >= en || lim >= tgt) continue;
+			const uint32_t base = q << logW, top = tgt < en ? tgt : en;
+			for (uint32_t g = lim + lane; g < top; g += 64) s_win[base + (g & Wm)] = hd[g];
 		}
 		__syncthreads();
 		if (lane == 0) {
 			for (uint32_t q = 0; q < nh; ++q) {
-				const uint32_t d = s_act[q], pt = s_ptr[d], lim = s_lim[d], en = s_end[d];
-				if (lim >= en || lim - pt >= Wlow) continue;
-				s_lim[d] = pt + W < en ? pt + W : en;
+				const uint32_t pt = (uint32_t)s_head[q], en = s_end[q];
+				if (pt >= en) continue;
+				const uint32_t tgt = ((pt >> logH) + 2u) << logH;
+				if (s_lim[q] < tgt) s_lim[q] = tgt;
+				s_head[q] = (uint64_t)pt | (uint64_t)s_win[(q << logW) + (pt & Wm)] << 32;
 			}
 			// the walk (ksort.h:124-138), until it is finished or needs a record beyond a window
 			uint32_t k = S.k, i0 = S.i0, i = S.i, d = S.d;
 			bool inchase = S.inchase != 0, need = false;
-			while (k < 256) {
+			#define BS_ADVANCE(b, j) do { \
+				const uint32_t jn_ = (j) + 1u; \
+				const uint32_t nx_ = s_win[((b) << logW) + (jn_ & Wm)]; \
+				const uint32_t inv_ = ((jn_ & Hm) == 0u && jn_ >= s_lim[b]) ? BS_INVALID : 0u; \
+				s_head[b] = (uint64_t)jn_ | (uint64_t)(nx_ | inv_) << 32; } while (0)
+			while (k < nh) {
 				if (!inchase) {
-					const uint32_t pk = s_ptr[k];
-					if (pk >= s_end[k]) { ++k; if (k < 256 && s_end[k] > s_h0[k]) M.J[k] = s_ptr[k] - s_h0[k]; continue; }
-					if (pk >= s_lim[k]) { need = true; break; }
-					d = s_win[s_wb[k] + (pk & Wm)];
-					s_ptr[k] = pk + 1;
+					const uint64_t h = s_head[k];
+					const uint32_t pk = (uint32_t)h, hi = (uint32_t)(h >> 32);
+					if (pk >= s_end[k]) { ++k; if (k < nh) M.J[M.act[k]] = (uint32_t)s_head[k] - s_h0[k]; continue; }
+					if (hi & BS_INVALID) { need = true; break; }
+					BS_ADVANCE(k, pk);
+					d = hi & 255u;
 					i0 = i = pk;
 					inchase = true;
 				}
 				while (d != k) {
-					const uint32_t j = s_ptr[d];
-					if (j >= s_lim[d]) { need = true; break; }
-					const uint32_t nd = s_win[s_wb[d] + (j & Wm)];
-					s_ptr[d] = j + 1;
+					const uint64_t h = s_head[d];
+					const uint32_t j = (uint32_t)h, hi = (uint32_t)(h >> 32);
+					if (hi & BS_INVALID) { need = true; break; }
+					BS_ADVANCE(d, j);
 					dest[i] = j;
-					i = j; d = nd;
+					i = j; d = hi & 255u;
 				}
 				if (need) break;
 				dest[i] = i0;
 				inchase = false;
 			}
+			#undef BS_ADVANCE
 			S.k = k; S.i0 = i0; S.i = i; S.d = d; S.inchase = inchase ? 1u : 0u; S.done = need ? 0u : 1u;
 		}
 		__syncthreads();
@@ -525,7 +593,10 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		RH_LAUNCH(k_bs_count, n_tiles, NT, 0, s, C);
 		RH_LAUNCH(k_bs_scan, n_rng, NT, 0, s, C);
 		RH_LAUNCH(k_bs_holes, n_tiles, NT, 0, s, C);
-		RH_LAUNCH(k_bs_walk, n_rng, 64, 0, s, C);
+		// few ranges: a wavefront each (nothing to gain from 64 walks per wavefront); many: one lane each where the regions fit
+		const int lanes = n_rng >= (uint32_t)BS_LANES_MIN_RANGES;
+		RH_LAUNCH(k_bs_walk_wave, n_rng, 64, 0, s, C, lanes ? 0 : 1);
+		if (lanes) RH_LAUNCH(k_bs_walk_lanes, (n_rng + 63) / 64, 64, 0, s, C);
 		RH_LAUNCH(k_bs_scatter, n_tiles, NT, 0, s, C);
 		RH_LAUNCH(k_bs_next, 1, NT, 0, s, C);
 		bs_range *tmp = C.rng[0]; C.rng[0] = C.rng[1]; C.rng[1] = tmp;

@@ -219,6 +219,10 @@ bool write_ind(const rh_index_s &ix, const char *path)
 
 } // namespace
 
+bool rh_load_model(const char *path, int k, int lev_col, std::vector<float> &vals) { return load_model(path, k, lev_col, vals); }
+void rh_make_pore_inds(const std::vector<float> &vals, int k, std::vector<unsigned char> &blob) { make_pore_inds(vals, k, blob); }
+bool rh_read_fasta(const char *path, std::vector<std::string> &names, std::vector<std::string> &seqs) { return read_fasta(path, names, seqs); }
+
 extern "C" rh_index *rh_index_load(const char *path)
 {
 	FILE *fp = fopen(path, "rb");
@@ -320,13 +324,20 @@ extern "C" rh_index *rh_index_build(const char *fasta_path, const char *pore_mod
 	return ix.release();
 }
 
+extern "C" int rh_index_write(const rh_index *ix, const char *out_ind)
+{
+	if (ix->key_hash.empty() && ix->dev_n_keys) { rh_set_error("the keys of this index are on the device only: rh_index_download first"); return -1; }
+	return write_ind(*ix, out_ind) ? 0 : -1;
+}
+
 extern "C" void rh_index_destroy(rh_index *ix) { delete ix; }
 extern "C" uint32_t rh_index_n_seq(const rh_index *ix) { return (uint32_t)ix->names.size(); }
 extern "C" const char *rh_index_seq_name(const rh_index *ix, uint32_t i) { return i < ix->names.size() ? ix->names[i].c_str() : nullptr; }
 extern "C" uint32_t rh_index_seq_len(const rh_index *ix, uint32_t i) { return i < ix->lens.size() ? ix->lens[i] : 0; }
-extern "C" uint64_t rh_index_n_keys(const rh_index *ix) { return ix->key_hash.size(); }
+extern "C" uint64_t rh_index_n_keys(const rh_index *ix) { return ix->key_hash.empty() ? ix->dev_n_keys : ix->key_hash.size(); }
 extern "C" uint64_t rh_index_n_positions(const rh_index *ix)
 {
+	if (ix->key_hash.empty()) return ix->dev_n_pos;
 	uint64_t n = 0;
 	for (uint32_t c : ix->key_n) n += c;
 	return n;
@@ -355,7 +366,12 @@ extern "C" void rh_mapopt_update(rh_mapopt_t *mo, const rh_index *ix)
 {
 	if (mo->mid_occ <= 0) {
 		int32_t thres = INT32_MAX;
-		if (mo->mid_occ_frac > 0. && !ix->key_n.empty()) {
+		if (mo->mid_occ_frac > 0. && ix->key_n.empty() && ix->dev_n_keys) {
+			// keys resident on the device only: the same order statistic from the occupancy histogram
+			const uint64_t kk = (uint32_t)((1. - mo->mid_occ_frac) * ix->dev_n_keys);
+			uint64_t run = 0;
+			for (size_t v = 0; v < ix->occ_hist.size(); ++v) { run += ix->occ_hist[v]; if (run > kk) { thres = (int32_t)v + 1; break; } }
+		} else if (mo->mid_occ_frac > 0. && !ix->key_n.empty()) {
 			std::vector<uint32_t> a(ix->key_n);
 			const size_t kk = (uint32_t)((1. - mo->mid_occ_frac) * a.size());
 			std::nth_element(a.begin(), a.begin() + kk, a.end());

@@ -18,7 +18,15 @@ struct rh_index_s {
 	std::vector<uint32_t> key_n;               // occurrences
 	std::vector<uint64_t> key_val;             // n == 1: the position word itself; n > 1: offset into pos[]
 	std::vector<uint64_t> pos;                 // position words id<<32 | pos<<1 | strand, ascending per key
+	// an index built on the device (rh_index_build_device) keeps its keys in HBM: the host copy holds the header fields, the
+	// per-key occupancy histogram (occ_hist[n] = keys with n occurrences, last bin = that many or more; mid_occ calibration)
+	// and the totals, until rh_index_download fetches the keys
+	std::vector<uint32_t> occ_hist;
+	uint64_t dev_n_keys = 0, dev_n_pos = 0;
 };
+bool rh_load_model(const char *path, int k, int lev_col, std::vector<float> &vals);
+void rh_make_pore_inds(const std::vector<float> &vals, int k, std::vector<unsigned char> &blob);
+bool rh_read_fasta(const char *path, std::vector<std::string> &names, std::vector<std::string> &seqs);
 
 // Device table geometry (see rh_device.hip): buckets of RH_TB_SLOTS 16-byte slots = one 128-byte line.
 #define RH_TB_SLOTS 8

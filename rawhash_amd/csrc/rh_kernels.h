@@ -5,6 +5,7 @@
 #include "rh_core.h"
 #include "rh_index.h"
 #include "rh_synth_core.h"
+#include <vector>
 
 #define RH_CHUNK_MAX   4096          // samples of one chunk held in LDS by the event kernel
 #define RH_EV_CAP      2048          // events per chunk: peaks are >= 2 samples apart (revent.c:140)
@@ -23,6 +24,19 @@ struct rh_dev_index {
 	int32_t flag;
 	rh_sketch_par sp;
 };
+
+// Resident index blob [table | positions | target lengths] and the 256-byte header that describes it (what RCCL
+// broadcasts to the other GPUs).
+struct rh_blob_header {
+	uint64_t magic, bytes, table_off, pos_off, len_off, n_pos;
+	int32_t lg_buckets; uint32_t n_seq; int32_t flag;
+	rh_sketch_par sp;
+	uint32_t max_len;
+};
+#define RH_BLOB_MAGIC 0x3130424958444952ULL   // "RIDXIB01"
+// index construction on the device (rh_index_device.hip)
+int rhk_index_build_device(hipStream_t s, uint32_t n_seq, const char *const *seqs, const uint32_t *lens, const std::vector<float> &model,
+                           const rh_idxopt_t *io, rh_blob_header *hdr, void **blob_out, std::vector<uint32_t> &occ_hist, uint64_t *n_keys_out, int n_threads);
 
 // scalar parameters every kernel may need
 struct rh_dev_opt {

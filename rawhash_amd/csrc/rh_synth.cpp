@@ -68,6 +68,21 @@ extern "C" int rh_synth_write_fasta(const rh_synth_cfg_t *c, const char *path)
 	return 0;
 }
 
+extern "C" int rh_synth_genome(const rh_synth_cfg_t *c, uint32_t chrom, char *out, int n_threads)
+{
+	if (chrom >= c->n_chrom) { rh_set_error("chromosome %u out of range", chrom); return -1; }
+	if (n_threads < 1) n_threads = 1;
+	std::vector<std::thread> th;
+	const uint64_t per = ((uint64_t)c->chrom_len + n_threads - 1) / n_threads;
+	for (int t = 0; t < n_threads; ++t)
+		th.emplace_back([=]() {
+			const uint64_t b = (uint64_t)t * per, e = b + per < c->chrom_len ? b + per : c->chrom_len;
+			for (uint64_t p = b; p < e; ++p) out[p] = "ACGT"[genome_base(c, chrom, (uint32_t)p)];
+		});
+	for (auto &t : th) t.join();
+	return 0;
+}
+
 static inline uint32_t read_span(const rh_synth_cfg_t *c) { return rh_sy_span(c->n_samples); }
 
 extern "C" int rh_synth_origin(const rh_synth_cfg_t *c, uint64_t idx, uint32_t *chrom, uint32_t *pos, uint32_t *strand, uint32_t *junk)

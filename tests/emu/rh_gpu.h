@@ -55,6 +55,7 @@ static inline unsigned long long atomicOr(unsigned long long *p, unsigned long l
 static inline unsigned long long atomicAnd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p &= v; return o; }
 static inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p |= v; return o; }
 static inline unsigned atomicAnd(unsigned *p, unsigned v) { unsigned o = *p; *p &= v; return o; }
+static inline unsigned long long atomicCAS(unsigned long long *p, unsigned long long c, unsigned long long v) { unsigned long long o = *p; if (o == c) *p = v; return o; }
 static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 
 static inline unsigned rh_readlane(unsigned v, unsigned l) { return (unsigned)emu_shfl_bits(v, 5, l); }

@@ -266,6 +266,89 @@ def check_sort_big(ctx, seed=0, sizes=(20000, 33000, 9000), kinds=(0, 1, 2, 3, 4
     assert len(bad) == 0, f"{len(bad)} records out of the reference's order, first at {bad[:5]}"
 
 
+def check_device_index(lib, tmpdir, preset="sensitive", chrom_len=60_000, n_chrom=3, with_gaps=True, seed=5):
+    """Index built on the device (rh_index_build_device) = index built on the host (which tests/test_oracle.py pins to the
+    reference): same keys, same occurrence counts, same position lists in the same order, same mid_occ; targets with runs of
+    ambiguous bases, lower case and a target shorter than one seed."""
+    import os
+    from rawhash_amd.api import Context, Index, MapOptions, SynthWorkload
+    rng = np.random.default_rng(seed)
+    wl = SynthWorkload(chrom_len=chrom_len, n_chrom=n_chrom, n_samples=8000, lib=lib)
+    fasta0, model = wl.write_reference(str(tmpdir))
+    seqs = [wl.genome(c).copy() for c in range(n_chrom)]
+    names = [f"chr{c + 1}" for c in range(n_chrom)]
+    if with_gaps:
+        s = seqs[0]
+        s[:37] = ord("N")                                  # leading gap
+        for _ in range(12):
+            a = int(rng.integers(100, chrom_len - 400)); s[a:a + int(rng.integers(1, 300))] = ord("N")
+        s[chrom_len // 2] = ord("R")                       # single ambiguity code
+        s[-5:] = ord("n")
+        low = seqs[1][1000:5000]; seqs[1][1000:5000] = low + 32   # lower case is valid
+        seqs.append(np.frombuffer(b"ACGTACG", dtype=np.uint8).copy()); names.append("tiny")
+        seqs.append(np.frombuffer(b"NNNNNNNNNNNNNNNNNNNNACGTTGCANNNNNNNN", dtype=np.uint8).copy()); names.append("mostly_gap")
+    fasta = os.path.join(str(tmpdir), "ref_gaps.fa")
+    with open(fasta, "w") as f:
+        for nm, sq in zip(names, seqs):
+            f.write(f">{nm}\n")
+            t = sq.tobytes().decode()
+            for i in range(0, len(t), 80):
+                f.write(t[i:i + 80] + "\n")
+    opts = MapOptions(preset, lib=lib)
+    host = Index.build(fasta, model, opts, n_threads=4, lib=lib)
+    ctx = Context(0, lib=lib)
+    dev = Index.build_device_seqs(ctx, names, seqs, model, opts, n_threads=4)
+    o1, o2 = MapOptions(preset, lib=lib).update(host), MapOptions(preset, lib=lib).update(dev)
+    assert o1.mo.mid_occ == o2.mo.mid_occ, (o1.mo.mid_occ, o2.mo.mid_occ)
+    assert dev.n_keys == host.n_keys and dev.n_positions == host.n_positions, (dev.n_keys, host.n_keys, dev.n_positions, host.n_positions)
+    assert [dev.seq_name(i) for i in range(dev.n_seq)] == names and [dev.seq_len(i) for i in range(dev.n_seq)] == [len(x) for x in seqs]
+    dev.download(ctx, n_threads=4)
+    hk = np.ctypeslib.as_array  # noqa
+    # every key of the host index, with its positions in order
+    import ctypes as C2
+    n = host.n_keys
+    lh = lib
+    checked = 0
+    # walk the host keys through rh_index_get on both objects
+    hashes = _index_hashes(host, lib)
+    assert np.array_equal(hashes, _index_hashes(dev, lib))
+    for h in hashes[:: max(1, len(hashes) // 4000)]:
+        a, b = host.get(int(h)), dev.get(int(h))
+        assert np.array_equal(a, b), f"positions of key {int(h):#x} differ"
+        checked += 1
+    # and the table the device built serves the same reads as the uploaded host index
+    ctx.close()
+    return checked, int(n)
+
+
+def _index_hashes(index, lib):
+    """sorted key hashes of a host index object, through the .ind writer/reader-independent accessor rh_index_get"""
+    import tempfile, os
+    # the C ABI has no key iterator: write the .ind and parse key words back (layout: SURVEY App. A.8)
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "x.ind")
+        index.write(p)
+        return _ind_hashes(p)
+
+
+def _ind_hashes(path):
+    import struct
+    with open(path, "rb") as f:
+        buf = f.read()
+    off = 2
+    w, e, n, q, k, n_seq, flag = struct.unpack_from("<7I", buf, off); off += 28 + 16
+    n_pore = struct.unpack_from("<I", buf, off + 16)[0]; off += 32 + n_pore * 4 + n_pore * 12
+    for _ in range(n_seq):
+        l = buf[off]; off += 1 + l + 4
+    out = []
+    for b in range(1 << 14):
+        npos = struct.unpack_from("<i", buf, off)[0]; off += 4 + npos * 8
+        size = struct.unpack_from("<I", buf, off)[0]; off += 4
+        kv = np.frombuffer(buf, dtype="<u8", count=size * 2, offset=off); off += size * 16
+        out.append(((kv[0::2] >> np.uint64(1)) << np.uint64(14)) | np.uint64(b))
+    return np.sort(np.concatenate(out))
+
+
 def check_e2e(ctx, wl, reads=None):
     reads = reads or wl.reads
     recs = ctx.map_batch(wl.opts, reads)

@@ -42,6 +42,14 @@ def test_exact_sort_multi_workgroup(ctx, emu_lib_smallcaps):
     c.close()
 
 
+def test_index_built_on_device(emu_lib, emu_lib_smallcaps, tmp_path):
+    checked, n = pc.check_device_index(emu_lib, tmp_path)
+    assert checked > 1000 and n > 10000
+    pc.check_device_index(emu_lib, tmp_path / "b", preset="fast", chrom_len=30_000, n_chrom=2, with_gaps=False, seed=6)
+    # blocks of 64 events with a 3-event warm-up: the speculative starts of the event filter are often wrong and get re-run
+    pc.check_device_index(emu_lib_smallcaps, tmp_path / "c", chrom_len=20_000, n_chrom=2, seed=7)
+
+
 def test_chain_adversarial(ctx, wl):
     n_an, n_ch, n_u = pc.check_chain_synthetic(ctx, wl, seed=2, n_reads=24, max_n=600)
     assert n_ch > 0 and n_u > 0
