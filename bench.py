@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
-"""Benchmark of the mapping hot path (BASELINE.json metric: reads/s mapped + raw-signal Gsamples/s).
+"""Benchmark of the mapping hot path (BASELINE.json metric: reads/s mapped + raw-signal Gsamples/s vs a human index).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload human|dmel|ecoli]
 
-Workload (config[1] of BASELINE.json): E. coli-sized synthetic genome (4.6 Mbp, preset `sensitive`), synthetic R9.4
-reads of 40 000 raw samples (= max_num_chunk x chunk_size), 100 000 reads PER GPU (weak scaling), 10 % unmappable.
-A "step" = one pass of the whole hot path (rh_map_batch: prefilter .. finalize, all chunk rounds) over the rank's
-batch, with the int16 samples already resident in HBM (generated there) and the index resident in HBM.
-For N > 1 launch with torch.distributed.run (one rank per GPU): rank 0 builds + uploads the index and the flattened
-device blob is broadcast to the other GPUs over RCCL; reads are sharded, there is no collective on the data path.
+Workloads (BASELINE.json configs; all synthetic, seeded):
+  human (default, the configuration the metric is quoted on): 24 chromosomes x 129 166 667 bp = 3.1 Gbp, preset `fast`
+        (what the reference's own human runs use), reads of 40 000 raw samples (= max_num_chunk x chunk_size), 10 %
+        unmappable; the index is built ON THE DEVICE (rh_index_build_device) and stays resident in HBM
+  dmel  6 x 24 Mbp = 144 Mbp, preset `sensitive`
+  ecoli 1 x 4.6 Mbp, preset `sensitive`
+A "step" = one pass of the whole hot path (rh_map_batch: prefilter .. finalize, all chunk rounds) over the rank's batch of
+reads, with the int16 samples already resident in HBM (generated there) and the index resident in HBM.  `value` = reads of
+all ranks / time of the K timed steps (barrier + synchronize on both sides, max over ranks).
+For N > 1 launch with torch.distributed.run (one rank per GPU): rank 0 builds the index, the flattened device blob is
+broadcast to the other GPUs over RCCL (the only collective); reads are sharded (weak scaling: --reads per GPU).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the largest share of device time: algorithmic bytes
-per launch (DESIGN.md section "Algorithmic bytes") / its average launch duration measured with HIP events on the
-context's stream.  `cpu_baseline` (N = 1 only) = the CPU oracle (oracle/rh_oracle.c, a port of the reference path,
-bit-identical to it on the goldens) on all host cores over a bounded sample of the same reads.
+Prints ONE JSON line (rank 0).  `roofline` is for the stage with the largest share of device time: algorithmic bytes per
+launch (DESIGN.md "Algorithmic bytes") / its average launch duration measured with HIP events on the launch stream.
+`cpu_baseline` (N = 1 only): the unmodified reference (oracle/_ref/ref_harness: its own kt_for(map_worker_for), its own
+index loader reading the .ind this library wrote) on the host cores over a bounded sample of the same reads, best of a
+thread sweep; the PAF it prints for the sample is compared with the HIP path's (`paf_sample_identical`).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import re
+import subprocess
 import sys
 import tempfile
 import time
@@ -28,6 +37,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    #          chrom_len, n_chrom, preset, reads/GPU, cpu sample, name
+    "human": (129_166_667, 24, "fast", 8192, 6000, "human-scale (3.1 Gbp)"),
+    "dmel": (24_000_000, 6, "sensitive", 50_000, 12_000, "D. melanogaster-scale (144 Mbp)"),
+    "ecoli": (4_600_000, 1, "sensitive", 100_000, 40_000, "E. coli-scale (4.6 Mbp)"),
+}
 
 # algorithmic bytes per stage as a function of the step's counters; S = samples, Ns seeds, Nh hits,
 # Na anchors (incl. carried), Nc chained anchors, Ne events
@@ -53,13 +69,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU")
-    ap.add_argument("--genome", type=int, default=4_600_000)
+    ap.add_argument("--workload", default="human", choices=sorted(WORKLOADS))
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the workload's default)")
     ap.add_argument("--samples", type=int, default=40_000)
     ap.add_argument("--junk", type=int, default=102, help="unmappable reads per 1024")
-    ap.add_argument("--preset", default="sensitive")
-    ap.add_argument("--cpu-sample", type=int, default=40000, help="reads of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads of the CPU-baseline sample (0 = skip, -1 = the workload's default)")
+    ap.add_argument("--cpu-threads", default="", help="thread counts of the CPU sweep, comma separated (default: cores/8 .. cores)")
     args = ap.parse_args()
+    chrom_len, n_chrom, preset, d_reads, d_sample, wl_name = WORKLOADS[args.workload]
+    if args.reads <= 0:
+        args.reads = d_reads
+    if args.cpu_sample < 0:
+        args.cpu_sample = d_sample
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -85,24 +106,31 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    wl = SynthWorkload(chrom_len=args.genome, n_chrom=1, n_samples=args.samples, junk_per_1024=args.junk)
-    opts = MapOptions(args.preset)
+    cores = os.cpu_count() or 8
+    wl = SynthWorkload(chrom_len=chrom_len, n_chrom=n_chrom, n_samples=args.samples, junk_per_1024=args.junk)
+    opts = MapOptions(preset)
     port = os.environ.get("MASTER_PORT", "0")
-    workdir = os.path.join(tempfile.gettempdir(), f"rawhash_amd_bench_{port}_{os.getppid() if world > 1 else os.getpid()}")
-    fasta, model = os.path.join(workdir, "ref.fa"), os.path.join(workdir, "model.txt")
-    ind = os.path.join(workdir, "ref.ind")
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    workdir = os.path.join(shm, f"rawhash_amd_bench_{port}_{os.getppid() if world > 1 else os.getpid()}")
+    os.makedirs(workdir, exist_ok=True)
+    model = os.path.join(workdir, "model.txt")
     ctx = Context(local_rank)
     t_setup = time.time()
     index = None
+    t_index = 0.0
     if rank == 0:
-        wl.write_reference(workdir)
-        index = Index.build(fasta, model, opts, out_ind=ind if args.cpu_sample and world == 1 else None, n_threads=os.cpu_count() or 8)
+        wl._l.rh_synth_write_model(C.byref(wl.cfg), model.encode())
+        seqs = [wl.genome(c, n_threads=min(cores, 64)) for c in range(n_chrom)]
+        t0 = time.time()
+        index = Index.build_device_seqs(ctx, [f"chr{i + 1}" for i in range(n_chrom)], seqs, model, opts, n_threads=min(cores, 64))
+        t_index = time.time() - t0
+        del seqs
         opts.update(index)
-        ctx.upload(index)
     keep = []
     if world > 1:
         # replicate the HBM-resident index: one RCCL broadcast of the flattened blob over xGMI (the only collective)
         from rawhash_amd.dist import replicate_index
+        dist.barrier()                                     # the model file is there
         keep.append(replicate_index(ctx, opts, None, device=f"cuda:{local_rank}"))
         dist.barrier()
     # this rank's shard of the read set, generated straight into HBM
@@ -116,11 +144,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    recs = None
     for _ in range(args.warmup):
-        ctx.map_batch(opts, batch)
+        recs = ctx.map_batch(opts, batch)
     acc = {}
     stage_ms, stage_n = {}, {}
-    n_mapped = 0
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -132,9 +160,9 @@ def main():
         for k, (ms, n) in st["stages"].items():
             stage_ms[k] = stage_ms.get(k, 0.0) + ms
             stage_n[k] = stage_n.get(k, 0) + n
-        n_mapped = int(recs["mapped"].sum())
     sync()
     elapsed = time.perf_counter() - t0
+    n_mapped = int(recs["mapped"].sum())
     if world > 1:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -150,39 +178,45 @@ def main():
         dom_bytes = ALGO_BYTES[dom](acc)
         achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
         path_bytes = 2 * acc["n_samples_used"] + 16 * acc["n_seeds"] + 8 * acc["n_hits"] + 32 * acc["n_anchors"] + 16 * acc["n_chained"] + 64 * acc["n_reads"]
-        scale = "E. coli" if args.genome <= 10_000_000 else "D. melanogaster" if args.genome <= 200_000_000 else "human"
         dev_ms = sum(kernels.values())
+        n_streams = int(os.environ.get("RH_SUB_BATCHES", "3"))
         out = {
-            "metric": f"reads/sec mapped ({scale}-scale index resident in HBM)", "value": round(value, 1), "unit": "reads/s",
+            "metric": f"reads/sec mapped ({wl_name} index resident in HBM)", "value": round(value, 1), "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16 signal; fp32/fp64 events; u64/i32 seeding+chaining", "data": "synthetic",
-            "config": {"workload": f"{scale}-sized synthetic genome {args.genome} bp + {args.reads} synthetic R9.4 reads/GPU x {args.samples} samples, preset {args.preset}, "
-                                   f"{args.junk}/1024 unmappable reads, index + int16 signal resident in HBM",
+            "config": {"workload": f"{wl_name}: synthetic genome {n_chrom} x {chrom_len} bp + {args.reads} synthetic R9.4 reads/GPU x {args.samples} samples, preset {preset}, "
+                                   f"{args.junk}/1024 unmappable reads, index built on the device and resident in HBM ({index.n_keys} keys, {index.n_positions} positions), int16 signal resident in HBM",
                        "reads_per_gpu": args.reads, "samples_per_read": args.samples, "mid_occ": int(opts.mo.mid_occ), "parallelism": f"reads sharded x{world}, index replicated"},
             "gsamples_per_s_consumed": round(acc["n_samples_used"] * world / elapsed / 1e9, 4),
             "gsamples_per_s_input": round(args.reads * args.samples * world * args.steps / elapsed / 1e9, 4),
             "mapped_fraction": round(n_mapped / args.reads, 4),
             "chunks_per_read": round(acc["n_chunks"] / acc["n_reads"], 3),
+            "anchors_per_chunk": round(acc["n_anchors"] / max(acc["n_chunks"], 1), 1),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom, args, stage_n[dom] / args.steps),
                          "avg_launch_ms": round(stage_ms[dom] / stage_n[dom], 4), "launches": stage_n[dom],
                          "algorithmic_bytes_per_launch": int(dom_bytes / stage_n[dom]),
-                         "concurrent_streams": int(os.environ.get("RH_SUB_BATCHES", "3")),
-                         "note": "launch durations are HIP-event times on each sub-batch's own stream; with >1 concurrent streams a launch shares the "
-                                 "chip with the other streams' kernels, so frac understates the kernel alone (RH_SUB_BATCHES=1: profiles/r01_final_bench_1stream.json)"},
+                         "concurrent_streams": n_streams,
+                         "note": "stage durations are HIP-event times on each sub-batch's own stream; with >1 concurrent streams a launch shares the "
+                                 "chip with the other streams' kernels, so frac understates the kernel alone (RH_SUB_BATCHES=1 runs: profiles/)"},
             "path": {"algorithmic_GB_per_step": round(path_bytes / args.steps / 1e9, 4), "device_ms_per_step": round(dev_ms / args.steps, 3),   # sum over concurrent sub-batch streams
-                    
-                     "achieved_GBs": round(path_bytes / elapsed / 1e9, 3)},
+                     "achieved_GBs": round(path_bytes / elapsed / 1e9, 3), "frac_of_hbm_peak": round(path_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items() if stage_n.get(k)},
-            "setup_s": round(t_setup, 2),
+            "index_build_s": round(t_index, 2), "setup_s": round(t_setup, 2),
         }
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(wl, model, ind, args)
+            try:
+                out["cpu_baseline"], out["paf_sample_identical"] = cpu_baseline(ctx, index, opts, wl, model, workdir, preset, recs, args, cores)
+            except Exception as e:   # the baseline is a reported extra: never lose the bench line because of it
+                out["cpu_baseline_error"] = repr(e)[:300]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if rank == 0:
+        import shutil
+        shutil.rmtree(workdir, ignore_errors=True)
 
 
 def pmc_traffic(stage, args, launches_per_step):
@@ -193,53 +227,64 @@ def pmc_traffic(stage, args, launches_per_step):
         return None
     with open(path) as f:
         d = json.load(f)
-    if d.get("reads") != args.reads or d.get("samples") != args.samples or d.get("junk") != args.junk:
+    if d.get("workload") != args.workload or d.get("reads") != args.reads or d.get("samples") != args.samples or d.get("junk") != args.junk:
         return None
     e = d.get("stages", {}).get(stage)
     return None if e is None or "bytes_per_step" not in e else int(e["bytes_per_step"] / max(launches_per_step, 1))
 
 
-def cpu_baseline(wl, model, ind, args):
-    """CPU baseline on every host core over a bounded sample of the same reads.
+def cpu_baseline(ctx, index, opts, wl, model, workdir, preset, recs, args, cores):
+    """The reference on the host cores over the first `cpu_sample` reads of the same set, and PAF parity on that sample.
 
-    kind "reference": the unmodified RawHash2 sources (oracle/_ref/ref_harness, prebuilt where /root/reference exists; its
-    `map` command runs the reference's own kt_for(map_worker_for) and reports the map-phase time, file loading excluded).
-    kind "port": oracle/rh_oracle.c (bit-identical restatement), also reported when the reference binary is present."""
-    import re
-    import subprocess
+    kind "reference": the unmodified RawHash2 sources (oracle/_ref/ref_harness, prebuilt where /root/reference exists): its
+    own .ind loader reads the index this library wrote, its `kt_for(map_worker_for)` maps mini-batches of 500 M samples (-K)
+    and its own printer writes the PAF; reported = map-phase time (file loading excluded), best of a thread sweep.
+    kind "port": oracle/rh_oracle.c (the bit-identical restatement) when the reference binary is not there."""
+    import numpy as np
     import oracle_lib as O
-    cores = os.cpu_count() or 1
+    from rawhash_amd import paf_lines, strip_mt
     n = min(args.cpu_sample, args.reads)
-    reads = wl.reads(model, 0, n, n_threads=cores, with_names=True)
+    t0 = time.time()
+    index.download(ctx, n_threads=min(cores, 64))
+    ind = os.path.join(workdir, "ref.ind")
+    index.write(ind)
+    t_ind = time.time() - t0
+    reads = wl.reads(model, 0, n, n_threads=min(cores, 64), with_names=True)
+    got = [strip_mt(x) for x in paf_lines(index, recs[:n], reads.names)]
+    sweep = [int(x) for x in args.cpu_threads.split(",")] if args.cpu_threads else sorted({max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores})
+    if O.have_reference():
+        rhr = os.path.join(workdir, "cpu_sample.rhr")
+        reads.write(rhr, wl.cfg.digitisation, wl.cfg.range, wl.cfg.offset)
+        paf = os.path.join(workdir, "ref.paf")
+        with open(paf, "w") as fo:
+            p = subprocess.run([O.REF_HARNESS, "map", preset, ind, rhr, ",".join(str(t) for t in sweep)], stdout=fo, stderr=subprocess.PIPE, text=True, timeout=3000)
+        runs = [(int(t), float(s)) for s, t in re.findall(r"map phase ([0-9.]+) s, threads (\d+)", p.stderr)]
+        if p.returncode == 0 and runs:
+            with open(paf) as f:
+                want = [O.strip_mt(x) for x in f]
+            identical = got == want
+            best_t, best_s = min(runs, key=lambda r: r[1])
+            load = re.search(r"index loaded in ([0-9.]+) s", p.stderr)
+            base = {"value": round(n / best_s, 1), "unit": "reads/s", "cores": cores, "threads": best_t, "kind": "reference",
+                    "sample": f"first {n} reads of the same synthetic set, map phase {best_s:.2f} s (file loading excluded), unmodified RawHash2 sources built by "
+                              f"oracle/Makefile (-O3 -ffp-contract=off), kt_for over 500 M-sample mini-batches",
+                    "thread_sweep_reads_per_s": {str(t): round(n / s, 1) for t, s in runs},
+                    "index_file_s": round(t_ind, 1), "reference_index_load_s": float(load.group(1)) if load else None,
+                    "paf_sha1": hashlib.sha1("\n".join(want).encode()).hexdigest()}
+            if not identical:
+                base["paf_lines_differing"] = sum(1 for a, b in zip(got, want) if a != b) + abs(len(got) - len(want))
+            return base, identical
     oix = O.OracleIndex(ind)
-    _, mo = O.preset(args.preset)
+    _, mo = O.preset(preset)
     O.lib().ro_mapopt_update(C.byref(mo), oix.h)
     b = reads.batch()
     t0 = time.perf_counter()
-    recs = O.map_batch(oix, mo, b, n_threads=cores)
+    orecs = O.map_batch(oix, mo, b, n_threads=cores)
     dt = time.perf_counter() - t0
-    port = {"value": round(n / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} reads of the same synthetic set, {dt:.2f} s wall, oracle/rh_oracle.c with {cores} pthreads",
-            "mapped_fraction": round(float(recs['mapped'].mean()), 4)}
-    if not O.have_reference():
-        return port
-    try:
-        n_ref = min(n, 20000)
-        sub = reads.subset(range(n_ref))
-        rhr = os.path.join(os.path.dirname(ind), "cpu_sample.rhr")
-        sub.write(rhr, wl.cfg.digitisation, wl.cfg.range, wl.cfg.offset)
-        p = subprocess.run([O.REF_HARNESS, "map", args.preset, ind, rhr, str(cores)], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=600)
-        m = re.search(r"map phase ([0-9.]+) s", p.stderr)
-        os.remove(rhr)
-        if p.returncode != 0 or not m:
-            return port
-        t_ref = float(m.group(1))
-        return {"value": round(n_ref / t_ref, 1), "unit": "reads/s", "cores": cores, "kind": "reference",
-                "sample": f"first {n_ref} reads of the same synthetic set, map phase {t_ref:.2f} s (file loading excluded), unmodified RawHash2 "
-                          f"sources built by oracle/Makefile (-O3 -ffp-contract=off), kt_for with {cores} threads",
-                "port": port}
-    except Exception:   # the baseline is a reported extra: never fail the bench because of it
-        return port
+    want = [O.strip_mt(x) for x in O.paf_lines(oix, orecs, reads.names)]
+    return ({"value": round(n / dt, 1), "unit": "reads/s", "cores": cores, "threads": cores, "kind": "port",
+             "sample": f"first {n} reads of the same synthetic set, {dt:.2f} s wall, oracle/rh_oracle.c with {cores} pthreads",
+             "mapped_fraction": round(float(orecs['mapped'].mean()), 4)}, got == want)
 
 
 if __name__ == "__main__":

@@ -35,6 +35,8 @@
 #include <vector>
 #include <string>
 #include <algorithm>
+#include <fcntl.h>
+#include <unistd.h>
 
 struct rhr_read { std::string name; std::vector<int16_t> raw; double dig, range, offset; };
 
@@ -137,39 +139,56 @@ static int cmd_map(int argc, char **argv)
 	if (argc < 5) return 2;
 	ri_idxopt_t ipt; ri_mapopt_t opt;
 	if (set_presets(argv[2], &ipt, &opt) < 0) return 1;
-	int n_threads = argc > 5 ? atoi(argv[5]) : 1;
+	// thread counts: one number, or a comma-separated list (the index is loaded once, the reads are mapped once per
+	// count; the PAF of the first run goes to stdout, the others are timed only)
+	std::vector<int> threads;
+	{
+		const char *p = argc > 5 ? argv[5] : "1";
+		while (*p) { int v = atoi(p); threads.push_back(v > 0 ? v : 1); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+		if (threads.empty()) threads.push_back(1);
+	}
+	double t_load = ri_realtime();
 	ri_idx_t *ri = load_index(argv[3], &ipt);
 	if (!ri) return 1;
+	t_load = ri_realtime() - t_load;
 	ri_mapopt_update(&opt, ri);
 	std::vector<rhr_read> reads;
 	if (!load_rhr(argv[4], reads)) { fprintf(stderr, "bad reads file\n"); return 1; }
+	fprintf(stderr, "[ref_harness] index loaded in %.3f s, %zu reads\n", t_load, reads.size());
 
-	pipeline_mt pl;
-	memset(&pl, 0, sizeof(pl));
-	pl.n_threads = n_threads > 0 ? n_threads : 1;
-	pl.opt = &opt; pl.ri = ri; pl.su_stop = 0;
-
-	const size_t BATCH = 4096;
-	double t_map = 0;
-	for (size_t b0 = 0; b0 < reads.size(); b0 += BATCH) {
-		size_t n = std::min(BATCH, reads.size() - b0);
-		// what step 0 does after reading (rmap.cpp:679-690)
-		step_mt *s = (step_mt*)calloc(1, sizeof(step_mt));
-		s->n_sig = (int)n;
-		s->sig = (ri_sig_t**)calloc(n, sizeof(ri_sig_t*));
-		for (size_t i = 0; i < n; ++i) s->sig[i] = to_sig(reads[b0 + i], pl.n_processed++);
-		s->p = &pl;
-		s->buf = (ri_tbuf_t**)calloc(pl.n_threads, sizeof(ri_tbuf_t*));
-		for (int i = 0; i < pl.n_threads; ++i) s->buf[i] = ri_tbuf_init();
-		s->reg = (ri_reg1_t**)calloc(n, sizeof(ri_reg1_t*));
-		for (size_t i = 0; i < n; ++i) s->reg[i] = (ri_reg1_t*)calloc(1, sizeof(ri_reg1_t));
-		double t0 = ri_realtime();
-		map_worker_pipeline(&pl, 1, s);   // kt_for(map_worker_for)
-		t_map += ri_realtime() - t0;
-		map_worker_pipeline(&pl, 2, s);   // PAF printer, frees the batch
+	int saved_stdout = -1;
+	for (size_t run = 0; run < threads.size(); ++run) {
+		pipeline_mt pl;
+		memset(&pl, 0, sizeof(pl));
+		pl.n_threads = threads[run];
+		pl.opt = &opt; pl.ri = ri; pl.su_stop = 0;
+		if (run == 1) { fflush(stdout); saved_stdout = dup(1); int nul = open("/dev/null", O_WRONLY); dup2(nul, 1); close(nul); }
+		double t_map = 0;
+		size_t b0 = 0;
+		while (b0 < reads.size()) {
+			// what step 0 does (rmap.cpp:601-690): reads are taken until their filtered signal adds up to mini_batch_size (-K, 500 M samples)
+			std::vector<ri_sig_t*> sigs;
+			int64_t sum = 0;
+			while (b0 < reads.size() && sum < opt.mini_batch_size) { ri_sig_t *sg = to_sig(reads[b0], pl.n_processed++); sum += sg->l_sig; sigs.push_back(sg); ++b0; }
+			const size_t n = sigs.size();
+			step_mt *s = (step_mt*)calloc(1, sizeof(step_mt));
+			s->n_sig = (int)n;
+			s->sig = (ri_sig_t**)calloc(n, sizeof(ri_sig_t*));
+			for (size_t i = 0; i < n; ++i) s->sig[i] = sigs[i];
+			s->p = &pl;
+			s->buf = (ri_tbuf_t**)calloc(pl.n_threads, sizeof(ri_tbuf_t*));
+			for (int i = 0; i < pl.n_threads; ++i) s->buf[i] = ri_tbuf_init();
+			s->reg = (ri_reg1_t**)calloc(n, sizeof(ri_reg1_t*));
+			for (size_t i = 0; i < n; ++i) s->reg[i] = (ri_reg1_t*)calloc(1, sizeof(ri_reg1_t));
+			double t0 = ri_realtime();
+			map_worker_pipeline(&pl, 1, s);   // kt_for(map_worker_for)
+			t_map += ri_realtime() - t0;
+			map_worker_pipeline(&pl, 2, s);   // PAF printer, frees the batch
+		}
+		fflush(stdout);
+		fprintf(stderr, "[ref_harness] mapped %zu reads, map phase %.6f s, threads %d, mid_occ %d\n", reads.size(), t_map, pl.n_threads, opt.mid_occ);
 	}
-	fflush(stdout);
-	fprintf(stderr, "[ref_harness] mapped %zu reads, map phase %.6f s, threads %d, mid_occ %d\n", reads.size(), t_map, pl.n_threads, opt.mid_occ);
+	if (saved_stdout >= 0) { fflush(stdout); dup2(saved_stdout, 1); close(saved_stdout); }
 	ri_idx_destroy(ri);
 	return 0;
 }

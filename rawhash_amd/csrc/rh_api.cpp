@@ -42,6 +42,17 @@ struct DevBuf {
 		cap = want;
 		return 0;
 	}
+	// grow to at least `bytes`, keeping the first `used` bytes
+	int ensure_keep(size_t bytes, size_t used, hipStream_t s)
+	{
+		if (bytes <= cap) return 0;
+		DevBuf nb;
+		if (nb.ensure(bytes + bytes / 2)) { if (nb.ensure(bytes)) return -1; }
+		if (p && used) { RH_HIP(hipMemcpyAsync(nb.p, p, used, hipMemcpyDeviceToDevice, s)); RH_HIP(hipStreamSynchronize(s)); }
+		if (p) (void)hipFree(p);
+		p = nb.p; cap = nb.cap; nb.p = nullptr;
+		return 0;
+	}
 	void release() { if (p && owned) (void)hipFree(p); p = nullptr; cap = 0; owned = true; }
 	template <class T> T *as() const { return (T*)p; }
 };
@@ -68,7 +79,9 @@ struct rh_ctx_s {
 	DevBuf act[2], n_act_dev;
 	DevBuf zbuf, t1buf, t2buf, n_norm, peaks, n_peaks;
 	DevBuf ev, n_ev, skip, sx, sy, n_seed, m_val, m_n, m_meta, m_pref, n_match, n_new, rep_len, a_off;
-	DevBuf anc, raw_anc, zs, n_z, need_exact, need_exact2, prev[2], u, n_u, n_v, ws, counters, rec;
+	DevBuf anc, raw_anc, zs, n_z, need_exact, need_exact2, prev_stage, u, n_u, n_v, ws, counters, rec;
+	DevBuf carry[2], carry_off, a_off_slice;                      // chained anchors carried into the next chunk, dense, ping-pong over the rounds
+	int share = 1;                                                 // sub-batches running concurrently on this device (memory budget per context)
 	DevBuf sort_alt, sort_ws;                                     // multi-workgroup segment sorter: second record array + tables (only when a read exceeds the LDS classes)
 	DevBuf sy_samples, sy_off, sy_cal_off, sy_cal_scale, sy_levels;
 	// timing
@@ -116,6 +129,7 @@ int fill_dev_opt(const rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
 	if (mo->flag & (RH_M_NO_ADAPTIVE | RH_M_ALL_CHAINS)) { rh_set_error("whole-read / all-vs-all (Rawsamble) mode is not built on the device yet"); return -1; }
 	if (mo->flag & (RH_M_RMQ | RH_M_DTW_EVALUATE_CHAINS)) { rh_set_error("RMQ chaining / DTW re-scoring are out of scope of this path"); return -1; }
 	if (mo->bw_long > mo->bw) { rh_set_error("bw_long > bw (RMQ re-chaining) is out of scope of this path"); return -1; }
+	if (mo->min_num_anchors < 2) { rh_set_error("min_num_anchors < 2 is not supported on the device (the per-anchor scratch assumes chains of at least two anchors)"); return -1; }
 	if (mo->window_length1 > 64 || mo->window_length2 > 64) { rh_set_error("segmentation windows > 64 not supported"); return -1; }
 	memset(o, 0, sizeof(*o));
 	o->chunk_size = mo->chunk_size; o->max_num_chunk = mo->max_num_chunk; o->min_events = mo->min_events;
@@ -199,18 +213,12 @@ int stage_round(rh_ctx *c, uint32_t n_act, rh_dev_round *rr)
 	return 0;
 }
 
-// anchor-sized arenas for `total` anchors; prev_out = c->prev[which]
-int stage_anchors(rh_ctx *c, uint64_t total, int which, rh_dev_round *rr)
+// anchor-sized arenas for a slice of `total` anchors
+int stage_anchors(rh_ctx *c, uint64_t total, rh_dev_round *rr)
 {
 	const size_t t = total ? total : 1;
-	const char *cap_env = getenv("RH_ARENA_MAX_BYTES");              // optional cap on the per-anchor scratch arena (shared devices, tests)
-	if (cap_env && t * RH_WS_PER_ANCHOR > (size_t)strtoull(cap_env, nullptr, 10)) {
-		g_oom = true;
-		rh_set_error("per-anchor arena of %zu bytes exceeds RH_ARENA_MAX_BYTES=%s", t * RH_WS_PER_ANCHOR, cap_env);
-		return -1;
-	}
-	if (c->anc.ensure(t * 16) || c->raw_anc.ensure(t * 16) || c->zs.ensure(t * 16) || c->prev[which].ensure(t * 16) || c->u.ensure(t * 8) || c->ws.ensure(t * RH_WS_PER_ANCHOR + 4096)) return -1;
-	rr->anc = c->anc.as<rh_mm128_t>(); rr->raw = c->raw_anc.as<rh_mm128_t>(); rr->zs = c->zs.as<rh_mm128_t>(); rr->prev_out = c->prev[which].as<rh_mm128_t>(); rr->prev_in = c->prev[which ^ 1].as<rh_mm128_t>();
+	if (c->anc.ensure(t * 16) || c->raw_anc.ensure(t * 16) || c->zs.ensure(t * 16) || c->prev_stage.ensure(t * 16) || c->u.ensure(t * 8) || c->ws.ensure(t * RH_WS_PER_ANCHOR + 4096)) return -1;
+	rr->anc = c->anc.as<rh_mm128_t>(); rr->raw = c->raw_anc.as<rh_mm128_t>(); rr->zs = c->zs.as<rh_mm128_t>(); rr->prev_out = c->prev_stage.as<rh_mm128_t>();
 	rr->u = c->u.as<uint64_t>(); rr->ws = c->ws.as<unsigned char>();
 	// segments longer than the LDS sort classes (large indexes): scratch of the multi-workgroup sorter
 	if (rr->max_anchors == 0 || rr->max_anchors > (uint32_t)RH_SORT_LDS_MIN_TOP) {
@@ -220,6 +228,42 @@ int stage_anchors(rh_ctx *c, uint64_t total, int which, rh_dev_round *rr)
 		rr->sort_alt = c->sort_alt.as<rh_mm128_t>(); rr->sort_ws = c->sort_ws.as<unsigned char>(); rr->sort_ws_bytes = c->sort_ws.cap; rr->sort_pin = c->pin + 16; rr->sort_total = t;
 	}
 	return 0;
+}
+// bytes of device memory a slice needs per anchor (the arrays above + the sorter's tables)
+const size_t kBytesPerAnchor = 16 * 4 + 8 + RH_WS_PER_ANCHOR + 16 + 18;
+
+// anchors one slice of a round may hold: what is free on the device (plus what this context's arenas hold already), shared
+// by the sub-batches running concurrently; RH_ARENA_MAX_BYTES caps the per-anchor scratch (shared devices, tests)
+uint64_t slice_budget(rh_ctx *c)
+{
+	size_t free_b = 0, total_b = 0;
+	uint64_t budget = ~0ull;
+	if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+		DevBuf *mine[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev_stage, &c->u, &c->ws, &c->sort_alt, &c->sort_ws};
+		size_t held = 0;
+		for (DevBuf *d : mine) held += d->cap;
+		const size_t reserve = total_b / 24 > ((size_t)3 << 30) ? total_b / 24 : ((size_t)3 << 30);
+		const size_t avail = free_b > reserve ? free_b - reserve : 0;
+		budget = (uint64_t)((double)(avail / (size_t)(c->share > 0 ? c->share : 1) + held) * 0.80 / (double)kBytesPerAnchor);
+	}
+	if (const char *cap_env = getenv("RH_ARENA_MAX_BYTES")) { const uint64_t m = strtoull(cap_env, nullptr, 10) / RH_WS_PER_ANCHOR; if (m < budget) budget = m; }
+	return budget > 1024 ? budget : 1024;
+}
+
+// the view of a round's per-slot arrays for the active reads [lo, lo + n)
+rh_dev_round slice_view(const rh_dev_round &rr, uint32_t lo, uint32_t n, uint64_t *a_off)
+{
+	rh_dev_round v = rr;
+	const size_t cap = RH_EV_CAP;
+	v.n_act = n; v.act = rr.act + lo; v.a_off = a_off;
+	v.n_norm = rr.n_norm + lo; v.peaks = rr.peaks + lo * cap; v.n_peaks = rr.n_peaks + lo;
+	v.ev = rr.ev + lo * cap; v.n_ev = rr.n_ev + lo; v.skip = rr.skip + lo;
+	v.sx = rr.sx + lo * cap; v.sy = rr.sy + lo * cap; v.n_seed = rr.n_seed + lo;
+	v.m_val = rr.m_val + lo * cap; v.m_n = rr.m_n + lo * cap; v.m_meta = rr.m_meta + lo * cap; v.m_pref = rr.m_pref + (size_t)lo * (cap + 1);
+	v.n_match = rr.n_match + lo; v.n_new = rr.n_new + lo; v.rep_len = rr.rep_len + lo;
+	v.need_exact = rr.need_exact + lo; v.need_exact2 = rr.need_exact2 + lo;
+	v.n_u = rr.n_u + lo; v.n_v = rr.n_v + lo; v.n_z = rr.n_z + lo;
+	return v;
 }
 
 int need_index(rh_ctx *c) { if (!c->have_index) { rh_set_error("no index resident on this context (rh_index_upload first)"); return -1; } return 0; }
@@ -265,7 +309,7 @@ extern "C" void rh_ctx_destroy(rh_ctx *c)
 	for (rh_ctx *sc : c->subs) rh_ctx_destroy(sc);
 	c->subs.clear();
 	DevBuf *all[] = {&c->logf_tab, &c->raw, &c->off, &c->cal_off, &c->cal_scale, &c->act[0], &c->act[1], &c->n_act_dev, &c->zbuf, &c->t1buf, &c->t2buf, &c->n_norm, &c->peaks, &c->n_peaks, &c->ev, &c->n_ev, &c->skip, &c->sx, &c->sy,
-	                 &c->n_seed, &c->m_val, &c->m_n, &c->m_meta, &c->m_pref, &c->n_match, &c->n_new, &c->rep_len, &c->a_off, &c->anc, &c->raw_anc, &c->zs, &c->n_z, &c->need_exact, &c->need_exact2, &c->prev[0], &c->prev[1], &c->u,
+	                 &c->n_seed, &c->m_val, &c->m_n, &c->m_meta, &c->m_pref, &c->n_match, &c->n_new, &c->rep_len, &c->a_off, &c->anc, &c->raw_anc, &c->zs, &c->n_z, &c->need_exact, &c->need_exact2, &c->prev_stage, &c->carry[0], &c->carry[1], &c->carry_off, &c->a_off_slice, &c->u,
 	                 &c->n_u, &c->n_v, &c->ws, &c->sort_alt, &c->sort_ws, &c->counters, &c->rec, &c->sy_samples, &c->sy_off, &c->sy_cal_off, &c->sy_cal_scale, &c->sy_levels};
 	for (DevBuf *b : all) b->release();
 	for (DevBuf &b : c->st) b.release();
@@ -490,7 +534,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 	hipStream_t s = c->stream;
 	rh_dev_reads rd;
 	{ StageTimer t(c, ST_H2D); if (stage_reads(c, in, &rd)) return -1; }
-	if (c->act[0].ensure((size_t)R * 4) || c->act[1].ensure((size_t)R * 4) || c->n_act_dev.ensure(64) || c->counters.ensure(16 * 8) || c->rec.ensure((size_t)R * sizeof(rh_map_record_t))) return -1;
+	if (c->act[0].ensure((size_t)R * 4) || c->act[1].ensure((size_t)R * 4) || c->n_act_dev.ensure(64) || c->carry[0].ensure(16) || c->carry[1].ensure(16) || c->counters.ensure(16 * 8) || c->rec.ensure((size_t)R * sizeof(rh_map_record_t))) return -1;
 	RH_HIP(hipMemsetAsync(c->counters.p, 0, 16 * 8, s));
 	{ StageTimer t(c, ST_PREFILTER); rhk_prefilter(s, o, rd); }
 	int cur = 0;
@@ -501,12 +545,13 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 	RH_HIP(hipStreamSynchronize(s));
 	n_act = (uint32_t)c->pin[0];
 	int which = 0;
+	uint64_t carry_used = 0;                                       // anchors in carry[which] so far this round
 	for (uint32_t chunk = 0; chunk < mo->max_num_chunk && n_act > 0; ++chunk) {
 		rh_dev_round rr{};
 		if (stage_round(c, n_act, &rr)) return -1;
 		rr.act = c->act[cur].as<uint32_t>(); rr.chunk = chunk;
 		rr.akey_on = c->akey_on ? 1 : 0; rr.akey_lo = c->akey_lo; rr.akey_mid = c->akey_mid;
-		rr.prev_in = c->prev[which ^ 1].as<rh_mm128_t>();
+		rr.prev_in = c->carry[which ^ 1].as<rh_mm128_t>();
 		{ StageTimer t(c, ST_EV_NORM); rhk_events_norm(s, o, rd, rr); }
 		{ StageTimer t(c, ST_EV_PEAKS); rhk_events_peaks(s, o, rr); }
 		{ StageTimer t(c, ST_EV_MEANS); rhk_events_means(s, o, rr); }
@@ -516,17 +561,58 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 		{ StageTimer t(c, ST_SCAN); rhk_scan_anchors(s, rd, rr); RH_HIP(hipMemcpyAsync(c->pin + 1, rr.a_off + n_act, 16, hipMemcpyDeviceToHost, s)); }
 		RH_HIP(hipStreamSynchronize(s));
 		total = c->pin[1];
-		rr.max_anchors = (uint32_t)c->pin[2];
-		if (stage_anchors(c, total, which, &rr)) return -1;
-		{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rr); }
-		{ StageTimer t(c, ST_SORT); if (rhk_sort(s, rr)) return -1; }
-		if (debug_rounds()) dump_round(c, chunk, n_act, rr);
-		{ StageTimer t(c, ST_CHAIN); rhk_chain(s, o, rr); }
-		{ StageTimer t(c, ST_ZSORT); if (rhk_zsort(s, o, rr)) return -1; }
-		{ StageTimer t(c, ST_BACKTRACK); if (rhk_backtrack(s, o, rd, rr)) return -1; }
-		{ StageTimer t(c, ST_RSORT); if (rhk_regions_sort(s, o, rd, rr)) return -1; }
-		{ StageTimer t(c, ST_REGIONS); rhk_regions(s, o, rd, rr, c->logf_tab.as<float>()); }
-		if (debug_rounds()) dump_round2(c, chunk, n_act, rr);
+		const uint32_t max_all = (uint32_t)c->pin[2];
+		// The anchor-sized stages run over slices of the active reads whose anchors fit the device together (one slice unless
+		// the index is large and the batch big); the event / seeding stages above ran for all of them at once.
+		const uint64_t budget = slice_budget(c);
+		std::vector<uint32_t> cuts;                                // slice boundaries in the active list
+		std::vector<uint64_t> a_off_h;
+		cuts.push_back(0);
+		if (total > budget) {
+			a_off_h.resize((size_t)n_act + 1);
+			RH_HIP(hipMemcpy(a_off_h.data(), rr.a_off, ((size_t)n_act + 1) * 8, hipMemcpyDeviceToHost));
+			uint32_t lo = 0;
+			for (uint32_t a = 1; a <= n_act; ++a)
+				if (a_off_h[a] - a_off_h[lo] > budget && a - 1 > lo) { cuts.push_back(a - 1); lo = a - 1; }
+		}
+		cuts.push_back(n_act);
+		carry_used = 0;
+		if (c->carry_off.ensure((size_t)(n_act + 1) * 8) || c->a_off_slice.ensure((size_t)(n_act + 2) * 8)) return -1;
+		for (size_t si = 0; si + 1 < cuts.size(); ++si) {
+			const uint32_t lo = cuts[si], n = cuts[si + 1] - lo;
+			rh_dev_round rs = rr;
+			uint64_t stotal = total;
+			rs.max_anchors = max_all;
+			if (cuts.size() > 2) {
+				rhk_rebase_offsets(s, rr.a_off + lo, n, c->a_off_slice.as<uint64_t>());
+				rs = slice_view(rr, lo, n, c->a_off_slice.as<uint64_t>());
+				stotal = a_off_h[lo + n] - a_off_h[lo];
+				uint32_t mx = 0;
+				for (uint32_t a = lo; a < lo + n; ++a) { const uint64_t m = a_off_h[a + 1] - a_off_h[a]; if (m > mx) mx = (uint32_t)m; }
+				rs.max_anchors = mx;
+			}
+			if (stage_anchors(c, stotal, &rs)) return -1;
+			{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rs); }
+			{ StageTimer t(c, ST_SORT); if (rhk_sort(s, rs)) return -1; }
+			if (debug_rounds()) dump_round(c, chunk, n, rs);
+			{ StageTimer t(c, ST_CHAIN); rhk_chain(s, o, rs); }
+			{ StageTimer t(c, ST_ZSORT); if (rhk_zsort(s, o, rs)) return -1; }
+			{ StageTimer t(c, ST_BACKTRACK); if (rhk_backtrack(s, o, rd, rs)) return -1; }
+			{ StageTimer t(c, ST_RSORT); if (rhk_regions_sort(s, o, rd, rs)) return -1; }
+			{ StageTimer t(c, ST_REGIONS); rhk_regions(s, o, rd, rs, c->logf_tab.as<float>()); }
+			if (debug_rounds()) dump_round2(c, chunk, n, rs);
+			// the chained anchors the reads carry into their next chunk: staging arena -> dense carry buffer
+			{
+				StageTimer t(c, ST_COMPACT);
+				rhk_carry_scan(s, rd, rs.act, n, carry_used, c->carry_off.as<uint64_t>(), c->n_act_dev.as<uint64_t>() + 2);
+				RH_HIP(hipMemcpyAsync(c->pin + 4, c->n_act_dev.as<uint64_t>() + 2, 8, hipMemcpyDeviceToHost, s));
+				RH_HIP(hipStreamSynchronize(s));
+				const uint64_t add = c->pin[4];
+				if (c->carry[which].ensure_keep((carry_used + add + 1) * 16, carry_used * 16, s)) return -1;
+				rhk_carry_copy(s, rd, rs.act, n, rs.prev_out, c->carry_off.as<uint64_t>(), c->carry[which].as<rh_mm128_t>());
+				carry_used += add;
+			}
+		}
 		{ StageTimer t(c, ST_COMPACT); rhk_compact_active(s, o, rd, rr.act, n_act, chunk + 1, c->act[cur ^ 1].as<uint32_t>(), c->n_act_dev.as<uint32_t>()); }
 		RH_HIP(hipMemcpyAsync(c->pin, c->n_act_dev.p, 4, hipMemcpyDeviceToHost, s));
 		RH_HIP(hipStreamSynchronize(s));
@@ -574,7 +660,7 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 	if (c->slice_hint == 0 || R <= c->slice_hint) {
 		if (map_batch_once(c, mo, in, out, out_cap, &n) == 0) { *n_out = n; return 0; }
 		if (!g_oom || R < 2) return -1;
-		DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev[0], &c->prev[1], &c->u, &c->ws, &c->sort_alt, &c->sort_ws};
+		DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev_stage, &c->u, &c->ws, &c->sort_alt, &c->sort_ws};
 		(void)hipStreamSynchronize(c->stream);
 		for (DevBuf *d : big) d->release();
 	} else slice = c->slice_hint;
@@ -591,7 +677,7 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 		if (map_batch_once(c, mo, &b, out + done, m, &n)) {
 			if (!g_oom || slice < 2) return -1;
 			slice /= 2;                                             // try smaller, from empty per-anchor arenas
-			DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev[0], &c->prev[1], &c->u, &c->ws, &c->sort_alt, &c->sort_ws};
+			DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev_stage, &c->u, &c->ws, &c->sort_alt, &c->sort_ws};
 			(void)hipStreamSynchronize(c->stream);
 			for (DevBuf *d : big) d->release();
 			continue;
@@ -616,7 +702,7 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 	const uint32_t R = in->n_reads;
 	int n_sub = c->n_sub;
 	while (n_sub > 1 && R / (uint32_t)n_sub < 2048u) --n_sub;
-	if (n_sub <= 1 || c->is_sub) return map_batch_single(c, mo, in, out, out_cap, n_out);
+	if (n_sub <= 1 || c->is_sub) { if (!c->is_sub) c->share = 1; return map_batch_single(c, mo, in, out, out_cap, n_out); }
 	*n_out = 0;
 	if (need_index(c)) return -1;
 	if (out_cap < R) { rh_set_error("output capacity %llu < %u reads", (unsigned long long)out_cap, R); return -1; }
@@ -652,6 +738,7 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 			uint64_t n = 0;
 			const bool saved = lc->is_sub;
 			lc->is_sub = true;                                      // no further splitting
+			lc->share = n_sub;                                      // the device's memory is shared by the sub-batches
 			rc[g] = map_batch_single(lc, mo, &b, out + lo[g], b.n_reads, &n);
 			lc->is_sub = saved;
 			if (rc[g]) err[g] = rh_last_error();
@@ -812,10 +899,10 @@ extern "C" int rh_seed_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, const
 		std::vector<uint32_t> np(n, 0);
 		for (uint32_t r = 0; r < R; ++r) np[r] = (uint32_t)(prev_offsets[r + 1] - prev_offsets[r]);
 		n_prev_total = prev_offsets[R];
-		if (c->prev[1].ensure((n_prev_total ? n_prev_total : 1) * 16)) return -1;
-		if (h2d(c->prev[1].p, prev, n_prev_total) || h2d(rd.n_prev, np.data(), R) || h2d(rd.prev_off, prev_offsets, R)) return -1;
-	} else if (c->prev[1].ensure(16)) return -1;
-	rr.prev_in = c->prev[1].as<rh_mm128_t>();
+		if (c->carry[1].ensure((n_prev_total ? n_prev_total : 1) * 16)) return -1;
+		if (h2d(c->carry[1].p, prev, n_prev_total) || h2d(rd.n_prev, np.data(), R) || h2d(rd.prev_off, prev_offsets, R)) return -1;
+	} else if (c->carry[1].ensure(16)) return -1;
+	rr.prev_in = c->carry[1].as<rh_mm128_t>();
 	RH_HIP(hipMemset(rr.counters, 0, 16 * 8));
 	hipStream_t s = c->stream;
 	rhk_probe(s, o, c->dix, rd, rr);
@@ -823,8 +910,8 @@ extern "C" int rh_seed_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, const
 	uint64_t total = 0;
 	RH_HIP(hipMemcpyAsync(&total, rr.a_off + R, 8, hipMemcpyDeviceToHost, s));
 	RH_HIP(hipStreamSynchronize(s));
-	if (stage_anchors(c, total, 0, &rr)) return -1;
-	rr.prev_in = c->prev[1].as<rh_mm128_t>();
+	if (stage_anchors(c, total, &rr)) return -1;
+	rr.prev_in = c->carry[1].as<rh_mm128_t>();
 	rhk_expand(s, o, c->dix, rd, rr);
 	if (rhk_sort(s, rr)) return -1;
 	RH_HIP(hipStreamSynchronize(s));
@@ -851,7 +938,7 @@ extern "C" int rh_chain_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, cons
 	rr.act = c->act[0].as<uint32_t>();
 	const uint64_t total = anchor_offsets[R];
 	for (uint32_t r = 0; r < R; ++r) { const uint64_t m = anchor_offsets[r + 1] - anchor_offsets[r]; if (m > rr.max_anchors) rr.max_anchors = (uint32_t)m; }
-	if (stage_anchors(c, total, 0, &rr)) return -1;
+	if (stage_anchors(c, total, &rr)) return -1;
 	std::vector<uint8_t> skip(R ? R : 1, 0);
 	if (h2d(rr.a_off, anchor_offsets, (size_t)R + 1) || h2d(rr.anc, anchors, total) || h2d(rr.skip, skip.data(), R)) return -1;
 	RH_HIP(hipMemset(rr.counters, 0, 16 * 8));
@@ -882,7 +969,7 @@ extern "C" int rh_sort128x_batch(rh_ctx *c, uint32_t n_seg, rh_mm128_t *a, const
 	RH_HIP(hipSetDevice(c->device));
 	const uint64_t total = n_seg ? offsets[n_seg] : 0;
 	rh_dev_round rr{};
-	if (stage_round(c, n_seg, &rr) || stage_anchors(c, total, 0, &rr)) return -1;
+	if (stage_round(c, n_seg, &rr) || stage_anchors(c, total, &rr)) return -1;
 	std::vector<uint8_t> skip(n_seg ? n_seg : 1, 0);
 	if (h2d(rr.raw, a, total) || h2d(rr.a_off, offsets, (size_t)n_seg + 1) || h2d(rr.skip, skip.data(), n_seg)) return -1;
 	if (rhk_sort(c->stream, rr)) return -1;

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(NT) void k_bs_holes(bs_ctx C)
 #define BS_LANE_NH 32
 #endif
 #ifndef BS_LANES_MIN_RANGES
-#define BS_LANES_MIN_RANGES 256           // ranges of a level from which the one-lane-per-range walker is used
+#define BS_LANES_MIN_RANGES 65536           // ranges of a level from which the one-lane-per-range walker is used
 #endif
 
 __global__ __launch_bounds__(64) void k_bs_walk_lanes(bs_ctx C)

@@ -10,7 +10,7 @@
 #define RH_CHUNK_MAX   4096          // samples of one chunk held in LDS by the event kernel
 #define RH_EV_CAP      2048          // events per chunk: peaks are >= 2 samples apart (revent.c:140)
 #define RH_MAX_CHUNKS  32            // chunk boundaries kept per read
-#define RH_WS_PER_ANCHOR 128         // bytes of per-anchor scratch shared by sort / DP / backtrack / regions
+#define RH_WS_PER_ANCHOR 64          // bytes of per-anchor scratch shared by DP / backtrack / compaction / regions (>= 128 B per chain: a chain has >= 2 anchors)
 #define RH_LOGF_N      (1u << 20)    // host-libm logf() table for integer arguments (MAPQ parity, hit.c:525-533)
 #define RH_DEV_MAXW    16            // largest minimiser window the device sketch supports
 
@@ -162,5 +162,8 @@ int rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd,
 void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r, const float *logf_tab);
 void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act_in, uint32_t n_in, uint32_t next_chunk,
                         uint32_t *act_out, uint32_t *n_out);
+void rhk_rebase_offsets(hipStream_t s, const uint64_t *a_off, uint32_t n, uint64_t *out);
+void rhk_carry_scan(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, uint64_t used, uint64_t *dst_off, uint64_t *total_out);
+void rhk_carry_copy(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, const rh_mm128_t *staging, const uint64_t *dst_off, rh_mm128_t *carry);
 void rhk_finalize(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, rh_map_record_t *rec);
 void rhk_synth_reads(hipStream_t s, const rh_synth_cfg_t &c, const int32_t *level16, uint64_t first, uint32_t n, int16_t *samples, uint64_t *off, double *cal_off, float *cal_scale);

@@ -830,6 +830,43 @@ __global__ __launch_bounds__(1024) void k_compact_active(rh_dev_opt o, rh_dev_re
 	for (uint32_t i = b; i < e; ++i) { const uint32_t r = act_in ? act_in[i] : i; if (!rd.done[r] && next_chunk < read_n_chunks(o, rd.l_sig[r])) act_out[run++] = r; }
 }
 
+// ------------------------------------------------------------------------------------------------ slices of a round, carried anchors
+// out[i] = a_off[i] - a_off[0] for the n + 1 offsets of a slice of the active list
+__global__ void k_rebase_offsets(const uint64_t *a_off, uint32_t n, uint64_t *out)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i <= n) out[i] = a_off[i] - a_off[0];
+}
+
+// The chained anchors a read carries into its next chunk (reg->prev_anchors) sit in the round's staging arena at the
+// read's anchor offset; they are packed read after read into the dense carry buffer.  One block: offsets of the slice's
+// reads in the carry buffer (from `used` on), total -> *total_out.
+__global__ __launch_bounds__(1024) void k_carry_scan(rh_dev_reads rd, const uint32_t *act, uint32_t n, uint64_t used, uint64_t *dst_off, uint64_t *total_out)
+{
+	__shared__ uint64_t s_part[1024];
+	const uint32_t tid = threadIdx.x, nt = blockDim.x;
+	const uint32_t per = (n + nt - 1) / nt, b = tid * per, e = b + per < n ? b + per : n;
+	uint64_t s = 0;
+	for (uint32_t i = b; i < e; ++i) s += rd.n_prev[act[i]];
+	s_part[tid] = s;
+	__syncthreads();
+	if (tid == 0) { uint64_t run = 0; for (uint32_t i = 0; i < nt; ++i) { const uint64_t v = s_part[i]; s_part[i] = run; run += v; } *total_out = run; }
+	__syncthreads();
+	uint64_t run = used + s_part[tid];
+	for (uint32_t i = b; i < e; ++i) { dst_off[i] = run; run += rd.n_prev[act[i]]; }
+}
+__global__ __launch_bounds__(NT) void k_carry_copy(rh_dev_reads rd, const uint32_t *act, uint32_t n, const rh_mm128_t *staging, const uint64_t *dst_off, rh_mm128_t *carry)
+{
+	const uint32_t a = blockIdx.x;
+	if (a >= n) return;
+	const uint32_t r = act[a], np = rd.n_prev[r];
+	const rh_mm128_t *src = staging + rd.prev_off[r];
+	rh_mm128_t *dst = carry + dst_off[a];
+	for (uint32_t j = threadIdx.x; j < np; j += NT) dst[j] = src[j];
+	__syncthreads();
+	if (threadIdx.x == 0) rd.prev_off[r] = dst_off[a];
+}
+
 // ------------------------------------------------------------------------------------------------ k_finalize
 // One thread per read: rmap.cpp:507-586.
 __global__ void k_finalize(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh_map_record_t *rec)
@@ -911,6 +948,9 @@ void rhk_scan_anchors(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round 
 void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_expand, r.n_act, NT, 0, s, o, ix, rd, r); }
 void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act_in, uint32_t n_in, uint32_t next_chunk, uint32_t *act_out, uint32_t *n_out)
 { RH_LAUNCH(k_compact_active, 1, 1024, 0, s, o, rd, act_in, n_in, next_chunk, act_out, n_out); }
+void rhk_rebase_offsets(hipStream_t s, const uint64_t *a_off, uint32_t n, uint64_t *out) { RH_LAUNCH(k_rebase_offsets, cdiv(n + 1, 256), 256, 0, s, a_off, n, out); }
+void rhk_carry_scan(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, uint64_t used, uint64_t *dst_off, uint64_t *total_out) { RH_LAUNCH(k_carry_scan, 1, 1024, 0, s, rd, act, n, used, dst_off, total_out); }
+void rhk_carry_copy(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, const rh_mm128_t *staging, const uint64_t *dst_off, rh_mm128_t *carry) { if (n) RH_LAUNCH(k_carry_copy, n, NT, 0, s, rd, act, n, staging, dst_off, carry); }
 void rhk_finalize(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, rh_map_record_t *rec) { if (rd.n_reads) RH_LAUNCH(k_finalize, cdiv(rd.n_reads, 256), 256, 0, s, o, ix, rd, rec); }
 void rhk_synth_reads(hipStream_t s, const rh_synth_cfg_t &c, const int32_t *level16, uint64_t first, uint32_t n, int16_t *samples, uint64_t *off, double *cal_off, float *cal_scale)
 { if (n) RH_LAUNCH(k_synth_reads, cdiv(n, 64), 64, 0, s, c, level16, first, n, samples, off, cal_off, cal_scale); }

@@ -504,7 +504,7 @@ __global__ void k_regions_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, co
 	if (only_flagged && !rr.need_exact[a]) return;
 	const rh_mm128_t *an = rr.anc + base;
 	const uint64_t *u = rr.u + base;
-	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;           // 128 B per anchor >= 128 B per chain
+	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;           // 64 B per anchor >= 128 B per chain (min_cnt >= 2)
 	rh_reg *rg = (rh_reg*)wsr;
 	rh_chain_head *ch = (rh_chain_head*)(wsr + (size_t)64 * n_u);
 	rh_mm128_t *z = (rh_mm128_t*)(wsr + (size_t)96 * n_u);

@@ -64,6 +64,27 @@ def test_exact_sort_multi_workgroup(ctx):
     pc.check_sort_big(ctx, seed=14, sizes=tuple([30000 + 17 * i for i in range(300)]), kinds=(0, 1, 0, 0, 3))
 
 
+def test_index_built_on_device(product_lib, tmp_path):
+    """rh_index_build_device = the host builder (pinned to the reference by tests/test_oracle.py): keys, counts, position
+    lists, mid_occ; targets with gaps / lower case / shorter than a seed; then a 6 Mbp reference (thousands of filter blocks)."""
+    checked, n = pc.check_device_index(product_lib, tmp_path)
+    assert checked > 1000 and n > 10000
+    pc.check_device_index(product_lib, tmp_path / "b", preset="fast", chrom_len=3_000_000, n_chrom=2, with_gaps=True, seed=9)
+
+
+def test_device_index_maps_like_uploaded_index(make_workload, product_lib):
+    """The table filled on the device serves reads exactly like the host-built, uploaded one (PAF vs the oracle)."""
+    from rawhash_amd.api import Index
+    w = make_workload(n_reads=300, n_samples=24_000, chrom_len=600_000)
+    c = Context(0, lib=product_lib)
+    dev = Index.build_device(c, w.fasta, w.model, w.opts, n_threads=8)
+    assert dev.n_keys == w.index.n_keys
+    recs = c.map_batch(w.opts, w.reads)
+    got = [strip_mt(x) for x in paf_lines(dev, recs, w.reads.names)]
+    assert got == w.oracle_paf()
+    c.close()
+
+
 def test_chain_adversarial(ctx, wl):
     """few reads -> workgroup walk in LDS; thousands -> the 64-candidates-per-round wave kernel"""
     for n_reads, max_n, seed in ((48, 900, 1), (2300, 260, 2), (2100, 60, 3)):
