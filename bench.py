@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 WORKLOADS = {
     #          chrom_len, n_chrom, preset, reads/GPU, cpu sample, name
-    "human": (129_166_667, 24, "fast", 8192, 6000, "human-scale (3.1 Gbp)"),
+    "human": (129_166_667, 24, "fast", 65536, 6000, "human-scale (3.1 Gbp)"),
     "dmel": (24_000_000, 6, "sensitive", 50_000, 12_000, "D. melanogaster-scale (144 Mbp)"),
     "ecoli": (4_600_000, 1, "sensitive", 100_000, 40_000, "E. coli-scale (4.6 Mbp)"),
 }
@@ -251,7 +251,7 @@ def cpu_baseline(ctx, index, opts, wl, model, workdir, preset, recs, args, cores
     t_ind = time.time() - t0
     reads = wl.reads(model, 0, n, n_threads=min(cores, 64), with_names=True)
     got = [strip_mt(x) for x in paf_lines(index, recs[:n], reads.names)]
-    sweep = [int(x) for x in args.cpu_threads.split(",")] if args.cpu_threads else sorted({max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores})
+    sweep = [int(x) for x in args.cpu_threads.split(",")] if args.cpu_threads else sorted({max(1, cores // 16), max(1, cores // 8), max(1, cores * 3 // 16), max(1, cores // 4), max(1, cores // 2), cores})
     if O.have_reference():
         rhr = os.path.join(workdir, "cpu_sample.rhr")
         reads.write(rhr, wl.cfg.digitisation, wl.cfg.range, wl.cfg.offset)

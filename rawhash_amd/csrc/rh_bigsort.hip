@@ -63,8 +63,8 @@ struct bs_ctx {
 	uint32_t *tile_h;                     // per tile: holes -> (after the scan) holes of the range before the tile
 	uint8_t *dg, *hd;                     // per record: digit; per hole: digit of its record
 	uint32_t *hp, *dest;                  // per hole: position in the range; hole (of the record's own region) it moves to
-	uint64_t *small_off[2]; uint32_t *small_cnt[2];   // segments for the block sorter, by the copy that holds them
-	uint32_t *hdr;                        // [0] ranges of this level [1] tiles [2],[3] block-sorter segments per copy [4] next level's ranges [5] error
+	uint64_t *small_off[4]; uint32_t *small_cnt[4];   // segments for the block sorter, by (copy that holds them) * 2 + (keys differ below bit 32 only)
+	uint32_t *hdr;                        // [0] ranges of this level [1] tiles [2..5] block-sorter segments per list [6] next level's ranges [7] error
 	uint32_t small_cap, rng_cap, n_lo;
 };
 
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(NT) void k_bs_init(rh_sort_job jb, bs_ctx C)
 		if (tid == 0) { s_run[0] += tot_r; s_run[1] += tot_t; }
 		__syncthreads();
 	}
-	if (tid == 0) { C.hdr[0] = s_run[0]; C.hdr[1] = s_run[1]; C.hdr[2] = 0; C.hdr[3] = 0; C.hdr[4] = 0; C.hdr[5] = s_run[0] > C.rng_cap ? 1u : 0u; }
+	if (tid == 0) { C.hdr[0] = s_run[0]; C.hdr[1] = s_run[1]; C.hdr[2] = 0; C.hdr[3] = 0; C.hdr[4] = 0; C.hdr[5] = 0; C.hdr[6] = 0; C.hdr[7] = s_run[0] > C.rng_cap ? 1u : 0u; }
 }
 
 __global__ __launch_bounds__(NT) void k_bs_clear(bs_ctx C)
@@ -204,17 +204,18 @@ __global__ __launch_bounds__(NT) void k_bs_plan(bs_ctx C)
 	}
 	const uint8_t alt = R.buf ^ 1;
 	if (fate == BS_SMALL) {
-		const uint32_t k = atomicAdd(&C.hdr[2 + alt], 1u);
-		if (k < C.small_cap) { C.small_off[alt][k] = R.beg + st; C.small_cnt[alt][k] = c; }
-		else C.hdr[5] = 1;
+		const uint32_t li = (uint32_t)alt * 2u + (s <= 32 ? 1u : 0u);   // the bucket's keys agree on every bit from s up
+		const uint32_t k = atomicAdd(&C.hdr[2 + li], 1u);
+		if (k < C.small_cap) { C.small_off[li][k] = R.beg + st; C.small_cnt[li][k] = c; }
+		else C.hdr[7] = 1;
 	} else if (fate == BS_BIG) {
-		const uint32_t k = atomicAdd(&C.hdr[4], 1u);
+		const uint32_t k = atomicAdd(&C.hdr[6], 1u);
 		if (k < C.rng_cap) {
 			bs_range q;
 			q.beg = R.beg + st; q.n = c; q.tile0 = 0; q.buf = alt; q.shift = (uint8_t)(s - 8);
 			for (int i = 0; i < 6; ++i) q.pad[i] = 0;
 			C.rng[1][k] = q;
-		} else C.hdr[5] = 1;
+		} else C.hdr[7] = 1;
 	}
 	M.fate[tid] = fate;
 }
@@ -343,60 +344,106 @@ __global__ __launch_bounds__(NT) void k_bs_holes(bs_ctx C)
 // ------------------------------------------------------------------------------------------------ K7: the token walk
 // The regions with holes are renumbered 0 .. nh-1 (digit order); the hole streams hold these dense numbers.
 //
-// k_bs_walk_lanes: ONE LANE per range (3 <= nh <= BS_LANE_NH).  A step is one dependent pair of loads (the region's
-// pointer from the lane's LDS column, the digit waiting there from the stream in HBM/L2); a wavefront advances 64 walks
-// per instruction, and the chip holds thousands of wavefronts: with tens of thousands of ranges per level (two per read)
-// the serial walks run at memory-system throughput instead of one walk's latency.
-// k_bs_walk_wave: one WAVEFRONT per range for the rest - nh == 2 is closed form (the i-th hole of the lower region
-// trades with the i-th of the upper one; all lanes), nh > BS_LANE_NH walks on lane 0 with the streams staged through
+// k_bs_walk_lanes<NHM, L>: ONE LANE per range (L walkers per wavefront, ranges with up to NHM regions).  A wavefront issues
+// one instruction for all its walkers, so many walks advance at the price of one; a walker's state - per region the
+// pointer and a 16-byte window of the hole digits waiting there - sits in its LDS column.  The walkers of a wavefront
+// advance in blocks of 8 steps on LDS alone, then the windows that are more than half used are reloaded from HBM/L2, all
+// loads in flight together: one memory round trip per block, one load per >= 9 pops of a region.
+// With tens of thousands of ranges per level (two per read on a large index) the serial walks run at the chip's
+// throughput instead of one walk's latency.
+// k_bs_walk_wave: one WAVEFRONT per range - nh == 2 is closed form (the i-th hole of the lower region trades with the
+// i-th of the upper one; all lanes); otherwise (levels with few ranges) lane 0 walks with the streams staged through
 // LDS windows (a ring per region, filled in aligned half-window blocks by all lanes) and one LDS read on the
-// dependency chain per step (s_head[region] = pointer + the digit waiting there + the region's window slot).
-#ifndef BS_LANE_NH
-#define BS_LANE_NH 32
-#endif
+// dependency chain per step (s_head[region] = pointer + the digit waiting there).
 #ifndef BS_LANES_MIN_RANGES
-#define BS_LANES_MIN_RANGES 65536           // ranges of a level from which the one-lane-per-range walker is used
+#define BS_LANES_MIN_RANGES 262144          // ranges of a level from which the one-lane-per-range walkers are used (measured on MI355X: below ~10^5 ranges a
+                                            // wavefront per range wins - its window refills are coalesced and rare, the lanes' are one cache line per region)
 #endif
+#define BS_LSTEPS 8
 
-__global__ __launch_bounds__(64) void k_bs_walk_lanes(bs_ctx C)
+template <int NHM, int L>
+__global__ __launch_bounds__(64) void k_bs_walk_lanes(bs_ctx C, uint32_t nh_lo)
 {
-	__shared__ uint32_t s_ptr[BS_LANE_NH * 64];
-	const uint32_t lane = threadIdx.x, r = blockIdx.x * 64 + lane, n_rng = C.hdr[0];
-	const bool mine = r < n_rng && C.meta[r].nh >= 3 && C.meta[r].nh <= (uint32_t)BS_LANE_NH;
+	__shared__ uint32_t s_ptr[NHM * L], s_wb[NHM * L];
+	__shared__ uint64_t s_w0[NHM * L], s_w1[NHM * L];              // 16 digits from s_wb on
+	const uint32_t lane = threadIdx.x, r = blockIdx.x * L + lane, n_rng = C.hdr[0];
+	bool mine = lane < (uint32_t)L && r < n_rng;
+	uint32_t nh = 0;
+	if (mine) { nh = C.meta[r].nh; mine = nh > nh_lo && nh <= (uint32_t)NHM && nh > 2; }
 	if (__ballot(mine) == 0) return;
 	const bs_range R = C.rng[0][mine ? r : 0];
 	bs_meta &M = C.meta[mine ? r : 0];
-	const uint32_t nh = mine ? M.nh : 0u;
-	for (uint32_t q = 0; q < nh; ++q) s_ptr[q * 64 + lane] = M.hst[M.act[q]];
+	if (!mine) nh = 0;
 	const uint8_t *hd = C.hd + R.beg;
 	uint32_t *dest = C.dest + R.beg;
-	uint32_t k = 0, pk = 0, ek = 0, i0 = 0, i = 0, d = 0;
+	#define LW(q) ((q) * (uint32_t)L + lane)
+	// the 16 digits from pointer p_ on: three aligned 8-byte loads (one or two cache lines), joined after they arrive
+	#define BS_WLOAD(p_, a0_, a1_, a2_, sh_) do { const uintptr_t ua_ = (uintptr_t)(hd + (p_)); const uint64_t *al_ = (const uint64_t*)(ua_ & ~(uintptr_t)7); \
+		sh_ = (uint32_t)(ua_ & 7u) * 8u; a0_ = al_[0]; a1_ = al_[1]; a2_ = al_[2]; } while (0)
+	#define BS_WJOIN(lo_, hi_, sh_) ((sh_) ? ((lo_) >> (sh_)) | ((hi_) << (64u - (sh_))) : (lo_))
+	for (uint32_t q = 0; q < nh; ++q) {
+		const uint32_t p = M.hst[M.act[q]];
+		uint64_t a0, a1, a2; uint32_t sh;
+		BS_WLOAD(p, a0, a1, a2, sh);
+		s_ptr[LW(q)] = p; s_wb[LW(q)] = p; s_w0[LW(q)] = BS_WJOIN(a0, a1, sh); s_w1[LW(q)] = BS_WJOIN(a1, a2, sh);
+	}
+	uint32_t k = 0, ek = 0, i0 = 0, i = 0, d = 0;
 	bool inchase = false, live = mine;
-	if (live) { pk = M.hst[M.act[0]]; ek = M.hst[M.act[0] + 1u]; }
+	if (live) ek = M.hst[M.act[0] + 1u];
 	while (__ballot(live)) {
-		if (live) {
-			uint32_t j;
-			if (!inchase) {
-				while (pk >= ek) {	// region k is complete: the walk turns to the next one (arrivals so far = its J)
-					if (++k >= nh) { live = false; break; }
-					const uint32_t dk = M.act[k], h0 = M.hst[dk];
-					pk = s_ptr[k * 64 + lane]; ek = M.hst[dk + 1u];
-					M.J[dk] = pk - h0;
-				}
-				if (live) { j = pk++; i0 = j; }
-			} else {
-				j = s_ptr[d * 64 + lane];
-				s_ptr[d * 64 + lane] = j + 1u;
-				dest[i] = j;
-			}
+		uint64_t hist = 0;
+		uint32_t npop = 0;
+#pragma unroll
+		for (int st = 0; st < BS_LSTEPS; ++st) {
 			if (live) {
-				i = j;
-				d = hd[j];
-				inchase = d != k;
-				if (!inchase) dest[i] = i0;
+				uint32_t q = d;
+				if (!inchase) {
+					uint32_t pk = s_ptr[LW(k)];
+					while (pk >= ek) {	// region k is complete: the walk turns to the next one (arrivals so far = its J)
+						if (++k >= nh) { live = false; break; }
+						const uint32_t dk = M.act[k];
+						pk = s_ptr[LW(k)]; ek = M.hst[dk + 1u];
+						M.J[dk] = pk - M.hst[dk];
+					}
+					q = k;
+				}
+				if (live) {
+					const uint32_t j = s_ptr[LW(q)];
+					s_ptr[LW(q)] = j + 1u;
+					if (inchase) dest[i] = j; else i0 = j;
+					const uint32_t off = j - s_wb[LW(q)];
+					const uint64_t w = off & 8u ? s_w1[LW(q)] : s_w0[LW(q)];
+					d = (uint32_t)(w >> ((off & 7u) * 8u)) & 255u;
+					hist |= (uint64_t)q << (8u * npop);
+					++npop;
+					i = j;
+					inchase = d != k;
+					if (!inchase) dest[i] = i0;
+				}
 			}
 		}
+		// A window holds 16 digits and a block pops at most 8 of a region: the windows of the regions popped in this block
+		// that are more than half used are reloaded (every load first, then the LDS stores) - one reload per >= 9 pops
+		uint64_t a0[BS_LSTEPS], a1[BS_LSTEPS], a2[BS_LSTEPS];
+		uint32_t sh[BS_LSTEPS], pp[BS_LSTEPS];
+		bool rl[BS_LSTEPS];
+#pragma unroll
+		for (int t = 0; t < BS_LSTEPS; ++t) {
+			a0[t] = 0; a1[t] = 0; a2[t] = 0; sh[t] = 0; pp[t] = 0; rl[t] = false;
+			if ((uint32_t)t < npop) {
+				const uint32_t q = (uint32_t)(hist >> (8 * t)) & 255u;
+				pp[t] = s_ptr[LW(q)];
+				rl[t] = pp[t] - s_wb[LW(q)] > 8u;
+				if (rl[t]) BS_WLOAD(pp[t], a0[t], a1[t], a2[t], sh[t]);
+			}
+		}
+#pragma unroll
+		for (int t = 0; t < BS_LSTEPS; ++t)
+			if (rl[t]) { const uint32_t q = (uint32_t)(hist >> (8 * t)) & 255u; s_w0[LW(q)] = BS_WJOIN(a0[t], a1[t], sh[t]); s_w1[LW(q)] = BS_WJOIN(a1[t], a2[t], sh[t]); s_wb[LW(q)] = pp[t]; }
 	}
+	#undef LW
+	#undef BS_WLOAD
+	#undef BS_WJOIN
 }
 
 #define BS_INVALID (1u << 31)
@@ -413,7 +460,7 @@ __global__ __launch_bounds__(64) void k_bs_walk_wave(bs_ctx C, int all)
 	const bs_range R = C.rng[0][r];
 	bs_meta &M = C.meta[r];
 	const uint32_t nh = M.nh;
-	if (nh == 0 || (!all && nh >= 3 && nh <= (uint32_t)BS_LANE_NH)) return;
+	if (nh == 0 || (!all && nh >= 3)) return;
 	for (uint32_t q = lane; q < nh; q += 64) { const uint32_t dk = M.act[q]; s_h0[q] = M.hst[dk]; s_end[q] = M.hst[dk + 1u]; }
 	__syncthreads();
 	const uint8_t *hd = C.hd + R.beg;
@@ -530,7 +577,7 @@ __global__ __launch_bounds__(NT) void k_bs_next(bs_ctx C)
 {
 	__shared__ uint32_t s_w[NT / 64];
 	const uint32_t tid = threadIdx.x;
-	const uint32_t n = C.hdr[4] < C.rng_cap ? C.hdr[4] : C.rng_cap;
+	const uint32_t n = C.hdr[6] < C.rng_cap ? C.hdr[6] : C.rng_cap;
 	uint32_t run = 0;
 	for (uint32_t i0 = 0; i0 < n; i0 += NT) {
 		const uint32_t i = i0 + tid;
@@ -541,21 +588,21 @@ __global__ __launch_bounds__(NT) void k_bs_next(bs_ctx C)
 		run += tot;
 	}
 	__syncthreads();
-	if (tid == 0) { C.hdr[0] = n; C.hdr[1] = run; C.hdr[4] = 0; }
+	if (tid == 0) { C.hdr[0] = n; C.hdr[1] = run; C.hdr[6] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------ host
 size_t rhk_bigsort_ws_bytes(uint64_t total, uint32_t n_lo)
 {
 	const uint64_t t = total ? total : 1, lo = n_lo ? n_lo : 1;
-	const uint64_t rng_cap = t / (lo + 1) + 2, small_cap = t / 4 + 256, tiles = t / BS_TILE + rng_cap + 2;
+	const uint64_t rng_cap = t / (lo + 1) + 2, small_cap = t / 8 + 256, tiles = t / BS_TILE + rng_cap + 2;
 	size_t b = 256;                                                // hdr
 	b += 2 * ((rng_cap * sizeof(bs_range) + 255) & ~(size_t)255);
 	b += (rng_cap * sizeof(bs_meta) + 255) & ~(size_t)255;
 	b += (tiles * 4 + 255) & ~(size_t)255;
-	b += 2 * ((t + 255) & ~(size_t)255);                           // dg, hd
+	b += 2 * ((t + 128 + 255) & ~(size_t)255);                      // dg, hd
 	b += 2 * ((t * 4 + 255) & ~(size_t)255);                       // hp, dest
-	b += 2 * ((small_cap * 8 + 255) & ~(size_t)255) + 2 * ((small_cap * 4 + 255) & ~(size_t)255);
+	b += 4 * ((small_cap * 8 + 255) & ~(size_t)255) + 4 * ((small_cap * 4 + 255) & ~(size_t)255);
 	return b;
 }
 
@@ -566,7 +613,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	bs_ctx C{};
 	C.buf[0] = const_cast<rh_mm128_t*>(jb.src); C.buf[1] = jb.big_alt; C.dst = jb.dst;
 	C.n_lo = n_lo;
-	C.rng_cap = (uint32_t)(t / (lo + 1) + 2); C.small_cap = (uint32_t)(t / 4 + 256);
+	C.rng_cap = (uint32_t)(t / (lo + 1) + 2); C.small_cap = (uint32_t)(t / 8 + 256);
 	const uint64_t tiles_cap = t / BS_TILE + C.rng_cap + 2;
 	unsigned char *p = jb.big_ws;
 	auto take = [&](size_t bytes) { unsigned char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
@@ -574,9 +621,9 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	C.rng[0] = (bs_range*)take((size_t)C.rng_cap * sizeof(bs_range)); C.rng[1] = (bs_range*)take((size_t)C.rng_cap * sizeof(bs_range));
 	C.meta = (bs_meta*)take((size_t)C.rng_cap * sizeof(bs_meta));
 	C.tile_h = (uint32_t*)take(tiles_cap * 4);
-	C.dg = (uint8_t*)take(t); C.hd = (uint8_t*)take(t);
+	C.dg = (uint8_t*)take(t); C.hd = (uint8_t*)take(t + 128);   // (+64: the lane walkers read whole aligned words around a pointer)
 	C.hp = (uint32_t*)take(t * 4); C.dest = (uint32_t*)take(t * 4);
-	for (int q = 0; q < 2; ++q) { C.small_off[q] = (uint64_t*)take((size_t)C.small_cap * 8); C.small_cnt[q] = (uint32_t*)take((size_t)C.small_cap * 4); }
+	for (int q = 0; q < 4; ++q) { C.small_off[q] = (uint64_t*)take((size_t)C.small_cap * 8); C.small_cnt[q] = (uint32_t*)take((size_t)C.small_cap * 4); }
 	if ((size_t)(p - jb.big_ws) > jb.big_ws_bytes) { rh_set_error("segment sorter: scratch of %zu bytes is too small (%zu needed)", jb.big_ws_bytes, (size_t)(p - jb.big_ws)); return -1; }
 	RH_LAUNCH(k_bs_init, 1, NT, 0, s, jb, C);
 	uint32_t *pin = (uint32_t*)jb.big_pin;
@@ -584,7 +631,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		RH_HIP(hipMemcpyAsync(pin, C.hdr, 32, hipMemcpyDeviceToHost, s));
 		RH_HIP(hipStreamSynchronize(s));
 		const uint32_t n_rng = pin[0], n_tiles = pin[1];
-		if (pin[5]) { rh_set_error("segment sorter: range / segment list overflow"); return -1; }
+		if (pin[7]) { rh_set_error("segment sorter: range / segment list overflow"); return -1; }
 		if (n_rng == 0) break;
 		RH_LAUNCH(k_bs_clear, n_rng, NT, 0, s, C);
 		RH_LAUNCH(k_bs_diff, n_tiles, NT, 0, s, C);
@@ -596,18 +643,24 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		// few ranges: a wavefront each (nothing to gain from 64 walks per wavefront); many: one lane each where the regions fit
 		const int lanes = n_rng >= (uint32_t)BS_LANES_MIN_RANGES;
 		RH_LAUNCH(k_bs_walk_wave, n_rng, 64, 0, s, C, lanes ? 0 : 1);
-		if (lanes) RH_LAUNCH(k_bs_walk_lanes, (n_rng + 63) / 64, 64, 0, s, C);
+		if (lanes) {	// by number of regions with holes: 64 / 32 / 8 walkers per wavefront
+			RH_LAUNCH((k_bs_walk_lanes<24, 64>), (n_rng + 63) / 64, 64, 0, s, C, 2u);
+			RH_LAUNCH((k_bs_walk_lanes<64, 32>), (n_rng + 31) / 32, 64, 0, s, C, 24u);
+			RH_LAUNCH((k_bs_walk_lanes<256, 8>), (n_rng + 7) / 8, 64, 0, s, C, 64u);   // LDS: 24 B per region and walker (36 / 48 / 48 KB)
+		}
 		RH_LAUNCH(k_bs_scatter, n_tiles, NT, 0, s, C);
 		RH_LAUNCH(k_bs_next, 1, NT, 0, s, C);
 		bs_range *tmp = C.rng[0]; C.rng[0] = C.rng[1]; C.rng[1] = tmp;
 	}
 	// the buckets that fit the LDS classes finish in the block sorter, from the copy that holds them
-	for (int q = 0; q < 2; ++q) {
+	const bool job32 = jb.kc_on && (uint32_t)jb.kc_lo + jb.kc_mid + jb.kc_hi <= 32u && jb.kc_mid <= 24u;
+	for (int q = 0; q < 4; ++q) {
 		const uint32_t ns = pin[2 + q];
 		if (!ns) continue;
 		rh_sort_job sj = jb;
 		sj.n_seg = ns; sj.skip = nullptr; sj.off = C.small_off[q]; sj.cnt = C.small_cnt[q];
-		sj.src = C.buf[q]; sj.dst = jb.dst; sj.need_exact = nullptr; sj.n_max = n_lo;
+		sj.src = C.buf[q >> 1]; sj.dst = jb.dst; sj.need_exact = nullptr; sj.n_max = n_lo;
+		if ((q & 1) && !job32) { sj.kc_on = 1; sj.kc_lo = 32; sj.kc_mid = 0; sj.kc_hi = 0; }   // keys that differ below bit 32 only: 32-bit words in LDS
 		sj.big_alt = nullptr; sj.big_ws = nullptr;
 		rhk_sort_job(s, sj, all_exact, 1u);
 	}

@@ -735,6 +735,9 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 #ifndef RGR_PRIM_CAP
 #define RGR_PRIM_CAP (64 * RGR_SLOTS)
 #endif
+#ifndef RGR_DIRECT
+#define RGR_DIRECT 4096     // chains per read from which the one-slot instance is skipped
+#endif
 
 template <int P>
 __global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, const float *logf_tab, uint32_t n_lo, int only_flagged)
@@ -745,6 +748,9 @@ __global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads r
 	const int32_t n_u = (int32_t)rr.n_u[a];
 	if (n_u <= (int32_t)n_lo) return;
 	if (only_flagged && !rr.need_exact[a]) return;                   // settled by the narrower instance
+	// tens of thousands of chains (an unmappable read on a large index, chunk after chunk) hold more than 64 primaries as a
+	// rule: such reads go to the wider instance directly instead of streaming through this one first
+	if (!only_flagged && P < RGR_SLOTS && n_u > RGR_DIRECT) { if (lane == 0) rr.need_exact[a] = 1; return; }
 	const uint32_t r = rr.act[a];
 	const uint64_t base = rr.a_off[a];
 	const rh_chain_head *heads = (const rh_chain_head*)(rr.ws + base * RH_WS_PER_ANCHOR);
