@@ -285,7 +285,8 @@ extern "C" int rh_ctx_create(rh_ctx **out, int device_id)
 	if (n <= 0) { rh_set_error("no HIP device visible: the mapping path has no CPU fallback"); return -1; }
 	if (device_id < 0 || device_id >= n) { rh_set_error("device %d out of range (%d visible)", device_id, n); return -1; }
 	RH_HIP(hipSetDevice(device_id));
-	std::unique_ptr<rh_ctx> c(new rh_ctx());
+	struct CtxDel { void operator()(rh_ctx *p) const { rh_ctx_destroy(p); } };   // failure paths release stream / events / buffers too
+	std::unique_ptr<rh_ctx, CtxDel> c(new rh_ctx());
 	c->device = device_id;
 	RH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	RH_HIP(hipEventCreate(&c->e0));
@@ -397,6 +398,12 @@ extern "C" int rh_index_adopt_blob(rh_ctx *c, const rh_index *, void *dev_ptr, u
 {
 	BlobHeader h; memcpy(&h, header, sizeof(h));
 	if (h.magic != kBlobMagic || h.bytes != bytes) { rh_set_error("index blob header mismatch"); return -1; }
+	{	// the offsets must describe three aligned, non-overlapping arrays inside the blob
+		const uint64_t tb = h.lg_buckets >= 0 && h.lg_buckets < 40 ? ((uint64_t)RH_TB_SLOTS << h.lg_buckets) * sizeof(rh_tslot) : ~0ull;
+		const bool ok = tb != ~0ull && (h.table_off & 15) == 0 && (h.pos_off & 7) == 0 && (h.len_off & 3) == 0 &&
+		                h.table_off + tb <= h.pos_off && h.n_pos <= (h.bytes >> 3) && h.pos_off + h.n_pos * 8 <= h.len_off && h.len_off + (uint64_t)h.n_seq * 4 <= h.bytes;
+		if (!ok) { rh_set_error("index blob header is inconsistent (offsets / sizes)"); return -1; }
+	}
 	if (c->blob_owned) c->blob.release();
 	c->blob.p = dev_ptr; c->blob.cap = bytes; c->blob_owned = take_ownership != 0;
 	return bind_blob(c, h);
@@ -628,6 +635,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 		RH_HIP(hipStreamSynchronize(s));
 		c->stats.n_events = cnt[0]; c->stats.n_seeds = cnt[1]; c->stats.n_hits = cnt[2]; c->stats.n_anchors = cnt[3]; c->stats.n_chained = cnt[4];
 		c->stats.n_samples_used = cnt[5]; c->stats.n_chunks = cnt[6];
+		if (cnt[7]) { rh_set_error("%llu chunk(s) hold more than %d event boundaries: beyond the per-chunk arrays of the device path", (unsigned long long)cnt[7], RH_EV_CAP); return -1; }
 	}
 	RH_HIP(hipStreamSynchronize(s));                                // the last stop event
 	stage_timers_collect(c);
@@ -708,8 +716,9 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 	if (out_cap < R) { rh_set_error("output capacity %llu < %u reads", (unsigned long long)out_cap, R); return -1; }
 	RH_HIP(hipSetDevice(c->device));
 	while ((int)c->subs.size() < n_sub - 1) {
-		std::unique_ptr<rh_ctx> sc(new rh_ctx());
-		sc->device = c->device; sc->is_sub = true; sc->n_sub = 1;
+		struct CtxDel { void operator()(rh_ctx *p) const { rh_ctx_destroy(p); } };
+		std::unique_ptr<rh_ctx, CtxDel> sc(new rh_ctx());
+		sc->device = c->device; sc->is_sub = true; sc->n_sub = 1; sc->blob_owned = false; sc->logf_tab.owned = false;
 		RH_HIP(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
 		RH_HIP(hipEventCreate(&sc->e0));
 		RH_HIP(hipEventCreate(&sc->e1));
@@ -748,8 +757,8 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 	for (int g = 0; g < n_sub; ++g) if (rc[g]) { rh_set_error("sub-batch %d: %s", g, err[g].c_str()); return -1; }
 	// merge the statistics of the sub-batches into this context's
 	rh_map_stats_t tot = c->stats;
-	for (rh_ctx *sc : c->subs) {
-		const rh_map_stats_t &q = sc->stats;
+	for (int g = 1; g < n_sub; ++g) {	// (only the sub-batches of THIS call: earlier, larger batches may have created more)
+		const rh_map_stats_t &q = c->subs[g - 1]->stats;
 		tot.n_reads += q.n_reads; tot.n_chunks += q.n_chunks; tot.n_samples_raw += q.n_samples_raw; tot.n_samples_used += q.n_samples_used;
 		tot.n_events += q.n_events; tot.n_seeds += q.n_seeds; tot.n_hits += q.n_hits; tot.n_anchors += q.n_anchors; tot.n_chained += q.n_chained;
 		for (int i = 0; i < 24; ++i) { tot.ms_kernel[i] += q.ms_kernel[i]; tot.n_launch[i] += q.n_launch[i]; }

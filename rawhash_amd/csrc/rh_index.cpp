@@ -8,6 +8,7 @@
 #include "rh_index.h"
 #include "rh_core.h"
 #include <algorithm>
+#include <exception>
 #include <cmath>
 #include <memory>
 #include <thread>
@@ -223,7 +224,14 @@ bool rh_load_model(const char *path, int k, int lev_col, std::vector<float> &val
 void rh_make_pore_inds(const std::vector<float> &vals, int k, std::vector<unsigned char> &blob) { make_pore_inds(vals, k, blob); }
 bool rh_read_fasta(const char *path, std::vector<std::string> &names, std::vector<std::string> &seqs) { return read_fasta(path, names, seqs); }
 
+static rh_index *index_load(const char *path);
 extern "C" rh_index *rh_index_load(const char *path)
+{
+	try { return index_load(path); }
+	catch (const std::exception &e) { rh_set_error("%s: %s", path, e.what()); return nullptr; }   // (bad_alloc must not cross the C ABI)
+}
+
+static rh_index *index_load(const char *path)
 {
 	FILE *fp = fopen(path, "rb");
 	if (!fp) { rh_set_error("cannot open %s", path); return nullptr; }
@@ -231,10 +239,13 @@ extern "C" rh_index *rh_index_load(const char *path)
 	char magic[2];
 	uint32_t pars[7];
 	auto fail = [&](const char *what) { fclose(fp); rh_set_error("%s: %s", path, what); return (rh_index*)nullptr; };
+	auto remaining = [&]() -> uint64_t { const long at = ftell(fp); if (at < 0 || fseek(fp, 0, SEEK_END)) return 0; const long end = ftell(fp); fseek(fp, at, SEEK_SET); return end > at ? (uint64_t)(end - at) : 0; };
+	const uint64_t file_bytes = remaining();
 	if (!rd(fp, magic, 1, 2) || magic[0] != 'R' || magic[1] != 'I') return fail("not a RawHash2 index (magic)");
 	if (!rd(fp, pars, 4, 7)) return fail("truncated header");
 	ix->w = pars[0]; ix->e = pars[1]; ix->n = pars[2]; ix->q = pars[3]; ix->k = pars[4]; ix->flag = pars[6];
 	const uint32_t n_seq = pars[5];
+	if ((uint64_t)n_seq * 5 > file_bytes) return fail("implausible number of sequences");
 	if (!rd(fp, &ix->diff, 4, 1) || !rd(fp, &ix->fine_min, 4, 1) || !rd(fp, &ix->fine_max, 4, 1) || !rd(fp, &ix->fine_range, 4, 1)) return fail("truncated header");
 	unsigned char pore[32];
 	if (!rd(fp, pore, 1, 32)) return fail("truncated pore header");
@@ -251,19 +262,19 @@ extern "C" rh_index *rh_index_load(const char *path)
 		ix->names.push_back(name); ix->lens.push_back(len);
 		if (ix->flag & RH_I_STORE_SIG) {   // stored target signals are not used by this path: skip
 			uint32_t fl;
-			if (!rd(fp, &fl, 4, 1) || fseek(fp, (long)fl * 4, SEEK_CUR)) return fail("truncated stored signal");
-			if (!(ix->flag & RH_I_NO_REV_TARGET)) { if (!rd(fp, &fl, 4, 1) || fseek(fp, (long)fl * 4, SEEK_CUR)) return fail("truncated stored signal"); }
+			if (!rd(fp, &fl, 4, 1) || (uint64_t)fl * 4 > remaining() || fseek(fp, (long)((uint64_t)fl * 4), SEEK_CUR)) return fail("truncated stored signal");
+			if (!(ix->flag & RH_I_NO_REV_TARGET)) { if (!rd(fp, &fl, 4, 1) || (uint64_t)fl * 4 > remaining() || fseek(fp, (long)((uint64_t)fl * 4), SEEK_CUR)) return fail("truncated stored signal"); }
 		}
 	}
 	std::vector<Entry> ent;
 	std::vector<uint64_t> kv;
 	for (uint32_t b = 0; b < (1u << kBucketBits); ++b) {
 		int32_t np; uint32_t size;
-		if (!rd(fp, &np, 4, 1) || np < 0) return fail("truncated bucket");
+		if (!rd(fp, &np, 4, 1) || np < 0 || (uint64_t)np * 8 > remaining()) return fail("truncated bucket");
 		const uint64_t base = ix->pos.size();
 		ix->pos.resize(base + np);
 		if (np && !rd(fp, ix->pos.data() + base, 8, np)) return fail("truncated bucket positions");
-		if (!rd(fp, &size, 4, 1)) return fail("truncated bucket");
+		if (!rd(fp, &size, 4, 1) || (uint64_t)size * 16 > remaining()) return fail("truncated bucket");
 		kv.resize((size_t)size * 2);
 		if (size && !rd(fp, kv.data(), 8, (size_t)size * 2)) return fail("truncated bucket keys");
 		for (uint32_t j = 0; j < size; ++j) {

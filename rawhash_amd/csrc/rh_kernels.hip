@@ -517,7 +517,10 @@ __global__ __launch_bounds__(64) void k_events_peaks(rh_dev_opt o, rh_dev_round 
 			np += (uint32_t)(e_short + e_long);
 		}
 	}
-	if (a < rr.n_act && k == 0) rr.n_peaks[a] = np < RH_EV_CAP ? np : RH_EV_CAP;
+	if (a < rr.n_act && k == 0) {
+		rr.n_peaks[a] = np < RH_EV_CAP ? np : RH_EV_CAP;
+		if (np > RH_EV_CAP) atomicAdd((unsigned long long*)&rr.counters[7], 1ull);   // more peaks than the per-chunk arrays hold: the call fails (no silent divergence)
+	}
 }
 
 // IQR-fenced mean of one sorted segment (revent.c:158-180): fp32 sum in ascending order

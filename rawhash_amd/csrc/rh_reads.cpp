@@ -2,6 +2,7 @@
 // The loader produces the SoA/CSR batch the C ABI takes: raw int16 samples + per-read calibration
 // {offset (double), scale = (float)(range/digitisation)} exactly as ri_read_sig_slow5 derives them (rsig.c:494).
 #include "rh_common.h"
+#include <exception>
 
 struct rh_reads_s {
 	std::vector<std::string> names;
@@ -11,7 +12,24 @@ struct rh_reads_s {
 	std::vector<float> cal_scale;
 };
 
+static long file_remaining(FILE *fp)
+{
+	const long at = ftell(fp);
+	if (at < 0 || fseek(fp, 0, SEEK_END) != 0) return -1;
+	const long end = ftell(fp);
+	fseek(fp, at, SEEK_SET);
+	return end < at ? -1 : end - at;
+}
+
+static rh_reads *reads_load_rhr(const char *path);
+
 extern "C" rh_reads *rh_reads_load(const char *path)
+{
+	try { return reads_load_rhr(path); }
+	catch (const std::exception &e) { rh_set_error("%s: %s", path, e.what()); return 0; }   // (bad_alloc must not cross the C ABI)
+}
+
+static rh_reads *reads_load_rhr(const char *path)
 {
 	FILE *fp = fopen(path, "rb");
 	if (!fp) { rh_set_error("cannot open %s", path); return 0; }
@@ -24,9 +42,10 @@ extern "C" rh_reads *rh_reads_load(const char *path)
 	for (uint32_t i = 0; i < n; ++i) {
 		uint32_t l, ns; double dig, range, off;
 		std::string name;
-		bool ok = fread(&l, 4, 1, fp) == 1;
+		bool ok = fread(&l, 4, 1, fp) == 1 && (long)l <= file_remaining(fp);      // lengths are checked against what is left of the file
 		if (ok) { name.resize(l); ok = l == 0 || fread(&name[0], 1, l, fp) == l; }
 		ok = ok && fread(&ns, 4, 1, fp) == 1 && fread(&dig, 8, 1, fp) == 1 && fread(&range, 8, 1, fp) == 1 && fread(&off, 8, 1, fp) == 1;
+		ok = ok && (long)ns * 2 <= file_remaining(fp);
 		if (ok) {
 			size_t o = r->samples.size();
 			r->samples.resize(o + ns);

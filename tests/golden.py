@@ -14,7 +14,7 @@ def cases():
 
 def build_case(case, directory, lib):
     from conftest import Workload
-    return Workload(directory, lib, **case["workload"])
+    return Workload(directory, lib, **case["workload"], build_index=not case.get("gpu_only"))
 
 
 def expected_paf(case):

@@ -22,6 +22,11 @@ CASES = [
     {"name": "small_faster_minimizers", "workload": dict(preset="faster", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=160, junk=150, noise=150_000, read_seed=13)},
     {"name": "small_viral_dense", "workload": dict(preset="viral", chrom_len=150_000, n_chrom=1, n_samples=20_000, n_reads=120, junk=100, noise=100_000, read_seed=14)},
     {"name": "clean_ecoli_like", "workload": dict(preset="sensitive", chrom_len=1_000_000, n_chrom=1, n_samples=40_000, n_reads=200, junk=102, noise=0, read_seed=15)},
+    # BASELINE.json configs[0]: E. coli-sized genome, 1 k reads, the reference's own CPU path
+    {"name": "config1_ecoli_4p6M_1k", "workload": dict(preset="sensitive", chrom_len=4_600_000, n_chrom=1, n_samples=40_000, n_reads=1000, junk=102, noise=0, read_seed=3)},
+    # BASELINE.json configs[2] at its index size (144 Mbp in 6 targets): a sample of its read set; the index is too large for the
+    # CPU suite, so only the -m gpu tests (index built on the device) check this one
+    {"name": "config3_dmel_144M_384", "gpu_only": True, "workload": dict(preset="sensitive", chrom_len=24_000_000, n_chrom=6, n_samples=40_000, n_reads=384, junk=102, noise=0, read_seed=3)},
 ]
 
 
@@ -33,7 +38,7 @@ def main():
     assert O.have_reference(), "build oracle/_ref first (make -C oracle ref)"
     for case in CASES:
         with tempfile.TemporaryDirectory() as d:
-            w = Workload(d, lib, **case["workload"])
+            w = Workload(d, lib, **case["workload"], build_index=not case.get("gpu_only"))
             cfg = w.wl.cfg
             rhr = os.path.join(d, "reads.rhr")
             w.reads.write(rhr, cfg.digitisation, cfg.range, cfg.offset)

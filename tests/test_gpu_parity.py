@@ -131,13 +131,86 @@ def test_batch_split_invariance(ctx, wl):
 def test_golden_paf(product_lib, gpu_ctx_factory, tmp_path):
     """HIP path vs PAF produced by the pinned reference build itself (tests/golden/, made by make_golden.py)."""
     import golden
+    from rawhash_amd.api import Index
     for case in golden.cases():
         w = golden.build_case(case, tmp_path / case["name"], product_lib)
         c = gpu_ctx_factory()
-        c.upload(w.index)
+        if case.get("gpu_only"):     # config-scale reference (144 Mbp): index built on the device
+            w.index = Index.build_device(c, w.fasta, w.model, w.opts, n_threads=32)
+            w.opts.update(w.index)
+        else:
+            c.upload(w.index)
         recs = c.map_batch(w.opts, w.reads)
         got = [strip_mt(x) for x in paf_lines(w.index, recs, w.reads.names)]
-        assert got == golden.expected_paf(case)
+        want = golden.expected_paf(case)
+        bad = [(g, x) for g, x in zip(got, want) if g != x]
+        assert len(got) == len(want) and not bad, f"{case['name']}: {len(bad)} PAF lines differ, first: {bad[:1]}"
+
+
+def test_config2_ecoli_scale_vs_oracle(make_workload, product_lib):
+    """BASELINE.json configs[1] at its index size: 4.6 Mbp index, 2560 reads of the bench's read set (10 % unmappable: all ten
+    chunk rounds with carried chains), HIP path vs the oracle on all host cores."""
+    import os
+    w = make_workload(n_reads=2560, n_samples=40_000, chrom_len=4_600_000, n_chrom=1, junk=102, noise=0, read_seed=3)
+    c = Context(0, lib=product_lib)
+    c.upload(w.index)
+    recs = c.map_batch(w.opts, w.reads)
+    got = [strip_mt(x) for x in paf_lines(w.index, recs, w.reads.names)]
+    want = w.oracle_paf(n_threads=os.cpu_count() or 8)
+    bad = [(g, x) for g, x in zip(got, want) if g != x]
+    assert not bad, f"{len(bad)} of {len(want)} PAF lines differ, first: {bad[0]}"
+    assert (recs["tag_ci"] == 10).sum() > 100 and recs["mapped"].mean() > 0.85
+    c.close()
+
+
+@pytest.mark.timeout(1200)
+def test_human_scale_index_vs_reference(product_lib, tmp_path):
+    """BASELINE.json configs[3] at its index size: 3.1 Gbp in 24 targets, index built on the device; 512 reads of the bench's
+    read set (preset fast) mapped by the HIP path and by the CPU side reading the .ind this library wrote - the unmodified
+    reference (oracle/_ref/ref_harness) where its binary travelled, else the oracle."""
+    import ctypes as C
+    import os
+    import subprocess
+    import oracle_lib as O
+    from rawhash_amd.api import Index, MapOptions, SynthWorkload
+    shm = "/dev/shm" if os.access("/dev/shm", os.W_OK) else str(tmp_path)
+    wd = os.path.join(shm, f"rh_human_test_{os.getpid()}")
+    os.makedirs(wd, exist_ok=True)
+    try:
+        cores = os.cpu_count() or 8
+        wl = SynthWorkload(chrom_len=129_166_667, n_chrom=24, n_samples=40_000, junk_per_1024=102, lib=product_lib)
+        opts = MapOptions("fast", lib=product_lib)
+        model = os.path.join(wd, "model.txt")
+        product_lib.rh_synth_write_model(C.byref(wl.cfg), model.encode())
+        seqs = [wl.genome(ch, n_threads=min(cores, 64)) for ch in range(24)]
+        c = Context(0, lib=product_lib)
+        index = Index.build_device_seqs(c, [f"chr{i + 1}" for i in range(24)], seqs, model, opts, n_threads=min(cores, 64))
+        del seqs
+        opts.update(index)
+        assert index.n_positions > 4_000_000_000
+        reads = wl.reads(model, 0, 512, n_threads=min(cores, 64))
+        recs = c.map_batch(opts, reads)
+        got = [strip_mt(x) for x in paf_lines(index, recs, reads.names)]
+        index.download(c, n_threads=min(cores, 64))
+        ind = os.path.join(wd, "ref.ind")
+        index.write(ind)
+        c.close()
+        if O.have_reference():
+            rhr = os.path.join(wd, "reads.rhr")
+            reads.write(rhr, wl.cfg.digitisation, wl.cfg.range, wl.cfg.offset)
+            out = subprocess.run([O.REF_HARNESS, "map", "fast", ind, rhr, str(min(cores, 32))], check=True, capture_output=True, text=True).stdout
+            want = [O.strip_mt(x) for x in out.splitlines()]
+        else:
+            oix = O.OracleIndex(ind)
+            _, mo = O.preset("fast")
+            O.lib().ro_mapopt_update(C.byref(mo), oix.h)
+            want = [O.strip_mt(x) for x in O.paf_lines(oix, O.map_batch(oix, mo, reads.batch(), n_threads=cores), reads.names)]
+        bad = [(g, x) for g, x in zip(got, want) if g != x]
+        assert len(got) == len(want) == 512 and not bad, f"{len(bad)} PAF lines differ, first: {bad[:1]}"
+        assert recs["mapped"].mean() > 0.85
+    finally:
+        import shutil
+        shutil.rmtree(wd, ignore_errors=True)
 
 
 def test_large_batch_paths(make_workload, gpu_ctx_factory):
