@@ -137,6 +137,10 @@ RH_API int  rh_index_device_blob(rh_ctx *ctx, void **dev_ptr, uint64_t *bytes, v
 RH_API int  rh_index_copy_blob(rh_ctx *ctx, void *dst_dev_ptr);   /* device-to-device copy of the resident blob */
 RH_API int  rh_index_adopt_blob(rh_ctx *ctx, const rh_index *idx_meta /* may be NULL */, void *dev_ptr, uint64_t bytes,
                                 const void *header /* from rank 0 */, int take_ownership);
+/* Single-process replication (a multi-threaded C/C++ host driving all GPUs of a node, one rh_ctx each): the resident index of
+ * ctxs[0] is copied device-to-device (hipMemcpyPeer: xGMI where the GPUs are linked) into every other context, which adopts
+ * it.  One process per GPU replicates with RCCL instead (rawhash_amd.dist / bench.py). */
+RH_API int  rh_index_bcast(rh_ctx *const *ctxs, int n);
 
 /* ri_idx_gen rindex.c:900 on the GPU: sketches the targets, sorts and groups the seeds and fills the
  * HBM-resident table of this context directly (as rh_index_upload would), in seconds for a human-sized reference.
@@ -158,6 +162,23 @@ RH_API int  rh_index_write(const rh_index *idx, const char *out_ind);          /
 RH_API uint64_t rh_map_max_records(const rh_read_batch_t *in, const rh_mapopt_t *mo);
 RH_API int  rh_map_batch(rh_ctx *ctx, const rh_mapopt_t *mo, const rh_read_batch_t *in,
                          rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out);
+
+/* The reference keeps up to two mini-batches in flight (kt_pipeline rmap.cpp:852 with pl_threads = 2, rmap.cpp:831): step 0
+ * reads batch k+1 while step 1 maps batch k.  rh_map_submit starts mapping a batch and returns at once; rh_map_wait blocks
+ * until that batch's records are in `out` (same contents as rh_map_batch).  Up to RH_MAX_IN_FLIGHT batches may be in flight on
+ * one context (each has its own stream and arenas; the upload of one overlaps the kernels of the other); `in`, its arrays and
+ * `out` must stay valid until rh_map_wait returns.  submit/wait calls on one context come from one thread at a time. */
+#define RH_MAX_IN_FLIGHT 2
+typedef struct rh_ticket_s { int32_t slot; uint32_t serial; } rh_ticket_t;
+RH_API int  rh_map_submit(rh_ctx *ctx, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap, rh_ticket_t *ticket);
+RH_API int  rh_map_wait(rh_ctx *ctx, rh_ticket_t ticket, uint64_t *n_out);
+
+/* Page-locked host memory for read batches (the int16 staging buffers of SURVEY 8 f3): uploads from it run at PCIe speed and
+ * asynchronously, overlapped with the kernels of the other sub-batches / batches in flight. */
+RH_API void *rh_pinned_alloc(size_t bytes);
+/* copy of a device-resident batch (rh_synth_reads_device) in host arrays: samples[offsets[n]], offsets[n + 1], cal_*[n] */
+RH_API int   rh_read_batch_to_host(rh_ctx *ctx, const rh_read_batch_t *dev, int16_t *samples, uint64_t *offsets, double *cal_offset, float *cal_scale);
+RH_API void  rh_pinned_free(void *p);
 
 /* Counters of the last rh_map_batch call (for the roofline model). */
 typedef struct rh_map_stats_s {

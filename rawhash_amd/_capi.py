@@ -79,6 +79,10 @@ class MapStats(C.Structure):
                [("ms_total", C.c_double), ("ms_kernel", C.c_double * 24), ("n_launch", C.c_uint32 * 24)]
 
 
+class Ticket(C.Structure):
+    _fields_ = [("slot", C.c_int32), ("serial", C.c_uint32)]
+
+
 class SynthCfg(C.Structure):
     _fields_ = [
         ("model_seed", C.c_uint64), ("genome_seed", C.c_uint64), ("read_seed", C.c_uint64),
@@ -131,6 +135,9 @@ def _declare(lib):
         "rh_index_adopt_blob": (i32, [vp, vp, vp, u64, vp, i32]),
         "rh_map_max_records": (u64, [P(ReadBatch), P(MapOpt)]),
         "rh_map_batch": (i32, [vp, P(MapOpt), P(ReadBatch), vp, u64, P(u64)]),
+        "rh_map_submit": (i32, [vp, P(MapOpt), P(ReadBatch), vp, u64, P(Ticket)]), "rh_map_wait": (i32, [vp, Ticket, P(u64)]),
+        "rh_read_batch_to_host": (i32, [vp, P(ReadBatch), vp, vp, vp, vp]),
+        "rh_pinned_alloc": (vp, [C.c_size_t]), "rh_pinned_free": (None, [vp]), "rh_index_bcast": (i32, [P(vp), i32]),
         "rh_map_last_stats": (i32, [vp, P(MapStats)]), "rh_stage_name": (cp, [i32]),
         "rh_events_batch": (i32, [vp, P(MapOpt), P(ReadBatch), u32, vp, u64, vp, vp]),
         "rh_sketch_batch": (i32, [vp, u32, vp, vp, vp, u64, vp]),

@@ -230,6 +230,21 @@ class Context:
         _check(self._l.rh_map_batch(self.h, C.byref(opts.mo), C.byref(b), ptr(out), cap, C.byref(n)), self._l)
         return out[: n.value]
 
+    def map_submit(self, opts, batch):
+        """Start mapping a batch (rh_map_submit); returns a handle for map_wait.  Up to 2 batches may be in flight."""
+        b = batch.batch() if isinstance(batch, Reads) else batch
+        cap = self._l.rh_map_max_records(C.byref(b), C.byref(opts.mo))
+        out = np.zeros(max(cap, 1), dtype=RECORD)
+        t = _capi.Ticket()
+        _check(self._l.rh_map_submit(self.h, C.byref(opts.mo), C.byref(b), ptr(out), cap, C.byref(t)), self._l)
+        return (t, out, b)
+
+    def map_wait(self, handle):
+        t, out, _b = handle
+        n = C.c_uint64(0)
+        _check(self._l.rh_map_wait(self.h, t, C.byref(n)), self._l)
+        return out[: n.value]
+
     def stats(self):
         s = MapStats()
         self._l.rh_map_last_stats(self.h, C.byref(s))

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <memory>
+#include <string>
 #include <thread>
 #include <cstdlib>
 
@@ -82,6 +83,7 @@ struct rh_ctx_s {
 	DevBuf anc, raw_anc, zs, n_z, need_exact, need_exact2, prev_stage, u, n_u, n_v, ws, counters, rec;
 	DevBuf carry[2], carry_off, a_off_slice;                      // chained anchors carried into the next chunk, dense, ping-pong over the rounds
 	int share = 1;                                                 // sub-batches running concurrently on this device (memory budget per context)
+	int flight_mult = 1;                                           // batches in flight that share the device with this context's
 	DevBuf sort_alt, sort_ws;                                     // multi-workgroup segment sorter: second record array + tables (only when a read exceeds the LDS classes)
 	DevBuf sy_samples, sy_off, sy_cal_off, sy_cal_scale, sy_levels;
 	// timing
@@ -89,6 +91,9 @@ struct rh_ctx_s {
 	std::vector<hipEvent_t> ev_pool; std::vector<int> ev_stage; size_t ev_used = 0;   // stage timers of the batch in flight
 	uint64_t *pin = nullptr;                                       // pinned host words for the per-round read-backs
 	rh_map_stats_t stats{};
+	// batches in flight (rh_map_submit / rh_map_wait): a slot = a borrowed context + the thread mapping on it
+	struct Flight { rh_ctx *ctx = nullptr; std::thread th; bool busy = false; uint32_t serial = 0; int rc = 0; uint64_t n_out = 0; std::string err; };
+	Flight flight[RH_MAX_IN_FLIGHT];
 	// concurrent sub-batches: extra contexts (own stream + arenas) that borrow this context's index and tables
 	std::vector<rh_ctx*> subs;
 	int n_sub = 1;
@@ -307,6 +312,7 @@ extern "C" void rh_ctx_destroy(rh_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
+	for (auto &f : c->flight) { if (f.th.joinable()) f.th.join(); if (f.ctx) rh_ctx_destroy(f.ctx); f.ctx = nullptr; }
 	for (rh_ctx *sc : c->subs) rh_ctx_destroy(sc);
 	c->subs.clear();
 	DevBuf *all[] = {&c->logf_tab, &c->raw, &c->off, &c->cal_off, &c->cal_scale, &c->act[0], &c->act[1], &c->n_act_dev, &c->zbuf, &c->t1buf, &c->t2buf, &c->n_norm, &c->peaks, &c->n_peaks, &c->ev, &c->n_ev, &c->skip, &c->sx, &c->sy,
@@ -710,7 +716,7 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 	const uint32_t R = in->n_reads;
 	int n_sub = c->n_sub;
 	while (n_sub > 1 && R / (uint32_t)n_sub < 2048u) --n_sub;
-	if (n_sub <= 1 || c->is_sub) { if (!c->is_sub) c->share = 1; return map_batch_single(c, mo, in, out, out_cap, n_out); }
+	if (n_sub <= 1 || c->is_sub) { if (!c->is_sub) c->share = c->flight_mult; return map_batch_single(c, mo, in, out, out_cap, n_out); }
 	*n_out = 0;
 	if (need_index(c)) return -1;
 	if (out_cap < R) { rh_set_error("output capacity %llu < %u reads", (unsigned long long)out_cap, R); return -1; }
@@ -747,7 +753,7 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 			uint64_t n = 0;
 			const bool saved = lc->is_sub;
 			lc->is_sub = true;                                      // no further splitting
-			lc->share = n_sub;                                      // the device's memory is shared by the sub-batches
+			lc->share = n_sub * c->flight_mult;                     // the device's memory is shared by the sub-batches (of every batch in flight)
 			rc[g] = map_batch_single(lc, mo, &b, out + lo[g], b.n_reads, &n);
 			lc->is_sub = saved;
 			if (rc[g]) err[g] = rh_last_error();
@@ -766,6 +772,102 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 	tot.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 	c->stats = tot;
 	*n_out = R;
+	return 0;
+}
+
+// =================================================================================================== batches in flight
+namespace {
+// a context with its own stream and arenas that serves reads from `c`'s resident index
+rh_ctx *borrow_ctx(rh_ctx *c)
+{
+	rh_ctx *b = new rh_ctx();
+	b->device = c->device; b->blob_owned = false; b->logf_tab.owned = false; b->n_sub = c->n_sub; b->flight_mult = RH_MAX_IN_FLIGHT;
+	if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&b->e0) != hipSuccess || hipEventCreate(&b->e1) != hipSuccess) {
+		rh_set_error("cannot create the stream of a batch slot"); rh_ctx_destroy(b); return nullptr;
+	}
+	return b;
+}
+void lend_index(rh_ctx *c, rh_ctx *b)
+{
+	b->dix = c->dix; b->have_index = c->have_index; b->blob_owned = false;
+	b->akey_on = c->akey_on; b->akey_lo = c->akey_lo; b->akey_mid = c->akey_mid;
+	b->logf_tab.p = c->logf_tab.p; b->logf_tab.cap = c->logf_tab.cap; b->logf_tab.owned = false;
+	memcpy(b->header, c->header, sizeof(b->header));
+}
+} // namespace
+
+extern "C" int rh_map_submit(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap, rh_ticket_t *ticket)
+{
+	if (need_index(c)) return -1;
+	int slot = -1;
+	for (int i = 0; i < RH_MAX_IN_FLIGHT; ++i) if (!c->flight[i].busy) { slot = i; break; }
+	if (slot < 0) { rh_set_error("%d batches are in flight on this context already: rh_map_wait first", RH_MAX_IN_FLIGHT); return -1; }
+	auto &f = c->flight[slot];
+	if (f.th.joinable()) f.th.join();
+	if (!f.ctx && !(f.ctx = borrow_ctx(c))) return -1;
+	lend_index(c, f.ctx);
+	f.busy = true; f.rc = 0; f.n_out = 0; f.err.clear(); ++f.serial;
+	const rh_mapopt_t mo_copy = *mo;
+	const rh_read_batch_t in_copy = *in;
+	rh_ctx *fc = f.ctx;
+	auto *fp = &f;
+	f.th = std::thread([fc, fp, mo_copy, in_copy, out, out_cap]() {
+		uint64_t n = 0;
+		fp->rc = rh_map_batch(fc, &mo_copy, &in_copy, out, out_cap, &n);
+		fp->n_out = n;
+		if (fp->rc) fp->err = rh_last_error();
+	});
+	ticket->slot = slot; ticket->serial = f.serial;
+	return 0;
+}
+
+extern "C" int rh_map_wait(rh_ctx *c, rh_ticket_t t, uint64_t *n_out)
+{
+	if (t.slot < 0 || t.slot >= RH_MAX_IN_FLIGHT || !c->flight[t.slot].busy || c->flight[t.slot].serial != t.serial) { rh_set_error("rh_map_wait: no such batch in flight"); return -1; }
+	auto &f = c->flight[t.slot];
+	if (f.th.joinable()) f.th.join();
+	f.busy = false;
+	if (n_out) *n_out = f.n_out;
+	c->stats = f.ctx->stats;
+	if (f.rc) { rh_set_error("%s", f.err.c_str()); return -1; }
+	return 0;
+}
+
+// a device-resident batch (rh_synth_reads_device) copied into host arrays (n_reads + 1 offsets)
+extern "C" int rh_read_batch_to_host(rh_ctx *c, const rh_read_batch_t *dev, int16_t *samples, uint64_t *offsets, double *cal_offset, float *cal_scale)
+{
+	if (!dev->samples_on_device) { rh_set_error("rh_read_batch_to_host: the batch is not on the device"); return -1; }
+	RH_HIP(hipSetDevice(c->device));
+	const uint32_t n = dev->n_reads;
+	RH_HIP(hipMemcpy(offsets, dev->offsets, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
+	if (offsets[n]) RH_HIP(hipMemcpy(samples, dev->samples, (size_t)offsets[n] * 2, hipMemcpyDeviceToHost));
+	if (n) { RH_HIP(hipMemcpy(cal_offset, dev->cal_offset, (size_t)n * 8, hipMemcpyDeviceToHost)); RH_HIP(hipMemcpy(cal_scale, dev->cal_scale, (size_t)n * 4, hipMemcpyDeviceToHost)); }
+	return 0;
+}
+
+extern "C" void *rh_pinned_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 1, 0) != hipSuccess) { (void)hipGetLastError(); rh_set_error("cannot page-lock %zu bytes", bytes); return nullptr; }
+	return p;
+}
+extern "C" void rh_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
+
+extern "C" int rh_index_bcast(rh_ctx *const *ctxs, int n)
+{
+	if (n < 1 || need_index(ctxs[0])) return -1;
+	rh_ctx *src = ctxs[0];
+	BlobHeader h; memcpy(&h, src->header, sizeof(h));
+	for (int i = 1; i < n; ++i) {
+		rh_ctx *d = ctxs[i];
+		RH_HIP(hipSetDevice(d->device));
+		if (d->blob_owned) d->blob.release(); else { d->blob.p = nullptr; d->blob.cap = 0; }
+		d->blob_owned = true; d->have_index = false;
+		if (d->blob.ensure(h.bytes)) return -1;
+		RH_HIP(hipMemcpyPeer(d->blob.p, d->device, src->blob.p, src->device, h.bytes));
+		if (bind_blob(d, h)) return -1;
+	}
+	RH_HIP(hipSetDevice(src->device));
 	return 0;
 }
 

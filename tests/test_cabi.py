@@ -1,0 +1,39 @@
+"""A compiled C++ consumer of the C ABI (tests/cabi/rawhash2_step1.cpp = the INTEGRATION.md binding as a program): it must
+build against include/rawhash_amd.h alone with g++, and on the GPU print the reference's golden PAF with two mini-batches in
+flight (rh_map_submit / rh_map_wait)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cabi", "rawhash2_step1.cpp")
+
+
+def build_consumer(out_dir, product_lib):
+    exe = os.path.join(str(out_dir), "rawhash2_step1")
+    libdir = os.path.join(ROOT, "rawhash_amd")
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), SRC, "-o", exe,
+                    "-L", libdir, "-lrawhash_amd", f"-Wl,-rpath,{libdir}"], check=True)
+    return exe
+
+
+def test_consumer_builds_with_plain_gxx(tmp_path, product_lib):
+    exe = build_consumer(tmp_path, product_lib)
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 2 and "usage" in p.stderr
+
+
+@pytest.mark.gpu
+def test_consumer_prints_the_golden_paf(tmp_path, product_lib):
+    import golden
+    from rawhash_amd import strip_mt
+    exe = build_consumer(tmp_path, product_lib)
+    case = [c for c in golden.cases() if c["name"] == "small_sensitive"][0]
+    w = golden.build_case(case, tmp_path / "wl", product_lib)
+    rhr = os.path.join(str(tmp_path), "reads.rhr")
+    w.reads.write(rhr, w.wl.cfg.digitisation, w.wl.cfg.range, w.wl.cfg.offset)
+    for per in ("37", "1000"):      # five mini-batches with two in flight / one batch
+        p = subprocess.run([exe, "sensitive", w.ind, rhr, per], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        assert [strip_mt(x) for x in p.stdout.splitlines()] == golden.expected_paf(case)

@@ -77,3 +77,29 @@ def test_two_rank_gloo_matches_single_process_and_oracle(tmp_path, emu_lib):
     O.lib().ro_mapopt_update(C.byref(mo), oix.h)
     want = [O.strip_mt(x) for x in O.paf_lines(oix, O.map_batch(oix, mo, reads.batch()), reads.names)]
     assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """The multi-GPU flow of bench.py (rank 0 builds the index on its device, blob broadcast, every rank adopts it and maps its
+    shard, barrier + max-over-ranks timing) run as the driver launches it, with two ranks sharing the one GPU of the test box
+    (gloo instead of RCCL: two RCCL ranks cannot share a device)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RH_BENCH_BACKEND="gloo", RH_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "ecoli", "--reads", "6000", "--steps", "2", "--warmup", "1", "--cpu-sample", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=850)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert 0.85 < d["mapped_fraction"] < 0.95 and d["value_h2d_included"] > 0

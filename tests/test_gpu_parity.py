@@ -117,6 +117,30 @@ def test_ragged_and_empty_reads(ctx, wl):
     pc.check_e2e(ctx, wl, rd)
 
 
+def test_two_batches_in_flight(ctx, wl):
+    """rh_map_submit / rh_map_wait: two batches in flight on one context return what rh_map_batch returns for each."""
+    idx = list(range(len(wl.reads)))
+    ra, rb = wl.reads.subset(idx[:150]), wl.reads.subset(idx[150:])
+    want_a, want_b = ctx.map_batch(wl.opts, ra).copy(), ctx.map_batch(wl.opts, rb).copy()
+    for _ in range(3):
+        ha = ctx.map_submit(wl.opts, ra)
+        hb = ctx.map_submit(wl.opts, rb)
+        with pytest.raises(Exception):
+            ctx.map_submit(wl.opts, ra)                      # a third one is refused
+        assert np.array_equal(ctx.map_wait(ha), want_a) and np.array_equal(ctx.map_wait(hb), want_b)
+
+
+def test_index_bcast_between_contexts(product_lib, wl):
+    """rh_index_bcast: the resident index of one context copied device-to-device into another (here on the same GPU)."""
+    import ctypes as C
+    a, b = Context(0, lib=product_lib), Context(0, lib=product_lib)
+    a.upload(wl.index)
+    arr = (C.c_void_p * 2)(a.h, b.h)
+    assert product_lib.rh_index_bcast(arr, 2) == 0
+    assert np.array_equal(a.map_batch(wl.opts, wl.reads), b.map_batch(wl.opts, wl.reads))
+    a.close(); b.close()
+
+
 def test_batch_split_invariance(ctx, wl):
     """Mapping is per-read independent: any split of the batch gives the same records (property used by sharding)."""
     full = ctx.map_batch(wl.opts, wl.reads)
