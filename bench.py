@@ -164,19 +164,23 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     n_mapped = int(recs["mapped"].sum())
-    # The same steps with the batch handed over in (page-locked) HOST memory: every step uploads the int16 signal over PCIe;
-    # two batches are kept in flight (rh_map_submit / rh_map_wait, what kt_pipeline does in the reference), so the upload of
-    # one overlaps the kernels of the other.  Reported next to `value`, never instead of it.
+    # The same steps with the batch handed over in (page-locked) HOST memory: every step uploads the int16 signal over PCIe,
+    # each sub-batch its slice on its own stream (the upload of one overlaps the kernels of the others).  Reported next to
+    # `value`, never instead of it.  (RH_BENCH_IN_FLIGHT=2 keeps two steps in flight with rh_map_submit / rh_map_wait, what
+    # kt_pipeline does in the reference; on one GPU it halves each batch's arena share and measured slower, see DESIGN.md.)
     elapsed_h2d = None
     if args.h2d:
         host = host_copy(ctx, batch, args)
         sync()
         t0 = time.perf_counter()
-        pending = []
+        pending, depth = [], int(os.environ.get("RH_BENCH_IN_FLIGHT", "1"))
         for _ in range(args.steps):
+            if depth <= 1:
+                recs_h = ctx.map_batch(opts, host["batch"])
+                continue
             pending.append(ctx.map_submit(opts, host["batch"]))
-            if len(pending) == 2:
-                ctx.map_wait(pending.pop(0))
+            if len(pending) == depth:
+                recs_h = ctx.map_wait(pending.pop(0))
         while pending:
             recs_h = ctx.map_wait(pending.pop(0))
         sync()

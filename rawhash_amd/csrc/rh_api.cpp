@@ -250,6 +250,7 @@ uint64_t slice_budget(rh_ctx *c)
 		const size_t reserve = total_b / 24 > ((size_t)3 << 30) ? total_b / 24 : ((size_t)3 << 30);
 		const size_t avail = free_b > reserve ? free_b - reserve : 0;
 		budget = (uint64_t)((double)(avail / (size_t)(c->share > 0 ? c->share : 1) + held) * 0.80 / (double)kBytesPerAnchor);
+		if (budget < (1u << 16)) return 0;                          // the device is full (other contexts / processes hold it)
 	}
 	if (const char *cap_env = getenv("RH_ARENA_MAX_BYTES")) { const uint64_t m = strtoull(cap_env, nullptr, 10) / RH_WS_PER_ANCHOR; if (m < budget) budget = m; }
 	return budget > 1024 ? budget : 1024;
@@ -269,6 +270,24 @@ rh_dev_round slice_view(const rh_dev_round &rr, uint32_t lo, uint32_t n, uint64_
 	v.need_exact = rr.need_exact + lo; v.need_exact2 = rr.need_exact2 + lo;
 	v.n_u = rr.n_u + lo; v.n_v = rr.n_v + lo; v.n_z = rr.n_z + lo;
 	return v;
+}
+
+// device memory of the per-batch arenas of a context and of its sub-batch contexts (the resident index stays)
+void release_arenas(rh_ctx *c)
+{
+	(void)hipStreamSynchronize(c->stream);
+	DevBuf *all[] = {&c->raw, &c->off, &c->cal_off, &c->cal_scale, &c->act[0], &c->act[1], &c->zbuf, &c->t1buf, &c->t2buf, &c->n_norm, &c->peaks, &c->n_peaks, &c->ev, &c->n_ev, &c->skip, &c->sx, &c->sy,
+	                 &c->n_seed, &c->m_val, &c->m_n, &c->m_meta, &c->m_pref, &c->n_match, &c->n_new, &c->rep_len, &c->a_off, &c->anc, &c->raw_anc, &c->zs, &c->n_z, &c->need_exact, &c->need_exact2, &c->prev_stage,
+	                 &c->carry[0], &c->carry[1], &c->carry_off, &c->a_off_slice, &c->u, &c->n_u, &c->n_v, &c->ws, &c->sort_alt, &c->sort_ws, &c->rec};
+	for (DevBuf *b : all) b->release();
+	for (DevBuf &b : c->st) b.release();
+	for (rh_ctx *sc : c->subs) release_arenas(sc);
+}
+bool holds_arenas(const rh_ctx *c)
+{
+	if (c->anc.cap || c->zbuf.cap || c->raw.cap) return true;
+	for (const rh_ctx *sc : c->subs) if (holds_arenas(sc)) return true;
+	return false;
 }
 
 int need_index(rh_ctx *c) { if (!c->have_index) { rh_set_error("no index resident on this context (rh_index_upload first)"); return -1; } return 0; }
@@ -578,6 +597,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 		// The anchor-sized stages run over slices of the active reads whose anchors fit the device together (one slice unless
 		// the index is large and the batch big); the event / seeding stages above ran for all of them at once.
 		const uint64_t budget = slice_budget(c);
+		if (budget == 0) { rh_set_error("not enough free device memory for the anchor arenas of a batch (the index and other batches in flight hold it)"); return -1; }
 		std::vector<uint32_t> cuts;                                // slice boundaries in the active list
 		std::vector<uint64_t> a_off_h;
 		cuts.push_back(0);
@@ -713,6 +733,7 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 // concurrently, each on its own HIP stream with its own arenas, so the rounds of different sub-batches overlap.
 extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out)
 {
+	for (auto &f : c->flight) if (f.ctx && !f.busy && holds_arenas(f.ctx)) release_arenas(f.ctx);   // idle batch slots give their arenas back
 	const uint32_t R = in->n_reads;
 	int n_sub = c->n_sub;
 	while (n_sub > 1 && R / (uint32_t)n_sub < 2048u) --n_sub;
@@ -804,6 +825,7 @@ extern "C" int rh_map_submit(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_bat
 	if (slot < 0) { rh_set_error("%d batches are in flight on this context already: rh_map_wait first", RH_MAX_IN_FLIGHT); return -1; }
 	auto &f = c->flight[slot];
 	if (f.th.joinable()) f.th.join();
+	if (holds_arenas(c)) release_arenas(c);                         // arenas of earlier synchronous calls: the batches in flight need the memory
 	if (!f.ctx && !(f.ctx = borrow_ctx(c))) return -1;
 	lend_index(c, f.ctx);
 	f.busy = true; f.rc = 0; f.n_out = 0; f.err.clear(); ++f.serial;

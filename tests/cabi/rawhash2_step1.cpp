@@ -56,7 +56,7 @@ int main(int argc, char **argv)
 	for (uint32_t k = 0; k < n; ++k) {                             // step 2: PAF in read order
 		const int len = rh_paf_format(idx, &rec[k], rh_reads_name(reads, rec[k].read_idx), 0.0, line, sizeof(line));
 		if (len < 0) return fail("rh_paf_format");
-		if (len) { fwrite(line, 1, (size_t)len, stdout); fputc('\n', stdout); }
+		if (len) fwrite(line, 1, (size_t)len, stdout);                // (the line ends with its newline, as fprintf'd by rmap.cpp:751)
 	}
 	rh_reads_destroy(reads); rh_ctx_destroy(ctx); rh_index_destroy(idx);
 	return 0;
