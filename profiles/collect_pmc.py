@@ -14,20 +14,35 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGE_OF = {"k_regions_reg": "regions", "k_chain_reorder": "backtrack", "k_regions_wave<1536>": "regions", "k_regions_wave<256>": "regions", "k_prefilter": "prefilter", "k_events_norm": "events_norm", "k_events_tstat": "events_norm", "k_events_peaks": "events_peaks", "k_events_means": "events_means",
-            "k_sketch": "sketch", "k_probe": "probe", "k_expand": "expand", "k_chain_wave": "chain", "k_backtrack_big": "backtrack",
-            "k_regions_wave": "regions"}
+WORKLOAD = os.environ.get("RH_PMC_WORKLOAD", "human")
+READS = int(os.environ.get("RH_PMC_READS", "65536"))
+SAMPLES, JUNK = 40000, 102
 
+# every kernel of the mapping path belongs to a stage of bench.py's table (prefix match on the kernel name)
+STAGE_OF = [("k_prefilter", "prefilter"), ("k_events_norm", "events_norm"), ("k_events_tstat", "events_norm"), ("k_events_peaks", "events_peaks"), ("k_events_means", "events_means"),
+            ("k_sketch", "sketch"), ("k_probe", "probe"), ("k_scan_anchors", "scan"), ("k_rebase_offsets", "scan"), ("k_expand", "expand"), ("k_chain_wave", "chain"), ("k_chain_serial", "chain"),
+            ("k_zbuild", "zsort"), ("k_backtrack_spec", "backtrack"), ("k_chain_gather", "backtrack"), ("k_chain_reorder", "backtrack"),
+            ("k_regions_prep", "rsort"), ("k_regions", "regions"), ("k_carry_", "compact"), ("k_compact_active", "compact"), ("k_finalize", "finalize")]
+NOT_PATH = ("k_synth_reads", "k_ix_", "__amd_rocclr")           # bench set-up (read generator, index construction, runtime copies)
 
-# k_sort_block / k_sort_big serve four stages; which one a dispatch belongs to follows from the kernel that precedes the
-# group of sort launches (single-stream run, so dispatch order = program order)
+# the segment sorters (k_sort_block, k_bs_*) serve four stages; which one a dispatch belongs to follows from the kernel that
+# precedes the group of sort launches (single-stream run, so dispatch order = program order)
 SORT_OWNER = {"k_expand": "sort", "k_zbuild": "zsort", "k_chain_gather": "backtrack", "k_regions_prep": "rsort"}
+
+
+def stage_of(k):
+    if "@" in k:
+        return k.split("@")[1]
+    for pre, st in STAGE_OF:
+        if k.startswith(pre):
+            return st
+    return None
 
 
 def one_pass(counter, out):
     env = dict(os.environ, RH_SUB_BATCHES="1")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--cpu-sample", "0"]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--workload", WORKLOAD, "--reads", str(READS), "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--no-h2d"]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
     f = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
@@ -37,7 +52,7 @@ def one_pass(counter, out):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if k in SORT_OWNER:
             owner = SORT_OWNER[k]
-        key = k if not k.startswith("k_sort") else k + "@" + owner
+        key = k + "@" + owner if k.startswith(("k_sort", "k_bs_")) else k
         e = acc.setdefault(key, [0, 0.0])
         e[0] += 1
         e[1] += float(r["Counter_Value"])
@@ -53,25 +68,33 @@ def main():
         rd = 2.0 * fetch.get(k, [0, 0.0])[1] * 1024.0
         wr = write.get(k, [0, 0.0])[1] * 1024.0
         kernels[k] = {"launches": n, "read_bytes": rd, "write_bytes": wr, "bytes_per_launch": (rd + wr) / max(n, 1)}
-    stages = {}
+    stages, unattributed, setup = {}, [], {"bytes": 0.0}
     for k, v in kernels.items():
-        st = STAGE_OF.get(k) or STAGE_OF.get(k.split("<")[0]) or (k.split("@")[1] if k.startswith("k_sort") else None)
+        if k.startswith(NOT_PATH):
+            setup["bytes"] += v["read_bytes"] + v["write_bytes"]
+            continue
+        st = stage_of(k)
         if st is None:
+            unattributed.append(k)
             continue
         e = stages.setdefault(st, {"launches": 0, "bytes": 0.0})
         e["launches"] += v["launches"]
         e["bytes"] += v["read_bytes"] + v["write_bytes"]
     for e in stages.values():
         e["bytes_per_step"] = e["bytes"]          # the profiled command runs exactly one step
-    out = {"reads": 100000, "samples": 40000, "junk": 102, "note": "read bytes = 2 x FETCH_SIZE KiB (gfx950), write bytes = WRITE_SIZE KiB",
+    out = {"workload": WORKLOAD, "reads": READS, "samples": SAMPLES, "junk": JUNK, "note": "read bytes = 2 x FETCH_SIZE KiB (gfx950), write bytes = WRITE_SIZE KiB; one stream (RH_SUB_BATCHES=1)",
+           "path_bytes_per_step": sum(e["bytes"] for e in stages.values()), "unattributed_kernels": unattributed, "setup_bytes": setup["bytes"],
            "kernels": kernels, "stages": stages}
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     pf = kernels.get("k_prefilter")
     if pf:
-        print("calibration: k_prefilter read bytes", pf["read_bytes"], "expected", 2 * 100000 * 40000)
-    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["read_bytes"] - kv[1]["write_bytes"])[:12]:
-        print(f"{k:32s} launches {v['launches']:4d}  read {v['read_bytes']/1e9:8.3f} GB  write {v['write_bytes']/1e9:8.3f} GB")
+        print("calibration: k_prefilter read bytes", pf["read_bytes"], "expected", 2 * READS * SAMPLES)
+    print("path total GB/step", out["path_bytes_per_step"] / 1e9, "unattributed", unattributed)
+    for st, e in sorted(stages.items(), key=lambda kv: -kv[1]["bytes"]):
+        print(f"{st:14s} {e['bytes'] / 1e9:9.2f} GB  {e['launches']} launches")
+    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["read_bytes"] - kv[1]["write_bytes"])[:14]:
+        print(f"{k:44s} launches {v['launches']:5d}  read {v['read_bytes']/1e9:8.3f} GB  write {v['write_bytes']/1e9:8.3f} GB")
 
 
 if __name__ == "__main__":

@@ -15,11 +15,11 @@ thread_local bool g_oom = false;   // the last failure on this thread was a devi
 
 struct DevBuf {
 	void *p = nullptr; size_t cap = 0; bool owned = true;
-	int ensure(size_t bytes)
+	int ensure(size_t bytes, bool margin = true)
 	{
 		if (bytes <= cap) return 0;
 		if (p) { RH_HIP(hipFree(p)); p = nullptr; cap = 0; }
-		size_t want = bytes + bytes / 4 + 256;
+		size_t want = margin ? bytes + bytes / 4 + 256 : bytes + 256;   // (anchor-sized arenas are budgeted: no growth margin)
 		// keep head-room on the device: the runtime itself allocates at dispatch time (kernel scratch, queues) and aborts the
 		// process when that fails, so an arena that would eat the last gigabytes is refused here like a failed hipMalloc
 		size_t free_b = 0, total_b = 0;
@@ -218,17 +218,20 @@ int stage_round(rh_ctx *c, uint32_t n_act, rh_dev_round *rr)
 	return 0;
 }
 
-// anchor-sized arenas for a slice of `total` anchors
-int stage_anchors(rh_ctx *c, uint64_t total, rh_dev_round *rr)
+// anchor-sized arenas for a slice of `total` anchors; a round that is cut into slices sizes them for `room` anchors (the slice
+// budget) once, so that the slices do not re-allocate tens of gigabytes each
+int stage_anchors(rh_ctx *c, uint64_t total, rh_dev_round *rr, uint64_t room = 0)
 {
-	const size_t t = total ? total : 1;
-	if (c->anc.ensure(t * 16) || c->raw_anc.ensure(t * 16) || c->zs.ensure(t * 16) || c->prev_stage.ensure(t * 16) || c->u.ensure(t * 8) || c->ws.ensure(t * RH_WS_PER_ANCHOR + 4096)) return -1;
+	const size_t t = total > room ? (total ? total : 1) : room;
+	const bool mg = room == 0;                                     // (budget-sized arenas: no growth margin)
+	if (c->anc.ensure(t * 16, mg) || c->raw_anc.ensure(t * 16, mg) || c->zs.ensure(t * 16, mg) || c->prev_stage.ensure(t * 16, mg) || c->u.ensure(t * 8, mg) ||
+	    c->ws.ensure(t * RH_WS_PER_ANCHOR + 4096, mg)) return -1;
 	rr->anc = c->anc.as<rh_mm128_t>(); rr->raw = c->raw_anc.as<rh_mm128_t>(); rr->zs = c->zs.as<rh_mm128_t>(); rr->prev_out = c->prev_stage.as<rh_mm128_t>();
 	rr->u = c->u.as<uint64_t>(); rr->ws = c->ws.as<unsigned char>();
 	// segments longer than the LDS sort classes (large indexes): scratch of the multi-workgroup sorter
 	if (rr->max_anchors == 0 || rr->max_anchors > (uint32_t)RH_SORT_LDS_MIN_TOP) {
 		const size_t wsb = rhk_bigsort_ws_bytes(t, (uint32_t)RH_SORT_LDS_MIN_TOP);
-		if (c->sort_alt.ensure(t * 16) || c->sort_ws.ensure(wsb)) return -1;
+		if (c->sort_alt.ensure(t * 16, mg) || c->sort_ws.ensure(wsb, mg)) return -1;
 		if (!c->pin) RH_HIP(hipHostMalloc((void**)&c->pin, 256, 0));
 		rr->sort_alt = c->sort_alt.as<rh_mm128_t>(); rr->sort_ws = c->sort_ws.as<unsigned char>(); rr->sort_ws_bytes = c->sort_ws.cap; rr->sort_pin = c->pin + 16; rr->sort_total = t;
 	}
@@ -249,7 +252,11 @@ uint64_t slice_budget(rh_ctx *c)
 		for (DevBuf *d : mine) held += d->cap;
 		const size_t reserve = total_b / 24 > ((size_t)3 << 30) ? total_b / 24 : ((size_t)3 << 30);
 		const size_t avail = free_b > reserve ? free_b - reserve : 0;
-		budget = (uint64_t)((double)(avail / (size_t)(c->share > 0 ? c->share : 1) + held) * 0.80 / (double)kBytesPerAnchor);
+		// three quarters of what this context may use (its share of the free memory + what its arenas hold already; the rest is
+		// for the dense carry buffers and the per-read arrays), but never less than the arenas hold: they stay as they are
+		const double may_use = (double)(avail / (size_t)(c->share > 0 ? c->share : 1)) + (double)held;
+		const double use = 0.75 * may_use > (double)held ? 0.75 * may_use : (double)held;
+		budget = (uint64_t)(use / (double)kBytesPerAnchor);
 		if (budget < (1u << 16)) return 0;                          // the device is full (other contexts / processes hold it)
 	}
 	if (const char *cap_env = getenv("RH_ARENA_MAX_BYTES")) { const uint64_t m = strtoull(cap_env, nullptr, 10) / RH_WS_PER_ANCHOR; if (m < budget) budget = m; }
@@ -624,7 +631,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 				for (uint32_t a = lo; a < lo + n; ++a) { const uint64_t m = a_off_h[a + 1] - a_off_h[a]; if (m > mx) mx = (uint32_t)m; }
 				rs.max_anchors = mx;
 			}
-			if (stage_anchors(c, stotal, &rs)) return -1;
+			if (stage_anchors(c, stotal, &rs, cuts.size() > 2 ? budget : 0)) return -1;
 			{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rs); }
 			{ StageTimer t(c, ST_SORT); if (rhk_sort(s, rs)) return -1; }
 			if (debug_rounds()) dump_round(c, chunk, n, rs);
@@ -694,6 +701,7 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 	if (c->slice_hint == 0 || R <= c->slice_hint) {
 		if (map_batch_once(c, mo, in, out, out_cap, &n) == 0) { *n_out = n; return 0; }
 		if (!g_oom || R < 2) return -1;
+		fprintf(stderr, "[rawhash_amd] device memory exhausted while mapping %u reads (%s): retrying in halves\n", R, rh_last_error());
 		DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev_stage, &c->u, &c->ws, &c->sort_alt, &c->sort_ws};
 		(void)hipStreamSynchronize(c->stream);
 		for (DevBuf *d : big) d->release();
