@@ -219,8 +219,12 @@ RH_API int  rh_paf_format(const rh_index *idx, const rh_map_record_t *rec, const
                           char *buf, size_t cap);
 
 /* ------------------------------------------------------------------------------------------- read container */
-/* Minimal own container ("RHR1") used by the CLI, tests and bench until a BLOW5 reader lands:
- * magic, u32 n; per read: u32 name_len, name, u32 n_samples, f64 digitisation, f64 range, f64 offset, i16[n]. */
+/* Reads from a file into the SoA batch (raw int16 + calibration: what step 0, ri_sig_read_frag rmap.cpp:601, hands to step 1):
+ *   BLOW5 (binary SLOW5, hasindu2008/slow5lib file format 1.0.0 / 0.2.0 / 0.1.0; replaces ri_read_sig_slow5 rsig.c:478-533 +
+ *          slow5lib): records uncompressed or zlib-compressed, signal uncompressed (zstd / svb-zd: refused with an error)
+ *   RHR1  (own minimal container used by tests and the reference harness): magic, u32 n; per read: u32 name_len, name,
+ *          u32 n_samples, f64 digitisation, f64 range, f64 offset, i16[n].
+ * The format is recognised by its magic. */
 typedef struct rh_reads_s rh_reads;
 RH_API rh_reads *rh_reads_load(const char *path);
 RH_API void      rh_reads_destroy(rh_reads *r);
@@ -229,6 +233,8 @@ RH_API const char *rh_reads_name(const rh_reads *r, uint32_t i);
 RH_API int       rh_reads_batch(const rh_reads *r, rh_read_batch_t *out);   /* views into r; valid until destroy */
 RH_API int       rh_reads_write(const char *path, uint32_t n, const char *const *names, const int16_t *samples,
                                 const uint64_t *offsets, double digitisation, double range, double offset);
+RH_API int       rh_reads_write_blow5(const char *path, uint32_t n, const char *const *names, const int16_t *samples, const uint64_t *offsets,
+                                      double digitisation, double range, double offset, double sampling_rate, int zlib_records);
 
 /* ------------------------------------------------------------------------------------------- synthetic workload */
 /* Deterministic, integer-only generator (same bytes on any host): i.i.d. genome, 6-mer pore model ~N(90,12) pA,

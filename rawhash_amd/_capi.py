@@ -148,6 +148,7 @@ def _declare(lib):
         "rh_reads_load": (vp, [cp]), "rh_reads_destroy": (None, [vp]), "rh_reads_n": (u32, [vp]),
         "rh_reads_name": (cp, [vp, u32]), "rh_reads_batch": (i32, [vp, P(ReadBatch)]),
         "rh_reads_write": (i32, [cp, u32, P(cp), vp, vp, C.c_double, C.c_double, C.c_double]),
+        "rh_reads_write_blow5": (i32, [cp, u32, P(cp), vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, i32]),
         "rh_synth_cfg_init": (None, [P(SynthCfg)]), "rh_synth_write_model": (i32, [P(SynthCfg), cp]),
         "rh_synth_write_fasta": (i32, [P(SynthCfg), cp]),
         "rh_synth_reads": (i32, [P(SynthCfg), cp, u64, u32, vp, vp, i32]),

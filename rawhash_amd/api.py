@@ -186,6 +186,14 @@ class Reads:
                                 float(digitisation), float(rng), float(offset)), l)
 
 
+def write_blow5(reads, path, digitisation, rng, offset, sampling_rate=4000.0, zlib_records=False, lib=None):
+    """Write a Reads batch as BLOW5 (one read group, no auxiliary fields)."""
+    l = lib or _capi.lib()
+    arr = (C.c_char_p * len(reads.names))(*[n.encode() for n in reads.names])
+    _check(l.rh_reads_write_blow5(os.fsencode(path), len(reads.names), arr, ptr(reads.samples), ptr(reads.offsets),
+                                  float(digitisation), float(rng), float(offset), float(sampling_rate), int(zlib_records)), l)
+
+
 class Context:
     """One GPU: HIP stream, device arenas and the HBM-resident index."""
 

@@ -45,3 +45,28 @@ def test_no_cpu_fallback(product_lib):
     """Without a GPU the compute entry points must fail loudly, not fall back."""
     with pytest.raises(RhError, match="no HIP device"):
         Context(0)
+
+
+def test_blow5_reader_round_trip(tmp_path, make_workload, product_lib):
+    """BLOW5 records (uncompressed and zlib) decode into the same raw int16 batch + calibration as the RHR1 container; a
+    truncated file and unsupported compression are errors, not crashes."""
+    import numpy as np
+    from rawhash_amd.api import Reads, RhError, write_blow5
+    w = make_workload(n_reads=24)
+    cfg = w.wl.cfg
+    for z in (False, True):
+        p = str(tmp_path / f"reads_{int(z)}.blow5")
+        write_blow5(w.reads, p, cfg.digitisation, cfg.range, cfg.offset, zlib_records=z, lib=product_lib)
+        r = Reads.load(p, lib=product_lib)
+        assert r.names == w.reads.names
+        assert np.array_equal(r.samples, w.reads.samples) and np.array_equal(r.offsets, w.reads.offsets)
+        assert np.array_equal(r.cal_offset, w.reads.cal_offset) and np.array_equal(r.cal_scale, w.reads.cal_scale)
+    raw = open(p, "rb").read()
+    cut = str(tmp_path / "cut.blow5")
+    open(cut, "wb").write(raw[: len(raw) // 2])
+    with pytest.raises(RhError):
+        Reads.load(cut, lib=product_lib)
+    bad = bytearray(raw); bad[9] = 2                     # zstd records
+    open(cut, "wb").write(bytes(bad))
+    with pytest.raises(RhError, match="zstd"):
+        Reads.load(cut, lib=product_lib)
