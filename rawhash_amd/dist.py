@@ -45,6 +45,11 @@ def replicate_index(ctx, opts, index=None, device="cuda", src=0):
     if rank != src:
         ctx.adopt_blob(blob.data_ptr(), nbytes, bytes(hdr_t.cpu().numpy().tobytes()), take_ownership=False)
         return blob
+    # the source keeps its own resident index: the staging copy goes back to the device (not into torch's cache: the mapping
+    # arenas are sized by what hipMemGetInfo reports free)
+    del blob
+    if str(device).startswith("cuda"):
+        torch.cuda.empty_cache()
     return None
 
 
