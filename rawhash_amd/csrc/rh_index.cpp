@@ -3,8 +3,8 @@
 //   rh_index_build  : FASTA + k-mer model -> sketches -> keys/positions (ri_idx_gen rindex.c:900, worker_pipeline :100,
 //                     ri_seq_to_sig rsig.c:13, load_pore rutils.c:133, worker_post rindex.c:311) and `.ind` writer
 //   rh_mapopt_update: mid_occ calibration (ri_idx_cal_max_occ rindex.c:1018, ri_mapopt_update :1041)
-// The `.ind` files written here load in the reference and vice versa; key/value pairs inside a bucket are written in
-// hash order rather than khash slot order (the reference re-inserts them with kh_put, so order is not observable).
+// The `.ind` files written here are byte-identical to the reference's (key/value pairs in khash slot order, KhashOrder below)
+// except for the 16 bytes of the header where the reference dumps two heap pointers of its ri_pore_t (written as 0 here).
 #include "rh_index.h"
 #include "rh_core.h"
 #include <algorithm>
@@ -166,6 +166,51 @@ void finalize_keys(rh_index_s &ix, std::vector<HostSeed> &all, int n_threads)
 	}
 }
 
+// Slot order of klib's khash (khash.h:232-330) for a bucket's keys inserted the way worker_post does (rindex.c:311-363:
+// kh_resize(n_keys), then kh_put in ascending hash order): ri_idx_dump (rindex.c:545) writes the pairs in slot order, so a
+// byte-identical .ind needs the table's geometry - power-of-two size, 0.77 load bound, hash = key >> 1, triangular probing,
+// and the in-place "kick-out" rehash when the table doubles.  Insert-only: no deleted slots ever exist outside a rehash.
+struct KhashOrder {
+	uint32_t n_buckets = 0, size = 0, upper = 0;
+	std::vector<uint8_t> used;
+	std::vector<uint64_t> keys, vals;
+	static uint32_t roundup32(uint32_t x) { --x; x |= x >> 1; x |= x >> 2; x |= x >> 4; x |= x >> 8; x |= x >> 16; return ++x; }
+	void resize(uint32_t want)
+	{
+		uint32_t nn = roundup32(want);
+		if (nn < 4) nn = 4;
+		if (size >= (uint32_t)(nn * 0.77 + 0.5)) return;             // requested size is too small
+		std::vector<uint8_t> nused(nn, 0);
+		if (n_buckets < nn) { keys.resize(nn); vals.resize(nn); }
+		const uint32_t nmask = nn - 1;
+		for (uint32_t j = 0; j != n_buckets; ++j) {
+			if (!used[j]) continue;
+			uint64_t key = keys[j], val = vals[j];
+			used[j] = 0;
+			for (;;) {                                                   // kick-out process
+				uint32_t i = (uint32_t)(key >> 1) & nmask, step = 0;
+				while (nused[i]) i = (i + (++step)) & nmask;
+				nused[i] = 1;
+				if (i < n_buckets && used[i]) { std::swap(keys[i], key); std::swap(vals[i], val); used[i] = 0; }
+				else { keys[i] = key; vals[i] = val; break; }
+			}
+		}
+		if (n_buckets > nn) { keys.resize(nn); vals.resize(nn); }
+		used.swap(nused);
+		n_buckets = nn;
+		upper = (uint32_t)(n_buckets * 0.77 + 0.5);
+	}
+	uint32_t put(uint64_t key)
+	{
+		if (size >= upper) resize(n_buckets > (size << 1) ? n_buckets - 1 : n_buckets + 1);
+		const uint32_t mask = n_buckets - 1;
+		uint32_t i = (uint32_t)(key >> 1) & mask, step = 0;
+		while (used[i]) i = (i + (++step)) & mask;
+		used[i] = 1; keys[i] = key; ++size;
+		return i;
+	}
+};
+
 bool write_ind(const rh_index_s &ix, const char *path)
 {
 	FILE *fp = fopen(path, "wb");
@@ -198,15 +243,20 @@ bool write_ind(const rh_index_s &ix, const char *path)
 	std::vector<uint64_t> p, kv;
 	for (uint32_t b = 0; b < nb; ++b) {
 		p.clear(); kv.clear();
+		KhashOrder kh;
+		const uint32_t n_keys = (uint32_t)(start[b + 1] - start[b]);
+		if (n_keys) kh.resize(n_keys);                               // worker_post: kh_resize(idx, h, n_keys) before the puts
 		for (uint64_t t = start[b]; t < start[b + 1]; ++t) {
 			const uint32_t i = order[t], n = ix.key_n[i];
 			const uint64_t key = (uint64_t)(ix.key_hash[i] >> kBucketBits) << 1;
-			if (n == 1) { kv.push_back(key | 1); kv.push_back(ix.key_val[i]); }
+			const uint32_t slot = kh.put(key);
+			if (n == 1) { kh.keys[slot] = key | 1; kh.vals[slot] = ix.key_val[i]; }
 			else {
-				kv.push_back(key); kv.push_back((uint64_t)p.size() << 32 | n);
+				kh.vals[slot] = (uint64_t)p.size() << 32 | n;
 				p.insert(p.end(), ix.pos.begin() + ix.key_val[i], ix.pos.begin() + ix.key_val[i] + n);
 			}
 		}
+		for (uint32_t sl = 0; sl < kh.n_buckets; ++sl) if (kh.used[sl]) { kv.push_back(kh.keys[sl]); kv.push_back(kh.vals[sl]); }   // ri_idx_dump: slot order
 		const int32_t np = (int32_t)p.size();
 		const uint32_t size = (uint32_t)(kv.size() / 2);
 		fwrite(&np, 4, 1, fp);

@@ -312,6 +312,12 @@ def check_device_index(lib, tmpdir, preset="sensitive", chrom_len=60_000, n_chro
     # walk the host keys through rh_index_get on both objects
     hashes = _index_hashes(host, lib)
     assert np.array_equal(hashes, _index_hashes(dev, lib))
+    # and the .ind files of the two are the same bytes (the host writer's are byte-identical to the reference's, test_oracle.py)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        pa, pb = os.path.join(d, "host.ind"), os.path.join(d, "dev.ind")
+        host.write(pa); dev.write(pb)
+        assert open(pa, "rb").read() == open(pb, "rb").read(), ".ind written from the device-built index differs"
     for h in hashes[:: max(1, len(hashes) // 4000)]:
         a, b = host.get(int(h)), dev.get(int(h))
         assert np.array_equal(a, b), f"positions of key {int(h):#x} differ"
