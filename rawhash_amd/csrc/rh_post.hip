@@ -910,6 +910,159 @@ __global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads r
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ regions, 64 chains at a time
+// Reads with thousands of chains (an unmappable read on a large index carries tens of thousands by its last chunks): streaming
+// them one by one through mm_set_parent costs a latency-bound step per chain.  Here the CHAINS of a tile sit in the lanes and
+// the primaries in LDS: every lane evaluates its chain against the whole primary list (uncovered length by a sweep over the
+// primaries sorted by start, then the first primary in list order that masks it - two uniform loops, LDS broadcasts).  A
+// chain's outcome depends on earlier chains only through the primaries they add, and a new primary is appended at the END
+// of the list: so every lane up to the first one that found no masking primary is final (secondaries: max / count updates of
+// their parents are order-free); that lane becomes a primary, and only the later lanes of the tile that overlap it are
+// evaluated again.  A tile takes 1 + (primaries it adds) rounds instead of 64 serial steps.
+#ifndef RGB_PCAP
+#define RGB_PCAP 1024      // primaries held in LDS
+#endif
+struct rgb_lds {
+	int32_t pqs[RGB_PCAP], pqe[RGB_PCAP];        // primaries in list order: query interval
+	uint32_t psc[RGB_PCAP], pcn[RGB_PCAP], psub[RGB_PCAP], pns[RGB_PCAP];   // score, anchors, best secondary score, secondaries with >= as many anchors
+	int32_t sqs[RGB_PCAP], sqe[RGB_PCAP];        // the same intervals sorted by (start, end)
+	uint32_t kk;
+};
+
+__global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, const float *logf_tab, uint32_t n_lo)
+{
+	__shared__ rgb_lds L;
+	const uint32_t a = blockIdx.x, lane = threadIdx.x;
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const int32_t n_u = (int32_t)rr.n_u[a];
+	if (n_u <= (int32_t)n_lo || !rr.need_exact[a]) return;
+	const uint32_t r = rr.act[a];
+	const uint64_t base = rr.a_off[a];
+	const rh_chain_head *heads = (const rh_chain_head*)(rr.ws + base * RH_WS_PER_ANCHOR);
+	const rh_mm128_t *zs = rr.zs + base;                             // keys in radix_sort_128x order (ascending)
+	const bool hard = (o.flag & RH_M_HARD_MLEVEL) != 0;
+	if (lane == 0) L.kk = 0;
+	__syncthreads();
+	for (int32_t i0 = 0; i0 < n_u; i0 += 64) {
+		const int32_t i = i0 + (int32_t)lane;
+		int32_t si = 0, ei = 0, sci = 0, cni = 0;
+		bool pending = i < n_u;
+		if (pending) {
+			const rh_mm128_t zi = zs[n_u - 1 - i];                    // descending: larger score first (hit.c:124-126)
+			const rh_chain_head *h = heads + (uint32_t)zi.y;
+			sci = (int32_t)(zi.x >> 32); si = (int32_t)h->y0; ei = h->y1 + 1; cni = h->cnt;
+		}
+		bool need_eval = pending;
+		int32_t sel = -1;
+		while (__ballot(pending)) {
+			const uint32_t kk = L.kk;
+			if (__ballot(need_eval)) {
+				int32_t reach = si, cov = 0, uncov = 0;
+				if (!hard) {
+					for (uint32_t j = 0; j < kk; ++j) {
+						const int32_t s = L.sqs[j], e = L.sqe[j];
+						if (need_eval && !(e <= si || s >= ei)) {
+							const int32_t cs = s < si ? si : s, ce = e > ei ? ei : e, from = cs > reach ? cs : reach;
+							if (ce > from) cov += ce - from;
+							if (ce > reach) reach = ce;
+						}
+					}
+					uncov = (ei - si) - cov;
+				}
+				if (need_eval) sel = -1;
+				for (uint32_t j = 0; j < kk; ++j) {
+					const int32_t sj = L.pqs[j], ej = L.pqe[j];
+					if (need_eval && sel < 0 && !(ej <= si || sj >= ei)) {
+						const int32_t mn = ej - sj < ei - si ? ej - sj : ei - si;
+						const int32_t mx = ej - sj > ei - si ? ej - sj : ei - si;
+						const int32_t ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj) : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
+						if ((float)ol / (float)mn - (float)uncov / (float)mx > o.mask_level && uncov <= o.mask_len) sel = (int32_t)j;
+					}
+				}
+				need_eval = false;
+			}
+			const uint64_t m_new = __ballot(pending && sel < 0);
+			const uint32_t f = m_new ? (uint32_t)__builtin_ctzll(m_new) : 64u;
+			if (pending && lane < f) {	// secondaries of existing primaries: final
+				atomicMax(&L.psub[sel], (uint32_t)sci);
+				if ((uint32_t)cni >= L.pcn[sel]) atomicAdd(&L.pns[sel], 1u);
+				pending = false;
+			}
+			if (f < 64u) {	// chain i0 + f opens a new primary
+				if (kk >= (uint32_t)RGB_PCAP) return;                    // (need_exact stays set: the serial kernels take the read)
+				const int32_t fs = __shfl(si, (int)f), fe = __shfl(ei, (int)f), fsc = __shfl(sci, (int)f), fcn = __shfl(cni, (int)f);
+				// its place in the intervals sorted by (start, end)
+				uint32_t below = 0;
+				for (uint32_t j = lane; j < kk; j += 64) below += (L.sqs[j] < fs || (L.sqs[j] == fs && L.sqe[j] <= fe)) ? 1u : 0u;
+				for (int d = 32; d > 0; d >>= 1) below += __shfl_xor(below, d);
+				int32_t ms[RGB_PCAP / 64], me[RGB_PCAP / 64];
+#pragma unroll
+				for (int q = 0; q < RGB_PCAP / 64; ++q) { const uint32_t j = (uint32_t)q * 64u + lane; ms[q] = 0; me[q] = 0; if (j >= below && j < kk) { ms[q] = L.sqs[j]; me[q] = L.sqe[j]; } }
+				__syncthreads();
+#pragma unroll
+				for (int q = 0; q < RGB_PCAP / 64; ++q) { const uint32_t j = (uint32_t)q * 64u + lane; if (j >= below && j < kk) { L.sqs[j + 1] = ms[q]; L.sqe[j + 1] = me[q]; } }
+				if (lane == 0) {
+					L.sqs[below] = fs; L.sqe[below] = fe;
+					L.pqs[kk] = fs; L.pqe[kk] = fe; L.psc[kk] = (uint32_t)fsc; L.pcn[kk] = (uint32_t)fcn; L.psub[kk] = 0; L.pns[kk] = 0;
+					L.kk = kk + 1;
+				}
+				if (lane == f) pending = false;
+				if (pending && !(fe <= si || fs >= ei)) need_eval = true;   // (lanes after f that overlap it see one more primary)
+			}
+			__syncthreads();
+		}
+	}
+	// secondaries dropped (mm_select_sub with best_n = 0): the kept regions are exactly the primaries, in order
+	const int32_t n_regs = (int32_t)L.kk;
+	int64_t sum_sc = 0;
+	for (int32_t k0 = 0; k0 < n_regs; k0 += 64) { const int32_t k = k0 + (int32_t)lane; int32_t v = k < n_regs ? (int32_t)L.psc[k] : 0; for (int d = 32; d > 0; d >>= 1) v += (int32_t)__shfl_xor((uint32_t)v, d); sum_sc += v; }
+	const float uniq_ratio = (float)sum_sc / (float)(sum_sc + rr.rep_len[a]);
+	int64_t sumQ = 0;
+	int32_t mapq0 = 0;
+	for (int32_t k0 = 0; k0 < n_regs; k0 += 64) {
+		const int32_t k = k0 + (int32_t)lane;
+		int32_t mq = 0;
+		if (k < n_regs) {
+			const int32_t sc = (int32_t)L.psc[k], cn = (int32_t)L.pcn[k];
+			const float pen_s1 = (float)((sc > 100 ? 1.0 : 0.01 * (double)sc) * (double)uniq_ratio);
+			float pen_cm = cn > 10 ? 1.0f : 0.1f * (float)cn;
+			pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
+			const int32_t subsc = (int32_t)L.psub[k] > o.min_sc ? (int32_t)L.psub[k] : o.min_sc;
+			const float x = (float)subsc / (float)sc;
+			mq = (int32_t)(pen_cm * 40.0f * (1.0f - x) * logf_int(sc, logf_tab));
+			mq -= (int32_t)(4.343f * logf_int((int32_t)L.pns[k] + 1, logf_tab) + .499f);
+			mq = mq > 0 ? mq : 0;
+			mq = mq < 60 ? mq : 60;
+		}
+		if (k0 == 0) mapq0 = __shfl(mq, 0);
+		int32_t v = mq;
+		for (int d = 32; d > 0; d >>= 1) v += (int32_t)__shfl_xor((uint32_t)v, d);
+		sumQ += v;
+	}
+	if (lane == 0) {
+		int stop = 0;
+		const int32_t score0 = (int32_t)L.psc[0];
+		if (n_regs == 1 && mapq0 >= o.min_mapq) stop = 1;
+		else {
+			float meanC = (float)sum_sc, meanQ = (float)sumQ;        // sums of small integers: exact in fp32 in any order
+			meanC /= (float)n_regs; meanQ /= (float)n_regs;
+			const float bestQ = (float)mapq0, bestC = (float)score0;
+			float r_bestq = (bestQ > 0) ? (bestQ / 30.0f) : 0.0f; if (r_bestq > 1) r_bestq = 1.0f;
+			float r_bestmq = (bestQ > 0) ? (1.0f - (meanQ / bestQ)) : 0.0f; if (r_bestmq < 0) r_bestmq = 0.0f;
+			float r_bestmc = (bestC > 0) ? (1.0f - (meanC / bestC)) : 0.0f; if (r_bestmc < 0) r_bestmc = 0.0f;
+			const float weighted = o.w_bestq * r_bestq + o.w_bestmq * r_bestmq + o.w_bestmc * r_bestmc;
+			if (weighted >= o.w_threshold) stop = 1;
+		}
+		const rh_chain_head h = heads[(uint32_t)zs[n_u - 1].y];
+		rh_reg best;
+		best.cnt = h.cnt; best.score = score0; best.mapq = (uint32_t)mapq0;
+		best.qs = (int32_t)h.y0; best.qe = h.y1 + 1; best.rs = (int32_t)h.x0; best.re = h.x1 + 1;
+		best.rid = (int32_t)(h.x0 << 1 >> 33); best.rev = (uint32_t)(h.x0 >> 63);
+		regions_commit(o, rd, rr, a, r, n_regs, &best, stop);
+		rr.need_exact[a] = 0;
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 static void sort_scratch(rh_sort_job &jb, const rh_dev_round &r) { jb.big_alt = r.sort_alt; jb.big_ws = r.sort_ws; jb.big_ws_bytes = r.sort_ws_bytes; jb.big_pin = r.sort_pin; jb.big_total = r.sort_total; }
 
@@ -957,6 +1110,7 @@ void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, con
 	if (wave_ok) {
 		// one register slot (<= 64 primaries: nearly every read) first; the reads that overflow it again with all slots
 		RH_LAUNCH(k_regions_reg<1>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL, 0);
+		RH_LAUNCH(k_regions_batch, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL);   // reads with many chains / more than 64 primaries
 		if (RGR_SLOTS > 1) RH_LAUNCH(k_regions_reg<RGR_SLOTS>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL, 1);
 		RH_LAUNCH(k_regions_wave<RGW_CAP0>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL);
 		RH_LAUNCH(k_regions_wave<RGW_CAP>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RGW_CAP0);
