@@ -20,6 +20,8 @@
 // ranges (still too large), segments for the LDS block sorter (<= its largest class; they finish there, insertion
 // sorts of <= 64 records included), or are final.  Records move once per level between two scratch copies (the
 // job's own source array and `alt`); finished buckets go straight to the destination array.
+#include <cstdio>
+#include <cstdlib>
 #include "rh_kernels.h"
 #include "rh_devutil.h"
 
@@ -627,12 +629,16 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	if ((size_t)(p - jb.big_ws) > jb.big_ws_bytes) { rh_set_error("segment sorter: scratch of %zu bytes is too small (%zu needed)", jb.big_ws_bytes, (size_t)(p - jb.big_ws)); return -1; }
 	RH_LAUNCH(k_bs_init, 1, NT, 0, s, jb, C);
 	uint32_t *pin = (uint32_t*)jb.big_pin;
+	static const bool trace = getenv("RH_BS_TRACE") != nullptr;   // development aid: per-level launch shapes and times on stderr
+	hipEvent_t ev[4] = {};
+	if (trace) for (auto &e : ev) hipEventCreate(&e);
 	for (int level = 0; level < 9; ++level) {
 		RH_HIP(hipMemcpyAsync(pin, C.hdr, 32, hipMemcpyDeviceToHost, s));
 		RH_HIP(hipStreamSynchronize(s));
 		const uint32_t n_rng = pin[0], n_tiles = pin[1];
 		if (pin[7]) { rh_set_error("segment sorter: range / segment list overflow"); return -1; }
 		if (n_rng == 0) break;
+		if (trace) hipEventRecord(ev[0], s);
 		RH_LAUNCH(k_bs_clear, n_rng, NT, 0, s, C);
 		RH_LAUNCH(k_bs_diff, n_tiles, NT, 0, s, C);
 		RH_LAUNCH(k_bs_hist, n_tiles, NT, 0, s, C);
@@ -642,16 +648,25 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		RH_LAUNCH(k_bs_holes, n_tiles, NT, 0, s, C);
 		// few ranges: a wavefront each (nothing to gain from 64 walks per wavefront); many: one lane each where the regions fit
 		const int lanes = n_rng >= (uint32_t)BS_LANES_MIN_RANGES;
+		if (trace) hipEventRecord(ev[1], s);
 		RH_LAUNCH(k_bs_walk_wave, n_rng, 64, 0, s, C, lanes ? 0 : 1);
 		if (lanes) {	// by number of regions with holes: 64 / 32 / 8 walkers per wavefront
 			RH_LAUNCH((k_bs_walk_lanes<24, 64>), (n_rng + 63) / 64, 64, 0, s, C, 2u);
 			RH_LAUNCH((k_bs_walk_lanes<64, 32>), (n_rng + 31) / 32, 64, 0, s, C, 24u);
 			RH_LAUNCH((k_bs_walk_lanes<256, 8>), (n_rng + 7) / 8, 64, 0, s, C, 64u);   // LDS: 24 B per region and walker (36 / 48 / 48 KB)
 		}
+		if (trace) hipEventRecord(ev[2], s);
 		RH_LAUNCH(k_bs_scatter, n_tiles, NT, 0, s, C);
 		RH_LAUNCH(k_bs_next, 1, NT, 0, s, C);
+		if (trace) {
+			hipEventRecord(ev[3], s); hipEventSynchronize(ev[3]);
+			float a = 0, b = 0, c = 0;
+			hipEventElapsedTime(&a, ev[0], ev[1]); hipEventElapsedTime(&b, ev[1], ev[2]); hipEventElapsedTime(&c, ev[2], ev[3]);
+			fprintf(stderr, "BS level %d segs %u total %llu rng %u tiles %u pre %.3f walk %.3f post %.3f\n", level, jb.n_seg, (unsigned long long)t, n_rng, n_tiles, a, b, c);
+		}
 		bs_range *tmp = C.rng[0]; C.rng[0] = C.rng[1]; C.rng[1] = tmp;
 	}
+	if (trace) for (auto &e : ev) hipEventDestroy(e);
 	// the buckets that fit the LDS classes finish in the block sorter, from the copy that holds them
 	const bool job32 = jb.kc_on && (uint32_t)jb.kc_lo + jb.kc_mid + jb.kc_hi <= 32u && jb.kc_mid <= 24u;
 	for (int q = 0; q < 4; ++q) {
