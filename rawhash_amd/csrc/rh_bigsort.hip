@@ -544,14 +544,17 @@ __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 	__shared__ uint32_t s_start[257], s_hst[257], s_J[256], s_cw[BS_TILE_IT * (NT / 64)];
 	__shared__ uint8_t s_fate[256];
 	const uint32_t n_rng = C.hdr[0], tid = threadIdx.x;
-	if (blockIdx.x >= C.hdr[1]) return;
-	const uint32_t r = bs_find_range(C, blockIdx.x, n_rng, &s_r);
+	// workgroup b runs on XCD b % 8: the tiles are dealt so that each XCD takes a contiguous eighth of them and a range's
+	// records, hole lists and destinations meet in one L2
+	const uint32_t per_xcd = gridDim.x >> 3, tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+	if (tile >= C.hdr[1]) return;
+	const uint32_t r = bs_find_range(C, tile, n_rng, &s_r);
 	const bs_range R = C.rng[0][r];
 	const bs_meta &M = C.meta[r];
 	s_start[tid] = M.start[tid]; s_hst[tid] = M.hst[tid]; s_J[tid] = M.J[tid]; s_fate[tid] = M.fate[tid];
 	if (tid == 0) { s_start[256] = M.start[256]; s_hst[256] = M.hst[256]; }
 	__syncthreads();
-	const uint32_t t0 = (blockIdx.x - R.tile0) * BS_TILE, hbase = C.tile_h[blockIdx.x];
+	const uint32_t t0 = (tile - R.tile0) * BS_TILE, hbase = C.tile_h[tile];
 	bs_cls q;
 	bs_classify(C.dg + R.beg, s_start, t0, R.n, s_cw, q);
 	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
@@ -656,7 +659,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 			RH_LAUNCH((k_bs_walk_lanes<256, 8>), (n_rng + 7) / 8, 64, 0, s, C, 64u);   // LDS: 24 B per region and walker (36 / 48 / 48 KB)
 		}
 		if (trace) hipEventRecord(ev[2], s);
-		RH_LAUNCH(k_bs_scatter, n_tiles, NT, 0, s, C);
+		RH_LAUNCH(k_bs_scatter, ((n_tiles + 7) / 8) * 8, NT, 0, s, C);
 		RH_LAUNCH(k_bs_next, 1, NT, 0, s, C);
 		if (trace) {
 			hipEventRecord(ev[3], s); hipEventSynchronize(ev[3]);
