@@ -90,9 +90,9 @@ typedef struct rh_read_batch_s {
 	const uint64_t *offsets;          /* n_reads+1 sample offsets into samples[] */
 	const double   *cal_offset;       /* per read: slow5 `offset`                (may be NULL -> 0) */
 	const float    *cal_scale;        /* per read: (float)(range/digitisation)   (may be NULL -> 1) */
-	const uint32_t *name_rank;        /* only for RH_M_ALL_CHAINS: rank of the read name among target names
-	                                     such that strcmp(qname, tname) >= 0  <=>  name_rank[q] >= target id
-	                                     (see INTEGRATION.md); NULL otherwise */
+	const uint32_t *name_rank;        /* only for RH_M_ALL_CHAINS (host array): rank of the read's name among the target
+	                                     names, such that strcmp(qname, tname) >= 0  <=>  name_rank[q] >= rank of the
+	                                     target (rh_index_name_ranks computes both sides); NULL otherwise */
 	int samples_on_device;            /* 1: samples/offsets/cal_* are device pointers already resident in HBM */
 } rh_read_batch_t;
 
@@ -151,6 +151,18 @@ RH_API int  rh_index_bcast(rh_ctx *const *ctxs, int n);
  * with rh_index_write). */
 RH_API rh_index *rh_index_build_device(rh_ctx *ctx, uint32_t n_seq, const char *const *names, const char *const *seqs, const uint32_t *lens,
                                        const char *pore_model_path, const rh_idxopt_t *io, int n_threads);
+/* ri_idx_siggen rindex.c:927 (Rawsamble: `rawhash2 -x ava -p model -d out.ind reads`): every read of the batch becomes a
+ * target (name, filtered signal length); event detection over the whole signal + sketch + bucketing run on the device.  `mo`
+ * supplies the segmentation parameters (window lengths, thresholds, peak height).  The index is resident on `ctx` afterwards
+ * (target name ranks included); rh_index_download + rh_index_write give the reference's .ind file. */
+RH_API rh_index *rh_index_build_signals_device(rh_ctx *ctx, const rh_read_batch_t *reads, const char *const *names, const char *pore_model_path,
+                                               const rh_idxopt_t *io, const rh_mapopt_t *mo);
+/* All-vs-all drops the hits on targets whose name is not greater than the read's (strcmp(qname, tname) >= 0, rmap.cpp:86).
+ * Names stay on the host: rh_index_name_ranks turns the comparison into integers (query_ranks[n] for `names`, target_ranks
+ * [n_seq] for the index's targets; either may be NULL), rh_index_set_target_ranks hands the target side to the device
+ * (rh_index_upload and rh_index_build_signals_device do it themselves; a broadcast / adopted blob needs the call). */
+RH_API int  rh_index_name_ranks(const rh_index *idx, const char *const *names, uint32_t n, uint32_t *query_ranks, uint32_t *target_ranks);
+RH_API int  rh_index_set_target_ranks(rh_ctx *ctx, const uint32_t *target_ranks, uint32_t n);
 RH_API rh_index *rh_index_build_device_fasta(rh_ctx *ctx, const char *fasta_path, const char *pore_model_path, const rh_idxopt_t *io, int n_threads);
 RH_API int  rh_index_download(rh_ctx *ctx, rh_index *idx, int n_threads);
 RH_API int  rh_index_write(const rh_index *idx, const char *out_ind);          /* ri_idx_dump rindex.c:545 */
@@ -162,6 +174,12 @@ RH_API int  rh_index_write(const rh_index *idx, const char *out_ind);          /
 RH_API uint64_t rh_map_max_records(const rh_read_batch_t *in, const rh_mapopt_t *mo);
 RH_API int  rh_map_batch(rh_ctx *ctx, const rh_mapopt_t *mo, const rh_read_batch_t *in,
                          rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out);
+/* The same when a read may have several records: all-vs-all overlapping (the ava presets, RI_M_ALL_CHAINS | RI_M_NO_ADAPTIVE)
+ * reports every chain whose score reaches min_chaining_score2 (rmap.cpp:421-500, records :557-586).  One round over the whole
+ * reads; the records of read r are out[rec_offsets[r] .. rec_offsets[r + 1]) (n_reads + 1 offsets, may be NULL), a read
+ * without a reported chain has its one unmapped record.  Needs `in->name_rank` and the targets' ranks on the context. */
+RH_API int  rh_map_batch_multi(rh_ctx *ctx, const rh_mapopt_t *mo, const rh_read_batch_t *in,
+                               rh_map_record_t *out, uint64_t out_cap, uint64_t *rec_offsets, uint64_t *n_out);
 
 /* The reference keeps up to two mini-batches in flight (kt_pipeline rmap.cpp:852 with pl_threads = 2, rmap.cpp:831): step 0
  * reads batch k+1 while step 1 maps batch k.  rh_map_submit starts mapping a batch and returns at once; rh_map_wait blocks

@@ -8,6 +8,8 @@
 //
 //   ref_harness index <preset> <ref.fa> <pore.model> <out.ind> [threads]
 //        = `rawhash2 -x <preset> -p <pore.model> -d <out.ind> <ref.fa>`   (main.cpp:568)
+//   ref_harness sigindex <preset> <reads.rhr> <pore.model> <out.ind> [threads]
+//        = `rawhash2 -x <preset> -p <pore.model> -d <out.ind> <reads>` for the signal-target presets (ava*)
 //   ref_harness map <preset> <ref.ind> <reads.rhr> [threads]  > out.paf
 //        = `rawhash2 -x <preset> <ref.ind> <reads>`: feeds an in-memory batch
 //          to the reference's own step-1/step-2 pipeline callbacks
@@ -121,6 +123,63 @@ static int cmd_index(int argc, char **argv)
 		ri_idx_destroy(ri);
 	}
 	ri_idx_reader_close(rdr);
+	return 0;
+}
+
+// ref_harness sigindex <preset> <reads.rhr> <pore.model> <out.ind> [threads]
+//   = `rawhash2 -x <preset> -p <pore.model> -d <out.ind> <reads>` for the signal-target (Rawsamble, RI_I_SIG_TARGET) presets.
+// ri_idx_siggen (rindex.c:927) cannot open a read file in this image, so the harness walks the reads itself and makes the
+// calls of worker_sig_pipeline (rindex.c:239-310) in its order: register the read as a target (step 0), detect_events over
+// the whole signal + ri_sketch with the read's id (step 1), ri_idx_add (step 2); then ri_idx_sort (= ri_idx_post) and
+// ri_idx_dump.  Every number in the file comes from the reference's own functions.
+void ri_idx_sort(ri_idx_t *ri, int n_threads);   // rindex.c:496 (defined there, not declared in rindex.h)
+static int cmd_sigindex(int argc, char **argv)
+{
+	if (argc < 6) return 2;
+	ri_idxopt_t ipt; ri_mapopt_t opt;
+	if (set_presets(argv[2], &ipt, &opt) < 0) return 1;
+	if (!(ipt.flag & RI_I_SIG_TARGET)) { fprintf(stderr, "preset %s does not build a signal-target index\n", argv[2]); return 1; }
+	int n_threads = argc > 6 ? atoi(argv[6]) : 3;
+	std::vector<rhr_read> reads;
+	if (!load_rhr(argv[3], reads)) { fprintf(stderr, "bad reads file\n"); return 1; }
+	ri_pore_t pore; pore.pore_vals = NULL; pore.pore_inds = NULL; pore.max_val = -5000.0; pore.min_val = 5000.0;
+	load_pore(argv[4], ipt.k, ipt.lev_col, &pore);
+	if (!pore.pore_vals) { fprintf(stderr, "cannot parse pore model\n"); return 1; }
+	ri_idx_t *ri = ri_idx_init(ipt.diff, ipt.b, ipt.w, ipt.e, ipt.n, ipt.q, ipt.k, ipt.fine_min, ipt.fine_max, ipt.fine_range, ipt.flag);
+	ri->pore = (ri_pore_t*)ri_kmalloc(ri->km, sizeof(ri_pore_t));
+	memcpy(ri->pore, &pore, sizeof(ri_pore_t));
+	ri->pore->pore_vals = (float*)ri_kmalloc(ri->km, pore.n_pore_vals * sizeof(float));
+	memcpy(ri->pore->pore_vals, pore.pore_vals, pore.n_pore_vals * sizeof(float));
+	ri->pore->pore_inds = (ri_porei_t*)ri_kmalloc(ri->km, pore.n_pore_vals * sizeof(ri_porei_t));
+	memcpy(ri->pore->pore_inds, pore.pore_inds, pore.n_pore_vals * sizeof(ri_porei_t));
+	ri->window_length1 = ipt.window_length1; ri->window_length2 = ipt.window_length2;
+	ri->threshold1 = ipt.threshold1; ri->threshold2 = ipt.threshold2; ri->peak_height = ipt.peak_height;
+	uint64_t sum_len = 0;
+	ri->sig = (ri_sig_t*)ri_kcalloc(ri->km, reads.size() ? reads.size() : 1, sizeof(ri_sig_t));
+	for (size_t i = 0; i < reads.size(); ++i) {
+		ri_sig_t *t = to_sig(reads[i], 0);
+		ri_sig_t *sig = &ri->sig[ri->n_seq];
+		sig->name = (char*)ri_kmalloc(ri->km, strlen(t->name) + 1);
+		strcpy(sig->name, t->name);
+		sig->l_sig = t->l_sig; sig->offset = sum_len; sum_len += t->l_sig;
+		t->rid = ri->n_seq++;
+		if (t->l_sig > 0) {
+			uint32_t s_len = 0, n_events_sum = 0;
+			double s_sum = 0, s_std = 0;
+			mm128_v a = {0, 0, 0};
+			float *s_values = detect_events(0, t->l_sig, t->sig, ri->window_length1, ri->window_length2, ri->threshold1, ri->threshold2, ri->peak_height, &s_sum, &s_std, &n_events_sum, &s_len);
+			ri_sketch(0, s_values, t->rid, 0, s_len, ri->diff, ri->w, ri->e, ri->n, ri->q, ri->k, ri->fine_min, ri->fine_max, ri->fine_range, &a, 0);
+			if (s_values) free(s_values);
+			ri_idx_add(ri, a.n, a.a);
+			ri_kfree(0, a.a);
+		}
+		free(t->sig); free(t->name); free(t);
+	}
+	ri_idx_sort(ri, n_threads);
+	FILE *fp = fopen(argv[5], "wb");
+	if (!fp) { fprintf(stderr, "cannot write %s\n", argv[5]); return 1; }
+	ri_idx_dump(fp, ri);
+	fclose(fp);
 	return 0;
 }
 
@@ -337,6 +396,7 @@ int main(int argc, char **argv)
 	int ret = 2;
 	if (argc >= 2) {
 		if (!strcmp(argv[1], "index")) ret = cmd_index(argc, argv);
+		else if (!strcmp(argv[1], "sigindex")) ret = cmd_sigindex(argc, argv);
 		else if (!strcmp(argv[1], "map")) ret = cmd_map(argc, argv);
 		else if (!strcmp(argv[1], "dump")) ret = cmd_dump(argc, argv);
 		else if (!strcmp(argv[1], "idxdump")) ret = cmd_idxdump(argc, argv);

@@ -129,6 +129,9 @@ def _declare(lib):
         "rh_index_upload": (i32, [vp, vp]),
         "rh_index_build_device": (vp, [vp, u32, P(cp), P(cp), vp, cp, P(IdxOpt), i32]),
         "rh_index_build_device_fasta": (vp, [vp, cp, cp, P(IdxOpt), i32]),
+        "rh_index_build_signals_device": (vp, [vp, P(ReadBatch), P(cp), cp, P(IdxOpt), P(MapOpt)]),
+        "rh_index_name_ranks": (i32, [vp, P(cp), u32, vp, vp]), "rh_index_set_target_ranks": (i32, [vp, vp, u32]),
+        "rh_map_batch_multi": (i32, [vp, P(MapOpt), P(ReadBatch), vp, u64, vp, P(u64)]),
         "rh_index_download": (i32, [vp, vp, i32]), "rh_index_write": (i32, [vp, cp]),
         "rh_synth_genome": (i32, [P(SynthCfg), u32, vp, i32]),
         "rh_index_device_blob": (i32, [vp, P(vp), P(u64), vp]),

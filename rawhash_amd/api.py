@@ -84,6 +84,25 @@ class Index:
             raise RhError(_capi.last_error(l))
         return cls(h, l)
 
+    @classmethod
+    def build_signals_device(cls, ctx, reads, pore_model, opts):
+        """ri_idx_siggen on the GPU (Rawsamble): every read becomes a target; the index is left resident in `ctx`."""
+        l = ctx._l
+        b = reads.batch()
+        arr = (C.c_char_p * len(reads.names))(*[n.encode() for n in reads.names])
+        h = l.rh_index_build_signals_device(ctx.h, C.byref(b), arr, os.fsencode(pore_model), C.byref(opts.io), C.byref(opts.mo))
+        if not h:
+            raise RhError(_capi.last_error(l))
+        return cls(h, l)
+
+    def name_ranks(self, names):
+        """(query ranks of `names`, ranks of this index's targets): strcmp(q, t) >= 0 <=> rank(q) >= rank(t) (rmap.cpp:86)."""
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        q = np.zeros(max(len(names), 1), dtype=np.uint32)
+        t = np.zeros(max(self.n_seq, 1), dtype=np.uint32)
+        _check(self._l.rh_index_name_ranks(self.h, arr, len(names), ptr(q), ptr(t)), self._l)
+        return q[: len(names)], t[: self.n_seq]
+
     def download(self, ctx, n_threads=8):
         """Fetch keys + positions of a device-built index into this host object (for get() / write())."""
         _check(self._l.rh_index_download(ctx.h, self.h, n_threads), self._l)
@@ -237,6 +256,24 @@ class Context:
         n = C.c_uint64(0)
         _check(self._l.rh_map_batch(self.h, C.byref(opts.mo), C.byref(b), ptr(out), cap, C.byref(n)), self._l)
         return out[: n.value]
+
+    def map_batch_multi(self, opts, reads, index, max_records=None):
+        """All-vs-all overlapping (ava presets): every reported chain of a read is a record.  Returns (records, offsets):
+        the records of read r are records[offsets[r]:offsets[r + 1]]."""
+        b = reads.batch()
+        qr, _ = index.name_ranks(reads.names)
+        qr = np.ascontiguousarray(qr)
+        b.name_rank = qr.ctypes.data if len(qr) else None
+        cap = max_records or (64 * len(reads) + 1024)
+        out = np.zeros(cap, dtype=RECORD)
+        off = np.zeros(len(reads) + 1, dtype=np.uint64)
+        n = C.c_uint64(0)
+        _check(self._l.rh_map_batch_multi(self.h, C.byref(opts.mo), C.byref(b), ptr(out), cap, ptr(off), C.byref(n)), self._l)
+        return out[: n.value], off
+
+    def set_target_ranks(self, ranks):
+        r = np.ascontiguousarray(ranks, dtype=np.uint32)
+        _check(self._l.rh_index_set_target_ranks(self.h, ptr(r), len(r)), self._l)
 
     def map_submit(self, opts, batch):
         """Start mapping a batch (rh_map_submit); returns a handle for map_wait.  Up to 2 batches may be in flight."""

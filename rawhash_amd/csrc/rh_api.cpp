@@ -81,6 +81,8 @@ struct rh_ctx_s {
 	DevBuf zbuf, t1buf, t2buf, n_norm, peaks, n_peaks;
 	DevBuf ev, n_ev, skip, sx, sy, n_seed, m_val, m_n, m_meta, m_pref, n_match, n_new, rep_len, a_off;
 	DevBuf anc, raw_anc, zs, n_z, need_exact, need_exact2, prev_stage, u, n_u, n_v, ws, counters, rec;
+	DevBuf name_rank, t_rank, rec_off;                            // all-vs-all: name ranks of the reads / of the targets, record offsets
+	uint32_t ev_row = RH_CHUNK_MAX + 64, ev_cap = RH_EV_CAP, whole = 0;   // strides of the per-read rows of the current batch (whole-read rounds: sized by its longest read)
 	DevBuf carry[2], carry_off, a_off_slice;                      // chained anchors carried into the next chunk, dense, ping-pong over the rounds
 	int share = 1;                                                 // sub-batches running concurrently on this device (memory budget per context)
 	int flight_mult = 1;                                           // batches in flight that share the device with this context's
@@ -131,13 +133,16 @@ int fill_dev_opt(const rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
 {
 	if (mo->chunk_size == 0 || mo->chunk_size > RH_CHUNK_MAX) { rh_set_error("chunk_size %u not supported on the device (1..%d)", mo->chunk_size, RH_CHUNK_MAX); return -1; }
 	if (mo->max_num_chunk > RH_MAX_CHUNKS) { rh_set_error("max_num_chunk %u > %d not supported", mo->max_num_chunk, RH_MAX_CHUNKS); return -1; }
-	if (mo->flag & (RH_M_NO_ADAPTIVE | RH_M_ALL_CHAINS)) { rh_set_error("whole-read / all-vs-all (Rawsamble) mode is not built on the device yet"); return -1; }
+	if ((mo->flag & RH_M_ALL_CHAINS) && !(mo->flag & RH_M_NO_ADAPTIVE)) { rh_set_error("all-chains output is built for whole-read rounds only (RH_M_ALL_CHAINS needs RH_M_NO_ADAPTIVE, as in the ava presets)"); return -1; }
+	if ((mo->flag & RH_M_NO_ADAPTIVE) && (mo->window_length1 > 15 || mo->window_length2 > 15)) { rh_set_error("whole-read rounds need segmentation windows <= 15"); return -1; }
+	if ((mo->flag & RH_M_ALL_CHAINS) && c->have_index && !c->dix.t_rank) { rh_set_error("all-vs-all mapping needs the name ranks of the targets (rh_index_set_target_ranks)"); return -1; }
 	if (mo->flag & (RH_M_RMQ | RH_M_DTW_EVALUATE_CHAINS)) { rh_set_error("RMQ chaining / DTW re-scoring are out of scope of this path"); return -1; }
 	if (mo->bw_long > mo->bw) { rh_set_error("bw_long > bw (RMQ re-chaining) is out of scope of this path"); return -1; }
 	if (mo->min_num_anchors < 2) { rh_set_error("min_num_anchors < 2 is not supported on the device (the per-anchor scratch assumes chains of at least two anchors)"); return -1; }
 	if (mo->window_length1 > 64 || mo->window_length2 > 64) { rh_set_error("segmentation windows > 64 not supported"); return -1; }
 	memset(o, 0, sizeof(*o));
 	o->chunk_size = mo->chunk_size; o->max_num_chunk = mo->max_num_chunk; o->min_events = mo->min_events;
+	if (mo->flag & RH_M_NO_ADAPTIVE) { o->chunk_size = 1u << 30; o->max_num_chunk = 1; }   // rmap.cpp:404-405: one round over the whole read
 	o->w1 = mo->window_length1; o->w2 = mo->window_length2; o->thr1 = mo->threshold1; o->thr2 = mo->threshold2; o->peak_height = mo->peak_height;
 	o->mid_occ = mo->mid_occ;
 	o->max_dist_t = mo->max_target_gap_length; o->max_dist_q = mo->max_query_gap_length; o->bw = mo->bw;
@@ -180,6 +185,11 @@ int stage_reads(rh_ctx *c, const rh_read_batch_t *in, rh_dev_reads *rd)
 		RH_HIP(hipStreamSynchronize(c->stream));   // co/cs are stack-owned
 		rd->raw = c->raw.as<int16_t>() - first; rd->off = c->off.as<uint64_t>(); rd->cal_off = c->cal_off.as<double>(); rd->cal_scale = c->cal_scale.as<float>();
 	}
+	if (in->name_rank) {
+		if (c->name_rank.ensure((size_t)(R + 1) * 4)) return -1;
+		if (R) RH_HIP(hipMemcpyAsync(c->name_rank.p, in->name_rank, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
+		rd->name_rank = c->name_rank.as<uint32_t>();
+	}
 	const size_t n = R ? R : 1;
 	size_t k = 0;
 	auto U32 = [&](uint32_t *&p, size_t cnt) { if (c->st[k].ensure(cnt * 4)) return -1; p = c->st[k].as<uint32_t>(); ++k; return 0; };
@@ -197,13 +207,14 @@ int stage_reads(rh_ctx *c, const rh_read_batch_t *in, rh_dev_reads *rd)
 // per-round arrays for n_act active reads
 int stage_round(rh_ctx *c, uint32_t n_act, rh_dev_round *rr)
 {
-	const size_t n = n_act ? n_act : 1, cap = (size_t)n * RH_EV_CAP;
-	const size_t rowb = (size_t)(n + 64) * (RH_CHUNK_MAX + 64) * 4;   // + 64 rows: the peak kernel reads whole 64-read tiles
-	if (c->zbuf.ensure(rowb) || c->t1buf.ensure(rowb) || c->t2buf.ensure(rowb) || c->n_norm.ensure(n * 4) || c->peaks.ensure(cap * 2) || c->n_peaks.ensure(n * 4)) return -1;
+	const size_t n = n_act ? n_act : 1, cap = (size_t)n * c->ev_cap;
+	const size_t rowb = (size_t)(n + 64) * c->ev_row * 4;           // + 64 rows: the peak kernel reads whole 64-read tiles
+	rr->ev_row = c->ev_row; rr->ev_cap = c->ev_cap; rr->whole = c->whole;
+	if (c->zbuf.ensure(rowb) || c->t1buf.ensure(rowb) || c->t2buf.ensure(rowb) || c->n_norm.ensure(n * 4) || c->peaks.ensure(cap * (c->whole ? 4 : 2)) || c->n_peaks.ensure(n * 4)) return -1;
 	rr->zbuf = c->zbuf.as<float>(); rr->t1buf = c->t1buf.as<float>(); rr->t2buf = c->t2buf.as<float>(); rr->n_norm = c->n_norm.as<uint32_t>();
 	rr->peaks = c->peaks.as<uint16_t>(); rr->n_peaks = c->n_peaks.as<uint32_t>();
 	if (c->ev.ensure(cap * 4) || c->n_ev.ensure(n * 4) || c->skip.ensure(n) || c->sx.ensure(cap * 8) || c->sy.ensure(cap * 8) || c->n_seed.ensure(n * 4) ||
-	    c->m_val.ensure(cap * 8) || c->m_n.ensure(cap * 4) || c->m_meta.ensure(cap * 4) || c->m_pref.ensure((size_t)n * (RH_EV_CAP + 1) * 4) ||
+	    c->m_val.ensure(cap * 8) || c->m_n.ensure(cap * 4) || c->m_meta.ensure(cap * 4) || c->m_pref.ensure((size_t)n * (c->ev_cap + 1) * 4) ||
 	    c->n_match.ensure(n * 4) || c->n_new.ensure(n * 4) || c->rep_len.ensure(n * 4) || c->a_off.ensure((n + 2) * 8) || c->n_u.ensure(n * 4) || c->n_v.ensure(n * 4) ||
 	    c->counters.ensure(16 * 8) || c->need_exact.ensure(n) || c->need_exact2.ensure(n) || c->n_z.ensure(n * 4)) return -1;
 	rr->n_z = c->n_z.as<uint32_t>();
@@ -267,9 +278,9 @@ uint64_t slice_budget(rh_ctx *c)
 rh_dev_round slice_view(const rh_dev_round &rr, uint32_t lo, uint32_t n, uint64_t *a_off)
 {
 	rh_dev_round v = rr;
-	const size_t cap = RH_EV_CAP;
+	const size_t cap = rr.ev_cap;
 	v.n_act = n; v.act = rr.act + lo; v.a_off = a_off;
-	v.n_norm = rr.n_norm + lo; v.peaks = rr.peaks + lo * cap; v.n_peaks = rr.n_peaks + lo;
+	v.n_norm = rr.n_norm + lo; v.peaks = rr.peaks + lo * cap * (rr.whole ? 2 : 1); v.n_peaks = rr.n_peaks + lo;
 	v.ev = rr.ev + lo * cap; v.n_ev = rr.n_ev + lo; v.skip = rr.skip + lo;
 	v.sx = rr.sx + lo * cap; v.sy = rr.sy + lo * cap; v.n_seed = rr.n_seed + lo;
 	v.m_val = rr.m_val + lo * cap; v.m_n = rr.m_n + lo * cap; v.m_meta = rr.m_meta + lo * cap; v.m_pref = rr.m_pref + (size_t)lo * (cap + 1);
@@ -360,6 +371,7 @@ extern "C" void rh_ctx_destroy(rh_ctx *c)
 // that another rank can adopt a broadcast copy.
 namespace {
 typedef rh_blob_header BlobHeader;
+int set_target_ranks_from(rh_ctx *c, const rh_index *ix);
 const uint64_t kBlobMagic = RH_BLOB_MAGIC;
 
 int bind_blob(rh_ctx *c, const BlobHeader &h)
@@ -369,6 +381,7 @@ int bind_blob(rh_ctx *c, const BlobHeader &h)
 	c->dix.pos = (const uint64_t*)(base + h.pos_off);
 	c->dix.seq_len = (const uint32_t*)(base + h.len_off);
 	c->dix.lg_buckets = h.lg_buckets; c->dix.n_seq = h.n_seq; c->dix.flag = h.flag; c->dix.sp = h.sp;
+	c->dix.t_rank = nullptr;                                        // (rh_index_set_target_ranks)
 	// anchor keys fit 32 bits when strand + target id + position do (they do up to a few hundred Mbp in a few targets)
 	uint32_t lo = 0, mid = 0;
 	while (lo < 32 && (1ull << lo) <= (uint64_t)h.max_len) ++lo;
@@ -405,7 +418,9 @@ extern "C" int rh_index_upload(rh_ctx *c, const rh_index *ix)
 	RH_HIP(hipMemcpy(base + h.table_off, slots.data(), slots.size() * sizeof(rh_tslot), hipMemcpyHostToDevice));
 	if (h.n_pos) RH_HIP(hipMemcpy(base + h.pos_off, ix->pos.data(), h.n_pos * 8, hipMemcpyHostToDevice));
 	if (h.n_seq) RH_HIP(hipMemcpy(base + h.len_off, ix->lens.data(), (size_t)h.n_seq * 4, hipMemcpyHostToDevice));
-	return bind_blob(c, h);
+	if (bind_blob(c, h)) return -1;
+	if (ix->flag & RH_I_SIG_TARGET) return set_target_ranks_from(c, ix);   // all-vs-all: the device compares name ranks (rmap.cpp:86)
+	return 0;
 }
 
 extern "C" int rh_index_device_blob(rh_ctx *c, void **dev_ptr, uint64_t *bytes, void *header_out)
@@ -479,6 +494,53 @@ extern "C" rh_index *rh_index_build_device_fasta(rh_ctx *c, const char *fasta_pa
 		np.push_back(names[i].c_str()); sp.push_back(seqs[i].data()); ln.push_back((uint32_t)seqs[i].size());
 	}
 	return rh_index_build_device(c, (uint32_t)seqs.size(), np.data(), sp.data(), ln.data(), pore_model_path, io, n_threads);
+}
+
+// ---------------------------------------------------------------------------------------------------- all-vs-all: name ranks
+// strcmp(qname, tname) >= 0 (rmap.cpp:86) as an integer comparison: the distinct target names in strcmp order get the odd
+// ranks 1, 3, 5, ...; a query name that is a target name takes its rank, any other the even rank just below the first greater
+// target.  Then strcmp(q, t) >= 0  <=>  rank(q) >= rank(t).
+namespace {
+void sorted_unique_names(const std::vector<std::string> &names, std::vector<const std::string*> &u)
+{
+	u.clear();
+	for (const std::string &n : names) u.push_back(&n);
+	std::sort(u.begin(), u.end(), [](const std::string *a, const std::string *b) { return strcmp(a->c_str(), b->c_str()) < 0; });
+	u.erase(std::unique(u.begin(), u.end(), [](const std::string *a, const std::string *b) { return strcmp(a->c_str(), b->c_str()) == 0; }), u.end());
+}
+uint32_t rank_of(const std::vector<const std::string*> &u, const char *q)
+{
+	size_t lo = 0, hi = u.size();                                  // first target name >= q
+	while (lo < hi) { const size_t mid = (lo + hi) / 2; if (strcmp(u[mid]->c_str(), q) < 0) lo = mid + 1; else hi = mid; }
+	if (lo < u.size() && strcmp(u[lo]->c_str(), q) == 0) return (uint32_t)(2 * lo + 1);
+	return (uint32_t)(2 * lo);
+}
+}
+extern "C" int rh_index_name_ranks(const rh_index *ix, const char *const *names, uint32_t n, uint32_t *query_ranks, uint32_t *target_ranks)
+{
+	std::vector<const std::string*> u;
+	sorted_unique_names(ix->names, u);
+	if (query_ranks) for (uint32_t i = 0; i < n; ++i) query_ranks[i] = rank_of(u, names[i] ? names[i] : "");
+	if (target_ranks) for (size_t t = 0; t < ix->names.size(); ++t) target_ranks[t] = rank_of(u, ix->names[t].c_str());
+	return 0;
+}
+extern "C" int rh_index_set_target_ranks(rh_ctx *c, const uint32_t *target_ranks, uint32_t n)
+{
+	if (need_index(c)) return -1;
+	RH_HIP(hipSetDevice(c->device));
+	if (n != c->dix.n_seq) { rh_set_error("%u target ranks for an index of %u targets", n, c->dix.n_seq); return -1; }
+	if (c->t_rank.ensure((size_t)(n ? n : 1) * 4)) return -1;
+	if (n) RH_HIP(hipMemcpy(c->t_rank.p, target_ranks, (size_t)n * 4, hipMemcpyHostToDevice));
+	c->dix.t_rank = c->t_rank.as<uint32_t>();
+	return 0;
+}
+namespace {
+int set_target_ranks_from(rh_ctx *c, const rh_index *ix)
+{
+	std::vector<uint32_t> tr(ix->names.size());
+	rh_index_name_ranks(ix, nullptr, 0, nullptr, tr.data());
+	return rh_index_set_target_ranks(c, tr.data(), (uint32_t)tr.size());
+}
 }
 
 // keys and positions of the resident index back into the host object (hash order), for rh_index_get / rh_index_write
@@ -557,7 +619,27 @@ void dump_round2(rh_ctx *c, uint32_t chunk, uint32_t n_act, const rh_dev_round &
 }
 
 // the whole path for one (sub-)batch on one context's stream
-int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out)
+// strides of the per-read rows: a chunk's worth, or (whole-read rounds) what the longest read of the batch needs
+int set_row_strides(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in)
+{
+	c->whole = (mo->flag & RH_M_NO_ADAPTIVE) ? 1 : 0;
+	c->ev_row = RH_CHUNK_MAX + 64; c->ev_cap = RH_EV_CAP;
+	if (!c->whole) return 0;
+	const uint32_t R = in->n_reads;
+	std::vector<uint64_t> off_h;
+	const uint64_t *off = in->offsets;
+	if (in->samples_on_device && R) { off_h.resize((size_t)R + 1); RH_HIP(hipMemcpy(off_h.data(), in->offsets, ((size_t)R + 1) * 8, hipMemcpyDeviceToHost)); off = off_h.data(); }
+	uint64_t mx = 0;
+	for (uint32_t r = 0; r < R; ++r) if (off[r + 1] - off[r] > mx) mx = off[r + 1] - off[r];
+	if (mx >= (1ull << 26)) { rh_set_error("whole-read rounds: reads of 2^26 samples or more are not supported"); return -1; }
+	c->ev_row = (uint32_t)((mx + 64 + 63) & ~63ull);
+	c->ev_cap = c->ev_row / 2 + 2;                                  // peaks are >= 2 samples apart (revent.c:140)
+	if (c->ev_cap < RH_EV_CAP) c->ev_cap = RH_EV_CAP;
+	return 0;
+}
+
+// rec_off != null: all-vs-all, a read may have several records (rec_off[r] .. rec_off[r + 1], n_reads + 1 offsets)
+int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out, uint64_t *rec_off = nullptr)
 {
 	*n_out = 0;
 	if (need_index(c)) return -1;
@@ -565,8 +647,13 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 	rh_dev_opt o;
 	if (fill_dev_opt(c, mo, &o)) return -1;
 	const uint32_t R = in->n_reads;
+	const bool ava = (mo->flag & RH_M_ALL_CHAINS) != 0;
+	if (ava && !rec_off) { rh_set_error("all-vs-all mapping returns several records per read: call rh_map_batch_multi"); return -1; }
+	if (ava && !in->name_rank) { rh_set_error("all-vs-all mapping needs the name ranks of the reads (rh_read_batch_t::name_rank, see rh_index_name_ranks)"); return -1; }
 	if (out_cap < R) { rh_set_error("output capacity %llu < %u reads", (unsigned long long)out_cap, R); return -1; }
+	if (rec_off) rec_off[0] = 0;
 	if (R == 0) return 0;
+	if (set_row_strides(c, mo, in)) return -1;
 	memset(&c->stats, 0, sizeof(c->stats));
 	c->ev_used = 0; c->ev_stage.clear();
 	const auto t_begin = std::chrono::steady_clock::now();
@@ -659,10 +746,22 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 		n_act = (uint32_t)c->pin[0];
 		cur ^= 1; which ^= 1;
 	}
-	{ StageTimer t(c, ST_FINALIZE); rhk_finalize(s, o, c->dix, rd, c->rec.as<rh_map_record_t>()); }
+	uint64_t n_rec = R;
+	if (!ava) { StageTimer t(c, ST_FINALIZE); rhk_finalize(s, o, c->dix, rd, c->rec.as<rh_map_record_t>()); }
+	else {	// the reported chains wait in the dense carry buffer of the (only) round
+		StageTimer t(c, ST_FINALIZE);
+		if (c->rec_off.ensure((size_t)(R + 1) * 8)) return -1;
+		rhk_ava_rec_scan(s, rd, c->rec_off.as<uint64_t>());
+		RH_HIP(hipMemcpyAsync(rec_off, c->rec_off.p, (size_t)(R + 1) * 8, hipMemcpyDeviceToHost, s));
+		RH_HIP(hipStreamSynchronize(s));
+		n_rec = rec_off[R];
+		if (n_rec > out_cap) { rh_set_error("output capacity %llu < %llu records", (unsigned long long)out_cap, (unsigned long long)n_rec); return -1; }
+		if (c->rec.ensure((size_t)n_rec * sizeof(rh_map_record_t))) return -1;
+		rhk_finalize_ava(s, o, c->dix, rd, c->carry[which ^ 1].as<rh_mm128_t>(), c->rec_off.as<uint64_t>(), c->rec.as<rh_map_record_t>());
+	}
 	{
 		StageTimer t(c, ST_D2H);
-		RH_HIP(hipMemcpyAsync(out, c->rec.p, (size_t)R * sizeof(rh_map_record_t), hipMemcpyDeviceToHost, s));
+		RH_HIP(hipMemcpyAsync(out, c->rec.p, (size_t)n_rec * sizeof(rh_map_record_t), hipMemcpyDeviceToHost, s));
 		uint64_t cnt[16];
 		RH_HIP(hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, s));
 		RH_HIP(hipStreamSynchronize(s));
@@ -676,7 +775,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 	c->stats.n_reads = R;
 	c->stats.n_samples_raw = in->samples_on_device ? 0 : in->offsets[R] - in->offsets[0];
 	c->stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-	*n_out = R;
+	*n_out = n_rec;
 	return 0;
 }
 void add_stats(rh_map_stats_t &tot, const rh_map_stats_t &q)
@@ -1139,3 +1238,91 @@ extern "C" int rh_synth_reads_device(rh_ctx *c, const rh_synth_cfg_t *cfg, const
 	out->samples_on_device = 1;
 	return 0;
 }
+
+// All-vs-all (RH_M_ALL_CHAINS) returns as many records per read as chains it reports (rmap.cpp:557-586), else one: the records
+// of read r are out[rec_offsets[r] .. rec_offsets[r + 1]).  One round over whole reads on the context's stream.
+extern "C" int rh_map_batch_multi(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap,
+                                  uint64_t *rec_offsets, uint64_t *n_out)
+{
+	for (auto &f : c->flight) if (f.ctx && !f.busy && holds_arenas(f.ctx)) release_arenas(f.ctx);
+	c->share = c->flight_mult;
+	std::vector<uint64_t> tmp;
+	if (!rec_offsets) { tmp.resize((size_t)in->n_reads + 1); rec_offsets = tmp.data(); }
+	if (!(mo->flag & RH_M_ALL_CHAINS)) {	// one record per read: the ordinary path, offsets 0 .. n
+		if (rh_map_batch(c, mo, in, out, out_cap, n_out)) return -1;
+		for (uint32_t r = 0; r <= in->n_reads; ++r) rec_offsets[r] = r;
+		return 0;
+	}
+	return map_batch_once(c, mo, in, out, out_cap, n_out, rec_offsets);
+}
+
+// ---------------------------------------------------------------------------------------------------- signal-target index
+// ri_idx_siggen (rindex.c:927) on the device: every read is a target (name, filtered length); its whole signal goes through
+// the event kernels and the sketch with the read's id (worker_sig_pipeline rindex.c:283-287: no min_events filter here), and
+// the seeds of all reads, in read order, through the same sort / key / table kernels as the FASTA index.
+extern "C" rh_index *rh_index_build_signals_device(rh_ctx *c, const rh_read_batch_t *in, const char *const *names, const char *pore_model_path,
+                                                   const rh_idxopt_t *io, const rh_mapopt_t *mo)
+{
+	if (hipSetDevice(c->device) != hipSuccess) { rh_set_error("hipSetDevice failed"); return nullptr; }
+	if (!(io->flag & RH_I_SIG_TARGET)) { rh_set_error("rh_index_build_signals_device builds signal-target indexes (RH_I_SIG_TARGET, the ava presets)"); return nullptr; }
+	if (io->e < 1 || io->e > 16 || io->q < 1 || io->q * io->e > 64 || io->w < 0 || io->w > RH_DEV_MAXW) { rh_set_error("unsupported index parameters e=%d q=%d w=%d", io->e, io->q, io->w); return nullptr; }
+	const uint32_t R = in->n_reads;
+	std::unique_ptr<rh_index_s> ix(new rh_index_s());
+	ix->w = io->w; ix->e = io->e; ix->n = io->n; ix->q = io->q; ix->k = io->k; ix->flag = io->flag;
+	ix->diff = io->diff; ix->fine_min = io->fine_min; ix->fine_max = io->fine_max; ix->fine_range = io->fine_range;
+	if (!rh_load_model(pore_model_path, io->k, io->lev_col, ix->pore_vals)) return nullptr;
+	ix->n_pore_vals = (uint32_t)ix->pore_vals.size(); ix->pore_k = (int16_t)io->k;
+	rh_make_pore_inds(ix->pore_vals, io->k, ix->pore_inds);
+	for (uint32_t i = 0; i < R; ++i) ix->names.push_back(names && names[i] ? names[i] : "");
+	// the resident index of this context is replaced
+	if (c->blob_owned) c->blob.release(); else { c->blob.p = nullptr; c->blob.cap = 0; }
+	c->have_index = false; c->dix.t_rank = nullptr;
+	rh_mapopt_t mw = *mo;
+	mw.flag = RH_M_NO_ADAPTIVE; mw.min_events = 0;
+	rh_dev_opt o;
+	if (fill_dev_opt(c, &mw, &o)) return nullptr;
+	c->dix.sp = rh_sketch_par{io->e, io->w, io->q, io->k, io->diff, io->fine_min, io->fine_max, io->fine_range};
+	hipStream_t s = c->stream;
+	void *dH = nullptr, *dY = nullptr;
+	uint64_t n_seeds = 0;
+	std::vector<uint32_t> lens(R ? R : 1, 0);
+	auto fail = [&]() -> rh_index* { if (dH) (void)hipFree(dH); if (dY) (void)hipFree(dY); return nullptr; };
+	if (R) {
+		rh_dev_reads rd;
+		if (set_row_strides(c, &mw, in) || stage_reads(c, in, &rd)) return nullptr;
+		if (c->act[0].ensure((size_t)R * 4) || c->n_act_dev.ensure(64) || c->counters.ensure(16 * 8) || c->rec_off.ensure((size_t)(R + 2) * 8)) return nullptr;
+		if (hipMemsetAsync(c->counters.p, 0, 16 * 8, s) != hipSuccess) return nullptr;
+		rhk_prefilter(s, o, rd);
+		rhk_compact_active(s, o, rd, nullptr, R, 0, c->act[0].as<uint32_t>(), c->n_act_dev.as<uint32_t>());
+		uint32_t n_act = 0;
+		if (hipMemcpyAsync(&n_act, c->n_act_dev.p, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rh_set_error("index build: device error"); return nullptr; }
+		rh_dev_round rr{};
+		if (stage_round(c, n_act, &rr)) return nullptr;
+		rr.act = c->act[0].as<uint32_t>(); rr.chunk = 0;
+		if (n_act) {
+			rhk_events_norm(s, o, rd, rr); rhk_events_peaks(s, o, rr); rhk_events_means(s, o, rr);
+			rhk_sketch(s, o, c->dix, rd, rr);
+			rhk_seed_scan(s, rr, c->rec_off.as<uint64_t>());
+			uint64_t cnt[16];
+			if (hipMemcpyAsync(&n_seeds, c->rec_off.as<uint64_t>() + n_act, 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+			    hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rh_set_error("index build: device error"); return nullptr; }
+			if (cnt[7]) { rh_set_error("index build: %llu read(s) hold more event boundaries than their arrays", (unsigned long long)cnt[7]); return nullptr; }
+		}
+		if (hipMalloc(&dH, (n_seeds + 1) * 4) != hipSuccess || hipMalloc(&dY, (n_seeds + 1) * 8) != hipSuccess) { rh_set_error("index build: out of device memory for %llu seeds", (unsigned long long)n_seeds); return fail(); }
+		if (n_act) rhk_seed_pack(s, rr, c->rec_off.as<uint64_t>(), (uint32_t*)dH, (uint64_t*)dY);
+		if (hipMemcpyAsync(lens.data(), rd.l_sig, (size_t)R * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rh_set_error("index build: device error"); return fail(); }
+	} else if (hipMalloc(&dH, 4) != hipSuccess || hipMalloc(&dY, 8) != hipSuccess) return fail();
+	uint32_t max_len = 0;
+	for (uint32_t i = 0; i < R; ++i) { ix->lens.push_back(lens[i]); if (lens[i] > max_len) max_len = lens[i]; }
+	release_arenas(c);                                              // the rows of whole reads are large: back to the device before the sort
+	BlobHeader h{};
+	void *blob = nullptr;
+	uint64_t n_keys = 0;
+	if (rhk_index_assemble(s, dH, dY, n_seeds, R, lens.data(), max_len, io, &h, &blob, ix->occ_hist, &n_keys)) return nullptr;
+	c->blob.p = blob; c->blob.cap = h.bytes; c->blob.owned = true; c->blob_owned = true;
+	if (bind_blob(c, h)) return nullptr;
+	ix->dev_n_keys = n_keys; ix->dev_n_pos = h.n_pos;
+	if (set_target_ranks_from(c, ix.get())) return nullptr;
+	return ix.release();
+}
+

@@ -482,6 +482,23 @@ int rhk_index_build_device(hipStream_t s, uint32_t n_seq, const char *const *seq
 	// per-sequence scratch is done with
 	dSeq.release(); dLv.release(); dPc.release(); dIn.release(); dOut.release(); dFlag.release(); dRuns.release();
 	for (int q = 0; q < 2; ++q) { dMask[q].release(); dPrefix[q].release(); dCode[q].release(); dPos[q].release(); }
+	void *hp = dH[0].p, *yp = dY[0].p;
+	dH[0].p = nullptr; dY[0].p = nullptr;                         // (handed over)
+	return rhk_index_assemble(s, hp, yp, n_seeds, n_seq, lens, max_len, io, hdr, blob_out, occ_hist, n_keys_out);
+}
+
+// Seeds (32-bit hash, position word) in target order -> resident blob [table | positions | target lengths].  Takes ownership
+// of the two device arrays (hipMalloc'ed, n_seeds + 1 entries).
+int rhk_index_assemble(hipStream_t s, void *seed_hash, void *seed_pos, uint64_t n_seeds, uint32_t n_seq, const uint32_t *lens, uint32_t max_len,
+                       const rh_idxopt_t *io, rh_blob_header *hdr, void **blob_out, std::vector<uint32_t> &occ_hist, uint64_t *n_keys_out)
+{
+	const rh_sketch_par sp = {io->e, io->w, io->q, io->k, io->diff, io->fine_min, io->fine_max, io->fine_range};
+	DevMem dH[2], dY[2], dSums, dScal;
+	dH[0].p = seed_hash; dY[0].p = seed_pos;
+	if (dScal.alloc(64)) return -1;
+	uint64_t *scal = nullptr;
+	RH_HIP(hipHostMalloc((void**)&scal, 64, 0));
+	struct PinFree { uint64_t *p; ~PinFree() { if (p) (void)hipHostFree(p); } } pin_free{scal};
 	// ---- stable LSD radix sort by hash
 	const uint64_t N = n_seeds, n_tiles = (N + IX_RT - 1) / IX_RT;
 	int cur = 0;

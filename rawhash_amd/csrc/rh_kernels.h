@@ -19,6 +19,7 @@ struct rh_dev_index {
 	const rh_tslot *table;           // (1 << lg_buckets) buckets x RH_TB_SLOTS slots
 	const uint64_t *pos;             // concatenated position lists
 	const uint32_t *seq_len;
+	const uint32_t *t_rank;          // all-vs-all: rank of every target's name (see rd.name_rank); null otherwise
 	int32_t lg_buckets;
 	uint32_t n_seq;
 	int32_t flag;
@@ -37,6 +38,9 @@ struct rh_blob_header {
 // index construction on the device (rh_index_device.hip)
 int rhk_index_build_device(hipStream_t s, uint32_t n_seq, const char *const *seqs, const uint32_t *lens, const std::vector<float> &model,
                            const rh_idxopt_t *io, rh_blob_header *hdr, void **blob_out, std::vector<uint32_t> &occ_hist, uint64_t *n_keys_out, int n_threads);
+
+int rhk_index_assemble(hipStream_t s, void *seed_hash, void *seed_pos, uint64_t n_seeds, uint32_t n_seq, const uint32_t *lens, uint32_t max_len,
+                       const rh_idxopt_t *io, rh_blob_header *hdr, void **blob_out, std::vector<uint32_t> &occ_hist, uint64_t *n_keys_out);
 
 // scalar parameters every kernel may need
 struct rh_dev_opt {
@@ -57,6 +61,7 @@ struct rh_dev_opt {
 struct rh_dev_reads {
 	uint32_t n_reads;
 	const int16_t *raw; const uint64_t *off; const double *cal_off; const float *cal_scale;
+	const uint32_t *name_rank;       // all-vs-all: rank of the read's name among the target names (strcmp(q, t) >= 0 <=> name_rank >= t_rank[t])
 	uint32_t *l_sig;                 // filtered length (sl:i tag)
 	uint32_t *chunk_start;           // n_reads x (RH_MAX_CHUNKS+1): raw index of the first sample of chunk c
 	double *sum, *sum2; uint32_t *n_sum;   // running normalisation sums (rmap.cpp:412-413)
@@ -74,6 +79,8 @@ struct rh_dev_round {
 	uint8_t akey_on, akey_lo, akey_mid;      // anchor x = rev << 63 | rid << 32 | pos with pos < 2^akey_lo, rid < 2^akey_mid (0 = unknown)
 	const uint32_t *act;             // read ids active this round
 	uint32_t n_act; uint32_t chunk;
+	uint32_t ev_row, ev_cap;         // strides of the per-read rows: samples (zbuf / t1buf / t2buf) and events (peaks, ev, seeds, matches)
+	uint32_t whole;                  // RH_M_NO_ADAPTIVE: a round covers whole reads (rows in HBM only, 32-bit peak positions)
 	float *zbuf, *t1buf, *t2buf; uint32_t *n_norm;   // n_act rows of (RH_CHUNK_MAX + 64): normalised signal, both t-statistics
 	uint16_t *peaks; uint32_t *n_peaks;              // n_act x RH_EV_CAP peak positions
 	float *ev; uint32_t *n_ev;       // n_act x RH_EV_CAP
@@ -166,4 +173,8 @@ void rhk_rebase_offsets(hipStream_t s, const uint64_t *a_off, uint32_t n, uint64
 void rhk_carry_scan(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, uint64_t used, uint64_t *dst_off, uint64_t *total_out);
 void rhk_carry_copy(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, const rh_mm128_t *staging, const uint64_t *dst_off, rh_mm128_t *carry);
 void rhk_finalize(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, rh_map_record_t *rec);
+void rhk_seed_scan(hipStream_t s, const rh_dev_round &r, uint64_t *off);
+void rhk_seed_pack(hipStream_t s, const rh_dev_round &r, const uint64_t *off, uint32_t *hash_out, uint64_t *pos_out);
+void rhk_ava_rec_scan(hipStream_t s, const rh_dev_reads &rd, uint64_t *rec_off);
+void rhk_finalize_ava(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_mm128_t *maps, const uint64_t *rec_off, rh_map_record_t *rec);
 void rhk_synth_reads(hipStream_t s, const rh_synth_cfg_t &c, const int32_t *level16, uint64_t first, uint32_t n, int16_t *samples, uint64_t *off, double *cal_off, float *cal_scale);

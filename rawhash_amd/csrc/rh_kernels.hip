@@ -249,7 +249,7 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 
 	// 2. z-score, drop |z| >= 3, compact: same scheme; the z values of pass 1 wait in s_b for their slots (which are
 	//    in the HBM row directly when the prefix sums are another launch's business)
-	float *zrow = rr.zbuf + (size_t)a * EV_ROW;
+	float *zrow = rr.zbuf + (size_t)a * rr.ev_row;
 	uint32_t n;
 	{
 		const uint32_t per = ((s_len + (NT / 64) * 256u - 1) / ((NT / 64) * 256u)) * 256u;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 	__syncthreads();
 
 	// 4. t-statistics of both windows and the normalised signal go to HBM rows (coalesced)
-	float *t1row = rr.t1buf + (size_t)a * EV_ROW, *t2row = rr.t2buf + (size_t)a * EV_ROW;
+	float *t1row = rr.t1buf + (size_t)a * rr.ev_row, *t2row = rr.t2buf + (size_t)a * rr.ev_row;
 	for (uint32_t i = tid; i < n; i += NT) {
 		zrow[i] = s_z[i];
 		t1row[i] = tstat_at(pa, pb, n, o.w1, i);
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(NT) void k_events_tstat(rh_dev_opt o, rh_dev_round 
 	uint32_t ln[RW / 2];
 	const float *lrow[RW / 2];
 #pragma unroll
-	for (uint32_t k = 0; k < RW / 2; ++k) { ln[k] = s_n[lc0 + 2 * k]; lrow[k] = rr.zbuf + (size_t)(a0 + lc0 + 2 * k) * EV_ROW + ls; }
+	for (uint32_t k = 0; k < RW / 2; ++k) { ln[k] = s_n[lc0 + 2 * k]; lrow[k] = rr.zbuf + (size_t)(a0 + lc0 + 2 * k) * rr.ev_row + ls; }
 	float zr[RW / 2];
 #pragma unroll
 	for (uint32_t k = 0; k < RW / 2; ++k) zr[k] = ls < ln[k] ? lrow[k][0] : 0.0f;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(NT) void k_events_tstat(rh_dev_opt o, rh_dev_round 
 	float acc = 0.0f, acc2 = 0.0f;                                     // wave 0: the two chains of chunk l
 	const uint32_t win = l < 32 ? o.w1 : o.w2;                         // t-statistics: lanes 0..31 the short window, 32..63 the long one
 	const float fwin = (float)win, rwin = 1.0f / fwin;
-	float *const tbuf = (l < 32 ? rr.t1buf : rr.t2buf) + (size_t)(a0 + w * RW) * EV_ROW;
+	float *const tbuf = (l < 32 ? rr.t1buf : rr.t2buf) + (size_t)(a0 + w * RW) * rr.ev_row;
 	uint32_t rn[RW];
 #pragma unroll
 	for (uint32_t k = 0; k < RW; ++k) rn[k] = s_n[w * RW + k];
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(NT) void k_events_tstat(rh_dev_opt o, rh_dev_round 
 #pragma unroll
 		for (uint32_t k = 0; k < RW; ++k) {
 			const float v = tstat_ring(s_pa, s_pb, w * RW + k, rn[k], win, fwin, rwin, i0);
-			if (i0 < rn[k]) tbuf[(size_t)k * EV_ROW + i0] = v;
+			if (i0 < rn[k]) tbuf[(size_t)k * rr.ev_row + i0] = v;
 		}
 	}
 }
@@ -449,6 +449,7 @@ __global__ __launch_bounds__(NT) void k_events_tstat(rh_dev_opt o, rh_dev_round 
 // HBM is read in full 256-byte rows.
 #define PK_TILE 64
 #define PK_CHUNKS 32
+template <typename PT>   // peak positions: 16 bits for a chunk, 32 for a whole read (RH_M_NO_ADAPTIVE)
 __global__ __launch_bounds__(64) void k_events_peaks(rh_dev_opt o, rh_dev_round rr)
 {
 	__shared__ float s_t[2][PK_TILE * (PK_CHUNKS + 1)];
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(64) void k_events_peaks(rh_dev_opt o, rh_dev_round 
 	int32_t pos = -1, valid = 0;
 	float val = FLT_MAX, held = 0.0f;                               // held: the long detector's sample of the step it is about to process
 	uint32_t ev_in = 0;                                             // masking event of that step: 1u << 31 | masked_to
-	uint16_t *pk = rr.peaks + (size_t)a * RH_EV_CAP;
+	PT *pk = (PT*)rr.peaks + (size_t)a * rr.ev_cap;
 	const uint32_t rows = rr.n_act - a0 < PK_CHUNKS ? rr.n_act - a0 : PK_CHUNKS;
 	for (uint32_t i0 = 0; i0 <= nmax; i0 += PK_TILE) {               // (<=: one more iteration for the lagging lanes)
 		__syncthreads();
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(64) void k_events_peaks(rh_dev_opt o, rh_dev_round 
 			float r1[PK_CHUNKS], r2[PK_CHUNKS];
 #pragma unroll
 			for (uint32_t row = 0; row < PK_CHUNKS; ++row) {
-				const size_t g = (size_t)(a0 + (row < rows ? row : 0u)) * EV_ROW + i0 + lane;
+				const size_t g = (size_t)(a0 + (row < rows ? row : 0u)) * rr.ev_row + i0 + lane;
 				r1[row] = rr.t1buf[g]; r2[row] = rr.t2buf[g];
 			}
 #pragma unroll
@@ -513,13 +514,13 @@ __global__ __launch_bounds__(64) void k_events_peaks(rh_dev_opt o, rh_dev_round 
 			if (k == 0) ev_in = 0;
 			const int32_t e_mine = emit >= 0 ? 1 : 0;
 			const int32_t e_short = rh_quad_perm_0022(e_mine), e_long = rh_quad_perm_1133(e_mine);
-			if (emit >= 0) { const uint32_t at = np + (k == 0 ? (uint32_t)e_long : 0u); if (at < RH_EV_CAP) pk[at] = (uint16_t)emit; }
+			if (emit >= 0) { const uint32_t at = np + (k == 0 ? (uint32_t)e_long : 0u); if (at < rr.ev_cap) pk[at] = (PT)emit; }
 			np += (uint32_t)(e_short + e_long);
 		}
 	}
 	if (a < rr.n_act && k == 0) {
-		rr.n_peaks[a] = np < RH_EV_CAP ? np : RH_EV_CAP;
-		if (np > RH_EV_CAP) atomicAdd((unsigned long long*)&rr.counters[7], 1ull);   // more peaks than the per-chunk arrays hold: the call fails (no silent divergence)
+		rr.n_peaks[a] = np < rr.ev_cap ? np : rr.ev_cap;
+		if (np > rr.ev_cap) atomicAdd((unsigned long long*)&rr.counters[7], 1ull);   // more peaks than the per-chunk arrays hold: the call fails (no silent divergence)
 	}
 }
 
@@ -577,13 +578,13 @@ __global__ __launch_bounds__(NT) void k_events_means(rh_dev_opt o, rh_dev_round 
 	if (a >= rr.n_act) return;
 	const uint32_t n = rr.n_norm[a];
 	const uint32_t np = n ? rr.n_peaks[a] : 0u;
-	const float *zrow = rr.zbuf + (size_t)a * EV_ROW;
-	const uint16_t *pk = rr.peaks + (size_t)a * RH_EV_CAP;
+	const float *zrow = rr.zbuf + (size_t)a * rr.ev_row;
+	const uint16_t *pk = rr.peaks + (size_t)a * rr.ev_cap;
 	for (uint32_t i = tid; i < n; i += NT) s_z[i] = zrow[i];
 	for (uint32_t i = tid; i < np; i += NT) s_peaks[i] = pk[i];
 	if (tid == 0) s_nlong = 0;
 	__syncthreads();
-	float *ev = rr.ev + (size_t)a * RH_EV_CAP;
+	float *ev = rr.ev + (size_t)a * rr.ev_cap;
 	for (uint32_t k0 = 0; k0 < np; k0 += NT) {
 		const uint32_t k = k0 + tid;
 		uint32_t start = 0, len = 0;
@@ -641,6 +642,101 @@ __global__ __launch_bounds__(NT) void k_events_means(rh_dev_opt o, rh_dev_round 
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ whole reads (RH_M_NO_ADAPTIVE)
+// The Rawsamble presets map a read in ONE round over its whole signal (rmap.cpp:404-405: l_chunk = qlen, max_chunk = 1), and
+// the signal-target index is built from whole reads too (rindex.c:283-287).  A read no longer fits LDS: the rows live in HBM
+// (stride rr.ev_row), the order-sensitive prefix sums / t-statistics and the peak detectors are the streaming kernels above
+// (they never assumed a length), and these two replace the LDS-resident ends of the chain.
+
+// One block per read: pA filter + fp64 statistics + z-score + compaction, in tiles of NT samples (order preserving).  The pA
+// values wait in the read's t1 row (k_events_tstat overwrites it afterwards).
+__global__ __launch_bounds__(NT) void k_events_norm_whole(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
+{
+	__shared__ uint32_t s_w[NT / 64];
+	__shared__ double s_red[2 * (NT / 64)];
+	__shared__ double s_stat[2];
+	const uint32_t a = blockIdx.x, tid = threadIdx.x;
+	if (a >= rr.n_act) return;
+	const uint32_t r = rr.act[a];
+	const uint64_t o0 = rd.off[r];
+	const uint32_t n_raw = (uint32_t)(rd.off[r + 1] - o0);
+	const int16_t *raw = rd.raw + o0;
+	const double coff = rd.cal_off[r];
+	const float cscale = rd.cal_scale[r];
+	float *parow = rr.t1buf + (size_t)a * rr.ev_row, *zrow = rr.zbuf + (size_t)a * rr.ev_row;
+	uint32_t s_len = 0;
+	double dsum = 0.0, dsum2 = 0.0;
+	for (uint32_t base = 0; base < n_raw; base += NT) {
+		const uint32_t i = base + tid;
+		bool valid = false; float pa = 0.0f;
+		if (i < n_raw) { pa = raw_to_pa(raw[i], coff, cscale); valid = pa > 30.0f && pa < 200.0f; }
+		uint32_t tot;
+		const uint32_t pos = s_len + block_rank(valid, s_w, tot);
+		if (valid) { parow[pos] = pa; dsum += (double)pa; const float sq = pa * pa; dsum2 += (double)sq; }
+		s_len += tot;
+	}
+	for (int d = 32; d > 0; d >>= 1) { dsum += __shfl_down(dsum, d); dsum2 += __shfl_down(dsum2, d); }
+	if (lane_id() == 0) { s_red[2 * wave_id()] = dsum; s_red[2 * wave_id() + 1] = dsum2; }
+	__syncthreads();
+	if (tid == 0) {
+		double S = rd.sum[r], S2 = rd.sum2[r];
+		for (uint32_t q = 0; q < NT / 64; ++q) { S += s_red[2 * q]; S2 += s_red[2 * q + 1]; }
+		const uint32_t N = rd.n_sum[r] + s_len;
+		rd.sum[r] = S; rd.sum2[r] = S2; rd.n_sum[r] = N;
+		const double mean = S / N;
+		s_stat[0] = mean;
+		s_stat[1] = sqrt(S2 / N - mean * mean);
+		atomicAdd((unsigned long long*)&rr.counters[5], (unsigned long long)s_len);
+		atomicAdd((unsigned long long*)&rr.counters[6], 1ull);
+	}
+	__syncthreads();                                              // (also: the pA row is complete)
+	const double mean = s_stat[0], sd = s_stat[1];
+	uint32_t n = 0;
+	for (uint32_t base = 0; base < s_len; base += NT) {
+		const uint32_t i = base + tid;
+		bool keep = false; float v = 0.0f;
+		if (i < s_len) { v = (float)(((double)parow[i] - mean) / sd); keep = v < 3.0f && v > -3.0f; }
+		uint32_t tot;
+		const uint32_t pos = n + block_rank(keep, s_w, tot);
+		if (keep) zrow[pos] = v;
+		n += tot;
+	}
+	if (tid == 0) rr.n_norm[a] = n;
+}
+
+// One block per read, one lane per segment between consecutive peaks (revent.c:193-219): sorted in registers up to 32
+// samples, in place in the (no longer needed) z row beyond that.
+__global__ __launch_bounds__(NT) void k_events_means_whole(rh_dev_opt o, rh_dev_round rr)
+{
+	const uint32_t a = blockIdx.x, tid = threadIdx.x;
+	if (a >= rr.n_act) return;
+	const uint32_t n = rr.n_norm[a];
+	const uint32_t np = n ? rr.n_peaks[a] : 0u;
+	float *zrow = rr.zbuf + (size_t)a * rr.ev_row;
+	const uint32_t *pk = (const uint32_t*)rr.peaks + (size_t)a * rr.ev_cap;
+	float *ev = rr.ev + (size_t)a * rr.ev_cap;
+	for (uint32_t k0 = 0; k0 < np; k0 += NT) {
+		const uint32_t k = k0 + tid;
+		uint32_t start = 0, len = 0;
+		if (k < np) { start = k ? pk[k - 1] : 0u; const uint32_t end = pk[k]; len = end > start ? end - start : 0u; }
+		const bool small = k < np && len <= 32;
+		float res = 0.0f;
+		if (__ballot(small && len > 16)) { if (small && len > 0) res = sort_mean_regs<32>(zrow + start, len); }
+		else if (small && len > 0) res = sort_mean_regs<16>(zrow + start, len);
+		if (k < np && !small) {
+			float *seg = zrow + start;
+			for (uint32_t i = 1; i < len; ++i) { const float x = seg[i]; uint32_t j = i; while (j > 0 && seg[j - 1] > x) { seg[j] = seg[j - 1]; --j; } seg[j] = x; }
+			res = fenced_mean_lds(seg, len);
+		}
+		if (k < np) ev[k] = res;
+	}
+	if (tid == 0) {
+		rr.n_ev[a] = np;
+		rr.skip[a] = np < o.min_events ? 1 : 0;
+		atomicAdd((unsigned long long*)&rr.counters[0], (unsigned long long)np);
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ k_sketch
 struct seed_emit {
 	uint64_t *sx, *sy; uint32_t n, cap;
@@ -664,10 +760,10 @@ __global__ __launch_bounds__(64) void k_sketch(rh_dev_opt o, rh_dev_index ix, rh
 	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
 	if (a >= rr.n_act) return;
 	if (rr.skip[a]) { rr.n_seed[a] = 0; return; }
-	seed_emit em = { rr.sx + (size_t)a * RH_EV_CAP, rr.sy + (size_t)a * RH_EV_CAP, 0u, RH_EV_CAP };
+	seed_emit em = { rr.sx + (size_t)a * rr.ev_cap, rr.sy + (size_t)a * rr.ev_cap, 0u, rr.ev_cap };
 	sketch_store_lds<MINIMISERS> st = { s_ring + threadIdx.x, s_bx + threadIdx.x, s_by + threadIdx.x };
-	rh_sketch_events<RH_DEV_MAXW>(rr.ev + (size_t)a * RH_EV_CAP, rr.n_ev[a], 0u, 0, ix.sp, em, st);
-	const uint32_t ns = em.n < RH_EV_CAP ? em.n : RH_EV_CAP;
+	rh_sketch_events<RH_DEV_MAXW>(rr.ev + (size_t)a * rr.ev_cap, rr.n_ev[a], 0u, 0, ix.sp, em, st);
+	const uint32_t ns = em.n < rr.ev_cap ? em.n : rr.ev_cap;
 	rr.n_seed[a] = ns;
 	atomicAdd((unsigned long long*)&rr.counters[1], (unsigned long long)ns);
 }
@@ -682,65 +778,76 @@ __global__ __launch_bounds__(NT) void k_probe(rh_dev_opt o, rh_dev_index ix, rh_
 	__shared__ uint64_t s_val[RH_EV_CAP];
 	__shared__ uint32_t s_flt[RH_EV_CAP];       // over-frequent seeds: q_pos | q_span << 26
 	__shared__ uint32_t s_w[NT / 64];
+	__shared__ int32_t s_rep[3];                // rep_st, rep_en, rep_len carried over the tiles of a whole read
 	const uint32_t a = blockIdx.x, tid = threadIdx.x;
 	if (a >= rr.n_act) return;
 	const uint32_t ns = rr.skip[a] ? 0u : rr.n_seed[a];
-	const uint64_t *sx = rr.sx + (size_t)a * RH_EV_CAP, *sy = rr.sy + (size_t)a * RH_EV_CAP;
+	const uint64_t *sx = rr.sx + (size_t)a * rr.ev_cap, *sy = rr.sy + (size_t)a * rr.ev_cap;
 	const uint32_t grp = tid >> 3, gl = tid & 7u, gshift = lane_id() & ~7u;
 	const uint64_t bmask = (1ull << ix.lg_buckets) - 1ull;
-	for (uint32_t i = grp; i < ns; i += NT / 8) {
-		const uint32_t hash = (uint32_t)(sx[i] >> 6);
-		uint64_t b = (uint64_t)((uint32_t)(hash * 0x9E3779B1u) >> (32 - ix.lg_buckets));
-		for (;;) {
-			const rh_tslot sl = ix.table[b * RH_TB_SLOTS + gl];
-			const bool hit = sl.n != 0 && sl.hash == hash, empty = sl.n == 0;
-			const uint32_t mh = (uint32_t)(__ballot(hit) >> gshift) & 0xFFu;
-			const uint32_t me = (uint32_t)(__ballot(empty) >> gshift) & 0xFFu;
-			if (mh) { if (hit) { s_n[i] = sl.n; s_val[i] = sl.val; } break; }
-			if (me) { if (gl == 0) s_n[i] = 0; break; }
-			b = (b + 1) & bmask;
-		}
-	}
-	__syncthreads();
-	// Bookkeeping of ri_collect_matches (rseed.c:105-154), order preserving and parallel: tandem flag from the neighbouring
-	// hashes, mid_occ filter, compaction of the kept matches with the running prefix of their occurrence counts; only the
-	// interval merge of the (few) over-frequent seeds is left to one lane.
-	uint64_t *m_val = rr.m_val + (size_t)a * RH_EV_CAP;
-	uint32_t *m_n = rr.m_n + (size_t)a * RH_EV_CAP, *m_meta = rr.m_meta + (size_t)a * RH_EV_CAP, *m_pref = rr.m_pref + (size_t)a * (RH_EV_CAP + 1);
-	uint32_t nm = 0, pref = 0, n_flt = 0;
-	for (uint32_t base = 0; base < ns; base += NT) {
-		const uint32_t i = base + tid;
-		bool kept = false, flt = false;
-		uint32_t cnt = 0, q_pos = 0, tandem = 0;
-		if (i < ns) {
-			cnt = s_n[i];
-			if (cnt != 0) {
-				const uint64_t h = sx[i] >> 6;
-				q_pos = (uint32_t)sy[i];
-				tandem = ((i > 0 && (sx[i - 1] >> 6) == h) || (i + 1 < ns && (sx[i + 1] >> 6) == h)) ? 1u : 0u;
-				flt = cnt > (uint32_t)o.mid_occ;
-				kept = !flt;
+	uint64_t *m_val = rr.m_val + (size_t)a * rr.ev_cap;
+	uint32_t *m_n = rr.m_n + (size_t)a * rr.ev_cap, *m_meta = rr.m_meta + (size_t)a * rr.ev_cap, *m_pref = rr.m_pref + (size_t)a * (rr.ev_cap + 1);
+	uint32_t nm = 0, pref = 0;
+	if (tid == 0) { s_rep[0] = 0; s_rep[1] = 0; s_rep[2] = 0; }
+	// tiles of RH_EV_CAP seeds (a chunk has one; a whole read, RH_M_NO_ADAPTIVE, as many as its events need)
+	for (uint32_t t0 = 0; t0 == 0 || t0 < ns; t0 += RH_EV_CAP) {
+		const uint32_t tn = ns - t0 < RH_EV_CAP ? ns - t0 : RH_EV_CAP;
+		__syncthreads();
+		for (uint32_t i = grp; i < tn; i += NT / 8) {
+			const uint32_t hash = (uint32_t)(sx[t0 + i] >> 6);
+			uint64_t b = (uint64_t)((uint32_t)(hash * 0x9E3779B1u) >> (32 - ix.lg_buckets));
+			for (;;) {
+				const rh_tslot sl = ix.table[b * RH_TB_SLOTS + gl];
+				const bool hit = sl.n != 0 && sl.hash == hash, empty = sl.n == 0;
+				const uint32_t mh = (uint32_t)(__ballot(hit) >> gshift) & 0xFFu;
+				const uint32_t me = (uint32_t)(__ballot(empty) >> gshift) & 0xFFu;
+				if (mh) { if (hit) { s_n[i] = sl.n; s_val[i] = sl.val; } break; }
+				if (me) { if (gl == 0) s_n[i] = 0; break; }
+				b = (b + 1) & bmask;
 			}
 		}
-		uint32_t tot_k, tot_c, tot_f;
-		const uint32_t rk = block_rank(kept, s_w, tot_k);
-		const uint32_t pc = block_excl_scan(kept ? cnt : 0u, s_w, tot_c);
-		const uint32_t rf = block_rank(flt, s_w, tot_f);
-		if (kept) { m_val[nm + rk] = s_val[i]; m_n[nm + rk] = cnt; m_meta[nm + rk] = (q_pos >> 1) | (tandem << 31); m_pref[nm + rk] = pref + pc; }
-		if (flt && n_flt + rf < RH_EV_CAP) s_flt[n_flt + rf] = (q_pos >> 1) | ((uint32_t)(sx[i] & 63u) << 26);
-		nm += tot_k; pref += tot_c; n_flt += tot_f;
+		__syncthreads();
+		// Bookkeeping of ri_collect_matches (rseed.c:105-154), order preserving and parallel: tandem flag from the neighbouring
+		// hashes, mid_occ filter, compaction of the kept matches with the running prefix of their occurrence counts; only the
+		// interval merge of the (few) over-frequent seeds is left to one lane.
+		uint32_t n_flt = 0;
+		for (uint32_t base = 0; base < tn; base += NT) {
+			const uint32_t il = base + tid, i = t0 + il;
+			bool kept = false, flt = false;
+			uint32_t cnt = 0, q_pos = 0, tandem = 0;
+			if (il < tn) {
+				cnt = s_n[il];
+				if (cnt != 0) {
+					const uint64_t h = sx[i] >> 6;
+					q_pos = (uint32_t)sy[i];
+					tandem = ((i > 0 && (sx[i - 1] >> 6) == h) || (i + 1 < ns && (sx[i + 1] >> 6) == h)) ? 1u : 0u;
+					flt = cnt > (uint32_t)o.mid_occ;
+					kept = !flt;
+				}
+			}
+			uint32_t tot_k, tot_c, tot_f;
+			const uint32_t rk = block_rank(kept, s_w, tot_k);
+			const uint32_t pc = block_excl_scan(kept ? cnt : 0u, s_w, tot_c);
+			const uint32_t rf = block_rank(flt, s_w, tot_f);
+			if (kept) { m_val[nm + rk] = s_val[il]; m_n[nm + rk] = cnt; m_meta[nm + rk] = (q_pos >> 1) | (tandem << 31); m_pref[nm + rk] = pref + pc; }
+			if (flt) s_flt[n_flt + rf] = (q_pos >> 1) | ((uint32_t)(sx[i] & 63u) << 26);
+			nm += tot_k; pref += tot_c; n_flt += tot_f;
+		}
+		__syncthreads();
+		if (tid == 0) {
+			int32_t rep_st = s_rep[0], rep_en = s_rep[1], rep_len = s_rep[2];
+			for (uint32_t k = 0; k < n_flt; ++k) {
+				const int32_t st = (int32_t)(s_flt[k] & 0x3FFFFFFu) + 1, en = st + (int32_t)(s_flt[k] >> 26) + 1;
+				if (st > rep_en) { rep_len += rep_en - rep_st; rep_st = st; rep_en = en; }
+				else rep_en = en;
+			}
+			s_rep[0] = rep_st; s_rep[1] = rep_en; s_rep[2] = rep_len;
+		}
 	}
 	__syncthreads();
 	if (tid == 0) {
-		int32_t rep_st = 0, rep_en = 0, rep_len = 0;
-		for (uint32_t k = 0; k < n_flt; ++k) {
-			const int32_t st = (int32_t)(s_flt[k] & 0x3FFFFFFu) + 1, en = st + (int32_t)(s_flt[k] >> 26) + 1;
-			if (st > rep_en) { rep_len += rep_en - rep_st; rep_st = st; rep_en = en; }
-			else rep_en = en;
-		}
-		rep_len += rep_en - rep_st;
 		m_pref[nm] = pref;
-		rr.n_match[a] = nm; rr.n_new[a] = pref; rr.rep_len[a] = rep_len;
+		rr.n_match[a] = nm; rr.n_new[a] = pref; rr.rep_len[a] = s_rep[2] + (s_rep[1] - s_rep[0]);
 		atomicAdd((unsigned long long*)&rr.counters[2], (unsigned long long)pref);
 	}
 }
@@ -791,17 +898,18 @@ __global__ __launch_bounds__(NT) void k_expand(rh_dev_opt o, rh_dev_index ix, rh
 		return;
 	}
 	const uint32_t nm = rr.n_match[a], nn = rr.n_new[a];
-	const uint64_t *m_val = rr.m_val + (size_t)a * RH_EV_CAP;
-	const uint32_t *m_n = rr.m_n + (size_t)a * RH_EV_CAP, *m_meta = rr.m_meta + (size_t)a * RH_EV_CAP, *m_pref = rr.m_pref + (size_t)a * (RH_EV_CAP + 1);
-	for (uint32_t i = tid; i <= nm; i += NT) s_pref[i] = m_pref[i];
+	const uint64_t *m_val = rr.m_val + (size_t)a * rr.ev_cap;
+	const uint32_t *m_n = rr.m_n + (size_t)a * rr.ev_cap, *m_meta = rr.m_meta + (size_t)a * rr.ev_cap, *m_pref = rr.m_pref + (size_t)a * (rr.ev_cap + 1);
+	const uint32_t *pf = nm <= RH_EV_CAP ? s_pref : m_pref;        // (a whole read's matches may not fit LDS: searched where they lie)
+	if (nm <= RH_EV_CAP) for (uint32_t i = tid; i <= nm; i += NT) s_pref[i] = m_pref[i];
 	__syncthreads();
 	const uint32_t q_off = rd.ev_off[r];
 	const uint64_t span = (uint64_t)(ix.sp.k + ix.sp.e - 1);
 	rh_mm128_t *anc = rr.raw + base;
 	for (uint32_t j = tid; j < nn; j += NT) {
 		uint32_t lo = 0, hi = nm;   // largest s with s_pref[s] <= j
-		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_pref[mid] <= j) lo = mid; else hi = mid; }
-		const uint32_t s = lo, k = j - s_pref[s];
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pf[mid] <= j) lo = mid; else hi = mid; }
+		const uint32_t s = lo, k = j - pf[s];
 		const uint64_t hit = m_n[s] == 1 ? m_val[s] : ix.pos[m_val[s] + k];
 		const uint32_t meta = m_meta[s];
 		rh_mm128_t p;
@@ -812,6 +920,77 @@ __global__ __launch_bounds__(NT) void k_expand(rh_dev_opt o, rh_dev_index ix, rh
 		anc[j] = p;
 	}
 	for (uint32_t j = tid; j < np; j += NT) anc[nn + j] = pin[j];
+}
+
+// ------------------------------------------------------------------------------------------------ all-vs-all (RH_M_ALL_CHAINS)
+// collect_seed_hits drops, hit by hit, the targets whose name is not greater than the read's (rmap.cpp:86: reads overlap
+// themselves and every pair would be reported twice).  Names stay on the host; their order arrives as ranks (rd.name_rank of
+// the reads, ix.t_rank of the targets: strcmp(qname, tname) >= 0  <=>  name_rank >= t_rank).  The kept hits must stay in
+// their order (the anchor sort is not stable), so the counts are taken first and the prefix rebuilt:
+//   k_ava_count   kept hits per match -> m_pref (exclusive prefix), n_new
+//   k_expand_ava  one wavefront per match: its kept hits, ranked by ballots, written from the match's prefix
+RH_DEV bool ava_keep(const rh_dev_index &ix, uint32_t qrank, uint64_t hit) { return !(qrank >= ix.t_rank[(uint32_t)(hit >> 32)]); }
+
+__global__ __launch_bounds__(NT) void k_ava_count(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh_dev_round rr)
+{
+	__shared__ uint32_t s_w[NT / 64];
+	const uint32_t a = blockIdx.x, tid = threadIdx.x, w = wave_id(), l = lane_id();
+	if (a >= rr.n_act) return;
+	const uint32_t nm = rr.n_match[a], qrank = rd.name_rank[rr.act[a]];
+	const uint64_t *m_val = rr.m_val + (size_t)a * rr.ev_cap;
+	const uint32_t *m_n = rr.m_n + (size_t)a * rr.ev_cap;
+	uint32_t *m_pref = rr.m_pref + (size_t)a * (rr.ev_cap + 1);
+	for (uint32_t sd = w; sd < nm; sd += NT / 64) {
+		const uint32_t n = m_n[sd];
+		const uint64_t v = m_val[sd];
+		uint32_t c = 0;
+		if (n == 1) c = ava_keep(ix, qrank, v) ? 1u : 0u;
+		else for (uint32_t k0 = 0; k0 < n; k0 += 64) { const uint32_t k = k0 + l; c += (uint32_t)__popcll(__ballot(k < n && ava_keep(ix, qrank, ix.pos[v + k]))); }
+		if (l == 0) m_pref[sd] = c;
+	}
+	__syncthreads();
+	uint32_t run = 0;
+	for (uint32_t base = 0; base < nm; base += NT) {
+		const uint32_t i = base + tid;
+		const uint32_t c = i < nm ? m_pref[i] : 0u;
+		uint32_t tot;
+		const uint32_t ex = block_excl_scan(c, s_w, tot);
+		if (i < nm) m_pref[i] = run + ex;
+		run += tot;
+	}
+	if (tid == 0) { m_pref[nm] = run; rr.n_new[a] = run; }
+}
+
+__global__ __launch_bounds__(NT) void k_expand_ava(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh_dev_round rr)
+{
+	const uint32_t a = blockIdx.x, w = wave_id(), l = lane_id();
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const uint32_t r = rr.act[a], nm = rr.n_match[a], qrank = rd.name_rank[r];
+	const uint64_t *m_val = rr.m_val + (size_t)a * rr.ev_cap;
+	const uint32_t *m_n = rr.m_n + (size_t)a * rr.ev_cap, *m_meta = rr.m_meta + (size_t)a * rr.ev_cap, *m_pref = rr.m_pref + (size_t)a * (rr.ev_cap + 1);
+	const uint32_t q_off = rd.ev_off[r];
+	const uint64_t span = (uint64_t)(ix.sp.k + ix.sp.e - 1);
+	rh_mm128_t *anc = rr.raw + rr.a_off[a];
+	for (uint32_t sd = w; sd < nm; sd += NT / 64) {
+		const uint32_t n = m_n[sd], meta = m_meta[sd];
+		const uint64_t v = m_val[sd];
+		uint32_t at = m_pref[sd];
+		for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+			const uint32_t k = k0 + l;
+			uint64_t hit = 0; bool keep = false;
+			if (k < n) { hit = n == 1 ? v : ix.pos[v + k]; keep = ava_keep(ix, qrank, hit); }
+			const uint64_t B = __ballot(keep);
+			if (keep) {
+				rh_mm128_t p;
+				p.x = (hit & 0x7FFFFFFF80000000ull) | (uint64_t)((uint32_t)(hit >> 1) & 0x7FFFFFFFu);
+				if (hit & 1ull) p.x |= 1ull << 63;
+				p.y = span << 32 | (uint64_t)(uint32_t)((meta & 0x7FFFFFFFu) + q_off);
+				if (meta >> 31) p.y |= 1ull << 38;
+				anc[at + lanes_below(B)] = p;
+			}
+			at += (uint32_t)__popcll(B);
+		}
+	}
 }
 
 // ------------------------------------------------------------------------------------------------ k_compact_active
@@ -870,12 +1049,35 @@ __global__ __launch_bounds__(NT) void k_carry_copy(rh_dev_reads rd, const uint32
 	if (threadIdx.x == 0) rd.prev_off[r] = dst_off[a];
 }
 
-// ------------------------------------------------------------------------------------------------ k_finalize
-// One thread per read: rmap.cpp:507-586.
-__global__ void k_finalize(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh_map_record_t *rec)
+// ------------------------------------------------------------------------------------------------ seeds of whole reads -> index
+// Signal-target index (rindex.c:283-305): the sketch of every read, in read order, as (32-bit hash, id << 32 | pos << 1).
+__global__ __launch_bounds__(1024) void k_seed_scan(rh_dev_round rr, uint64_t *off)
 {
-	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= rd.n_reads) return;
+	__shared__ uint64_t s_part[1024];
+	const uint32_t tid = threadIdx.x, nt = blockDim.x, n = rr.n_act;
+	const uint32_t per = (n + nt - 1) / nt, b = tid * per, e = b + per < n ? b + per : n;
+	uint64_t s = 0;
+	for (uint32_t i = b; i < e; ++i) s += rr.n_seed[i];
+	s_part[tid] = s;
+	__syncthreads();
+	if (tid == 0) { uint64_t run = 0; for (uint32_t i = 0; i < nt; ++i) { const uint64_t v = s_part[i]; s_part[i] = run; run += v; } off[n] = run; }
+	__syncthreads();
+	uint64_t run = s_part[tid];
+	for (uint32_t i = b; i < e; ++i) { off[i] = run; run += rr.n_seed[i]; }
+}
+__global__ __launch_bounds__(NT) void k_seed_pack(rh_dev_round rr, const uint64_t *off, uint32_t *hash_out, uint64_t *pos_out)
+{
+	const uint32_t a = blockIdx.x;
+	if (a >= rr.n_act) return;
+	const uint32_t ns = rr.n_seed[a], id = rr.act[a];
+	const uint64_t *sx = rr.sx + (size_t)a * rr.ev_cap, *sy = rr.sy + (size_t)a * rr.ev_cap;
+	for (uint32_t i = threadIdx.x; i < ns; i += NT) { hash_out[off[a] + i] = (uint32_t)(sx[i] >> 6); pos_out[off[a] + i] = (uint64_t)id << 32 | (uint32_t)sy[i]; }
+}
+
+// ------------------------------------------------------------------------------------------------ k_finalize
+// rmap.cpp:507-586: the record of a read from the summary of its last round
+RH_DEV rh_map_record_t finalize_one(const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, uint32_t r, float *scale_out = nullptr)
+{
 	const uint32_t qlen = rd.l_sig[r];
 	const uint32_t l_chunk = o.chunk_size > qlen ? qlen : o.chunk_size;
 	const uint32_t iters = read_n_chunks(o, qlen);
@@ -885,6 +1087,7 @@ __global__ void k_finalize(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh_ma
 	else { c_count = iters; if (c_count > 0) --c_count; }
 	const uint32_t offset = rd.ev_off[r];
 	const float scale = (offset == 0) ? 0.0f : (o.sample_per_base == 0) ? 0.0f : ((float)(c_count + 1) * (float)l_chunk / (float)offset) / o.sample_per_base;
+	if (scale_out) *scale_out = scale;
 	const int32_t n_cregs = rd.ls_ncregs[r];
 	if (!mapped && n_cregs > 0 && rd.ls_mapq[r] > o.min_mapq) mapped = 1;   // last-chance rule, rmap.cpp:515
 	rh_map_record_t q;
@@ -908,7 +1111,60 @@ __global__ void k_finalize(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh_ma
 		q.fragment_length = (uint32_t)(re - rs + 1);
 		q.mapq = (uint8_t)rd.ls_mapq[r]; q.rev = rev == 1; q.mapped = 1;
 	}
-	rec[r] = q;
+	return q;
+}
+
+// One thread per read.
+__global__ void k_finalize(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh_map_record_t *rec)
+{
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= rd.n_reads) return;
+	rec[r] = finalize_one(o, ix, rd, r);
+}
+
+// All-vs-all: a read has as many records as chains it reports (regions_commit_ava left them, two words each, in the dense
+// carry buffer), or one.  rec_off = exclusive scan of the record counts (one block), then one thread per read writes them.
+__global__ __launch_bounds__(1024) void k_ava_rec_scan(rh_dev_reads rd, uint64_t *rec_off)
+{
+	__shared__ uint64_t s_part[1024];
+	const uint32_t tid = threadIdx.x, nt = blockDim.x, n = rd.n_reads;
+	const uint32_t per = (n + nt - 1) / nt, b = tid * per, e = b + per < n ? b + per : n;
+	uint64_t s = 0;
+	for (uint32_t i = b; i < e; ++i) { const uint32_t m = rd.n_prev[i] / 2; s += m ? m : 1u; }
+	s_part[tid] = s;
+	__syncthreads();
+	if (tid == 0) { uint64_t run = 0; for (uint32_t i = 0; i < nt; ++i) { const uint64_t v = s_part[i]; s_part[i] = run; run += v; } rec_off[n] = run; }
+	__syncthreads();
+	uint64_t run = s_part[tid];
+	for (uint32_t i = b; i < e; ++i) { rec_off[i] = run; const uint32_t m = rd.n_prev[i] / 2; run += m ? m : 1u; }
+}
+
+__global__ void k_finalize_ava(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, const rh_mm128_t *maps, const uint64_t *rec_off, rh_map_record_t *rec)
+{
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= rd.n_reads) return;
+	const uint32_t nm = rd.n_prev[r] / 2;
+	float scale;
+	rh_map_record_t q = finalize_one(o, ix, rd, r, &scale);       // ci / sl / nc are the same for all
+	if (nm == 0) { rec[rec_off[r]] = q; return; }
+	const rh_mm128_t *mp = maps + rd.prev_off[r];
+	const uint32_t offset = rd.ev_off[r];
+	for (uint32_t m = 0; m < nm; ++m) {
+		const rh_mm128_t w0 = mp[2 * m], w1 = mp[2 * m + 1];
+		const int32_t rid = (int32_t)(uint32_t)w0.x, rs = (int32_t)(w0.x >> 32), re = (int32_t)(uint32_t)w0.y, qs = (int32_t)(w0.y >> 32);
+		const int32_t qe = (int32_t)(uint32_t)w1.x, score = (int32_t)(w1.x >> 32), cnt = (int32_t)(uint32_t)w1.y;
+		const uint32_t mapq = (uint32_t)(w1.y >> 32) & 0xFFu, rev = (uint32_t)(w1.y >> 40) & 1u;
+		q.tag_cm = cnt; q.tag_s1 = score;
+		q.read_length = o.sig_target ? offset : (uint32_t)(scale * (float)qe);   // (signal targets: event coordinates, rmap.cpp:574-578)
+		q.ref_id = (uint32_t)rid;
+		q.read_start_position = o.sig_target ? (uint32_t)qs : (uint32_t)(scale * (float)qs);
+		q.read_end_position = o.sig_target ? (uint32_t)qe : (uint32_t)(scale * (float)qe);
+		const uint32_t tlen = (uint32_t)rid < ix.n_seq ? ix.seq_len[rid] : 0u;
+		q.fragment_start_position = rev ? (uint32_t)(tlen + 1u - (uint32_t)re) : (uint32_t)rs;
+		q.fragment_length = (uint32_t)(re - rs + 1);
+		q.mapq = (uint8_t)mapq; q.rev = (uint8_t)rev; q.mapped = 1;
+		rec[rec_off[r] + m] = q;
+	}
 }
 
 // ------------------------------------------------------------------------------------------------ k_synth_reads
@@ -931,29 +1187,40 @@ void rhk_prefilter(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd) {
 void rhk_events_norm(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
 {
 	if (!r.n_act) return;
-	if (o.w1 > TS_WMAX || o.w2 > TS_WMAX) { RH_LAUNCH(k_events_norm<true>, r.n_act, NT, 0, s, o, rd, r); return; }
-	RH_LAUNCH(k_events_norm<false>, r.n_act, NT, 0, s, o, rd, r);
+	if (r.whole) RH_LAUNCH(k_events_norm_whole, r.n_act, NT, 0, s, o, rd, r);
+	else if (o.w1 > TS_WMAX || o.w2 > TS_WMAX) { RH_LAUNCH(k_events_norm<true>, r.n_act, NT, 0, s, o, rd, r); return; }
+	else RH_LAUNCH(k_events_norm<false>, r.n_act, NT, 0, s, o, rd, r);
 	const char *force = getenv("RH_TSTAT_CB");                      // tests: pin the chunks-per-block variant
 	const uint32_t cb = force ? (uint32_t)atoi(force) : r.n_act >= 64u * 768u ? 64u : r.n_act >= 16u * 768u ? 16u : 8u;
 	if (cb >= 64) RH_LAUNCH(k_events_tstat<64>, cdiv(r.n_act, 64), NT, 0, s, o, r);
 	else if (cb >= 16) RH_LAUNCH(k_events_tstat<16>, cdiv(r.n_act, 16), NT, 0, s, o, r);
 	else RH_LAUNCH(k_events_tstat<8>, cdiv(r.n_act, 8), NT, 0, s, o, r);
 }
-void rhk_events_peaks(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_peaks, cdiv(r.n_act, PK_CHUNKS), 64, 0, s, o, r); }
-void rhk_events_means(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_means, r.n_act, NT, 0, s, o, r); }
+void rhk_events_peaks(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r) { if (r.n_act) { if (r.whole) RH_LAUNCH(k_events_peaks<uint32_t>, cdiv(r.n_act, PK_CHUNKS), 64, 0, s, o, r); else RH_LAUNCH(k_events_peaks<uint16_t>, cdiv(r.n_act, PK_CHUNKS), 64, 0, s, o, r); } }
+void rhk_events_means(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r) { if (!r.n_act) return; if (r.whole) RH_LAUNCH(k_events_means_whole, r.n_act, NT, 0, s, o, r); else RH_LAUNCH(k_events_means, r.n_act, NT, 0, s, o, r); }
 void rhk_sketch(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) {
 	if (!r.n_act) return;
 	if (ix.sp.w > 0) RH_LAUNCH(k_sketch<true>, cdiv(r.n_act, 64), 64, 0, s, o, ix, rd, r);
 	else RH_LAUNCH(k_sketch<false>, cdiv(r.n_act, 64), 64, 0, s, o, ix, rd, r);
 }
-void rhk_probe(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_probe, r.n_act, NT, 0, s, o, ix, rd, r); }
+void rhk_probe(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r)
+{
+	if (!r.n_act) return;
+	RH_LAUNCH(k_probe, r.n_act, NT, 0, s, o, ix, rd, r);
+	if (o.flag & RH_M_ALL_CHAINS) RH_LAUNCH(k_ava_count, r.n_act, NT, 0, s, o, ix, rd, r);
+}
 void rhk_scan_anchors(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r) { RH_LAUNCH(k_scan_anchors, 1, 1024, 0, s, rd, r); }
-void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_expand, r.n_act, NT, 0, s, o, ix, rd, r); }
+void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (!r.n_act) return; if (o.flag & RH_M_ALL_CHAINS) RH_LAUNCH(k_expand_ava, r.n_act, NT, 0, s, o, ix, rd, r); else RH_LAUNCH(k_expand, r.n_act, NT, 0, s, o, ix, rd, r); }
 void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act_in, uint32_t n_in, uint32_t next_chunk, uint32_t *act_out, uint32_t *n_out)
 { RH_LAUNCH(k_compact_active, 1, 1024, 0, s, o, rd, act_in, n_in, next_chunk, act_out, n_out); }
 void rhk_rebase_offsets(hipStream_t s, const uint64_t *a_off, uint32_t n, uint64_t *out) { RH_LAUNCH(k_rebase_offsets, cdiv(n + 1, 256), 256, 0, s, a_off, n, out); }
 void rhk_carry_scan(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, uint64_t used, uint64_t *dst_off, uint64_t *total_out) { RH_LAUNCH(k_carry_scan, 1, 1024, 0, s, rd, act, n, used, dst_off, total_out); }
 void rhk_carry_copy(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, const rh_mm128_t *staging, const uint64_t *dst_off, rh_mm128_t *carry) { if (n) RH_LAUNCH(k_carry_copy, n, NT, 0, s, rd, act, n, staging, dst_off, carry); }
 void rhk_finalize(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, rh_map_record_t *rec) { if (rd.n_reads) RH_LAUNCH(k_finalize, cdiv(rd.n_reads, 256), 256, 0, s, o, ix, rd, rec); }
+void rhk_seed_scan(hipStream_t s, const rh_dev_round &r, uint64_t *off) { RH_LAUNCH(k_seed_scan, 1, 1024, 0, s, r, off); }
+void rhk_seed_pack(hipStream_t s, const rh_dev_round &r, const uint64_t *off, uint32_t *hash_out, uint64_t *pos_out) { if (r.n_act) RH_LAUNCH(k_seed_pack, r.n_act, NT, 0, s, r, off, hash_out, pos_out); }
+void rhk_ava_rec_scan(hipStream_t s, const rh_dev_reads &rd, uint64_t *rec_off) { RH_LAUNCH(k_ava_rec_scan, 1, 1024, 0, s, rd, rec_off); }
+void rhk_finalize_ava(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_mm128_t *maps, const uint64_t *rec_off, rh_map_record_t *rec)
+{ if (rd.n_reads) RH_LAUNCH(k_finalize_ava, cdiv(rd.n_reads, 256), 256, 0, s, o, ix, rd, maps, rec_off, rec); }
 void rhk_synth_reads(hipStream_t s, const rh_synth_cfg_t &c, const int32_t *level16, uint64_t first, uint32_t n, int16_t *samples, uint64_t *off, double *cal_off, float *cal_scale)
 { if (n) RH_LAUNCH(k_synth_reads, cdiv(n, 64), 64, 0, s, c, level16, first, n, samples, off, cal_off, cal_scale); }

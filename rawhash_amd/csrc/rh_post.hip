@@ -437,6 +437,28 @@ RH_DEV void regions_commit(const rh_dev_opt &o, const rh_dev_reads &rd, const rh
 	if (stop) { rd.done[r] = 1; rd.stop_chunk[r] = rr.chunk; }
 }
 
+// All-vs-all (RI_M_ALL_CHAINS, rmap.cpp:421-500): a read reports one chain with enough MAPQ, or else every chain whose score
+// reaches min_chaining_score2.  The reported chains leave as pairs of 16-byte words in the read's slot of the carry staging
+// (a whole-read round carries no anchors anywhere), so that the carry compaction gathers them densely for k_finalize_ava:
+//   x0 = rs << 32 | rid, y0 = qs << 32 | re, x1 = score << 32 | qe, y1 = rev << 40 | mapq << 32 | cnt
+RH_DEV void regions_commit_ava(const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &rr, uint32_t a, uint32_t r, int32_t n_regs, const rh_reg *rg)
+{
+	rh_mm128_t *out = rr.prev_out + rr.a_off[a];
+	uint32_t nm = 0;
+	const bool single = n_regs == 1 && (int32_t)rg[0].mapq >= o.min_mapq;
+	for (int32_t i = 0; i < n_regs; ++i) {
+		const rh_reg &q = rg[i];
+		if (!(single || q.score >= o.min_sc2)) continue;
+		rh_mm128_t w0, w1;
+		w0.x = (uint64_t)(uint32_t)q.rs << 32 | (uint32_t)q.rid; w0.y = (uint64_t)(uint32_t)q.qs << 32 | (uint32_t)q.re;
+		w1.x = (uint64_t)(uint32_t)q.score << 32 | (uint32_t)q.qe; w1.y = (uint64_t)(q.rev & 1u) << 40 | (uint64_t)(q.mapq & 0xFFu) << 32 | (uint32_t)q.cnt;
+		out[2 * nm] = w0; out[2 * nm + 1] = w1;
+		++nm;
+	}
+	rd.n_prev[r] = 2 * nm; rd.prev_off[r] = rr.a_off[a];
+	if (nm) { rd.done[r] = 1; rd.stop_chunk[r] = rr.chunk; }
+}
+
 #ifndef RG_CAP
 #define RG_CAP 512
 #endif
@@ -466,10 +488,10 @@ __global__ __launch_bounds__(64) void k_regions(rh_dev_opt o, rh_dev_reads rd, r
 	const uint32_t a = blockIdx.x, lane = threadIdx.x;
 	if (a >= rr.n_act) return;
 	const uint32_t r = rr.act[a];
-	if (rr.skip[a]) { if (lane == 0) rd.ls_ncregs[r] = 0; return; }   // chunk dropped: creg stays NULL (rmap.cpp:232-235, :419)
+	if (rr.skip[a]) { if (lane == 0) { rd.ls_ncregs[r] = 0; if (o.flag & RH_M_ALL_CHAINS) rd.n_prev[r] = 0; } return; }   // chunk dropped: creg stays NULL (rmap.cpp:232-235, :419)
 	const uint64_t base = rr.a_off[a];
 	const int32_t n_u = (int32_t)rr.n_u[a];
-	if (n_u == 0) { if (lane == 0) regions_commit(o, rd, rr, a, r, 0, nullptr, 0); return; }
+	if (n_u == 0) { if (lane == 0) { regions_commit(o, rd, rr, a, r, 0, nullptr, 0); if (o.flag & RH_M_ALL_CHAINS) rd.n_prev[r] = 0; } return; }
 	if (n_u > RG_CAP || n_u <= (int32_t)n_lo) return;             // others: k_regions_big
 	if (only_flagged && !rr.need_exact[a]) return;                // done by k_regions_wave
 	const rh_mm128_t *an = rr.anc + base;
@@ -488,7 +510,8 @@ __global__ __launch_bounds__(64) void k_regions(rh_dev_opt o, rh_dev_reads rd, r
 	if (lane == 0) {
 		int stop;
 		const int32_t n_regs = regions_core(o, n_u, L.u, L.ch, L.rg, L.z, L.cov, L.w, L.tmp, L.cw, rr.rep_len[a], rr.n_ev[a], rd.ev_off[r], logf_tab, &stop);
-		regions_commit(o, rd, rr, a, r, n_regs, &L.rg[0], stop);
+		regions_commit(o, rd, rr, a, r, n_regs, &L.rg[0], (o.flag & RH_M_ALL_CHAINS) ? 0 : stop);
+		if (o.flag & RH_M_ALL_CHAINS) regions_commit_ava(o, rd, rr, a, r, n_regs, L.rg);
 	}
 }
 
@@ -520,7 +543,8 @@ __global__ void k_regions_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, co
 	}
 	int stop;
 	const int32_t n_regs = regions_core(o, n_u, u, ch, rg, z, cov, w, tmp, cw, rr.rep_len[a], rr.n_ev[a], rd.ev_off[r], logf_tab, &stop);
-	regions_commit(o, rd, rr, a, r, n_regs, &rg[0], stop);
+	regions_commit(o, rd, rr, a, r, n_regs, &rg[0], (o.flag & RH_M_ALL_CHAINS) ? 0 : stop);
+	if (o.flag & RH_M_ALL_CHAINS) regions_commit_ava(o, rd, rr, a, r, n_regs, rg);
 }
 
 // ------------------------------------------------------------------------------------------------ regions, wave-cooperative
