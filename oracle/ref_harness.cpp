@@ -93,6 +93,7 @@ static void apply_overrides(ri_idxopt_t *ipt, ri_mapopt_t *opt)
 	if ((s = getenv("RH_MID_OCC"))) opt->mid_occ = atoi(s);
 	if ((s = getenv("RH_W"))) ipt->w = atoi(s);
 	if ((s = getenv("RH_E"))) ipt->e = atoi(s);
+	if ((s = getenv("RH_NO_ADAPTIVE")) && atoi(s)) opt->flag |= RI_M_NO_ADAPTIVE;   // --disable-adaptive (main.cpp:369)
 }
 
 static int set_presets(const char *preset, ri_idxopt_t *ipt, ri_mapopt_t *opt)

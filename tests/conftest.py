@@ -46,13 +46,16 @@ class Workload:
     """Synthetic reference + index + reads, generated from seeds by the product library's host code."""
 
     def __init__(self, directory, lib, preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=12_000, n_reads=48,
-                 junk=150, noise=150_000, read_seed=3, index_lib=None, build_index=True):
+                 junk=150, noise=150_000, read_seed=3, index_lib=None, build_index=True, no_adaptive=False):
         from rawhash_amd.api import SynthWorkload, MapOptions, Index
         self.dir, self.preset = str(directory), preset
         self.wl = SynthWorkload(chrom_len=chrom_len, n_chrom=n_chrom, n_samples=n_samples, junk_per_1024=junk, noise_q24=noise,
                                 read_seed=read_seed, lib=lib)
         self.fasta, self.model = self.wl.write_reference(self.dir)
         self.opts = MapOptions(preset, lib=lib)
+        self.no_adaptive = no_adaptive
+        if no_adaptive:
+            self.opts.mo.flag |= 0x20           # RH_M_NO_ADAPTIVE: one round over the whole read
         self.ind = os.path.join(self.dir, f"ref_{preset}.ind")
         self.index = None
         if build_index:     # (large references: the caller builds the index on the device instead)
@@ -64,6 +67,8 @@ class Workload:
         import oracle_lib as O
         oix = O.OracleIndex(self.ind)
         _, mo = O.preset(self.preset)
+        if self.no_adaptive:
+            mo.flag |= 0x20
         O.lib().ro_mapopt_update(C.byref(mo), oix.h)
         return oix, mo
 
@@ -73,6 +78,31 @@ class Workload:
         oix, mo = self.oracle()
         recs = O.map_batch(oix, mo, reads.batch(), n_threads=n_threads)
         return [O.strip_mt(x) for x in O.paf_lines(oix, recs, reads.names)]
+
+
+class AvaWorkload:
+    """Rawsamble input: synthetic reads that overlap each other (drawn from one short genome), to be indexed as signal targets
+    and overlapped all-vs-all."""
+
+    def __init__(self, directory, lib, preset="ava", chrom_len=20_000, n_samples=27_000, n_reads=60, junk=50, noise=150_000, read_seed=21):
+        from rawhash_amd.api import SynthWorkload, MapOptions
+        self.dir, self.preset = str(directory), preset
+        self.wl = SynthWorkload(chrom_len=chrom_len, n_chrom=1, n_samples=n_samples, junk_per_1024=junk, noise_q24=noise, read_seed=read_seed, lib=lib)
+        self.fasta, self.model = self.wl.write_reference(self.dir)
+        self.opts = MapOptions(preset, lib=lib)
+        self.reads = self.wl.reads(self.model, 0, n_reads)
+        cfg = self.wl.cfg
+        self.rhr = os.path.join(self.dir, "reads.rhr")
+        self.reads.write(self.rhr, cfg.digitisation, cfg.range, cfg.offset, lib=lib)
+
+    def oracle_paf(self, ind_path, n_threads=4):
+        """The oracle on an index file (signal-target indexes are built by the device path or by the reference)."""
+        import oracle_lib as O
+        oix = O.OracleIndex(ind_path)
+        _, mo = O.preset(self.preset)
+        O.lib().ro_mapopt_update(C.byref(mo), oix.h)
+        recs = O.map_batch(oix, mo, self.reads.batch(), names=self.reads.names, n_threads=n_threads, max_rec_per_read=256)
+        return [O.strip_mt(x) for x in O.paf_lines(oix, recs, self.reads.names)]
 
 
 @pytest.fixture(scope="session")

@@ -12,9 +12,19 @@ def cases():
         return json.load(f)
 
 
+def ava_cases():
+    with open(os.path.join(GOLD, "ava_cases.json")) as f:
+        return json.load(f)
+
+
+def build_ava_case(case, directory, lib):
+    from conftest import AvaWorkload
+    return AvaWorkload(directory, lib, **case["workload"])
+
+
 def build_case(case, directory, lib):
     from conftest import Workload
-    return Workload(directory, lib, **case["workload"], build_index=not case.get("gpu_only"))
+    return Workload(directory, lib, **case["workload"], build_index=not case.get("gpu_only"), no_adaptive=bool(case.get("no_adaptive")))
 
 
 def expected_paf(case):

@@ -26,7 +26,16 @@ CASES = [
     {"name": "config1_ecoli_4p6M_1k", "workload": dict(preset="sensitive", chrom_len=4_600_000, n_chrom=1, n_samples=40_000, n_reads=1000, junk=102, noise=0, read_seed=3)},
     # BASELINE.json configs[2] at its index size (144 Mbp in 6 targets): a sample of its read set; the index is too large for the
     # CPU suite, so only the -m gpu tests (index built on the device) check this one
+    # whole-read rounds on a sequence index: `--disable-adaptive` (RI_M_NO_ADAPTIVE, main.cpp:369)
+    {"name": "small_sensitive_whole_reads", "no_adaptive": True, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=96, junk=150, noise=150_000, read_seed=16)},
     {"name": "config3_dmel_144M_384", "gpu_only": True, "workload": dict(preset="sensitive", chrom_len=24_000_000, n_chrom=6, n_samples=40_000, n_reads=384, junk=102, noise=0, read_seed=3)},
+]
+
+
+AVA_CASES = [
+    # BASELINE.json configs[4] in the small: reads of 3000 bases (27 k samples) drawn from a short genome so that they overlap
+    {"name": "ava_small", "workload": dict(preset="ava", chrom_len=20_000, n_samples=27_000, n_reads=60, junk=50, noise=150_000, read_seed=21)},
+    {"name": "ava_sensitive_small", "workload": dict(preset="ava-sensitive", chrom_len=20_000, n_samples=27_000, n_reads=48, junk=50, noise=150_000, read_seed=22)},
 ]
 
 
@@ -38,14 +47,15 @@ def main():
     assert O.have_reference(), "build oracle/_ref first (make -C oracle ref)"
     for case in CASES:
         with tempfile.TemporaryDirectory() as d:
-            w = Workload(d, lib, **case["workload"], build_index=not case.get("gpu_only"))
+            w = Workload(d, lib, **case["workload"], build_index=not case.get("gpu_only"), no_adaptive=bool(case.get("no_adaptive")))
             cfg = w.wl.cfg
             rhr = os.path.join(d, "reads.rhr")
             w.reads.write(rhr, cfg.digitisation, cfg.range, cfg.offset)
             preset = case["workload"]["preset"]
             ref_ind = os.path.join(d, "refbuilt.ind")
             subprocess.run([O.REF_HARNESS, "index", preset, w.fasta, w.model, ref_ind, "4"], check=True, stderr=subprocess.DEVNULL)
-            out = subprocess.run([O.REF_HARNESS, "map", preset, ref_ind, rhr, "1"], check=True, capture_output=True, text=True).stdout
+            env = dict(os.environ, RH_NO_ADAPTIVE="1") if case.get("no_adaptive") else None
+            out = subprocess.run([O.REF_HARNESS, "map", preset, ref_ind, rhr, "1"], check=True, capture_output=True, text=True, env=env).stdout
             lines = [O.strip_mt(l) for l in out.splitlines()]
             assert len(lines) == len(w.reads)
             with open(os.path.join(HERE, case["name"] + ".paf"), "w") as f:
@@ -53,6 +63,23 @@ def main():
             print(case["name"], len(lines), "lines,", sum(1 for l in lines if l.split("\t")[4] != "*"), "mapped")
     with open(os.path.join(HERE, "cases.json"), "w") as f:
         json.dump(CASES, f, indent=1)
+    # Rawsamble (all-vs-all overlapping): `ref_harness sigindex` builds the signal-target index from the reads with the
+    # reference's own functions, `ref_harness map` overlaps the same reads against it
+    import hashlib
+    from conftest import AvaWorkload
+    for case in AVA_CASES:
+        with tempfile.TemporaryDirectory() as d:
+            w = AvaWorkload(d, lib, **case["workload"])
+            ref_ind = os.path.join(d, "ref.ind")
+            subprocess.run([O.REF_HARNESS, "sigindex", w.preset, w.rhr, w.model, ref_ind, "4"], check=True, stderr=subprocess.DEVNULL)
+            out = subprocess.run([O.REF_HARNESS, "map", w.preset, ref_ind, w.rhr, "1"], check=True, capture_output=True, text=True).stdout
+            lines = [O.strip_mt(l) for l in out.splitlines()]
+            with open(os.path.join(HERE, case["name"] + ".paf"), "w") as f:
+                f.write("\n".join(lines) + "\n")
+            case["ind_sha256"] = hashlib.sha256(O.mask_ind(open(ref_ind, "rb").read())).hexdigest()
+            print(case["name"], len(lines), "lines,", sum(1 for l in lines if l.split("\t")[4] != "*"), "overlaps,", len(w.reads), "reads")
+    with open(os.path.join(HERE, "ava_cases.json"), "w") as f:
+        json.dump(AVA_CASES, f, indent=1)
 
 
 if __name__ == "__main__":

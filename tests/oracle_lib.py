@@ -121,6 +121,14 @@ def paf_lines(ix, recs, names, mt_ms=0.0):
     return lines
 
 
+def mask_ind(data):
+    """.ind bytes with the 16 bytes of heap pointers the reference leaks into the header (raw fwrite of ri_pore_t,
+    rindex.c:557, file offset 46..61) zeroed."""
+    b = bytearray(data)
+    b[46:62] = bytes(16)
+    return bytes(b)
+
+
 def strip_mt(line):
     """Drop the wall-clock mt:f: tag (excluded from parity)."""
     return "\t".join(f for f in line.rstrip("\n").split("\t") if not f.startswith("mt:f:"))

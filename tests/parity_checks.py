@@ -2,6 +2,8 @@
 of the same sources (CPU tests).  The checker is always the CPU oracle (oracle/rh_oracle.c)."""
 import ctypes as C
 
+import os
+
 import numpy as np
 
 import oracle_lib as O
@@ -364,3 +366,32 @@ def check_e2e(ctx, wl, reads=None):
     bad = [(g, w) for g, w in zip(got, want) if g != w]
     assert not bad, f"{len(bad)} PAF lines differ, first: {bad[0]}"
     return recs
+
+
+def check_ava(lib, case, directory, oracle_threads=4):
+    """Rawsamble on the device path of `lib`: the signal-target index built from the reads must be the reference's .ind byte
+    for byte (golden hash of the file `ref_harness sigindex` wrote), the oracle on that file and the device's all-vs-all
+    mapping must both print the reference's PAF (golden)."""
+    import hashlib
+    import golden
+    import oracle_lib as O
+    from rawhash_amd.api import Context, Index, paf_lines
+    w = golden.build_ava_case(case, directory, lib)
+    c = Context(0, lib=lib)
+    try:
+        ix = Index.build_signals_device(c, w.reads, w.model, w.opts)
+        ix.download(c)
+        ind = os.path.join(str(directory), "device_built.ind")
+        ix.write(ind)
+        assert hashlib.sha256(O.mask_ind(open(ind, "rb").read())).hexdigest() == case["ind_sha256"], "signal-target .ind differs from the reference's"
+        want = golden.expected_paf(case)
+        assert w.oracle_paf(ind, n_threads=oracle_threads) == want, "oracle (all-vs-all) differs from the reference's PAF"
+        w.opts.update(ix)
+        recs, off = c.map_batch_multi(w.opts, w.reads, ix)
+        got = [O.strip_mt(x) for x in paf_lines(ix, recs, w.reads.names, lib=lib)]
+        bad = [(g, x) for g, x in zip(got, want) if g != x]
+        assert len(got) == len(want) and not bad, f"{case['name']}: {len(bad)} PAF lines differ, first: {bad[:1]}"
+        assert int(off[-1]) == len(recs) and all(int(r["read_idx"]) == i for i in range(len(w.reads)) for r in recs[int(off[i]):int(off[i + 1])])
+        return len(recs)
+    finally:
+        c.close()

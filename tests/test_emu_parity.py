@@ -80,3 +80,26 @@ def test_oversized_read_fallbacks(make_workload, emu_lib_smallcaps):
     pc.check_sort(c, seed=4, n_seg=20, big=(1025, 2000, 3500, 4096, 1600, 2049))
     pc.check_chain_synthetic(c, w, seed=5, n_reads=40, max_n=500)
     c.close()
+
+
+def test_whole_read_rounds_golden(emu_lib, tmp_path):
+    """RI_M_NO_ADAPTIVE (`--disable-adaptive`): one round over the whole read, rows in HBM, against the reference's PAF."""
+    import golden
+    from rawhash_amd.api import paf_lines
+    import oracle_lib as O
+    case = [c for c in golden.cases() if c.get("no_adaptive")][0]
+    w = golden.build_case(case, tmp_path, emu_lib)
+    c = Context(0, lib=emu_lib)
+    c.upload(w.index)
+    sub = w.reads.subset(range(40))
+    recs = c.map_batch(w.opts, sub)
+    got = [O.strip_mt(x) for x in paf_lines(w.index, recs, sub.names, lib=emu_lib)]
+    assert got == golden.expected_paf(case)[:40]
+    c.close()
+
+
+def test_rawsamble_all_vs_all_golden(emu_lib, tmp_path):
+    """Signal-target index built by the device kernels = the reference's .ind; all-vs-all overlaps = the reference's PAF."""
+    import golden
+    case = golden.ava_cases()[0]
+    assert pc.check_ava(emu_lib, case, tmp_path) > len(golden.expected_paf(case)) // 2

@@ -1,4 +1,6 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle on a real MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -315,3 +317,46 @@ def test_batch_sliced_when_arenas_do_not_fit(make_workload, product_lib, monkeyp
     again = [strip_mt(x) for x in paf_lines(w.index, c.map_batch(w.opts, w.reads), w.reads.names)]   # second call starts from the remembered slice size
     c.close()
     assert sliced == whole and again == whole and len(whole) == 48
+
+
+def test_rawsamble_all_vs_all_golden(product_lib, tmp_path):
+    """BASELINE.json configs[4] (Rawsamble) in the small: signal-target index built on the GPU = the reference's .ind byte for
+    byte, all-vs-all overlaps = the reference's PAF (both presets of tests/golden/ava_cases.json)."""
+    import golden
+    import parity_checks as pc
+    for case in golden.ava_cases():
+        pc.check_ava(product_lib, case, tmp_path / case["name"], oracle_threads=os.cpu_count() or 8)
+
+
+def test_rawsamble_scale_vs_oracle(product_lib, tmp_path):
+    """All-vs-all at depth: 3000 reads of 3000 bases over a 300 kbp genome (30x), index built on the GPU, every overlap
+    record against the oracle (which loads the .ind the GPU wrote)."""
+    from conftest import AvaWorkload
+    from rawhash_amd.api import Index
+    w = AvaWorkload(tmp_path, product_lib, preset="ava", chrom_len=300_000, n_samples=27_000, n_reads=3000, junk=50, noise=150_000, read_seed=23)
+    c = Context(0, lib=product_lib)
+    ix = Index.build_signals_device(c, w.reads, w.model, w.opts)
+    ix.download(c)
+    ind = str(tmp_path / "dev.ind")
+    ix.write(ind)
+    w.opts.update(ix)
+    recs, off = c.map_batch_multi(w.opts, w.reads, ix, max_records=400 * len(w.reads))
+    got = [strip_mt(x) for x in paf_lines(ix, recs, w.reads.names)]
+    want = w.oracle_paf(ind, n_threads=os.cpu_count() or 8)
+    bad = [(g, x) for g, x in zip(got, want) if g != x]
+    assert len(got) == len(want) and not bad, f"{len(bad)} of {len(want)} PAF lines differ, first: {bad[:1]}"
+    assert len(got) > len(w.reads)                                # (reads with several overlaps)
+    c.close()
+
+
+def test_whole_read_rounds_golden(product_lib, tmp_path):
+    """RI_M_NO_ADAPTIVE on a sequence index (`--disable-adaptive`): the reference's PAF."""
+    import golden
+    case = [c for c in golden.cases() if c.get("no_adaptive")][0]
+    w = golden.build_case(case, tmp_path, product_lib)
+    c = Context(0, lib=product_lib)
+    c.upload(w.index)
+    recs = c.map_batch(w.opts, w.reads)
+    got = [strip_mt(x) for x in paf_lines(w.index, recs, w.reads.names)]
+    assert got == golden.expected_paf(case)
+    c.close()
