@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="human", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="human", choices=sorted(WORKLOADS) + ["ava"])
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the workload's default)")
     ap.add_argument("--samples", type=int, default=40_000)
     ap.add_argument("--junk", type=int, default=102, help="unmappable reads per 1024")
@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--no-h2d", dest="h2d", action="store_false", help="skip the PCIe-inclusive measurement (batches in pinned host memory)")
     ap.add_argument("--cpu-threads", default="", help="thread counts of the CPU sweep, comma separated (default: cores/8 .. cores)")
     args = ap.parse_args()
+    if args.workload == "ava":
+        return bench_ava(args)
     chrom_len, n_chrom, preset, d_reads, d_sample, wl_name = WORKLOADS[args.workload]
     if args.reads <= 0:
         args.reads = d_reads
@@ -244,6 +246,100 @@ def main():
     if rank == 0:
         import shutil
         shutil.rmtree(workdir, ignore_errors=True)
+
+
+def bench_ava(args):
+    """BASELINE.json configs[4], a secondary line (`--workload ava`): Rawsamble all-vs-all overlapping of 50 k synthetic reads
+    of 3000 bases (27 k samples) drawn from a 1 Mbp genome (~150x).  A step = every read overlapped against the signal-target
+    index of all of them (one whole-read round, every reported chain a record); the index is built on the device from the same
+    reads before the timed region (its time is reported).  One GPU: queries shard like reads of the headline path, the
+    index build does not (it is a second or so)."""
+    import numpy as np
+    import oracle_lib as O
+    from rawhash_amd import Context, Index, MapOptions, SynthWorkload, paf_lines, strip_mt
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        sys.exit("bench.py --workload ava runs on one GPU")
+    n = args.reads if args.reads > 0 else 50_000
+    n_samples, genome, preset = 27_000, 1_000_000, "ava"
+    cores = os.cpu_count() or 8
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    workdir = os.path.join(shm, f"rawhash_amd_bench_ava_{os.getpid()}")
+    os.makedirs(workdir, exist_ok=True)
+    wl = SynthWorkload(chrom_len=genome, n_chrom=1, n_samples=n_samples, junk_per_1024=50, noise_q24=150_000, read_seed=23)
+    _, model = wl.write_reference(workdir)
+    opts = MapOptions(preset)
+    reads = wl.reads(model, 0, n, n_threads=min(cores, 64), with_names=True)
+    ctx = Context(0)
+    t0 = time.perf_counter()
+    index = Index.build_signals_device(ctx, reads, model, opts)
+    t_index = time.perf_counter() - t0
+    opts.update(index)
+    cap = 400 * n + 1024
+    for _ in range(args.warmup):
+        recs, off = ctx.map_batch_multi(opts, reads, index, max_records=cap)
+    stage_ms, stage_n, acc = {}, {}, {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        recs, off = ctx.map_batch_multi(opts, reads, index, max_records=cap)   # host batch: the upload of the int16 signal is inside the step
+        st = ctx.stats()
+        for k, v in st.items():
+            if k not in ("stages", "ms_total"):
+                acc[k] = acc.get(k, 0) + v
+        for k, (ms, c) in st["stages"].items():
+            stage_ms[k] = stage_ms.get(k, 0.0) + ms
+            stage_n[k] = stage_n.get(k, 0) + c
+    elapsed = time.perf_counter() - t0
+    kernels = {k: v for k, v in stage_ms.items() if k in ALGO_BYTES and stage_n.get(k)}
+    dom = max(kernels, key=kernels.get)
+    dom_bytes = ALGO_BYTES[dom](acc)
+    achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
+    out = {
+        "metric": "reads/sec overlapped all-vs-all (Rawsamble, signal-target index resident in HBM)", "value": round(n * args.steps / elapsed, 1), "unit": "reads/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int16 signal; fp32/fp64 events; u64/i32 seeding+chaining", "data": "synthetic",
+        "config": {"workload": f"Rawsamble all-vs-all: {n} synthetic R9.4 reads x {n_samples} samples from a {genome} bp genome, preset {preset}, signal-target index built "
+                               f"on the device from the same reads ({index.n_keys} keys, {index.n_positions} positions), int16 signal uploaded from host memory in every step",
+                   "reads_per_gpu": n, "samples_per_read": n_samples, "mid_occ": int(opts.mo.mid_occ)},
+        "records_per_step": int(len(recs)), "overlaps_per_read": round(float((recs["mapped"] != 0).sum()) / n, 2),
+        "index_build_s": round(t_index, 3), "value_with_index_build": round(n / (elapsed / args.steps + t_index), 1),
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                     "avg_launch_ms": round(stage_ms[dom] / stage_n[dom], 4), "launches": stage_n[dom], "algorithmic_bytes_per_launch": int(dom_bytes / stage_n[dom])},
+        "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items() if stage_n.get(k)},
+    }
+    sample = args.cpu_sample if args.cpu_sample >= 0 else 20000
+    if sample > 0 and O.have_reference():
+        # the unmodified reference: its functions build the signal-target index of all reads (`ref_harness sigindex`), then its
+        # kt_for(map_worker_for) overlaps the first `sample` reads against it; PAF of that sample compared with the device's
+        try:
+            sample = min(sample, n)
+            rhr_all, rhr_s, ind = os.path.join(workdir, "all.rhr"), os.path.join(workdir, "sample.rhr"), os.path.join(workdir, "ref.ind")
+            reads.write(rhr_all, wl.cfg.digitisation, wl.cfg.range, wl.cfg.offset)
+            reads.subset(range(sample)).write(rhr_s, wl.cfg.digitisation, wl.cfg.range, wl.cfg.offset)
+            t0 = time.perf_counter()
+            subprocess.run([O.REF_HARNESS, "sigindex", preset, rhr_all, model, ind, str(min(cores, 64))], check=True, stderr=subprocess.DEVNULL, timeout=3000)
+            t_ref_index = time.perf_counter() - t0
+            sweep = [int(x) for x in args.cpu_threads.split(",")] if args.cpu_threads else sorted({max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores})
+            paf = os.path.join(workdir, "ref.paf")
+            with open(paf, "w") as fo:
+                p = subprocess.run([O.REF_HARNESS, "map", preset, ind, rhr_s, ",".join(str(t) for t in sweep)], stdout=fo, stderr=subprocess.PIPE, text=True, timeout=3000)
+            runs = [(int(t), float(sec)) for sec, t in re.findall(r"map phase ([0-9.]+) s, threads (\d+)", p.stderr)]
+            with open(paf) as f:
+                want = [O.strip_mt(x) for x in f]
+            got = [strip_mt(x) for x in paf_lines(index, recs[: int(off[sample])], reads.names)]
+            best_t, best_s = min(runs, key=lambda r: r[1])
+            out["cpu_baseline"] = {"value": round(sample / best_s, 1), "unit": "reads/s", "cores": cores, "threads": best_t, "kind": "reference",
+                                   "sample": f"first {sample} reads overlapped against the index of all {n}, map phase {best_s:.2f} s, unmodified RawHash2 sources (oracle/Makefile)",
+                                   "thread_sweep_reads_per_s": {str(t): round(sample / sec, 1) for t, sec in runs},
+                                   "reference_index_build_s": round(t_ref_index, 2)}
+            out["paf_sample_identical"] = got == want
+            if got != want:
+                out["cpu_baseline"]["paf_lines_differing"] = sum(1 for a, b in zip(got, want) if a != b) + abs(len(got) - len(want))
+        except Exception as e:
+            out["cpu_baseline_error"] = repr(e)[:300]
+    print(json.dumps(out), flush=True)
+    ctx.close()
+    import shutil
+    shutil.rmtree(workdir, ignore_errors=True)
 
 
 def host_copy(ctx, batch, args):
