@@ -84,13 +84,23 @@ class AvaWorkload:
     """Rawsamble input: synthetic reads that overlap each other (drawn from one short genome), to be indexed as signal targets
     and overlapped all-vs-all."""
 
-    def __init__(self, directory, lib, preset="ava", chrom_len=20_000, n_samples=27_000, n_reads=60, junk=50, noise=150_000, read_seed=21):
+    def __init__(self, directory, lib, preset="ava", chrom_len=20_000, n_samples=27_000, n_reads=60, junk=50, noise=150_000, read_seed=21, ragged=False):
         from rawhash_amd.api import SynthWorkload, MapOptions
         self.dir, self.preset = str(directory), preset
         self.wl = SynthWorkload(chrom_len=chrom_len, n_chrom=1, n_samples=n_samples, junk_per_1024=junk, noise_q24=noise, read_seed=read_seed, lib=lib)
         self.fasta, self.model = self.wl.write_reference(self.dir)
         self.opts = MapOptions(preset, lib=lib)
         self.reads = self.wl.reads(self.model, 0, n_reads)
+        if ragged:      # reads of very different lengths, an empty one and two too short to give min_events events
+            from rawhash_amd.api import Reads
+            r = self.reads
+            lens = [int(n_samples * (0.15 + 0.85 * ((i * 37) % 100) / 99.0)) for i in range(n_reads)]
+            if n_reads > 7:
+                lens[3], lens[5], lens[7] = 0, 90, 300
+            parts = [r.samples[int(r.offsets[i]):int(r.offsets[i]) + lens[i]] for i in range(n_reads)]
+            off = np.zeros(n_reads + 1, dtype=np.uint64)
+            off[1:] = np.cumsum(lens)
+            self.reads = Reads(np.concatenate(parts), off, r.names, r.cal_offset, r.cal_scale)
         cfg = self.wl.cfg
         self.rhr = os.path.join(self.dir, "reads.rhr")
         self.reads.write(self.rhr, cfg.digitisation, cfg.range, cfg.offset, lib=lib)

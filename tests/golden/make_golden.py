@@ -35,6 +35,7 @@ CASES = [
 AVA_CASES = [
     # BASELINE.json configs[4] in the small: reads of 3000 bases (27 k samples) drawn from a short genome so that they overlap
     {"name": "ava_small", "workload": dict(preset="ava", chrom_len=20_000, n_samples=27_000, n_reads=60, junk=50, noise=150_000, read_seed=21)},
+    {"name": "ava_ragged", "workload": dict(preset="ava", chrom_len=15_000, n_samples=27_000, n_reads=64, junk=50, noise=150_000, read_seed=24, ragged=True)},
     {"name": "ava_sensitive_small", "workload": dict(preset="ava-sensitive", chrom_len=20_000, n_samples=27_000, n_reads=48, junk=50, noise=150_000, read_seed=22)},
 ]
 

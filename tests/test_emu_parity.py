@@ -103,3 +103,11 @@ def test_rawsamble_all_vs_all_golden(emu_lib, tmp_path):
     import golden
     case = golden.ava_cases()[0]
     assert pc.check_ava(emu_lib, case, tmp_path) > len(golden.expected_paf(case)) // 2
+
+
+def test_rawsamble_ragged_reads_golden(emu_lib, tmp_path):
+    """The same with reads of very different lengths (row strides set by the longest), an empty read and reads too short for
+    min_events."""
+    import golden
+    case = [c for c in golden.ava_cases() if c["name"] == "ava_ragged"][0]
+    pc.check_ava(emu_lib, case, tmp_path)

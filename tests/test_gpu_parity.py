@@ -349,6 +349,27 @@ def test_rawsamble_scale_vs_oracle(product_lib, tmp_path):
     c.close()
 
 
+def test_rawsamble_long_reads_vs_oracle(product_lib, tmp_path):
+    """Whole-read rounds far beyond a chunk: 600 k-sample reads (66 k bases, ~62 k events each; the prefilter's tile counts no
+    longer fit LDS, the seeds of a read take 30 probe tiles), ragged, all-vs-all against the oracle."""
+    from conftest import AvaWorkload
+    from rawhash_amd.api import Index
+    w = AvaWorkload(tmp_path, product_lib, preset="ava", chrom_len=200_000, n_samples=600_000, n_reads=40, junk=50, noise=150_000, read_seed=25, ragged=True)
+    c = Context(0, lib=product_lib)
+    ix = Index.build_signals_device(c, w.reads, w.model, w.opts)
+    ix.download(c)
+    ind = str(tmp_path / "dev.ind")
+    ix.write(ind)
+    w.opts.update(ix)
+    recs, off = c.map_batch_multi(w.opts, w.reads, ix)
+    got = [strip_mt(x) for x in paf_lines(ix, recs, w.reads.names)]
+    want = w.oracle_paf(ind, n_threads=os.cpu_count() or 8)
+    bad = [(g, x) for g, x in zip(got, want) if g != x]
+    assert len(got) == len(want) and not bad, f"{len(bad)} of {len(want)} PAF lines differ, first: {bad[:1]}"
+    assert sum(1 for x in got if x.split("\t")[4] != "*") > 10
+    c.close()
+
+
 def test_whole_read_rounds_golden(product_lib, tmp_path):
     """RI_M_NO_ADAPTIVE on a sequence index (`--disable-adaptive`): the reference's PAF."""
     import golden
