@@ -362,6 +362,14 @@ __global__ __launch_bounds__(NT) void k_bs_holes(bs_ctx C)
                                             // wavefront per range wins - its window refills are coalesced and rare, the lanes' are one cache line per region)
 #endif
 #define BS_LSTEPS 8
+#ifndef BS_MULTI_MIN_RANGES
+#define BS_MULTI_MIN_RANGES 4096            // ranges of a level from which several walks share a wavefront (fewer: a wavefront each, the level is bound by one walk's latency)
+#endif
+#ifndef BS_MW_G16_FROM
+#define BS_MW_G16_FROM 8192                 // more ranges than this: 16 walks per wavefront, ...
+#define BS_MW_G32_FROM 16384                // ... 32
+#endif
+#define BS_MW_NHM 24                        // ... for ranges with up to this many regions that have holes (targets x strands of a large index)
 
 template <int NHM, int L>
 __global__ __launch_bounds__(64) void k_bs_walk_lanes(bs_ctx C, uint32_t nh_lo)
@@ -451,7 +459,7 @@ __global__ __launch_bounds__(64) void k_bs_walk_lanes(bs_ctx C, uint32_t nh_lo)
 #define BS_INVALID (1u << 31)
 struct bs_walk_state { uint32_t k, i0, i, d, inchase, done; };
 
-__global__ __launch_bounds__(64) void k_bs_walk_wave(bs_ctx C, int all)
+__global__ __launch_bounds__(64) void k_bs_walk_wave(bs_ctx C, uint32_t skip_lo, uint32_t skip_hi)   // ranges with skip_lo <= regions with holes <= skip_hi are another kernel's
 {
 	__shared__ uint8_t s_win[BS_WIN_BYTES];
 	__shared__ uint64_t s_head[256];                               // ptr | (digit | invalid << 31) << 32, by dense region
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(64) void k_bs_walk_wave(bs_ctx C, int all)
 	const bs_range R = C.rng[0][r];
 	bs_meta &M = C.meta[r];
 	const uint32_t nh = M.nh;
-	if (nh == 0 || (!all && nh >= 3)) return;
+	if (nh == 0 || (nh >= skip_lo && nh <= skip_hi)) return;
 	for (uint32_t q = lane; q < nh; q += 64) { const uint32_t dk = M.act[q]; s_h0[q] = M.hst[dk]; s_end[q] = M.hst[dk + 1u]; }
 	__syncthreads();
 	const uint8_t *hd = C.hd + R.beg;
@@ -535,6 +543,128 @@ __global__ __launch_bounds__(64) void k_bs_walk_wave(bs_ctx C, int all)
 		__syncthreads();
 		if (S.done) break;
 	}
+}
+
+// k_bs_walk_multi<NHM, G>: G ranges per wavefront (ranges with 3 .. NHM regions that have holes) - lanes 0 .. G-1 walk, one
+// range each, one pop per iteration; the walk is bound by instruction issue (a wavefront pays for 64 lanes whatever is active),
+// and here G walks share every instruction.  The hole-digit streams come through a 64-byte LDS ring per (walker, region),
+// indexed by the hole's absolute address so that a refill is one aligned 16-byte load + one 16-byte LDS store; the refills are
+// all lanes' work (pair p = walker * NHM + region belongs to lane p & 63) and are software pipelined: every BS_MW_PERIOD
+// iterations the loads for the stretch after next are issued, and committed one period later, so that HBM latency is never
+// waited for.  A walker that does run into the end of its ring (flagged in the head) idles until the next commit.
+#ifndef BS_MW_PERIOD
+#define BS_MW_PERIOD 32
+#endif
+#define BS_MW_RING 64
+template <int NHM, int G>
+__global__ __launch_bounds__(64) void k_bs_walk_multi(bs_ctx C)
+{
+	static_assert((NHM * G) % 64 == 0, "whole rows of (walker, region) pairs");
+	constexpr int NP = NHM * G / 64;                              // pairs per lane: p = lane + 64 t
+	__shared__ __attribute__((aligned(16))) uint8_t s_win[G * NHM * BS_MW_RING];
+	__shared__ uint64_t s_head[G * NHM];                           // hole index | (digit | invalid << 31) << 32
+	__shared__ uint32_t s_lim[G * NHM], s_end[G * NHM];            // committed up to (absolute, multiple of 16) / end of the region's holes (hole index)
+	__shared__ uint32_t s_nh[G], s_beg[G];
+	const uint32_t lane = threadIdx.x, n_rng = C.hdr[0], r0 = blockIdx.x * G;
+	if (lane < (uint32_t)G) {
+		uint32_t nh = 0, beg = 0;
+		if (r0 + lane < n_rng) { nh = C.meta[r0 + lane].nh; beg = C.rng[0][r0 + lane].beg; if (nh < 3 || nh > (uint32_t)NHM) nh = 0; }
+		s_nh[lane] = nh; s_beg[lane] = beg;
+	}
+	__syncthreads();
+	{ bool any = false; for (int g = 0; g < G; ++g) any |= s_nh[g] != 0; if (!any) return; }
+	// this lane's pairs (registers: every loop over t below is fully unrolled)
+	bool p_on[NP];
+	uint32_t p_end[NP], p_abs0[NP], ld_n[NP];
+	uint4 la[NP], lb[NP];
+#pragma unroll
+	for (int t = 0; t < NP; ++t) {
+		const uint32_t p = lane + 64u * (uint32_t)t, g = p / NHM, q = p % NHM;
+		p_on[t] = q < s_nh[g];
+		p_end[t] = 0; p_abs0[t] = 0; ld_n[t] = 0; la[t] = uint4{0, 0, 0, 0}; lb[t] = uint4{0, 0, 0, 0};
+		if (p_on[t]) {
+			const bs_meta &Mg = C.meta[r0 + g];
+			const uint32_t dk = Mg.act[q], h0 = Mg.hst[dk], h1 = Mg.hst[dk + 1u], beg = s_beg[g];
+			s_head[p] = (uint64_t)h0 | (uint64_t)BS_INVALID << 32; s_end[p] = h1; s_lim[p] = (beg + h0) & ~15u;
+			p_end[t] = beg + h1; p_abs0[t] = beg;
+		}
+	}
+	__syncthreads();
+	// chunks (16 bytes at s_lim, s_lim + 16) a pair can take now: the ring holds the 64 bytes from the pointer's chunk on
+	#define BS_MW_ISSUE_ALL() _Pragma("unroll") for (int t = 0; t < NP; ++t) { \
+		ld_n[t] = 0; \
+		if (p_on[t]) { const uint32_t p = lane + 64u * (uint32_t)t, pa = ((uint32_t)s_head[p] + p_abs0[t]) & ~15u, lm = s_lim[p]; \
+		               if (lm < p_end[t] && lm + 16u - pa <= (uint32_t)BS_MW_RING) { ld_n[t] = 1; if (lm + 16u < p_end[t] && lm + 32u - pa <= (uint32_t)BS_MW_RING) ld_n[t] = 2; } \
+		               if (ld_n[t] >= 1) la[t] = *reinterpret_cast<const uint4*>(C.hd + lm); \
+		               if (ld_n[t] >= 2) lb[t] = *reinterpret_cast<const uint4*>(C.hd + lm + 16u); } }
+	#define BS_MW_COMMIT_ALL() _Pragma("unroll") for (int t = 0; t < NP; ++t) { \
+		if (p_on[t] && ld_n[t]) { const uint32_t p = lane + 64u * (uint32_t)t, lm = s_lim[p]; uint8_t *ring = s_win + (size_t)p * BS_MW_RING; \
+		               *reinterpret_cast<uint4*>(ring + (lm & (BS_MW_RING - 1u))) = la[t]; \
+		               if (ld_n[t] == 2) *reinterpret_cast<uint4*>(ring + ((lm + 16u) & (BS_MW_RING - 1u))) = lb[t]; \
+		               const uint32_t nl = lm + 16u * ld_n[t]; s_lim[p] = nl; \
+		               const uint64_t hh = s_head[p]; const uint32_t aa = (uint32_t)hh + p_abs0[t]; \
+		               if (((uint32_t)(hh >> 32) & BS_INVALID) && aa < nl) s_head[p] = (uint64_t)(uint32_t)hh | (uint64_t)ring[aa & (BS_MW_RING - 1u)] << 32; } }
+	BS_MW_ISSUE_ALL() BS_MW_COMMIT_ALL()
+	__syncthreads();
+	BS_MW_ISSUE_ALL() BS_MW_COMMIT_ALL()                            // rings full: 64 bytes from each region's first hole
+	__syncthreads();
+	const bool walker = lane < (uint32_t)G && s_nh[lane < (uint32_t)G ? lane : 0] != 0;
+	const uint32_t g = walker ? lane : 0, nh = walker ? s_nh[g] : 0, beg = s_beg[g];
+	bs_meta &M = C.meta[r0 + g];
+	uint32_t *dest = C.dest + beg;
+	uint64_t *hd_ = s_head + g * NHM;
+	const uint32_t *lim_ = s_lim + g * NHM, *end_ = s_end + g * NHM;
+	const uint8_t *win_ = s_win + (size_t)g * NHM * BS_MW_RING;
+	// The walk, one pop per iteration: (q, h) = the region to pop next and its head, already in registers.  A lone wavefront
+	// gets a dependent instruction through every ~8 cycles, so the iteration is kept short: the common case (every live walker
+	// pops) is branch-free selects; a region running out of holes and a walker at the end of its ring are the wavefront's slow
+	// path, taken only when a lane needs it.  The head of the next region is requested before this pop's head update is written
+	// back (LDS answers in order: one round trip per step); the store that closes a cycle waits for the next iteration, so that
+	// an iteration stores once.
+	uint32_t k = 0, i0 = 0, i = 0, q = 0, endk = walker ? end_[0] : 0, pend_a = 0, pend_v = 0;
+	bool inchase = false, live = walker, pend = false;
+	uint64_t h = walker ? hd_[0] : 0;
+	for (;;) {
+		BS_MW_ISSUE_ALL()
+		for (int it = 0; it < BS_MW_PERIOD; ++it) {
+			const uint32_t j = (uint32_t)h, hi = (uint32_t)(h >> 32);
+			const bool out = !inchase && j >= endk, stall = (hi & BS_INVALID) != 0;
+			if (__ballot(live && (out || stall))) {               // slow path (whole wavefront, rarely)
+				if (live && out) {                                  // region k has no hole left: the next one becomes the base
+					if (pend) { dest[pend_a] = pend_v; pend = false; }
+					++k;
+					if (k >= nh) live = false;
+					else { M.J[M.act[k]] = (uint32_t)hd_[k] - M.hst[M.act[k]]; endk = end_[k]; q = k; h = hd_[k]; }
+				}
+				continue;                                           // (a stalled walker waits for the next commit; the others lose one turn)
+			}
+			if (live) {
+				const uint32_t jn = j + 1u, an = jn + beg, d = hi & 255u;   // the record found in the hole belongs to region d: it goes there next
+				const bool closes = d == k;                       // ... unless that is the cycle's own region (never for the pop that starts a cycle)
+				const uint32_t nx = win_[q * BS_MW_RING + (an & (BS_MW_RING - 1u))];
+				const uint32_t lm = lim_[q];
+				const uint64_t hn = hd_[d];                         // (stale if d == q: replaced below)
+				const uint64_t hq = (uint64_t)jn | (uint64_t)(nx | (((an & 15u) == 0u && an >= lm) ? BS_INVALID : 0u)) << 32;
+				hd_[q] = hq;
+				const uint32_t sa = inchase ? i : pend_a, sv = inchase ? j : pend_v;
+				if (inchase || pend) dest[sa] = sv;
+				i0 = inchase ? i0 : j;
+				pend = closes; pend_a = j; pend_v = i0;
+				i = j;
+				inchase = !closes;
+				h = d == q ? hq : hn;
+				q = d;
+			}
+		}
+		if (walker && !live && pend) { dest[pend_a] = pend_v; pend = false; }
+		__syncthreads();
+		if (!__ballot(live)) break;
+		BS_MW_COMMIT_ALL()
+		__syncthreads();
+		if (live) h = hd_[q];                                      // (a commit may have made it valid)
+	}
+	#undef BS_MW_ISSUE_ALL
+	#undef BS_MW_COMMIT_ALL
 }
 
 // ------------------------------------------------------------------------------------------------ K8: placement
@@ -634,14 +764,14 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	uint32_t *pin = (uint32_t*)jb.big_pin;
 	static const bool trace = getenv("RH_BS_TRACE") != nullptr;   // development aid: per-level launch shapes and times on stderr
 	hipEvent_t ev[4] = {};
-	if (trace) for (auto &e : ev) hipEventCreate(&e);
+	if (trace) for (auto &e : ev) (void)hipEventCreate(&e);
 	for (int level = 0; level < 9; ++level) {
 		RH_HIP(hipMemcpyAsync(pin, C.hdr, 32, hipMemcpyDeviceToHost, s));
 		RH_HIP(hipStreamSynchronize(s));
 		const uint32_t n_rng = pin[0], n_tiles = pin[1];
 		if (pin[7]) { rh_set_error("segment sorter: range / segment list overflow"); return -1; }
 		if (n_rng == 0) break;
-		if (trace) hipEventRecord(ev[0], s);
+		if (trace) (void)hipEventRecord(ev[0], s);
 		RH_LAUNCH(k_bs_clear, n_rng, NT, 0, s, C);
 		RH_LAUNCH(k_bs_diff, n_tiles, NT, 0, s, C);
 		RH_LAUNCH(k_bs_hist, n_tiles, NT, 0, s, C);
@@ -650,26 +780,31 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		RH_LAUNCH(k_bs_scan, n_rng, NT, 0, s, C);
 		RH_LAUNCH(k_bs_holes, n_tiles, NT, 0, s, C);
 		// few ranges: a wavefront each (nothing to gain from 64 walks per wavefront); many: one lane each where the regions fit
-		const int lanes = n_rng >= (uint32_t)BS_LANES_MIN_RANGES;
-		if (trace) hipEventRecord(ev[1], s);
-		RH_LAUNCH(k_bs_walk_wave, n_rng, 64, 0, s, C, lanes ? 0 : 1);
+		const int lanes = n_rng >= (uint32_t)BS_LANES_MIN_RANGES, multi = !lanes && n_rng >= (uint32_t)BS_MULTI_MIN_RANGES;
+		if (trace) (void)hipEventRecord(ev[1], s);
+		RH_LAUNCH(k_bs_walk_wave, n_rng, 64, 0, s, C, lanes ? 3u : multi ? 3u : 1u, lanes ? 256u : multi ? (uint32_t)BS_MW_NHM : 0u);
+		if (multi) {	// walks per wavefront: so that the level takes about one wavefront per SIMD (a walk's step time does not depend on how many lanes walk)
+			if (n_rng > (uint32_t)BS_MW_G32_FROM) RH_LAUNCH((k_bs_walk_multi<BS_MW_NHM, 32>), (n_rng + 31) / 32, 64, 0, s, C);
+			else if (n_rng > (uint32_t)BS_MW_G16_FROM) RH_LAUNCH((k_bs_walk_multi<BS_MW_NHM, 16>), (n_rng + 15) / 16, 64, 0, s, C);
+			else RH_LAUNCH((k_bs_walk_multi<BS_MW_NHM, 8>), (n_rng + 7) / 8, 64, 0, s, C);
+		}
 		if (lanes) {	// by number of regions with holes: 64 / 32 / 8 walkers per wavefront
 			RH_LAUNCH((k_bs_walk_lanes<24, 64>), (n_rng + 63) / 64, 64, 0, s, C, 2u);
 			RH_LAUNCH((k_bs_walk_lanes<64, 32>), (n_rng + 31) / 32, 64, 0, s, C, 24u);
 			RH_LAUNCH((k_bs_walk_lanes<256, 8>), (n_rng + 7) / 8, 64, 0, s, C, 64u);   // LDS: 24 B per region and walker (36 / 48 / 48 KB)
 		}
-		if (trace) hipEventRecord(ev[2], s);
+		if (trace) (void)hipEventRecord(ev[2], s);
 		RH_LAUNCH(k_bs_scatter, ((n_tiles + 7) / 8) * 8, NT, 0, s, C);
 		RH_LAUNCH(k_bs_next, 1, NT, 0, s, C);
 		if (trace) {
-			hipEventRecord(ev[3], s); hipEventSynchronize(ev[3]);
+			(void)hipEventRecord(ev[3], s); (void)hipEventSynchronize(ev[3]);
 			float a = 0, b = 0, c = 0;
-			hipEventElapsedTime(&a, ev[0], ev[1]); hipEventElapsedTime(&b, ev[1], ev[2]); hipEventElapsedTime(&c, ev[2], ev[3]);
+			(void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]); (void)hipEventElapsedTime(&c, ev[2], ev[3]);
 			fprintf(stderr, "BS level %d segs %u total %llu rng %u tiles %u pre %.3f walk %.3f post %.3f\n", level, jb.n_seg, (unsigned long long)t, n_rng, n_tiles, a, b, c);
 		}
 		bs_range *tmp = C.rng[0]; C.rng[0] = C.rng[1]; C.rng[1] = tmp;
 	}
-	if (trace) for (auto &e : ev) hipEventDestroy(e);
+	if (trace) for (auto &e : ev) (void)hipEventDestroy(e);
 	// the buckets that fit the LDS classes finish in the block sorter, from the copy that holds them
 	const bool job32 = jb.kc_on && (uint32_t)jb.kc_lo + jb.kc_mid + jb.kc_hi <= 32u && jb.kc_mid <= 24u;
 	for (int q = 0; q < 4; ++q) {

@@ -26,6 +26,7 @@ void rh_set_error(const char *fmt, ...);
 
 struct int2 { int x, y; };
 struct float4 { float x, y, z, w; };
+struct uint4 { unsigned int x, y, z, w; };
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 
