@@ -63,6 +63,7 @@ struct bs_ctx {
 	bs_range *rng[2];                     // this level's ranges / next level's
 	bs_meta *meta;
 	uint32_t *tile_h;                     // per tile: holes -> (after the scan) holes of the range before the tile
+	uint32_t *tile_rng;                   // per tile: its range
 	uint8_t *dg, *hd;                     // per record: digit; per hole: digit of its record
 	uint32_t *hp, *dest;                  // per hole: position in the range; hole (of the record's own region) it moves to
 	uint64_t *small_off[4]; uint32_t *small_cnt[4];   // segments for the block sorter, by (copy that holds them) * 2 + (keys differ below bit 32 only)
@@ -70,15 +71,17 @@ struct bs_ctx {
 	uint32_t small_cap, rng_cap, n_lo;
 };
 
-RH_DEV uint32_t bs_find_range(const bs_ctx &C, uint32_t tile, uint32_t n_rng, uint32_t *s_r)
+// the range a tile belongs to: looked up once per level (k_bs_tile_map), not by every kernel of the level (a binary search over
+// the ranges is ~14 dependent loads by one lane while its workgroup waits)
+RH_DEV uint32_t bs_find_range(const bs_ctx &C, uint32_t tile, uint32_t, uint32_t *) { return C.tile_rng[tile]; }
+
+__global__ __launch_bounds__(NT) void k_bs_tile_map(bs_ctx C)
 {
-	if (threadIdx.x == 0) {
-		uint32_t lo = 0, hi = n_rng;      // largest r with tile0[r] <= tile
-		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (C.rng[0][mid].tile0 <= tile) lo = mid; else hi = mid; }
-		*s_r = lo;
-	}
-	__syncthreads();
-	return *s_r;
+	const uint32_t tile = blockIdx.x * NT + threadIdx.x, n_rng = C.hdr[0];
+	if (tile >= C.hdr[1]) return;
+	uint32_t lo = 0, hi = n_rng;          // largest r with tile0[r] <= tile
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (C.rng[0][mid].tile0 <= tile) lo = mid; else hi = mid; }
+	C.tile_rng[tile] = lo;
 }
 
 // ------------------------------------------------------------------------------------------------ level set-up
@@ -224,9 +227,8 @@ __global__ __launch_bounds__(NT) void k_bs_plan(bs_ctx C)
 
 // ------------------------------------------------------------------------------------------------ tiles: classification
 // region of position p: largest b with start[b] <= p (empty buckets share their start with the next one)
-RH_DEV uint32_t bs_region(const uint32_t *start, uint32_t p)
+RH_DEV uint32_t bs_region(const uint32_t *start, uint32_t p, uint32_t lo = 0, uint32_t hi = 256)   // the region of position p, known to be in [lo, hi)
 {
-	uint32_t lo = 0, hi = 256;
 	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (start[mid] <= p) lo = mid; else hi = mid; }
 	return lo;
 }
@@ -238,12 +240,15 @@ RH_DEV uint32_t bs_classify(const uint8_t *dg, const uint32_t *s_start, uint32_t
 {
 	const uint32_t tid = threadIdx.x, w = wave_id();
 	uint64_t bal[BS_TILE_IT];
+	// a tile lies in one region or a few: the regions of its ends (the same LDS words for every lane) bracket every record's
+	const uint32_t p_last = t0 + BS_TILE - 1u < n ? t0 + BS_TILE - 1u : n - 1u;
+	const uint32_t b_lo = bs_region(s_start, t0), b_hi = bs_region(s_start, p_last, b_lo, 256u);
 #pragma unroll
 	for (int it = 0; it < BS_TILE_IT; ++it) {
 		const uint32_t p = t0 + (uint32_t)it * NT + tid;
 		bool hole = false;
 		q.d[it] = 0; q.b[it] = 0;
-		if (p < n) { q.d[it] = dg[p]; q.b[it] = bs_region(s_start, p); hole = q.d[it] != q.b[it]; }
+		if (p < n) { q.d[it] = dg[p]; q.b[it] = b_lo == b_hi ? b_lo : bs_region(s_start, p, b_lo, b_hi + 1u); hole = q.d[it] != q.b[it]; }
 		bal[it] = __ballot(hole);
 		if (lane_id() == 0) s_cw[it * (NT / 64) + w] = (uint32_t)__popcll(bal[it]);
 	}
@@ -734,7 +739,7 @@ size_t rhk_bigsort_ws_bytes(uint64_t total, uint32_t n_lo)
 	size_t b = 256;                                                // hdr
 	b += 2 * ((rng_cap * sizeof(bs_range) + 255) & ~(size_t)255);
 	b += (rng_cap * sizeof(bs_meta) + 255) & ~(size_t)255;
-	b += (tiles * 4 + 255) & ~(size_t)255;
+	b += 2 * ((tiles * 4 + 255) & ~(size_t)255);
 	b += 2 * ((t + 128 + 255) & ~(size_t)255);                      // dg, hd
 	b += 2 * ((t * 4 + 255) & ~(size_t)255);                       // hp, dest
 	b += 4 * ((small_cap * 8 + 255) & ~(size_t)255) + 4 * ((small_cap * 4 + 255) & ~(size_t)255);
@@ -755,7 +760,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	C.hdr = (uint32_t*)take(256);
 	C.rng[0] = (bs_range*)take((size_t)C.rng_cap * sizeof(bs_range)); C.rng[1] = (bs_range*)take((size_t)C.rng_cap * sizeof(bs_range));
 	C.meta = (bs_meta*)take((size_t)C.rng_cap * sizeof(bs_meta));
-	C.tile_h = (uint32_t*)take(tiles_cap * 4);
+	C.tile_h = (uint32_t*)take(tiles_cap * 4); C.tile_rng = (uint32_t*)take(tiles_cap * 4);
 	C.dg = (uint8_t*)take(t); C.hd = (uint8_t*)take(t + 128);   // (+64: the lane walkers read whole aligned words around a pointer)
 	C.hp = (uint32_t*)take(t * 4); C.dest = (uint32_t*)take(t * 4);
 	for (int q = 0; q < 4; ++q) { C.small_off[q] = (uint64_t*)take((size_t)C.small_cap * 8); C.small_cnt[q] = (uint32_t*)take((size_t)C.small_cap * 4); }
@@ -772,6 +777,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		if (pin[7]) { rh_set_error("segment sorter: range / segment list overflow"); return -1; }
 		if (n_rng == 0) break;
 		if (trace) (void)hipEventRecord(ev[0], s);
+		RH_LAUNCH(k_bs_tile_map, (n_tiles + NT - 1) / NT, NT, 0, s, C);
 		RH_LAUNCH(k_bs_clear, n_rng, NT, 0, s, C);
 		RH_LAUNCH(k_bs_diff, n_tiles, NT, 0, s, C);
 		RH_LAUNCH(k_bs_hist, n_tiles, NT, 0, s, C);
