@@ -82,6 +82,7 @@ struct rh_ctx_s {
 	DevBuf ev, n_ev, skip, sx, sy, n_seed, m_val, m_n, m_meta, m_pref, n_match, n_new, rep_len, a_off;
 	DevBuf anc, raw_anc, zs, n_z, need_exact, need_exact2, prev_stage, u, n_u, n_v, ws, counters, rec;
 	DevBuf name_rank, t_rank, rec_off;                            // all-vs-all: name ranks of the reads / of the targets, record offsets
+	uint64_t arena_room = 0;                                       // anchors the per-anchor arenas were sized for when a round was last cut into slices (the budget sticks to it)
 	uint32_t ev_row = RH_CHUNK_MAX + 64, ev_cap = RH_EV_CAP, whole = 0;   // strides of the per-read rows of the current batch (whole-read rounds: sized by its longest read)
 	DevBuf carry[2], carry_off, a_off_slice;                      // chained anchors carried into the next chunk, dense, ping-pong over the rounds
 	int share = 1;                                                 // sub-batches running concurrently on this device (memory budget per context)
@@ -269,6 +270,9 @@ uint64_t slice_budget(rh_ctx *c)
 		const double use = 0.75 * may_use > (double)held ? 0.75 * may_use : (double)held;
 		budget = (uint64_t)(use / (double)kBytesPerAnchor);
 		if (budget < (1u << 16)) return 0;                          // the device is full (other contexts / processes hold it)
+		// The arenas were sized for a budget once: a slightly larger one (the free memory moves by rounding and by what the other
+		// sub-batches hold at the moment) must not re-allocate tens of gigabytes on a nearly full device - that takes seconds.
+		if (c->arena_room && held && budget > c->arena_room && budget < c->arena_room + c->arena_room / 2) budget = c->arena_room;
 	}
 	if (const char *cap_env = getenv("RH_ARENA_MAX_BYTES")) { const uint64_t m = strtoull(cap_env, nullptr, 10) / RH_WS_PER_ANCHOR; if (m < budget) budget = m; }
 	return budget > 1024 ? budget : 1024;
@@ -299,6 +303,7 @@ void release_arenas(rh_ctx *c)
 	                 &c->carry[0], &c->carry[1], &c->carry_off, &c->a_off_slice, &c->u, &c->n_u, &c->n_v, &c->ws, &c->sort_alt, &c->sort_ws, &c->rec};
 	for (DevBuf *b : all) b->release();
 	for (DevBuf &b : c->st) b.release();
+	c->arena_room = 0;
 	for (rh_ctx *sc : c->subs) release_arenas(sc);
 }
 bool holds_arenas(const rh_ctx *c)
@@ -703,6 +708,9 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 				if (a_off_h[a] - a_off_h[lo] > budget && a - 1 > lo) { cuts.push_back(a - 1); lo = a - 1; }
 		}
 		cuts.push_back(n_act);
+		static const bool trace_rounds = getenv("RH_TRACE_ROUNDS") != nullptr;   // development aid
+		if (trace_rounds) fprintf(stderr, "[ctx %p] round %u: %u reads, %llu anchors, budget %llu, %zu slice(s), %.1f ms since the call began\n", (void*)c, chunk, n_act,
+		                          (unsigned long long)total, (unsigned long long)budget, cuts.size() - 1, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
 		carry_used = 0;
 		if (c->carry_off.ensure((size_t)(n_act + 1) * 8) || c->a_off_slice.ensure((size_t)(n_act + 2) * 8)) return -1;
 		for (size_t si = 0; si + 1 < cuts.size(); ++si) {
@@ -719,6 +727,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 				rs.max_anchors = mx;
 			}
 			if (stage_anchors(c, stotal, &rs, cuts.size() > 2 ? budget : 0)) return -1;
+			if (cuts.size() > 2) c->arena_room = budget;
 			{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rs); }
 			{ StageTimer t(c, ST_SORT); if (rhk_sort(s, rs)) return -1; }
 			if (debug_rounds()) dump_round(c, chunk, n, rs);
@@ -804,6 +813,7 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 		DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev_stage, &c->u, &c->ws, &c->sort_alt, &c->sort_ws};
 		(void)hipStreamSynchronize(c->stream);
 		for (DevBuf *d : big) d->release();
+		c->arena_room = 0;
 	} else slice = c->slice_hint;
 	rh_map_stats_t tot{};
 	while (done < R) {
@@ -821,6 +831,8 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 			DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev_stage, &c->u, &c->ws, &c->sort_alt, &c->sort_ws};
 			(void)hipStreamSynchronize(c->stream);
 			for (DevBuf *d : big) d->release();
+			c->arena_room = 0;
+		c->arena_room = 0;
 			continue;
 		}
 		for (uint32_t i = 0; i < m; ++i) out[done + i].read_idx += done;
