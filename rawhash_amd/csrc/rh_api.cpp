@@ -806,6 +806,19 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 	g_oom = false;
 	uint64_t n = 0;
 	uint32_t slice = R / 2, done = 0;
+	// The event / seeding stages hold rows for every active read of a call (~140 KB each: z / t1 / t2 rows, peaks, events, seeds,
+	// matches): a call takes as many reads as fit a third of this context's share of the free memory (a million-read batch is
+	// mapped in a few consecutive calls; the anchor-sized stages have their own slices inside a call).
+	if (!(mo->flag & RH_M_NO_ADAPTIVE)) {
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+			const size_t per_read = (size_t)(RH_CHUNK_MAX + 64) * 12 + (size_t)RH_EV_CAP * 44 + 4096;
+			size_t mine = holds_arenas(c) ? c->zbuf.cap + c->t1buf.cap + c->t2buf.cap + c->sx.cap + c->sy.cap + c->m_val.cap : 0;
+			const uint64_t lim = (uint64_t)(((double)free_b / (c->share > 0 ? c->share : 1) + (double)mine) / 3.0 / (double)per_read);
+			const uint32_t cap = lim > 0xFFFFFFFFull ? 0xFFFFFFFFu : (lim < 4096 ? 4096u : (uint32_t)lim);
+			if (R > cap && (c->slice_hint == 0 || c->slice_hint > cap)) c->slice_hint = cap;
+		}
+	}
 	if (c->slice_hint == 0 || R <= c->slice_hint) {
 		if (map_batch_once(c, mo, in, out, out_cap, &n) == 0) { *n_out = n; return 0; }
 		if (!g_oom || R < 2) return -1;
