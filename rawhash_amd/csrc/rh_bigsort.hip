@@ -368,7 +368,7 @@ __global__ __launch_bounds__(NT) void k_bs_holes(bs_ctx C)
 #endif
 #define BS_LSTEPS 8
 #ifndef BS_MULTI_MIN_RANGES
-#define BS_MULTI_MIN_RANGES 4096            // ranges of a level from which several walks share a wavefront (fewer: a wavefront each, the level is bound by one walk's latency)
+#define BS_MULTI_MIN_RANGES 1024            // ranges of a level from which several walks share a wavefront (measured with three sub-batch streams sharing the chip: what counts there is the issue time a level takes from the others, and G walks per wavefront cost one walk's)
 #endif
 #ifndef BS_MW_G16_FROM
 #define BS_MW_G16_FROM 8192                 // more ranges than this: 16 walks per wavefront, ...
