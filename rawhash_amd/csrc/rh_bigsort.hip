@@ -21,6 +21,7 @@
 // sorts of <= 64 records included), or are final.  Records move once per level between two scratch copies (the
 // job's own source array and `alt`); finished buckets go straight to the destination array.
 #include <cstdio>
+#include <vector>
 #include <cstdlib>
 #include "rh_kernels.h"
 #include "rh_devutil.h"
@@ -806,7 +807,14 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 			(void)hipEventRecord(ev[3], s); (void)hipEventSynchronize(ev[3]);
 			float a = 0, b = 0, c = 0;
 			(void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]); (void)hipEventElapsedTime(&c, ev[2], ev[3]);
-			fprintf(stderr, "BS level %d segs %u total %llu rng %u tiles %u pre %.3f walk %.3f post %.3f\n", level, jb.n_seg, (unsigned long long)t, n_rng, n_tiles, a, b, c);
+			// records by the number of regions with holes of their range: <= 2 (closed form), 3..24, 25..64, 65..128, more
+			std::vector<uint32_t> nhv(n_rng); std::vector<bs_range> rv(n_rng);
+			(void)hipMemcpy2D(nhv.data(), 4, &C.meta[0].nh, sizeof(bs_meta), 4, n_rng, hipMemcpyDeviceToHost);
+			(void)hipMemcpy(rv.data(), C.rng[0], (size_t)n_rng * sizeof(bs_range), hipMemcpyDeviceToHost);
+			uint64_t bins[5] = {0, 0, 0, 0, 0};
+			for (uint32_t r = 0; r < n_rng; ++r) bins[nhv[r] <= 2 ? 0 : nhv[r] <= 24 ? 1 : nhv[r] <= 64 ? 2 : nhv[r] <= 128 ? 3 : 4] += rv[r].n;
+			fprintf(stderr, "BS level %d segs %u total %llu rng %u tiles %u pre %.3f walk %.3f post %.3f  records by regions: <=2 %llu, <=24 %llu, <=64 %llu, <=128 %llu, more %llu\n", level, jb.n_seg,
+			        (unsigned long long)t, n_rng, n_tiles, a, b, c, (unsigned long long)bins[0], (unsigned long long)bins[1], (unsigned long long)bins[2], (unsigned long long)bins[3], (unsigned long long)bins[4]);
 		}
 		bs_range *tmp = C.rng[0]; C.rng[0] = C.rng[1]; C.rng[1] = tmp;
 	}
