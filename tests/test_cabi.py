@@ -10,10 +10,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "cabi", "rawhash2_step1.cpp")
 
 
-def build_consumer(out_dir, product_lib):
-    exe = os.path.join(str(out_dir), "rawhash2_step1")
+SRC_AVA = os.path.join(ROOT, "tests", "cabi", "rawhash2_ava.cpp")
+
+
+def build_consumer(out_dir, product_lib, src=SRC):
+    exe = os.path.join(str(out_dir), os.path.splitext(os.path.basename(src))[0])
     libdir = os.path.join(ROOT, "rawhash_amd")
-    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), SRC, "-o", exe,
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
                     "-L", libdir, "-lrawhash_amd", f"-Wl,-rpath,{libdir}"], check=True)
     return exe
 
@@ -22,6 +25,30 @@ def test_consumer_builds_with_plain_gxx(tmp_path, product_lib):
     exe = build_consumer(tmp_path, product_lib)
     p = subprocess.run([exe], capture_output=True, text=True)
     assert p.returncode == 2 and "usage" in p.stderr
+
+
+def test_rawsamble_consumer_builds_with_plain_gxx(tmp_path, product_lib):
+    exe = build_consumer(tmp_path, product_lib, SRC_AVA)
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 2 and "usage" in p.stderr
+
+
+@pytest.mark.gpu
+def test_rawsamble_consumer_prints_the_golden_paf_and_ind(tmp_path, product_lib):
+    """INTEGRATION.md section 3 as a program: `-x ava -d out.ind reads` then the all-vs-all run, both through the C ABI from C++:
+    the .ind is the reference's byte for byte, the overlaps are the reference's PAF."""
+    import hashlib
+    import golden
+    import oracle_lib as O
+    from rawhash_amd import strip_mt
+    exe = build_consumer(tmp_path, product_lib, SRC_AVA)
+    for case in golden.ava_cases():
+        w = golden.build_ava_case(case, tmp_path / case["name"], product_lib)
+        ind = os.path.join(str(tmp_path), case["name"] + ".ind")
+        p = subprocess.run([exe, w.preset, w.model, w.rhr, ind], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        assert [strip_mt(x) for x in p.stdout.splitlines()] == golden.expected_paf(case)
+        assert hashlib.sha256(O.mask_ind(open(ind, "rb").read())).hexdigest() == case["ind_sha256"]
 
 
 @pytest.mark.gpu
