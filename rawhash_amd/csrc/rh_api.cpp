@@ -1278,7 +1278,49 @@ extern "C" int rh_map_batch_multi(rh_ctx *c, const rh_mapopt_t *mo, const rh_rea
 		for (uint32_t r = 0; r <= in->n_reads; ++r) rec_offsets[r] = r;
 		return 0;
 	}
-	return map_batch_once(c, mo, in, out, out_cap, n_out, rec_offsets);
+	// A whole-read round holds rows as long as the longest read of the call for every read of the call (~34 bytes per sample of
+	// row): the batch goes through in consecutive groups of reads whose rows fit a quarter of the free memory (one group unless
+	// the lengths are very uneven or the batch is huge).  Reads are independent: the records are the same.
+	const uint32_t R = in->n_reads;
+	*n_out = 0; rec_offsets[0] = 0;
+	if (R == 0) return 0;
+	if (hipSetDevice(c->device) != hipSuccess) { rh_set_error("hipSetDevice failed"); return -1; }
+	std::vector<uint64_t> off_h;
+	const uint64_t *off = in->offsets;
+	if (in->samples_on_device) { off_h.resize((size_t)R + 1); RH_HIP(hipMemcpy(off_h.data(), in->offsets, ((size_t)R + 1) * 8, hipMemcpyDeviceToHost)); off = off_h.data(); }
+	size_t free_b = 0, total_b = 0;
+	RH_HIP(hipMemGetInfo(&free_b, &total_b));
+	uint64_t budget = (uint64_t)((double)free_b / 4.0 / 34.0);       // samples of row the groups may hold
+	if (const char *e = getenv("RH_WHOLE_ROWS_MAX_SAMPLES")) budget = strtoull(e, nullptr, 10);   // (tests)
+	uint32_t done = 0;
+	uint64_t n_total = 0;
+	std::vector<uint64_t> tmp_off;
+	rh_map_stats_t tot{};
+	while (done < R) {
+		uint32_t m = 0;
+		uint64_t mx = 0;
+		while (done + m < R) {
+			const uint64_t len = off[done + m + 1] - off[done + m] + 64, nmx = len > mx ? len : mx;
+			if (m > 0 && nmx * (m + 1) > budget) break;
+			mx = nmx; ++m;
+		}
+		rh_read_batch_t b = *in;
+		b.n_reads = m;
+		b.offsets = in->offsets + done;
+		if (in->cal_offset) b.cal_offset = in->cal_offset + done;
+		if (in->cal_scale) b.cal_scale = in->cal_scale + done;
+		b.name_rank = in->name_rank ? in->name_rank + done : nullptr;
+		tmp_off.assign((size_t)m + 1, 0);
+		uint64_t n = 0;
+		if (map_batch_once(c, mo, &b, out + n_total, out_cap - n_total, &n, tmp_off.data())) return -1;
+		for (uint64_t k = 0; k < n; ++k) out[n_total + k].read_idx += done;
+		for (uint32_t i = 0; i <= m; ++i) rec_offsets[done + i] = n_total + tmp_off[i];
+		add_stats(tot, c->stats);
+		n_total += n; done += m;
+	}
+	c->stats = tot;
+	*n_out = n_total;
+	return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------- signal-target index
@@ -1309,34 +1351,70 @@ extern "C" rh_index *rh_index_build_signals_device(rh_ctx *c, const rh_read_batc
 	c->dix.sp = rh_sketch_par{io->e, io->w, io->q, io->k, io->diff, io->fine_min, io->fine_max, io->fine_range};
 	hipStream_t s = c->stream;
 	void *dH = nullptr, *dY = nullptr;
-	uint64_t n_seeds = 0;
+	uint64_t n_seeds = 0, seed_cap = 0;
 	std::vector<uint32_t> lens(R ? R : 1, 0);
 	auto fail = [&]() -> rh_index* { if (dH) (void)hipFree(dH); if (dY) (void)hipFree(dY); return nullptr; };
-	if (R) {
+	// room for `need` seeds in the two arrays (geometric growth, contents kept)
+	auto seeds_reserve = [&](uint64_t need) -> int {
+		if (need + 1 <= seed_cap) return 0;
+		const uint64_t nc = need + 1 > 2 * seed_cap ? need + 1 : 2 * seed_cap;
+		void *nh = nullptr, *ny = nullptr;
+		if (hipMalloc(&nh, nc * 4) != hipSuccess || hipMalloc(&ny, nc * 8) != hipSuccess) { if (nh) (void)hipFree(nh); rh_set_error("index build: out of device memory for %llu seeds", (unsigned long long)nc); return -1; }
+		if (n_seeds) { (void)hipMemcpyAsync(nh, dH, n_seeds * 4, hipMemcpyDeviceToDevice, s); (void)hipMemcpyAsync(ny, dY, n_seeds * 8, hipMemcpyDeviceToDevice, s); }
+		if (hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(nh); (void)hipFree(ny); rh_set_error("index build: device error"); return -1; }
+		if (dH) (void)hipFree(dH);
+		if (dY) (void)hipFree(dY);
+		dH = nh; dY = ny; seed_cap = nc;
+		return 0;
+	};
+	if (seeds_reserve(0)) return fail();
+	// the reads go through in consecutive groups whose rows (as long as the group's longest read, ~34 bytes per sample) fit a
+	// quarter of the free memory; one group unless the lengths are very uneven or the read set is huge
+	std::vector<uint64_t> off_h;
+	const uint64_t *off = in->offsets;
+	if (R && in->samples_on_device) { off_h.resize((size_t)R + 1); if (hipMemcpy(off_h.data(), in->offsets, ((size_t)R + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) { rh_set_error("index build: device error"); return fail(); } off = off_h.data(); }
+	size_t free_b = 0, total_b = 0;
+	(void)hipMemGetInfo(&free_b, &total_b);
+	uint64_t budget = (uint64_t)((double)free_b / 4.0 / 34.0);
+	if (const char *e = getenv("RH_WHOLE_ROWS_MAX_SAMPLES")) budget = strtoull(e, nullptr, 10);   // (tests)
+	for (uint32_t done = 0; done < R;) {
+		uint32_t m = 0;
+		uint64_t mx = 0;
+		while (done + m < R) {
+			const uint64_t len = off[done + m + 1] - off[done + m] + 64, nmx = len > mx ? len : mx;
+			if (m > 0 && nmx * (m + 1) > budget) break;
+			mx = nmx; ++m;
+		}
+		rh_read_batch_t b = *in;
+		b.n_reads = m; b.offsets = in->offsets + done; b.name_rank = nullptr;
+		if (in->cal_offset) b.cal_offset = in->cal_offset + done;
+		if (in->cal_scale) b.cal_scale = in->cal_scale + done;
 		rh_dev_reads rd;
-		if (set_row_strides(c, &mw, in) || stage_reads(c, in, &rd)) return nullptr;
-		if (c->act[0].ensure((size_t)R * 4) || c->n_act_dev.ensure(64) || c->counters.ensure(16 * 8) || c->rec_off.ensure((size_t)(R + 2) * 8)) return nullptr;
-		if (hipMemsetAsync(c->counters.p, 0, 16 * 8, s) != hipSuccess) return nullptr;
+		if (set_row_strides(c, &mw, &b) || stage_reads(c, &b, &rd)) return fail();
+		if (c->act[0].ensure((size_t)m * 4) || c->n_act_dev.ensure(64) || c->counters.ensure(16 * 8) || c->rec_off.ensure((size_t)(m + 2) * 8)) return fail();
+		if (hipMemsetAsync(c->counters.p, 0, 16 * 8, s) != hipSuccess) return fail();
 		rhk_prefilter(s, o, rd);
-		rhk_compact_active(s, o, rd, nullptr, R, 0, c->act[0].as<uint32_t>(), c->n_act_dev.as<uint32_t>());
+		rhk_compact_active(s, o, rd, nullptr, m, 0, c->act[0].as<uint32_t>(), c->n_act_dev.as<uint32_t>());
 		uint32_t n_act = 0;
-		if (hipMemcpyAsync(&n_act, c->n_act_dev.p, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rh_set_error("index build: device error"); return nullptr; }
+		if (hipMemcpyAsync(&n_act, c->n_act_dev.p, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rh_set_error("index build: device error"); return fail(); }
 		rh_dev_round rr{};
-		if (stage_round(c, n_act, &rr)) return nullptr;
+		if (stage_round(c, n_act, &rr)) return fail();
 		rr.act = c->act[0].as<uint32_t>(); rr.chunk = 0;
+		uint64_t n_g = 0;
 		if (n_act) {
 			rhk_events_norm(s, o, rd, rr); rhk_events_peaks(s, o, rr); rhk_events_means(s, o, rr);
 			rhk_sketch(s, o, c->dix, rd, rr);
 			rhk_seed_scan(s, rr, c->rec_off.as<uint64_t>());
 			uint64_t cnt[16];
-			if (hipMemcpyAsync(&n_seeds, c->rec_off.as<uint64_t>() + n_act, 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
-			    hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rh_set_error("index build: device error"); return nullptr; }
-			if (cnt[7]) { rh_set_error("index build: %llu read(s) hold more event boundaries than their arrays", (unsigned long long)cnt[7]); return nullptr; }
+			if (hipMemcpyAsync(&n_g, c->rec_off.as<uint64_t>() + n_act, 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+			    hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rh_set_error("index build: device error"); return fail(); }
+			if (cnt[7]) { rh_set_error("index build: %llu read(s) hold more event boundaries than their arrays", (unsigned long long)cnt[7]); return fail(); }
+			if (seeds_reserve(n_seeds + n_g)) return fail();
+			rhk_seed_pack(s, rr, c->rec_off.as<uint64_t>(), done, (uint32_t*)dH + n_seeds, (uint64_t*)dY + n_seeds);
 		}
-		if (hipMalloc(&dH, (n_seeds + 1) * 4) != hipSuccess || hipMalloc(&dY, (n_seeds + 1) * 8) != hipSuccess) { rh_set_error("index build: out of device memory for %llu seeds", (unsigned long long)n_seeds); return fail(); }
-		if (n_act) rhk_seed_pack(s, rr, c->rec_off.as<uint64_t>(), (uint32_t*)dH, (uint64_t*)dY);
-		if (hipMemcpyAsync(lens.data(), rd.l_sig, (size_t)R * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rh_set_error("index build: device error"); return fail(); }
-	} else if (hipMalloc(&dH, 4) != hipSuccess || hipMalloc(&dY, 8) != hipSuccess) return fail();
+		if (hipMemcpyAsync(lens.data() + done, rd.l_sig, (size_t)m * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rh_set_error("index build: device error"); return fail(); }
+		n_seeds += n_g; done += m;
+	}
 	uint32_t max_len = 0;
 	for (uint32_t i = 0; i < R; ++i) { ix->lens.push_back(lens[i]); if (lens[i] > max_len) max_len = lens[i]; }
 	release_arenas(c);                                              // the rows of whole reads are large: back to the device before the sort

@@ -809,7 +809,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 			(void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]); (void)hipEventElapsedTime(&c, ev[2], ev[3]);
 			// records by the number of regions with holes of their range: <= 2 (closed form), 3..24, 25..64, 65..128, more
 			std::vector<uint32_t> nhv(n_rng); std::vector<bs_range> rv(n_rng);
-			(void)hipMemcpy2D(nhv.data(), 4, &C.meta[0].nh, sizeof(bs_meta), 4, n_rng, hipMemcpyDeviceToHost);
+			{ std::vector<bs_meta> mv(n_rng); (void)hipMemcpy(mv.data(), C.meta, (size_t)n_rng * sizeof(bs_meta), hipMemcpyDeviceToHost); for (uint32_t r = 0; r < n_rng; ++r) nhv[r] = mv[r].nh; }
 			(void)hipMemcpy(rv.data(), C.rng[0], (size_t)n_rng * sizeof(bs_range), hipMemcpyDeviceToHost);
 			uint64_t bins[5] = {0, 0, 0, 0, 0};
 			for (uint32_t r = 0; r < n_rng; ++r) bins[nhv[r] <= 2 ? 0 : nhv[r] <= 24 ? 1 : nhv[r] <= 64 ? 2 : nhv[r] <= 128 ? 3 : 4] += rv[r].n;

@@ -796,9 +796,9 @@ __global__ __launch_bounds__(NT) void k_probe(rh_dev_opt o, rh_dev_index ix, rh_
 		for (uint32_t i = grp; i < tn; i += NT / 8) {
 			const uint32_t hash = (uint32_t)(sx[t0 + i] >> 6);
 			uint64_t b = (uint64_t)((uint32_t)(hash * 0x9E3779B1u) >> (32 - ix.lg_buckets));
-			for (;;) {
+			for (uint64_t left = bmask + 1ull;; --left) {               // (an adopted table without a free slot must not hang the probe: bounded by its size)
 				const rh_tslot sl = ix.table[b * RH_TB_SLOTS + gl];
-				const bool hit = sl.n != 0 && sl.hash == hash, empty = sl.n == 0;
+				const bool hit = sl.n != 0 && sl.hash == hash, empty = sl.n == 0 || left == 0;
 				const uint32_t mh = (uint32_t)(__ballot(hit) >> gshift) & 0xFFu;
 				const uint32_t me = (uint32_t)(__ballot(empty) >> gshift) & 0xFFu;
 				if (mh) { if (hit) { s_n[i] = sl.n; s_val[i] = sl.val; } break; }
@@ -1065,11 +1065,11 @@ __global__ __launch_bounds__(1024) void k_seed_scan(rh_dev_round rr, uint64_t *o
 	uint64_t run = s_part[tid];
 	for (uint32_t i = b; i < e; ++i) { off[i] = run; run += rr.n_seed[i]; }
 }
-__global__ __launch_bounds__(NT) void k_seed_pack(rh_dev_round rr, const uint64_t *off, uint32_t *hash_out, uint64_t *pos_out)
+__global__ __launch_bounds__(NT) void k_seed_pack(rh_dev_round rr, const uint64_t *off, uint32_t id0, uint32_t *hash_out, uint64_t *pos_out)
 {
 	const uint32_t a = blockIdx.x;
 	if (a >= rr.n_act) return;
-	const uint32_t ns = rr.n_seed[a], id = rr.act[a];
+	const uint32_t ns = rr.n_seed[a], id = id0 + rr.act[a];
 	const uint64_t *sx = rr.sx + (size_t)a * rr.ev_cap, *sy = rr.sy + (size_t)a * rr.ev_cap;
 	for (uint32_t i = threadIdx.x; i < ns; i += NT) { hash_out[off[a] + i] = (uint32_t)(sx[i] >> 6); pos_out[off[a] + i] = (uint64_t)id << 32 | (uint32_t)sy[i]; }
 }
@@ -1218,7 +1218,7 @@ void rhk_carry_scan(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, 
 void rhk_carry_copy(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, const rh_mm128_t *staging, const uint64_t *dst_off, rh_mm128_t *carry) { if (n) RH_LAUNCH(k_carry_copy, n, NT, 0, s, rd, act, n, staging, dst_off, carry); }
 void rhk_finalize(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, rh_map_record_t *rec) { if (rd.n_reads) RH_LAUNCH(k_finalize, cdiv(rd.n_reads, 256), 256, 0, s, o, ix, rd, rec); }
 void rhk_seed_scan(hipStream_t s, const rh_dev_round &r, uint64_t *off) { RH_LAUNCH(k_seed_scan, 1, 1024, 0, s, r, off); }
-void rhk_seed_pack(hipStream_t s, const rh_dev_round &r, const uint64_t *off, uint32_t *hash_out, uint64_t *pos_out) { if (r.n_act) RH_LAUNCH(k_seed_pack, r.n_act, NT, 0, s, r, off, hash_out, pos_out); }
+void rhk_seed_pack(hipStream_t s, const rh_dev_round &r, const uint64_t *off, uint32_t id0, uint32_t *hash_out, uint64_t *pos_out) { if (r.n_act) RH_LAUNCH(k_seed_pack, r.n_act, NT, 0, s, r, off, id0, hash_out, pos_out); }
 void rhk_ava_rec_scan(hipStream_t s, const rh_dev_reads &rd, uint64_t *rec_off) { RH_LAUNCH(k_ava_rec_scan, 1, 1024, 0, s, rd, rec_off); }
 void rhk_finalize_ava(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_mm128_t *maps, const uint64_t *rec_off, rh_map_record_t *rec)
 { if (rd.n_reads) RH_LAUNCH(k_finalize_ava, cdiv(rd.n_reads, 256), 256, 0, s, o, ix, rd, maps, rec_off, rec); }

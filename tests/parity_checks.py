@@ -376,6 +376,7 @@ def check_ava(lib, case, directory, oracle_threads=4):
     import golden
     import oracle_lib as O
     from rawhash_amd.api import Context, Index, paf_lines
+    os.makedirs(str(directory), exist_ok=True)
     w = golden.build_ava_case(case, directory, lib)
     c = Context(0, lib=lib)
     try:

@@ -105,9 +105,11 @@ def test_rawsamble_all_vs_all_golden(emu_lib, tmp_path):
     assert pc.check_ava(emu_lib, case, tmp_path) > len(golden.expected_paf(case)) // 2
 
 
-def test_rawsamble_ragged_reads_golden(emu_lib, tmp_path):
+def test_rawsamble_ragged_reads_golden(emu_lib, tmp_path, monkeypatch):
     """The same with reads of very different lengths (row strides set by the longest), an empty read and reads too short for
-    min_events."""
+    min_events, under a row budget that cuts the read set into groups of a few reads (index build and mapping; the GPU suite
+    runs the same case in one group)."""
     import golden
     case = [c for c in golden.ava_cases() if c["name"] == "ava_ragged"][0]
-    pc.check_ava(emu_lib, case, tmp_path)
+    monkeypatch.setenv("RH_WHOLE_ROWS_MAX_SAMPLES", "70000")
+    pc.check_ava(emu_lib, case, tmp_path / "groups")
