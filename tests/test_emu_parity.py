@@ -91,10 +91,10 @@ def test_whole_read_rounds_golden(emu_lib, tmp_path):
     w = golden.build_case(case, tmp_path, emu_lib)
     c = Context(0, lib=emu_lib)
     c.upload(w.index)
-    sub = w.reads.subset(range(40))
+    sub = w.reads.subset(range(20))
     recs = c.map_batch(w.opts, sub)
     got = [O.strip_mt(x) for x in paf_lines(w.index, recs, sub.names, lib=emu_lib)]
-    assert got == golden.expected_paf(case)[:40]
+    assert got == golden.expected_paf(case)[:20]
     c.close()
 
 
@@ -111,5 +111,5 @@ def test_rawsamble_ragged_reads_golden(emu_lib, tmp_path, monkeypatch):
     runs the same case in one group)."""
     import golden
     case = [c for c in golden.ava_cases() if c["name"] == "ava_ragged"][0]
-    monkeypatch.setenv("RH_WHOLE_ROWS_MAX_SAMPLES", "70000")
+    monkeypatch.setenv("RH_WHOLE_ROWS_MAX_SAMPLES", "300000")
     pc.check_ava(emu_lib, case, tmp_path / "groups")
