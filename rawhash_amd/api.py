@@ -257,10 +257,11 @@ class Context:
         _check(self._l.rh_map_batch(self.h, C.byref(opts.mo), C.byref(b), ptr(out), cap, C.byref(n)), self._l)
         return out[: n.value]
 
-    def map_batch_multi(self, opts, reads, index, max_records=None):
+    def map_batch_multi(self, opts, reads, index, max_records=None, device_batch=None):
         """All-vs-all overlapping (ava presets): every reported chain of a read is a record.  Returns (records, offsets):
-        the records of read r are records[offsets[r]:offsets[r + 1]]."""
-        b = reads.batch()
+        the records of read r are records[offsets[r]:offsets[r + 1]].  `device_batch`: the same reads already resident in HBM
+        (a ReadBatch of device pointers); `reads` then only supplies the names."""
+        b = device_batch if device_batch is not None else reads.batch()
         qr, _ = index.name_ranks(reads.names)
         qr = np.ascontiguousarray(qr)
         b.name_rank = qr.ctypes.data if len(qr) else None
