@@ -787,7 +787,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		RH_LAUNCH(k_bs_scan, n_rng, NT, 0, s, C);
 		RH_LAUNCH(k_bs_holes, n_tiles, NT, 0, s, C);
 		// few ranges: a wavefront each (nothing to gain from 64 walks per wavefront); many: one lane each where the regions fit
-		const int lanes = n_rng >= (uint32_t)BS_LANES_MIN_RANGES, multi = !lanes && n_rng >= (uint32_t)BS_MULTI_MIN_RANGES;
+		const int lanes = n_rng >= (uint32_t)BS_LANES_MIN_RANGES, multi = !lanes && n_rng >= (uint32_t)BS_MULTI_MIN_RANGES && t < (1ull << 32);   // (k_bs_walk_multi keeps absolute hole addresses in 32 bits)
 		if (trace) (void)hipEventRecord(ev[1], s);
 		RH_LAUNCH(k_bs_walk_wave, n_rng, 64, 0, s, C, lanes ? 3u : multi ? 3u : 1u, lanes ? 256u : multi ? (uint32_t)BS_MW_NHM : 0u);
 		if (multi) {	// walks per wavefront: so that the level takes about one wavefront per SIMD (a walk's step time does not depend on how many lanes walk)
