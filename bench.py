@@ -257,28 +257,56 @@ def bench_ava(args):
     import numpy as np
     import oracle_lib as O
     from rawhash_amd import Context, Index, MapOptions, SynthWorkload, paf_lines, strip_mt
-    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
-        sys.exit("bench.py --workload ava runs on one GPU")
+    # N GPUs: the 50 k reads are the targets on every GPU (each rank builds the same signal-target index from them: a fraction of
+    # a second, no broadcast needed) and the queries are sharded: rank r overlaps its contiguous share of the reads against all
+    # of them.  Total work is fixed: "scaling": "strong".  No collective on the data path.
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("RH_BENCH_BACKEND", "nccl")
+        if os.environ.get("RH_BENCH_ONE_DEVICE"):
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend=backend)
     n = args.reads if args.reads > 0 else 50_000
     n_samples, genome, preset = 27_000, 1_000_000, "ava"
     cores = os.cpu_count() or 8
     shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
-    workdir = os.path.join(shm, f"rawhash_amd_bench_ava_{os.getpid()}")
+    workdir = os.path.join(shm, f"rawhash_amd_bench_ava_{os.getpid()}_{rank}")
     os.makedirs(workdir, exist_ok=True)
     wl = SynthWorkload(chrom_len=genome, n_chrom=1, n_samples=n_samples, junk_per_1024=50, noise_q24=150_000, read_seed=23)
     _, model = wl.write_reference(workdir)
     opts = MapOptions(preset)
-    reads = wl.reads(model, 0, n, n_threads=min(cores, 64), with_names=True)
-    ctx = Context(0)
+    targets = wl.reads(model, 0, n, n_threads=min(cores, 64), with_names=True)
+    ctx = Context(local_rank)
     t0 = time.perf_counter()
-    index = Index.build_signals_device(ctx, reads, model, opts)
+    index = Index.build_signals_device(ctx, targets, model, opts)
     t_index = time.perf_counter() - t0
     opts.update(index)
-    cap = 400 * n + 1024
-    dev = wl.reads_device(ctx, model, 0, n)                        # the same reads generated straight into HBM (resident when the timed region starts)
+    q0, q1 = n * rank // world, n * (rank + 1) // world             # this rank's queries
+    reads = targets if world == 1 else targets.subset(range(q0, q1))
+    cap = 400 * len(reads) + 1024
+    dev = wl.reads_device(ctx, model, q0, q1 - q0)                 # the same reads generated straight into HBM (resident when the timed region starts)
+
+    def sync():
+        if world > 1:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         recs, off = ctx.map_batch_multi(opts, reads, index, max_records=cap, device_batch=dev)
     stage_ms, stage_n, acc = {}, {}, {}
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         recs, off = ctx.map_batch_multi(opts, reads, index, max_records=cap, device_batch=dev)
@@ -289,41 +317,60 @@ def bench_ava(args):
         for k, (ms, c) in st["stages"].items():
             stage_ms[k] = stage_ms.get(k, 0.0) + ms
             stage_n[k] = stage_n.get(k, 0) + c
+    sync()
     elapsed = time.perf_counter() - t0
     elapsed_h2d = None
     if args.h2d:                                                   # the same steps from host memory: the int16 signal is uploaded inside every step
+        sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             recs_h, _ = ctx.map_batch_multi(opts, reads, index, max_records=cap)
+        sync()
         elapsed_h2d = time.perf_counter() - t0
         assert len(recs_h) == len(recs)
+    n_records = len(recs)
+    if world > 1:
+        import torch
+        t = torch.tensor([elapsed, elapsed_h2d or 0.0], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, elapsed_h2d = float(t[0].item()), (float(t[1].item()) or None)
+        c = torch.tensor([n_records], dtype=torch.int64, device=f"cuda:{local_rank}")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        n_records = int(c.item())
+    if rank != 0:
+        dist.barrier()
+        dist.destroy_process_group()
+        ctx.close()
+        import shutil
+        shutil.rmtree(workdir, ignore_errors=True)
+        return
     kernels = {k: v for k, v in stage_ms.items() if k in ALGO_BYTES and stage_n.get(k)}
     dom = max(kernels, key=kernels.get)
     dom_bytes = ALGO_BYTES[dom](acc)
     achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
     out = {
         "metric": "reads/sec overlapped all-vs-all (Rawsamble, signal-target index resident in HBM)", "value": round(n * args.steps / elapsed, 1), "unit": "reads/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None, "dtype": "int16 signal; fp32/fp64 events; u64/i32 seeding+chaining", "data": "synthetic",
         "config": {"workload": f"Rawsamble all-vs-all: {n} synthetic R9.4 reads x {n_samples} samples from a {genome} bp genome, preset {preset}, signal-target index built "
                                f"on the device from the same reads ({index.n_keys} keys, {index.n_positions} positions), int16 signal resident in HBM",
-                   "reads_per_gpu": n, "samples_per_read": n_samples, "mid_occ": int(opts.mo.mid_occ)},
+                   "reads_per_gpu": q1 - q0, "samples_per_read": n_samples, "mid_occ": int(opts.mo.mid_occ), "parallelism": f"queries sharded x{world}, index built on every GPU"},
         "value_h2d_included": None if not elapsed_h2d else round(n * args.steps / elapsed_h2d, 1),
-        "records_per_step": int(len(recs)), "overlaps_per_read": round(float((recs["mapped"] != 0).sum()) / n, 2),
+        "records_per_step": int(n_records),
         "index_build_s": round(t_index, 3), "value_with_index_build": round(n / (elapsed / args.steps + t_index), 1),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                      "avg_launch_ms": round(stage_ms[dom] / stage_n[dom], 4), "launches": stage_n[dom], "algorithmic_bytes_per_launch": int(dom_bytes / stage_n[dom])},
         "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items() if stage_n.get(k)},
     }
     sample = args.cpu_sample if args.cpu_sample >= 0 else 20000
-    if sample > 0 and O.have_reference():
+    if world == 1 and sample > 0 and O.have_reference():
         # the unmodified reference: its functions build the signal-target index of all reads (`ref_harness sigindex`), then its
         # kt_for(map_worker_for) overlaps the first `sample` reads against it; PAF of that sample compared with the device's
         try:
             sample = min(sample, n)
             rhr_all, rhr_s, ind = os.path.join(workdir, "all.rhr"), os.path.join(workdir, "sample.rhr"), os.path.join(workdir, "ref.ind")
-            reads.write(rhr_all, wl.cfg.digitisation, wl.cfg.range, wl.cfg.offset)
-            reads.subset(range(sample)).write(rhr_s, wl.cfg.digitisation, wl.cfg.range, wl.cfg.offset)
+            targets.write(rhr_all, wl.cfg.digitisation, wl.cfg.range, wl.cfg.offset)
+            targets.subset(range(sample)).write(rhr_s, wl.cfg.digitisation, wl.cfg.range, wl.cfg.offset)
             t0 = time.perf_counter()
             subprocess.run([O.REF_HARNESS, "sigindex", preset, rhr_all, model, ind, str(min(cores, 64))], check=True, stderr=subprocess.DEVNULL, timeout=3000)
             t_ref_index = time.perf_counter() - t0
@@ -346,6 +393,9 @@ def bench_ava(args):
         except Exception as e:
             out["cpu_baseline_error"] = repr(e)[:300]
     print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     ctx.close()
     import shutil
     shutil.rmtree(workdir, ignore_errors=True)

@@ -103,3 +103,32 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert 0.85 < d["mapped_fraction"] < 0.95 and d["value_h2d_included"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_ava_two_ranks_on_one_gpu():
+    """bench.py --workload ava on N > 1: every rank builds the signal-target index of all reads on its device and overlaps its
+    share of the queries (strong scaling, no collective on the data path) - two ranks sharing the test box's GPU over gloo; the
+    records of the two shards add up to the single-rank count."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RH_BENCH_BACKEND="gloo", RH_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["--workload", "ava", "--reads", "3000", "--steps", "2", "--warmup", "1", "--cpu-sample", "0"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2"] + args
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=850)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["records_per_step"] == d1["records_per_step"] > 3000
