@@ -550,10 +550,19 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 #endif
 	const sort_kc kc = { jb.kc_lo, jb.kc_mid, jb.kc_hi };
 	if (tid == 0) L.kc = kc;
-	for (uint32_t i = tid; i < n; i += NT) {
-		const uint64_t x = src[i].x;
-		if (sizeof(KT) == 8) L.key[i] = (KT)x;
-		else L.key[i] = (KT)((x & ((1ull << kc.lo_bits) - 1ull)) | ((x >> 32) & ((1ull << kc.mid_bits) - 1ull)) << kc.lo_bits | (kc.hi_bits ? x >> 63 : 0ull) << (kc.lo_bits + kc.mid_bits));
+	// (four loads in flight per thread: a workgroup's wall time is what its LDS footprint lets the CU overlap with three others)
+	for (uint32_t i0 = tid; i0 < n; i0 += 4 * NT) {
+		uint64_t xs[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; xs[u] = i < n ? src[i].x : 0ull; }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint32_t i = i0 + (uint32_t)u * NT;
+			const uint64_t x = xs[u];
+			if (i >= n) continue;
+			if (sizeof(KT) == 8) L.key[i] = (KT)x;
+			else L.key[i] = (KT)((x & ((1ull << kc.lo_bits) - 1ull)) | ((x >> 32) & ((1ull << kc.mid_bits) - 1ull)) << kc.lo_bits | (kc.hi_bits ? x >> 63 : 0ull) << (kc.lo_bits + kc.mid_bits));
+		}
 	}
 	for (uint32_t i = tid; i < CAP / 32 + 3; i += NT) L.tbit[i] = 0;
 	if (tid == 0) { L.tie = 0; L.n_tg = 0; }
@@ -563,7 +572,13 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 #ifdef RH_KPROF
 	kp_t0 = clock64();
 #endif
-	for (uint32_t i = tid; i < n; i += NT) dst[i] = src[L.ia[i]];
+	for (uint32_t i0 = tid; i0 < n; i0 += 4 * NT) {
+		rh_mm128_t rv[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; rv[u] = src[i < n ? L.ia[i] : 0u]; }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; if (i < n) dst[i] = rv[u]; }
+	}
 	KPROF(12);
 	if (mode != 0) return;
 	for (uint32_t i = tid; i < n; i += NT) {
