@@ -87,7 +87,7 @@ struct rh_ctx_s {
 	DevBuf carry[2], carry_off, a_off_slice;                      // chained anchors carried into the next chunk, dense, ping-pong over the rounds
 	int share = 1;                                                 // sub-batches running concurrently on this device (memory budget per context)
 	int flight_mult = 1;                                           // batches in flight that share the device with this context's
-	DevBuf sort_alt, sort_ws;                                     // multi-workgroup segment sorter: second record array + tables (only when a read exceeds the LDS classes)
+	DevBuf sort_ws;                                               // multi-workgroup segment sorter: tables (only when a read exceeds the LDS classes)
 	DevBuf sy_samples, sy_off, sy_cal_off, sy_cal_scale, sy_levels;
 	// timing
 	hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -243,14 +243,14 @@ int stage_anchors(rh_ctx *c, uint64_t total, rh_dev_round *rr, uint64_t room = 0
 	// segments longer than the LDS sort classes (large indexes): scratch of the multi-workgroup sorter
 	if (rr->max_anchors == 0 || rr->max_anchors > (uint32_t)RH_SORT_LDS_MIN_TOP) {
 		const size_t wsb = rhk_bigsort_ws_bytes(t, (uint32_t)RH_SORT_LDS_MIN_TOP);
-		if (c->sort_alt.ensure(t * 16, mg) || c->sort_ws.ensure(wsb, mg)) return -1;
+		if (c->sort_ws.ensure(wsb, mg)) return -1;
 		if (!c->pin) RH_HIP(hipHostMalloc((void**)&c->pin, 256, 0));
-		rr->sort_alt = c->sort_alt.as<rh_mm128_t>(); rr->sort_ws = c->sort_ws.as<unsigned char>(); rr->sort_ws_bytes = c->sort_ws.cap; rr->sort_pin = c->pin + 16; rr->sort_total = t;
+		rr->sort_ws = c->sort_ws.as<unsigned char>(); rr->sort_ws_bytes = c->sort_ws.cap; rr->sort_pin = c->pin + 16; rr->sort_total = t;
 	}
 	return 0;
 }
 // bytes of device memory a slice needs per anchor (the arrays above + the sorter's tables)
-const size_t kBytesPerAnchor = 16 * 4 + 8 + RH_WS_PER_ANCHOR + 16 + 18;
+const size_t kBytesPerAnchor = 16 * 4 + 8 + RH_WS_PER_ANCHOR + 18;
 
 // anchors one slice of a round may hold: what is free on the device (plus what this context's arenas hold already), shared
 // by the sub-batches running concurrently; RH_ARENA_MAX_BYTES caps the per-anchor scratch (shared devices, tests)
@@ -259,7 +259,7 @@ uint64_t slice_budget(rh_ctx *c)
 	size_t free_b = 0, total_b = 0;
 	uint64_t budget = ~0ull;
 	if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-		DevBuf *mine[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev_stage, &c->u, &c->ws, &c->sort_alt, &c->sort_ws};
+		DevBuf *mine[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev_stage, &c->u, &c->ws, &c->sort_ws};
 		size_t held = 0;
 		for (DevBuf *d : mine) held += d->cap;
 		const size_t reserve = total_b / 24 > ((size_t)3 << 30) ? total_b / 24 : ((size_t)3 << 30);
@@ -300,7 +300,7 @@ void release_arenas(rh_ctx *c)
 	(void)hipStreamSynchronize(c->stream);
 	DevBuf *all[] = {&c->raw, &c->off, &c->cal_off, &c->cal_scale, &c->act[0], &c->act[1], &c->zbuf, &c->t1buf, &c->t2buf, &c->n_norm, &c->peaks, &c->n_peaks, &c->ev, &c->n_ev, &c->skip, &c->sx, &c->sy,
 	                 &c->n_seed, &c->m_val, &c->m_n, &c->m_meta, &c->m_pref, &c->n_match, &c->n_new, &c->rep_len, &c->a_off, &c->anc, &c->raw_anc, &c->zs, &c->n_z, &c->need_exact, &c->need_exact2, &c->prev_stage,
-	                 &c->carry[0], &c->carry[1], &c->carry_off, &c->a_off_slice, &c->u, &c->n_u, &c->n_v, &c->ws, &c->sort_alt, &c->sort_ws, &c->rec};
+	                 &c->carry[0], &c->carry[1], &c->carry_off, &c->a_off_slice, &c->u, &c->n_u, &c->n_v, &c->ws, &c->sort_ws, &c->rec};
 	for (DevBuf *b : all) b->release();
 	for (DevBuf &b : c->st) b.release();
 	c->arena_room = 0;
@@ -359,7 +359,7 @@ extern "C" void rh_ctx_destroy(rh_ctx *c)
 	c->subs.clear();
 	DevBuf *all[] = {&c->logf_tab, &c->raw, &c->off, &c->cal_off, &c->cal_scale, &c->act[0], &c->act[1], &c->n_act_dev, &c->zbuf, &c->t1buf, &c->t2buf, &c->n_norm, &c->peaks, &c->n_peaks, &c->ev, &c->n_ev, &c->skip, &c->sx, &c->sy,
 	                 &c->n_seed, &c->m_val, &c->m_n, &c->m_meta, &c->m_pref, &c->n_match, &c->n_new, &c->rep_len, &c->a_off, &c->anc, &c->raw_anc, &c->zs, &c->n_z, &c->need_exact, &c->need_exact2, &c->prev_stage, &c->carry[0], &c->carry[1], &c->carry_off, &c->a_off_slice, &c->u,
-	                 &c->n_u, &c->n_v, &c->ws, &c->sort_alt, &c->sort_ws, &c->counters, &c->rec, &c->sy_samples, &c->sy_off, &c->sy_cal_off, &c->sy_cal_scale, &c->sy_levels};
+	                 &c->n_u, &c->n_v, &c->ws, &c->sort_ws, &c->counters, &c->rec, &c->sy_samples, &c->sy_off, &c->sy_cal_off, &c->sy_cal_scale, &c->sy_levels};
 	for (DevBuf *b : all) b->release();
 	for (DevBuf &b : c->st) b.release();
 	if (c->blob_owned) c->blob.release();
@@ -728,17 +728,9 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 			}
 			if (stage_anchors(c, stotal, &rs, cuts.size() > 2 ? budget : 0)) return -1;
 			if (cuts.size() > 2) c->arena_room = budget;
-			{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rs); }
-			{ StageTimer t(c, ST_SORT); if (rhk_sort(s, rs)) return -1; }
-			if (debug_rounds()) dump_round(c, chunk, n, rs);
-			{ StageTimer t(c, ST_CHAIN); rhk_chain(s, o, rs); }
-			{ StageTimer t(c, ST_ZSORT); if (rhk_zsort(s, o, rs)) return -1; }
-			{ StageTimer t(c, ST_BACKTRACK); if (rhk_backtrack(s, o, rd, rs)) return -1; }
-			{ StageTimer t(c, ST_RSORT); if (rhk_regions_sort(s, o, rd, rs)) return -1; }
-			{ StageTimer t(c, ST_REGIONS); rhk_regions(s, o, rd, rs, c->logf_tab.as<float>()); }
-			if (debug_rounds()) dump_round2(c, chunk, n, rs);
-			// the chained anchors the reads carry into their next chunk: staging arena -> dense carry buffer
-			{
+			// the chained anchors the reads carry into their next chunk: staging arena -> dense carry buffer (all-vs-all: the
+			// reported chains, which the region stage leaves there)
+			auto pack_carry = [&]() -> int {
 				StageTimer t(c, ST_COMPACT);
 				rhk_carry_scan(s, rd, rs.act, n, carry_used, c->carry_off.as<uint64_t>(), c->n_act_dev.as<uint64_t>() + 2);
 				RH_HIP(hipMemcpyAsync(c->pin + 4, c->n_act_dev.as<uint64_t>() + 2, 8, hipMemcpyDeviceToHost, s));
@@ -747,7 +739,19 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 				if (c->carry[which].ensure_keep((carry_used + add + 1) * 16, carry_used * 16, s)) return -1;
 				rhk_carry_copy(s, rd, rs.act, n, rs.prev_out, c->carry_off.as<uint64_t>(), c->carry[which].as<rh_mm128_t>());
 				carry_used += add;
-			}
+				return 0;
+			};
+			{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rs); }
+			{ StageTimer t(c, ST_SORT); if (rhk_sort(s, rs)) return -1; }
+			if (debug_rounds()) dump_round(c, chunk, n, rs);
+			{ StageTimer t(c, ST_CHAIN); rhk_chain(s, o, rs); }
+			{ StageTimer t(c, ST_ZSORT); if (rhk_zsort(s, o, rs)) return -1; }
+			{ StageTimer t(c, ST_BACKTRACK); if (rhk_backtrack(s, o, rd, rs)) return -1; }
+			if (!ava && pack_carry()) return -1;                      // (before the region sort: it borrows the staging arena)
+			{ StageTimer t(c, ST_RSORT); if (rhk_regions_sort(s, o, rd, rs)) return -1; }
+			{ StageTimer t(c, ST_REGIONS); rhk_regions(s, o, rd, rs, c->logf_tab.as<float>()); }
+			if (debug_rounds()) dump_round2(c, chunk, n, rs);
+			if (ava && pack_carry()) return -1;
 		}
 		{ StageTimer t(c, ST_COMPACT); rhk_compact_active(s, o, rd, rr.act, n_act, chunk + 1, c->act[cur ^ 1].as<uint32_t>(), c->n_act_dev.as<uint32_t>()); }
 		RH_HIP(hipMemcpyAsync(c->pin, c->n_act_dev.p, 4, hipMemcpyDeviceToHost, s));
@@ -823,7 +827,7 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 		if (map_batch_once(c, mo, in, out, out_cap, &n) == 0) { *n_out = n; return 0; }
 		if (!g_oom || R < 2) return -1;
 		fprintf(stderr, "[rawhash_amd] device memory exhausted while mapping %u reads (%s): retrying in halves\n", R, rh_last_error());
-		DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev_stage, &c->u, &c->ws, &c->sort_alt, &c->sort_ws};
+		DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev_stage, &c->u, &c->ws, &c->sort_ws};
 		(void)hipStreamSynchronize(c->stream);
 		for (DevBuf *d : big) d->release();
 		c->arena_room = 0;
@@ -841,7 +845,7 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 		if (map_batch_once(c, mo, &b, out + done, m, &n)) {
 			if (!g_oom || slice < 2) return -1;
 			slice /= 2;                                             // try smaller, from empty per-anchor arenas
-			DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev_stage, &c->u, &c->ws, &c->sort_alt, &c->sort_ws};
+			DevBuf *big[] = {&c->anc, &c->raw_anc, &c->zs, &c->prev_stage, &c->u, &c->ws, &c->sort_ws};
 			(void)hipStreamSynchronize(c->stream);
 			for (DevBuf *d : big) d->release();
 			c->arena_room = 0;

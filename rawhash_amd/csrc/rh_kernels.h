@@ -97,7 +97,7 @@ struct rh_dev_round {
 	uint64_t *u; uint32_t *n_u, *n_v;        // chains: score<<32 | count
 	rh_mm128_t *zs; uint32_t *n_z;           // backtrack candidates (score, anchor) in radix_sort_128x order
 	unsigned char *ws;               // RH_WS_PER_ANCHOR bytes per anchor
-	rh_mm128_t *sort_alt; unsigned char *sort_ws; size_t sort_ws_bytes; void *sort_pin; uint64_t sort_total;   // scratch of the multi-workgroup segment sorter (rh_bigsort.hip)
+	unsigned char *sort_ws; size_t sort_ws_bytes; void *sort_pin; uint64_t sort_total;   // tables of the multi-workgroup segment sorter (rh_bigsort.hip); its second record array is an arena idle at the time
 	uint64_t *counters;              // [0] events [1] seeds [2] hits [3] anchors [4] chained [5] samples used [6] chunks [7] chunks with more peaks than RH_EV_CAP (an error)
 };
 

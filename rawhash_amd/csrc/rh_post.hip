@@ -1088,7 +1088,8 @@ __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-static void sort_scratch(rh_sort_job &jb, const rh_dev_round &r) { jb.big_alt = r.sort_alt; jb.big_ws = r.sort_ws; jb.big_ws_bytes = r.sort_ws_bytes; jb.big_pin = r.sort_pin; jb.big_total = r.sort_total; }
+// the multi-workgroup sorter's second record array is whichever 16-byte-per-anchor arena is idle during that sort
+static void sort_scratch(rh_sort_job &jb, const rh_dev_round &r, rh_mm128_t *idle) { jb.big_alt = idle; jb.big_ws = r.sort_ws; jb.big_ws_bytes = r.sort_ws_bytes; jb.big_pin = r.sort_pin; jb.big_total = r.sort_total; }
 
 int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 {
@@ -1096,7 +1097,7 @@ int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 	RH_LAUNCH(k_zbuild, r.n_act, 64, 0, s, o, r);
 	// candidates (score, anchor index) -> reference order; scores are full of ties: exact permutation for every read
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_z, r.raw, r.zs, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 64, (uint8_t)(o.min_sc >= 0), 32, 0, 0, r.max_anchors };   // keys = scores >= min_sc: non-negative int32
-	sort_scratch(jb, r);
+	sort_scratch(jb, r, r.prev_out);                               // (the carry staging is written by k_chain_gather, later)
 	return rhk_sort_job(s, jb, true, 0u);
 }
 
@@ -1107,7 +1108,7 @@ int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, co
 	// compact_a: chains gathered, put into the reference's order of their first anchor, written back
 	RH_LAUNCH(k_chain_gather, r.n_act, NT, 0, s, r);
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };   // keys = first anchors
-	sort_scratch(jb, r);
+	sort_scratch(jb, r, r.anc);                                    // (k_chain_gather has copied every chain out of the sorted anchors; k_chain_reorder rewrites them)
 	if (rhk_sort_job(s, jb, false, 0u)) return -1;
 	RH_LAUNCH(k_chain_reorder, r.n_act, NT, 0, s, rd, r);
 	return 0;
@@ -1121,7 +1122,7 @@ int rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd,
 	if (!r.n_act || !regions_wave_ok(o)) return 0;
 	RH_LAUNCH(k_regions_prep, r.n_act, 64, 0, s, o, rd, r);
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, 0, 0, 0, 0, r.max_anchors };   // keys = hashed: full 64 bits
-	sort_scratch(jb, r);
+	sort_scratch(jb, r, r.prev_out);                               // (the carried anchors have left the staging: the round loop packs them before this sort)
 	return rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL);
 }
 

@@ -640,12 +640,12 @@ int rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t 
 	return 0;
 }
 
-static void sort_scratch(rh_sort_job &jb, const rh_dev_round &r) { jb.big_alt = r.sort_alt; jb.big_ws = r.sort_ws; jb.big_ws_bytes = r.sort_ws_bytes; jb.big_pin = r.sort_pin; jb.big_total = r.sort_total; }
+static void sort_scratch(rh_sort_job &jb, const rh_dev_round &r, rh_mm128_t *idle) { jb.big_alt = idle; jb.big_ws = r.sort_ws; jb.big_ws_bytes = r.sort_ws_bytes; jb.big_pin = r.sort_pin; jb.big_total = r.sort_total; }
 
 // anchor sort of a chunk round: unsorted expand output -> reference order
 int rhk_sort(hipStream_t s, const rh_dev_round &r)
 {
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, nullptr, r.raw, r.anc, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 0, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };
-	sort_scratch(jb, r);
+	sort_scratch(jb, r, r.zs);                                     // (the candidate array is idle until the chain DP has run)
 	return rhk_sort_job(s, jb, false, 0u);
 }
