@@ -632,6 +632,7 @@ __global__ __launch_bounds__(64) void k_bs_walk_multi(bs_ctx C)
 	uint64_t h = walker ? hd_[0] : 0;
 	for (;;) {
 		BS_MW_ISSUE_ALL()
+#pragma unroll 4
 		for (int it = 0; it < BS_MW_PERIOD; ++it) {
 			const uint32_t j = (uint32_t)h, hi = (uint32_t)(h >> 32);
 			const bool out = !inchase && j >= endk, stall = (hi & BS_INVALID) != 0;
