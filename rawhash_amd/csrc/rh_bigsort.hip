@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NT) void k_bs_plan(bs_ctx C)
 	}
 	const uint8_t alt = R.buf ^ 1;
 	if (fate == BS_SMALL) {
-		const uint32_t li = (uint32_t)alt * 2u + (s <= 32 ? 1u : 0u);   // the bucket's keys agree on every bit from s up
+		const uint32_t li = (uint32_t)alt * 2u + (s <= 32 && c <= (uint32_t)RH_SORT32_CAP3 ? 1u : 0u);   // the bucket's keys agree on every bit from s up (32-bit LDS keys, if that class takes it)
 		const uint32_t k = atomicAdd(&C.hdr[2 + li], 1u);
 		if (k < C.small_cap) { C.small_off[li][k] = R.beg + st; C.small_cnt[li][k] = c; }
 		else C.hdr[7] = 1;
