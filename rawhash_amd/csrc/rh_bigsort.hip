@@ -209,12 +209,26 @@ __global__ __launch_bounds__(NT) void k_bs_plan(bs_ctx C)
 		else fate = BS_BIG;
 	}
 	const uint8_t alt = R.buf ^ 1;
-	if (fate == BS_SMALL) {
-		const uint32_t li = (uint32_t)alt * 2u + (s <= 32 && c <= (uint32_t)RH_SORT32_CAP3 ? 1u : 0u);   // the bucket's keys agree on every bit from s up (32-bit LDS keys, if that class takes it)
-		const uint32_t k = atomicAdd(&C.hdr[2 + li], 1u);
-		if (k < C.small_cap) { C.small_off[li][k] = R.beg + st; C.small_cnt[li][k] = c; }
-		else C.hdr[7] = 1;
-	} else if (fate == BS_BIG) {
+	// Buckets for the block sorter go to one of two lists of the copy that holds them: 32-bit LDS keys when the bucket's keys
+	// agree on every bit from bit 32 up and that class takes a bucket of this size, 64-bit keys otherwise.  One atomic per
+	// wavefront and list (ranked by ballot): a level has up to a million such buckets.
+	const bool small = fate == BS_SMALL, narrow = small && s <= 32 && c <= (uint32_t)RH_SORT32_CAP3;
+#pragma unroll
+	for (int w = 0; w < 2; ++w) {
+		const bool mine = small && (narrow == (w == 1));
+		const uint64_t m = __ballot(mine);
+		if (m == 0) continue;
+		const uint32_t li = (uint32_t)alt * 2u + (uint32_t)w, leader = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+		uint32_t base = 0;
+		if (lane_id() == leader) base = atomicAdd(&C.hdr[2 + li], (uint32_t)__popcll(m));
+		base = __shfl(base, (int)leader);
+		if (mine) {
+			const uint32_t k = base + lanes_below(m);
+			if (k < C.small_cap) { C.small_off[li][k] = R.beg + st; C.small_cnt[li][k] = c; }
+			else C.hdr[7] = 1;
+		}
+	}
+	if (fate == BS_BIG) {
 		const uint32_t k = atomicAdd(&C.hdr[6], 1u);
 		if (k < C.rng_cap) {
 			bs_range q;

@@ -42,6 +42,7 @@ static inline void __threadfence() {}
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline double __shfl_down(double v, int d) { unsigned long long b; memcpy(&b, &v, 8); b = emu_shfl_down_bits(b, (unsigned)d); memcpy(&v, &b, 8); return v; }
 static inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
+static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline unsigned __shfl_up(unsigned v, int d) { return (unsigned)emu_shfl_bits(v, 3, (unsigned)d); }
 static inline unsigned __shfl_xor(unsigned v, int d) { return (unsigned)emu_shfl_bits(v, 4, (unsigned)d); }
 static inline unsigned long long __shfl_xor(unsigned long long v, int d) { return emu_shfl_bits(v, 4, (unsigned)d); }
