@@ -359,7 +359,7 @@ extern "C" void rh_ctx_destroy(rh_ctx *c)
 	c->subs.clear();
 	DevBuf *all[] = {&c->logf_tab, &c->raw, &c->off, &c->cal_off, &c->cal_scale, &c->act[0], &c->act[1], &c->n_act_dev, &c->zbuf, &c->t1buf, &c->t2buf, &c->n_norm, &c->peaks, &c->n_peaks, &c->ev, &c->n_ev, &c->skip, &c->sx, &c->sy,
 	                 &c->n_seed, &c->m_val, &c->m_n, &c->m_meta, &c->m_pref, &c->n_match, &c->n_new, &c->rep_len, &c->a_off, &c->anc, &c->raw_anc, &c->zs, &c->n_z, &c->need_exact, &c->need_exact2, &c->prev_stage, &c->carry[0], &c->carry[1], &c->carry_off, &c->a_off_slice, &c->u,
-	                 &c->n_u, &c->n_v, &c->ws, &c->sort_ws, &c->counters, &c->rec, &c->sy_samples, &c->sy_off, &c->sy_cal_off, &c->sy_cal_scale, &c->sy_levels};
+	                 &c->n_u, &c->n_v, &c->ws, &c->sort_ws, &c->counters, &c->rec, &c->sy_samples, &c->sy_off, &c->sy_cal_off, &c->sy_cal_scale, &c->sy_levels, &c->name_rank, &c->t_rank, &c->rec_off};
 	for (DevBuf *b : all) b->release();
 	for (DevBuf &b : c->st) b.release();
 	if (c->blob_owned) c->blob.release();
