@@ -36,6 +36,8 @@ AVA_CASES = [
     # BASELINE.json configs[4] in the small: reads of 3000 bases (27 k samples) drawn from a short genome so that they overlap
     {"name": "ava_small", "workload": dict(preset="ava", chrom_len=20_000, n_samples=27_000, n_reads=60, junk=50, noise=150_000, read_seed=21)},
     {"name": "ava_ragged", "workload": dict(preset="ava", chrom_len=15_000, n_samples=27_000, n_reads=64, junk=50, noise=150_000, read_seed=24, ragged=True)},
+    {"name": "ava_viral_small", "workload": dict(preset="ava-viral", chrom_len=12_000, n_samples=27_000, n_reads=40, junk=50, noise=150_000, read_seed=26)},
+    {"name": "ava_large_small", "workload": dict(preset="ava-large", chrom_len=20_000, n_samples=27_000, n_reads=48, junk=50, noise=150_000, read_seed=27)},
     {"name": "ava_sensitive_small", "workload": dict(preset="ava-sensitive", chrom_len=20_000, n_samples=27_000, n_reads=48, junk=50, noise=150_000, read_seed=22)},
 ]
 
