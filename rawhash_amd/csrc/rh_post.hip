@@ -184,6 +184,7 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 #ifndef CG_CAP
 #define CG_CAP 2048
 #endif
+#define CG_SHORT 8            // anchors a lane copies on its own when a read has more than CG_CAP chains
 __global__ __launch_bounds__(NT) void k_chain_gather(rh_dev_round rr)
 {
 	__shared__ uint32_t s_w[NT / 64];
@@ -213,11 +214,30 @@ __global__ __launch_bounds__(NT) void k_chain_gather(rh_dev_round rr)
 	// of an L2 array per slot otherwise)
 	const uint32_t *tab = ck0;
 	if (n_u <= CG_CAP) { for (uint32_t i = tid; i < n_u; i += NT) s_off[i] = ck0[i]; tab = s_off; __syncthreads(); }
-	for (uint32_t q = tid; q < n_v; q += NT) {
-		uint32_t lo = 0, hi = n_u;                                   // chain whose [ck0, ck0 + cnt) holds slot q
-		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tab[mid] <= q) lo = mid; else hi = mid; }
-		const uint32_t k0 = tab[lo], ni = (uint32_t)u[lo];
-		pa[q] = an[v[k0 + (ni - (q - k0) - 1)]];
+	if (n_u <= CG_CAP) {
+		for (uint32_t q = tid; q < n_v; q += NT) {
+			uint32_t lo = 0, hi = n_u;                               // chain whose [ck0, ck0 + cnt) holds slot q
+			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tab[mid] <= q) lo = mid; else hi = mid; }
+			const uint32_t k0 = tab[lo], ni = (uint32_t)u[lo];
+			pa[q] = an[v[k0 + (ni - (q - k0) - 1)]];
+		}
+	} else {
+		// thousands of chains (an unmappable read on a large index: ~2 anchors per chain): one lane per chain copies its few
+		// anchors - neighbouring lanes write neighbouring slots and nobody searches; a long chain is the whole wavefront's
+		const uint32_t l = lane_id();
+		for (uint32_t i0 = wave_id() * 64u; i0 < n_u; i0 += NT) {
+			const uint32_t i = i0 + l;
+			uint32_t k0 = 0, ni = 0;
+			if (i < n_u) { k0 = ck0[i]; ni = (uint32_t)u[i]; }
+			if (ni <= CG_SHORT) for (uint32_t j = 0; j < ni; ++j) pa[k0 + j] = an[v[k0 + (ni - j - 1)]];
+			uint64_t longm = __ballot(ni > CG_SHORT);
+			while (longm) {
+				const int src = __ffsll((unsigned long long)longm) - 1;
+				longm &= longm - 1;
+				const uint32_t kk = __shfl(k0, src), nn = __shfl(ni, src);
+				for (uint32_t j = l; j < nn; j += 64) pa[kk + j] = an[v[kk + (nn - j - 1)]];
+			}
+		}
 	}
 	__syncthreads();
 	for (uint32_t i = tid; i < n_u; i += NT) { rh_mm128_t e; e.x = pa[ck0[i]].x; e.y = (uint64_t)ck0[i] << 32 | (uint64_t)i; w[i] = e; }
@@ -253,10 +273,27 @@ __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_ro
 	__syncthreads();
 	const uint32_t *tab = dk;
 	if (n_u <= CG_CAP) { for (uint32_t i = tid; i < n_u; i += NT) s_off[i] = dk[i]; tab = s_off; __syncthreads(); }
-	for (uint32_t q = tid; q < n_v; q += NT) {
-		uint32_t lo = 0, hi = n_u;
-		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tab[mid] <= q) lo = mid; else hi = mid; }
-		an[q] = pa[(uint32_t)(w[lo].y >> 32) + (q - tab[lo])];
+	if (n_u <= CG_CAP) {
+		for (uint32_t q = tid; q < n_v; q += NT) {
+			uint32_t lo = 0, hi = n_u;
+			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tab[mid] <= q) lo = mid; else hi = mid; }
+			an[q] = pa[(uint32_t)(w[lo].y >> 32) + (q - tab[lo])];
+		}
+	} else {	// one lane per chain (see k_chain_gather)
+		const uint32_t l = lane_id();
+		for (uint32_t i0 = wave_id() * 64u; i0 < n_u; i0 += NT) {
+			const uint32_t i = i0 + l;
+			uint32_t from = 0, to = 0, ni = 0;
+			if (i < n_u) { from = (uint32_t)(w[i].y >> 32); to = dk[i]; ni = (uint32_t)u2[i]; }
+			if (ni <= CG_SHORT) for (uint32_t j = 0; j < ni; ++j) an[to + j] = pa[from + j];
+			uint64_t longm = __ballot(ni > CG_SHORT);
+			while (longm) {
+				const int src = __ffsll((unsigned long long)longm) - 1;
+				longm &= longm - 1;
+				const uint32_t ff = __shfl(from, src), tt = __shfl(to, src), nn = __shfl(ni, src);
+				for (uint32_t j = l; j < nn; j += 64) an[tt + j] = pa[ff + j];
+			}
+		}
 	}
 	for (uint32_t i = tid; i < n_u; i += NT) u[i] = u2[i];
 	if (tid == 0) {
