@@ -29,29 +29,31 @@ extern "C" __attribute__((visibility("default"))) int rh_debug_kprof_post(unsign
 #endif
 
 // ------------------------------------------------------------------------------------------------ k_zbuild
-__global__ __launch_bounds__(64) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
+__global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 {
-	const uint32_t a = blockIdx.x, lane = threadIdx.x;
+	__shared__ uint32_t s_w[NT / 64];
+	const uint32_t a = blockIdx.x, tid = threadIdx.x;
 	if (a >= rr.n_act) return;
-	if (rr.skip[a]) { if (lane == 0) rr.n_z[a] = 0; return; }
+	if (rr.skip[a]) { if (tid == 0) rr.n_z[a] = 0; return; }
 	const uint64_t base = rr.a_off[a];
 	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
 	const int32_t *fp = (const int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR);   // {f, p} interleaved
 	rh_mm128_t *z = rr.raw + base;               // the unsorted anchor copy is dead after the anchor sort
 	uint32_t *t4 = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)16 * n);   // backtrack's "touched" marks (1 B per anchor)
-	for (int32_t i = (int32_t)lane; i < (n + 3) / 4; i += 64) t4[i] = 0u;
+	for (int32_t i = (int32_t)tid; i < (n + 3) / 4; i += NT) t4[i] = 0u;
 	uint32_t *claim = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)20 * n);   // k_backtrack_spec's per-anchor claim stamps
-	for (int32_t i = (int32_t)lane; i < n; i += 64) claim[i] = 0u;
+	for (int32_t i = (int32_t)tid; i < n; i += NT) claim[i] = 0u;
 	uint32_t nz = 0;
-	for (int32_t i0 = 0; i0 < n; i0 += 64) {
-		const int32_t i = i0 + (int32_t)lane;
+	for (int32_t i0 = 0; i0 < n; i0 += NT) {                        // (a workgroup per read: an unmappable read on a large index has 10^5 anchors)
+		const int32_t i = i0 + (int32_t)tid;
 		const int32_t fi = i < n ? fp[2 * i] : INT32_MIN;
 		const bool ok = i < n && fi >= o.min_sc;
-		const uint64_t m = __ballot(ok);
-		if (ok) { rh_mm128_t e; e.x = (uint64_t)(int64_t)fi; e.y = (uint64_t)(uint32_t)i; z[nz + lanes_below(m)] = e; }
-		nz += (uint32_t)__popcll(m);
+		uint32_t tot;
+		const uint32_t rk = block_rank(ok, s_w, tot);
+		if (ok) { rh_mm128_t e; e.x = (uint64_t)(int64_t)fi; e.y = (uint64_t)(uint32_t)i; z[nz + rk] = e; }
+		nz += tot;
 	}
-	if (lane == 0) rr.n_z[a] = nz;
+	if (tid == 0) rr.n_z[a] = nz;
 }
 
 // ------------------------------------------------------------------------------------------------ backtrack
@@ -591,9 +593,10 @@ __global__ void k_regions_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, co
 #define RGW_COV 512
 
 // chain heads + sort keys (hit.c:111-120) for reads with more than RG_SMALL chains; heads -> scratch, keys -> rr.raw
-__global__ __launch_bounds__(64) void k_regions_prep(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
+__global__ __launch_bounds__(NT) void k_regions_prep(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
 {
-	const uint32_t a = blockIdx.x, lane = threadIdx.x;
+	__shared__ uint32_t s_w[NT / 64];
+	const uint32_t a = blockIdx.x, lane = threadIdx.x;               // (a workgroup per read: unmappable reads have tens of thousands of chains)
 	if (a >= rr.n_act || rr.skip[a]) return;
 	const int32_t n_u = (int32_t)rr.n_u[a];
 	if (n_u <= RG_SMALL) return;
@@ -607,13 +610,12 @@ __global__ __launch_bounds__(64) void k_regions_prep(rh_dev_opt o, rh_dev_reads 
 	hash ^= rh_wang32(rd.ev_off[r] + rr.n_ev[a]) + rh_wang32(11u);
 	hash = rh_wang32(hash);
 	uint32_t carry = 0;
-	for (int32_t i0 = 0; i0 < n_u; i0 += 64) {
+	for (int32_t i0 = 0; i0 < n_u; i0 += NT) {
 		const int32_t i = i0 + (int32_t)lane;
 		const uint64_t ui = i < n_u ? u[i] : 0ull;
 		const uint32_t cnt = (uint32_t)ui;
-		uint32_t inc = cnt;
-		for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= (uint32_t)d) inc += t; }
-		const uint32_t k = carry + inc - cnt;
+		uint32_t tot;
+		const uint32_t k = carry + block_excl_scan(cnt, s_w, tot);
 		if (i < n_u) {
 			const rh_mm128_t f0 = an[k], f1 = an[k + cnt - 1];
 			rh_chain_head h; h.x0 = f0.x; h.y0 = f0.y; h.x1 = (int32_t)f1.x; h.y1 = (int32_t)f1.y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(64) void k_regions_prep(rh_dev_opt o, rh_dev_reads 
 			rh_mm128_t e; e.x = ui ^ (uint64_t)hh; e.y = (uint64_t)(uint32_t)i;
 			z[i] = e;
 		}
-		carry += __shfl(inc, 63);
+		carry += tot;
 	}
 }
 
@@ -1131,7 +1133,7 @@ static void sort_scratch(rh_sort_job &jb, const rh_dev_round &r, rh_mm128_t *idl
 int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 {
 	if (!r.n_act) return 0;
-	RH_LAUNCH(k_zbuild, r.n_act, 64, 0, s, o, r);
+	RH_LAUNCH(k_zbuild, r.n_act, NT, 0, s, o, r);
 	// candidates (score, anchor index) -> reference order; scores are full of ties: exact permutation for every read
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_z, r.raw, r.zs, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 64, (uint8_t)(o.min_sc >= 0), 32, 0, 0, r.max_anchors };   // keys = scores >= min_sc: non-negative int32
 	sort_scratch(jb, r, r.prev_out);                               // (the carry staging is written by k_chain_gather, later)
@@ -1157,7 +1159,7 @@ static bool regions_wave_ok(const rh_dev_opt &o) { return o.best_n == 0 && o.pri
 int rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
 {
 	if (!r.n_act || !regions_wave_ok(o)) return 0;
-	RH_LAUNCH(k_regions_prep, r.n_act, 64, 0, s, o, rd, r);
+	RH_LAUNCH(k_regions_prep, r.n_act, NT, 0, s, o, rd, r);
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, 0, 0, 0, 0, r.max_anchors };   // keys = hashed: full 64 bits
 	sort_scratch(jb, r, r.prev_out);                               // (the carried anchors have left the staging: the round loop packs them before this sort)
 	return rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL);
