@@ -819,7 +819,8 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 			const size_t per_read = (size_t)(RH_CHUNK_MAX + 64) * 12 + (size_t)RH_EV_CAP * 44 + 4096;
 			size_t mine = holds_arenas(c) ? c->zbuf.cap + c->t1buf.cap + c->t2buf.cap + c->sx.cap + c->sy.cap + c->m_val.cap : 0;
 			const uint64_t lim = (uint64_t)(((double)free_b / (c->share > 0 ? c->share : 1) + (double)mine) / 3.0 / (double)per_read);
-			const uint32_t cap = lim > 0xFFFFFFFFull ? 0xFFFFFFFFu : (lim < 4096 ? 4096u : (uint32_t)lim);
+			uint32_t cap = lim > 0xFFFFFFFFull ? 0xFFFFFFFFu : (lim < 4096 ? 4096u : (uint32_t)lim);
+			if (const char *e = getenv("RH_CALL_READS_MAX")) { const uint32_t m = (uint32_t)strtoul(e, nullptr, 10); if (m && m < cap) cap = m; }   // (tests)
 			if (R > cap && (c->slice_hint == 0 || c->slice_hint > cap)) c->slice_hint = cap;
 		}
 	}

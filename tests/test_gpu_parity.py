@@ -319,6 +319,22 @@ def test_batch_sliced_when_arenas_do_not_fit(make_workload, product_lib, monkeyp
     assert sliced == whole and again == whole and len(whole) == 48
 
 
+def test_batch_in_consecutive_calls_when_rows_do_not_fit(make_workload, product_lib, monkeypatch):
+    """A batch whose event / seeding rows exceed the device (a million reads) is mapped in consecutive calls: forced here with a
+    limit of 13 reads per call on a 48-read batch, with and without sub-batches."""
+    w = make_workload(n_reads=48)
+    c = Context(0, lib=product_lib)
+    c.upload(w.index)
+    whole = c.map_batch(w.opts, w.reads)
+    c.close()
+    monkeypatch.setenv("RH_CALL_READS_MAX", "13")
+    c = Context(0, lib=product_lib)
+    c.upload(w.index)
+    cut = c.map_batch(w.opts, w.reads)
+    c.close()
+    assert np.array_equal(whole, cut) and len(cut) == 48
+
+
 def test_rawsamble_all_vs_all_golden(product_lib, tmp_path):
     """BASELINE.json configs[4] (Rawsamble) in the small: signal-target index built on the GPU = the reference's .ind byte for
     byte, all-vs-all overlaps = the reference's PAF (both presets of tests/golden/ava_cases.json)."""
