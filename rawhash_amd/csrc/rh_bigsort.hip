@@ -68,7 +68,7 @@ struct bs_ctx {
 	uint8_t *dg, *hd;                     // per record: digit; per hole: digit of its record
 	uint32_t *hp, *dest;                  // per hole: position in the range; hole (of the record's own region) it moves to
 	uint64_t *small_off[4]; uint32_t *small_cnt[4];   // segments for the block sorter, by (copy that holds them) * 2 + (keys differ below bit 32 only)
-	uint32_t *hdr;                        // [0] ranges of this level [1] tiles [2..5] block-sorter segments per list [6] next level's ranges [7] error
+	uint32_t *hdr;                        // [0] ranges of this level [1] tiles [2..5] block-sorter segments per list [6] next level's ranges [7] error [8..11] largest segment per list
 	uint32_t small_cap, rng_cap, n_lo;
 };
 
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(NT) void k_bs_init(rh_sort_job jb, bs_ctx C)
 		if (tid == 0) { s_run[0] += tot_r; s_run[1] += tot_t; }
 		__syncthreads();
 	}
-	if (tid == 0) { C.hdr[0] = s_run[0]; C.hdr[1] = s_run[1]; C.hdr[2] = 0; C.hdr[3] = 0; C.hdr[4] = 0; C.hdr[5] = 0; C.hdr[6] = 0; C.hdr[7] = s_run[0] > C.rng_cap ? 1u : 0u; }
+	if (tid == 0) { C.hdr[0] = s_run[0]; C.hdr[1] = s_run[1]; C.hdr[2] = 0; C.hdr[3] = 0; C.hdr[4] = 0; C.hdr[5] = 0; C.hdr[6] = 0; C.hdr[7] = s_run[0] > C.rng_cap ? 1u : 0u; C.hdr[8] = 0; C.hdr[9] = 0; C.hdr[10] = 0; C.hdr[11] = 0; }
 }
 
 __global__ __launch_bounds__(NT) void k_bs_clear(bs_ctx C)
@@ -220,7 +220,9 @@ __global__ __launch_bounds__(NT) void k_bs_plan(bs_ctx C)
 		if (m == 0) continue;
 		const uint32_t li = (uint32_t)alt * 2u + (uint32_t)w, leader = (uint32_t)__ffsll((unsigned long long)m) - 1u;
 		uint32_t base = 0;
-		if (lane_id() == leader) base = atomicAdd(&C.hdr[2 + li], (uint32_t)__popcll(m));
+		uint32_t cmax = mine ? c : 0u;                               // the list's largest bucket: the host launches no block-sorter class above it
+		for (int d = 32; d > 0; d >>= 1) { const uint32_t t = __shfl_xor(cmax, d); cmax = t > cmax ? t : cmax; }
+		if (lane_id() == leader) { base = atomicAdd(&C.hdr[2 + li], (uint32_t)__popcll(m)); atomicMax(&C.hdr[8 + li], cmax); }
 		base = __shfl(base, (int)leader);
 		if (mine) {
 			const uint32_t k = base + lanes_below(m);
@@ -787,7 +789,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	hipEvent_t ev[4] = {};
 	if (trace) for (auto &e : ev) (void)hipEventCreate(&e);
 	for (int level = 0; level < 9; ++level) {
-		RH_HIP(hipMemcpyAsync(pin, C.hdr, 32, hipMemcpyDeviceToHost, s));
+		RH_HIP(hipMemcpyAsync(pin, C.hdr, 48, hipMemcpyDeviceToHost, s));
 		RH_HIP(hipStreamSynchronize(s));
 		const uint32_t n_rng = pin[0], n_tiles = pin[1];
 		if (pin[7]) { rh_set_error("segment sorter: range / segment list overflow"); return -1; }
@@ -841,7 +843,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		if (!ns) continue;
 		rh_sort_job sj = jb;
 		sj.n_seg = ns; sj.skip = nullptr; sj.off = C.small_off[q]; sj.cnt = C.small_cnt[q];
-		sj.src = C.buf[q >> 1]; sj.dst = jb.dst; sj.need_exact = nullptr; sj.n_max = n_lo;
+		sj.src = C.buf[q >> 1]; sj.dst = jb.dst; sj.need_exact = nullptr; sj.n_max = pin[8 + q] < n_lo ? pin[8 + q] : n_lo;   // (an LDS class above the list's largest bucket would be a launch of blocks that all leave at once, each waiting for its LDS)
 		if ((q & 1) && !job32) { sj.kc_on = 1; sj.kc_lo = 32; sj.kc_mid = 0; sj.kc_hi = 0; }   // keys that differ below bit 32 only: 32-bit words in LDS
 		sj.big_alt = nullptr; sj.big_ws = nullptr;
 		rhk_sort_job(s, sj, all_exact, 1u);
