@@ -269,7 +269,10 @@ class Context:
         out = np.zeros(cap, dtype=RECORD)
         off = np.zeros(len(reads) + 1, dtype=np.uint64)
         n = C.c_uint64(0)
-        _check(self._l.rh_map_batch_multi(self.h, C.byref(opts.mo), C.byref(b), ptr(out), cap, ptr(off), C.byref(n)), self._l)
+        try:
+            _check(self._l.rh_map_batch_multi(self.h, C.byref(opts.mo), C.byref(b), ptr(out), cap, ptr(off), C.byref(n)), self._l)
+        finally:
+            b.name_rank = None      # qr dies with this frame: never leave its address in the caller's batch
         return out[: n.value], off
 
     def set_target_ranks(self, ranks):
@@ -283,10 +286,12 @@ class Context:
         out = np.zeros(max(cap, 1), dtype=RECORD)
         t = _capi.Ticket()
         _check(self._l.rh_map_submit(self.h, C.byref(opts.mo), C.byref(b), ptr(out), cap, C.byref(t)), self._l)
-        return (t, out, b)
+        # the ctypes struct holds raw pointers only: the handle keeps the source object (and with it the numpy arrays the
+        # background mapping thread reads) alive until map_wait
+        return (t, out, b, batch)
 
     def map_wait(self, handle):
-        t, out, _b = handle
+        t, out = handle[0], handle[1]
         n = C.c_uint64(0)
         _check(self._l.rh_map_wait(self.h, t, C.byref(n)), self._l)
         return out[: n.value]

@@ -48,7 +48,7 @@ struct DevBuf {
 	{
 		if (bytes <= cap) return 0;
 		DevBuf nb;
-		if (nb.ensure(bytes + bytes / 2)) { if (nb.ensure(bytes)) return -1; }
+		if (nb.ensure(bytes + bytes / 2)) { if (nb.ensure(bytes)) return -1; g_oom = false; }   // (the fallback fitted: no out-of-memory condition is pending)
 		if (p && used) { RH_HIP(hipMemcpyAsync(nb.p, p, used, hipMemcpyDeviceToDevice, s)); RH_HIP(hipStreamSynchronize(s)); }
 		if (p) (void)hipFree(p);
 		p = nb.p; cap = nb.cap; nb.p = nullptr;
@@ -400,8 +400,16 @@ int bind_blob(rh_ctx *c, const BlobHeader &h)
 }
 } // namespace
 
+// the resident blob may only be replaced while no rh_map_submit batch is mapping against it (the borrowed contexts alias it)
+static int index_replaceable(rh_ctx *c, const char *who)
+{
+	for (auto &f : c->flight) if (f.busy) { rh_set_error("%s: a batch is still in flight on this context (rh_map_wait first): the resident index cannot be replaced", who); return -1; }
+	return 0;
+}
+
 extern "C" int rh_index_upload(rh_ctx *c, const rh_index *ix)
 {
+	if (index_replaceable(c, "rh_index_upload")) return -1;
 	RH_HIP(hipSetDevice(c->device));
 	if (ix->e > 16 || ix->w > RH_DEV_MAXW) { rh_set_error("index parameters e=%d w=%d exceed the device sketch limits (e<=16, w<=%d)", ix->e, ix->w, RH_DEV_MAXW); return -1; }
 	std::vector<rh_tslot> slots;
@@ -418,7 +426,7 @@ extern "C" int rh_index_upload(rh_ctx *c, const rh_index *ix)
 	for (uint32_t L : ix->lens) if (L > h.max_len) h.max_len = L;
 	h.sp = rh_sketch_par{ix->e, ix->w, ix->q, ix->k, ix->diff, ix->fine_min, ix->fine_max, ix->fine_range};
 	if (!c->blob_owned) { c->blob.p = nullptr; c->blob.cap = 0; c->blob_owned = true; }
-	if (c->blob.ensure(h.bytes)) return -1;
+	if (c->blob.ensure(h.bytes, false)) return -1;                  // (an index is as large as it is: no growth margin)
 	unsigned char *base = c->blob.as<unsigned char>();
 	RH_HIP(hipMemcpy(base + h.table_off, slots.data(), slots.size() * sizeof(rh_tslot), hipMemcpyHostToDevice));
 	if (h.n_pos) RH_HIP(hipMemcpy(base + h.pos_off, ix->pos.data(), h.n_pos * 8, hipMemcpyHostToDevice));
@@ -448,6 +456,7 @@ extern "C" int rh_index_copy_blob(rh_ctx *c, void *dst)
 
 extern "C" int rh_index_adopt_blob(rh_ctx *c, const rh_index *, void *dev_ptr, uint64_t bytes, const void *header, int take_ownership)
 {
+	if (index_replaceable(c, "rh_index_adopt_blob")) return -1;
 	BlobHeader h; memcpy(&h, header, sizeof(h));
 	if (h.magic != kBlobMagic || h.bytes != bytes) { rh_set_error("index blob header mismatch"); return -1; }
 	{	// the offsets must describe three aligned, non-overlapping arrays inside the blob
@@ -465,6 +474,7 @@ extern "C" int rh_index_adopt_blob(rh_ctx *c, const rh_index *, void *dev_ptr, u
 extern "C" rh_index *rh_index_build_device(rh_ctx *c, uint32_t n_seq, const char *const *names, const char *const *seqs, const uint32_t *lens,
                                            const char *pore_model_path, const rh_idxopt_t *io, int n_threads)
 {
+	if (index_replaceable(c, "rh_index_build_device")) return nullptr;
 	if (hipSetDevice(c->device) != hipSuccess) { rh_set_error("hipSetDevice failed"); return nullptr; }
 	if (io->flag & RH_I_SIG_TARGET) { rh_set_error("signal-target (Rawsamble) indexes are built by rh_index_build_signals"); return nullptr; }
 	if (io->w != 0) { rh_set_error("minimiser indexes (w = %d) are built on the host: rh_index_build", io->w); return nullptr; }
@@ -809,7 +819,7 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 	if (out_cap < R) { rh_set_error("output capacity %llu < %u reads", (unsigned long long)out_cap, R); return -1; }
 	g_oom = false;
 	uint64_t n = 0;
-	uint32_t slice = R / 2, done = 0;
+	uint32_t slice = R / 2, done = 0, call_cap = 0xFFFFFFFFu;
 	// The event / seeding stages hold rows for every active read of a call (~140 KB each: z / t1 / t2 rows, peaks, events, seeds,
 	// matches): a call takes as many reads as fit a third of this context's share of the free memory (a million-read batch is
 	// mapped in a few consecutive calls; the anchor-sized stages have their own slices inside a call).
@@ -821,10 +831,12 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 			const uint64_t lim = (uint64_t)(((double)free_b / (c->share > 0 ? c->share : 1) + (double)mine) / 3.0 / (double)per_read);
 			uint32_t cap = lim > 0xFFFFFFFFull ? 0xFFFFFFFFu : (lim < 4096 ? 4096u : (uint32_t)lim);
 			if (const char *e = getenv("RH_CALL_READS_MAX")) { const uint32_t m = (uint32_t)strtoul(e, nullptr, 10); if (m && m < cap) cap = m; }   // (tests)
-			if (R > cap && (c->slice_hint == 0 || c->slice_hint > cap)) c->slice_hint = cap;
+			call_cap = cap;                                             // one hipMemGetInfo snapshot: a limit of this call only, never remembered
 		}
 	}
-	if (c->slice_hint == 0 || R <= c->slice_hint) {
+	const uint32_t hint = c->slice_hint && c->slice_hint < call_cap ? c->slice_hint : call_cap;
+	bool halved = false;
+	if (R <= hint) {
 		if (map_batch_once(c, mo, in, out, out_cap, &n) == 0) { *n_out = n; return 0; }
 		if (!g_oom || R < 2) return -1;
 		fprintf(stderr, "[rawhash_amd] device memory exhausted while mapping %u reads (%s): retrying in halves\n", R, rh_last_error());
@@ -832,7 +844,8 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 		(void)hipStreamSynchronize(c->stream);
 		for (DevBuf *d : big) d->release();
 		c->arena_room = 0;
-	} else slice = c->slice_hint;
+		halved = true;
+	} else slice = hint;
 	rh_map_stats_t tot{};
 	while (done < R) {
 		const uint32_t m = R - done < slice ? R - done : slice;
@@ -850,14 +863,14 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 			(void)hipStreamSynchronize(c->stream);
 			for (DevBuf *d : big) d->release();
 			c->arena_room = 0;
-		c->arena_room = 0;
+			halved = true;
 			continue;
 		}
 		for (uint32_t i = 0; i < m; ++i) out[done + i].read_idx += done;
 		add_stats(tot, c->stats);
 		done += m;
 	}
-	c->slice_hint = slice;
+	if (halved || (c->slice_hint && slice < c->slice_hint)) c->slice_hint = slice;   // only what an out-of-memory retry taught us sticks
 	c->stats = tot;
 	*n_out = R;
 	return 0;
@@ -1015,6 +1028,7 @@ extern "C" void rh_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
 extern "C" int rh_index_bcast(rh_ctx *const *ctxs, int n)
 {
 	if (n < 1 || need_index(ctxs[0])) return -1;
+	for (int i = 0; i < n; ++i) if (index_replaceable(ctxs[i], "rh_index_bcast")) return -1;
 	rh_ctx *src = ctxs[0];
 	BlobHeader h; memcpy(&h, src->header, sizeof(h));
 	for (int i = 1; i < n; ++i) {
@@ -1022,10 +1036,25 @@ extern "C" int rh_index_bcast(rh_ctx *const *ctxs, int n)
 		RH_HIP(hipSetDevice(d->device));
 		if (d->blob_owned) d->blob.release(); else { d->blob.p = nullptr; d->blob.cap = 0; }
 		d->blob_owned = true; d->have_index = false;
-		if (d->blob.ensure(h.bytes)) return -1;
-		RH_HIP(hipMemcpyPeer(d->blob.p, d->device, src->blob.p, src->device, h.bytes));
-		if (bind_blob(d, h)) return -1;
+		if (d->blob.ensure(h.bytes, false)) return -1;
 	}
+	// doubling tree 0 -> 1, {0,1} -> {2,3}, {0..3} -> {4..7}: every GPU that holds the blob feeds one that does not, each copy over
+	// its own point-to-point xGMI link, ceil(log2 n) rounds of one blob time instead of n - 1 copies out of GPU 0
+	std::vector<hipStream_t> st((size_t)n, nullptr);
+	int rc = 0;
+	for (int have = 1; have < n && !rc; have *= 2) {
+		const int m = have < n - have ? have : n - have;
+		for (int i = 0; i < m && !rc; ++i) {
+			rh_ctx *a = ctxs[i], *b = ctxs[have + i];
+			if (hipSetDevice(a->device) != hipSuccess) { rc = -1; break; }
+			if (!st[i] && hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) { rc = -1; break; }
+			if (hipMemcpyPeerAsync(b->blob.p, b->device, a->blob.p, a->device, h.bytes, st[i]) != hipSuccess) rc = -1;
+		}
+		for (int i = 0; i < m; ++i) if (st[i]) { (void)hipSetDevice(ctxs[i]->device); if (hipStreamSynchronize(st[i]) != hipSuccess) rc = -1; }
+	}
+	for (int i = 0; i < n; ++i) if (st[i]) { (void)hipSetDevice(ctxs[i]->device); (void)hipStreamDestroy(st[i]); }
+	if (rc) { rh_set_error("rh_index_bcast: a peer copy of the index blob failed: %s", hipGetErrorString(hipGetLastError())); return -1; }
+	for (int i = 1; i < n; ++i) { RH_HIP(hipSetDevice(ctxs[i]->device)); if (bind_blob(ctxs[i], h)) return -1; }
 	RH_HIP(hipSetDevice(src->device));
 	return 0;
 }
@@ -1336,6 +1365,7 @@ extern "C" rh_index *rh_index_build_signals_device(rh_ctx *c, const rh_read_batc
                                                    const rh_idxopt_t *io, const rh_mapopt_t *mo)
 {
 	if (hipSetDevice(c->device) != hipSuccess) { rh_set_error("hipSetDevice failed"); return nullptr; }
+	if (index_replaceable(c, "rh_index_build_signals_device")) return nullptr;
 	if (!(io->flag & RH_I_SIG_TARGET)) { rh_set_error("rh_index_build_signals_device builds signal-target indexes (RH_I_SIG_TARGET, the ava presets)"); return nullptr; }
 	if (io->e < 1 || io->e > 16 || io->q < 1 || io->q * io->e > 64 || io->w < 0 || io->w > RH_DEV_MAXW) { rh_set_error("unsupported index parameters e=%d q=%d w=%d", io->e, io->q, io->w); return nullptr; }
 	const uint32_t R = in->n_reads;

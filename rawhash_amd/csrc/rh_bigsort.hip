@@ -690,6 +690,109 @@ __global__ __launch_bounds__(64) void k_bs_walk_multi(bs_ctx C)
 	#undef BS_MW_COMMIT_ALL
 }
 
+// k_bs_walk_tok<RPL>: one WAVEFRONT per range, one LANE per region (RPL regions per lane: up to 64 * RPL regions with holes), and
+// the token itself in scalar registers.  A region's state - the index of its next hole and the digits waiting in it and in the one
+// after it - are VGPRs of its lane; a step is two v_readlane (digit and hole of the region the token stands on) and a handful of
+// scalar instructions, the only dependency chain being v_readlane -> SGPR -> lane select of the next v_readlane (~60 cycles on
+// gfx950, against ~800 for a step of the LDS-resident walkers above: a level costs its LONGEST range x the step time, and the late
+// rounds' unmappable reads have ranges of 10^5 holes).  The lane of the popped region advances on its own: the digit after next
+// comes from its 64-byte LDS ring two pops of the region ahead of its use, so no LDS latency is on the chain (consecutive pops are
+// never in the same region).  The rings are refilled as in k_bs_walk_multi - aligned 16-byte loads issued at the start of a period
+// of BS_TK_PERIOD = 32 pops, committed at its end - and never run dry: a region is popped at most every other step, 16 times a
+// period, and a commit leaves >= 33 digits (or the rest of the region) ahead of its pointer as it was when the loads were issued.
+// dest[] leaves through two log registers (lane t = the t-th pop's hole and successor), stored 64 entries at a time.
+// Everything the token touches must stay wave-uniform: one lane-dependent branch out of the walk loop and the compiler keeps every
+// token register in a VGPR (a v_readfirstlane per use).
+#define BS_TK_PERIOD 32
+template <int RPL>
+__global__ __launch_bounds__(64) void k_bs_walk_tok(bs_ctx C, uint32_t nh_lo, uint32_t nh_hi)
+{
+	static_assert(BS_TK_PERIOD == 32 && BS_MW_RING == 64, "the no-underflow argument above is for these");
+	__shared__ __attribute__((aligned(16))) uint8_t s_win[RPL * 64 * BS_MW_RING];
+	const uint32_t lane = threadIdx.x, r = blockIdx.x;
+	if (r >= C.hdr[0]) return;
+	bs_meta &M = C.meta[r];
+	const uint32_t nh = M.nh;
+	if (nh < nh_lo || nh > nh_hi) return;
+	const uint32_t beg = (uint32_t)C.rng[0][r].beg;                 // (the host takes this kernel only when every absolute hole address fits 32 bits)
+	uint32_t *dest = C.dest + beg;
+	// this lane's regions: q = lane + 64 t
+	bool on[RPL];
+	uint32_t jr[RPL], en[RPL], lim[RPL], head[RPL], nxt[RPL], ra[RPL], ld_n[RPL];   // next hole (index in the range), end of the region's holes, ring committed up to (absolute), digits at jr / jr + 1, LDS address of the digit at jr + 2
+	uint4 la[RPL], lb[RPL];
+#pragma unroll
+	for (int t = 0; t < RPL; ++t) {
+		const uint32_t q = lane + 64u * (uint32_t)t;
+		on[t] = q < nh;
+		jr[t] = 0; en[t] = 0; lim[t] = 0; head[t] = 0; nxt[t] = 0; ra[t] = 0; ld_n[t] = 0; la[t] = uint4{0, 0, 0, 0}; lb[t] = uint4{0, 0, 0, 0};
+		if (on[t]) { const uint32_t dk = M.act[q]; jr[t] = M.hst[dk]; en[t] = M.hst[dk + 1u]; lim[t] = (beg + jr[t]) & ~15u; }
+	}
+	#define BS_TK_RING(t) ((uint32_t)(lane + 64u * (uint32_t)(t)) * (uint32_t)BS_MW_RING)
+	#define BS_TK_ISSUE() _Pragma("unroll") for (int t = 0; t < RPL; ++t) { \
+		ld_n[t] = 0; \
+		if (on[t]) { const uint32_t pa_ = (beg + jr[t]) & ~15u, lm_ = lim[t], ea_ = beg + en[t]; \
+		             if (lm_ < ea_ && lm_ + 16u - pa_ <= (uint32_t)BS_MW_RING) { ld_n[t] = 1; if (lm_ + 16u < ea_ && lm_ + 32u - pa_ <= (uint32_t)BS_MW_RING) ld_n[t] = 2; } \
+		             if (ld_n[t] >= 1) la[t] = *reinterpret_cast<const uint4*>(C.hd + lm_); \
+		             if (ld_n[t] >= 2) lb[t] = *reinterpret_cast<const uint4*>(C.hd + lm_ + 16u); } }
+	#define BS_TK_COMMIT() do { _Pragma("unroll") for (int t = 0; t < RPL; ++t) { \
+		if (on[t] && ld_n[t]) { const uint32_t lm_ = lim[t]; \
+		             *reinterpret_cast<uint4*>(s_win + BS_TK_RING(t) + (lm_ & (BS_MW_RING - 1u))) = la[t]; \
+		             if (ld_n[t] == 2) *reinterpret_cast<uint4*>(s_win + BS_TK_RING(t) + ((lm_ + 16u) & (BS_MW_RING - 1u))) = lb[t]; \
+		             lim[t] = lm_ + 16u * ld_n[t]; } } \
+		RH_WAVE_SYNC(); } while (0)
+	#define BS_TK_READ(arr, sl, ln) (RPL == 1 ? rh_readlane(arr[0], ln) : (sl) == 0u ? rh_readlane(arr[0], ln) : (sl) == 1u ? rh_readlane(arr[RPL > 1 ? 1 : 0], ln) : (sl) == 2u ? rh_readlane(arr[RPL > 2 ? 2 : 0], ln) : rh_readlane(arr[RPL > 3 ? 3 : 0], ln))
+	BS_TK_ISSUE() BS_TK_COMMIT();
+	BS_TK_ISSUE() BS_TK_COMMIT();                                    // rings full: 64 bytes from each region's first hole on
+#pragma unroll
+	for (int t = 0; t < RPL; ++t)
+		if (on[t]) { const uint32_t a_ = beg + jr[t]; head[t] = s_win[BS_TK_RING(t) + (a_ & 63u)]; nxt[t] = s_win[BS_TK_RING(t) + ((a_ + 1u) & 63u)]; ra[t] = BS_TK_RING(t) + ((a_ + 2u) & 63u); }
+	BS_TK_ISSUE()
+	// The token.  The loop nest is the reference's (ksort.h:124-138): for each base region k, for each of its holes, chase the
+	// record found there until one that belongs to k turns up.
+	uint32_t k = 0, nlog = 0, per = BS_TK_PERIOD;
+	uint32_t logA = 0, logV = 0;
+	#define BS_TK_LOG(a_, v_) do { logA = rh_writelane(logA, (a_), nlog); logV = rh_writelane(logV, (v_), nlog); if (++nlog == 64u) { dest[logA] = logV; nlog = 0; } } while (0)
+	// pop region c_: d_ = the digit in its next hole, j_ = that hole; the region's lane moves on
+	#define BS_TK_POP(c_, d_, j_) do { \
+		const uint32_t l_ = (c_) & 63u, sl_ = RPL == 1 ? 0u : (c_) >> 6; \
+		if (per == 0u) { BS_TK_COMMIT(); BS_TK_ISSUE() per = BS_TK_PERIOD; }   /* a period is over: commit the loads in flight, issue the next */ \
+		--per; \
+		d_ = BS_TK_READ(head, sl_, l_); j_ = BS_TK_READ(jr, sl_, l_); \
+		_Pragma("unroll") for (int t = 0; t < RPL; ++t) \
+			if (lane == l_ && sl_ == (uint32_t)t) { \
+				head[t] = nxt[t]; \
+				nxt[t] = s_win[ra[t]]; \
+				ra[t] = (ra[t] & ~63u) | ((ra[t] + 1u) & 63u); \
+				jr[t] += 1u; \
+			} \
+		} while (0)
+	while (k < nh) {
+		const uint32_t lk = k & 63u, sk = RPL == 1 ? 0u : k >> 6;
+		const uint32_t endk = BS_TK_READ(en, sk, lk);
+		if (k) { const uint32_t jk = BS_TK_READ(jr, sk, lk); if (lane == 0) { const uint32_t dk = M.act[k]; M.J[dk] = jk - M.hst[dk]; } }   // arrivals so far = J
+		while (BS_TK_READ(jr, sk, lk) < endk) {                      // until region k has no hole left (then the next one becomes the base)
+			uint32_t d, i0, j;
+			BS_TK_POP(k, d, i0);                                      // the hole that starts a cycle (its record belongs elsewhere: d != k)
+			uint32_t prev = i0;
+			do {
+				const uint32_t c = d;
+				BS_TK_POP(c, d, j);
+				BS_TK_LOG(prev, j);                                   // the record carried from `prev` lands in this hole
+				prev = j;
+			} while (d != k);
+			BS_TK_LOG(prev, i0);                                      // ... and the one that belongs to k in the hole the cycle started from
+		}
+		++k;
+	}
+	if (lane < nlog) dest[logA] = logV;
+	#undef BS_TK_LOG
+	#undef BS_TK_POP
+	#undef BS_TK_RING
+	#undef BS_TK_ISSUE
+	#undef BS_TK_COMMIT
+	#undef BS_TK_READ
+}
+
 // ------------------------------------------------------------------------------------------------ K8: placement
 __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 {
@@ -786,13 +889,16 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	RH_LAUNCH(k_bs_init, 1, NT, 0, s, jb, C);
 	uint32_t *pin = (uint32_t*)jb.big_pin;
 	static const bool trace = getenv("RH_BS_TRACE") != nullptr;   // development aid: per-level launch shapes and times on stderr
+	static const bool walk_old = getenv("RH_BS_WALK_OLD") != nullptr;   // development aid: the LDS-resident walkers instead of the scalar-token one
+	static const uint32_t tok_max = getenv("RH_BS_TOK_MAX") ? (uint32_t)strtoul(getenv("RH_BS_TOK_MAX"), nullptr, 10) : 0xFFFFFFFFu;
+	static const bool tok4 = getenv("RH_BS_TOK4") != nullptr;       // development aid: four regions per lane for ranges with more than 64 regions that have holes
 	hipEvent_t ev[4] = {};
 	if (trace) for (auto &e : ev) (void)hipEventCreate(&e);
 	for (int level = 0; level < 9; ++level) {
 		RH_HIP(hipMemcpyAsync(pin, C.hdr, 48, hipMemcpyDeviceToHost, s));
 		RH_HIP(hipStreamSynchronize(s));
 		const uint32_t n_rng = pin[0], n_tiles = pin[1];
-		if (pin[7]) { rh_set_error("segment sorter: range / segment list overflow"); return -1; }
+		if (pin[7]) { rh_set_error(pin[7] == 2 ? "segment sorter: a token walk made no progress" : "segment sorter: range / segment list overflow"); return -1; }
 		if (n_rng == 0) break;
 		if (trace) (void)hipEventRecord(ev[0], s);
 		RH_LAUNCH(k_bs_tile_map, (n_tiles + NT - 1) / NT, NT, 0, s, C);
@@ -805,7 +911,13 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		RH_LAUNCH(k_bs_holes, n_tiles, NT, 0, s, C);
 		// few ranges: a wavefront each (nothing to gain from 64 walks per wavefront); many: one lane each where the regions fit
 		const int lanes = n_rng >= (uint32_t)BS_LANES_MIN_RANGES, multi = !lanes && n_rng >= (uint32_t)BS_MULTI_MIN_RANGES && t < (1ull << 32);   // (k_bs_walk_multi keeps absolute hole addresses in 32 bits)
+		const int tok = !lanes && !walk_old && t < (1ull << 32) && n_rng <= tok_max;   // scalar token, one lane per region (absolute hole addresses in 32 bits): levels too narrow for the walks to fill the chip
 		if (trace) (void)hipEventRecord(ev[1], s);
+		if (tok) {
+			RH_LAUNCH(k_bs_walk_wave, n_rng, 64, 0, s, C, 3u, tok4 ? 256u : 64u);   // two regions with holes: closed form (and, measured faster there, more than 64: one LDS-resident walker per wavefront)
+			RH_LAUNCH((k_bs_walk_tok<1>), n_rng, 64, 0, s, C, 3u, 64u);
+			if (tok4) RH_LAUNCH((k_bs_walk_tok<4>), n_rng, 64, 0, s, C, 65u, 256u);
+		} else {
 		RH_LAUNCH(k_bs_walk_wave, n_rng, 64, 0, s, C, lanes ? 3u : multi ? 3u : 1u, lanes ? 256u : multi ? (uint32_t)BS_MW_NHM : 0u);
 		if (multi) {	// walks per wavefront: so that the level takes about one wavefront per SIMD (a walk's step time does not depend on how many lanes walk)
 			if (n_rng > (uint32_t)BS_MW_G32_FROM) RH_LAUNCH((k_bs_walk_multi<BS_MW_NHM, 32>), (n_rng + 31) / 32, 64, 0, s, C);
@@ -816,6 +928,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 			RH_LAUNCH((k_bs_walk_lanes<24, 64>), (n_rng + 63) / 64, 64, 0, s, C, 2u);
 			RH_LAUNCH((k_bs_walk_lanes<64, 32>), (n_rng + 31) / 32, 64, 0, s, C, 24u);
 			RH_LAUNCH((k_bs_walk_lanes<256, 8>), (n_rng + 7) / 8, 64, 0, s, C, 64u);   // LDS: 24 B per region and walker (36 / 48 / 48 KB)
+		}
 		}
 		if (trace) (void)hipEventRecord(ev[2], s);
 		RH_LAUNCH(k_bs_scatter, ((n_tiles + 7) / 8) * 8, NT, 0, s, C);
@@ -846,7 +959,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		sj.src = C.buf[q >> 1]; sj.dst = jb.dst; sj.need_exact = nullptr; sj.n_max = pin[8 + q] < n_lo ? pin[8 + q] : n_lo;   // (an LDS class above the list's largest bucket would be a launch of blocks that all leave at once, each waiting for its LDS)
 		if ((q & 1) && !job32) { sj.kc_on = 1; sj.kc_lo = 32; sj.kc_mid = 0; sj.kc_hi = 0; }   // keys that differ below bit 32 only: 32-bit words in LDS
 		sj.big_alt = nullptr; sj.big_ws = nullptr;
-		rhk_sort_job(s, sj, all_exact, 1u);
+		if (rhk_sort_job(s, sj, all_exact, 1u)) return -1;
 	}
 	return 0;
 }

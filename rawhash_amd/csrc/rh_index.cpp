@@ -264,7 +264,9 @@ bool write_ind(const rh_index_s &ix, const char *path)
 		fwrite(&size, 4, 1, fp);
 		fwrite(kv.data(), 8, kv.size(), fp);
 	}
-	fclose(fp);
+	// a full disk must not leave a silently truncated index behind: stdio keeps the first write error in the stream
+	const bool bad = ferror(fp) != 0;
+	if (fclose(fp) != 0 || bad) { rh_set_error("%s: write failed (disk full?)", path); return false; }
 	return true;
 }
 

@@ -196,7 +196,7 @@ extern "C" int rh_reads_write_blow5(const char *path, uint32_t n, const char *co
 		fwrite(out, 1, rsz, fp);
 	}
 	fwrite("5WOLB", 1, 5, fp);
-	fclose(fp);
+	{ const bool bad = ferror(fp) != 0; if (fclose(fp) != 0 || bad) { rh_set_error("%s: write failed (disk full?)", path); return -1; } }
 	return 0;
 }
 
@@ -229,6 +229,6 @@ extern "C" int rh_reads_write(const char *path, uint32_t n, const char *const *n
 		fwrite(&digitisation, 8, 1, fp); fwrite(&range, 8, 1, fp); fwrite(&offset, 8, 1, fp);
 		fwrite(samples + offsets[i], 2, ns, fp);
 	}
-	fclose(fp);
+	{ const bool bad = ferror(fp) != 0; if (fclose(fp) != 0 || bad) { rh_set_error("%s: write failed (disk full?)", path); return -1; } }
 	return 0;
 }

@@ -69,6 +69,7 @@ static inline unsigned rh_wave_shr1(unsigned v, unsigned first) { const unsigned
 static inline int rh_quad_perm_0022(int v) { return (int)emu_shfl_bits((unsigned)v, 5, (threadIdx.x & 63u) & ~1u); }
 static inline int rh_quad_perm_1133(int v) { return (int)emu_shfl_bits((unsigned)v, 5, (threadIdx.x & 63u) | 1u); }
 #define RH_WAVE_SYNC() ((void)emu_ballot(1))
+#define RH_SGPR(x) ((void)0)
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
@@ -94,6 +95,7 @@ static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyPeer(void *d, int, const void *s, int, size_t n) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, int) { *s = (void*)1; return hipSuccess; }
