@@ -40,7 +40,9 @@ struct bs_range {
 	uint32_t tile0;                       // first tile of the range in this level's tile numbering
 	uint8_t buf;                          // which copy holds it: 0 = job source, 1 = alt
 	uint8_t shift;                        // highest byte shift this level may split on
-	uint8_t pad[6];
+	uint8_t has_dg;                       // its digits were written by the placement of the level above (at the byte predicted from dmask)
+	uint8_t pad[5];
+	uint64_t dmask;                       // has_dg: bits on which the keys of the PARENT range differ below the parent's byte - a superset of this range's
 };
 
 // per-range tables of a level
@@ -65,7 +67,7 @@ struct bs_ctx {
 	bs_meta *meta;
 	uint32_t *tile_h;                     // per tile: holes -> (after the scan) holes of the range before the tile
 	uint32_t *tile_rng;                   // per tile: its range
-	uint8_t *dg, *hd;                     // per record: digit; per hole: digit of its record
+	uint8_t *dg, *dg_next, *hd;           // per record: digit (this level's / written for the next level's ranges); per hole: digit of its record
 	uint32_t *hp, *dest;                  // per hole: position in the range; hole (of the record's own region) it moves to
 	uint64_t *small_off[4]; uint32_t *small_cnt[4];   // segments for the block sorter, by (copy that holds them) * 2 + (keys differ below bit 32 only)
 	uint32_t *hdr;                        // [0] ranges of this level [1] tiles [2..5] block-sorter segments per list [6] next level's ranges [7] error [8..11] largest segment per list
@@ -104,8 +106,8 @@ __global__ __launch_bounds__(NT) void k_bs_init(rh_sort_job jb, bs_ctx C)
 		const uint32_t tk = block_excl_scan(big ? (n + BS_TILE - 1) / BS_TILE : 0u, s_w, tot_t);
 		if (big) {
 			bs_range q;
-			q.beg = jb.off[a]; q.n = n; q.tile0 = s_run[1] + tk; q.buf = 0; q.shift = 56;
-			for (int i = 0; i < 6; ++i) q.pad[i] = 0;
+			q.beg = jb.off[a]; q.n = n; q.tile0 = s_run[1] + tk; q.buf = 0; q.shift = 56; q.has_dg = 0; q.dmask = 0;
+			for (int i = 0; i < 5; ++i) q.pad[i] = 0;
 			if (s_run[0] + rk < C.rng_cap) C.rng[0][s_run[0] + rk] = q;
 		}
 		__syncthreads();
@@ -121,7 +123,9 @@ __global__ __launch_bounds__(NT) void k_bs_clear(bs_ctx C)
 	if (r >= C.hdr[0]) return;
 	bs_meta &M = C.meta[r];
 	M.cnt[tid] = 0; M.inpl[tid] = 0;
-	if (tid == 0) { M.k_or = 0; M.k_and = ~0ull; }
+	// a range whose digits came with it: its keys are not read again; the parent's differing bits stand in for its own (their
+	// highest byte is the byte the digits were taken from; k_bs_fix looks at the keys if the range turns out to agree on it)
+	if (tid == 0) { const bs_range R = C.rng[0][r]; if (R.has_dg) { M.k_or = R.dmask; M.k_and = 0; } else { M.k_or = 0; M.k_and = ~0ull; } }
 }
 
 // ------------------------------------------------------------------------------------------------ K1: OR / AND of the keys
@@ -133,6 +137,7 @@ __global__ __launch_bounds__(NT) void k_bs_diff(bs_ctx C)
 	if (blockIdx.x >= C.hdr[1]) return;
 	const uint32_t r = bs_find_range(C, blockIdx.x, n_rng, &s_r);
 	const bs_range R = C.rng[0][r];
+	if (R.has_dg) return;
 	const uint32_t t0 = (blockIdx.x - R.tile0) * BS_TILE;
 	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
 	uint64_t vo = 0, va = ~0ull;
@@ -179,13 +184,50 @@ __global__ __launch_bounds__(NT) void k_bs_hist(bs_ctx C)
 	for (int it = 0; it < BS_TILE_IT; ++it) {
 		const uint32_t p = t0 + (uint32_t)it * NT + tid;
 		if (p < R.n) {
-			const uint32_t d = s < 0 ? 0u : (uint32_t)(src[p].x >> s) & 255u;
-			dg[p] = (uint8_t)d;
+			uint32_t d;
+			if (R.has_dg) d = dg[p];
+			else { d = s < 0 ? 0u : (uint32_t)(src[p].x >> s) & 255u; dg[p] = (uint8_t)d; }
 			atomicAdd(&s_cnt[d], 1u);
 		}
 	}
 	__syncthreads();
 	if (s_cnt[tid]) atomicAdd(&C.meta[r].cnt[tid], s_cnt[tid]);
+}
+
+// K2b: a range that came with its digits (has_dg) and turns out to agree on the byte they were taken from - its histogram has one
+// bucket - is the one case where the parent's differing bits said too much: its own keys are read after all (one workgroup per
+// range; rare - a target whose hits fall into one 16 Mbp stretch, a score byte with one value), OR / AND, histogram and digits redone
+__global__ __launch_bounds__(NT) void k_bs_fix(bs_ctx C)
+{
+	__shared__ uint64_t s_red[2 * (NT / 64)];
+	__shared__ uint32_t s_w[NT / 64];
+	const uint32_t r = blockIdx.x, tid = threadIdx.x;
+	if (r >= C.hdr[0]) return;
+	const bs_range R = C.rng[0][r];
+	if (!R.has_dg) return;
+	bs_meta &M = C.meta[r];
+	uint32_t nb;
+	(void)block_rank(M.cnt[tid] != 0, s_w, nb);
+	if (nb != 1 || R.n < 2) return;
+	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
+	uint64_t vo = 0, va = ~0ull;
+	for (uint32_t p = tid; p < R.n; p += NT) { const uint64_t k = src[p].x; vo |= k; va &= k; }
+	for (int d = 32; d > 0; d >>= 1) { vo |= __shfl_xor(vo, d); va &= __shfl_xor(va, d); }
+	if (lane_id() == 0) { s_red[2 * wave_id()] = vo; s_red[2 * wave_id() + 1] = va; }
+	__syncthreads();
+	for (uint32_t q = 0; q < NT / 64; ++q) { vo |= s_red[2 * q]; va &= s_red[2 * q + 1]; }
+	const uint64_t diff = vo & ~va;
+	int s = -1;
+	if (diff) { s = (63 - __clzll(diff)) & ~7; if (s > (int)R.shift) s = (int)R.shift; }
+	M.cnt[tid] = 0;
+	__syncthreads();
+	if (tid == 0) { M.k_or = vo; M.k_and = va; }
+	uint8_t *dg = C.dg + R.beg;
+	for (uint32_t p = tid; p < R.n; p += NT) {
+		const uint32_t d = s < 0 ? 0u : (uint32_t)(src[p].x >> s) & 255u;
+		dg[p] = (uint8_t)d;
+		atomicAdd(&M.cnt[d], 1u);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------ K3: regions, fates, children
@@ -202,9 +244,12 @@ __global__ __launch_bounds__(NT) void k_bs_plan(bs_ctx C)
 	const uint32_t st = block_excl_scan(c, s_w, total);
 	M.start[tid] = st;
 	if (tid == 0) { M.start[256] = total; M.s = s; }
+	// bits on which the range's keys differ below this level's byte: what its buckets can still differ on (none: every bucket is
+	// final; else their highest byte is where the placement takes the next level's digits from)
+	const uint64_t low = s > 0 ? (M.k_or & ~M.k_and) & ((1ull << s) - 1ull) : 0ull;
 	uint8_t fate = BS_EMPTY;
 	if (c) {
-		if (s <= 0 || c == 1) fate = BS_FINAL;                    // all keys equal, last byte done, or a single record
+		if (s <= 0 || c == 1 || low == 0) fate = BS_FINAL;        // all keys equal, last byte done, nothing below differs, or a single record
 		else if (c <= C.n_lo) fate = BS_SMALL;
 		else fate = BS_BIG;
 	}
@@ -234,8 +279,8 @@ __global__ __launch_bounds__(NT) void k_bs_plan(bs_ctx C)
 		const uint32_t k = atomicAdd(&C.hdr[6], 1u);
 		if (k < C.rng_cap) {
 			bs_range q;
-			q.beg = R.beg + st; q.n = c; q.tile0 = 0; q.buf = alt; q.shift = (uint8_t)(s - 8);
-			for (int i = 0; i < 6; ++i) q.pad[i] = 0;
+			q.beg = R.beg + st; q.n = c; q.tile0 = 0; q.buf = alt; q.shift = (uint8_t)(s - 8); q.has_dg = 1; q.dmask = low;
+			for (int i = 0; i < 5; ++i) q.pad[i] = 0;
 			C.rng[1][k] = q;
 		} else C.hdr[7] = 1;
 	}
@@ -816,6 +861,11 @@ __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
 	rh_mm128_t *out_alt = C.buf[R.buf ^ 1] + R.beg, *out_fin = C.dst + R.beg;
 	const uint32_t *hp = C.hp + R.beg, *dest = C.dest + R.beg;
+	// the buckets that are next-level ranges get their digits now, while the record is in a register: the byte they will be
+	// split on is the highest one on which this range's keys differ below its own byte
+	uint8_t *dgn = C.dg_next + R.beg;
+	int ps = 0;
+	{ const uint64_t low = M.s > 0 ? (M.k_or & ~M.k_and) & ((1ull << M.s) - 1ull) : 0ull; if (low) ps = (63 - __clzll(low)) & ~7; }
 #pragma unroll
 	for (int it = 0; it < BS_TILE_IT; ++it) {
 		const uint32_t p = t0 + (uint32_t)it * NT + tid;
@@ -829,7 +879,9 @@ __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 			else np = hp[j];
 		}
 		const rh_mm128_t rec = src[p];
-		if (s_fate[d] == BS_FINAL) out_fin[np] = rec; else out_alt[np] = rec;
+		const uint32_t ft = s_fate[d];
+		if (ft == BS_FINAL) out_fin[np] = rec; else out_alt[np] = rec;
+		if (ft == BS_BIG) dgn[np] = (uint8_t)(rec.x >> ps);
 	}
 }
 
@@ -861,7 +913,7 @@ size_t rhk_bigsort_ws_bytes(uint64_t total, uint32_t n_lo)
 	b += 2 * ((rng_cap * sizeof(bs_range) + 255) & ~(size_t)255);
 	b += (rng_cap * sizeof(bs_meta) + 255) & ~(size_t)255;
 	b += 2 * ((tiles * 4 + 255) & ~(size_t)255);
-	b += 2 * ((t + 128 + 255) & ~(size_t)255);                      // dg, hd
+	b += 3 * ((t + 128 + 255) & ~(size_t)255);                      // dg (two: this level's and the next one's), hd
 	b += 2 * ((t * 4 + 255) & ~(size_t)255);                       // hp, dest
 	b += 4 * ((small_cap * 8 + 255) & ~(size_t)255) + 4 * ((small_cap * 4 + 255) & ~(size_t)255);
 	return b;
@@ -882,7 +934,8 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	C.rng[0] = (bs_range*)take((size_t)C.rng_cap * sizeof(bs_range)); C.rng[1] = (bs_range*)take((size_t)C.rng_cap * sizeof(bs_range));
 	C.meta = (bs_meta*)take((size_t)C.rng_cap * sizeof(bs_meta));
 	C.tile_h = (uint32_t*)take(tiles_cap * 4); C.tile_rng = (uint32_t*)take(tiles_cap * 4);
-	C.dg = (uint8_t*)take(t); C.hd = (uint8_t*)take(t + 128);   // (+64: the lane walkers read whole aligned words around a pointer)
+	uint8_t *dgb[2] = { (uint8_t*)take(t + 128), (uint8_t*)take(t + 128) };
+	C.hd = (uint8_t*)take(t + 128);   // (+64: the lane walkers read whole aligned words around a pointer)
 	C.hp = (uint32_t*)take(t * 4); C.dest = (uint32_t*)take(t * 4);
 	for (int q = 0; q < 4; ++q) { C.small_off[q] = (uint64_t*)take((size_t)C.small_cap * 8); C.small_cnt[q] = (uint32_t*)take((size_t)C.small_cap * 4); }
 	if ((size_t)(p - jb.big_ws) > jb.big_ws_bytes) { rh_set_error("segment sorter: scratch of %zu bytes is too small (%zu needed)", jb.big_ws_bytes, (size_t)(p - jb.big_ws)); return -1; }
@@ -901,10 +954,12 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		if (pin[7]) { rh_set_error(pin[7] == 2 ? "segment sorter: a token walk made no progress" : "segment sorter: range / segment list overflow"); return -1; }
 		if (n_rng == 0) break;
 		if (trace) (void)hipEventRecord(ev[0], s);
+		C.dg = dgb[level & 1]; C.dg_next = dgb[(level & 1) ^ 1];
 		RH_LAUNCH(k_bs_tile_map, (n_tiles + NT - 1) / NT, NT, 0, s, C);
 		RH_LAUNCH(k_bs_clear, n_rng, NT, 0, s, C);
 		RH_LAUNCH(k_bs_diff, n_tiles, NT, 0, s, C);
 		RH_LAUNCH(k_bs_hist, n_tiles, NT, 0, s, C);
+		if (level) RH_LAUNCH(k_bs_fix, n_rng, NT, 0, s, C);
 		RH_LAUNCH(k_bs_plan, n_rng, NT, 0, s, C);
 		RH_LAUNCH(k_bs_count, n_tiles, NT, 0, s, C);
 		RH_LAUNCH(k_bs_scan, n_rng, NT, 0, s, C);
