@@ -229,6 +229,10 @@ RH_API int  rh_chain_batch(rh_ctx *ctx, const rh_mapopt_t *mo, uint32_t n_reads,
                            rh_mm128_t *prev_out /* the *_a copy = next chunk's prev_anchors, may be NULL */);
 /* radix_sort_128x ksort.h:101-151 (exact, unstable permutation) on independent segments */
 RH_API int  rh_sort128x_batch(rh_ctx *ctx, uint32_t n_seg, rh_mm128_t *a, const uint64_t *offsets);
+/* the same sort the way the region keys of mm_gen_regs (hit.c:111-126: score << 32 | count ^ 32-bit hash, practically never equal) take
+   it: segments beyond the LDS classes are placed level by level in any order (a sorted order without equal keys is unique), then
+   checked; has_ties[s] = 1 for the long segments that do hold equal keys and have to be redone with rh_sort128x_batch's exact passes */
+RH_API int  rh_sort128x_any_batch(rh_ctx *ctx, uint32_t n_seg, rh_mm128_t *a, const uint64_t *offsets, uint8_t *has_ties);
 
 /* ------------------------------------------------------------------------------------------- PAF (host) */
 /* One PAF line per record exactly as rmap.cpp:740-783 prints it; `mt_ms` fills the mt:f: tag (wall clock in the

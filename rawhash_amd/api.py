@@ -360,6 +360,14 @@ class Context:
         _check(self._l.rh_sort128x_batch(self.h, len(off) - 1, ptr(a), ptr(off)), self._l)
         return a
 
+    def sort128x_any(self, arr, offsets):
+        """The sorter's any-order path (region keys): returns (sorted copy, has_ties per segment)."""
+        a = np.ascontiguousarray(arr, dtype=MM128).copy()
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ties = np.zeros(max(len(off) - 1, 1), dtype=np.uint8)
+        _check(self._l.rh_sort128x_any_batch(self.h, len(off) - 1, ptr(a), ptr(off), ptr(ties)), self._l)
+        return a, ties[: len(off) - 1]
+
 
 def paf_lines(index, recs, names, mt_ms=0.0, lib=None):
     """PAF text of the records exactly as rmap.cpp:740-783 prints it (mt:f: filled with mt_ms)."""

@@ -1278,6 +1278,33 @@ extern "C" int rh_sort128x_batch(rh_ctx *c, uint32_t n_seg, rh_mm128_t *a, const
 	return 0;
 }
 
+extern "C" int rh_sort128x_any_batch(rh_ctx *c, uint32_t n_seg, rh_mm128_t *a, const uint64_t *offsets, uint8_t *has_ties)
+{
+	// the sorter's path for keys that are almost never equal (region keys, hit.c:111-126): long segments are placed level by level in
+	// any order, then checked for equal neighbours; has_ties[s] = 1 for the long segments the caller would redo with the exact passes
+	RH_HIP(hipSetDevice(c->device));
+	const uint64_t total = n_seg ? offsets[n_seg] : 0;
+	rh_dev_round rr{};
+	if (stage_round(c, n_seg, &rr) || stage_anchors(c, total, &rr)) return -1;
+	std::vector<uint8_t> skip(n_seg ? n_seg : 1, 0);
+	if (h2d(rr.raw, a, total) || h2d(rr.a_off, offsets, (size_t)n_seg + 1) || h2d(rr.skip, skip.data(), n_seg)) return -1;
+	rh_sort_job jb = { rr.n_act, rr.skip, rr.a_off, nullptr, rr.raw, rr.anc, rr.need_exact2, rr.ws, RH_WS_PER_ANCHOR, 0, 0, 0, 0, 0, rr.max_anchors };
+	jb.big_alt = rr.zs; jb.big_ws = rr.sort_ws; jb.big_ws_bytes = rr.sort_ws_bytes; jb.big_pin = rr.sort_pin; jb.big_total = rr.sort_total;
+	uint32_t n_redo = 0;
+	jb.any_order = 1; jb.redo_skip = rr.need_exact; jb.n_redo = &n_redo;
+	RH_HIP(hipMemset(rr.need_exact, 1, n_seg ? n_seg : 1));
+	if (rhk_sort_job(c->stream, jb, false, 0u)) return -1;
+	RH_HIP(hipStreamSynchronize(c->stream));
+	RH_HIP(hipGetLastError());
+	if (total) RH_HIP(hipMemcpy(a, rr.anc, total * 16, hipMemcpyDeviceToHost));
+	std::vector<uint8_t> rs;
+	if (d2h(rs, rr.need_exact, n_seg)) return -1;
+	uint32_t cnt = 0;
+	for (uint32_t i = 0; i < n_seg; ++i) { has_ties[i] = rs[i] ? 0 : 1; cnt += has_ties[i]; }
+	if (cnt != n_redo) { rh_set_error("any-order sort: %u segments flagged, %u counted", cnt, n_redo); return -1; }
+	return 0;
+}
+
 // =================================================================================================== synthetic batch in HBM
 extern "C" int rh_synth_reads_device(rh_ctx *c, const rh_synth_cfg_t *cfg, const char *model_path, uint64_t first, uint32_t n, rh_read_batch_t *out)
 {

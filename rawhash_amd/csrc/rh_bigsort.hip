@@ -114,7 +114,7 @@ __global__ __launch_bounds__(NT) void k_bs_init(rh_sort_job jb, bs_ctx C)
 		if (tid == 0) { s_run[0] += tot_r; s_run[1] += tot_t; }
 		__syncthreads();
 	}
-	if (tid == 0) { C.hdr[0] = s_run[0]; C.hdr[1] = s_run[1]; C.hdr[2] = 0; C.hdr[3] = 0; C.hdr[4] = 0; C.hdr[5] = 0; C.hdr[6] = 0; C.hdr[7] = s_run[0] > C.rng_cap ? 1u : 0u; C.hdr[8] = 0; C.hdr[9] = 0; C.hdr[10] = 0; C.hdr[11] = 0; }
+	if (tid == 0) { C.hdr[0] = s_run[0]; C.hdr[1] = s_run[1]; C.hdr[2] = 0; C.hdr[3] = 0; C.hdr[4] = 0; C.hdr[5] = 0; C.hdr[6] = 0; C.hdr[7] = s_run[0] > C.rng_cap ? 1u : 0u; C.hdr[8] = 0; C.hdr[9] = 0; C.hdr[10] = 0; C.hdr[11] = 0; C.hdr[12] = 0; }
 }
 
 __global__ __launch_bounds__(NT) void k_bs_clear(bs_ctx C)
@@ -885,6 +885,68 @@ __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 	}
 }
 
+// K8': placement in any order (jobs whose keys are almost never equal: the sorted order of a segment without ties is unique, so
+// neither the holes nor the walk are needed): a tile counts its digits in LDS, reserves a stretch of every bucket it feeds with one
+// atomic on the range's cursor and drops its records there.  Which tile gets which stretch is decided by the scheduler - harmless
+// for distinct keys; segments that do hold equal keys are found afterwards (k_bs_tiecheck) and redone with the exact passes.
+__global__ __launch_bounds__(NT) void k_bs_scatter_any(bs_ctx C)
+{
+	__shared__ uint32_t s_r;
+	__shared__ uint32_t s_start[256], s_cnt[256], s_base[256];
+	__shared__ uint8_t s_fate[256];
+	const uint32_t n_rng = C.hdr[0], tid = threadIdx.x, tile = blockIdx.x;
+	if (tile >= C.hdr[1]) return;
+	const uint32_t r = bs_find_range(C, tile, n_rng, &s_r);
+	const bs_range R = C.rng[0][r];
+	bs_meta &M = C.meta[r];
+	s_start[tid] = M.start[tid]; s_fate[tid] = M.fate[tid]; s_cnt[tid] = 0;
+	__syncthreads();
+	const uint32_t t0 = (tile - R.tile0) * BS_TILE;
+	const uint8_t *dg = C.dg + R.beg;
+	uint32_t d[BS_TILE_IT], lr[BS_TILE_IT];
+#pragma unroll
+	for (int it = 0; it < BS_TILE_IT; ++it) {
+		const uint32_t p = t0 + (uint32_t)it * NT + tid;
+		d[it] = 0; lr[it] = 0;
+		if (p < R.n) { d[it] = dg[p]; lr[it] = atomicAdd(&s_cnt[d[it]], 1u); }
+	}
+	__syncthreads();
+	if (s_cnt[tid]) s_base[tid] = atomicAdd(&M.inpl[tid], s_cnt[tid]);      // (inpl: zeroed by k_bs_clear, otherwise unused on this path)
+	__syncthreads();
+	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
+	rh_mm128_t *out_alt = C.buf[R.buf ^ 1] + R.beg, *out_fin = C.dst + R.beg;
+	uint8_t *dgn = C.dg_next + R.beg;
+	int ps = 0;
+	{ const uint64_t low = M.s > 0 ? (M.k_or & ~M.k_and) & ((1ull << M.s) - 1ull) : 0ull; if (low) ps = (63 - __clzll(low)) & ~7; }
+#pragma unroll
+	for (int it = 0; it < BS_TILE_IT; ++it) {
+		const uint32_t p = t0 + (uint32_t)it * NT + tid;
+		if (p >= R.n) continue;
+		const uint32_t np = s_start[d[it]] + s_base[d[it]] + lr[it], ft = s_fate[d[it]];
+		const rh_mm128_t rec = src[p];
+		if (ft == BS_FINAL) out_fin[np] = rec; else out_alt[np] = rec;
+		if (ft == BS_BIG) dgn[np] = (uint8_t)(rec.x >> ps);
+	}
+}
+
+// after an any-order job: which of its long segments hold equal keys (neighbours in the sorted result)?  skip_out[a] = 0 for those
+// - the skip array of the exact re-run - and 1 for every other segment; hdr[12] counts them
+__global__ __launch_bounds__(NT) void k_bs_tiecheck(rh_sort_job jb, bs_ctx C)
+{
+	__shared__ uint32_t s_w[NT / 64];
+	const uint32_t a = blockIdx.x, tid = threadIdx.x;
+	if (a >= jb.n_seg) return;
+	uint32_t n = 0;
+	if (!(jb.skip && jb.skip[a])) n = jb.cnt ? jb.cnt[a] : (uint32_t)(jb.off[a + 1] - jb.off[a]);
+	if (n <= C.n_lo) { if (tid == 0) jb.redo_skip[a] = 1; return; }
+	const rh_mm128_t *v = jb.dst + jb.off[a];
+	bool tie = false;
+	for (uint32_t i = tid; i + 1 < n; i += NT) tie |= v[i].x == v[i + 1].x;
+	uint32_t tot;
+	(void)block_rank(tie, s_w, tot);
+	if (tid == 0) { jb.redo_skip[a] = tot ? 0 : 1; if (tot) atomicAdd(&C.hdr[12], 1u); }
+}
+
 // K9: the next level's ranges get their tile numbers; they become "this level"
 __global__ __launch_bounds__(NT) void k_bs_next(bs_ctx C)
 {
@@ -961,6 +1023,12 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		RH_LAUNCH(k_bs_hist, n_tiles, NT, 0, s, C);
 		if (level) RH_LAUNCH(k_bs_fix, n_rng, NT, 0, s, C);
 		RH_LAUNCH(k_bs_plan, n_rng, NT, 0, s, C);
+		if (jb.any_order) {	// no holes, no walk: tiles reserve stretches of their buckets
+			RH_LAUNCH(k_bs_scatter_any, n_tiles, NT, 0, s, C);
+			RH_LAUNCH(k_bs_next, 1, NT, 0, s, C);
+			bs_range *tmp2 = C.rng[0]; C.rng[0] = C.rng[1]; C.rng[1] = tmp2;
+			continue;
+		}
 		RH_LAUNCH(k_bs_count, n_tiles, NT, 0, s, C);
 		RH_LAUNCH(k_bs_scan, n_rng, NT, 0, s, C);
 		RH_LAUNCH(k_bs_holes, n_tiles, NT, 0, s, C);
@@ -1014,7 +1082,14 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		sj.src = C.buf[q >> 1]; sj.dst = jb.dst; sj.need_exact = nullptr; sj.n_max = pin[8 + q] < n_lo ? pin[8 + q] : n_lo;   // (an LDS class above the list's largest bucket would be a launch of blocks that all leave at once, each waiting for its LDS)
 		if ((q & 1) && !job32) { sj.kc_on = 1; sj.kc_lo = 32; sj.kc_mid = 0; sj.kc_hi = 0; }   // keys that differ below bit 32 only: 32-bit words in LDS
 		sj.big_alt = nullptr; sj.big_ws = nullptr;
+		sj.any_order = 0; sj.redo_skip = nullptr; sj.n_redo = nullptr;
 		if (rhk_sort_job(s, sj, all_exact, 1u)) return -1;
+	}
+	if (jb.any_order) {
+		RH_LAUNCH(k_bs_tiecheck, jb.n_seg, NT, 0, s, jb, C);
+		RH_HIP(hipMemcpyAsync(pin, C.hdr + 12, 4, hipMemcpyDeviceToHost, s));
+		RH_HIP(hipStreamSynchronize(s));
+		if (jb.n_redo) *jb.n_redo = pin[0];
 	}
 	return 0;
 }

@@ -145,6 +145,11 @@ struct rh_sort_job {
 	// segments beyond the LDS classes (rh_bigsort.hip): a second record array the size of src (src itself is overwritten),
 	// scratch of rhk_bigsort_ws_bytes(big_total, ...) bytes, 32 pinned host bytes for the per-level read-backs
 	rh_mm128_t *big_alt; unsigned char *big_ws; size_t big_ws_bytes; void *big_pin; uint64_t big_total;
+	// keys that are almost never equal (hashed): a sorted order without ties is unique, so the segments beyond the LDS classes are
+	// placed level by level in ANY order (no token walk); afterwards every segment is checked for equal neighbours:
+	// redo_skip[a] = 0 for the segments that hold equal keys (the caller redoes them with any_order = 0 and skip = redo_skip),
+	// 1 for all others; *n_redo (host) = their number
+	uint8_t any_order; uint8_t *redo_skip; uint32_t *n_redo;
 };
 int rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n);   // segments with <= min_n records are left alone
 uint32_t rhk_sort_lds_max(const rh_sort_job &jb);                        // longest segment the LDS classes take for this job's keys

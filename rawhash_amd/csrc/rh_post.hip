@@ -8,6 +8,8 @@
 //                     the mapping decision of map_worker_for (rmap.cpp:423-500) and the bookkeeping of ri_map_frag (:386):
 //                     k_regions_reg keeps the primaries in registers; k_regions_wave (LDS), k_regions / k_regions_big
 //                     (serial core) take the reads and option sets it cannot
+#include <cstdio>
+#include <cstdlib>
 #include "rh_kernels.h"
 #include "rh_devutil.h"
 
@@ -593,11 +595,11 @@ __global__ void k_regions_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, co
 #define RGW_COV 512
 
 // chain heads + sort keys (hit.c:111-120) for reads with more than RG_SMALL chains; heads -> scratch, keys -> rr.raw
-__global__ __launch_bounds__(NT) void k_regions_prep(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
+__global__ __launch_bounds__(NT) void k_regions_prep(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, const uint8_t *skip2)
 {
 	__shared__ uint32_t s_w[NT / 64];
 	const uint32_t a = blockIdx.x, lane = threadIdx.x;               // (a workgroup per read: unmappable reads have tens of thousands of chains)
-	if (a >= rr.n_act || rr.skip[a]) return;
+	if (a >= rr.n_act || rr.skip[a] || (skip2 && skip2[a])) return;
 	const int32_t n_u = (int32_t)rr.n_u[a];
 	if (n_u <= RG_SMALL) return;
 	const uint32_t r = rr.act[a];
@@ -1159,9 +1161,23 @@ static bool regions_wave_ok(const rh_dev_opt &o) { return o.best_n == 0 && o.pri
 int rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
 {
 	if (!r.n_act || !regions_wave_ok(o)) return 0;
-	RH_LAUNCH(k_regions_prep, r.n_act, NT, 0, s, o, rd, r);
+	RH_LAUNCH(k_regions_prep, r.n_act, NT, 0, s, o, rd, r, (const uint8_t*)nullptr);
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, 0, 0, 0, 0, r.max_anchors };   // keys = hashed: full 64 bits
 	sort_scratch(jb, r, r.prev_out);                               // (the carried anchors have left the staging: the round loop packs them before this sort)
+	// The keys are score << 32 | (count ^ 32-bit hash): two of a read's chains agree on one with probability ~2^-32 per pair, so the
+	// long segments (unmappable reads: tens of thousands of chains) are placed without the token walks, the few reads that do hold
+	// equal keys are found afterwards and only they are sorted again with the exact passes (need_exact is idle here: rhk_regions
+	// resets it).  RH_RSORT_EXACT=1 (development aid) takes the exact passes for every read.
+	static const bool exact_all = getenv("RH_RSORT_EXACT") != nullptr;
+	if (exact_all) return rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL);
+	uint32_t n_redo = 0;
+	jb.any_order = 1; jb.redo_skip = r.need_exact; jb.n_redo = &n_redo;
+	if (rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL)) return -1;
+	static const bool trace = getenv("RH_BS_TRACE") != nullptr;
+	if (trace) fprintf(stderr, "RSORT any-order: %u of %u reads hold equal region keys and are redone\n", n_redo, r.n_act);
+	if (!n_redo) return 0;
+	RH_LAUNCH(k_regions_prep, r.n_act, NT, 0, s, o, rd, r, (const uint8_t*)r.need_exact);   // their keys again (the sorter overwrote its input)
+	jb.any_order = 0; jb.redo_skip = nullptr; jb.n_redo = nullptr; jb.skip = r.need_exact;   // (covers r.skip: the check marks skipped reads "no redo")
 	return rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL);
 }
 

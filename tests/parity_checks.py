@@ -268,6 +268,44 @@ def check_sort_big(ctx, seed=0, sizes=(20000, 33000, 9000), kinds=(0, 1, 2, 3, 4
     assert len(bad) == 0, f"{len(bad)} records out of the reference's order, first at {bad[:5]}"
 
 
+def check_sort_any(ctx, seed=0, sizes=(20000, 33000, 9000, 500, 70000, 12000)):
+    """The any-order path of the segment sorter (region keys: score << 32 | count ^ hash): long segments without equal keys come
+    out in the one sorted order there is (= the reference's); long segments with equal keys are flagged for the exact re-run;
+    short ones go through the LDS block sorter exactly as before."""
+    rng = np.random.default_rng(seed)
+    segs, tied = [], []
+    for i, n in enumerate(sizes):
+        score = rng.integers(40, 900 if i % 2 else 200, size=n, dtype=np.uint64)
+        x = (score << np.uint64(32)) | rng.integers(0, 1 << 32, size=n, dtype=np.uint64)
+        x = np.unique(x)
+        while len(x) < n:
+            x = np.unique(np.concatenate([x, (rng.integers(40, 200, size=n - len(x), dtype=np.uint64) << np.uint64(32)) | rng.integers(0, 1 << 32, size=n - len(x), dtype=np.uint64)]))
+        x = rng.permutation(x)
+        t = i % 3 == 1
+        if t:
+            j = rng.integers(0, n, size=3)
+            x[j[1:]] = x[j[0]]
+            t = len(np.unique(x)) < n
+        segs.append(x); tied.append(t)
+    off = np.zeros(len(sizes) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in segs])
+    a = np.zeros(int(off[-1]), dtype=MM128)
+    a["x"] = np.concatenate(segs)
+    a["y"] = np.arange(len(a), dtype=np.uint64)
+    want = a.copy()
+    assert O.lib().ro_sort128x_batch(len(sizes), ptr(want), ptr(off)) == 0
+    got, ties = ctx.sort128x_any(a, off)
+    lds_max = 8192
+    for s, n in enumerate(sizes):
+        b, e = int(off[s]), int(off[s + 1])
+        assert np.array_equal(got["x"][b:e], want["x"][b:e]), f"segment {s}: not sorted"
+        if n > lds_max:
+            assert bool(ties[s]) == tied[s], f"segment {s}: tie flag {ties[s]}, equal keys {tied[s]}"
+        if not tied[s]:
+            assert np.array_equal(got["y"][b:e], want["y"][b:e]), f"segment {s}: records differ from the reference's"
+    return int(ties.sum())
+
+
 def check_device_index(lib, tmpdir, preset="sensitive", chrom_len=60_000, n_chrom=3, with_gaps=True, seed=5):
     """Index built on the device (rh_index_build_device) = index built on the host (which tests/test_oracle.py pins to the
     reference): same keys, same occurrence counts, same position lists in the same order, same mid_occ; targets with runs of

@@ -42,6 +42,11 @@ def test_exact_sort_multi_workgroup(ctx, emu_lib_smallcaps):
     c.close()
 
 
+def test_any_order_sort(ctx):
+    """Region keys (hit.c:111-126) through the sorter's any-order levels + tie check."""
+    assert pc.check_sort_any(ctx, seed=3) >= 1
+
+
 def test_index_built_on_device(emu_lib, emu_lib_smallcaps, tmp_path):
     checked, n = pc.check_device_index(emu_lib, tmp_path)
     assert checked > 1000 and n > 10000

@@ -57,6 +57,12 @@ def test_exact_sort(ctx):
     pc.check_sort(ctx, seed=5, n_seg=40, big=(8193, 9000, 20000, 70000, 30000, 12345, 100000, 16384, 50000, 65537, 33333, 9999))
 
 
+def test_any_order_sort(ctx):
+    """Region keys (hit.c:111-126) through the sorter's any-order levels + tie check, many long segments."""
+    assert pc.check_sort_any(ctx, seed=5) >= 1
+    assert pc.check_sort_any(ctx, seed=6, sizes=tuple([9000 + 911 * i for i in range(120)])) >= 1
+
+
 def test_exact_sort_multi_workgroup(ctx):
     """Segments beyond the LDS classes (rh_bigsort.hip): every key kind, several levels, one segment of more than 2^20
     records, and many segments at once (thousands of ranges per level)."""
