@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 WORKLOADS = {
     #          chrom_len, n_chrom, preset, reads/GPU, cpu sample, name
-    "human": (129_166_667, 24, "fast", 65536, 6000, "human-scale (3.1 Gbp)"),
+    "human": (129_166_667, 24, "fast", 65536, 20000, "human-scale (3.1 Gbp)"),
     "dmel": (24_000_000, 6, "sensitive", 50_000, 12_000, "D. melanogaster-scale (144 Mbp)"),
     "ecoli": (4_600_000, 1, "sensitive", 100_000, 40_000, "E. coli-scale (4.6 Mbp)"),
 }
@@ -458,20 +458,46 @@ def cpu_baseline(ctx, index, opts, wl, model, workdir, preset, recs, args, cores
         rhr = os.path.join(workdir, "cpu_sample.rhr")
         reads.write(rhr, wl.cfg.digitisation, wl.cfg.range, wl.cfg.offset)
         paf = os.path.join(workdir, "ref.paf")
-        with open(paf, "w") as fo:
-            p = subprocess.run([O.REF_HARNESS, "map", preset, ind, rhr, ",".join(str(t) for t in sweep)], stdout=fo, stderr=subprocess.PIPE, text=True, timeout=3000)
-        runs = [(int(t), float(s)) for s, t in re.findall(r"map phase ([0-9.]+) s, threads (\d+)", p.stderr)]
-        if p.returncode == 0 and runs:
-            with open(paf) as f:
-                want = [O.strip_mt(x) for x in f]
-            identical = got == want
-            best_t, best_s = min(runs, key=lambda r: r[1])
+        # Two passes of the harness: memory policy as the process finds it (the single-threaded .ind loader first-touches the whole
+        # index on its own NUMA node), and every page interleaved over all nodes (RH_REF_INTERLEAVE=1 = `numactl --interleave=all`,
+        # which the image lacks).  Both thread sweeps are reported; the baseline is the best run of either.
+        half = [t for t in sweep if t <= max(1, cores // 4)] or sweep[:1]
+        passes = [("default", {}, half if len(sweep) > 3 else sweep), ("interleave", {"RH_REF_INTERLEAVE": "1"}, [t for t in sweep if t >= max(1, cores // 8)])]
+        if args.cpu_threads:
+            passes = [(nm, ev, sweep) for nm, ev, _ in passes]
+        runs, want, load_s, notes = {}, None, {}, []
+        for nm, ev, ts in passes:
+            with open(paf, "w") as fo:
+                p = subprocess.run([O.REF_HARNESS, "map", preset, ind, rhr, ",".join(str(t) for t in ts)], stdout=fo, stderr=subprocess.PIPE, text=True, timeout=3000,
+                                   env=dict(os.environ, **ev))
+            rr = [(int(t), float(sec)) for sec, t in re.findall(r"map phase ([0-9.]+) s, threads (\d+)", p.stderr)]
+            if p.returncode != 0 or not rr:
+                notes.append(f"{nm}: harness rc {p.returncode}")
+                continue
+            runs[nm] = rr
             load = re.search(r"index loaded in ([0-9.]+) s", p.stderr)
-            base = {"value": round(n / best_s, 1), "unit": "reads/s", "cores": cores, "threads": best_t, "kind": "reference",
+            load_s[nm] = float(load.group(1)) if load else None
+            il = re.search(r"interleaved over (\d+) NUMA", p.stderr)
+            if il:
+                notes.append(f"{nm}: {il.group(1)} NUMA node(s)")
+            with open(paf) as f:
+                w = [O.strip_mt(x) for x in f]
+            if want is not None and w != want:
+                notes.append(f"{nm}: PAF differs from the first pass")
+            want = want or w
+        if runs:
+            identical = got == want
+            best_nm, (best_t, best_s) = min(((nm, min(rr, key=lambda r: r[1])) for nm, rr in runs.items()), key=lambda x: x[1][1])
+            try:
+                numa_nodes = len([d for d in os.listdir("/sys/devices/system/node") if re.fullmatch(r"node\d+", d)])
+            except OSError:
+                numa_nodes = None
+            base = {"value": round(n / best_s, 1), "unit": "reads/s", "cores": cores, "threads": best_t, "kind": "reference", "memory_policy": best_nm,
                     "sample": f"first {n} reads of the same synthetic set, map phase {best_s:.2f} s (file loading excluded), unmodified RawHash2 sources built by "
                               f"oracle/Makefile (-O3 -ffp-contract=off), kt_for over 500 M-sample mini-batches",
-                    "thread_sweep_reads_per_s": {str(t): round(n / s, 1) for t, s in runs},
-                    "index_file_s": round(t_ind, 1), "reference_index_load_s": float(load.group(1)) if load else None,
+                    "thread_sweep_reads_per_s": {nm: {str(t): round(n / sec, 1) for t, sec in rr} for nm, rr in runs.items()},
+                    "numa_nodes": numa_nodes, "notes": notes,
+                    "index_file_s": round(t_ind, 1), "reference_index_load_s": load_s,
                     "paf_sha1": hashlib.sha1("\n".join(want).encode()).hexdigest()}
             if not identical:
                 base["paf_lines_differing"] = sum(1 for a, b in zip(got, want) if a != b) + abs(len(got) - len(want))

@@ -94,6 +94,10 @@ typedef struct rh_read_batch_s {
 	                                     names, such that strcmp(qname, tname) >= 0  <=>  name_rank[q] >= rank of the
 	                                     target (rh_index_name_ranks computes both sides); NULL otherwise */
 	int samples_on_device;            /* 1: samples/offsets/cal_* are device pointers already resident in HBM */
+	int fast5_ingest;                 /* 1: raw -> pA as the FAST5 reader does it (rsig.c:363-374): offset and scale are floats there, so
+	                                     (raw + (float)cal_offset) * cal_scale is float arithmetic, and a sample that passes the
+	                                     30 < pA < 200 test is truncated to int16 before it becomes the float signal.  0: the
+	                                     SLOW5 / POD5 readers (rsig.c:452, :497: double offset, no truncation) */
 } rh_read_batch_t;
 
 typedef struct rh_index_s rh_index;  /* host-side parsed .ind (flattened) */

@@ -69,6 +69,23 @@ static ri_sig_t *to_sig(const rhr_read &r, uint32_t rid)
 	ri_sig_t *s = (ri_sig_t*)calloc(1, sizeof(ri_sig_t));
 	s->name = strdup(r.name.c_str());
 	s->rid = rid;
+	static const bool fast5 = getenv("RH_FAST5_INGEST") && atoi(getenv("RH_FAST5_INGEST"));
+	if (fast5) {	// rsig.c:346-374 (the FAST5 reader, compiled out here with HDF5): float dig / ran / offset, the kept pA value goes back
+		// into the int16_t signal vector - truncated - and only then becomes the float signal
+		float dig = (float)r.dig, ran = (float)r.range, offset = (float)r.offset;
+		std::vector<int16_t> sig(r.raw.begin(), r.raw.end());
+		uint32_t l_sig = 0;
+		float scale = ran / dig;
+		float pa = 0;
+		for (size_t i = 0; i < sig.size(); i++) {
+			pa = (sig[i] + offset) * scale;
+			if (pa > 30.0f && pa < 200.0f) sig[l_sig++] = pa;
+		}
+		s->sig = (float*)calloc(l_sig ? l_sig : 1, sizeof(float));
+		s->l_sig = l_sig;
+		std::copy(sig.begin(), sig.begin() + l_sig, s->sig);
+		return s;
+	}
 	float *sigF = (float*)malloc((r.raw.size() + 1) * sizeof(float));
 	uint32_t l_sig = 0;
 	float pa = 0.0f;
@@ -391,9 +408,29 @@ static int cmd_idxdump(int argc, char **argv)
 	return 0;
 }
 
+// RH_REF_INTERLEAVE=1: every page this process touches from here on is interleaved over all NUMA nodes (what `numactl --interleave=all`
+// does; the image has no numactl).  The index loader is single-threaded: without it the whole table is first-touched on the loader's
+// node and every worker thread of the other socket reads it remotely.  Returns the number of nodes found (0 = policy not set).
+#include <sys/syscall.h>
+#include <dirent.h>
+static int numa_interleave_all()
+{
+	int n_nodes = 0;
+	if (DIR *d = opendir("/sys/devices/system/node")) {
+		while (struct dirent *e = readdir(d)) if (!strncmp(e->d_name, "node", 4) && e->d_name[4] >= '0' && e->d_name[4] <= '9') { const int k = atoi(e->d_name + 4) + 1; if (k > n_nodes) n_nodes = k; }
+		closedir(d);
+	}
+	if (n_nodes < 2 || n_nodes > 1024) return n_nodes < 2 ? n_nodes : 0;
+	unsigned long mask[16] = {0};
+	for (int i = 0; i < n_nodes; ++i) mask[i / (8 * sizeof(long))] |= 1ul << (i % (8 * sizeof(long)));
+	if (syscall(SYS_set_mempolicy, 3 /* MPOL_INTERLEAVE */, mask, (unsigned long)(sizeof(mask) * 8)) != 0) { perror("[ref_harness] set_mempolicy"); return 0; }
+	return n_nodes;
+}
+
 int main(int argc, char **argv)
 {
 	ri_verbose = 1; ri_realtime0 = ri_realtime();
+	if (const char *e = getenv("RH_REF_INTERLEAVE")) if (atoi(e)) fprintf(stderr, "[ref_harness] memory interleaved over %d NUMA node(s)\n", numa_interleave_all());
 	int ret = 2;
 	if (argc >= 2) {
 		if (!strcmp(argv[1], "index")) ret = cmd_index(argc, argv);

@@ -292,9 +292,17 @@ void ro_mapopt_update(rh_mapopt_t *mo, const ro_index *ix)
 }
 
 /* ================================================================== a0: raw -> pA + filter (rsig.c:494-503) */
-uint32_t ro_pa_filter(const int16_t *raw, uint64_t n, double cal_offset, float cal_scale, float *out)
+uint32_t ro_pa_filter(const int16_t *raw, uint64_t n, double cal_offset, float cal_scale, int fast5, float *out)
 {
 	uint32_t l = 0;
+	if (fast5) {	/* rsig.c:346-374: dig / ran / offset are floats, the kept value goes back into the int16_t vector first */
+		const float offset = (float)cal_offset;
+		for (uint64_t i = 0; i < n; ++i) {
+			float pa = (raw[i] + offset) * cal_scale;
+			if (pa > 30.0f && pa < 200.0f) { const int16_t t = (int16_t)pa; out[l++] = (float)t; }
+		}
+		return l;
+	}
 	for (uint64_t i = 0; i < n; ++i) {
 		float pa = (raw[i] + cal_offset) * cal_scale;
 		if (pa > 30.0f && pa < 200.0f) out[l++] = pa;
@@ -1035,7 +1043,7 @@ static void *map_thread(void *arg)
 			uint64_t n = jb->in->offsets[r + 1] - jb->in->offsets[r];
 			float *sig = (float*)malloc((n ? n : 1) * sizeof(float));
 			uint32_t l = ro_pa_filter(jb->in->samples + jb->in->offsets[r], n, jb->in->cal_offset ? jb->in->cal_offset[r] : 0.0,
-			                          jb->in->cal_scale ? jb->in->cal_scale[r] : 1.0f, sig);
+			                          jb->in->cal_scale ? jb->in->cal_scale[r] : 1.0f, jb->in->fast5_ingest, sig);
 			jb->recs[r] = (rh_map_record_t*)malloc(jb->max_rec * sizeof(rh_map_record_t));
 			jb->n_recs[r] = map_read(jb->ix, jb->mo, &jb->ip, r, sig, l, jb->names ? jb->names[r] : 0,
 			                         jb->in->name_rank ? jb->in->name_rank[r] : 0, jb->recs[r], jb->max_rec, cnt);
@@ -1084,7 +1092,7 @@ int ro_events_batch(const rh_mapopt_t *mo, const rh_read_batch_t *in, uint32_t c
 	for (uint32_t r = 0; r < in->n_reads; ++r) {
 		uint64_t n = in->offsets[r + 1] - in->offsets[r];
 		float *sig = (float*)malloc((n ? n : 1) * sizeof(float));
-		uint32_t qlen = ro_pa_filter(in->samples + in->offsets[r], n, in->cal_offset ? in->cal_offset[r] : 0.0, in->cal_scale ? in->cal_scale[r] : 1.0f, sig);
+		uint32_t qlen = ro_pa_filter(in->samples + in->offsets[r], n, in->cal_offset ? in->cal_offset[r] : 0.0, in->cal_scale ? in->cal_scale[r] : 1.0f, in->fast5_ingest, sig);
 		if (l_sig) l_sig[r] = qlen;
 		uint32_t l_chunk = (mo->chunk_size > qlen || (mo->flag & RH_M_NO_ADAPTIVE)) ? qlen : mo->chunk_size;
 		double ms = 0, ss = 0; uint32_t ns = 0;

@@ -37,7 +37,7 @@ void ro_mapopt_init(rh_mapopt_t *mo);                           /* roptions.c:34
 int  ro_set_preset(const char *preset, rh_idxopt_t *io, rh_mapopt_t *mo);  /* main.cpp:111 */
 
 /* single-read stage functions */
-uint32_t ro_pa_filter(const int16_t *raw, uint64_t n, double cal_offset, float cal_scale, float *out);  /* rsig.c:496-503 */
+uint32_t ro_pa_filter(const int16_t *raw, uint64_t n, double cal_offset, float cal_scale, int fast5, float *out);  /* rsig.c:496-503; fast5: rsig.c:346-374 */
 float   *ro_detect_events(uint32_t s_len, const float *sig, uint32_t w1, uint32_t w2, float thr1, float thr2, float peak_height,
                           double *mean_sum, double *std_dev_sum, uint32_t *n_events_sum, uint32_t *n_events);   /* revent.c:257; caller frees */
 uint64_t ro_sketch(const float *ev, uint32_t len, uint32_t id, int strand, const rh_idxopt_t *ip, rh_mm128_t *out, uint64_t cap); /* rsketch.c:271 */

@@ -70,6 +70,7 @@ class ReadBatch(C.Structure):
         ("samples", C.c_void_p), ("offsets", C.c_void_p), ("cal_offset", C.c_void_p), ("cal_scale", C.c_void_p),
         ("name_rank", C.c_void_p),
         ("samples_on_device", C.c_int),
+        ("fast5_ingest", C.c_int),
     ]
 
 
@@ -97,7 +98,7 @@ def ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def make_batch(samples, offsets, cal_offset=None, cal_scale=None, name_rank=None, keep=None):
+def make_batch(samples, offsets, cal_offset=None, cal_scale=None, name_rank=None, keep=None, fast5=False):
     """Build a ReadBatch view over numpy arrays; the arrays are returned too so callers keep them alive."""
     samples = np.ascontiguousarray(samples, dtype=np.int16)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -105,7 +106,7 @@ def make_batch(samples, offsets, cal_offset=None, cal_scale=None, name_rank=None
     co = None if cal_offset is None else np.ascontiguousarray(cal_offset, dtype=np.float64)
     cs = None if cal_scale is None else np.ascontiguousarray(cal_scale, dtype=np.float32)
     nr = None if name_rank is None else np.ascontiguousarray(name_rank, dtype=np.uint32)
-    b = ReadBatch(n, ptr(samples), ptr(offsets), ptr(co), ptr(cs), ptr(nr), 0)
+    b = ReadBatch(n, ptr(samples), ptr(offsets), ptr(co), ptr(cs), ptr(nr), 0, 1 if fast5 else 0)
     b._keep = (samples, offsets, co, cs, nr)
     return b
 

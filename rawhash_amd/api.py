@@ -156,7 +156,8 @@ class Index:
 class Reads:
     """A batch of raw reads (int16 ADC samples + calibration), SoA/CSR."""
 
-    def __init__(self, samples, offsets, names, cal_offset, cal_scale):
+    def __init__(self, samples, offsets, names, cal_offset, cal_scale, fast5=False):
+        self.fast5 = bool(fast5)          # raw -> pA as the reference's FAST5 reader does it (rh_read_batch_t.fast5_ingest)
         self.samples = np.ascontiguousarray(samples, dtype=np.int16)
         self.offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self.names = list(names)
@@ -168,7 +169,7 @@ class Reads:
         return len(self.offsets) - 1
 
     def batch(self):
-        return _capi.make_batch(self.samples, self.offsets, self.cal_offset, self.cal_scale)
+        return _capi.make_batch(self.samples, self.offsets, self.cal_offset, self.cal_scale, fast5=self.fast5)
 
     def subset(self, idx):
         idx = list(idx)
@@ -176,7 +177,7 @@ class Reads:
         off = np.zeros(len(idx) + 1, dtype=np.uint64)
         off[1:] = np.cumsum([len(p) for p in parts])
         return Reads(np.concatenate(parts) if parts else np.zeros(0, np.int16), off, [self.names[i] for i in idx],
-                     self.cal_offset[idx], self.cal_scale[idx])
+                     self.cal_offset[idx], self.cal_scale[idx], fast5=self.fast5)
 
     @classmethod
     def load(cls, path, lib=None):

@@ -168,6 +168,7 @@ int stage_reads(rh_ctx *c, const rh_read_batch_t *in, rh_dev_reads *rd)
 	const uint32_t R = in->n_reads;
 	memset(rd, 0, sizeof(*rd));
 	rd->n_reads = R;
+	rd->fast5 = in->fast5_ingest ? 1u : 0u;
 	if (in->samples_on_device) {
 		if (!in->cal_offset || !in->cal_scale) { rh_set_error("device batches must carry cal_offset and cal_scale"); return -1; }
 		rd->raw = in->samples; rd->off = in->offsets; rd->cal_off = in->cal_offset; rd->cal_scale = in->cal_scale;

@@ -60,6 +60,7 @@ struct rh_dev_opt {
 // per-batch read state (all arrays have n_reads entries unless noted)
 struct rh_dev_reads {
 	uint32_t n_reads;
+	uint32_t fast5;                  // raw -> pA the way the FAST5 reader does it (float arithmetic, value truncated to int16: rsig.c:363-374)
 	const int16_t *raw; const uint64_t *off; const double *cal_off; const float *cal_scale;
 	const uint32_t *name_rank;       // all-vs-all: rank of the read's name among the target names (strcmp(q, t) >= 0 <=> name_rank >= t_rank[t])
 	uint32_t *l_sig;                 // filtered length (sl:i tag)

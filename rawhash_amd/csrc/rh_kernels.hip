@@ -16,26 +16,32 @@
 #include "rh_kernels.h"
 #include "rh_devutil.h"
 
-RH_DEV float raw_to_pa(int16_t raw, double cal_off, float cal_scale)
+// f5 = 0: the SLOW5 / POD5 readers (rsig.c:497, :452): (raw + offset) * scale with a double offset, evaluated in double, narrowed.
+// f5 = 1: the FAST5 reader (rsig.c:363-374): offset is a float there, so the whole expression is float arithmetic; the value that
+//         passes the 30 < pA < 200 test is then written back into the reader's int16_t vector - truncated - before it becomes the
+//         float signal (rh_pa_value below).  The filter looks at the untruncated value in both.
+RH_DEV float raw_to_pa(int16_t raw, double cal_off, float cal_scale, uint32_t f5)
 {
-	return (float)(((double)raw + cal_off) * (double)cal_scale);   // (raw + offset) * scale evaluated in double, rsig.c:497
+	if (f5) return ((float)raw + (float)cal_off) * cal_scale;
+	return (float)(((double)raw + cal_off) * (double)cal_scale);
 }
+RH_DEV float rh_pa_value(float pa, uint32_t f5) { return f5 ? (float)(int16_t)pa : pa; }
 
 // ------------------------------------------------------------------------------------------------ k_prefilter
 // One block per read: count samples surviving the pA filter and record, for every chunk boundary, the raw index of the
 // first surviving sample of that chunk.  Each wavefront owns a contiguous quarter of the read and works on tiles of 256
 // samples (four coalesced 128-byte rows) with ballots only: pass 1 counts, one barrier turns the four counts into
 // offsets, pass 2 re-reads the quarter (L2) and ranks just the tiles that hold a chunk boundary.
-RH_DEV uint64_t pa_tile_ballot(const int16_t *raw, uint32_t i, uint32_t end, double coff, float cscale)
+RH_DEV uint64_t pa_tile_ballot(const int16_t *raw, uint32_t i, uint32_t end, double coff, float cscale, uint32_t f5)
 {
 	bool valid = false;
-	if (i < end) { const float pa = raw_to_pa(raw[i], coff, cscale); valid = pa > 30.0f && pa < 200.0f; }
+	if (i < end) { const float pa = raw_to_pa(raw[i], coff, cscale, f5); valid = pa > 30.0f && pa < 200.0f; }
 	return __ballot(valid);
 }
 
 // survivors of the pA filter among the 256 samples from `base` (clipped at end).  Counting needs no order: each lane takes
 // 4 consecutive samples in one 8-byte load (512 B per request instead of 128)
-RH_DEV uint32_t pa_tile_count(const int16_t *raw, uint32_t base, uint32_t end, double coff, float cscale)
+RH_DEV uint32_t pa_tile_count(const int16_t *raw, uint32_t base, uint32_t end, double coff, float cscale, uint32_t f5)
 {
 	const uint32_t i0 = base + 4u * lane_id();
 	int16_t v[4] = {0, 0, 0, 0};
@@ -44,7 +50,7 @@ RH_DEV uint32_t pa_tile_count(const int16_t *raw, uint32_t base, uint32_t end, d
 	uint32_t tc = 0;
 #pragma unroll
 	for (uint32_t k = 0; k < 4; ++k) {
-		const float pa = raw_to_pa(v[k], coff, cscale);
+		const float pa = raw_to_pa(v[k], coff, cscale, f5);
 		tc += (uint32_t)__popcll(__ballot(i0 + k < end && pa > 30.0f && pa < 200.0f));
 	}
 	return tc;
@@ -63,6 +69,7 @@ __global__ __launch_bounds__(NT) void k_prefilter(rh_dev_opt o, rh_dev_reads rd)
 	const int16_t *raw = rd.raw + o0;
 	const double coff = rd.cal_off[r];
 	const float cscale = rd.cal_scale[r];
+	const uint32_t f5 = rd.fast5;
 	uint32_t *cs = rd.chunk_start + (size_t)r * (RH_MAX_CHUNKS + 1);
 	for (uint32_t k = tid; k <= RH_MAX_CHUNKS; k += NT) cs[k] = n;
 	const uint32_t C = o.chunk_size;
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(NT) void k_prefilter(rh_dev_opt o, rh_dev_reads rd)
 	const bool keep = (n + 255) / 256 <= PF_TILES;                // per-tile counts of pass 1 kept in LDS: pass 2 re-reads boundary tiles only
 	uint32_t cnt = 0;
 	for (uint32_t base = beg; base < end; base += 256) {
-		const uint32_t tc = pa_tile_count(raw, base, end, coff, cscale);
+		const uint32_t tc = pa_tile_count(raw, base, end, coff, cscale, f5);
 		if (keep && l == 0) s_tc[base >> 8] = (uint16_t)tc;
 		cnt += tc;
 	}
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(NT) void k_prefilter(rh_dev_opt o, rh_dev_reads rd)
 			uint64_t B[4];
 			tc = 0;
 #pragma unroll
-			for (uint32_t k = 0; k < 4; ++k) { B[k] = pa_tile_ballot(raw, base + k * 64 + l, end, coff, cscale); tc += (uint32_t)__popcll(B[k]); }
+			for (uint32_t k = 0; k < 4; ++k) { B[k] = pa_tile_ballot(raw, base + k * 64 + l, end, coff, cscale, f5); tc += (uint32_t)__popcll(B[k]); }
 			if (nb < run + tc) {
 				uint32_t before = run;
 #pragma unroll
@@ -191,6 +198,7 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 	const int16_t *raw = rd.raw + o0;
 	const double coff = rd.cal_off[r];
 	const float cscale = rd.cal_scale[r];
+	const uint32_t f5 = rd.fast5;
 	const uint32_t *cs = rd.chunk_start + (size_t)r * (RH_MAX_CHUNKS + 1);
 	const uint32_t cs0 = cs[c], cs1 = cs[c + 1];
 	const uint32_t C = o.chunk_size;
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 		const uint32_t per = ((span + (NT / 64) * 256u - 1) / ((NT / 64) * 256u)) * 256u;
 		const uint32_t beg = cs0 + (w * per < span ? w * per : span), end = beg + per < cs1 ? beg + per : cs1;
 		uint32_t cnt = 0;
-		for (uint32_t base = beg; base < end; base += 256) cnt += pa_tile_count(raw, base, end, coff, cscale);
+		for (uint32_t base = beg; base < end; base += 256) cnt += pa_tile_count(raw, base, end, coff, cscale, f5);
 		if (l == 0) s_w[w] = cnt;
 		__syncthreads();
 		uint32_t run = 0, count = 0;
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 			for (uint32_t k = 0; k < 4; ++k) {
 				const uint32_t i = base + k * 64 + l;
 				bool valid = false; float pa = 0.0f;
-				if (i < end) { pa = raw_to_pa(raw[i], coff, cscale); valid = pa > 30.0f && pa < 200.0f; }
+				if (i < end) { pa = raw_to_pa(raw[i], coff, cscale, f5); valid = pa > 30.0f && pa < 200.0f; pa = rh_pa_value(pa, f5); }
 				const uint64_t B = __ballot(valid);
 				const uint32_t pos = run + lanes_below(B);
 				if (valid && pos < C) {
@@ -663,13 +671,14 @@ __global__ __launch_bounds__(NT) void k_events_norm_whole(rh_dev_opt o, rh_dev_r
 	const int16_t *raw = rd.raw + o0;
 	const double coff = rd.cal_off[r];
 	const float cscale = rd.cal_scale[r];
+	const uint32_t f5 = rd.fast5;
 	float *parow = rr.t1buf + (size_t)a * rr.ev_row, *zrow = rr.zbuf + (size_t)a * rr.ev_row;
 	uint32_t s_len = 0;
 	double dsum = 0.0, dsum2 = 0.0;
 	for (uint32_t base = 0; base < n_raw; base += NT) {
 		const uint32_t i = base + tid;
 		bool valid = false; float pa = 0.0f;
-		if (i < n_raw) { pa = raw_to_pa(raw[i], coff, cscale); valid = pa > 30.0f && pa < 200.0f; }
+		if (i < n_raw) { pa = raw_to_pa(raw[i], coff, cscale, f5); valid = pa > 30.0f && pa < 200.0f; pa = rh_pa_value(pa, f5); }
 		uint32_t tot;
 		const uint32_t pos = s_len + block_rank(valid, s_w, tot);
 		if (valid) { parow[pos] = pa; dsum += (double)pa; const float sq = pa * pa; dsum2 += (double)sq; }

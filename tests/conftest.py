@@ -46,7 +46,7 @@ class Workload:
     """Synthetic reference + index + reads, generated from seeds by the product library's host code."""
 
     def __init__(self, directory, lib, preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=12_000, n_reads=48,
-                 junk=150, noise=150_000, read_seed=3, index_lib=None, build_index=True, no_adaptive=False):
+                 junk=150, noise=150_000, read_seed=3, index_lib=None, build_index=True, no_adaptive=False, fast5=False):
         from rawhash_amd.api import SynthWorkload, MapOptions, Index
         self.dir, self.preset = str(directory), preset
         self.wl = SynthWorkload(chrom_len=chrom_len, n_chrom=n_chrom, n_samples=n_samples, junk_per_1024=junk, noise_q24=noise,
@@ -62,6 +62,7 @@ class Workload:
             self.index = Index.build(self.fasta, self.model, self.opts, out_ind=self.ind, n_threads=8, lib=lib)
             self.opts.update(self.index)
         self.reads = self.wl.reads(self.model, 0, n_reads)
+        self.reads.fast5 = bool(fast5)     # the same int16 samples taken in the way the reference's FAST5 reader does (rsig.c:346-374)
 
     def oracle(self):
         import oracle_lib as O

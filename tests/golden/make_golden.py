@@ -28,6 +28,9 @@ CASES = [
     # CPU suite, so only the -m gpu tests (index built on the device) check this one
     # whole-read rounds on a sequence index: `--disable-adaptive` (RI_M_NO_ADAPTIVE, main.cpp:369)
     {"name": "small_sensitive_whole_reads", "no_adaptive": True, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=96, junk=150, noise=150_000, read_seed=16)},
+    # the int16 samples taken in the way the FAST5 reader does (rsig.c:346-374: float arithmetic, kept values truncated to int16):
+    # BASELINE config 1 is stated on FAST5 reads.  RH_FAST5_INGEST=1 makes the harness restate those lines (the reader itself needs HDF5)
+    {"name": "small_sensitive_fast5_ingest", "env": {"RH_FAST5_INGEST": "1"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=160, junk=150, noise=150_000, read_seed=17, fast5=True)},
     {"name": "config3_dmel_144M_384", "gpu_only": True, "workload": dict(preset="sensitive", chrom_len=24_000_000, n_chrom=6, n_samples=40_000, n_reads=384, junk=102, noise=0, read_seed=3)},
 ]
 
@@ -48,7 +51,10 @@ def main():
     from rawhash_amd import _capi
     lib = _capi.lib()
     assert O.have_reference(), "build oracle/_ref first (make -C oracle ref)"
+    only = set(sys.argv[1:])                # optional: regenerate just the named cases (the case lists are always rewritten)
     for case in CASES:
+        if only and case["name"] not in only:
+            continue
         with tempfile.TemporaryDirectory() as d:
             w = Workload(d, lib, **case["workload"], build_index=not case.get("gpu_only"), no_adaptive=bool(case.get("no_adaptive")))
             cfg = w.wl.cfg
@@ -57,7 +63,9 @@ def main():
             preset = case["workload"]["preset"]
             ref_ind = os.path.join(d, "refbuilt.ind")
             subprocess.run([O.REF_HARNESS, "index", preset, w.fasta, w.model, ref_ind, "4"], check=True, stderr=subprocess.DEVNULL)
-            env = dict(os.environ, RH_NO_ADAPTIVE="1") if case.get("no_adaptive") else None
+            env = dict(os.environ, **case.get("env", {}))
+            if case.get("no_adaptive"):
+                env["RH_NO_ADAPTIVE"] = "1"
             out = subprocess.run([O.REF_HARNESS, "map", preset, ref_ind, rhr, "1"], check=True, capture_output=True, text=True, env=env).stdout
             lines = [O.strip_mt(l) for l in out.splitlines()]
             assert len(lines) == len(w.reads)
@@ -70,7 +78,14 @@ def main():
     # reference's own functions, `ref_harness map` overlaps the same reads against it
     import hashlib
     from conftest import AvaWorkload
+    old_sha = {}
+    if os.path.exists(os.path.join(HERE, "ava_cases.json")):
+        with open(os.path.join(HERE, "ava_cases.json")) as f:
+            old_sha = {c["name"]: c.get("ind_sha256") for c in json.load(f)}
     for case in AVA_CASES:
+        if only and case["name"] not in only:
+            case["ind_sha256"] = old_sha.get(case["name"])
+            continue
         with tempfile.TemporaryDirectory() as d:
             w = AvaWorkload(d, lib, **case["workload"])
             ref_ind = os.path.join(d, "ref.ind")

@@ -103,6 +103,29 @@ def test_whole_read_rounds_golden(emu_lib, tmp_path):
     c.close()
 
 
+def test_fast5_ingest_golden(emu_lib, tmp_path):
+    """rh_read_batch_t.fast5_ingest: raw -> pA as the FAST5 reader does it (float arithmetic, kept values truncated to int16,
+    rsig.c:346-374), against the PAF the reference prints for that ingest."""
+    import golden
+    from rawhash_amd.api import paf_lines
+    import oracle_lib as O
+    case = [c for c in golden.cases() if c["name"] == "small_sensitive_fast5_ingest"][0]
+    w = golden.build_case(case, tmp_path, emu_lib)
+    c = Context(0, lib=emu_lib)
+    c.upload(w.index)
+    sub = w.reads.subset(range(24))
+    assert sub.fast5
+    recs = c.map_batch(w.opts, sub)
+    got = [O.strip_mt(x) for x in paf_lines(w.index, recs, sub.names, lib=emu_lib)]
+    assert got == golden.expected_paf(case)[:24]
+    sub.fast5 = False                      # the same samples the SLOW5 way: different signal values (no truncation)
+    ev_a, _, _ = c.events(w.opts, sub, 0)
+    sub.fast5 = True
+    ev_b, _, _ = c.events(w.opts, sub, 0)
+    assert len(ev_a) and (len(ev_a) != len(ev_b) or (ev_a != ev_b).any())
+    c.close()
+
+
 def test_rawsamble_all_vs_all_golden(emu_lib, tmp_path):
     """Signal-target index built by the device kernels = the reference's .ind; all-vs-all overlaps = the reference's PAF."""
     import golden
