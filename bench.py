@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--junk", type=int, default=102, help="unmappable reads per 1024")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads of the CPU-baseline sample (0 = skip, -1 = the workload's default)")
     ap.add_argument("--no-h2d", dest="h2d", action="store_false", help="skip the PCIe-inclusive measurement (batches in pinned host memory)")
+    ap.add_argument("--dry-run", action="store_true", help="parse the launch (arguments + torch.distributed environment), print the plan as JSON and exit before touching a GPU")
     ap.add_argument("--cpu-threads", default="", help="thread counts of the CPU sweep, comma separated (default: cores/8 .. cores)")
     args = ap.parse_args()
     if args.workload == "ava":
@@ -93,6 +94,12 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
+    if args.dry_run:
+        print(json.dumps({"dry_run": True, "world": world, "rank": rank, "local_rank": local_rank, "gpus": args.gpus, "workload": args.workload,
+                          "reads_per_gpu": args.reads, "first_read": rank * args.reads, "steps": args.steps, "warmup": args.warmup,
+                          "backend": os.environ.get("RH_BENCH_BACKEND", "nccl"), "master": f"{os.environ.get('MASTER_ADDR', '')}:{os.environ.get('MASTER_PORT', '')}",
+                          "cpu_baseline": world == 1 and args.cpu_sample > 0}))
+        return
     from rawhash_amd import Context, Index, MapOptions, SynthWorkload
     dist = None
     if world > 1:

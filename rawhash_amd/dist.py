@@ -4,6 +4,7 @@ The path shards by reads -- contiguous blocks per rank, no collective on the dat
 rank 0 uploads it, the flattened device blob is broadcast once and adopted by every rank's context.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -39,7 +40,11 @@ def replicate_index(ctx, opts, index=None, device="cuda", src=0):
     blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
     if rank == src:
         ctx.copy_blob_to(blob.data_ptr())
-    dist.broadcast(blob, src)
+    # a human-scale blob is 45 GB: broadcast in pieces that stay below 2^31 elements per collective (the count of a collective is
+    # an int in places down the stack) and let consecutive pieces pipeline over the xGMI ring
+    piece = int(os.environ.get("RH_BCAST_PIECE_BYTES", str(1 << 30)))
+    for o in range(0, nbytes, piece):
+        dist.broadcast(blob[o:o + piece], src)
     if str(device).startswith("cuda"):
         torch.cuda.synchronize()
     if rank != src:

@@ -65,7 +65,7 @@ def test_two_rank_gloo_matches_single_process_and_oracle(tmp_path, emu_lib):
     import oracle_lib as O
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RH_BCAST_PIECE_BYTES="100000")   # (the index blob goes over in dozens of pieces)
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                     "--master-port", "29533", str(script), ROOT, str(tmp_path)], check=True, env=env, timeout=600)
     got = pickle.load(open(tmp_path / "paf.pkl", "rb"))
@@ -132,3 +132,24 @@ def test_bench_ava_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["records_per_step"] == d1["records_per_step"] > 3000
+
+
+def test_bench_launch_plan_for_eight_gpus():
+    """`bench.py --gpus 8` as the driver launches it (torch.distributed.run environment), parsed without touching a GPU:
+    every rank takes its own contiguous shard, only a single-GPU run carries the CPU baseline leg, and a bare
+    `--gpus 8` without the launcher is refused."""
+    import json
+    plans = []
+    for r in range(8):
+        env = dict(os.environ, WORLD_SIZE="8", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29544")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--dry-run"],
+                             check=True, capture_output=True, text=True, env=env, timeout=120).stdout
+        plans.append(json.loads(out.strip().splitlines()[-1]))
+    assert [p["rank"] for p in plans] == list(range(8)) and all(p["world"] == 8 and p["gpus"] == 8 for p in plans)
+    assert [p["first_read"] for p in plans] == [r * plans[0]["reads_per_gpu"] for r in range(8)]
+    assert all(p["steps"] == 4 and p["warmup"] == 2 and p["backend"] == "nccl" and not p["cpu_baseline"] for p in plans)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], check=True, capture_output=True, text=True, env=env, timeout=120)
+    assert json.loads(one.stdout.strip().splitlines()[-1])["cpu_baseline"] is True
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], capture_output=True, text=True, env=env, timeout=120)
+    assert bad.returncode != 0 and "torch.distributed.run" in (bad.stderr + bad.stdout)
