@@ -231,6 +231,11 @@ RH_API int  rh_chain_batch(rh_ctx *ctx, const rh_mapopt_t *mo, uint32_t n_reads,
                            rh_mm128_t *chained, uint64_t chained_cap, uint64_t *chained_offsets,
                            uint64_t *u, uint64_t u_cap, uint64_t *u_offsets,
                            rh_mm128_t *prev_out /* the *_a copy = next chunk's prev_anchors, may be NULL */);
+/* mm_gen_regs + mm_set_parent + mm_select_sub + mm_set_mapq (hit.c:100-367, 502-539) on top of rh_chain_batch's chains, as ri_map_frag
+   runs them (rmap.cpp:346-377); qlen[r] = reg->offset + n_events seeds the region hash.  summary: 10 int32 per read =
+   {n_cregs, cnt, score, mapq, qs, qe, rs, re, rid, rev} of creg[0] (what the mapping decision and the record are built from) */
+RH_API int  rh_regions_batch(rh_ctx *ctx, const rh_mapopt_t *mo, uint32_t n_reads, const rh_mm128_t *anchors, const uint64_t *anchor_offsets,
+                             const int32_t *rep_len, const uint32_t *qlen, int32_t *summary);
 /* radix_sort_128x ksort.h:101-151 (exact, unstable permutation) on independent segments */
 RH_API int  rh_sort128x_batch(rh_ctx *ctx, uint32_t n_seg, rh_mm128_t *a, const uint64_t *offsets);
 /* the same sort the way the region keys of mm_gen_regs (hit.c:111-126: score << 32 | count ^ 32-bit hash, practically never equal) take

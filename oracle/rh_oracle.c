@@ -1172,6 +1172,40 @@ int ro_chain_batch(const ro_index *ix, const rh_mapopt_t *mo, uint32_t n_reads, 
 	return 0;
 }
 
+/* a17-a19 as a stage: mm_gen_regs + mm_set_parent + mm_select_sub + mm_set_mapq (hit.c:100-367, 502-539) of the chains of every read,
+   as ri_map_frag calls them (rmap.cpp:346-377).  chained / u: output of ro_chain_batch; qlen[r] = reg->offset + n_events (hash seed).
+   regs_out: 18 int32 per kept region in the order {id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0,
+   mapq, rev, hash}; reg_offsets[n_reads + 1] */
+int ro_regions_batch(const rh_mapopt_t *mo, uint32_t n_reads, const a128 *chained, const uint64_t *chained_offsets, const uint64_t *u, const uint64_t *u_offsets,
+                     const int32_t *rep_len, const uint32_t *qlen, int32_t *regs_out, uint64_t regs_cap, uint64_t *reg_offsets)
+{
+	uint64_t k = 0;
+	reg_offsets[0] = 0;
+	for (uint32_t r = 0; r < n_reads; ++r) {
+		int n_u = (int)(u_offsets[r + 1] - u_offsets[r]);
+		uint32_t hash = 0;
+		hash ^= wang32(qlen[r]) + wang32(11);
+		hash = wang32(hash);
+		int n = n_u;
+		reg_t *g = gen_regs(hash, n_u, u + u_offsets[r], chained + chained_offsets[r]);
+		set_parent(mo->mask_level, mo->mask_len, n, g, (mo->flag & RH_M_HARD_MLEVEL) ? 1 : 0);
+		if (!(mo->flag & RH_M_ALL_CHAINS)) select_sub(mo->pri_ratio, mo->best_n, 1, mo->max_target_gap_length * 0.8, &n, g);
+		set_mapq(n, g, mo->min_chaining_score, rep_len[r]);
+		if (k + (uint64_t)n > regs_cap) { free(g); return -1; }
+		for (int i = 0; i < n; ++i) {
+			const reg_t *q = &g[i];
+			int32_t *o = regs_out + (k + i) * 18;
+			o[0] = q->id; o[1] = q->cnt; o[2] = q->rid; o[3] = q->score; o[4] = q->qs; o[5] = q->qe; o[6] = q->rs; o[7] = q->re; o[8] = q->parent;
+			o[9] = q->subsc; o[10] = q->as; o[11] = q->mlen; o[12] = q->blen; o[13] = q->n_sub; o[14] = q->score0; o[15] = (int32_t)q->mapq;
+			o[16] = (int32_t)q->rev; o[17] = (int32_t)q->hash;
+		}
+		k += n;
+		reg_offsets[r + 1] = k;
+		free(g);
+	}
+	return 0;
+}
+
 int ro_sort128x_batch(uint32_t n_seg, a128 *a, const uint64_t *offsets)
 {
 	for (uint32_t s = 0; s < n_seg; ++s) ro_radix_sort_128x(a + offsets[s], a + offsets[s + 1]);

@@ -54,6 +54,8 @@ int ro_seed_batch(const ro_index *ix, const rh_mapopt_t *mo, uint32_t n_reads, c
 int ro_chain_batch(const ro_index *ix, const rh_mapopt_t *mo, uint32_t n_reads, const rh_mm128_t *anchors, const uint64_t *anchor_offsets,
                    rh_mm128_t *chained, uint64_t chained_cap, uint64_t *chained_offsets,
                    uint64_t *u, uint64_t u_cap, uint64_t *u_offsets, rh_mm128_t *prev_out);
+int ro_regions_batch(const rh_mapopt_t *mo, uint32_t n_reads, const rh_mm128_t *chained, const uint64_t *chained_offsets, const uint64_t *u, const uint64_t *u_offsets,
+                     const int32_t *rep_len, const uint32_t *qlen, int32_t *regs_out, uint64_t regs_cap, uint64_t *reg_offsets);   /* hit.c:100-367, 502-539 as a stage */
 int ro_sort128x_batch(uint32_t n_seg, rh_mm128_t *a, const uint64_t *offsets);
 
 /* the whole path: kt_for(map_worker_for) rmap.cpp:700 */

@@ -1263,6 +1263,43 @@ extern "C" int rh_chain_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, cons
 	return 0;
 }
 
+extern "C" int rh_regions_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, const rh_mm128_t *anchors, const uint64_t *anchor_offsets,
+                                const int32_t *rep_len, const uint32_t *qlen, int32_t *summary /* R x 10 */)
+{
+	// chain -> backtrack -> compact (as rh_chain_batch) and then the region stage of a round: keys + sort (hit.c:111-126), parents,
+	// secondaries dropped, MAPQ (hit.c:195-367, 502-539); summary[r] = {n_cregs, cnt, score, mapq, qs, qe, rs, re, rid, rev} of region 0
+	if (need_index(c)) return -1;
+	RH_HIP(hipSetDevice(c->device));
+	rh_mapopt_t m2 = *mo; m2.flag = 0; m2.bw_long = 0;
+	rh_dev_opt o;
+	if (fill_dev_opt(c, &m2, &o)) return -1;
+	rh_dev_reads rd;
+	if (stage_state_only(c, R, &rd)) return -1;
+	rh_dev_round rr{};
+	if (stage_round(c, R, &rr) || make_identity(c, R, 0)) return -1;
+	rr.act = c->act[0].as<uint32_t>();
+	const uint64_t total = anchor_offsets[R];
+	for (uint32_t r = 0; r < R; ++r) { const uint64_t m = anchor_offsets[r + 1] - anchor_offsets[r]; if (m > rr.max_anchors) rr.max_anchors = (uint32_t)m; }
+	if (stage_anchors(c, total, &rr)) return -1;
+	std::vector<uint8_t> skip(R ? R : 1, 0);
+	if (h2d(rr.a_off, anchor_offsets, (size_t)R + 1) || h2d(rr.anc, anchors, total) || h2d(rr.skip, skip.data(), R)) return -1;
+	if (h2d(rr.rep_len, rep_len, R) || h2d(rr.n_ev, qlen, R)) return -1;       // (ev_off = 0: the hash seed is offset + n_events, rmap.cpp:346)
+	RH_HIP(hipMemset(rr.counters, 0, 16 * 8));
+	RH_HIP(hipMemset(rr.n_u, 0, (size_t)(R ? R : 1) * 4)); RH_HIP(hipMemset(rr.n_v, 0, (size_t)(R ? R : 1) * 4));
+	hipStream_t s = c->stream;
+	rhk_chain(s, o, rr);
+	if (rhk_zsort(s, o, rr) || rhk_backtrack(s, o, rd, rr)) return -1;
+	if (rhk_regions_sort(s, o, rd, rr)) return -1;
+	rhk_regions(s, o, rd, rr, c->logf_tab.as<float>());
+	RH_HIP(hipStreamSynchronize(s));
+	RH_HIP(hipGetLastError());
+	std::vector<int32_t> f[10];
+	const int32_t *src[10] = { rd.ls_ncregs, rd.ls_cnt, rd.ls_score, rd.ls_mapq, rd.ls_qs, rd.ls_qe, rd.ls_rs, rd.ls_re, rd.ls_rid, rd.ls_rev };
+	for (int k = 0; k < 10; ++k) if (d2h(f[k], src[k], R)) return -1;
+	for (uint32_t r = 0; r < R; ++r) for (int k = 0; k < 10; ++k) summary[(size_t)r * 10 + k] = f[k][r];
+	return 0;
+}
+
 extern "C" int rh_sort128x_batch(rh_ctx *c, uint32_t n_seg, rh_mm128_t *a, const uint64_t *offsets)
 {
 	// runs the production sort stage (rhk_sort: LDS block sort fast/exact passes + oversized fallback) on free-standing segments

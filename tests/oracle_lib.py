@@ -44,6 +44,7 @@ def lib():
             "ro_sketch_batch": (i32, [vp, u32, vp, vp, vp, u64, vp]),
             "ro_seed_batch": (i32, [vp, P(MapOpt), u32, vp, vp, vp, vp, vp, vp, u64, vp, vp]),
             "ro_chain_batch": (i32, [vp, P(MapOpt), u32, vp, vp, vp, u64, vp, vp, u64, vp, vp]),
+            "ro_regions_batch": (i32, [P(MapOpt), u32, vp, vp, vp, vp, vp, vp, vp, u64, vp]),
             "ro_sort128x_batch": (i32, [u32, vp, vp]),
             "ro_map_batch": (i32, [vp, P(MapOpt), P(ReadBatch), vp, vp, u64, P(u64), i32]),
             "ro_last_counters": (None, [vp]),

@@ -147,9 +147,9 @@ def check_stages(ctx, wl):
     return len(oan), len(och)
 
 
-def check_chain_synthetic(ctx, wl, seed=0, n_reads=64, max_n=700):
-    """DP + backtrack + compact_a on adversarial anchor sets: collinear runs (long chains, every member a backtrack
-    candidate), bundles of anchors competing for the same predecessor (fan-in), random clutter, equal target positions."""
+def synthetic_anchor_sets(seed=0, n_reads=64, max_n=700):
+    """Adversarial anchor sets: collinear runs (long chains, every member a backtrack candidate), bundles of anchors competing
+    for the same predecessor (fan-in), random clutter, equal target positions."""
     rng = np.random.default_rng(seed)
     segs, off = [], [0]
     for r in range(n_reads):
@@ -181,11 +181,59 @@ def check_chain_synthetic(ctx, wl, seed=0, n_reads=64, max_n=700):
         segs.append(seg); off.append(off[-1] + n)
     an = np.concatenate(segs) if segs else np.zeros(0, dtype=MM128)
     ao = np.array(off, dtype=np.uint64)
+    return an, ao
+
+
+def check_chain_synthetic(ctx, wl, seed=0, n_reads=64, max_n=700):
+    """DP + backtrack + compact_a on the adversarial anchor sets."""
+    an, ao = synthetic_anchor_sets(seed, n_reads, max_n)
     och, oco, ou, ouo, opv = oracle_chains(wl, an, ao)
     ch, co, u, uo, pv = ctx.chain(wl.opts, an, ao)
     assert np.array_equal(co, oco) and np.array_equal(uo, ouo), "chain counts differ"
     assert np.array_equal(u, ou) and np.array_equal(ch, och) and np.array_equal(pv, opv), "chains differ"
     return len(an), len(och), len(ou)
+
+
+def oracle_regions(wl, ch, co, u, uo, rep_len, qlen):
+    """hit.c:100-367, 502-539 on the oracle's chains: (regs (k, 18) int32, offsets)."""
+    _, mo = wl.oracle()
+    n = len(co) - 1
+    cap = len(u) + 16
+    regs = np.zeros((cap, 18), dtype=np.int32)
+    ro = np.zeros(n + 1, dtype=np.uint64)
+    rl = np.ascontiguousarray(rep_len, dtype=np.int32)
+    ql = np.ascontiguousarray(qlen, dtype=np.uint32)
+    assert O.lib().ro_regions_batch(C.byref(mo), n, ptr(ch), ptr(co), ptr(u), ptr(uo), ptr(rl), ptr(ql), ptr(regs), cap, ptr(ro)) == 0
+    return regs[: int(ro[n])], ro
+
+
+def check_regions(ctx, wl, seed=0, n_reads=64, max_n=700):
+    """a17-a19 at stage level: region keys + exact sort (mm_gen_regs), parents / secondaries (mm_set_parent, mm_select_sub) and
+    MAPQ (mm_set_mapq) of the device against the oracle, on the chunk-0 anchors of the workload's reads and on the adversarial
+    anchor sets (hundreds of chains per read, many equal scores): n_cregs and every field of creg[0] the record is built from."""
+    ev, eoff = oracle_events(wl, 0)
+    osd, oso = oracle_seeds(wl, ev, eoff)
+    n = len(oso) - 1
+    oan, oao, orep = oracle_anchors(wl, osd, oso, np.zeros(n, dtype=np.uint32))
+    sets = [(oan, oao, orep, (eoff[1:] - eoff[:-1]).astype(np.uint32))]
+    san, sao = synthetic_anchor_sets(seed, n_reads, max_n)
+    rng = np.random.default_rng(seed + 1)
+    sets.append((san, sao, rng.integers(0, 400, size=len(sao) - 1).astype(np.int32), rng.integers(100, 3000, size=len(sao) - 1).astype(np.uint32)))
+    checked = with_regs = 0
+    for an, ao, rep, qlen in sets:
+        och, oco, ou, ouo, _ = oracle_chains(wl, an, ao)
+        regs, ro = oracle_regions(wl, och, oco, ou, ouo, rep, qlen)
+        got = ctx.regions(wl.opts, an, ao, rep, qlen)
+        for r in range(len(ao) - 1):
+            k0, k1 = int(ro[r]), int(ro[r + 1])
+            assert got[r, 0] == k1 - k0, f"read {r}: n_cregs {got[r, 0]} != {k1 - k0}"
+            if k1 > k0:
+                q = regs[k0]     # id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0, mapq, rev, hash
+                want = [q[1], q[3], q[15], q[4], q[5], q[6], q[7], q[2], q[16]]
+                assert list(got[r, 1:]) == [int(v) for v in want], f"read {r}: creg[0] {list(got[r, 1:])} != {want}"
+                with_regs += 1
+            checked += 1
+    return checked, with_regs
 
 
 def check_sort(ctx, seed=0, n_seg=40, big=()):

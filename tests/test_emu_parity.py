@@ -60,6 +60,11 @@ def test_chain_adversarial(ctx, wl):
     assert n_ch > 0 and n_u > 0
 
 
+def test_stage_regions(ctx, wl):
+    checked, with_regs = pc.check_regions(ctx, wl, seed=4, n_reads=40, max_n=500)
+    assert checked > 40 and with_regs > 20
+
+
 def test_end_to_end_paf(ctx, wl):
     recs = pc.check_e2e(ctx, wl)
     assert recs["mapped"].sum() > 0 and (recs["mapped"] == 0).sum() > 0   # both outcomes exercised

@@ -57,6 +57,12 @@ def test_exact_sort(ctx):
     pc.check_sort(ctx, seed=5, n_seg=40, big=(8193, 9000, 20000, 70000, 30000, 12345, 100000, 16384, 50000, 65537, 33333, 9999))
 
 
+def test_stage_regions(ctx, wl):
+    """a17-a19 (mm_gen_regs / mm_set_parent / mm_select_sub / mm_set_mapq) at stage level against the oracle."""
+    checked, with_regs = pc.check_regions(ctx, wl, seed=9, n_reads=300, max_n=2500)
+    assert checked > 300 and with_regs > 150
+
+
 def test_any_order_sort(ctx):
     """Region keys (hit.c:111-126) through the sorter's any-order levels + tie check, many long segments."""
     assert pc.check_sort_any(ctx, seed=5) >= 1

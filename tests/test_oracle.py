@@ -136,6 +136,20 @@ def test_oracle_vs_reference_stage_dumps(make_workload, tmp_path):
         assert np.array_equal(np.frombuffer(d[(4, r, 0)], dtype=np.uint64), u[int(uo[r]):int(uo[r + 1])]), "chain u[]"
         assert np.array_equal(np.frombuffer(d[(5, r, 0)], dtype=MM128), ch[int(co[r]):int(co[r + 1])]), "chained anchors"
         assert struct.unpack_from("<i", d[(7, r, 0)])[0] == rep[r], "rep_len"
+    # a17-a19: the regions the reference holds after mm_gen_regs / mm_set_parent / mm_select_sub / mm_set_mapq (hit.c), all 18 fields of
+    # every kept region of chunk 0 (record T_REGS of the dump; T_SCALARS = rep_len, n_events, offset)
+    qlen = np.array([struct.unpack_from("<3i", d[(7, r, 0)])[1] + struct.unpack_from("<3i", d[(7, r, 0)])[2] if (7, r, 0) in d else 0 for r in range(n)], dtype=np.uint32)
+    regs = np.zeros((len(u) + 16, 18), dtype=np.int32); ro = np.zeros(n + 1, dtype=np.uint64)
+    assert O.lib().ro_regions_batch(C.byref(mo), n, ptr(ch), ptr(co), ptr(u), ptr(uo), ptr(rep), ptr(qlen), ptr(regs), len(regs), ptr(ro)) == 0
+    n_reg_reads = 0
+    for r in range(n):
+        if (6, r, 0) not in d:
+            assert ro[r + 1] == ro[r]
+            continue
+        ref_regs = np.frombuffer(d[(6, r, 0)], dtype=np.int32).reshape(-1, 18)
+        assert np.array_equal(ref_regs, regs[int(ro[r]):int(ro[r + 1])]), f"regions of read {r} differ from the reference's"
+        n_reg_reads += len(ref_regs) > 0
+    assert n_reg_reads > 10
 
 
 @needs_ref
