@@ -17,6 +17,16 @@ def ava_cases():
         return json.load(f)
 
 
+def repeat_cases():
+    with open(os.path.join(GOLD, "repeat_cases.json")) as f:
+        return json.load(f)
+
+
+def build_repeat_case(case, directory, lib):
+    from repeat_workload import RepeatWorkload
+    return RepeatWorkload(directory, lib, **case["workload"])
+
+
 def build_ava_case(case, directory, lib):
     from conftest import AvaWorkload
     return AvaWorkload(directory, lib, **case["workload"])

@@ -45,6 +45,16 @@ AVA_CASES = [
 ]
 
 
+# Repeat-rich references (tests/repeat_workload.py): tandem repeats, segmental duplications with 1 % divergence, assembly gaps.
+# The small one runs in the CPU suite (oracle) and on the GPU; the 52 Mbp one puts > 8192 anchors into a chunk, so the multi-workgroup
+# exact sorter works on real tie-ridden keys (GPU suite only: the index is built on the device)
+REPEAT_CASES = [
+    {"name": "repeat_small_2M", "workload": dict(preset="sensitive", n_chrom=2, chrom_len=1_000_000, n_reads=120, genome_seed=41, read_seed=43)},
+    {"name": "repeat_fast_2M", "workload": dict(preset="fast", n_chrom=2, chrom_len=1_000_000, n_reads=120, genome_seed=45, read_seed=47)},
+    {"name": "repeat_rich_52M", "gpu_only": True, "workload": dict(preset="sensitive", n_chrom=4, chrom_len=13_000_000, n_reads=200, genome_seed=51, read_seed=53)},
+]
+
+
 def main():
     import oracle_lib as O
     from conftest import Workload
@@ -74,6 +84,22 @@ def main():
             print(case["name"], len(lines), "lines,", sum(1 for l in lines if l.split("\t")[4] != "*"), "mapped")
     with open(os.path.join(HERE, "cases.json"), "w") as f:
         json.dump(CASES, f, indent=1)
+    from repeat_workload import RepeatWorkload
+    for case in REPEAT_CASES:
+        if only and case["name"] not in only:
+            continue
+        with tempfile.TemporaryDirectory() as d:
+            w = RepeatWorkload(d, lib, **case["workload"])
+            ref_ind = os.path.join(d, "refbuilt.ind")
+            subprocess.run([O.REF_HARNESS, "index", w.preset, w.fasta, w.model, ref_ind, "8"], check=True, stderr=subprocess.DEVNULL)
+            out = subprocess.run([O.REF_HARNESS, "map", w.preset, ref_ind, w.rhr, "8"], check=True, capture_output=True, text=True).stdout
+            lines = [O.strip_mt(l) for l in out.splitlines()]
+            assert len(lines) == len(w.reads)
+            with open(os.path.join(HERE, case["name"] + ".paf"), "w") as f:
+                f.write("\n".join(lines) + "\n")
+            print(case["name"], len(lines), "lines,", sum(1 for l in lines if l.split("\t")[4] != "*"), "mapped")
+    with open(os.path.join(HERE, "repeat_cases.json"), "w") as f:
+        json.dump(REPEAT_CASES, f, indent=1)
     # Rawsamble (all-vs-all overlapping): `ref_harness sigindex` builds the signal-target index from the reads with the
     # reference's own functions, `ref_harness map` overlaps the same reads against it
     import hashlib

@@ -252,6 +252,28 @@ def test_golden_paf(product_lib, gpu_ctx_factory, tmp_path):
         assert len(got) == len(want) and not bad, f"{case['name']}: {len(bad)} PAF lines differ, first: {bad[:1]}"
 
 
+def test_repeat_rich_golden(product_lib, gpu_ctx_factory, tmp_path):
+    """Repeat-rich references (tandem repeats of 2-200 bp units, duplicated 10-100 kb blocks with 1 % divergence, runs of N;
+    tests/repeat_workload.py) against the PAF the reference printed: mid_occ filtering, the tandem flag (rseed.c:105-154), rep_len, and -
+    on the 52 Mbp case, whose chunks hold more than 8192 anchors - the multi-workgroup exact sorter on real tie-ridden keys.
+    Indexes are built on the device from the FASTA."""
+    import golden
+    from rawhash_amd.api import Index
+    for case in golden.repeat_cases():
+        w = golden.build_repeat_case(case, tmp_path / case["name"], product_lib)
+        c = gpu_ctx_factory()
+        index = Index.build_device(c, w.fasta, w.model, w.opts, n_threads=32)
+        w.opts.update(index)
+        recs = c.map_batch(w.opts, w.reads)
+        st = c.stats()
+        got = [strip_mt(x) for x in paf_lines(index, recs, w.reads.names)]
+        want = golden.expected_paf(case)
+        bad = [(g, x) for g, x in zip(got, want) if g != x]
+        assert len(got) == len(want) and not bad, f"{case['name']}: {len(bad)} PAF lines differ, first: {bad[:1]}"
+        if case.get("gpu_only"):
+            assert st["n_anchors"] / max(st["n_chunks"], 1) > 8192, "the large case is meant to reach the multi-workgroup sorter"
+
+
 def test_config2_ecoli_scale_vs_oracle(make_workload, product_lib):
     """BASELINE.json configs[1] at its index size: 4.6 Mbp index, 2560 reads of the bench's read set (10 % unmappable: all ten
     chunk rounds with carried chains), HIP path vs the oracle on all host cores."""

@@ -23,6 +23,26 @@ def test_oracle_matches_golden_paf(case, product_lib, tmp_path):
     assert w.oracle_paf() == golden.expected_paf(case)
 
 
+@pytest.mark.parametrize("case", [c for c in golden.repeat_cases() if not c.get("gpu_only")], ids=lambda c: c["name"])
+def test_oracle_matches_repeat_rich_golden(case, product_lib, tmp_path):
+    """Tandem repeats, segmental duplications, assembly gaps (tests/repeat_workload.py): mid_occ filter, tandem flag, rep_len and
+    heavy key ties, against the PAF the reference printed for the same inputs."""
+    import ctypes as C
+    from rawhash_amd.api import Index
+    w = golden.build_repeat_case(case, tmp_path, product_lib)
+    ind = str(tmp_path / "rep.ind")
+    index = Index.build(w.fasta, w.model, w.opts, out_ind=ind, n_threads=8, lib=product_lib)
+    oix = O.OracleIndex(ind)
+    _, mo = O.preset(w.preset)
+    O.lib().ro_mapopt_update(C.byref(mo), oix.h)
+    recs = O.map_batch(oix, mo, w.reads.batch(), n_threads=8)
+    got = [O.strip_mt(x) for x in O.paf_lines(oix, recs, w.reads.names)]
+    want = golden.expected_paf(case)
+    bad = [(g, x) for g, x in zip(got, want) if g != x]
+    assert len(got) == len(want) and not bad, f"{len(bad)} PAF lines differ, first: {bad[:1]}"
+    assert sum(1 for l in want if "\t*\t" in l) > 10 and sum(1 for l in want if "\t*\t" not in l) > 50
+
+
 def test_paf_formatters_agree(make_workload, product_lib):
     """product rh_paf_format == oracle ro_paf_format on the same records"""
     from rawhash_amd.api import paf_lines
