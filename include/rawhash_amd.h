@@ -262,6 +262,7 @@ RH_API void      rh_reads_destroy(rh_reads *r);
 RH_API uint32_t  rh_reads_n(const rh_reads *r);
 RH_API const char *rh_reads_name(const rh_reads *r, uint32_t i);
 RH_API int       rh_reads_batch(const rh_reads *r, rh_read_batch_t *out);   /* views into r; valid until destroy */
+RH_API int       rh_reads_pinned(const rh_reads *r);                          /* 1: the samples sit in page-locked memory (uploads at PCIe speed, no staging copy) */
 RH_API int       rh_reads_write(const char *path, uint32_t n, const char *const *names, const int16_t *samples,
                                 const uint64_t *offsets, double digitisation, double range, double offset);
 RH_API int       rh_reads_write_blow5(const char *path, uint32_t n, const char *const *names, const int16_t *samples, const uint64_t *offsets,

@@ -151,7 +151,7 @@ def _declare(lib):
         "rh_sort128x_batch": (i32, [vp, u32, vp, vp]), "rh_sort128x_any_batch": (i32, [vp, u32, vp, vp, vp]),
         "rh_paf_format": (i32, [vp, P(MapRecord), cp, C.c_double, cp, C.c_size_t]),
         "rh_reads_load": (vp, [cp]), "rh_reads_destroy": (None, [vp]), "rh_reads_n": (u32, [vp]),
-        "rh_reads_name": (cp, [vp, u32]), "rh_reads_batch": (i32, [vp, P(ReadBatch)]),
+        "rh_reads_name": (cp, [vp, u32]), "rh_reads_batch": (i32, [vp, P(ReadBatch)]), "rh_reads_pinned": (i32, [vp]),
         "rh_reads_write": (i32, [cp, u32, P(cp), vp, vp, C.c_double, C.c_double, C.c_double]),
         "rh_reads_write_blow5": (i32, [cp, u32, P(cp), vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, i32]),
         "rh_synth_cfg_init": (None, [P(SynthCfg)]), "rh_synth_write_model": (i32, [P(SynthCfg), cp]),

@@ -206,8 +206,44 @@ class Reads:
                                 float(digitisation), float(rng), float(offset)), l)
 
 
-def write_blow5(reads, path, digitisation, rng, offset, sampling_rate=4000.0, zlib_records=False, lib=None):
-    """Write a Reads batch as BLOW5 (one read group, no auxiliary fields)."""
+class ReadsFile:
+    """A read file kept in the library's own staging buffer (page-locked when a GPU is there): batch() is a view into it, so
+    rh_map_batch uploads straight from the memory the reader decoded into."""
+
+    def __init__(self, path, lib=None):
+        self._l = lib or _capi.lib()
+        self.h = self._l.rh_reads_load(os.fsencode(path))
+        if not self.h:
+            raise RhError(_capi.last_error(self._l))
+        self.names = [self._l.rh_reads_name(self.h, i).decode() for i in range(self._l.rh_reads_n(self.h))]
+        self.pinned = bool(self._l.rh_reads_pinned(self.h))
+
+    def __len__(self):
+        return len(self.names)
+
+    def batch(self):
+        b = ReadBatch()
+        self._l.rh_reads_batch(self.h, C.byref(b))
+        b._keep = self
+        return b
+
+    def close(self):
+        if self.h:
+            self._l.rh_reads_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_blow5(reads, path, digitisation, rng, offset, sampling_rate=4000.0, zlib_records=False, lib=None, records=None, svb_zd=False):
+    """Write a Reads batch as BLOW5 (one read group, no auxiliary fields).  records: "none" | "zlib" | "zstd" (default: zlib_records);
+    svb_zd: StreamVByte zig-zag delta compression of the signal."""
+    code = {"none": 0, "zlib": 1, "zstd": 2}[records] if records else int(bool(zlib_records))
+    zlib_records = code | (0x100 if svb_zd else 0)
     l = lib or _capi.lib()
     arr = (C.c_char_p * len(reads.names))(*[n.encode() for n in reads.names])
     _check(l.rh_reads_write_blow5(os.fsencode(path), len(reads.names), arr, ptr(reads.samples), ptr(reads.offsets),

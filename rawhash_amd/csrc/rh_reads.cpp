@@ -1,24 +1,55 @@
-// "RHR1" read container (own format; stands in for SLOW5/BLOW5 until a native reader lands).
-// The loader produces the SoA/CSR batch the C ABI takes: raw int16 samples + per-read calibration
-// {offset (double), scale = (float)(range/digitisation)} exactly as ri_read_sig_slow5 derives them (rsig.c:494).
+// Read containers -> the SoA/CSR batch the C ABI takes: raw int16 samples + per-read calibration {offset (double),
+// scale = (float)(range/digitisation)} exactly as ri_read_sig_slow5 derives them (rsig.c:494).
+//   BLOW5 (binary SLOW5): what the reference reads through slow5lib (rsig.c:170-206, 478-533) - uncompressed, zlib and zstd records,
+//                         raw or svb-zd (StreamVByte zig-zag delta) signals
+//   RHR1                : the repo's own trivial container (tests, the reference harness)
+// Samples are decoded straight into ONE page-locked staging buffer (hipHostMalloc; plain memory when no HIP runtime answers, e.g. in
+// the CPU test suite), so rh_map_batch / rh_map_submit upload them at PCIe speed without an intermediate copy.
 #include "rh_common.h"
 #include <exception>
+#include <dlfcn.h>
+#include <sys/stat.h>
+
+extern "C" void *rh_pinned_alloc(size_t bytes);
+extern "C" void rh_pinned_free(void *p);
+
+namespace {
+// growable int16 staging buffer in page-locked host memory
+struct Staging {
+	int16_t *p = nullptr; size_t n = 0, cap = 0; bool pinned = false;
+	~Staging() { release(); }
+	void release() { if (p) { if (pinned) rh_pinned_free(p); else free(p); } p = nullptr; n = cap = 0; }
+	bool reserve(size_t want)
+	{
+		if (want <= cap) return true;
+		size_t nc = cap ? cap : ((size_t)1 << 20);
+		while (nc < want) nc *= 2;
+		static const bool no_pin = getenv("RH_READS_NO_PIN") != nullptr;
+		int16_t *q = no_pin ? nullptr : (int16_t*)rh_pinned_alloc(nc * 2);
+		const bool pin = q != nullptr;
+		if (!q) q = (int16_t*)malloc(nc * 2);
+		if (!q) return false;
+		if (n) memcpy(q, p, n * 2);
+		if (p) { if (pinned) rh_pinned_free(p); else free(p); }
+		p = q; cap = nc; pinned = pin;
+		return true;
+	}
+	int16_t *grow(size_t k) { if (!reserve(n + k)) return nullptr; int16_t *at = p + n; n += k; return at; }
+};
+}
 
 struct rh_reads_s {
 	std::vector<std::string> names;
-	std::vector<int16_t> samples;
+	Staging samples;
 	std::vector<uint64_t> offsets;
 	std::vector<double> cal_offset;
 	std::vector<float> cal_scale;
 };
 
-static long file_remaining(FILE *fp)
+static uint64_t file_size_of(FILE *fp)
 {
-	const long at = ftell(fp);
-	if (at < 0 || fseek(fp, 0, SEEK_END) != 0) return -1;
-	const long end = ftell(fp);
-	fseek(fp, at, SEEK_SET);
-	return end < at ? -1 : end - at;
+	struct stat st;
+	return fstat(fileno(fp), &st) == 0 && st.st_size >= 0 ? (uint64_t)st.st_size : 0;
 }
 
 static rh_reads *reads_load_rhr(const char *path);
@@ -42,27 +73,31 @@ static rh_reads *reads_load_rhr(const char *path)
 {
 	FILE *fp = fopen(path, "rb");
 	if (!fp) { rh_set_error("cannot open %s", path); return 0; }
+	const uint64_t fsize = file_size_of(fp);                        // once: positions are tracked arithmetically from here on
+	uint64_t at = 0;
 	char magic[4]; uint32_t n;
 	if (fread(magic, 1, 4, fp) != 4 || memcmp(magic, "RHR1", 4) != 0 || fread(&n, 4, 1, fp) != 1) {
 		fclose(fp); rh_set_error("%s: not an RHR1 file", path); return 0;
 	}
+	at = 8;
 	rh_reads *r = new rh_reads_s();
 	r->offsets.push_back(0);
 	for (uint32_t i = 0; i < n; ++i) {
-		uint32_t l, ns; double dig, range, off;
+		uint32_t l = 0, ns = 0; double dig = 0, range = 0, off = 0;
 		std::string name;
-		bool ok = fread(&l, 4, 1, fp) == 1 && (long)l <= file_remaining(fp);      // lengths are checked against what is left of the file
-		if (ok) { name.resize(l); ok = l == 0 || fread(&name[0], 1, l, fp) == l; }
+		bool ok = fread(&l, 4, 1, fp) == 1 && (at += 4, (uint64_t)l <= fsize - at);      // lengths are checked against what is left of the file
+		if (ok) { name.resize(l); ok = l == 0 || fread(&name[0], 1, l, fp) == l; at += l; }
 		ok = ok && fread(&ns, 4, 1, fp) == 1 && fread(&dig, 8, 1, fp) == 1 && fread(&range, 8, 1, fp) == 1 && fread(&off, 8, 1, fp) == 1;
-		ok = ok && (long)ns * 2 <= file_remaining(fp);
+		at += 28;
+		ok = ok && at <= fsize && (uint64_t)ns * 2 <= fsize - at;
 		if (ok) {
-			size_t o = r->samples.size();
-			r->samples.resize(o + ns);
-			ok = ns == 0 || fread(&r->samples[o], 2, ns, fp) == ns;
+			int16_t *dst = r->samples.grow(ns);
+			ok = dst != nullptr && (ns == 0 || fread(dst, 2, ns, fp) == ns);
+			at += (uint64_t)ns * 2;
 		}
 		if (!ok) { fclose(fp); delete r; rh_set_error("%s: truncated at read %u", path, i); return 0; }
 		r->names.push_back(name);
-		r->offsets.push_back(r->samples.size());
+		r->offsets.push_back(r->samples.n);
 		r->cal_offset.push_back(off);
 		r->cal_scale.push_back((float)(range / dig));
 	}
@@ -71,34 +106,104 @@ static rh_reads *reads_load_rhr(const char *path)
 }
 
 // ---------------------------------------------------------------------------------------------------- BLOW5
-// Binary SLOW5 (hasindu2008/slow5lib, file format spec 1.0.0; what ri_read_sig_slow5 rsig.c:478-533 gets through slow5lib):
+// Binary SLOW5 (hasindu2008/slow5lib, file format spec 1.0.0; what ri_read_sig_slow5 rsig.c:478-533 gets through slow5lib).
+// slow5lib is an empty submodule of the reference tree, so this follows the published format, and is pinned by byte-level fixtures
+// the tests assemble by hand from it (tests/test_abi.py) - "parity unpinned" against slow5lib itself until a file written by
+// slow5tools is available:
 //   file header : "BLOW5\1" | version major, minor, patch (u8 x 3) | record compression (u8: 0 none, 1 zlib, 2 zstd)
 //                 | signal compression (u8: 0 none, 1 svb-zd; files from version 0.2.0 on) | number of read groups (u32)
 //                 | zero padding up to byte 64 | header text size (u32) | SLOW5 header text
-//   record      : record size (u64) | body (deflated as a whole when record compression = zlib):
+//   record      : record size (u64) | body (compressed as a whole: one zlib stream / one zstd frame per record):
 //                 read_id length (u16) | read_id | read_group (u32) | digitisation, offset, range, sampling_rate (f64 x 4)
-//                 | len_raw_signal (u64) | raw_signal (i16 x len) | auxiliary fields (ignored here)
+//                 | len_raw_signal (u64) | raw_signal | auxiliary fields (ignored here)
+//   raw_signal  : i16 x len, or with svb-zd: compressed byte count | u32 number of values | StreamVByte block of the
+//                 zig-zag-encoded first differences (x[0] - 0, x[1] - x[0], ...) of the samples widened to 32 bits.
+//                 StreamVByte (Lemire's 32-bit format): ceil(n / 4) control bytes, two bits per value (bytes used - 1, first value in
+//                 the low bits), then the values' 1 - 4 little-endian data bytes back to back.
 //   end of file : "5WOLB"
-// Records are decoded straight into the SoA batch (int16 samples + per-read calibration): the raw->pA conversion is the
-// device's.  zstd records and svb-zd signal compression are refused with an error (neither library is in this image).
+// The width of the "compressed byte count" could not be checked against slow5lib here; the reader therefore accepts a u64, a u32 or
+// no count at all, whichever makes the block consistent (inner value count = len_raw_signal, decode consumes exactly the block).
 #include <zlib.h>
+
+namespace {
+// libzstd is loaded at run time (the image has the library, not its headers): only the one-shot frame API is needed
+struct Zstd {
+	void *h = nullptr;
+	size_t (*decompress)(void*, size_t, const void*, size_t) = nullptr;
+	unsigned long long (*content_size)(const void*, size_t) = nullptr;
+	unsigned (*is_error)(size_t) = nullptr;
+	size_t (*compress)(void*, size_t, const void*, size_t, int) = nullptr;
+	size_t (*bound)(size_t) = nullptr;
+	bool ok = false;
+	Zstd()
+	{
+		for (const char *nm : {"libzstd.so.1", "libzstd.so"}) if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+		if (!h) return;
+		decompress = (decltype(decompress))dlsym(h, "ZSTD_decompress"); content_size = (decltype(content_size))dlsym(h, "ZSTD_getFrameContentSize");
+		is_error = (decltype(is_error))dlsym(h, "ZSTD_isError"); compress = (decltype(compress))dlsym(h, "ZSTD_compress"); bound = (decltype(bound))dlsym(h, "ZSTD_compressBound");
+		ok = decompress && content_size && is_error && compress && bound;
+	}
+};
+Zstd &zstd() { static Zstd z; return z; }
+
+// StreamVByte block of n values at p (at most avail bytes): decoded zig-zag deltas accumulated into int16 samples.
+// Returns the bytes consumed, 0 if the block does not fit avail.
+size_t svb_zd_decode(const unsigned char *p, size_t avail, uint32_t n, int16_t *out)
+{
+	const size_t n_ctl = ((size_t)n + 3) / 4;
+	if (n_ctl > avail) return 0;
+	const unsigned char *ctl = p, *dat = p + n_ctl, *end = p + avail;
+	int32_t prev = 0;
+	for (uint32_t i = 0; i < n; ++i) {
+		const unsigned code = (ctl[i >> 2] >> ((i & 3) * 2)) & 3u;
+		if (dat + code + 1 > end) return 0;
+		uint32_t v = dat[0];
+		if (code >= 1) v |= (uint32_t)dat[1] << 8;
+		if (code >= 2) v |= (uint32_t)dat[2] << 16;
+		if (code >= 3) v |= (uint32_t)dat[3] << 24;
+		dat += code + 1;
+		const int32_t d = (int32_t)(v >> 1) ^ -(int32_t)(v & 1u);     // zig-zag
+		prev += d;
+		out[i] = (int16_t)prev;
+	}
+	return (size_t)(dat - p);
+}
+
+size_t svb_zd_encode(const int16_t *x, uint32_t n, std::vector<unsigned char> &out)   // (the writer: tests, format conversion)
+{
+	const size_t n_ctl = ((size_t)n + 3) / 4, at0 = out.size();
+	out.resize(at0 + n_ctl, 0);
+	int32_t prev = 0;
+	for (uint32_t i = 0; i < n; ++i) {
+		const int32_t d = (int32_t)x[i] - prev; prev = x[i];
+		const uint32_t v = ((uint32_t)d << 1) ^ (uint32_t)(d >> 31);
+		const unsigned code = v < (1u << 8) ? 0 : v < (1u << 16) ? 1 : v < (1u << 24) ? 2 : 3;
+		out[at0 + (i >> 2)] |= (unsigned char)(code << ((i & 3) * 2));
+		for (unsigned b = 0; b <= code; ++b) out.push_back((unsigned char)(v >> (8 * b)));
+	}
+	return out.size() - at0;
+}
+}
 
 static rh_reads *reads_load_blow5(const char *path)
 {
 	FILE *fp = fopen(path, "rb");
 	if (!fp) { rh_set_error("cannot open %s", path); return 0; }
 	auto fail = [&](rh_reads *r, const char *what) { fclose(fp); delete r; rh_set_error("%s: %s", path, what); return (rh_reads*)0; };
+	const uint64_t fsize = file_size_of(fp);
 	unsigned char hd[64];
 	if (fread(hd, 1, 64, fp) != 64 || memcmp(hd, "BLOW5\1", 6)) return fail(0, "not a BLOW5 file");
 	const int vmaj = hd[6], vmin = hd[7];
 	const int rec_comp = hd[9];
 	const bool has_sig_byte = vmaj > 0 || vmin >= 2;
 	const int sig_comp = has_sig_byte ? hd[10] : 0;
-	if (rec_comp == 2) return fail(0, "zstd-compressed BLOW5 records are not supported (convert with `slow5tools view -c zlib`)");
-	if (rec_comp != 0 && rec_comp != 1) return fail(0, "unknown BLOW5 record compression");
-	if (sig_comp != 0) return fail(0, "svb-zd signal compression is not supported (convert with `slow5tools view -s none`)");
+	if (rec_comp < 0 || rec_comp > 2) return fail(0, "unknown BLOW5 record compression");
+	if (rec_comp == 2 && !zstd().ok) return fail(0, "zstd-compressed BLOW5 records need libzstd.so.1, which could not be loaded (convert with `slow5tools view -c zlib`)");
+	if (sig_comp != 0 && sig_comp != 1) return fail(0, "unknown BLOW5 signal compression");
 	uint32_t hsize;
-	if (fread(&hsize, 4, 1, fp) != 1 || (long)hsize > file_remaining(fp) || fseek(fp, (long)hsize, SEEK_CUR)) return fail(0, "truncated BLOW5 header");
+	uint64_t at = 64;
+	if (fread(&hsize, 4, 1, fp) != 1 || (at += 4, (uint64_t)hsize > fsize - at) || fseek(fp, (long)hsize, SEEK_CUR)) return fail(0, "truncated BLOW5 header");
+	at += hsize;
 	rh_reads *r = new rh_reads_s();
 	r->offsets.push_back(0);
 	std::vector<unsigned char> raw, body;
@@ -108,10 +213,12 @@ static rh_reads *reads_load_blow5(const char *path)
 		if (got >= 5 && !memcmp(szb, "5WOLB", 5)) break;               // end-of-file marker
 		if (got == 0) break;                                           // (files cut before the marker still give their records)
 		if (got != 8) return fail(r, "truncated BLOW5 record");
+		at += 8;
 		uint64_t rsz; memcpy(&rsz, szb, 8);
-		if ((long)rsz > file_remaining(fp) || rsz > (1ull << 34)) return fail(r, "implausible BLOW5 record size");
+		if (at > fsize || rsz > fsize - at || rsz >= (1ull << 32)) return fail(r, "implausible BLOW5 record size");   // (records are one read: far below 4 GiB, which is also what zlib's 32-bit counters take)
 		raw.resize(rsz);
 		if (rsz && fread(raw.data(), 1, rsz, fp) != rsz) return fail(r, "truncated BLOW5 record");
+		at += rsz;
 		const unsigned char *b = raw.data();
 		size_t blen = rsz;
 		if (rec_comp == 1) {	// one zlib stream per record
@@ -123,31 +230,59 @@ static rh_reads *reads_load_blow5(const char *path)
 			int rc;
 			do {
 				if (out == body.size()) body.resize(body.size() * 2);
-				zs.next_out = body.data() + out; zs.avail_out = (uInt)(body.size() - out);
+				const size_t room = body.size() - out;
+				zs.next_out = body.data() + out; zs.avail_out = (uInt)(room < 0x40000000u ? room : 0x40000000u);
+				const uInt gave = zs.avail_out;
 				rc = inflate(&zs, Z_NO_FLUSH);
-				out = body.size() - zs.avail_out;
+				out += gave - zs.avail_out;
 			} while (rc == Z_OK);
 			inflateEnd(&zs);
 			if (rc != Z_STREAM_END) return fail(r, "corrupt zlib BLOW5 record");
 			b = body.data(); blen = out;
+		} else if (rec_comp == 2) {	// one zstd frame per record
+			const unsigned long long full = zstd().content_size(raw.data(), rsz);
+			if (full == 0ull - 1 || full == 0ull - 2 || full > (1ull << 34)) return fail(r, "corrupt zstd BLOW5 record (frame size)");
+			body.resize((size_t)full + 8);
+			const size_t got2 = zstd().decompress(body.data(), body.size(), raw.data(), rsz);
+			if (zstd().is_error(got2) || got2 != full) return fail(r, "corrupt zstd BLOW5 record");
+			b = body.data(); blen = got2;
 		}
-		size_t at = 0;
-		auto need = [&](size_t n) { return at + n <= blen; };
+		size_t pos = 0;
+		auto need = [&](size_t n) { return pos + n <= blen; };
 		uint16_t idl; uint32_t rg; double dig, off, range, rate; uint64_t ns;
-		if (!need(2)) return fail(r, "short BLOW5 record"); memcpy(&idl, b + at, 2); at += 2;
+		if (!need(2)) return fail(r, "short BLOW5 record"); memcpy(&idl, b + pos, 2); pos += 2;
 		if (!need(idl)) return fail(r, "short BLOW5 record");
-		std::string name((const char*)b + at, idl); at += idl;
+		std::string name((const char*)b + pos, idl); pos += idl;
 		if (!need(4 + 32 + 8)) return fail(r, "short BLOW5 record");
-		memcpy(&rg, b + at, 4); at += 4;
-		memcpy(&dig, b + at, 8); at += 8; memcpy(&off, b + at, 8); at += 8; memcpy(&range, b + at, 8); at += 8; memcpy(&rate, b + at, 8); at += 8;
-		memcpy(&ns, b + at, 8); at += 8;
-		if (ns > (1ull << 32) || !need(ns * 2)) return fail(r, "short BLOW5 record (signal)");
-		const size_t o = r->samples.size();
-		r->samples.resize(o + ns);
-		if (ns) memcpy(&r->samples[o], b + at, ns * 2);
+		memcpy(&rg, b + pos, 4); pos += 4;
+		memcpy(&dig, b + pos, 8); pos += 8; memcpy(&off, b + pos, 8); pos += 8; memcpy(&range, b + pos, 8); pos += 8; memcpy(&rate, b + pos, 8); pos += 8;
+		memcpy(&ns, b + pos, 8); pos += 8;
+		if (ns > (1ull << 32)) return fail(r, "short BLOW5 record (signal)");
+		int16_t *dst = r->samples.grow(ns);
+		if (!dst) return fail(r, "out of memory for the sample staging buffer");
+		if (sig_comp == 0) {
+			if (!need(ns * 2)) return fail(r, "short BLOW5 record (signal)");
+			if (ns) memcpy(dst, b + pos, ns * 2);
+		} else {	// svb-zd: [compressed byte count (u64 | u32 | absent)] u32 values | StreamVByte block - the count's width by consistency
+			bool done = false;
+			for (int width : {8, 4, 0}) {
+				size_t q = pos;
+				uint64_t cnt = 0;
+				if (width) { if (q + width > blen) continue; memcpy(&cnt, b + q, width); q += width; if (cnt < 4 || cnt > blen - q) continue; }
+				if (q + 4 > blen) continue;
+				uint32_t nv; memcpy(&nv, b + q, 4);
+				if (nv != ns) continue;
+				const size_t avail = width ? (size_t)cnt - 4 : blen - q - 4;
+				const size_t used = svb_zd_decode(b + q + 4, avail, nv, dst);
+				if ((ns && !used) || (width && used != avail)) continue;
+				done = true;
+				break;
+			}
+			if (!done) return fail(r, "corrupt svb-zd signal in a BLOW5 record");
+		}
 		(void)rg; (void)rate;
 		r->names.push_back(name);
-		r->offsets.push_back(r->samples.size());
+		r->offsets.push_back(r->samples.n);
 		r->cal_offset.push_back(off);
 		r->cal_scale.push_back((float)(range / dig));                  // rsig.c:494
 	}
@@ -155,17 +290,20 @@ static rh_reads *reads_load_blow5(const char *path)
 	return r;
 }
 
-// Writer (tests, format conversion): one read group, no auxiliary fields; zlib != 0 deflates every record.
+// Writer (tests, format conversion): one read group, no auxiliary fields.  `compression` & 0xFF = record compression (0 none, 1 zlib,
+// 2 zstd); bit 8 = svb-zd signal compression (compressed byte count written as u64).
 extern "C" int rh_reads_write_blow5(const char *path, uint32_t n, const char *const *names, const int16_t *samples, const uint64_t *offsets,
-                                    double digitisation, double range, double offset, double sampling_rate, int zlib_records)
+                                    double digitisation, double range, double offset, double sampling_rate, int compression)
 {
+	const int rec_comp = compression & 0xFF; const bool svb = (compression & 0x100) != 0;
+	if (rec_comp > 2 || (rec_comp == 2 && !zstd().ok)) { rh_set_error("BLOW5 writer: record compression %d is not available", rec_comp); return -1; }
 	FILE *fp = fopen(path, "wb");
 	if (!fp) { rh_set_error("cannot write %s", path); return -1; }
 	unsigned char hd[64];
 	memset(hd, 0, sizeof(hd));
 	memcpy(hd, "BLOW5\1", 6);
 	hd[6] = 1; hd[7] = 0; hd[8] = 0;                                   // file format 1.0.0
-	hd[9] = zlib_records ? 1 : 0; hd[10] = 0;
+	hd[9] = (unsigned char)rec_comp; hd[10] = svb ? 1 : 0;
 	const uint32_t n_rg = 1;
 	memcpy(hd + 11, &n_rg, 4);
 	fwrite(hd, 1, 64, fp);
@@ -183,10 +321,23 @@ extern "C" int rh_reads_write_blow5(const char *path, uint32_t n, const char *co
 		body.clear();
 		auto put = [&](const void *p, size_t k) { const unsigned char *q = (const unsigned char*)p; body.insert(body.end(), q, q + k); };
 		put(&idl, 2); put(names[i], idl); put(&rg, 4); put(&digitisation, 8); put(&offset, 8); put(&range, 8); put(&sampling_rate, 8); put(&ns, 8);
-		put(samples + offsets[i], ns * 2);
+		if (!svb) put(samples + offsets[i], ns * 2);
+		else {
+			std::vector<unsigned char> blk;
+			const uint32_t nv = (uint32_t)ns;
+			blk.insert(blk.end(), (const unsigned char*)&nv, (const unsigned char*)&nv + 4);
+			svb_zd_encode(samples + offsets[i], nv, blk);
+			const uint64_t cnt = blk.size();
+			put(&cnt, 8); put(blk.data(), blk.size());
+		}
 		const unsigned char *out = body.data();
 		uint64_t rsz = body.size();
-		if (zlib_records) {
+		if (rec_comp == 2) {
+			comp.resize(zstd().bound(body.size()));
+			const size_t cl = zstd().compress(comp.data(), comp.size(), body.data(), body.size(), 3);
+			if (zstd().is_error(cl)) { fclose(fp); rh_set_error("zstd failed"); return -1; }
+			out = comp.data(); rsz = cl;
+		} else if (rec_comp == 1) {
 			uLongf cl = compressBound((uLong)body.size());
 			comp.resize(cl);
 			if (compress2(comp.data(), &cl, body.data(), (uLong)body.size(), Z_DEFAULT_COMPRESSION) != Z_OK) { fclose(fp); rh_set_error("zlib failed"); return -1; }
@@ -201,6 +352,7 @@ extern "C" int rh_reads_write_blow5(const char *path, uint32_t n, const char *co
 }
 
 extern "C" void rh_reads_destroy(rh_reads *r) { delete r; }
+extern "C" int rh_reads_pinned(const rh_reads *r) { return r->samples.pinned ? 1 : 0; }
 extern "C" uint32_t rh_reads_n(const rh_reads *r) { return (uint32_t)r->names.size(); }
 extern "C" const char *rh_reads_name(const rh_reads *r, uint32_t i) { return i < r->names.size() ? r->names[i].c_str() : 0; }
 
@@ -208,7 +360,7 @@ extern "C" int rh_reads_batch(const rh_reads *r, rh_read_batch_t *out)
 {
 	memset(out, 0, sizeof(*out));
 	out->n_reads = (uint32_t)r->names.size();
-	out->samples = r->samples.data();
+	out->samples = r->samples.p;
 	out->offsets = r->offsets.data();
 	out->cal_offset = r->cal_offset.data();
 	out->cal_scale = r->cal_scale.data();

@@ -222,6 +222,19 @@ def test_nccl_replicate_index_across_devices(product_lib, tmp_path):
     assert (tmp_path / "ok").exists()
 
 
+def test_blow5_file_maps_from_pinned_staging(ctx, wl, product_lib, tmp_path):
+    """zstd records + svb-zd signals (slow5tools' defaults) decoded straight into the page-locked staging buffer; mapping from that
+    buffer gives the records of the in-memory batch."""
+    from rawhash_amd.api import ReadsFile, write_blow5
+    cfg = wl.wl.cfg
+    p = str(tmp_path / "reads.blow5")
+    write_blow5(wl.reads, p, cfg.digitisation, cfg.range, cfg.offset, records="zstd", svb_zd=True, lib=product_lib)
+    f = ReadsFile(p, lib=product_lib)
+    assert f.pinned and f.names == wl.reads.names
+    assert np.array_equal(ctx.map_batch(wl.opts, f.batch()), ctx.map_batch(wl.opts, wl.reads))
+    f.close()
+
+
 def test_batch_split_invariance(ctx, wl):
     """Mapping is per-read independent: any split of the batch gives the same records (property used by sharding)."""
     full = ctx.map_batch(wl.opts, wl.reads)
