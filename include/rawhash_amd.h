@@ -67,6 +67,7 @@ typedef struct rh_mapopt_s {
 	int64_t flag;
 	uint32_t window_length1, window_length2;
 	float threshold1, threshold2, peak_height;
+	int32_t rmq_inner_dist, rmq_size_cap;   /* --rmq-inner-dist [1000], --rmq-size-cap [100000] (roptions.c:65-66): RH_M_RMQ chaining and the bw_long > bw re-chaining */
 } rh_mapopt_t;
 
 /* One output record = ri_map_t (rmap.h:12-22) + the integer tag values rmap.cpp:523-571 formats.

@@ -111,6 +111,10 @@ static void apply_overrides(ri_idxopt_t *ipt, ri_mapopt_t *opt)
 	if ((s = getenv("RH_W"))) ipt->w = atoi(s);
 	if ((s = getenv("RH_E"))) ipt->e = atoi(s);
 	if ((s = getenv("RH_NO_ADAPTIVE")) && atoi(s)) opt->flag |= RI_M_NO_ADAPTIVE;   // --disable-adaptive (main.cpp:369)
+	if ((s = getenv("RH_RMQ")) && atoi(s)) opt->flag |= RI_M_RMQ;                    // --rmq (main.cpp:330)
+	if ((s = getenv("RH_RMQ_INNER_DIST"))) opt->rmq_inner_dist = atoi(s);           // --rmq-inner-dist (:331)
+	if ((s = getenv("RH_RMQ_SIZE_CAP"))) opt->rmq_size_cap = atoi(s);               // --rmq-size-cap (:332)
+	if ((s = getenv("RH_BW_LONG"))) opt->bw_long = atoi(s);                         // --bw-long (:333)
 }
 
 static int set_presets(const char *preset, ri_idxopt_t *ipt, ri_mapopt_t *opt)

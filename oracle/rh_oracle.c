@@ -33,6 +33,7 @@ void ro_mapopt_init(rh_mapopt_t *mo)
 	mo->max_chain_iter = 200; mo->max_num_skips = 5; mo->min_num_anchors = 2;
 	mo->min_chaining_score = 15; mo->min_chaining_score2 = 0;
 	mo->chain_gap_scale = 0.8f; mo->chain_skip_scale = 0.0f;
+	mo->rmq_inner_dist = 1000; mo->rmq_size_cap = 100000;	/* roptions.c:65-66 */
 	mo->mask_level = 0.5f; mo->mask_len = INT_MAX; mo->pri_ratio = 0.3f; mo->best_n = 0; mo->alt_drop = 0.15f;
 	mo->w_bestmq = 0.05f; mo->w_bestmc = 0.6f; mo->w_bestq = 0.35f; mo->w_threshold = 0.45f;
 	mo->min_events = 50; mo->max_num_chunk = 10; mo->min_mapq = 2;
@@ -628,51 +629,12 @@ static int64_t bk_end(int32_t max_drop, const a128 *z, const int32_t *f, const i
 	return max_i;
 }
 
-/* mg_lchain_dp lchain.c:385-530 with mg_chain_backtrack :95-194 and compact_a :214-281.
- * in : a[n] sorted anchors (freed here).  out: returned array of chained anchors (*n updated), *u_out (malloc, n_u),
- *      *prev_out = copy of the chained anchors in pre-sort chain order (next chunk's prev_anchors). */
-static a128 *chain_dp(const rh_mapopt_t *mo, float pen_gap, float pen_skip, int64_t *n_io, a128 *a, a128 **prev_out, int *n_u_out, uint64_t **u_out)
+/* mg_chain_backtrack (lchain.c:95-194) + compact_a (:214-281) on filled f / p / v / t (all freed here, and a); what both
+ * mg_lchain_dp and mg_lchain_rmq end with */
+static a128 *chain_finish(int64_t n, a128 *a, int32_t *f, int64_t *p, int32_t *v, int32_t *t, int min_cnt, int min_sc, int32_t max_drop,
+                          int64_t *n_io, a128 **prev_out, int *n_u_out, uint64_t **u_out)
 {
-	int max_dist_t = mo->max_target_gap_length, max_dist_q = mo->max_query_gap_length, bw = mo->bw;
-	const int max_skip = mo->max_num_skips, max_iter = mo->max_chain_iter, min_cnt = mo->min_num_anchors, min_sc = mo->min_chaining_score;
-	const int32_t max_drop = bw;
-	int64_t n = *n_io;
-	*u_out = 0; *n_u_out = 0;
-	free(*prev_out); *prev_out = 0;
-	if (n == 0 || a == 0) { free(a); *n_io = 0; return 0; }
-	if (max_dist_t < bw) max_dist_t = bw;
-	if (max_dist_q < bw) max_dist_q = bw;
-	int64_t *p = (int64_t*)malloc(n * 8);
-	int32_t *f = (int32_t*)malloc(n * 4), *v = (int32_t*)malloc(n * 4), *t = (int32_t*)calloc(n, 4);
-	int64_t st = 0, max_ii = -1;
-	for (int64_t i = 0; i < n; ++i) {
-		int64_t max_j = -1, end_j, j;
-		int32_t max_f = (int32_t)((a[i].y >> 32) & 63), n_skip = 0;
-		while (st < i && (a[i].x >> 32 != a[st].x >> 32 || a[i].x > a[st].x + (uint64_t)max_dist_t)) ++st;
-		if (i - st > max_iter) st = i - max_iter;
-		for (j = i - 1; j >= st; --j) {
-			int32_t sc = pair_score(&a[i], &a[j], max_dist_t, max_dist_q, bw, pen_gap, pen_skip);
-			if (sc == INT32_MIN) continue;
-			sc += f[j];
-			if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
-			else if (t[j] == (int32_t)i) { if (++n_skip > max_skip) break; }
-			if (p[j] >= 0) t[p[j]] = (int32_t)i;
-		}
-		end_j = j;
-		if (max_ii < 0 || a[i].x - a[max_ii].x > (uint64_t)(int64_t)max_dist_t) {
-			int32_t mx = INT32_MIN;
-			max_ii = -1;
-			for (j = i - 1; j >= st; --j) if (mx < f[j]) { mx = f[j]; max_ii = j; }
-		}
-		if (max_ii >= 0 && max_ii < end_j) {
-			int32_t tmp = pair_score(&a[i], &a[max_ii], max_dist_t, max_dist_q, bw, pen_gap, pen_skip);
-			if (tmp != INT32_MIN && max_f < tmp + f[max_ii]) { max_f = tmp + f[max_ii]; max_j = max_ii; }
-		}
-		f[i] = max_f; p[i] = max_j;
-		v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
-		if (max_ii < 0 || (a[i].x - a[max_ii].x <= (uint64_t)(int64_t)max_dist_t && f[max_ii] < f[i])) max_ii = i;
-	}
-	/* backtrack (lchain.c:95-194): v[] is reused for the chain members */
+	/* backtrack: v[] is reused for the chain members */
 	int64_t n_z = 0, n_v = 0; int32_t n_u = 0;
 	uint64_t *u = 0;
 	for (int64_t i = 0; i < n; ++i) if (f[i] >= min_sc) ++n_z;
@@ -723,6 +685,336 @@ static a128 *chain_dp(const rh_mapopt_t *mo, float pen_gap, float pen_skip, int6
 	*prev_out = pa;
 	*n_io = k;
 	return res;
+}
+
+
+/* mg_lchain_dp lchain.c:385-530 with mg_chain_backtrack :95-194 and compact_a :214-281.
+ * in : a[n] sorted anchors (freed here).  out: returned array of chained anchors (*n updated), *u_out (malloc, n_u),
+ *      *prev_out = copy of the chained anchors in pre-sort chain order (next chunk's prev_anchors). */
+static a128 *chain_dp(const rh_mapopt_t *mo, float pen_gap, float pen_skip, int64_t *n_io, a128 *a, a128 **prev_out, int *n_u_out, uint64_t **u_out)
+{
+	int max_dist_t = mo->max_target_gap_length, max_dist_q = mo->max_query_gap_length, bw = mo->bw;
+	const int max_skip = mo->max_num_skips, max_iter = mo->max_chain_iter, min_cnt = mo->min_num_anchors, min_sc = mo->min_chaining_score;
+	const int32_t max_drop = bw;
+	int64_t n = *n_io;
+	*u_out = 0; *n_u_out = 0;
+	free(*prev_out); *prev_out = 0;
+	if (n == 0 || a == 0) { free(a); *n_io = 0; return 0; }
+	if (max_dist_t < bw) max_dist_t = bw;
+	if (max_dist_q < bw) max_dist_q = bw;
+	int64_t *p = (int64_t*)malloc(n * 8);
+	int32_t *f = (int32_t*)malloc(n * 4), *v = (int32_t*)malloc(n * 4), *t = (int32_t*)calloc(n, 4);
+	int64_t st = 0, max_ii = -1;
+	for (int64_t i = 0; i < n; ++i) {
+		int64_t max_j = -1, end_j, j;
+		int32_t max_f = (int32_t)((a[i].y >> 32) & 63), n_skip = 0;
+		while (st < i && (a[i].x >> 32 != a[st].x >> 32 || a[i].x > a[st].x + (uint64_t)max_dist_t)) ++st;
+		if (i - st > max_iter) st = i - max_iter;
+		for (j = i - 1; j >= st; --j) {
+			int32_t sc = pair_score(&a[i], &a[j], max_dist_t, max_dist_q, bw, pen_gap, pen_skip);
+			if (sc == INT32_MIN) continue;
+			sc += f[j];
+			if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
+			else if (t[j] == (int32_t)i) { if (++n_skip > max_skip) break; }
+			if (p[j] >= 0) t[p[j]] = (int32_t)i;
+		}
+		end_j = j;
+		if (max_ii < 0 || a[i].x - a[max_ii].x > (uint64_t)(int64_t)max_dist_t) {
+			int32_t mx = INT32_MIN;
+			max_ii = -1;
+			for (j = i - 1; j >= st; --j) if (mx < f[j]) { mx = f[j]; max_ii = j; }
+		}
+		if (max_ii >= 0 && max_ii < end_j) {
+			int32_t tmp = pair_score(&a[i], &a[max_ii], max_dist_t, max_dist_q, bw, pen_gap, pen_skip);
+			if (tmp != INT32_MIN && max_f < tmp + f[max_ii]) { max_f = tmp + f[max_ii]; max_j = max_ii; }
+		}
+		f[i] = max_f; p[i] = max_j;
+		v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
+		if (max_ii < 0 || (a[i].x - a[max_ii].x <= (uint64_t)(int64_t)max_dist_t && f[max_ii] < f[i])) max_ii = i;
+	}
+	return chain_finish(n, a, f, p, v, t, min_cnt, min_sc, max_drop, n_io, prev_out, n_u_out, u_out);
+}
+
+/* ================================================================== f4: RMQ chaining (lchain.c:532-756 over krmq.h)
+ * krmq.h (klib, vendored in the reference) is an AVL tree keyed by (y, i) whose nodes also carry the size of their subtree and a
+ * pointer `s` to the element of least `pri` in it.  Equal `pri` values are told apart by position in the tree - an ancestor wins over
+ * its descendants, left over right - so the anchor mg_lchain_rmq picks depends on the tree's SHAPE, i.e. on the exact insertion /
+ * deletion / rotation history.  Restated operation by operation. */
+typedef struct rq_node_s {
+	int32_t y; int64_t i; double pri;
+	struct rq_node_s *p[2], *s;
+	signed char balance; unsigned size;
+} rq_node;
+#define RQ_DEPTH 64
+static inline int rq_cmp(const rq_node *a, const rq_node *b) { return a->y < b->y ? -1 : a->y > b->y ? 1 : (a->i > b->i) - (a->i < b->i); }	/* lc_elem_cmp lchain.c:539 */
+#define rq_lt2(a, b) ((a)->pri < (b)->pri)																/* lc_elem_lt2 :540 */
+#define rq_size(p) ((p) ? (p)->size : 0u)
+#define rq_size_child(q, k) ((q)->p[(k)] ? (q)->p[(k)]->size : 0u)
+
+static rq_node *rq_find(const rq_node *root, const rq_node *x)	/* krmq.h:81-96 */
+{
+	const rq_node *p = root;
+	while (p) { int c = rq_cmp(x, p); if (c < 0) p = p->p[0]; else if (c > 0) p = p->p[1]; else break; }
+	return (rq_node*)p;
+}
+static void rq_interval(const rq_node *root, const rq_node *x, rq_node **lower, rq_node **upper)	/* krmq.h:97-108 */
+{
+	const rq_node *p = root, *l = 0, *u = 0;
+	while (p) { int c = rq_cmp(x, p); if (c < 0) { u = p; p = p->p[0]; } else if (c > 0) { l = p; p = p->p[1]; } else { l = u = p; break; } }
+	*lower = (rq_node*)l; *upper = (rq_node*)u;
+}
+static rq_node *rq_rmq(const rq_node *root, const rq_node *lo, const rq_node *up)	/* krmq.h:110-150: closed interval */
+{
+	const rq_node *p = root, *path[2][RQ_DEPTH], *min;
+	int plen[2] = {0, 0}, pcmp[2][RQ_DEPTH], i, c, lca;
+	if (!root) return 0;
+	while (p) { c = rq_cmp(lo, p); path[0][plen[0]] = p; pcmp[0][plen[0]++] = c; if (c < 0) p = p->p[0]; else if (c > 0) p = p->p[1]; else break; }
+	p = root;
+	while (p) { c = rq_cmp(up, p); path[1][plen[1]] = p; pcmp[1][plen[1]++] = c; if (c < 0) p = p->p[0]; else if (c > 0) p = p->p[1]; else break; }
+	for (i = 0; i < plen[0] && i < plen[1]; ++i) if (path[0][i] == path[1][i] && pcmp[0][i] <= 0 && pcmp[1][i] >= 0) break;
+	if (i == plen[0] || i == plen[1]) return 0;
+	lca = i; min = path[0][lca];
+	for (i = lca + 1; i < plen[0]; ++i) if (pcmp[0][i] <= 0) {
+		if (rq_lt2(path[0][i], min)) min = path[0][i];
+		if (path[0][i]->p[1] && rq_lt2(path[0][i]->p[1]->s, min)) min = path[0][i]->p[1]->s;
+	}
+	for (i = lca + 1; i < plen[1]; ++i) if (pcmp[1][i] >= 0) {
+		if (rq_lt2(path[1][i], min)) min = path[1][i];
+		if (path[1][i]->p[0] && rq_lt2(path[1][i]->p[0]->s, min)) min = path[1][i]->p[0]->s;
+	}
+	return (rq_node*)min;
+}
+static inline void rq_update_min(rq_node *p, const rq_node *q, const rq_node *r)	/* krmq.h:154-157 */
+{
+	p->s = !q || rq_lt2(p, q->s) ? p : q->s;
+	p->s = !r || rq_lt2(p->s, r->s) ? p->s : r->s;
+}
+static rq_node *rq_rotate1(rq_node *p, int dir)	/* krmq.h:159-170 */
+{
+	int opp = 1 - dir;
+	rq_node *q = p->p[opp], *s = p->s;
+	unsigned size_p = p->size;
+	p->size -= q->size - rq_size_child(q, dir);
+	q->size = size_p;
+	rq_update_min(p, p->p[dir], q->p[dir]);
+	q->s = s;
+	p->p[opp] = q->p[dir];
+	q->p[dir] = p;
+	return q;
+}
+static rq_node *rq_rotate2(rq_node *p, int dir)	/* krmq.h:172-192 */
+{
+	int b1, opp = 1 - dir;
+	rq_node *q = p->p[opp], *r = q->p[dir], *s = p->s;
+	unsigned size_x_dir = rq_size_child(r, dir);
+	r->size = p->size;
+	p->size -= q->size - size_x_dir;
+	q->size -= size_x_dir + 1;
+	rq_update_min(p, p->p[dir], r->p[dir]);
+	rq_update_min(q, q->p[opp], r->p[opp]);
+	r->s = s;
+	p->p[opp] = r->p[dir]; r->p[dir] = p;
+	q->p[dir] = r->p[opp]; r->p[opp] = q;
+	b1 = dir == 0 ? +1 : -1;
+	if (r->balance == b1) { q->balance = 0; p->balance = (signed char)-b1; }
+	else if (r->balance == 0) q->balance = p->balance = 0;
+	else { q->balance = (signed char)b1; p->balance = 0; }
+	r->balance = 0;
+	return r;
+}
+static rq_node *rq_insert(rq_node **root_, rq_node *x)	/* krmq.h:194-242 */
+{
+	unsigned char stack[RQ_DEPTH];
+	rq_node *path[RQ_DEPTH], *bp, *bq, *p, *q, *r = 0;
+	int i, which = 0, top, b1, path_len;
+	bp = *root_; bq = 0;
+	for (p = bp, q = bq, top = path_len = 0; p; q = p, p = p->p[which]) {
+		int c = rq_cmp(x, p);
+		if (c == 0) return p;
+		if (p->balance != 0) { bq = q; bp = p; top = 0; }
+		stack[top++] = (unsigned char)(which = (c > 0));
+		path[path_len++] = p;
+	}
+	x->balance = 0; x->size = 1; x->p[0] = x->p[1] = 0; x->s = x;
+	if (q == 0) *root_ = x; else q->p[which] = x;
+	if (bp == 0) return x;
+	for (i = 0; i < path_len; ++i) ++path[i]->size;
+	for (i = path_len - 1; i >= 0; --i) { rq_update_min(path[i], path[i]->p[0], path[i]->p[1]); if (path[i]->s != x) break; }
+	for (p = bp, top = 0; p != x; p = p->p[stack[top]], ++top) { if (stack[top] == 0) --p->balance; else ++p->balance; }
+	if (bp->balance > -2 && bp->balance < 2) return x;
+	which = (bp->balance < 0);
+	b1 = which == 0 ? +1 : -1;
+	q = bp->p[1 - which];
+	if (q->balance == b1) { r = rq_rotate1(bp, which); q->balance = bp->balance = 0; }
+	else r = rq_rotate2(bp, which);
+	if (bq == 0) *root_ = r; else bq->p[bp != bq->p[0]] = r;
+	return x;
+}
+static rq_node *rq_erase(rq_node **root_, const rq_node *x)	/* krmq.h:244-327 (x != NULL) */
+{
+	rq_node *p, *path[RQ_DEPTH], fake;
+	unsigned char dir[RQ_DEPTH];
+	int i, d = 0, c;
+	fake = **root_; fake.p[0] = *root_; fake.p[1] = 0;
+	for (c = -1, p = &fake; c; c = rq_cmp(x, p)) {
+		int which = (c > 0);
+		dir[d] = (unsigned char)which; path[d++] = p;
+		p = p->p[which];
+		if (p == 0) return 0;
+	}
+	for (i = 1; i < d; ++i) --path[i]->size;
+	if (p->p[1] == 0) path[d - 1]->p[dir[d - 1]] = p->p[0];
+	else {
+		rq_node *q = p->p[1];
+		if (q->p[0] == 0) {
+			q->p[0] = p->p[0]; q->balance = p->balance;
+			path[d - 1]->p[dir[d - 1]] = q;
+			path[d] = q; dir[d++] = 1;
+			q->size = p->size - 1;
+		} else {
+			rq_node *r;
+			int e = d++;
+			for (;;) { dir[d] = 0; path[d++] = q; r = q->p[0]; if (r->p[0] == 0) break; q = r; }
+			r->p[0] = p->p[0]; q->p[0] = r->p[1]; r->p[1] = p->p[1];
+			r->balance = p->balance;
+			path[e - 1]->p[dir[e - 1]] = r;
+			path[e] = r; dir[e] = 1;
+			for (i = e + 1; i < d; ++i) --path[i]->size;
+			r->size = p->size - 1;
+		}
+	}
+	for (i = d - 1; i >= 0; --i) rq_update_min(path[i], path[i]->p[0], path[i]->p[1]);	/* (includes the fake root, as the original) */
+	while (--d > 0) {
+		rq_node *q = path[d];
+		int which, other, b1 = 1, b2 = 2;
+		which = dir[d]; other = 1 - which;
+		if (which) { b1 = -b1; b2 = -b2; }
+		q->balance = (signed char)(q->balance + b1);
+		if (q->balance == b1) break;
+		else if (q->balance == b2) {
+			rq_node *r = q->p[other];
+			if (r->balance == -b1) path[d - 1]->p[dir[d - 1]] = rq_rotate2(q, which);
+			else {
+				path[d - 1]->p[dir[d - 1]] = rq_rotate1(q, which);
+				if (r->balance == 0) { r->balance = (signed char)-b1; q->balance = (signed char)b1; break; }
+				else r->balance = q->balance = 0;
+			}
+		}
+	}
+	*root_ = fake.p[0];
+	return p;
+}
+typedef struct { const rq_node *stack[RQ_DEPTH], **top; } rq_itr;
+static int rq_itr_find(const rq_node *root, const rq_node *x, rq_itr *it)	/* krmq.h:355-367 */
+{
+	const rq_node *p = root;
+	it->top = it->stack - 1;
+	while (p) { int c; *++it->top = p; c = rq_cmp(x, p); if (c < 0) p = p->p[0]; else if (c > 0) p = p->p[1]; else break; }
+	return p ? 1 : 0;
+}
+static int rq_itr_prev(rq_itr *it)	/* krmq_itr_next_bidir(itr, 0), krmq.h:368-384 */
+{
+	const rq_node *p;
+	if (it->top < it->stack) return 0;
+	p = (*it->top)->p[0];
+	if (p) { for (; p; p = p->p[1]) *++it->top = p; return 1; }
+	do { p = *it->top--; } while (it->top >= it->stack && p == (*it->top)->p[0]);
+	return it->top < it->stack ? 0 : 1;
+}
+#define rq_at(it) ((it)->top < (it)->stack ? 0 : *(it)->top)
+
+static inline int32_t sc_simple(const a128 *ai, const a128 *aj, float pen_gap, float pen_skip, int32_t *exact, int32_t *width)	/* comput_sc_simple lchain.c:557-581 */
+{
+	int32_t dq = (int32_t)ai->y - (int32_t)aj->y, dr, dd, dg, q_span, sc;
+	dr = (int32_t)(ai->x - aj->x);
+	*width = dd = dr > dq ? dr - dq : dq - dr;
+	dg = dr < dq ? dr : dq;
+	q_span = (int32_t)((aj->y >> 32) & 63);
+	sc = q_span < dg ? q_span : dg;
+	if (exact) *exact = (dd == 0 && dg <= q_span);
+	if (dd || dq > q_span) {
+		float lin = pen_gap * (float)dd + pen_skip * (float)dg;
+		float lg = dd >= 1 ? log2_approx((float)(dd + 1)) : 0.0f;
+		sc -= (int)(lin + .5f * lg);
+	}
+	return sc;
+}
+
+/* mg_lchain_rmq lchain.c:606-756.  Same contract as chain_dp. */
+static a128 *chain_rmq(int max_dist, int max_dist_inner, int bw, int max_skip, int cap_rmq_size, int min_cnt, int min_sc, float pen_gap, float pen_skip,
+                       int64_t *n_io, a128 *a, a128 **prev_out, int *n_u_out, uint64_t **u_out)
+{
+	const int32_t max_drop = bw;
+	int64_t n = *n_io, i, i0, st = 0, st_inner = 0;
+	*u_out = 0; *n_u_out = 0;
+	if (n == 0 || a == 0) { free(a); free(*prev_out); *prev_out = 0; *n_io = 0; return 0; }
+	free(*prev_out); *prev_out = 0;	/* (compact_a overwrites *_a; every exit below frees or replaces it) */
+	if (max_dist < bw) max_dist = bw;
+	if (max_dist_inner <= 0 || max_dist_inner >= max_dist) max_dist_inner = 0;
+	int64_t *p = (int64_t*)malloc(n * 8);
+	int32_t *f = (int32_t*)malloc(n * 4), *v = (int32_t*)malloc(n * 4), *t = (int32_t*)calloc(n, 4);
+	rq_node *pool = (rq_node*)malloc((size_t)n * 2 * sizeof(rq_node));	/* node j of the outer tree = pool[2j], of the inner tree = pool[2j + 1] */
+	rq_node *root = 0, *root_inner = 0;
+	for (i = i0 = 0; i < n; ++i) {
+		int64_t max_j = -1;
+		int32_t q_span = (int32_t)((a[i].y >> 32) & 63), max_f = q_span;
+		rq_node s, *q, *r, lo, hi;
+		if (i0 < i && a[i0].x != a[i].x) {	/* add in-range anchors */
+			for (int64_t j = i0; j < i; ++j) {
+				q = &pool[2 * j];
+				q->y = (int32_t)a[j].y; q->i = j; q->pri = -(f[j] + 0.5 * pen_gap * ((int32_t)a[j].x + (int32_t)a[j].y));
+				rq_insert(&root, q);
+				if (max_dist_inner > 0) { r = &pool[2 * j + 1]; *r = *q; rq_insert(&root_inner, r); }
+			}
+			i0 = i;
+		}
+		while (st < i && (a[i].x >> 32 != a[st].x >> 32 || a[i].x > a[st].x + (uint64_t)max_dist || rq_size(root) > (unsigned)cap_rmq_size)) {
+			s.y = (int32_t)a[st].y; s.i = st;
+			if ((q = rq_find(root, &s)) != 0) rq_erase(&root, q);
+			++st;
+		}
+		if (max_dist_inner > 0) {
+			while (st_inner < i && (a[i].x >> 32 != a[st_inner].x >> 32 || a[i].x > a[st_inner].x + (uint64_t)max_dist_inner || rq_size(root_inner) > (unsigned)cap_rmq_size)) {
+				s.y = (int32_t)a[st_inner].y; s.i = st_inner;
+				if ((q = rq_find(root_inner, &s)) != 0) rq_erase(&root_inner, q);
+				++st_inner;
+			}
+		}
+		lo.i = INT32_MAX; lo.y = (int32_t)a[i].y - max_dist;
+		hi.i = 0; hi.y = (int32_t)a[i].y;
+		if ((q = rq_rmq(root, &lo, &hi)) != 0) {
+			int32_t sc, exact, width, n_skip = 0;
+			int64_t j = q->i;
+			sc = f[j] + sc_simple(&a[i], &a[j], pen_gap, pen_skip, &exact, &width);
+			if (width <= bw && sc > max_f) { max_f = sc; max_j = j; }
+			if (!exact && root_inner && (int32_t)a[i].y > 0) {
+				rq_node *lo2, *hi2;
+				s.y = (int32_t)a[i].y - 1; s.i = n;
+				rq_interval(root_inner, &s, &lo2, &hi2);
+				if (lo2) {
+					const rq_node *qq;
+					int32_t width2;
+					rq_itr itr;
+					rq_itr_find(root_inner, lo2, &itr);
+					while ((qq = rq_at(&itr)) != 0) {
+						if (qq->y < (int32_t)a[i].y - max_dist_inner) break;
+						j = qq->i;
+						sc = f[j] + sc_simple(&a[i], &a[j], pen_gap, pen_skip, 0, &width2);
+						if (width2 <= bw) {
+							if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
+							else if (t[j] == (int32_t)i) { if (++n_skip > max_skip) break; }
+							if (p[j] >= 0) t[p[j]] = (int32_t)i;
+						}
+						if (!rq_itr_prev(&itr)) break;
+					}
+				}
+			}
+		}
+		f[i] = max_f; p[i] = max_j;
+		v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
+	}
+	free(pool);
+	return chain_finish(n, a, f, p, v, t, min_cnt, min_sc, max_drop, n_io, prev_out, n_u_out, u_out);
 }
 
 /* ================================================================== a17-a19: regions, parents, MAPQ (hit.c) */
@@ -935,7 +1227,15 @@ static void map_chunk(const ro_index *ix, const rh_mapopt_t *mo, const rh_idxopt
 	cnt[4] += n_hits; cnt[5] += (uint64_t)n_a;
 	float pen_gap = mo->chain_gap_scale * 0.01 * (ip->e + ip->k - 1), pen_skip = mo->chain_skip_scale * 0.01 * (ip->e + ip->k - 1);
 	uint64_t *u = 0; int n_u = 0;
-	a = chain_dp(mo, pen_gap, pen_skip, &n_a, a, &st->prev, &n_u, &u);
+	{	/* rmap.cpp:317-342: DP or RMQ chaining, then the optional RMQ re-chaining of the chained anchors with the long bandwidth */
+		const int max_gap = mo->max_target_gap_length > mo->max_query_gap_length ? mo->max_target_gap_length : mo->max_query_gap_length;
+		if (!(mo->flag & RH_M_RMQ)) a = chain_dp(mo, pen_gap, pen_skip, &n_a, a, &st->prev, &n_u, &u);
+		else a = chain_rmq(max_gap, mo->rmq_inner_dist, mo->bw, mo->max_num_skips, mo->rmq_size_cap, mo->min_num_anchors, mo->min_chaining_score, pen_gap, pen_skip, &n_a, a, &st->prev, &n_u, &u);
+		if (mo->bw_long > mo->bw) {
+			free(u); u = 0; n_u = 0;	/* (the reference leaks the first u[]; its contents are not used again) */
+			a = chain_rmq(max_gap, mo->rmq_inner_dist, mo->bw_long, mo->max_num_skips, mo->rmq_size_cap, mo->min_num_anchors, mo->min_chaining_score, pen_gap, pen_skip, &n_a, a, &st->prev, &n_u, &u);
+		}
+	}
 	st->n_prev = n_a > 0 ? n_a : 0;
 	if (n_a <= 0) { free(st->prev); st->prev = 0; }
 	cnt[6] += (uint64_t)st->n_prev;
@@ -1161,7 +1461,16 @@ int ro_chain_batch(const ro_index *ix, const rh_mapopt_t *mo, uint32_t n_reads, 
 		a128 *a = (a128*)malloc((n ? n : 1) * sizeof(a128)), *pv = 0; uint64_t *uu = 0; int n_u = 0;
 		memcpy(a, anchors + anchor_offsets[r], n * sizeof(a128));
 		if (n == 0) { free(a); a = 0; }
-		a128 *res = chain_dp(mo, pen_gap, pen_skip, &n, a, &pv, &n_u, &uu);
+		a128 *res;
+		{	/* rmap.cpp:317-342 */
+			const int max_gap = mo->max_target_gap_length > mo->max_query_gap_length ? mo->max_target_gap_length : mo->max_query_gap_length;
+			if (!(mo->flag & RH_M_RMQ)) res = chain_dp(mo, pen_gap, pen_skip, &n, a, &pv, &n_u, &uu);
+			else res = chain_rmq(max_gap, mo->rmq_inner_dist, mo->bw, mo->max_num_skips, mo->rmq_size_cap, mo->min_num_anchors, mo->min_chaining_score, pen_gap, pen_skip, &n, a, &pv, &n_u, &uu);
+			if (mo->bw_long > mo->bw) {
+				free(uu); uu = 0; n_u = 0;
+				res = chain_rmq(max_gap, mo->rmq_inner_dist, mo->bw_long, mo->max_num_skips, mo->rmq_size_cap, mo->min_num_anchors, mo->min_chaining_score, pen_gap, pen_skip, &n, res, &pv, &n_u, &uu);
+			}
+		}
 		if (k + (uint64_t)n > chained_cap || ku + (uint64_t)n_u > u_cap) { free(res); free(pv); free(uu); return -1; }
 		if (n > 0) { memcpy(chained + k, res, n * sizeof(a128)); if (prev_out) memcpy(prev_out + k, pv, n * sizeof(a128)); }
 		if (n_u > 0) memcpy(u + ku, uu, n_u * 8);

@@ -42,6 +42,7 @@ class MapOpt(C.Structure):
         ("flag", C.c_int64),
         ("window_length1", C.c_uint32), ("window_length2", C.c_uint32),
         ("threshold1", C.c_float), ("threshold2", C.c_float), ("peak_height", C.c_float),
+        ("rmq_inner_dist", C.c_int32), ("rmq_size_cap", C.c_int32),
     ]
 
 

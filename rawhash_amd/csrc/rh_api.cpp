@@ -130,6 +130,10 @@ void stage_timers_collect(rh_ctx *c)
 	c->ev_used = 0; c->ev_stage.clear();
 }
 
+// the chaining of a round as ri_map_frag runs it (rmap.cpp:317-342): DP or RMQ, candidates sorted, backtracked and compacted; then,
+// if bw_long > bw, the chained anchors are chained AGAIN by the RMQ variant with the long bandwidth (same backtrack / compaction)
+static int chain_stages(rh_ctx *c, hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &rr, bool timed);
+
 int fill_dev_opt(const rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
 {
 	if (mo->chunk_size == 0 || mo->chunk_size > RH_CHUNK_MAX) { rh_set_error("chunk_size %u not supported on the device (1..%d)", mo->chunk_size, RH_CHUNK_MAX); return -1; }
@@ -137,8 +141,7 @@ int fill_dev_opt(const rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
 	if ((mo->flag & RH_M_ALL_CHAINS) && !(mo->flag & RH_M_NO_ADAPTIVE)) { rh_set_error("all-chains output is built for whole-read rounds only (RH_M_ALL_CHAINS needs RH_M_NO_ADAPTIVE, as in the ava presets)"); return -1; }
 	if ((mo->flag & RH_M_NO_ADAPTIVE) && (mo->window_length1 > 15 || mo->window_length2 > 15)) { rh_set_error("whole-read rounds need segmentation windows <= 15"); return -1; }
 	if ((mo->flag & RH_M_ALL_CHAINS) && c->have_index && !c->dix.t_rank) { rh_set_error("all-vs-all mapping needs the name ranks of the targets (rh_index_set_target_ranks)"); return -1; }
-	if (mo->flag & (RH_M_RMQ | RH_M_DTW_EVALUATE_CHAINS)) { rh_set_error("RMQ chaining / DTW re-scoring are out of scope of this path"); return -1; }
-	if (mo->bw_long > mo->bw) { rh_set_error("bw_long > bw (RMQ re-chaining) is out of scope of this path"); return -1; }
+	if (mo->flag & RH_M_DTW_EVALUATE_CHAINS) { rh_set_error("DTW re-scoring of chains (--dtw-evaluate-chains) is not built on this path"); return -1; }
 	if (mo->min_num_anchors < 2) { rh_set_error("min_num_anchors < 2 is not supported on the device (the per-anchor scratch assumes chains of at least two anchors)"); return -1; }
 	if (mo->window_length1 > 64 || mo->window_length2 > 64) { rh_set_error("segmentation windows > 64 not supported"); return -1; }
 	memset(o, 0, sizeof(*o));
@@ -148,6 +151,7 @@ int fill_dev_opt(const rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
 	o->mid_occ = mo->mid_occ;
 	o->max_dist_t = mo->max_target_gap_length; o->max_dist_q = mo->max_query_gap_length; o->bw = mo->bw;
 	o->max_skip = mo->max_num_skips; o->max_iter = mo->max_chain_iter; o->min_cnt = mo->min_num_anchors;
+	o->bw_long = mo->bw_long; o->rmq_inner_dist = mo->rmq_inner_dist; o->rmq_size_cap = mo->rmq_size_cap;
 	o->min_sc = mo->min_chaining_score; o->min_sc2 = mo->min_chaining_score2;
 	if (c->have_index) {	// rmap.cpp:318: computed in double, narrowed to float
 		const int span = c->dix.sp.e + c->dix.sp.k - 1;
@@ -159,6 +163,25 @@ int fill_dev_opt(const rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
 	o->min_strand_sc = (int32_t)(mo->max_target_gap_length * 0.8);   // rmap.cpp:354
 	o->w_bestq = mo->w_bestq; o->w_bestmq = mo->w_bestmq; o->w_bestmc = mo->w_bestmc; o->w_threshold = mo->w_threshold;
 	o->min_mapq = mo->min_mapq; o->sample_per_base = mo->sample_per_base; o->flag = mo->flag;
+	return 0;
+}
+
+static int chain_stages(rh_ctx *c, hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &rr, bool timed)
+{
+	const int32_t max_gap = o.max_dist_t > o.max_dist_q ? o.max_dist_t : o.max_dist_q;
+	struct Opt { rh_ctx *c; bool on; StageTimer *t = nullptr; Opt(rh_ctx *c_, bool on_, int st) : c(c_), on(on_) { if (on) t = new StageTimer(c, st); } ~Opt() { delete t; } };
+	for (int pass = 0; pass < 2; ++pass) {
+		rh_dev_opt op = o;
+		if (pass == 1) { if (o.bw_long <= o.bw) break; op.bw = o.bw_long; }   // (max_drop of the backtrack = the bandwidth of the pass, lchain.c:625)
+		{
+			Opt t(c, timed, ST_CHAIN);
+			if (pass == 1) rhk_chain_rmq(s, op, rr, rr.n_v, max_gap, o.rmq_inner_dist, o.rmq_size_cap);   // the chained anchors of the first pass, in place
+			else if (o.flag & RH_M_RMQ) rhk_chain_rmq(s, op, rr, nullptr, max_gap, o.rmq_inner_dist, o.rmq_size_cap);
+			else rhk_chain(s, op, rr);
+		}
+		{ Opt t(c, timed, ST_ZSORT); if (rhk_zsort(s, op, rr)) return -1; }
+		{ Opt t(c, timed, ST_BACKTRACK); if (rhk_backtrack(s, op, rd, rr)) return -1; }
+	}
 	return 0;
 }
 
@@ -755,9 +778,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 			{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rs); }
 			{ StageTimer t(c, ST_SORT); if (rhk_sort(s, rs)) return -1; }
 			if (debug_rounds()) dump_round(c, chunk, n, rs);
-			{ StageTimer t(c, ST_CHAIN); rhk_chain(s, o, rs); }
-			{ StageTimer t(c, ST_ZSORT); if (rhk_zsort(s, o, rs)) return -1; }
-			{ StageTimer t(c, ST_BACKTRACK); if (rhk_backtrack(s, o, rd, rs)) return -1; }
+			if (chain_stages(c, s, o, rd, rs, true)) return -1;
 			if (!ava && pack_carry()) return -1;                      // (before the region sort: it borrows the staging arena)
 			{ StageTimer t(c, ST_RSORT); if (rhk_regions_sort(s, o, rd, rs)) return -1; }
 			{ StageTimer t(c, ST_REGIONS); rhk_regions(s, o, rd, rs, c->logf_tab.as<float>()); }
@@ -1228,7 +1249,7 @@ extern "C" int rh_chain_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, cons
 {
 	if (need_index(c)) return -1;
 	RH_HIP(hipSetDevice(c->device));
-	rh_mapopt_t m2 = *mo; m2.flag = 0; m2.bw_long = 0;
+	rh_mapopt_t m2 = *mo; m2.flag = mo->flag & RH_M_RMQ;   // (the chaining variant stays: --rmq / --bw-long at stage level)
 	rh_dev_opt o;
 	if (fill_dev_opt(c, &m2, &o)) return -1;
 	rh_dev_reads rd;
@@ -1244,8 +1265,7 @@ extern "C" int rh_chain_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, cons
 	RH_HIP(hipMemset(rr.counters, 0, 16 * 8));
 	RH_HIP(hipMemset(rr.n_u, 0, (size_t)(R ? R : 1) * 4)); RH_HIP(hipMemset(rr.n_v, 0, (size_t)(R ? R : 1) * 4));
 	hipStream_t s = c->stream;
-	rhk_chain(s, o, rr);
-	if (rhk_zsort(s, o, rr) || rhk_backtrack(s, o, rd, rr)) return -1;
+	if (chain_stages(c, s, o, rd, rr, false)) return -1;
 	RH_HIP(hipStreamSynchronize(s));
 	RH_HIP(hipGetLastError());
 	std::vector<uint32_t> nu, nv; std::vector<rh_mm128_t> an, pv; std::vector<uint64_t> uu;
@@ -1270,7 +1290,7 @@ extern "C" int rh_regions_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, co
 	// secondaries dropped, MAPQ (hit.c:195-367, 502-539); summary[r] = {n_cregs, cnt, score, mapq, qs, qe, rs, re, rid, rev} of region 0
 	if (need_index(c)) return -1;
 	RH_HIP(hipSetDevice(c->device));
-	rh_mapopt_t m2 = *mo; m2.flag = 0; m2.bw_long = 0;
+	rh_mapopt_t m2 = *mo; m2.flag = mo->flag & RH_M_RMQ;   // (the chaining variant stays: --rmq / --bw-long at stage level)
 	rh_dev_opt o;
 	if (fill_dev_opt(c, &m2, &o)) return -1;
 	rh_dev_reads rd;
@@ -1287,8 +1307,7 @@ extern "C" int rh_regions_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, co
 	RH_HIP(hipMemset(rr.counters, 0, 16 * 8));
 	RH_HIP(hipMemset(rr.n_u, 0, (size_t)(R ? R : 1) * 4)); RH_HIP(hipMemset(rr.n_v, 0, (size_t)(R ? R : 1) * 4));
 	hipStream_t s = c->stream;
-	rhk_chain(s, o, rr);
-	if (rhk_zsort(s, o, rr) || rhk_backtrack(s, o, rd, rr)) return -1;
+	if (chain_stages(c, s, o, rd, rr, false)) return -1;
 	if (rhk_regions_sort(s, o, rd, rr)) return -1;
 	rhk_regions(s, o, rd, rr, c->logf_tab.as<float>());
 	RH_HIP(hipStreamSynchronize(s));

@@ -331,6 +331,309 @@ __global__ void k_chain_serial(rh_dev_opt o, rh_dev_round rr)
 	#undef P_
 }
 
+// ------------------------------------------------------------------------------------------------ RMQ chaining (f4)
+// mg_lchain_rmq (lchain.c:606-756): the predecessor of an anchor is the element of least priority pri = -(f + 0.5 gap_pen (x + y))
+// among the anchors within max_dist on the query, looked up in a balanced tree keyed by (y, index); a second "inner" tree over the
+// last max_dist_inner target bases is walked anchor by anchor when the first choice is not exact.  The reference's tree (klib krmq.h)
+// is an AVL tree whose nodes carry their subtree's size and a pointer to its element of least pri, and equal pri values are told
+// apart by POSITION IN THE TREE (an ancestor beats its descendants, the left subtree the right one) - so which of two equally good
+// predecessors is chosen depends on the exact insertion / deletion / rotation history.  That history is reproduced here: one lane
+// per read, the AVL tree as index arrays in the read's scratch (node id = anchor index), every operation the klib way (insertion
+// with a single re-balancing point, deletion by in-order successor, the two rotations with their subtree-minimum updates).
+// An opt-in, accuracy-for-speed mode of the reference (--rmq, --bw-long); serial per read by construction.
+struct rq_tree {
+	int32_t *l, *r, *s; uint32_t *sz; int8_t *bal;               // children, subtree minimum (node id), subtree size, balance factor
+	int32_t root;
+};
+#define RQ_NIL (-1)
+#define RQ_FAKE (-2)                                                // the stand-in parent of the root during a deletion (krmq.h:247)
+#define RQ_DEPTH 64
+
+struct rq_env { const rh_mm128_t *an; const int32_t *fp; float pen_gap; };
+RH_DEV double rq_pri(const rq_env &E, int32_t j)
+{
+	const double g = 0.5 * (double)E.pen_gap;                     // (0.5 * chn_pen_gap) * (x + y): the reference's association (lchain.c:672)
+	return -((double)E.fp[2 * j] + g * (double)((int32_t)E.an[j].x + (int32_t)E.an[j].y));
+}
+RH_DEV int rq_cmp_key(int32_t ya, int64_t ia, const rq_env &E, int32_t b)	// lc_elem_cmp (lchain.c:539) of key (ya, ia) against node b
+{
+	const int32_t yb = (int32_t)E.an[b].y;
+	return ya < yb ? -1 : ya > yb ? 1 : (ia > (int64_t)b) - (ia < (int64_t)b);
+}
+RH_DEV int32_t &rq_child(rq_tree &T, int32_t &fake_l, int32_t p, int which) { return p == RQ_FAKE ? fake_l : (which ? T.r[p] : T.l[p]); }
+RH_DEV uint32_t rq_csize(const rq_tree &T, int32_t p, int which) { const int32_t c = which ? T.r[p] : T.l[p]; return c == RQ_NIL ? 0u : T.sz[c]; }
+RH_DEV void rq_update_min(rq_tree &T, const rq_env &E, int32_t p, int32_t q, int32_t r)	// krmq.h:154-157
+{
+	int32_t s = (q == RQ_NIL || rq_pri(E, p) < rq_pri(E, T.s[q])) ? p : T.s[q];
+	s = (r == RQ_NIL || rq_pri(E, s) < rq_pri(E, T.s[r])) ? s : T.s[r];
+	T.s[p] = s;
+}
+RH_DEV int32_t rq_rotate1(rq_tree &T, const rq_env &E, int32_t p, int dir)	// (a,(b,c)q)p => ((a,b)p,c)q   krmq.h:159-170
+{
+	const int opp = 1 - dir;
+	int32_t fk = RQ_NIL;
+	const int32_t q = rq_child(T, fk, p, opp), s = T.s[p];
+	const uint32_t size_p = T.sz[p];
+	T.sz[p] -= T.sz[q] - rq_csize(T, q, dir);
+	T.sz[q] = size_p;
+	rq_update_min(T, E, p, rq_child(T, fk, p, dir), rq_child(T, fk, q, dir));
+	T.s[q] = s;
+	rq_child(T, fk, p, opp) = rq_child(T, fk, q, dir);
+	rq_child(T, fk, q, dir) = p;
+	return q;
+}
+RH_DEV int32_t rq_rotate2(rq_tree &T, const rq_env &E, int32_t p, int dir)	// (a,((b,c)r,d)q)p => ((a,b)p,(c,d)q)r   krmq.h:172-192
+{
+	const int opp = 1 - dir;
+	int32_t fk = RQ_NIL;
+	const int32_t q = rq_child(T, fk, p, opp), r = rq_child(T, fk, q, dir), s = T.s[p];
+	const uint32_t size_x_dir = rq_csize(T, r, dir);
+	T.sz[r] = T.sz[p];
+	T.sz[p] -= T.sz[q] - size_x_dir;
+	T.sz[q] -= size_x_dir + 1u;
+	rq_update_min(T, E, p, rq_child(T, fk, p, dir), rq_child(T, fk, r, dir));
+	rq_update_min(T, E, q, rq_child(T, fk, q, opp), rq_child(T, fk, r, opp));
+	T.s[r] = s;
+	rq_child(T, fk, p, opp) = rq_child(T, fk, r, dir); rq_child(T, fk, r, dir) = p;
+	rq_child(T, fk, q, dir) = rq_child(T, fk, r, opp); rq_child(T, fk, r, opp) = q;
+	const int b1 = dir == 0 ? +1 : -1;
+	if (T.bal[r] == b1) { T.bal[q] = 0; T.bal[p] = (int8_t)-b1; }
+	else if (T.bal[r] == 0) { T.bal[q] = 0; T.bal[p] = 0; }
+	else { T.bal[q] = (int8_t)b1; T.bal[p] = 0; }
+	T.bal[r] = 0;
+	return r;
+}
+RH_DEV void rq_insert(rq_tree &T, const rq_env &E, int32_t x)	// krmq.h:194-242 (x is never present already: node ids are anchor indices)
+{
+	uint8_t stack[RQ_DEPTH];
+	int32_t path[RQ_DEPTH];
+	int32_t fk = RQ_NIL;
+	const int32_t yx = (int32_t)E.an[x].y;
+	int32_t bp = T.root, bq = RQ_NIL, p, q;
+	int which = 0, top = 0, path_len = 0;
+	for (p = bp, q = bq; p != RQ_NIL; q = p, p = rq_child(T, fk, p, which)) {
+		const int c = rq_cmp_key(yx, x, E, p);
+		if (T.bal[p] != 0) { bq = q; bp = p; top = 0; }
+		stack[top++] = (uint8_t)(which = (c > 0));
+		path[path_len++] = p;
+	}
+	T.bal[x] = 0; T.sz[x] = 1; T.l[x] = RQ_NIL; T.r[x] = RQ_NIL; T.s[x] = x;
+	if (q == RQ_NIL) T.root = x; else rq_child(T, fk, q, which) = x;
+	if (bp == RQ_NIL) return;
+	for (int i = 0; i < path_len; ++i) ++T.sz[path[i]];
+	for (int i = path_len - 1; i >= 0; --i) { rq_update_min(T, E, path[i], T.l[path[i]], T.r[path[i]]); if (T.s[path[i]] != x) break; }
+	for (p = bp, top = 0; p != x; p = rq_child(T, fk, p, stack[top]), ++top) { if (stack[top] == 0) --T.bal[p]; else ++T.bal[p]; }
+	if (T.bal[bp] > -2 && T.bal[bp] < 2) return;
+	which = T.bal[bp] < 0;
+	const int b1 = which == 0 ? +1 : -1;
+	q = rq_child(T, fk, bp, 1 - which);
+	int32_t r;
+	if (T.bal[q] == b1) { r = rq_rotate1(T, E, bp, which); T.bal[q] = 0; T.bal[bp] = 0; }
+	else r = rq_rotate2(T, E, bp, which);
+	if (bq == RQ_NIL) T.root = r; else rq_child(T, fk, bq, bp != T.l[bq]) = r;
+}
+RH_DEV int32_t rq_find(const rq_tree &T, const rq_env &E, int32_t y, int64_t i)	// krmq.h:81-96
+{
+	int32_t p = T.root;
+	while (p != RQ_NIL) { const int c = rq_cmp_key(y, i, E, p); if (c < 0) p = T.l[p]; else if (c > 0) p = T.r[p]; else break; }
+	return p;
+}
+RH_DEV void rq_erase(rq_tree &T, const rq_env &E, int32_t x)	// krmq.h:244-327, x in the tree
+{
+	int32_t path[RQ_DEPTH];
+	uint8_t dir[RQ_DEPTH];
+	int32_t fake_l = T.root;                                      // fake.p[0] = root, fake.p[1] = 0
+	const int32_t yx = (int32_t)E.an[x].y;
+	int d = 0, c;
+	int32_t p;
+	for (c = -1, p = RQ_FAKE; c; c = rq_cmp_key(yx, x, E, p)) {
+		const int which = c > 0;
+		dir[d] = (uint8_t)which; path[d++] = p;
+		p = rq_child(T, fake_l, p, which);
+		if (p == RQ_NIL) return;
+	}
+	for (int i = 1; i < d; ++i) --T.sz[path[i]];
+	if (T.r[p] == RQ_NIL) rq_child(T, fake_l, path[d - 1], dir[d - 1]) = T.l[p];
+	else {
+		int32_t q = T.r[p];
+		if (T.l[q] == RQ_NIL) {
+			T.l[q] = T.l[p]; T.bal[q] = T.bal[p];
+			rq_child(T, fake_l, path[d - 1], dir[d - 1]) = q;
+			path[d] = q; dir[d++] = 1;
+			T.sz[q] = T.sz[p] - 1u;
+		} else {
+			int32_t r;
+			const int e = d++;
+			for (;;) { dir[d] = 0; path[d++] = q; r = T.l[q]; if (T.l[r] == RQ_NIL) break; q = r; }
+			T.l[r] = T.l[p]; T.l[q] = T.r[r]; T.r[r] = T.r[p];
+			T.bal[r] = T.bal[p];
+			rq_child(T, fake_l, path[e - 1], dir[e - 1]) = r;
+			path[e] = r; dir[e] = 1;
+			for (int i = e + 1; i < d; ++i) --T.sz[path[i]];
+			T.sz[r] = T.sz[p] - 1u;
+		}
+	}
+	for (int i = d - 1; i >= 1; --i) rq_update_min(T, E, path[i], T.l[path[i]], T.r[path[i]]);   // (path[0] is the fake root: its minimum is never read)
+	while (--d > 0) {
+		const int32_t q = path[d];
+		int b1 = 1, b2 = 2;
+		const int which = dir[d], other = 1 - which;
+		if (which) { b1 = -b1; b2 = -b2; }
+		T.bal[q] = (int8_t)(T.bal[q] + b1);
+		if (T.bal[q] == b1) break;
+		else if (T.bal[q] == b2) {
+			int32_t fk = RQ_NIL;
+			const int32_t r = rq_child(T, fk, q, other);
+			if (T.bal[r] == -b1) rq_child(T, fake_l, path[d - 1], dir[d - 1]) = rq_rotate2(T, E, q, which);
+			else {
+				rq_child(T, fake_l, path[d - 1], dir[d - 1]) = rq_rotate1(T, E, q, which);
+				if (T.bal[r] == 0) { T.bal[r] = (int8_t)-b1; T.bal[q] = (int8_t)b1; break; }
+				else { T.bal[r] = 0; T.bal[q] = 0; }
+			}
+		}
+	}
+	T.root = fake_l;
+}
+RH_DEV int32_t rq_rmq(const rq_tree &T, const rq_env &E, int32_t ylo, int64_t ilo, int32_t yup, int64_t iup)	// closed interval, krmq.h:110-150
+{
+	int32_t path[2][RQ_DEPTH];
+	int8_t pcmp[2][RQ_DEPTH];
+	int plen[2] = {0, 0}, i, c;
+	if (T.root == RQ_NIL) return RQ_NIL;
+	int32_t p = T.root;
+	while (p != RQ_NIL) { c = rq_cmp_key(ylo, ilo, E, p); path[0][plen[0]] = p; pcmp[0][plen[0]++] = (int8_t)c; if (c < 0) p = T.l[p]; else if (c > 0) p = T.r[p]; else break; }
+	p = T.root;
+	while (p != RQ_NIL) { c = rq_cmp_key(yup, iup, E, p); path[1][plen[1]] = p; pcmp[1][plen[1]++] = (int8_t)c; if (c < 0) p = T.l[p]; else if (c > 0) p = T.r[p]; else break; }
+	for (i = 0; i < plen[0] && i < plen[1]; ++i) if (path[0][i] == path[1][i] && pcmp[0][i] <= 0 && pcmp[1][i] >= 0) break;
+	if (i == plen[0] || i == plen[1]) return RQ_NIL;
+	const int lca = i;
+	int32_t mn = path[0][lca];
+	double mp = rq_pri(E, mn);
+	for (i = lca + 1; i < plen[0]; ++i) if (pcmp[0][i] <= 0) {
+		const int32_t u = path[0][i];
+		if (rq_pri(E, u) < mp) { mn = u; mp = rq_pri(E, u); }
+		if (T.r[u] != RQ_NIL && rq_pri(E, T.s[T.r[u]]) < mp) { mn = T.s[T.r[u]]; mp = rq_pri(E, mn); }
+	}
+	for (i = lca + 1; i < plen[1]; ++i) if (pcmp[1][i] >= 0) {
+		const int32_t u = path[1][i];
+		if (rq_pri(E, u) < mp) { mn = u; mp = rq_pri(E, u); }
+		if (T.l[u] != RQ_NIL && rq_pri(E, T.s[T.l[u]]) < mp) { mn = T.s[T.l[u]]; mp = rq_pri(E, mn); }
+	}
+	return mn;
+}
+// comput_sc_simple (lchain.c:557-581)
+RH_DEV int32_t rq_sc_simple(const rh_mm128_t &ai, const rh_mm128_t &aj, float pen_gap, float pen_skip, int32_t *exact, int32_t *width)
+{
+	const int32_t dq = (int32_t)ai.y - (int32_t)aj.y, dr = (int32_t)(ai.x - aj.x);
+	const int32_t dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq, q_span = (int32_t)((aj.y >> 32) & 63);
+	*width = dd;
+	int32_t sc = q_span < dg ? q_span : dg;
+	if (exact) *exact = (dd == 0 && dg <= q_span);
+	if (dd || dq > q_span) {
+		const float lin = pen_gap * (float)dd + pen_skip * (float)dg;
+		const float lg = dd >= 1 ? rh_log2_approx((float)(dd + 1)) : 0.0f;
+		sc -= (int32_t)(lin + .5f * lg);
+	}
+	return sc;
+}
+
+// one lane per read; counts[a] (optional) = anchors of read a when they are not a_off[a + 1] - a_off[a] (the re-chaining of chains)
+__global__ void k_chain_rmq(rh_dev_opt o, rh_dev_round rr, const uint32_t *counts, int32_t max_dist_in, int32_t max_dist_inner_in, int32_t cap_rmq_size)
+{
+	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const uint64_t base = rr.a_off[a];
+	const int32_t n_lay = (int32_t)(rr.a_off[a + 1] - base);         // the segment: what the later stages lay their arrays out by
+	const int32_t n = counts ? (int32_t)counts[a] : n_lay;           // the anchors to chain (the chained anchors of the first pass when re-chaining)
+	if (n_lay == 0) return;
+	const rh_mm128_t *an = rr.anc + base;
+	int32_t *fp = (int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR), *v = fp + 2 * (size_t)n_lay, *t = v + n_lay;   // {f,p} interleaved, as the DP kernels leave them
+	// the two trees behind f / p / v / t in the read's scratch: 2 x 17 bytes per anchor (RH_WS_PER_ANCHOR = 64 covers 16 + 34)
+	rq_tree T[2];
+	{
+		int32_t *w = t + n_lay;
+		for (int k = 0; k < 2; ++k) { T[k].l = w; T[k].r = w + n_lay; T[k].s = w + 2 * (size_t)n_lay; T[k].sz = (uint32_t*)(w + 3 * (size_t)n_lay); w += 4 * (size_t)n_lay; T[k].root = RQ_NIL; }
+		int8_t *b = (int8_t*)w;
+		T[0].bal = b; T[1].bal = b + n_lay;
+	}
+	// positions beyond the anchors of this pass: never a backtrack candidate, never a predecessor
+	for (int32_t i = n; i < n_lay; ++i) { fp[2 * i] = INT32_MIN / 2; fp[2 * i + 1] = -1; v[i] = INT32_MIN / 2; }
+	#define F_(i) fp[2 * (i)]
+	#define P_(i) fp[2 * (i) + 1]
+	const rq_env E = { an, fp, o.pen_gap };
+	const int32_t bw = o.bw;
+	int32_t max_dist = max_dist_in, max_dist_inner = max_dist_inner_in;
+	if (max_dist < bw) max_dist = bw;
+	if (max_dist_inner <= 0 || max_dist_inner >= max_dist) max_dist_inner = 0;
+	for (int32_t i = 0; i < n; ++i) t[i] = 0;
+	int32_t i0 = 0, st = 0, st_inner = 0;
+	for (int32_t i = 0; i < n; ++i) {
+		const rh_mm128_t ai = an[i];
+		int32_t max_j = -1, max_f = (int32_t)((ai.y >> 32) & 63);
+		if (i0 < i && an[i0].x != ai.x) {	// add in-range anchors
+			for (int32_t j = i0; j < i; ++j) { rq_insert(T[0], E, j); if (max_dist_inner > 0) rq_insert(T[1], E, j); }
+			i0 = i;
+		}
+		while (st < i && (ai.x >> 32 != an[st].x >> 32 || ai.x > an[st].x + (uint64_t)max_dist || (T[0].root != RQ_NIL && T[0].sz[T[0].root] > (uint32_t)cap_rmq_size))) {
+			if (rq_find(T[0], E, (int32_t)an[st].y, st) != RQ_NIL) rq_erase(T[0], E, st);
+			++st;
+		}
+		if (max_dist_inner > 0) {
+			while (st_inner < i && (ai.x >> 32 != an[st_inner].x >> 32 || ai.x > an[st_inner].x + (uint64_t)max_dist_inner || (T[1].root != RQ_NIL && T[1].sz[T[1].root] > (uint32_t)cap_rmq_size))) {
+				if (rq_find(T[1], E, (int32_t)an[st_inner].y, st_inner) != RQ_NIL) rq_erase(T[1], E, st_inner);
+				++st_inner;
+			}
+		}
+		const int32_t q = rq_rmq(T[0], E, (int32_t)ai.y - max_dist, (int64_t)INT32_MAX, (int32_t)ai.y, 0);
+		if (q != RQ_NIL) {
+			int32_t exact, width, n_skip = 0;
+			int32_t j = q;
+			int32_t sc = F_(j) + rq_sc_simple(ai, an[j], o.pen_gap, o.pen_skip, &exact, &width);
+			if (width <= bw && sc > max_f) { max_f = sc; max_j = j; }
+			if (!exact && T[1].root != RQ_NIL && (int32_t)ai.y > 0) {
+				// krmq_interval for (y - 1, n): the greatest element below it; then walk down the keys from there (krmq_itr_find + itr_prev)
+				const int32_t ys = (int32_t)ai.y - 1;
+				int32_t lo = RQ_NIL;
+				for (int32_t p = T[1].root; p != RQ_NIL;) { const int c = rq_cmp_key(ys, (int64_t)n, E, p); if (c < 0) p = T[1].l[p]; else if (c > 0) { lo = p; p = T[1].r[p]; } else { lo = p; break; } }
+				if (lo != RQ_NIL) {
+					int32_t stack[RQ_DEPTH];
+					int top = -1;
+					for (int32_t p = T[1].root; p != RQ_NIL;) { stack[++top] = p; const int c = rq_cmp_key((int32_t)an[lo].y, (int64_t)lo, E, p); if (c < 0) p = T[1].l[p]; else if (c > 0) p = T[1].r[p]; else break; }
+					while (top >= 0) {
+						const int32_t qq = stack[top];
+						if ((int32_t)an[qq].y < (int32_t)ai.y - max_dist_inner) break;
+						j = qq;
+						int32_t width2;
+						sc = F_(j) + rq_sc_simple(ai, an[j], o.pen_gap, o.pen_skip, nullptr, &width2);
+						if (width2 <= bw) {
+							if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
+							else if (t[j] == i) { if (++n_skip > o.max_skip) break; }
+							if (P_(j) >= 0) t[P_(j)] = i;
+						}
+						// krmq_itr_prev
+						int32_t p = T[1].l[stack[top]];
+						if (p != RQ_NIL) { for (; p != RQ_NIL; p = T[1].r[p]) stack[++top] = p; }
+						else {
+							do { p = stack[top--]; } while (top >= 0 && p == T[1].l[stack[top]]);
+							if (top < 0) break;
+						}
+					}
+				}
+			}
+		}
+		F_(i) = max_f; P_(i) = max_j;
+		v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
+	}
+	#undef F_
+	#undef P_
+}
+
+void rhk_chain_rmq(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r, const uint32_t *counts, int32_t max_dist, int32_t max_dist_inner, int32_t cap_rmq_size)
+{
+	if (!r.n_act) return;
+	RH_LAUNCH(k_chain_rmq, (r.n_act + 63) / 64, 64, 0, s, o, r, counts, max_dist, max_dist_inner, cap_rmq_size);
+}
+
 void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 {
 	if (!r.n_act) return;

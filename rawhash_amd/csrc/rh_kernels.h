@@ -48,6 +48,7 @@ struct rh_dev_opt {
 	uint32_t w1, w2; float thr1, thr2, peak_height;
 	int32_t mid_occ;
 	int32_t max_dist_t, max_dist_q, bw, max_skip, max_iter, min_cnt, min_sc, min_sc2;
+	int32_t bw_long, rmq_inner_dist, rmq_size_cap;      // RH_M_RMQ chaining / bw_long > bw re-chaining (lchain.c:606, rmap.cpp:336)
 	float pen_gap, pen_skip;
 	float mask_level; int32_t mask_len; float pri_ratio; int32_t best_n; int32_t min_strand_sc;
 	float w_bestq, w_bestmq, w_bestmc, w_threshold;
@@ -169,6 +170,7 @@ void rhk_scan_anchors(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round 
 void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
 int rhk_sort(hipStream_t s, const rh_dev_round &r);
 void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
+void rhk_chain_rmq(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r, const uint32_t *counts, int32_t max_dist, int32_t max_dist_inner, int32_t cap_rmq_size);   // mg_lchain_rmq (lchain.c:606); o.bw = the bandwidth of this pass
 int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
 int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
 int rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);

@@ -26,6 +26,7 @@ extern "C" void rh_mapopt_init(rh_mapopt_t *mo)
 	mo->max_chain_iter = 200; mo->max_num_skips = 5; mo->min_num_anchors = 2;
 	mo->min_chaining_score = 15; mo->min_chaining_score2 = 0;
 	mo->chain_gap_scale = 0.8f; mo->chain_skip_scale = 0.0f;
+	mo->rmq_inner_dist = 1000; mo->rmq_size_cap = 100000;
 	// regions
 	mo->mask_level = 0.5f; mo->mask_len = INT_MAX; mo->pri_ratio = 0.3f; mo->best_n = 0; mo->alt_drop = 0.15f;
 	// decision

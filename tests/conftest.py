@@ -46,7 +46,7 @@ class Workload:
     """Synthetic reference + index + reads, generated from seeds by the product library's host code."""
 
     def __init__(self, directory, lib, preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=12_000, n_reads=48,
-                 junk=150, noise=150_000, read_seed=3, index_lib=None, build_index=True, no_adaptive=False, fast5=False):
+                 junk=150, noise=150_000, read_seed=3, index_lib=None, build_index=True, no_adaptive=False, fast5=False, mapopt=None):
         from rawhash_amd.api import SynthWorkload, MapOptions, Index
         self.dir, self.preset = str(directory), preset
         self.wl = SynthWorkload(chrom_len=chrom_len, n_chrom=n_chrom, n_samples=n_samples, junk_per_1024=junk, noise_q24=noise,
@@ -54,8 +54,10 @@ class Workload:
         self.fasta, self.model = self.wl.write_reference(self.dir)
         self.opts = MapOptions(preset, lib=lib)
         self.no_adaptive = no_adaptive
+        self.mapopt = dict(mapopt or {})        # rh_mapopt_t fields set on top of the preset ("flag" is OR-ed in): --rmq, --bw-long ...
         if no_adaptive:
             self.opts.mo.flag |= 0x20           # RH_M_NO_ADAPTIVE: one round over the whole read
+        self._apply_mapopt(self.opts.mo)
         self.ind = os.path.join(self.dir, f"ref_{preset}.ind")
         self.index = None
         if build_index:     # (large references: the caller builds the index on the device instead)
@@ -64,12 +66,20 @@ class Workload:
         self.reads = self.wl.reads(self.model, 0, n_reads)
         self.reads.fast5 = bool(fast5)     # the same int16 samples taken in the way the reference's FAST5 reader does (rsig.c:346-374)
 
+    def _apply_mapopt(self, mo):
+        for k, v in self.mapopt.items():
+            if k == "flag":
+                mo.flag |= v
+            else:
+                setattr(mo, k, v)
+
     def oracle(self):
         import oracle_lib as O
         oix = O.OracleIndex(self.ind)
         _, mo = O.preset(self.preset)
         if self.no_adaptive:
             mo.flag |= 0x20
+        self._apply_mapopt(mo)
         O.lib().ro_mapopt_update(C.byref(mo), oix.h)
         return oix, mo
 
@@ -121,7 +131,7 @@ def make_workload(tmp_path_factory, product_lib):
     cache = {}
 
     def make(lib=None, **kw):
-        key = (id(lib),) + tuple(sorted(kw.items()))
+        key = (id(lib),) + tuple(sorted((k, tuple(sorted(v.items())) if isinstance(v, dict) else v) for k, v in kw.items()))
         if key not in cache:
             cache[key] = Workload(tmp_path_factory.mktemp("wl"), lib or product_lib, **kw)
         return cache[key]

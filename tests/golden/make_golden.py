@@ -31,6 +31,12 @@ CASES = [
     # the int16 samples taken in the way the FAST5 reader does (rsig.c:346-374: float arithmetic, kept values truncated to int16):
     # BASELINE config 1 is stated on FAST5 reads.  RH_FAST5_INGEST=1 makes the harness restate those lines (the reader itself needs HDF5)
     {"name": "small_sensitive_fast5_ingest", "env": {"RH_FAST5_INGEST": "1"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=160, junk=150, noise=150_000, read_seed=17, fast5=True)},
+    # f4: RMQ chaining (--rmq, lchain.c:606) with the inner tree, without it (--rmq-inner-dist 0), with a tree small enough to hit
+    # --rmq-size-cap, and the RMQ re-chaining of DP chains with a longer bandwidth (--bw-long, rmap.cpp:336)
+    {"name": "small_sensitive_rmq", "env": {"RH_RMQ": "1"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=120, junk=150, noise=150_000, read_seed=31, mapopt={"flag": 2})},
+    {"name": "small_fast_rmq_no_inner", "env": {"RH_RMQ": "1", "RH_RMQ_INNER_DIST": "0"}, "workload": dict(preset="fast", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=96, junk=150, noise=150_000, read_seed=32, mapopt={"flag": 2, "rmq_inner_dist": 0})},
+    {"name": "small_sensitive_rmq_cap", "env": {"RH_RMQ": "1", "RH_RMQ_SIZE_CAP": "40", "RH_RMQ_INNER_DIST": "300"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=96, junk=150, noise=150_000, read_seed=33, mapopt={"flag": 2, "rmq_size_cap": 40, "rmq_inner_dist": 300})},
+    {"name": "small_sensitive_bw_long", "env": {"RH_BW_LONG": "2000"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=120, junk=150, noise=150_000, read_seed=34, mapopt={"bw_long": 2000})},
     {"name": "config3_dmel_144M_384", "gpu_only": True, "workload": dict(preset="sensitive", chrom_len=24_000_000, n_chrom=6, n_samples=40_000, n_reads=384, junk=102, noise=0, read_seed=3)},
 ]
 

@@ -65,6 +65,23 @@ def test_stage_regions(ctx, wl):
     assert checked > 40 and with_regs > 20
 
 
+RMQ_VARIANTS = [{"flag": 2}, {"flag": 2, "rmq_inner_dist": 0}, {"flag": 2, "rmq_size_cap": 40, "rmq_inner_dist": 300}, {"bw_long": 2000}, {"flag": 2, "bw_long": 1500}]
+
+
+@pytest.mark.parametrize("mapopt", RMQ_VARIANTS, ids=lambda m: "_".join(f"{k}{v}" for k, v in m.items()))
+def test_rmq_chaining(make_workload, emu_lib, mapopt):
+    """f4: mg_lchain_rmq (--rmq: krmq AVL tree reproduced operation by operation, with / without the inner tree, with a size cap
+    that evicts) and the RMQ re-chaining of chains with a long bandwidth (--bw-long), stage level on adversarial anchor sets and
+    end to end against the oracle (which test_oracle pins to PAF printed by the reference for each variant)."""
+    w = make_workload(lib=emu_lib, n_reads=14, n_samples=12_000, mapopt=mapopt)
+    c = Context(0, lib=emu_lib)
+    c.upload(w.index)
+    n_an, n_ch, n_u = pc.check_chain_synthetic(c, w, seed=6, n_reads=24, max_n=400)
+    assert n_ch > 0 and n_u > 0
+    pc.check_e2e(c, w)
+    c.close()
+
+
 def test_end_to_end_paf(ctx, wl):
     recs = pc.check_e2e(ctx, wl)
     assert recs["mapped"].sum() > 0 and (recs["mapped"] == 0).sum() > 0   # both outcomes exercised

@@ -63,6 +63,19 @@ def test_stage_regions(ctx, wl):
     assert checked > 300 and with_regs > 150
 
 
+@pytest.mark.parametrize("mapopt", [{"flag": 2}, {"flag": 2, "rmq_size_cap": 40, "rmq_inner_dist": 300}, {"bw_long": 2000}, {"flag": 2, "bw_long": 1500}],
+                         ids=lambda m: "_".join(f"{k}{v}" for k, v in m.items()))
+def test_rmq_chaining(make_workload, product_lib, gpu_ctx_factory, mapopt):
+    """f4: --rmq / --bw-long (mg_lchain_rmq, lchain.c:606) on the device: adversarial anchor sets at stage level and 300 reads end to
+    end against the oracle; the goldens printed by the reference for these variants are part of test_golden_paf."""
+    w = make_workload(n_reads=300, n_samples=20_000, mapopt=mapopt)
+    c = gpu_ctx_factory()
+    c.upload(w.index)
+    n_an, n_ch, n_u = pc.check_chain_synthetic(c, w, seed=16, n_reads=200, max_n=1500)
+    assert n_ch > 0 and n_u > 0
+    pc.check_e2e(c, w)
+
+
 def test_any_order_sort(ctx):
     """Region keys (hit.c:111-126) through the sorter's any-order levels + tie check, many long segments."""
     assert pc.check_sort_any(ctx, seed=5) >= 1
