@@ -501,7 +501,7 @@ extern "C" rh_index *rh_index_build_device(rh_ctx *c, uint32_t n_seq, const char
 	if (index_replaceable(c, "rh_index_build_device")) return nullptr;
 	if (hipSetDevice(c->device) != hipSuccess) { rh_set_error("hipSetDevice failed"); return nullptr; }
 	if (io->flag & RH_I_SIG_TARGET) { rh_set_error("signal-target (Rawsamble) indexes are built by rh_index_build_signals"); return nullptr; }
-	if (io->w != 0) { rh_set_error("minimiser indexes (w = %d) are built on the host: rh_index_build", io->w); return nullptr; }
+	if (io->w < 0 || io->w > RH_DEV_MAXW) { rh_set_error("minimiser window w = %d outside what the device sketch maps with (0..%d)", io->w, RH_DEV_MAXW); return nullptr; }
 	if (io->e < 1 || io->e > 16 || io->q < 1 || io->q * io->e > 64 || io->k < 1 || io->k > 12) { rh_set_error("unsupported index parameters e=%d q=%d k=%d", io->e, io->q, io->k); return nullptr; }
 	std::unique_ptr<rh_index_s> ix(new rh_index_s());
 	ix->w = io->w; ix->e = io->e; ix->n = io->n; ix->q = io->q; ix->k = io->k; ix->flag = io->flag;

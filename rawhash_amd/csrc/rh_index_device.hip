@@ -241,9 +241,71 @@ __global__ __launch_bounds__(NT) void k_ix_seeds(const uint8_t *kcode, const uin
 	Y[idx] = (uint64_t)id << 32 | (uint64_t)(pos << 1) | (uint64_t)(uint32_t)strand;
 }
 
+// ------------------------------------------------------------------------------------------------ minimisers (w > 0)
+// ri_sketch_min (rsketch.c:55-141) keeps, of every w consecutive seeds, the one with the least hash - minimap2's loop, quirks
+// included: the NEWEST of equal minima is "the" minimum, the older equal ones are pushed when a minimum is (re)established, a
+// minimum is pushed when it is replaced or leaves the window and once more at the end (so a seed can be emitted twice).  The loop is
+// serial, but its state after seed t-1 is a function of the last w seeds only: min = the most recent minimum among seeds
+// [t-w, t-1], buf_pos = t mod w.  So every seed t replays step t on its own from the w seeds before it: a counting launch, an
+// exclusive scan, an emitting launch.  (l of the reference = t + e: the first seed exists once e events are kept.)
+struct ix_min_state { uint32_t x; int32_t at; };                 // hash and ordinal of a minimum (at < 0: none yet)
+RH_DEV ix_min_state ix_recent_min(const uint32_t *Hs, int64_t lo, int64_t hi)   // most recent minimum of seeds [lo, hi]
+{
+	ix_min_state m = {0xFFFFFFFFu, -1};
+	for (int64_t j = lo; j <= hi; ++j) if (m.at < 0 || Hs[j] <= m.x) { m.x = Hs[j]; m.at = (int32_t)j; }
+	return m;
+}
+// step t of the loop: calls emit(ordinal) for every seed pushed at this step, in the reference's order
+template <class F>
+RH_DEV void ix_min_step(const uint32_t *Hs, uint32_t n_seed, uint32_t t, int w, F emit)
+{
+	const int64_t T = (int64_t)t;
+	const ix_min_state m = T > 0 ? ix_recent_min(Hs, T - w > 0 ? T - w : 0, T - 1) : ix_min_state{0xFFFFFFFFu, -1};
+	const uint32_t hx = Hs[t];
+	if (T == (int64_t)w - 1 && m.at >= 0)                            // the first full window: identical seeds have not been stored yet
+		for (int64_t j = 0; j < T; ++j) if (Hs[j] == m.x && j != m.at) emit((uint32_t)j);
+	ix_min_state cur = m;
+	if (m.at < 0 || hx <= m.x) {                                     // a new minimum: write the old one
+		if (T >= (int64_t)w && m.at >= 0) emit((uint32_t)m.at);
+		cur.x = hx; cur.at = (int32_t)T;
+	} else if (m.at == T - (int64_t)w) {                             // the old minimum has left the window
+		emit((uint32_t)m.at);
+		cur = ix_recent_min(Hs, T - w + 1, T);
+		for (int64_t j = T - w + 1; j <= T; ++j) if (Hs[j] == cur.x && j != cur.at) emit((uint32_t)j);
+	}
+	if (t + 1u == n_seed && cur.at >= 0) emit((uint32_t)cur.at);     // after the loop: the last minimum
+}
+__global__ __launch_bounds__(NT) void k_ix_hash(const uint8_t *kcode, const uint32_t *kpos, uint32_t n_seed, int strand, uint32_t id, rh_sketch_par sp, uint32_t *Hs, uint64_t *Ys)
+{
+	const uint32_t t = blockIdx.x * NT + threadIdx.x;
+	if (t >= n_seed) return;
+	const uint32_t qb = (uint32_t)sp.q;
+	const uint64_t mask_events = (qb * sp.e >= 64) ? ~0ULL : ((1ULL << (qb * sp.e)) - 1);
+	uint64_t qv = 0;
+	for (int j = 0; j < sp.e; ++j) qv = ((qv << qb) | (uint64_t)kcode[t + (uint32_t)j]) & mask_events;
+	Hs[t] = (uint32_t)rh_seed_hash32(qv);
+	Ys[t] = (uint64_t)id << 32 | (uint64_t)(kpos[t] << 1) | (uint64_t)(uint32_t)strand;
+}
+__global__ __launch_bounds__(NT) void k_ix_min_count(const uint32_t *Hs, uint32_t n_seed, int w, uint32_t *cnt)
+{
+	const uint32_t t = blockIdx.x * NT + threadIdx.x;
+	if (t >= n_seed) return;
+	uint32_t c = 0;
+	ix_min_step(Hs, n_seed, t, w, [&](uint32_t) { ++c; });
+	cnt[t] = c;
+}
+__global__ __launch_bounds__(NT) void k_ix_min_emit(const uint32_t *Hs, const uint64_t *Ys, uint32_t n_seed, int w, const uint64_t *off, uint32_t *H, uint64_t *Y, uint64_t base, uint64_t cap)
+{
+	const uint32_t t = blockIdx.x * NT + threadIdx.x;
+	if (t >= n_seed) return;
+	uint64_t o = base + off[t];
+	ix_min_step(Hs, n_seed, t, w, [&](uint32_t j) { if (o < cap) { H[o] = Hs[j]; Y[o] = Ys[j]; } ++o; });
+}
+
 // ------------------------------------------------------------------------------------------------ radix sort by hash
 // counts[d * n_tiles + tile]
-__global__ __launch_bounds__(NT) void k_ix_rs_count(const uint32_t *H, uint64_t n, int shift, uint32_t *counts, uint64_t n_tiles)
+// (ykey: the digit comes from the position word Y instead of the hash - the passes that put a minimiser index's seeds into position order)
+__global__ __launch_bounds__(NT) void k_ix_rs_count(const uint32_t *H, const uint64_t *Y, int ykey, uint64_t n, int shift, uint32_t *counts, uint64_t n_tiles)
 {
 	__shared__ uint32_t s_cnt[256];
 	const uint32_t tid = threadIdx.x;
@@ -252,7 +314,7 @@ __global__ __launch_bounds__(NT) void k_ix_rs_count(const uint32_t *H, uint64_t 
 	const uint64_t base = (uint64_t)blockIdx.x * IX_RT;
 	for (uint32_t it = 0; it < IX_RT_IT; ++it) {
 		const uint64_t i = base + (uint64_t)it * NT + tid;
-		if (i < n) atomicAdd(&s_cnt[(H[i] >> shift) & 255u], 1u);
+		if (i < n) atomicAdd(&s_cnt[ykey ? (uint32_t)(Y[i] >> shift) & 255u : (H[i] >> shift) & 255u], 1u);
 	}
 	__syncthreads();
 	counts[(uint64_t)tid * n_tiles + blockIdx.x] = s_cnt[tid];
@@ -279,7 +341,7 @@ __global__ void k_ix_rs_base(uint64_t *dig_total)
 	if (threadIdx.x == 0) { uint64_t run = 0; for (int d = 0; d < 256; ++d) { const uint64_t v = dig_total[d]; dig_total[d] = run; run += v; } }
 }
 // stable scatter of one tile: records in tile order = (round, wavefront, lane); ranks from wave ballots
-__global__ __launch_bounds__(NT) void k_ix_rs_scatter(const uint32_t *H, const uint64_t *Y, uint64_t n, int shift, const uint64_t *offs, const uint64_t *dig_base, uint64_t n_tiles,
+__global__ __launch_bounds__(NT) void k_ix_rs_scatter(const uint32_t *H, const uint64_t *Y, int ykey, uint64_t n, int shift, const uint64_t *offs, const uint64_t *dig_base, uint64_t n_tiles,
                                                       uint32_t *H2, uint64_t *Y2)
 {
 	__shared__ uint16_t s_hist[IX_RT_IT * (NT / 64) * 256];         // [round][wave][digit]: records of the digit, then (exclusive) those before
@@ -289,13 +351,14 @@ __global__ __launch_bounds__(NT) void k_ix_rs_scatter(const uint32_t *H, const u
 	s_off[tid] = dig_base[tid] + offs[(uint64_t)tid * n_tiles + blockIdx.x];
 	__syncthreads();
 	const uint64_t base = (uint64_t)blockIdx.x * IX_RT;
-	uint32_t h[IX_RT_IT], rk[IX_RT_IT];
+	uint32_t h[IX_RT_IT], rk[IX_RT_IT], dg[IX_RT_IT];
 #pragma unroll
 	for (uint32_t it = 0; it < IX_RT_IT; ++it) {
 		const uint64_t i = base + (uint64_t)it * NT + tid;
 		const bool in = i < n;
 		h[it] = in ? H[i] : 0u;
-		const uint32_t d = (h[it] >> shift) & 255u;
+		const uint32_t d = in ? (ykey ? (uint32_t)(Y[i] >> shift) & 255u : (h[it] >> shift) & 255u) : 0u;
+		dg[it] = d;
 		uint64_t peers = __ballot(in);
 #pragma unroll
 		for (int bit = 0; bit < 8; ++bit) { const uint64_t m = __ballot((d >> bit) & 1u); peers &= ((d >> bit) & 1u) ? m : ~m; }
@@ -312,7 +375,7 @@ __global__ __launch_bounds__(NT) void k_ix_rs_scatter(const uint32_t *H, const u
 	for (uint32_t it = 0; it < IX_RT_IT; ++it) {
 		const uint64_t i = base + (uint64_t)it * NT + tid;
 		if (i < n) {
-			const uint32_t d = (h[it] >> shift) & 255u;
+			const uint32_t d = dg[it];
 			const uint64_t dst = s_off[d] + s_hist[(it * (NT / 64) + w) * 256 + d] + rk[it];
 			H2[dst] = h[it]; Y2[dst] = Y[i];
 		}
@@ -411,10 +474,15 @@ int rhk_index_build_device(hipStream_t s, uint32_t n_seq, const char *const *seq
 	if (max_len >= (1u << 31)) { rh_set_error("index build: target sequences of 2^31 bases or more are not supported"); return -1; }
 	const uint32_t max_ev = max_len >= (uint32_t)k ? max_len - k + 1 : 0, max_words = max_ev / 32 + 2, max_blocks = max_ev / IX_L + 2;
 	// seeds of all sequences: at most one per event
-	DevMem dH[2], dY[2], dModel, dSeq, dLv, dMask[2], dPc, dPrefix[2], dCode[2], dPos[2], dIn, dOut, dFlag, dSums, dScal, dRuns;
+	DevMem dH[2], dY[2], dModel, dSeq, dLv, dMask[2], dPc, dPrefix[2], dCode[2], dPos[2], dIn, dOut, dFlag, dSums, dScal, dRuns, dHs, dYs, dCnt, dOffs;
+	const uint64_t seed_cap = total_ev + 1;
+	if (io->w > 0) {	// minimisers: a strand's seeds (hash, position word) before the window filter, emission counts and offsets
+		if (io->w > 255) { rh_set_error("index build: minimiser window %d > 255", io->w); return -1; }
+		if (dHs.alloc((size_t)max_ev * 4 + 16) || dYs.alloc((size_t)max_ev * 8 + 16) || dCnt.alloc((size_t)max_ev * 4 + 16) || dOffs.alloc((size_t)max_ev * 8 + 16)) return -1;
+	}
 	if (dH[0].alloc((total_ev + 1) * 4) || dY[0].alloc((total_ev + 1) * 8) || dModel.alloc(model.size() * 4) || dSeq.alloc((size_t)max_len + 16) || dLv.alloc((size_t)max_ev * 4 + 16)) return -1;
 	for (int q = 0; q < 2; ++q) if (dMask[q].alloc((size_t)max_words * 4) || dPrefix[q].alloc((size_t)max_words * 4) || dCode[q].alloc((size_t)max_ev + 64) || dPos[q].alloc((size_t)max_ev * 4 + 16)) return -1;
-	if (dPc.alloc((size_t)max_words * 4) || dIn.alloc((size_t)max_blocks * 4) || dOut.alloc((size_t)max_blocks * 4) || dFlag.alloc(max_blocks) || dSums.alloc(((size_t)max_words / 2048 + 4) * 8) || dScal.alloc(64)) return -1;
+	if (dPc.alloc((size_t)max_words * 4) || dIn.alloc((size_t)max_blocks * 4) || dOut.alloc((size_t)max_blocks * 4) || dFlag.alloc(max_blocks) || dSums.alloc(((size_t)(io->w > 0 ? max_ev : max_words) / 2048 + 4) * 8) || dScal.alloc(64)) return -1;
 	RH_HIP(hipMemcpyAsync(dModel.p, model.data(), model.size() * 4, hipMemcpyHostToDevice, s));
 	uint64_t n_seeds = 0;
 	uint64_t *scal = nullptr;
@@ -469,6 +537,23 @@ int rhk_index_build_device(hipStream_t s, uint32_t n_seq, const char *const *seq
 			seeds[st] = kept[st] >= (uint32_t)e ? kept[st] - e + 1 : 0;
 			RH_LAUNCH(k_ix_compact, (n_words + NT - 1) / NT, NT, 0, s, dLv.as<float>(), dMask[st].as<uint32_t>(), dPrefix[st].as<uint32_t>(), n_words, sp, dCode[st].as<uint8_t>(), dPos[st].as<uint32_t>());
 		}
+		if (io->w > 0) {	// ri_sketch_min: window filter of every strand's seed stream; the position order is restored by the assembly's sort
+			for (int st = 0; st < n_strands; ++st) {
+				if (!seeds[st]) continue;
+				const uint32_t ns = seeds[st];
+				RH_LAUNCH(k_ix_hash, (ns + NT - 1) / NT, NT, 0, s, dCode[st].as<uint8_t>(), dPos[st].as<uint32_t>(), ns, st, id, sp, dHs.as<uint32_t>(), dYs.as<uint64_t>());
+				RH_LAUNCH(k_ix_min_count, (ns + NT - 1) / NT, NT, 0, s, dHs.as<uint32_t>(), ns, io->w, dCnt.as<uint32_t>());
+				if (ix_scan<uint64_t>(s, dCnt.as<uint32_t>(), ns, dOffs.as<uint64_t>(), dSums.as<uint64_t>(), dScal.as<uint64_t>())) return -1;
+				RH_HIP(hipMemcpyAsync(scal, dScal.p, 8, hipMemcpyDeviceToHost, s));
+				RH_HIP(hipStreamSynchronize(s));
+				const uint64_t emitted = scal[0];
+				if (n_seeds + emitted > seed_cap) { rh_set_error("index build: more minimisers than events (%llu > %llu)", (unsigned long long)(n_seeds + emitted), (unsigned long long)seed_cap); return -1; }
+				RH_LAUNCH(k_ix_min_emit, (ns + NT - 1) / NT, NT, 0, s, dHs.as<uint32_t>(), dYs.as<uint64_t>(), ns, io->w, dOffs.as<uint64_t>(), dH[0].as<uint32_t>(), dY[0].as<uint64_t>(), n_seeds, seed_cap);
+				n_seeds += emitted;
+			}
+			RH_HIP(hipStreamSynchronize(s));
+			continue;
+		}
 		for (int st = 0; st < n_strands; ++st) {
 			if (!seeds[st]) continue;
 			const int o = st ^ 1;
@@ -480,17 +565,17 @@ int rhk_index_build_device(hipStream_t s, uint32_t n_seq, const char *const *seq
 		RH_HIP(hipStreamSynchronize(s));                            // the staging buffers are reused by the next sequence
 	}
 	// per-sequence scratch is done with
-	dSeq.release(); dLv.release(); dPc.release(); dIn.release(); dOut.release(); dFlag.release(); dRuns.release();
+	dSeq.release(); dLv.release(); dPc.release(); dIn.release(); dOut.release(); dFlag.release(); dRuns.release(); dHs.release(); dYs.release(); dCnt.release(); dOffs.release();
 	for (int q = 0; q < 2; ++q) { dMask[q].release(); dPrefix[q].release(); dCode[q].release(); dPos[q].release(); }
 	void *hp = dH[0].p, *yp = dY[0].p;
 	dH[0].p = nullptr; dY[0].p = nullptr;                         // (handed over)
-	return rhk_index_assemble(s, hp, yp, n_seeds, n_seq, lens, max_len, io, hdr, blob_out, occ_hist, n_keys_out);
+	return rhk_index_assemble(s, hp, yp, n_seeds, n_seq, lens, max_len, io, hdr, blob_out, occ_hist, n_keys_out, io->w > 0);
 }
 
 // Seeds (32-bit hash, position word) in target order -> resident blob [table | positions | target lengths].  Takes ownership
 // of the two device arrays (hipMalloc'ed, n_seeds + 1 entries).
 int rhk_index_assemble(hipStream_t s, void *seed_hash, void *seed_pos, uint64_t n_seeds, uint32_t n_seq, const uint32_t *lens, uint32_t max_len,
-                       const rh_idxopt_t *io, rh_blob_header *hdr, void **blob_out, std::vector<uint32_t> &occ_hist, uint64_t *n_keys_out)
+                       const rh_idxopt_t *io, rh_blob_header *hdr, void **blob_out, std::vector<uint32_t> &occ_hist, uint64_t *n_keys_out, bool sort_pos)
 {
 	const rh_sketch_par sp = {io->e, io->w, io->q, io->k, io->diff, io->fine_min, io->fine_max, io->fine_range};
 	DevMem dH[2], dY[2], dSums, dScal;
@@ -505,11 +590,16 @@ int rhk_index_assemble(hipStream_t s, void *seed_hash, void *seed_pos, uint64_t 
 	if (N) {
 		DevMem dCnt, dOff, dDig;
 		if (dH[1].alloc((N + 1) * 4) || dY[1].alloc((N + 1) * 8) || dCnt.alloc(n_tiles * 256 * 4) || dOff.alloc(n_tiles * 256 * 8) || dDig.alloc(256 * 8)) return -1;
-		for (int shift = 0; shift < 32; shift += 8) {
-			RH_LAUNCH(k_ix_rs_count, (uint32_t)n_tiles, NT, 0, s, dH[cur].as<uint32_t>(), N, shift, dCnt.as<uint32_t>(), n_tiles);
+		// seeds that do not arrive in position order (minimiser indexes: emitted strand by strand, some twice) are first put into the
+		// order of their position words id << 32 | pos << 1 | strand - what radix_sort_64 leaves a key's list in (rindex.c:350)
+		int y_bytes = 0;
+		if (sort_pos) { y_bytes = 4; for (uint64_t v = n_seq ? n_seq - 1 : 0; v; v >>= 8) ++y_bytes; }
+		for (int pass = 0; pass < y_bytes + 4; ++pass) {
+			const int ykey = pass < y_bytes, shift = ykey ? pass * 8 : (pass - y_bytes) * 8;
+			RH_LAUNCH(k_ix_rs_count, (uint32_t)n_tiles, NT, 0, s, dH[cur].as<uint32_t>(), dY[cur].as<uint64_t>(), ykey, N, shift, dCnt.as<uint32_t>(), n_tiles);
 			RH_LAUNCH(k_ix_rs_scan, 256, NT, 0, s, dCnt.as<uint32_t>(), dOff.as<uint64_t>(), n_tiles, dDig.as<uint64_t>());
 			RH_LAUNCH(k_ix_rs_base, 1, 64, 0, s, dDig.as<uint64_t>());
-			RH_LAUNCH(k_ix_rs_scatter, (uint32_t)n_tiles, NT, 0, s, dH[cur].as<uint32_t>(), dY[cur].as<uint64_t>(), N, shift, dOff.as<uint64_t>(), dDig.as<uint64_t>(), n_tiles,
+			RH_LAUNCH(k_ix_rs_scatter, (uint32_t)n_tiles, NT, 0, s, dH[cur].as<uint32_t>(), dY[cur].as<uint64_t>(), ykey, N, shift, dOff.as<uint64_t>(), dDig.as<uint64_t>(), n_tiles,
 			          dH[cur ^ 1].as<uint32_t>(), dY[cur ^ 1].as<uint64_t>());
 			cur ^= 1;
 		}

@@ -57,6 +57,7 @@ AVA_CASES = [
 REPEAT_CASES = [
     {"name": "repeat_small_2M", "workload": dict(preset="sensitive", n_chrom=2, chrom_len=1_000_000, n_reads=120, genome_seed=41, read_seed=43)},
     {"name": "repeat_fast_2M", "workload": dict(preset="fast", n_chrom=2, chrom_len=1_000_000, n_reads=120, genome_seed=45, read_seed=47)},
+    {"name": "repeat_faster_2M", "workload": dict(preset="faster", n_chrom=2, chrom_len=1_000_000, n_reads=120, genome_seed=55, read_seed=57)},   # minimisers (w = 3) over tandem repeats: equal minima
     {"name": "repeat_rich_52M", "gpu_only": True, "workload": dict(preset="sensitive", n_chrom=4, chrom_len=13_000_000, n_reads=200, genome_seed=51, read_seed=53)},
 ]
 

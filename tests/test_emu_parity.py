@@ -53,6 +53,9 @@ def test_index_built_on_device(emu_lib, emu_lib_smallcaps, tmp_path):
     pc.check_device_index(emu_lib, tmp_path / "b", preset="fast", chrom_len=30_000, n_chrom=2, with_gaps=False, seed=6)
     # blocks of 64 events with a 3-event warm-up: the speculative starts of the event filter are often wrong and get re-run
     pc.check_device_index(emu_lib_smallcaps, tmp_path / "c", chrom_len=20_000, n_chrom=2, seed=7)
+    # minimiser indexes (w > 0, ri_sketch_min rsketch.c:55-141): preset faster (w = 3) with gaps; low-entropy sequence for equal minima
+    pc.check_device_index(emu_lib, tmp_path / "d", preset="faster", chrom_len=40_000, n_chrom=2, seed=8)
+    pc.check_device_index(emu_lib_smallcaps, tmp_path / "e", preset="faster", chrom_len=15_000, n_chrom=3, with_gaps=False, seed=9)
 
 
 def test_chain_adversarial(ctx, wl):

@@ -97,6 +97,7 @@ def test_index_built_on_device(product_lib, tmp_path):
     checked, n = pc.check_device_index(product_lib, tmp_path)
     assert checked > 1000 and n > 10000
     pc.check_device_index(product_lib, tmp_path / "b", preset="fast", chrom_len=3_000_000, n_chrom=2, with_gaps=True, seed=9)
+    pc.check_device_index(product_lib, tmp_path / "c", preset="faster", chrom_len=3_000_000, n_chrom=2, with_gaps=True, seed=10)   # minimisers (w = 3)
 
 
 def test_device_index_maps_like_uploaded_index(make_workload, product_lib):
