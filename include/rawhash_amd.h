@@ -68,7 +68,16 @@ typedef struct rh_mapopt_s {
 	uint32_t window_length1, window_length2;
 	float threshold1, threshold2, peak_height;
 	int32_t rmq_inner_dist, rmq_size_cap;   /* --rmq-inner-dist [1000], --rmq-size-cap [100000] (roptions.c:65-66): RH_M_RMQ chaining and the bw_long > bw re-chaining */
+	/* RH_M_DTW_EVALUATE_CHAINS (--dtw-evaluate-chains; the index must carry the target signals: RH_I_STORE_SIG), roptions.c:84, 96-101 */
+	uint32_t dtw_border_constraint;         /* RH_DTW_BORDER_GLOBAL 0 | RH_DTW_BORDER_SPARSE 1 (between consecutive anchors) [sparse] */
+	uint32_t dtw_fill_method;               /* RH_DTW_FILL_FULL 0 | RH_DTW_FILL_BANDED 1 [banded] */
+	float dtw_band_radius_frac, dtw_match_bonus, dtw_min_score;   /* [0.10, 0.4, 20.0] */
+	float w_bestma;                         /* --w-bestma [0.2]: weight of the alignment score in the mapping decision (rmap.cpp:474) */
 } rh_mapopt_t;
+#define RH_DTW_BORDER_GLOBAL 0u
+#define RH_DTW_BORDER_SPARSE 1u
+#define RH_DTW_FILL_FULL     0u
+#define RH_DTW_FILL_BANDED   1u
 
 /* One output record = ri_map_t (rmap.h:12-22) + the integer tag values rmap.cpp:523-571 formats.
  * Unmapped reads get exactly one record with mapped=0 (rmap.cpp:521-556). */

@@ -115,6 +115,12 @@ static void apply_overrides(ri_idxopt_t *ipt, ri_mapopt_t *opt)
 	if ((s = getenv("RH_RMQ_INNER_DIST"))) opt->rmq_inner_dist = atoi(s);           // --rmq-inner-dist (:331)
 	if ((s = getenv("RH_RMQ_SIZE_CAP"))) opt->rmq_size_cap = atoi(s);               // --rmq-size-cap (:332)
 	if ((s = getenv("RH_BW_LONG"))) opt->bw_long = atoi(s);                         // --bw-long (:333)
+	if ((s = getenv("RH_STORE_SIG")) && atoi(s)) ipt->flag |= RI_I_STORE_SIG;       // --store-sig (:367)
+	if ((s = getenv("RH_DTW")) && atoi(s)) opt->flag |= RI_M_DTW_EVALUATE_CHAINS;   // --dtw-evaluate-chains (:372)
+	if ((s = getenv("RH_DTW_BORDER"))) opt->dtw_border_constraint = (uint32_t)atoi(s);   // --dtw-border-constraint global = 0 | sparse = 1 (:374)
+	if ((s = getenv("RH_DTW_FILL"))) opt->dtw_fill_method = (uint32_t)atoi(s);      // --dtw-fill-method full = 0 | banded = 1 (:384)
+	if ((s = getenv("RH_DTW_BAND_FRAC"))) opt->dtw_band_radius_frac = (float)atof(s);
+	if ((s = getenv("RH_DTW_MIN_SCORE"))) opt->dtw_min_score = (float)atof(s);      // --dtw-min-score (:390)
 }
 
 static int set_presets(const char *preset, ri_idxopt_t *ipt, ri_mapopt_t *opt)

@@ -34,6 +34,8 @@ void ro_mapopt_init(rh_mapopt_t *mo)
 	mo->min_chaining_score = 15; mo->min_chaining_score2 = 0;
 	mo->chain_gap_scale = 0.8f; mo->chain_skip_scale = 0.0f;
 	mo->rmq_inner_dist = 1000; mo->rmq_size_cap = 100000;	/* roptions.c:65-66 */
+	mo->dtw_border_constraint = RH_DTW_BORDER_SPARSE; mo->dtw_fill_method = RH_DTW_FILL_BANDED;	/* roptions.c:96-101, :84 */
+	mo->dtw_band_radius_frac = 0.10f; mo->dtw_match_bonus = 0.4f; mo->dtw_min_score = 20.0f; mo->w_bestma = 0.2f;
 	mo->mask_level = 0.5f; mo->mask_len = INT_MAX; mo->pri_ratio = 0.3f; mo->best_n = 0; mo->alt_drop = 0.15f;
 	mo->w_bestmq = 0.05f; mo->w_bestmc = 0.6f; mo->w_bestq = 0.35f; mo->w_threshold = 0.45f;
 	mo->min_events = 50; mo->max_num_chunk = 10; mo->min_mapq = 2;
@@ -144,6 +146,7 @@ struct ro_index_s {
 	/* open-addressing table over the 32-bit seed hash: slot = {hash+1 (0 = empty), n, val} */
 	uint64_t tmask;
 	uint32_t *t_hash; uint32_t *t_n; uint64_t *t_val;   /* n==1: val = position word; n>1: val = offset into pos[] */
+	float **F, **R; uint32_t *fl, *rl;                  /* RH_I_STORE_SIG: expected signal of every target, forward / reverse (rindex.c:716-726) */
 };
 
 static int rd(void *dst, size_t sz, size_t n, FILE *fp) { return fread(dst, sz, n, fp) == n ? 0 : -1; }
@@ -174,9 +177,15 @@ ro_index *ro_index_load(const char *path)
 		if (l && rd(ix->name[i], 1, l, fp)) goto fail;
 		if (rd(&ix->len[i], 4, 1, fp)) goto fail;
 		if (ix->flag & RH_I_STORE_SIG) {
-			uint32_t fl;
-			if (rd(&fl, 4, 1, fp) || fseek(fp, (long)fl * 4, SEEK_CUR)) goto fail;
-			if (!(ix->flag & RH_I_NO_REV_TARGET)) { if (rd(&fl, 4, 1, fp) || fseek(fp, (long)fl * 4, SEEK_CUR)) goto fail; }
+			if (!ix->F) { ix->F = (float**)calloc(ix->n_seq, sizeof(float*)); ix->R = (float**)calloc(ix->n_seq, sizeof(float*)); ix->fl = (uint32_t*)calloc(ix->n_seq, 4); ix->rl = (uint32_t*)calloc(ix->n_seq, 4); }
+			if (rd(&ix->fl[i], 4, 1, fp)) goto fail;
+			ix->F[i] = (float*)malloc(((size_t)ix->fl[i] + 1) * 4);
+			if (ix->fl[i] && rd(ix->F[i], 4, ix->fl[i], fp)) goto fail;
+			if (!(ix->flag & RH_I_NO_REV_TARGET)) {
+				if (rd(&ix->rl[i], 4, 1, fp)) goto fail;
+				ix->R[i] = (float*)malloc(((size_t)ix->rl[i] + 1) * 4);
+				if (ix->rl[i] && rd(ix->R[i], 4, ix->rl[i], fp)) goto fail;
+			}
 		}
 	}
 	{	/* pass 1: sizes */
@@ -1021,6 +1030,7 @@ static a128 *chain_rmq(int max_dist, int max_dist_inner, int bw, int max_skip, i
 typedef struct {
 	int32_t id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0;
 	uint32_t mapq, rev, hash, strand_retained;
+	float alignment_score;	/* RH_M_DTW_EVALUATE_CHAINS (rmap.cpp:128-208) */
 } reg_t;
 
 static inline uint64_t hash64u(uint64_t key)	/* hit.c:73-83 */
@@ -1176,7 +1186,7 @@ static void select_sub(float pri_ratio, int best_n, int check_strand, int min_st
 	*n_ = k;
 }
 
-static void set_mapq(int n, reg_t *r, int min_chain_sc, int rep_len)	/* hit.c:502-539 (non-DTW branch) */
+static void set_mapq(int n, reg_t *r, int min_chain_sc, int rep_len, int is_dtw)	/* hit.c:502-539 */
 {
 	if (n == 0) return;
 	int64_t sum_sc = 0;
@@ -1190,11 +1200,142 @@ static void set_mapq(int n, reg_t *r, int min_chain_sc, int rep_len)	/* hit.c:50
 		pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
 		subsc = q->subsc > min_chain_sc ? q->subsc : min_chain_sc;
 		float x = (float)subsc / q->score0;
-		mapq = (int)(pen_cm * 40.0f * (1.0f - x) * logf(q->score));
+		mapq = 0;
+		if (is_dtw && q->alignment_score > 0) mapq = (int)(pen_cm * 40.0f * (1.0f - x) * 2 * logf(q->alignment_score));
+		else if (!is_dtw) mapq = (int)(pen_cm * 40.0f * (1.0f - x) * logf(q->score));
 		mapq -= (int)(4.343f * logf(q->n_sub + 1) + .499f);
 		mapq = mapq > 0 ? mapq : 0;
 		q->mapq = mapq < 60 ? mapq : 60;
 	}
+}
+
+/* ================================================================== f4: DTW re-scoring of chains (rmap.cpp:128-208, dtw.cpp) */
+#define DTW_DIST(A, B) fabsf((A) - (B))	/* DISTANCE, dtw.cpp:12 (float abs) */
+static inline float fmin2(float a, float b) { return b < a ? b : a; }	/* std::min */
+
+static float dtw_global(const float *a, uint32_t a_len, const float *b, uint32_t b_len, int exclude_last)	/* DTW_global dtw.cpp:37-66 */
+{
+	float *dp = (float*)malloc((a_len ? a_len : 1) * sizeof(float));
+	dp[0] = DTW_DIST(a[0], b[0]);
+	for (uint32_t j = 1; j < a_len; j++) dp[j] = dp[j - 1] + DTW_DIST(a[j], b[0]);
+	for (uint32_t i = 1; i < b_len; i++) {
+		float old_left = dp[0];
+		dp[0] = dp[0] + DTW_DIST(a[0], b[i]);
+		for (uint32_t j = 1; j < a_len; j++) {
+			float top = dp[j - 1], left = dp[j], topleft = old_left;
+			float center = fmin2(fmin2(top, left), topleft) + DTW_DIST(a[j], b[i]);
+			dp[j] = center;
+			old_left = left;
+		}
+	}
+	float res = exclude_last ? dp[a_len - 1] - DTW_DIST(a[a_len - 1], b[b_len - 1]) : dp[a_len - 1];
+	free(dp);
+	return res;
+}
+
+/* DTW_global_slantedbanded_antidiagonalwise dtw.cpp:273-523: three rotating anti-diagonal buffers; cells outside the clipped range of
+ * an anti-diagonal keep whatever an earlier one left there, and the neighbours read them - the buffers are kept exactly as there */
+static float dtw_banded(const float *a, uint32_t a_length, const float *b, uint32_t b_length, int band_radius, int exclude_last)
+{
+	if (a_length < b_length) { const float *tv = a; uint32_t tl = a_length; a = b; a_length = b_length; b = tv; b_length = tl; }
+	int extra = (int)(((a_length - b_length) * band_radius + a_length - 1) / a_length);	/* (unsigned arithmetic, as there) */
+	band_radius += extra;
+	const int plen = band_radius + (band_radius % 2 == 0 ? 1 : 0), slen = band_radius + (band_radius % 2 == 1 ? 1 : 0);
+	const int primary_larger = plen > slen;
+	const int dpsize = plen > slen ? plen : slen;
+	float *store = (float*)malloc((size_t)dpsize * 3 * sizeof(float));
+	float *dp0 = store, *dp1 = store + dpsize, *dp2 = store + dpsize * 2, *tmp;
+	for (int i = 0; i < dpsize * 3; i++) store[i] = 1e10;
+	int center_row = 0;
+	{
+		int off = plen / 2, i = (0 + plen / 2) - off, j = (center_row - plen / 2) + off;
+		if (j >= 0 && j < (int)b_length && i >= 0 && i < (int)a_length) {
+			if (primary_larger) dp2[off] = DTW_DIST(a[i], b[j]); else dp2[off + 1] = DTW_DIST(a[i], b[j]);
+		}
+		tmp = dp0; dp0 = dp1; dp1 = dp2; dp2 = tmp;
+	}
+	int prev_inc = 0;
+	for (int it = 1; (uint32_t)it < a_length; it++) {
+		const int center_column = it;
+		int inc = 0;
+		if ((int64_t)(center_row + 1) * (int64_t)a_length <= (int64_t)b_length * (int64_t)center_column) { center_row++; inc = 1; }
+		if (inc) {
+			const int si = center_column + slen / 2 - 1, sj = center_row - slen / 2;
+			int o0 = 0; if (si - (int)a_length + 1 > o0) o0 = si - (int)a_length + 1; if (-sj > o0) o0 = -sj;
+			int o1 = slen; if (si + 1 < o1) o1 = si + 1; if ((int)b_length - sj < o1) o1 = (int)b_length - sj;
+			for (int off = o0; off < o1; off++) {
+				const int i = si - off, j = sj + off;
+				float top, topleft, left;
+				if (primary_larger) { top = dp1[off]; topleft = dp0[off]; left = dp1[off + 1]; }
+				else {
+					const int is_first = off == 0, is_last = off == slen - 1;
+					top = is_first ? 1e10f : dp1[off];
+					topleft = is_first && !prev_inc ? 1e10f : dp0[off];
+					left = is_last ? 1e10f : dp1[off + 1];
+				}
+				dp2[off] = fmin2(fmin2(top, left), topleft) + DTW_DIST(a[i], b[j]);
+			}
+			tmp = dp0; dp0 = dp1; dp1 = dp2; dp2 = tmp;
+		}
+		const int si = center_column + plen / 2, sj = center_row - plen / 2;
+		int o0 = 0; if (si - (int)a_length + 1 > o0) o0 = si - (int)a_length + 1; if (-sj > o0) o0 = -sj;
+		int o1 = plen; if (si + 1 < o1) o1 = si + 1; if ((int)b_length - sj < o1) o1 = (int)b_length - sj;
+		for (int off = o0; off < o1; off++) {
+			const int i = si - off, j = sj + off;
+			float top, topleft, left;
+			const int is_first = off == 0, is_last = off == plen - 1;
+			if (primary_larger) {
+				if (inc) { top = is_first ? 1e10f : dp1[off - 1]; topleft = dp0[off]; left = is_last ? 1e10f : dp1[off]; }
+				else { top = is_first ? 1e10f : dp1[off - 1]; topleft = is_first ? 1e10f : dp0[off - 1]; left = dp1[off]; }
+				dp2[off] = fmin2(fmin2(top, left), topleft) + DTW_DIST(a[i], b[j]);
+			} else {
+				if (inc) { top = dp1[off]; topleft = dp0[off + 1]; left = dp1[off + 1]; }
+				else { top = is_first ? 1e10f : dp1[off]; topleft = is_first && !prev_inc ? 1e10f : dp0[off]; left = dp1[off + 1]; }
+				dp2[off + 1] = fmin2(fmin2(top, left), topleft) + DTW_DIST(a[i], b[j]);
+			}
+		}
+		tmp = dp0; dp0 = dp1; dp1 = dp2; dp2 = tmp;
+		prev_inc = inc;
+	}
+	float res = primary_larger ? dp1[plen / 2] : dp1[plen / 2 + 1];
+	if (exclude_last) res -= DTW_DIST(a[a_length - 1], b[b_length - 1]);
+	free(store);
+	return res;
+}
+
+/* align_chain rmap.cpp:128-208 */
+static void align_chain(reg_t *c, const a128 *anchors, const ro_index *ix, const float *read_events, const rh_mapopt_t *mo, float min_score)
+{
+	const float *ref = c->rev ? ix->R[c->rid] : ix->F[c->rid];
+	float dtw_cost = 0.0f;
+	uint32_t n_aligned = 0;
+	if (mo->dtw_border_constraint == RH_DTW_BORDER_GLOBAL) {
+		const float *revents = ref + c->rs; const uint32_t rlen = (uint32_t)(c->re - c->rs + 1);
+		const float *qevents = read_events + c->qs; const uint32_t qlen = (uint32_t)(c->qe - c->qs + 1);
+		float max_attainable = qlen * mo->dtw_match_bonus;
+		if (max_attainable < min_score) { c->alignment_score = -1e10; return; }
+		if (mo->dtw_fill_method == RH_DTW_FILL_FULL) dtw_cost = dtw_global(qevents, qlen, revents, rlen, 0);
+		else { int band = (int)(qlen * mo->dtw_band_radius_frac); if (band < 1) band = 1; dtw_cost = dtw_banded(qevents, qlen, revents, rlen, band, 0); }
+		n_aligned = qlen;
+	} else {
+		const uint32_t parts = (uint32_t)c->cnt - 1;
+		const uint32_t qfull = (uint32_t)(c->qe - c->qs + 1);
+		float cur_max = qfull * mo->dtw_match_bonus;
+		for (uint32_t part = 0; part < parts; part++) {
+			const a128 *sa = &anchors[part], *ea = &anchors[part + 1];
+			const float *revents = ref + (uint32_t)sa->x; const uint32_t rlen = (uint32_t)ea->x - (uint32_t)sa->x + 1;
+			const float *qevents = read_events + (uint32_t)sa->y; const uint32_t qlen = (uint32_t)ea->y - (uint32_t)sa->y + 1;
+			if (cur_max < min_score) { c->alignment_score = -1e10; return; }
+			const int excl = part != parts - 1;
+			float sub;
+			if (mo->dtw_fill_method == RH_DTW_FILL_FULL) sub = dtw_global(qevents, qlen, revents, rlen, excl);
+			else { int band = (int)(qlen * mo->dtw_band_radius_frac); if (band < 1) band = 1; sub = dtw_banded(qevents, qlen, revents, rlen, band, excl); }
+			dtw_cost += sub;
+			cur_max -= sub;
+			n_aligned += qlen;
+		}
+	}
+	c->alignment_score = n_aligned * mo->dtw_match_bonus - dtw_cost;
 }
 
 /* ================================================================== a2/a3: per-read driver (rmap.cpp:210-387, :389-599) */
@@ -1203,6 +1344,7 @@ typedef struct {
 	a128 *prev; int64_t n_prev;
 	reg_t *creg; int n_cregs;
 	double mean_sum, std_dev_sum; uint32_t n_sum;
+	float *events;            /* RH_M_DTW_EVALUATE_CHAINS: the events of every processed chunk (reg->events, rmap.cpp:237-241) */
 } rstate_t;
 
 static uint64_t g_cnt[8];
@@ -1216,6 +1358,10 @@ static void map_chunk(const ro_index *ix, const rh_mapopt_t *mo, const rh_idxopt
 	                             &st->mean_sum, &st->std_dev_sum, &st->n_sum, &n_events);
 	cnt[0]++; cnt[1] += s_len; cnt[2] += n_events;
 	if (n_events < mo->min_events) { free(ev); return; }
+	if (mo->flag & RH_M_DTW_EVALUATE_CHAINS) {
+		st->events = (float*)realloc(st->events, ((size_t)st->offset + n_events) * sizeof(float));
+		memcpy(st->events + st->offset, ev, n_events * sizeof(float));
+	}
 	uint64_t cap = (uint64_t)n_events * 2 + 16;
 	a128 *sd = (a128*)malloc(cap * sizeof(a128));
 	uint64_t n_sd = ro_sketch(ev, n_events, 0, 0, ip, sd, cap);
@@ -1246,7 +1392,16 @@ static void map_chunk(const ro_index *ix, const rh_mapopt_t *mo, const rh_idxopt
 	st->creg = gen_regs(hash, n_u, u, a);
 	set_parent(mo->mask_level, mo->mask_len, st->n_cregs, st->creg, (mo->flag & RH_M_HARD_MLEVEL) ? 1 : 0);
 	if (!(mo->flag & RH_M_ALL_CHAINS)) select_sub(mo->pri_ratio, mo->best_n, 1, mo->max_target_gap_length * 0.8, &st->n_cregs, st->creg);
-	set_mapq(st->n_cregs, st->creg, mo->min_chaining_score, rep_len);
+	if (mo->flag & RH_M_DTW_EVALUATE_CHAINS) {	/* rmap.cpp:355-374 */
+		float best_found = 0.0f;
+		for (int i = 0; i < st->n_cregs; ++i) {
+			reg_t *c = &st->creg[i];
+			align_chain(c, a + c->as, ix, st->events, mo, best_found);
+			if (c->alignment_score >= mo->dtw_min_score) { if (c->alignment_score > best_found) best_found = c->alignment_score; }
+			else if (c->alignment_score < mo->dtw_min_score && c->alignment_score < 0) c->alignment_score = (mo->dtw_min_score > 0) ? 0 : mo->dtw_min_score;
+		}
+	}
+	set_mapq(st->n_cregs, st->creg, mo->min_chaining_score, rep_len, (mo->flag & RH_M_DTW_EVALUATE_CHAINS) ? 1 : 0);
 	free(a); free(u);
 	st->offset += n_events;
 }
@@ -1268,14 +1423,29 @@ static uint32_t map_read(const ro_index *ix, const rh_mapopt_t *mo, const rh_idx
 		free(st.creg); st.creg = 0; st.n_cregs = 0;
 		map_chunk(ix, mo, ip, sig + s_qs, s_qe - s_qs, &st, qname, name_rank, cnt);
 		int n_chains = ((mo->flag & RH_M_ALL_CHAINS) || st.n_cregs < 1) ? st.n_cregs : 1;
-		if (st.n_cregs == 1 && (int)st.creg[0].mapq >= mo->min_mapq) { c_ids[n_maps++] = 0; break; }
+		const int dtw = (mo->flag & RH_M_DTW_EVALUATE_CHAINS) != 0;
+		if (st.n_cregs == 1 && ((int)st.creg[0].mapq >= mo->min_mapq || (dtw && st.creg[0].alignment_score >= mo->dtw_min_score))) { c_ids[n_maps++] = 0; break; }
 		float meanC = 0, meanQ = 0;
 		for (int c = 0; c < st.n_cregs; ++c) { meanC += st.creg[c].score; meanQ += st.creg[c].mapq; }
 		if (st.n_cregs > 0) { meanC /= st.n_cregs; meanQ /= st.n_cregs; }
 		for (int ic = 0; ic < n_chains; ++ic) {
 			float r_bestmq = 0.0f, r_bestmc = 0.0f, r_bestq = 0.0f, weighted = 0.0f;
 			float bestQ = st.creg[ic].mapq, bestC = st.creg[ic].score;
-			if (!(mo->flag & RH_M_ALL_CHAINS)) {
+			if (!(mo->flag & RH_M_ALL_CHAINS) && dtw) {	/* rmap.cpp:458-478 */
+				float bestA = st.creg[ic].alignment_score, r_bestma;
+				if (n_chains == 1) {
+					int best_ind = 0;
+					for (int i = 1; i < st.n_cregs; ++i) if (st.creg[i].alignment_score > bestA) { bestA = st.creg[i].alignment_score; best_ind = i; }
+					ic = best_ind;
+					bestQ = st.creg[ic].mapq; bestC = st.creg[ic].score;
+				}
+				if (bestA >= mo->dtw_min_score) {
+					r_bestma = (bestA > 0) ? (bestA / 50.0f) : 0.0f; if (r_bestma < 0) r_bestma = 0.0f;
+					r_bestmq = (bestQ > 0) ? (1.0f - (meanQ / bestQ)) : 0.0f; if (r_bestmq < 0) r_bestmq = 0.0f;
+					r_bestmc = (bestC > 0) ? (1.0f - (meanC / bestC)) : 0.0f; if (r_bestmc < 0) r_bestmc = 0.0f;
+					weighted = mo->w_bestma * r_bestma + mo->w_bestmq * r_bestmq + mo->w_bestmc * r_bestmc;
+				}
+			} else if (!(mo->flag & RH_M_ALL_CHAINS)) {
 				r_bestq = (bestQ > 0) ? (bestQ / 30.0f) : 0.0f; if (r_bestq > 1) r_bestq = 1.0f;
 				r_bestmq = (bestQ > 0) ? (1.0f - (meanQ / bestQ)) : 0.0f; if (r_bestmq < 0) r_bestmq = 0.0f;
 				r_bestmc = (bestC > 0) ? (1.0f - (meanC / bestC)) : 0.0f; if (r_bestmc < 0) r_bestmc = 0.0f;
@@ -1316,7 +1486,7 @@ static uint32_t map_read(const ro_index *ix, const rh_mapopt_t *mo, const rh_idx
 		}
 		n_rec = n_maps;
 	}
-	free(st.prev); free(st.creg); free(c_ids);
+	free(st.prev); free(st.creg); free(c_ids); free(st.events);
 	return n_rec;
 }
 
@@ -1499,7 +1669,7 @@ int ro_regions_batch(const rh_mapopt_t *mo, uint32_t n_reads, const a128 *chaine
 		reg_t *g = gen_regs(hash, n_u, u + u_offsets[r], chained + chained_offsets[r]);
 		set_parent(mo->mask_level, mo->mask_len, n, g, (mo->flag & RH_M_HARD_MLEVEL) ? 1 : 0);
 		if (!(mo->flag & RH_M_ALL_CHAINS)) select_sub(mo->pri_ratio, mo->best_n, 1, mo->max_target_gap_length * 0.8, &n, g);
-		set_mapq(n, g, mo->min_chaining_score, rep_len[r]);
+		set_mapq(n, g, mo->min_chaining_score, rep_len[r], 0);
 		if (k + (uint64_t)n > regs_cap) { free(g); return -1; }
 		for (int i = 0; i < n; ++i) {
 			const reg_t *q = &g[i];

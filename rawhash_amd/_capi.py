@@ -43,6 +43,8 @@ class MapOpt(C.Structure):
         ("window_length1", C.c_uint32), ("window_length2", C.c_uint32),
         ("threshold1", C.c_float), ("threshold2", C.c_float), ("peak_height", C.c_float),
         ("rmq_inner_dist", C.c_int32), ("rmq_size_cap", C.c_int32),
+        ("dtw_border_constraint", C.c_uint32), ("dtw_fill_method", C.c_uint32),
+        ("dtw_band_radius_frac", C.c_float), ("dtw_match_bonus", C.c_float), ("dtw_min_score", C.c_float), ("w_bestma", C.c_float),
     ]
 
 

@@ -232,6 +232,17 @@ bool write_ind(const rh_index_s &ix, const char *path)
 		fwrite(&l, 1, 1, fp);
 		fwrite(ix.names[i].data(), 1, l, fp);
 		fwrite(&ix.lens[i], 4, 1, fp);
+		if (ix.flag & RH_I_STORE_SIG) {	// rindex.c:590-598
+			const std::vector<float> empty;
+			const std::vector<float> &F = i < ix.sigF.size() ? ix.sigF[i] : empty;
+			const uint32_t fl = (uint32_t)F.size();
+			fwrite(&fl, 4, 1, fp); fwrite(F.data(), 4, fl, fp);
+			if (!(ix.flag & RH_I_NO_REV_TARGET)) {
+				const std::vector<float> &R = i < ix.sigR.size() ? ix.sigR[i] : empty;
+				const uint32_t rl = (uint32_t)R.size();
+				fwrite(&rl, 4, 1, fp); fwrite(R.data(), 4, rl, fp);
+			}
+		}
 	}
 	// regroup the hash-sorted keys by their low 14 bits (stable: hash order is kept inside a bucket)
 	const uint32_t nb = 1u << kBucketBits, bmask = nb - 1;
@@ -312,10 +323,16 @@ static rh_index *index_load(const char *path)
 		if (l && !rd(fp, &name[0], 1, l)) return fail("truncated sequence table");
 		if (!rd(fp, &len, 4, 1)) return fail("truncated sequence table");
 		ix->names.push_back(name); ix->lens.push_back(len);
-		if (ix->flag & RH_I_STORE_SIG) {   // stored target signals are not used by this path: skip
+		if (ix->flag & RH_I_STORE_SIG) {   // stored target signals (rindex.c:716-726): what DTW re-scoring aligns with
 			uint32_t fl;
-			if (!rd(fp, &fl, 4, 1) || (uint64_t)fl * 4 > remaining() || fseek(fp, (long)((uint64_t)fl * 4), SEEK_CUR)) return fail("truncated stored signal");
-			if (!(ix->flag & RH_I_NO_REV_TARGET)) { if (!rd(fp, &fl, 4, 1) || (uint64_t)fl * 4 > remaining() || fseek(fp, (long)((uint64_t)fl * 4), SEEK_CUR)) return fail("truncated stored signal"); }
+			if (!rd(fp, &fl, 4, 1) || (uint64_t)fl * 4 > remaining()) return fail("truncated stored signal");
+			ix->sigF.emplace_back(fl);
+			if (fl && !rd(fp, ix->sigF.back().data(), 4, fl)) return fail("truncated stored signal");
+			if (!(ix->flag & RH_I_NO_REV_TARGET)) {
+				if (!rd(fp, &fl, 4, 1) || (uint64_t)fl * 4 > remaining()) return fail("truncated stored signal");
+				ix->sigR.emplace_back(fl);
+				if (fl && !rd(fp, ix->sigR.back().data(), 4, fl)) return fail("truncated stored signal");
+			}
 		}
 	}
 	std::vector<Entry> ent;
@@ -364,6 +381,7 @@ extern "C" rh_index *rh_index_build(const char *fasta_path, const char *pore_mod
 	const int n_strands = (io->flag & RH_I_NO_REV_TARGET) ? 1 : 2;
 	const size_t n_tasks = seqs.size() * n_strands;
 	std::vector<std::vector<HostSeed>> part(n_tasks);
+	if (io->flag & RH_I_STORE_SIG) { ix->sigF.resize(seqs.size()); if (n_strands == 2) ix->sigR.resize(seqs.size()); }
 	std::vector<std::thread> th;
 	for (int t = 0; t < n_threads; ++t)
 		th.emplace_back([&, t]() {
@@ -371,6 +389,7 @@ extern "C" rh_index *rh_index_build(const char *fasta_path, const char *pore_mod
 			for (size_t task = t; task < n_tasks; task += n_threads) {
 				const size_t si = task / n_strands; const int strand = (int)(task % n_strands);
 				seq_to_levels(seqs[si], ix->pore_vals, io->k, strand, lv);
+				if (io->flag & RH_I_STORE_SIG) (strand ? ix->sigR : ix->sigF)[si] = lv;   // --store-sig (rindex.c:133-160)
 				if (lv.empty()) continue;
 				SeedSink sink{&part[task]};
 				{ rh_sketch_store_local<256> st; rh_sketch_events<256>(lv.data(), (uint32_t)lv.size(), (uint32_t)si, strand, sp, sink, st); }

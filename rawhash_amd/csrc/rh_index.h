@@ -22,6 +22,9 @@ struct rh_index_s {
 	// per-key occupancy histogram (occ_hist[n] = keys with n occurrences, last bin = that many or more; mid_occ calibration)
 	// and the totals, until rh_index_download fetches the keys
 	std::vector<uint32_t> occ_hist;
+	// RH_I_STORE_SIG (--store-sig): the expected signal of every target, one level per k-mer (ri_seq_to_sig rsig.c:13), forward and -
+	// unless RH_I_NO_REV_TARGET - reverse strand; what DTW re-scoring (--dtw-evaluate-chains) aligns the read's events with
+	std::vector<std::vector<float>> sigF, sigR;
 	uint64_t dev_n_keys = 0, dev_n_pos = 0;
 };
 bool rh_load_model(const char *path, int k, int lev_col, std::vector<float> &vals);

@@ -27,6 +27,8 @@ extern "C" void rh_mapopt_init(rh_mapopt_t *mo)
 	mo->min_chaining_score = 15; mo->min_chaining_score2 = 0;
 	mo->chain_gap_scale = 0.8f; mo->chain_skip_scale = 0.0f;
 	mo->rmq_inner_dist = 1000; mo->rmq_size_cap = 100000;
+	mo->dtw_border_constraint = RH_DTW_BORDER_SPARSE; mo->dtw_fill_method = RH_DTW_FILL_BANDED;
+	mo->dtw_band_radius_frac = 0.10f; mo->dtw_match_bonus = 0.4f; mo->dtw_min_score = 20.0f; mo->w_bestma = 0.2f;
 	// regions
 	mo->mask_level = 0.5f; mo->mask_len = INT_MAX; mo->pri_ratio = 0.3f; mo->best_n = 0; mo->alt_drop = 0.15f;
 	// decision

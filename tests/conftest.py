@@ -46,7 +46,7 @@ class Workload:
     """Synthetic reference + index + reads, generated from seeds by the product library's host code."""
 
     def __init__(self, directory, lib, preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=12_000, n_reads=48,
-                 junk=150, noise=150_000, read_seed=3, index_lib=None, build_index=True, no_adaptive=False, fast5=False, mapopt=None):
+                 junk=150, noise=150_000, read_seed=3, index_lib=None, build_index=True, no_adaptive=False, fast5=False, mapopt=None, idxflag=0):
         from rawhash_amd.api import SynthWorkload, MapOptions, Index
         self.dir, self.preset = str(directory), preset
         self.wl = SynthWorkload(chrom_len=chrom_len, n_chrom=n_chrom, n_samples=n_samples, junk_per_1024=junk, noise_q24=noise,
@@ -58,6 +58,7 @@ class Workload:
         if no_adaptive:
             self.opts.mo.flag |= 0x20           # RH_M_NO_ADAPTIVE: one round over the whole read
         self._apply_mapopt(self.opts.mo)
+        self.opts.io.flag |= idxflag            # e.g. 0x10 = RH_I_STORE_SIG (--store-sig: DTW re-scoring needs the target signals)
         self.ind = os.path.join(self.dir, f"ref_{preset}.ind")
         self.index = None
         if build_index:     # (large references: the caller builds the index on the device instead)

@@ -37,6 +37,11 @@ CASES = [
     {"name": "small_fast_rmq_no_inner", "env": {"RH_RMQ": "1", "RH_RMQ_INNER_DIST": "0"}, "workload": dict(preset="fast", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=96, junk=150, noise=150_000, read_seed=32, mapopt={"flag": 2, "rmq_inner_dist": 0})},
     {"name": "small_sensitive_rmq_cap", "env": {"RH_RMQ": "1", "RH_RMQ_SIZE_CAP": "40", "RH_RMQ_INNER_DIST": "300"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=96, junk=150, noise=150_000, read_seed=33, mapopt={"flag": 2, "rmq_size_cap": 40, "rmq_inner_dist": 300})},
     {"name": "small_sensitive_bw_long", "env": {"RH_BW_LONG": "2000"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=120, junk=150, noise=150_000, read_seed=34, mapopt={"bw_long": 2000})},
+    # f4: DTW re-scoring of chains (--dtw-evaluate-chains on a --store-sig index, rmap.cpp:128-208, dtw.cpp): the defaults (alignment between
+    # consecutive anchors, slanted band), the whole chain at once (global border), full matrices instead of bands
+    {"name": "small_sensitive_dtw", "env": {"RH_STORE_SIG": "1", "RH_DTW": "1"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=120, junk=150, noise=150_000, read_seed=41, idxflag=0x10, mapopt={"flag": 0x40})},
+    {"name": "small_fast_dtw_global", "env": {"RH_STORE_SIG": "1", "RH_DTW": "1", "RH_DTW_BORDER": "0"}, "workload": dict(preset="fast", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=96, junk=150, noise=150_000, read_seed=42, idxflag=0x10, mapopt={"flag": 0x40, "dtw_border_constraint": 0})},
+    {"name": "small_sensitive_dtw_full", "env": {"RH_STORE_SIG": "1", "RH_DTW": "1", "RH_DTW_FILL": "0", "RH_DTW_MIN_SCORE": "5"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=96, junk=150, noise=150_000, read_seed=43, idxflag=0x10, mapopt={"flag": 0x40, "dtw_fill_method": 0, "dtw_min_score": 5.0})},
     {"name": "config3_dmel_144M_384", "gpu_only": True, "workload": dict(preset="sensitive", chrom_len=24_000_000, n_chrom=6, n_samples=40_000, n_reads=384, junk=102, noise=0, read_seed=3)},
 ]
 
@@ -79,8 +84,8 @@ def main():
             w.reads.write(rhr, cfg.digitisation, cfg.range, cfg.offset)
             preset = case["workload"]["preset"]
             ref_ind = os.path.join(d, "refbuilt.ind")
-            subprocess.run([O.REF_HARNESS, "index", preset, w.fasta, w.model, ref_ind, "4"], check=True, stderr=subprocess.DEVNULL)
             env = dict(os.environ, **case.get("env", {}))
+            subprocess.run([O.REF_HARNESS, "index", preset, w.fasta, w.model, ref_ind, "4"], check=True, stderr=subprocess.DEVNULL, env=env)
             if case.get("no_adaptive"):
                 env["RH_NO_ADAPTIVE"] = "1"
             out = subprocess.run([O.REF_HARNESS, "map", preset, ref_ind, rhr, "1"], check=True, capture_output=True, text=True, env=env).stdout

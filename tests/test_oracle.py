@@ -173,8 +173,9 @@ def test_oracle_vs_reference_stage_dumps(make_workload, tmp_path):
 
 
 @needs_ref
-@pytest.mark.parametrize("preset,chrom,nch", [("sensitive", 500_000, 2), ("fast", 300_000, 3), ("faster", 200_000, 1), ("viral", 50_000, 1)])
-def test_ind_file_is_byte_identical_to_the_reference(product_lib, tmp_path, preset, chrom, nch):
+@pytest.mark.parametrize("preset,chrom,nch,store_sig", [("sensitive", 500_000, 2, False), ("fast", 300_000, 3, False), ("faster", 200_000, 1, False), ("viral", 50_000, 1, False),
+                                                        ("sensitive", 200_000, 2, True)])
+def test_ind_file_is_byte_identical_to_the_reference(product_lib, tmp_path, preset, chrom, nch, store_sig):
     """rh_index_build + rh_index_write = `rawhash2 -d` byte for byte (keys in khash slot order, positions as worker_post leaves
     them), except the 16 bytes at offset 46 where the reference dumps two heap pointers of its ri_pore_t."""
     import subprocess
@@ -182,9 +183,13 @@ def test_ind_file_is_byte_identical_to_the_reference(product_lib, tmp_path, pres
     wl = SynthWorkload(chrom_len=chrom, n_chrom=nch, n_samples=8000, lib=product_lib)
     fasta, model = wl.write_reference(str(tmp_path))
     opts = MapOptions(preset, lib=product_lib)
+    env = dict(os.environ)
+    if store_sig:                       # --store-sig: the targets' expected signals (forward, reverse) follow each name (rindex.c:590-598)
+        opts.io.flag |= 0x10
+        env["RH_STORE_SIG"] = "1"
     mine, ref = str(tmp_path / "mine.ind"), str(tmp_path / "ref.ind")
     Index.build(fasta, model, opts, out_ind=mine, n_threads=4, lib=product_lib)
-    subprocess.run([O.REF_HARNESS, "index", preset, fasta, model, ref, "3"], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([O.REF_HARNESS, "index", preset, fasta, model, ref, "3"], check=True, stderr=subprocess.DEVNULL, env=env)
     a, b = bytearray(open(mine, "rb").read()), bytearray(open(ref, "rb").read())
     a[46:62] = b[46:62] = b"\0" * 16
     assert len(a) == len(b) and a == b
