@@ -81,6 +81,7 @@ struct rh_ctx_s {
 	DevBuf zbuf, t1buf, t2buf, n_norm, peaks, n_peaks;
 	DevBuf ev, n_ev, skip, sx, sy, n_seed, m_val, m_n, m_meta, m_pref, n_match, n_new, rep_len, a_off;
 	DevBuf anc, raw_anc, zs, n_z, need_exact, need_exact2, prev_stage, u, n_u, n_v, ws, counters, rec;
+	DevBuf events, dtw_ws, dtw_n, dtw_off, dtw_rec, dtw_dec;       // RH_M_DTW_EVALUATE_CHAINS: reads' events, DP buffers, per-region values for the host's MAPQ, its decisions
 	DevBuf name_rank, t_rank, rec_off;                            // all-vs-all: name ranks of the reads / of the targets, record offsets
 	uint64_t arena_room = 0;                                       // anchors the per-anchor arenas were sized for when a round was last cut into slices (the budget sticks to it)
 	uint32_t ev_row = RH_CHUNK_MAX + 64, ev_cap = RH_EV_CAP, whole = 0;   // strides of the per-read rows of the current batch (whole-read rounds: sized by its longest read)
@@ -141,7 +142,11 @@ int fill_dev_opt(const rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
 	if ((mo->flag & RH_M_ALL_CHAINS) && !(mo->flag & RH_M_NO_ADAPTIVE)) { rh_set_error("all-chains output is built for whole-read rounds only (RH_M_ALL_CHAINS needs RH_M_NO_ADAPTIVE, as in the ava presets)"); return -1; }
 	if ((mo->flag & RH_M_NO_ADAPTIVE) && (mo->window_length1 > 15 || mo->window_length2 > 15)) { rh_set_error("whole-read rounds need segmentation windows <= 15"); return -1; }
 	if ((mo->flag & RH_M_ALL_CHAINS) && c->have_index && !c->dix.t_rank) { rh_set_error("all-vs-all mapping needs the name ranks of the targets (rh_index_set_target_ranks)"); return -1; }
-	if (mo->flag & RH_M_DTW_EVALUATE_CHAINS) { rh_set_error("DTW re-scoring of chains (--dtw-evaluate-chains) is not built on this path"); return -1; }
+	if (mo->flag & RH_M_DTW_EVALUATE_CHAINS) {
+		if (mo->flag & RH_M_ALL_CHAINS) { rh_set_error("DTW re-scoring with all-chains output is not supported on the device"); return -1; }
+		if (c->have_index && !c->dix.sig) { rh_set_error("DTW re-scoring needs the targets' signals: build the index with RH_I_STORE_SIG (--store-sig) and upload it (rh_index_upload)"); return -1; }
+		if (mo->dtw_border_constraint > 1u || mo->dtw_fill_method > 1u) { rh_set_error("DTW border constraint %u / fill method %u not supported (global | sparse, full | banded)", mo->dtw_border_constraint, mo->dtw_fill_method); return -1; }
+	}
 	if (mo->min_num_anchors < 2) { rh_set_error("min_num_anchors < 2 is not supported on the device (the per-anchor scratch assumes chains of at least two anchors)"); return -1; }
 	if (mo->window_length1 > 64 || mo->window_length2 > 64) { rh_set_error("segmentation windows > 64 not supported"); return -1; }
 	memset(o, 0, sizeof(*o));
@@ -152,6 +157,7 @@ int fill_dev_opt(const rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
 	o->max_dist_t = mo->max_target_gap_length; o->max_dist_q = mo->max_query_gap_length; o->bw = mo->bw;
 	o->max_skip = mo->max_num_skips; o->max_iter = mo->max_chain_iter; o->min_cnt = mo->min_num_anchors;
 	o->bw_long = mo->bw_long; o->rmq_inner_dist = mo->rmq_inner_dist; o->rmq_size_cap = mo->rmq_size_cap;
+	o->dtw_border = mo->dtw_border_constraint; o->dtw_fill = mo->dtw_fill_method; o->dtw_band_frac = mo->dtw_band_radius_frac; o->dtw_match_bonus = mo->dtw_match_bonus; o->dtw_min_score = mo->dtw_min_score;
 	o->min_sc = mo->min_chaining_score; o->min_sc2 = mo->min_chaining_score2;
 	if (c->have_index) {	// rmap.cpp:318: computed in double, narrowed to float
 		const int span = c->dix.sp.e + c->dix.sp.k - 1;
@@ -163,6 +169,90 @@ int fill_dev_opt(const rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
 	o->min_strand_sc = (int32_t)(mo->max_target_gap_length * 0.8);   // rmap.cpp:354
 	o->w_bestq = mo->w_bestq; o->w_bestmq = mo->w_bestmq; o->w_bestmc = mo->w_bestmc; o->w_threshold = mo->w_threshold;
 	o->min_mapq = mo->min_mapq; o->sample_per_base = mo->sample_per_base; o->flag = mo->flag;
+	return 0;
+}
+
+// RH_M_DTW_EVALUATE_CHAINS, the region stage of a slice of n active reads: regions + alignment scores on the device (k_regions_dtw), then
+// mm_set_mapq's DTW branch (hit.c:502-539: logf of the fractional alignment score - the host's libm, like the reference) and the mapping
+// decision of rmap.cpp:423-500 on the host, and the verdict committed on the device.
+static int dtw_regions_stage(rh_ctx *c, hipStream_t s, const rh_dev_opt &o, const rh_mapopt_t *mo, const rh_dev_reads &rd, rh_dev_round rs, uint32_t n, uint32_t chunk)
+{
+	const uint64_t ev_now = (uint64_t)(chunk + 1) * rs.ev_cap < rd.ev_stride ? (uint64_t)(chunk + 1) * rs.ev_cap : rd.ev_stride;
+	rs.dtw_stride = (uint32_t)(4 * ev_now + 64);                    // full matrix: one row of the read's events; bands: 3 x (2 x band + 3) with band <= frac x events
+	if (c->dtw_n.ensure((size_t)n * 4) || c->dtw_ws.ensure((size_t)n * rs.dtw_stride * 4) || c->dtw_off.ensure((size_t)(n + 1) * 8) || c->dtw_dec.ensure((size_t)n * 12)) return -1;
+	rs.dtw_n = c->dtw_n.as<uint32_t>(); rs.dtw_ws = c->dtw_ws.as<float>();
+	rhk_regions_dtw(s, o, c->dix, rd, rs);
+	std::vector<uint32_t> nreg(n);
+	std::vector<int32_t> rep(n);
+	RH_HIP(hipMemcpyAsync(nreg.data(), rs.dtw_n, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+	RH_HIP(hipMemcpyAsync(rep.data(), rs.rep_len, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+	RH_HIP(hipStreamSynchronize(s));
+	std::vector<uint64_t> off((size_t)n + 1, 0);
+	for (uint32_t a = 0; a < n; ++a) {
+		if (nreg[a] & 0x80000000u) { rh_set_error("DTW re-scoring: a band / matrix row does not fit the per-read DP buffer (dtw_band_radius_frac %.2f too large for this device path)", (double)mo->dtw_band_radius_frac); return -1; }
+		off[a + 1] = off[a] + nreg[a];
+	}
+	const uint64_t T = off[n];
+	std::vector<int32_t> recs((size_t)(T ? T : 1) * 8);
+	if (T) {
+		if (c->dtw_rec.ensure((size_t)T * 32)) return -1;
+		RH_HIP(hipMemcpyAsync(c->dtw_off.p, off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s));
+		rs.dtw_off = c->dtw_off.as<uint64_t>(); rs.dtw_rec = c->dtw_rec.as<float>();
+		rhk_dtw_pack(s, rs);
+		RH_HIP(hipMemcpyAsync(recs.data(), c->dtw_rec.p, (size_t)T * 32, hipMemcpyDeviceToHost, s));
+		RH_HIP(hipStreamSynchronize(s));
+	}
+	std::vector<int32_t> dec((size_t)n * 3, 0);
+	std::vector<int32_t> mq;
+	for (uint32_t a = 0; a < n; ++a) {
+		const int32_t nr = (int32_t)nreg[a];
+		if (!nr) continue;
+		const int32_t *R8 = recs.data() + off[a] * 8;                  // per region: score, cnt, subsc, score0, n_sub, is-primary, alignment score (float bits)
+		auto ascore = [&](int32_t i) { float f; memcpy(&f, &R8[(size_t)i * 8 + 6], 4); return f; };
+		// mm_set_mapq, is_dtw = 1 (hit.c:502-539)
+		int64_t sum_sc = 0;
+		for (int32_t i = 0; i < nr; ++i) if (R8[(size_t)i * 8 + 5]) sum_sc += R8[(size_t)i * 8];
+		const float uniq_ratio = (float)sum_sc / (sum_sc + rep[a]);
+		mq.assign((size_t)nr, 0);
+		for (int32_t i = 0; i < nr; ++i) {
+			const int32_t score = R8[(size_t)i * 8], cnt = R8[(size_t)i * 8 + 1], subsc0 = R8[(size_t)i * 8 + 2], score0 = R8[(size_t)i * 8 + 3], n_sub = R8[(size_t)i * 8 + 4];
+			int mapq = 0;
+			float pen_s1 = (score > 100 ? 1.0f : 0.01 * score) * uniq_ratio;
+			float pen_cm = cnt > 10 ? 1.0f : 0.1f * cnt;
+			pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
+			const int subsc = subsc0 > mo->min_chaining_score ? subsc0 : mo->min_chaining_score;
+			float x = (float)subsc / score0;
+			if (ascore(i) > 0) mapq = (int)(pen_cm * 40.0f * (1.0f - x) * 2 * logf(ascore(i)));
+			mapq -= (int)(4.343f * logf(n_sub + 1) + .499f);
+			mapq = mapq > 0 ? mapq : 0;
+			mq[i] = mapq < 60 ? mapq : 60;
+		}
+		// the decision (rmap.cpp:423-500, one chain reported: no all-chains mode here)
+		int sel = 0, stop = 0;
+		if (nr == 1 && (mq[0] >= mo->min_mapq || ascore(0) >= mo->dtw_min_score)) stop = 1;
+		else {
+			float meanC = 0, meanQ = 0;
+			for (int32_t i = 0; i < nr; ++i) { meanC += R8[(size_t)i * 8]; meanQ += mq[i]; }
+			meanC /= nr; meanQ /= nr;
+			float bestA = ascore(0);
+			int best = 0;
+			for (int32_t i = 1; i < nr; ++i) if (ascore(i) > bestA) { bestA = ascore(i); best = i; }
+			const float bestQ = mq[best], bestC = R8[(size_t)best * 8];
+			float weighted = 0.0f;
+			if (bestA >= mo->dtw_min_score) {
+				float r_bestma = (bestA > 0) ? (bestA / 50.0f) : 0.0f; if (r_bestma < 0) r_bestma = 0.0f;
+				float r_bestmq = (bestQ > 0) ? (1.0f - (meanQ / bestQ)) : 0.0f; if (r_bestmq < 0) r_bestmq = 0.0f;
+				float r_bestmc = (bestC > 0) ? (1.0f - (meanC / bestC)) : 0.0f; if (r_bestmc < 0) r_bestmc = 0.0f;
+				weighted = mo->w_bestma * r_bestma + mo->w_bestmq * r_bestmq + mo->w_bestmc * r_bestmc;
+			}
+			if (weighted >= mo->w_threshold) { stop = 1; sel = best; }
+		}
+		dec[(size_t)a * 3] = sel; dec[(size_t)a * 3 + 1] = mq[sel]; dec[(size_t)a * 3 + 2] = stop;
+	}
+	RH_HIP(hipMemcpyAsync(c->dtw_dec.p, dec.data(), (size_t)n * 12, hipMemcpyHostToDevice, s));
+	rs.dtw_dec = c->dtw_dec.as<int32_t>();
+	rhk_dtw_commit(s, o, rd, rs);
+	RH_HIP(hipStreamSynchronize(s));                                  // (dec is a stack vector)
 	return 0;
 }
 
@@ -324,7 +414,8 @@ void release_arenas(rh_ctx *c)
 	(void)hipStreamSynchronize(c->stream);
 	DevBuf *all[] = {&c->raw, &c->off, &c->cal_off, &c->cal_scale, &c->act[0], &c->act[1], &c->zbuf, &c->t1buf, &c->t2buf, &c->n_norm, &c->peaks, &c->n_peaks, &c->ev, &c->n_ev, &c->skip, &c->sx, &c->sy,
 	                 &c->n_seed, &c->m_val, &c->m_n, &c->m_meta, &c->m_pref, &c->n_match, &c->n_new, &c->rep_len, &c->a_off, &c->anc, &c->raw_anc, &c->zs, &c->n_z, &c->need_exact, &c->need_exact2, &c->prev_stage,
-	                 &c->carry[0], &c->carry[1], &c->carry_off, &c->a_off_slice, &c->u, &c->n_u, &c->n_v, &c->ws, &c->sort_ws, &c->rec};
+	                 &c->carry[0], &c->carry[1], &c->carry_off, &c->a_off_slice, &c->u, &c->n_u, &c->n_v, &c->ws, &c->sort_ws, &c->rec,
+	                 &c->events, &c->dtw_ws, &c->dtw_n, &c->dtw_off, &c->dtw_rec, &c->dtw_dec};
 	for (DevBuf *b : all) b->release();
 	for (DevBuf &b : c->st) b.release();
 	c->arena_room = 0;
@@ -383,7 +474,8 @@ extern "C" void rh_ctx_destroy(rh_ctx *c)
 	c->subs.clear();
 	DevBuf *all[] = {&c->logf_tab, &c->raw, &c->off, &c->cal_off, &c->cal_scale, &c->act[0], &c->act[1], &c->n_act_dev, &c->zbuf, &c->t1buf, &c->t2buf, &c->n_norm, &c->peaks, &c->n_peaks, &c->ev, &c->n_ev, &c->skip, &c->sx, &c->sy,
 	                 &c->n_seed, &c->m_val, &c->m_n, &c->m_meta, &c->m_pref, &c->n_match, &c->n_new, &c->rep_len, &c->a_off, &c->anc, &c->raw_anc, &c->zs, &c->n_z, &c->need_exact, &c->need_exact2, &c->prev_stage, &c->carry[0], &c->carry[1], &c->carry_off, &c->a_off_slice, &c->u,
-	                 &c->n_u, &c->n_v, &c->ws, &c->sort_ws, &c->counters, &c->rec, &c->sy_samples, &c->sy_off, &c->sy_cal_off, &c->sy_cal_scale, &c->sy_levels, &c->name_rank, &c->t_rank, &c->rec_off};
+	                 &c->n_u, &c->n_v, &c->ws, &c->sort_ws, &c->counters, &c->rec, &c->sy_samples, &c->sy_off, &c->sy_cal_off, &c->sy_cal_scale, &c->sy_levels, &c->name_rank, &c->t_rank, &c->rec_off,
+	                 &c->events, &c->dtw_ws, &c->dtw_n, &c->dtw_off, &c->dtw_rec, &c->dtw_dec};
 	for (DevBuf *b : all) b->release();
 	for (DevBuf &b : c->st) b.release();
 	if (c->blob_owned) c->blob.release();
@@ -411,6 +503,8 @@ int bind_blob(rh_ctx *c, const BlobHeader &h)
 	c->dix.seq_len = (const uint32_t*)(base + h.len_off);
 	c->dix.lg_buckets = h.lg_buckets; c->dix.n_seq = h.n_seq; c->dix.flag = h.flag; c->dix.sp = h.sp;
 	c->dix.t_rank = nullptr;                                        // (rh_index_set_target_ranks)
+	c->dix.sig_off = h.sig_off ? (const uint64_t*)(base + h.sig_off) : nullptr;
+	c->dix.sig = h.sig_off ? (const float*)(base + h.sig_off + ((uint64_t)2 * h.n_seq + 1) * 8) : nullptr;
 	// anchor keys fit 32 bits when strand + target id + position do (they do up to a few hundred Mbp in a few targets)
 	uint32_t lo = 0, mid = 0;
 	while (lo < 32 && (1ull << lo) <= (uint64_t)h.max_len) ++lo;
@@ -445,6 +539,17 @@ extern "C" int rh_index_upload(rh_ctx *c, const rh_index *ix)
 	h.n_pos = ix->pos.size();
 	h.len_off = h.pos_off + (h.n_pos ? h.n_pos : 1) * 8;
 	h.bytes = h.len_off + (ix->lens.size() ? ix->lens.size() : 1) * 4;
+	std::vector<uint64_t> so;
+	if ((ix->flag & RH_I_STORE_SIG) && !ix->sigF.empty()) {	// --store-sig: [u64 so[2 n + 1] | floats] behind the lengths (DTW re-scoring aligns with them)
+		h.bytes = (h.bytes + 7) & ~7ull;
+		h.sig_off = h.bytes;
+		so.assign(2 * ix->lens.size() + 1, 0);
+		for (size_t i = 0; i < ix->lens.size(); ++i) {
+			so[2 * i + 1] = so[2 * i] + (i < ix->sigF.size() ? ix->sigF[i].size() : 0);
+			so[2 * i + 2] = so[2 * i + 1] + (i < ix->sigR.size() ? ix->sigR[i].size() : 0);
+		}
+		h.bytes += so.size() * 8 + (so.back() ? so.back() : 1) * 4;
+	}
 	h.lg_buckets = lg; h.n_seq = (uint32_t)ix->lens.size(); h.flag = ix->flag;
 	h.max_len = 0;
 	for (uint32_t L : ix->lens) if (L > h.max_len) h.max_len = L;
@@ -455,6 +560,14 @@ extern "C" int rh_index_upload(rh_ctx *c, const rh_index *ix)
 	RH_HIP(hipMemcpy(base + h.table_off, slots.data(), slots.size() * sizeof(rh_tslot), hipMemcpyHostToDevice));
 	if (h.n_pos) RH_HIP(hipMemcpy(base + h.pos_off, ix->pos.data(), h.n_pos * 8, hipMemcpyHostToDevice));
 	if (h.n_seq) RH_HIP(hipMemcpy(base + h.len_off, ix->lens.data(), (size_t)h.n_seq * 4, hipMemcpyHostToDevice));
+	if (h.sig_off) {
+		RH_HIP(hipMemcpy(base + h.sig_off, so.data(), so.size() * 8, hipMemcpyHostToDevice));
+		unsigned char *data = base + h.sig_off + so.size() * 8;
+		for (size_t i = 0; i < ix->lens.size(); ++i) {
+			if (i < ix->sigF.size() && !ix->sigF[i].empty()) RH_HIP(hipMemcpy(data + so[2 * i] * 4, ix->sigF[i].data(), ix->sigF[i].size() * 4, hipMemcpyHostToDevice));
+			if (i < ix->sigR.size() && !ix->sigR[i].empty()) RH_HIP(hipMemcpy(data + so[2 * i + 1] * 4, ix->sigR[i].data(), ix->sigR[i].size() * 4, hipMemcpyHostToDevice));
+		}
+	}
 	if (bind_blob(c, h)) return -1;
 	if (ix->flag & RH_I_SIG_TARGET) return set_target_ranks_from(c, ix);   // all-vs-all: the device compares name ranks (rmap.cpp:86)
 	return 0;
@@ -501,6 +614,7 @@ extern "C" rh_index *rh_index_build_device(rh_ctx *c, uint32_t n_seq, const char
 	if (index_replaceable(c, "rh_index_build_device")) return nullptr;
 	if (hipSetDevice(c->device) != hipSuccess) { rh_set_error("hipSetDevice failed"); return nullptr; }
 	if (io->flag & RH_I_SIG_TARGET) { rh_set_error("signal-target (Rawsamble) indexes are built by rh_index_build_signals"); return nullptr; }
+	if (io->flag & RH_I_STORE_SIG) { rh_set_error("--store-sig indexes (target signals for DTW re-scoring) are built on the host: rh_index_build"); return nullptr; }
 	if (io->w < 0 || io->w > RH_DEV_MAXW) { rh_set_error("minimiser window w = %d outside what the device sketch maps with (0..%d)", io->w, RH_DEV_MAXW); return nullptr; }
 	if (io->e < 1 || io->e > 16 || io->q < 1 || io->q * io->e > 64 || io->k < 1 || io->k > 12) { rh_set_error("unsupported index parameters e=%d q=%d k=%d", io->e, io->q, io->k); return nullptr; }
 	std::unique_ptr<rh_index_s> ix(new rh_index_s());
@@ -699,6 +813,12 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 	hipStream_t s = c->stream;
 	rh_dev_reads rd;
 	{ StageTimer t(c, ST_H2D); if (stage_reads(c, in, &rd)) return -1; }
+	const bool dtw = (mo->flag & RH_M_DTW_EVALUATE_CHAINS) != 0;
+	if (dtw) {	// every read keeps the events of all its processed chunks
+		rd.ev_stride = (mo->flag & RH_M_NO_ADAPTIVE) ? c->ev_cap : mo->max_num_chunk * (uint32_t)RH_EV_CAP;
+		if (c->events.ensure((size_t)R * rd.ev_stride * 4)) return -1;
+		rd.events = c->events.as<float>();
+	}
 	if (c->act[0].ensure((size_t)R * 4) || c->act[1].ensure((size_t)R * 4) || c->n_act_dev.ensure(64) || c->carry[0].ensure(16) || c->carry[1].ensure(16) || c->counters.ensure(16 * 8) || c->rec.ensure((size_t)R * sizeof(rh_map_record_t))) return -1;
 	RH_HIP(hipMemsetAsync(c->counters.p, 0, 16 * 8, s));
 	{ StageTimer t(c, ST_PREFILTER); rhk_prefilter(s, o, rd); }
@@ -720,6 +840,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 		{ StageTimer t(c, ST_EV_NORM); rhk_events_norm(s, o, rd, rr); }
 		{ StageTimer t(c, ST_EV_PEAKS); rhk_events_peaks(s, o, rr); }
 		{ StageTimer t(c, ST_EV_MEANS); rhk_events_means(s, o, rr); }
+		if (dtw) rhk_events_append(s, rd, rr);                          // reg->events (rmap.cpp:237-241)
 		{ StageTimer t(c, ST_SKETCH); rhk_sketch(s, o, c->dix, rd, rr); }
 		{ StageTimer t(c, ST_PROBE); rhk_probe(s, o, c->dix, rd, rr); }
 		uint64_t total = 0;
@@ -780,8 +901,11 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 			if (debug_rounds()) dump_round(c, chunk, n, rs);
 			if (chain_stages(c, s, o, rd, rs, true)) return -1;
 			if (!ava && pack_carry()) return -1;                      // (before the region sort: it borrows the staging arena)
-			{ StageTimer t(c, ST_RSORT); if (rhk_regions_sort(s, o, rd, rs)) return -1; }
-			{ StageTimer t(c, ST_REGIONS); rhk_regions(s, o, rd, rs, c->logf_tab.as<float>()); }
+			if (dtw) { StageTimer t(c, ST_REGIONS); if (dtw_regions_stage(c, s, o, mo, rd, rs, n, chunk)) return -1; }
+			else {
+				{ StageTimer t(c, ST_RSORT); if (rhk_regions_sort(s, o, rd, rs)) return -1; }
+				{ StageTimer t(c, ST_REGIONS); rhk_regions(s, o, rd, rs, c->logf_tab.as<float>()); }
+			}
 			if (debug_rounds()) dump_round2(c, chunk, n, rs);
 			if (ava && pack_carry()) return -1;
 		}

@@ -20,6 +20,7 @@ struct rh_dev_index {
 	const uint64_t *pos;             // concatenated position lists
 	const uint32_t *seq_len;
 	const uint32_t *t_rank;          // all-vs-all: rank of every target's name (see rd.name_rank); null otherwise
+	const uint64_t *sig_off; const float *sig;   // RH_I_STORE_SIG: expected signals of the targets (DTW re-scoring); null otherwise
 	int32_t lg_buckets;
 	uint32_t n_seq;
 	int32_t flag;
@@ -33,6 +34,8 @@ struct rh_blob_header {
 	int32_t lg_buckets; uint32_t n_seq; int32_t flag;
 	rh_sketch_par sp;
 	uint32_t max_len;
+	uint32_t pad_;
+	uint64_t sig_off;                // RH_I_STORE_SIG: offset of [u64 so[2 n_seq + 1] | float data] - target i's forward signal = data[so[2i] .. so[2i+1]), reverse = [so[2i+1] .. so[2i+2]); 0 = none
 };
 #define RH_BLOB_MAGIC 0x3130424958444952ULL   // "RIDXIB01"
 // index construction on the device (rh_index_device.hip)
@@ -49,6 +52,7 @@ struct rh_dev_opt {
 	int32_t mid_occ;
 	int32_t max_dist_t, max_dist_q, bw, max_skip, max_iter, min_cnt, min_sc, min_sc2;
 	int32_t bw_long, rmq_inner_dist, rmq_size_cap;      // RH_M_RMQ chaining / bw_long > bw re-chaining (lchain.c:606, rmap.cpp:336)
+	uint32_t dtw_border, dtw_fill; float dtw_band_frac, dtw_match_bonus, dtw_min_score;   // RH_M_DTW_EVALUATE_CHAINS (rmap.cpp:128-208)
 	float pen_gap, pen_skip;
 	float mask_level; int32_t mask_len; float pri_ratio; int32_t best_n; int32_t min_strand_sc;
 	float w_bestq, w_bestmq, w_bestmc, w_threshold;
@@ -73,6 +77,7 @@ struct rh_dev_reads {
 	uint32_t *stop_chunk;            // chunk index at which it stopped
 	// summary of the regions of the last processed chunk (what the record is built from)
 	int32_t *ls_ncregs, *ls_cnt, *ls_score, *ls_mapq, *ls_qs, *ls_qe, *ls_rs, *ls_re, *ls_rid, *ls_rev;
+	float *events; uint32_t ev_stride;   // RH_M_DTW_EVALUATE_CHAINS: the events of every processed chunk of every read (reg->events, rmap.cpp:237-241), ev_stride floats per read
 };
 
 // per-round work arrays indexed by active slot a in [0, n_act)
@@ -100,6 +105,8 @@ struct rh_dev_round {
 	rh_mm128_t *zs; uint32_t *n_z;           // backtrack candidates (score, anchor) in radix_sort_128x order
 	unsigned char *ws;               // RH_WS_PER_ANCHOR bytes per anchor
 	unsigned char *sort_ws; size_t sort_ws_bytes; void *sort_pin; uint64_t sort_total;   // tables of the multi-workgroup segment sorter (rh_bigsort.hip); its second record array is an arena idle at the time
+	float *dtw_ws; uint32_t dtw_stride;      // RH_M_DTW_EVALUATE_CHAINS: DP buffers, dtw_stride floats per active read
+	uint32_t *dtw_n; float *dtw_rec; const uint64_t *dtw_off; const int32_t *dtw_dec;   // regions per read; packed per-region values for the host's MAPQ; their offsets; the host's decisions (3 int32 per read)
 	uint64_t *counters;              // [0] events [1] seeds [2] hits [3] anchors [4] chained [5] samples used [6] chunks [7] chunks with more peaks than RH_EV_CAP (an error)
 };
 
@@ -175,6 +182,11 @@ int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
 int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
 int rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r, const float *logf_tab);
+// RH_M_DTW_EVALUATE_CHAINS: regions + DTW scores (device), MAPQ and decision (host: logf of a float), commit (device)
+void rhk_events_append(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r);
+void rhk_regions_dtw(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
+void rhk_dtw_pack(hipStream_t s, const rh_dev_round &r);
+void rhk_dtw_commit(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act_in, uint32_t n_in, uint32_t next_chunk,
                         uint32_t *act_out, uint32_t *n_out);
 void rhk_rebase_offsets(hipStream_t s, const uint64_t *a_off, uint32_t n, uint64_t *out);

@@ -335,7 +335,7 @@ RH_DEV void sync_regs(int32_t n, rh_reg *r, int32_t *tmp)
 
 // Serial core on whatever memory the arrays live in.  Returns the number of regions kept; *stop = mapping decision.
 RH_DEV int32_t regions_core(const rh_dev_opt &o, int32_t n_u, const uint64_t *u, const rh_chain_head *ch, rh_reg *rg, rh_mm128_t *z, uint64_t *cov,
-                            int32_t *w, int32_t *tmp, uint32_t *cw, int32_t rep_len, uint32_t n_events, uint32_t offset, const float *logf_tab, int *stop)
+                            int32_t *w, int32_t *tmp, uint32_t *cw, int32_t rep_len, uint32_t n_events, uint32_t offset, const float *logf_tab, int *stop, bool before_mapq = false)
 {
 	int32_t n_regs = n_u;
 	*stop = 0;
@@ -432,6 +432,7 @@ RH_DEV int32_t regions_core(const rh_dev_opt &o, int32_t n_u, const uint64_t *u,
 		if (kk != n_regs) sync_regs(kk, rg, tmp);
 		n_regs = kk;
 	}
+	if (before_mapq) return n_regs;                                 // (DTW re-scoring: alignment scores first, MAPQ and decision on the host)
 	// MAPQ
 	{
 		int64_t sum_sc = 0;
@@ -1128,6 +1129,223 @@ __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ DTW re-scoring of chains (f4)
+// --dtw-evaluate-chains (rmap.cpp:128-208, 355-374; dtw.cpp): every region kept by mm_select_sub is aligned - read events against
+// the target's expected signal (RH_I_STORE_SIG) - between consecutive anchors ("sparse", the default) or over the whole chain
+// ("global"), with a slanted band (default) or the full matrix; regions are taken in order and one whose best attainable score falls
+// below the best alignment found so far is abandoned.  An opt-in accuracy mode of the reference: one lane per read, the reference's
+// loops as they are - its band DP keeps three anti-diagonal buffers and reads cells an earlier anti-diagonal left behind, which a
+// re-formulation would not reproduce.  The MAPQ of this mode takes logf of the (fractional) alignment score: that and the mapping
+// decision are left to the host's libm (rh_api.cpp), the device computes the alignment scores and commits the host's verdict.
+RH_DEV float dtw_dist(float a, float b) { return fabsf(a - b); }
+RH_DEV float dtw_min3(float top, float left, float topleft) { const float m = left < top ? left : top; return topleft < m ? topleft : m; }   // std::min(std::min(top, left), topleft)
+
+RH_DEV float dtw_full(const float *a, uint32_t a_len, const float *b, uint32_t b_len, bool excl, float *dp)	// DTW_global dtw.cpp:37-66
+{
+	dp[0] = dtw_dist(a[0], b[0]);
+	for (uint32_t j = 1; j < a_len; ++j) dp[j] = dp[j - 1] + dtw_dist(a[j], b[0]);
+	for (uint32_t i = 1; i < b_len; ++i) {
+		float old_left = dp[0];
+		dp[0] = dp[0] + dtw_dist(a[0], b[i]);
+		for (uint32_t j = 1; j < a_len; ++j) {
+			const float top = dp[j - 1], left = dp[j], topleft = old_left;
+			dp[j] = dtw_min3(top, left, topleft) + dtw_dist(a[j], b[i]);
+			old_left = left;
+		}
+	}
+	return excl ? dp[a_len - 1] - dtw_dist(a[a_len - 1], b[b_len - 1]) : dp[a_len - 1];
+}
+// DTW_global_slantedbanded_antidiagonalwise dtw.cpp:273-523; store: 3 * dpsize floats.  Returns NaN if the buffers do not fit `cap`.
+RH_DEV float dtw_banded(const float *a, uint32_t a_length, const float *b, uint32_t b_length, int band_radius, bool excl, float *store, uint32_t cap)
+{
+	if (a_length < b_length) { const float *tv = a; const uint32_t tl = a_length; a = b; a_length = b_length; b = tv; b_length = tl; }
+	const int extra = (int)(((a_length - b_length) * (uint32_t)band_radius + a_length - 1u) / a_length);
+	band_radius += extra;
+	const int plen = band_radius + (band_radius % 2 == 0 ? 1 : 0), slen = band_radius + (band_radius % 2 == 1 ? 1 : 0);
+	const bool primary_larger = plen > slen;
+	const int dpsize = plen > slen ? plen : slen;
+	if ((uint64_t)dpsize * 3u > cap) return __uint_as_float(0x7FC00000u);
+	float *dp0 = store, *dp1 = store + dpsize, *dp2 = store + 2 * dpsize, *tmp;
+	for (int i = 0; i < dpsize * 3; ++i) store[i] = 1e10f;
+	int center_row = 0;
+	{	// iteration 0: the top left corner
+		const int off = plen / 2;
+		if (0 < (int)b_length && 0 < (int)a_length) { if (primary_larger) dp2[off] = dtw_dist(a[0], b[0]); else dp2[off + 1] = dtw_dist(a[0], b[0]); }
+		tmp = dp0; dp0 = dp1; dp1 = dp2; dp2 = tmp;
+	}
+	bool prev_inc = false;
+	for (int it = 1; (uint32_t)it < a_length; ++it) {
+		const int center_column = it;
+		bool inc = false;
+		if ((int64_t)(center_row + 1) * (int64_t)a_length <= (int64_t)b_length * (int64_t)center_column) { ++center_row; inc = true; }
+		if (inc) {	// the secondary anti-diagonal of a step down
+			const int si = center_column + slen / 2 - 1, sj = center_row - slen / 2;
+			int o0 = 0; if (si - (int)a_length + 1 > o0) o0 = si - (int)a_length + 1; if (-sj > o0) o0 = -sj;
+			int o1 = slen; if (si + 1 < o1) o1 = si + 1; if ((int)b_length - sj < o1) o1 = (int)b_length - sj;
+			for (int off = o0; off < o1; ++off) {
+				const int i = si - off, j = sj + off;
+				float top, topleft, left;
+				if (primary_larger) { top = dp1[off]; topleft = dp0[off]; left = dp1[off + 1]; }
+				else {
+					const bool is_first = off == 0, is_last = off == slen - 1;
+					top = is_first ? 1e10f : dp1[off];
+					topleft = is_first && !prev_inc ? 1e10f : dp0[off];
+					left = is_last ? 1e10f : dp1[off + 1];
+				}
+				dp2[off] = dtw_min3(top, left, topleft) + dtw_dist(a[i], b[j]);
+			}
+			tmp = dp0; dp0 = dp1; dp1 = dp2; dp2 = tmp;
+		}
+		const int si = center_column + plen / 2, sj = center_row - plen / 2;
+		int o0 = 0; if (si - (int)a_length + 1 > o0) o0 = si - (int)a_length + 1; if (-sj > o0) o0 = -sj;
+		int o1 = plen; if (si + 1 < o1) o1 = si + 1; if ((int)b_length - sj < o1) o1 = (int)b_length - sj;
+		for (int off = o0; off < o1; ++off) {
+			const int i = si - off, j = sj + off;
+			const bool is_first = off == 0, is_last = off == plen - 1;
+			float top, topleft, left;
+			if (primary_larger) {
+				if (inc) { top = is_first ? 1e10f : dp1[off - 1]; topleft = dp0[off]; left = is_last ? 1e10f : dp1[off]; }
+				else { top = is_first ? 1e10f : dp1[off - 1]; topleft = is_first ? 1e10f : dp0[off - 1]; left = dp1[off]; }
+				dp2[off] = dtw_min3(top, left, topleft) + dtw_dist(a[i], b[j]);
+			} else {	// (accesses to a primary anti-diagonal start at [1])
+				if (inc) { top = dp1[off]; topleft = dp0[off + 1]; left = dp1[off + 1]; }
+				else { top = is_first ? 1e10f : dp1[off]; topleft = is_first && !prev_inc ? 1e10f : dp0[off]; left = dp1[off + 1]; }
+				dp2[off + 1] = dtw_min3(top, left, topleft) + dtw_dist(a[i], b[j]);
+			}
+		}
+		tmp = dp0; dp0 = dp1; dp1 = dp2; dp2 = tmp;
+		prev_inc = inc;
+	}
+	float res = primary_larger ? dp1[plen / 2] : dp1[plen / 2 + 1];
+	if (excl) res -= dtw_dist(a[a_length - 1], b[b_length - 1]);
+	return res;
+}
+// align_chain rmap.cpp:128-208.  Returns the alignment score (-1e10: abandoned); *bad set if the DP buffers were too small.
+RH_DEV float dtw_align_chain(const rh_dev_opt &o, const rh_reg &c, const rh_mm128_t *anchors, const float *ref, const float *ev, float min_score, float *dp, uint32_t dp_cap, bool *bad)
+{
+	float cost = 0.0f;
+	uint32_t n_aligned = 0;
+	if (o.dtw_border == 0u) {	// global
+		const float *rv = ref + c.rs; const uint32_t rlen = (uint32_t)(c.re - c.rs + 1);
+		const float *qv = ev + c.qs; const uint32_t qlen = (uint32_t)(c.qe - c.qs + 1);
+		if ((float)qlen * o.dtw_match_bonus < min_score) return -1e10f;
+		if (o.dtw_fill == 0u) { if (qlen > dp_cap) { *bad = true; return 0.0f; } cost = dtw_full(qv, qlen, rv, rlen, false, dp); }
+		else { int band = (int)((float)qlen * o.dtw_band_frac); if (band < 1) band = 1; cost = dtw_banded(qv, qlen, rv, rlen, band, false, dp, dp_cap); }
+		n_aligned = qlen;
+	} else {	// between consecutive anchors
+		const uint32_t parts = (uint32_t)c.cnt - 1u;
+		float cur_max = (float)(uint32_t)(c.qe - c.qs + 1) * o.dtw_match_bonus;
+		for (uint32_t part = 0; part < parts; ++part) {
+			const rh_mm128_t sa = anchors[part], ea = anchors[part + 1];
+			const float *rv = ref + (uint32_t)sa.x; const uint32_t rlen = (uint32_t)ea.x - (uint32_t)sa.x + 1u;
+			const float *qv = ev + (uint32_t)sa.y; const uint32_t qlen = (uint32_t)ea.y - (uint32_t)sa.y + 1u;
+			if (cur_max < min_score) return -1e10f;
+			const bool excl = part != parts - 1u;
+			float sub;
+			if (o.dtw_fill == 0u) { if (qlen > dp_cap) { *bad = true; return 0.0f; } sub = dtw_full(qv, qlen, rv, rlen, excl, dp); }
+			else { int band = (int)((float)qlen * o.dtw_band_frac); if (band < 1) band = 1; sub = dtw_banded(qv, qlen, rv, rlen, band, excl, dp, dp_cap); }
+			cost += sub;
+			cur_max -= sub;
+			n_aligned += qlen;
+		}
+	}
+	if (cost != cost) { *bad = true; return 0.0f; }
+	return (float)n_aligned * o.dtw_match_bonus - cost;
+}
+
+// reg->events: the events of this round's chunk behind those of the chunks before (rmap.cpp:237-241; a dropped chunk adds nothing)
+__global__ __launch_bounds__(NT) void k_events_append(rh_dev_reads rd, rh_dev_round rr)
+{
+	const uint32_t a = blockIdx.x;
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const uint32_t r = rr.act[a], n = rr.n_ev[a], off = rd.ev_off[r];
+	const float *src = rr.ev + (size_t)a * rr.ev_cap;
+	float *dst = rd.events + (size_t)r * rd.ev_stride + off;
+	for (uint32_t i = threadIdx.x; i < n && off + i < rd.ev_stride; i += NT) dst[i] = src[i];
+}
+
+// one read per lane: regions up to mm_select_sub (the serial core on HBM scratch, as k_regions_big), then the alignment score of every kept
+// region in order (rmap.cpp:355-374).  Leaves rg[] in the read's scratch, rr.dtw_n[a] = regions kept (0x80000000 | .. on a buffer overflow)
+__global__ void k_regions_dtw(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh_dev_round rr)
+{
+	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a >= rr.n_act) return;
+	rr.dtw_n[a] = 0;
+	if (rr.skip[a]) return;
+	const uint32_t r = rr.act[a];
+	const uint64_t base = rr.a_off[a];
+	const int32_t n_u = (int32_t)rr.n_u[a];
+	if (n_u == 0) return;
+	const rh_mm128_t *an = rr.anc + base;
+	const uint64_t *u = rr.u + base;
+	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;           // 64 B per anchor >= 128 B per chain (min_cnt >= 2)
+	rh_reg *rg = (rh_reg*)wsr;
+	rh_chain_head *ch = (rh_chain_head*)(wsr + (size_t)64 * n_u);
+	rh_mm128_t *z = (rh_mm128_t*)(wsr + (size_t)96 * n_u);
+	uint64_t *cov = (uint64_t*)(wsr + (size_t)112 * n_u);
+	int32_t *w = (int32_t*)(wsr + (size_t)120 * n_u), *tmp = (int32_t*)(wsr + (size_t)124 * n_u);
+	uint32_t *cw = (uint32_t*)rg;
+	uint32_t k = 0;
+	for (int32_t i = 0; i < n_u; ++i) {
+		const uint32_t cnt = (uint32_t)u[i];
+		rh_chain_head h; h.x0 = an[k].x; h.y0 = an[k].y; h.x1 = (int32_t)an[k + cnt - 1].x; h.y1 = (int32_t)an[k + cnt - 1].y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
+		ch[i] = h;
+		k += cnt;
+	}
+	int stop;
+	const int32_t n_regs = regions_core(o, n_u, u, ch, rg, z, cov, w, tmp, cw, rr.rep_len[a], rr.n_ev[a], rd.ev_off[r], nullptr, &stop, true);
+	// alignment scores go where the chain heads were (4 B per region; the heads are not needed any more)
+	float *ascore = (float*)ch;
+	const float *ev = rd.events + (size_t)r * rd.ev_stride;
+	float *dp = rr.dtw_ws + (size_t)a * rr.dtw_stride;
+	bool bad = false;
+	float best = 0.0f;
+	for (int32_t i = 0; i < n_regs; ++i) {
+		const rh_reg &c = rg[i];
+		const float *ref = ix.sig + ix.sig_off[2 * (size_t)c.rid + (c.rev ? 1u : 0u)];
+		float as = dtw_align_chain(o, c, an + c.as, ref, ev, best, dp, rr.dtw_stride, &bad);
+		if (as >= o.dtw_min_score) { if (as > best) best = as; }
+		else if (as < o.dtw_min_score && as < 0.0f) as = o.dtw_min_score > 0.0f ? 0.0f : o.dtw_min_score;
+		ascore[i] = as;
+	}
+	rr.dtw_n[a] = (uint32_t)n_regs | (bad ? 0x80000000u : 0u);
+}
+
+// per region what the host needs for mm_set_mapq (hit.c:502-539) and the decision (rmap.cpp:423-500): 8 floats / ints each, packed
+__global__ __launch_bounds__(NT) void k_dtw_pack(rh_dev_round rr)
+{
+	const uint32_t a = blockIdx.x;
+	if (a >= rr.n_act) return;
+	const uint32_t n = rr.dtw_n[a] & 0x7FFFFFFFu;
+	if (!n) return;
+	const uint64_t base = rr.a_off[a];
+	const int32_t n_u = (int32_t)rr.n_u[a];
+	const unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
+	const rh_reg *rg = (const rh_reg*)wsr;
+	const float *ascore = (const float*)(wsr + (size_t)64 * n_u);
+	int32_t *out = (int32_t*)rr.dtw_rec + rr.dtw_off[a] * 8;
+	for (uint32_t i = threadIdx.x; i < n; i += NT) {
+		const rh_reg &q = rg[i];
+		int32_t *o8 = out + (size_t)i * 8;
+		o8[0] = q.score; o8[1] = q.cnt; o8[2] = q.subsc; o8[3] = q.score0; o8[4] = q.n_sub; o8[5] = q.parent == q.id ? 1 : 0; o8[6] = (int32_t)__float_as_uint(ascore[i]); o8[7] = 0;
+	}
+}
+
+// the host's verdict per read {region to commit, its MAPQ, stop}: the state the record is built from (rmap.cpp:423-500, 507-586)
+__global__ void k_dtw_commit(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
+{
+	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a >= rr.n_act) return;
+	const uint32_t r = rr.act[a];
+	if (rr.skip[a]) { rd.ls_ncregs[r] = 0; return; }                // chunk dropped: creg stays NULL (rmap.cpp:232-235, :419)
+	const uint32_t n = rr.dtw_n[a] & 0x7FFFFFFFu;
+	if (!n) { regions_commit(o, rd, rr, a, r, 0, nullptr, 0); return; }
+	const rh_reg *rg = (const rh_reg*)(rr.ws + rr.a_off[a] * RH_WS_PER_ANCHOR);
+	rh_reg sel = rg[rr.dtw_dec[3 * (size_t)a]];
+	sel.mapq = (uint32_t)rr.dtw_dec[3 * (size_t)a + 1];
+	regions_commit(o, rd, rr, a, r, (int32_t)n, &sel, rr.dtw_dec[3 * (size_t)a + 2]);
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 // the multi-workgroup sorter's second record array is whichever 16-byte-per-anchor arena is idle during that sort
 static void sort_scratch(rh_sort_job &jb, const rh_dev_round &r, rh_mm128_t *idle) { jb.big_alt = idle; jb.big_ws = r.sort_ws; jb.big_ws_bytes = r.sort_ws_bytes; jb.big_pin = r.sort_pin; jb.big_total = r.sort_total; }
@@ -1200,3 +1418,8 @@ void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, con
 	RH_LAUNCH(k_regions_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, logf_tab, 0u, (uint32_t)RG_SMALL, 0);
 	RH_LAUNCH(k_regions_big, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_CAP, 0x7FFFFFFFu, wave_ok ? 1 : 0);
 }
+
+void rhk_events_append(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_append, r.n_act, NT, 0, s, rd, r); }
+void rhk_regions_dtw(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_regions_dtw, (r.n_act + 63) / 64, 64, 0, s, o, ix, rd, r); }
+void rhk_dtw_pack(hipStream_t s, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_dtw_pack, r.n_act, NT, 0, s, r); }
+void rhk_dtw_commit(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_dtw_commit, (r.n_act + 63) / 64, 64, 0, s, o, rd, r); }

@@ -85,6 +85,22 @@ def test_rmq_chaining(make_workload, emu_lib, mapopt):
     c.close()
 
 
+DTW_VARIANTS = [{"flag": 0x40}, {"flag": 0x40, "dtw_border_constraint": 0}, {"flag": 0x40, "dtw_fill_method": 0, "dtw_min_score": 5.0},
+                {"flag": 0x40, "dtw_border_constraint": 0, "dtw_fill_method": 0}]
+
+
+@pytest.mark.parametrize("mapopt", DTW_VARIANTS, ids=lambda m: "_".join(f"{k}{v}" for k, v in m.items()))
+def test_dtw_rescoring(make_workload, emu_lib, mapopt):
+    """f4: --dtw-evaluate-chains on a --store-sig index (align_chain rmap.cpp:128-208, the band / full DTW of dtw.cpp, DTW MAPQ and
+    decision) end to end against the oracle, which test_oracle pins to PAF printed by the reference for these variants."""
+    w = make_workload(lib=emu_lib, n_reads=16, n_samples=12_000, idxflag=0x10, mapopt=mapopt)
+    c = Context(0, lib=emu_lib)
+    c.upload(w.index)
+    recs = pc.check_e2e(c, w)
+    assert recs["mapped"].sum() > 0
+    c.close()
+
+
 def test_end_to_end_paf(ctx, wl):
     recs = pc.check_e2e(ctx, wl)
     assert recs["mapped"].sum() > 0 and (recs["mapped"] == 0).sum() > 0   # both outcomes exercised

@@ -76,6 +76,18 @@ def test_rmq_chaining(make_workload, product_lib, gpu_ctx_factory, mapopt):
     pc.check_e2e(c, w)
 
 
+@pytest.mark.parametrize("mapopt", [{"flag": 0x40}, {"flag": 0x40, "dtw_border_constraint": 0}, {"flag": 0x40, "dtw_fill_method": 0, "dtw_min_score": 5.0}],
+                         ids=lambda m: "_".join(f"{k}{v}" for k, v in m.items()))
+def test_dtw_rescoring(make_workload, product_lib, gpu_ctx_factory, mapopt):
+    """f4: --dtw-evaluate-chains on a --store-sig index, 300 reads end to end against the oracle (the reference-printed goldens of these
+    variants are part of test_golden_paf)."""
+    w = make_workload(n_reads=300, n_samples=20_000, idxflag=0x10, mapopt=mapopt)
+    c = gpu_ctx_factory()
+    c.upload(w.index)
+    recs = pc.check_e2e(c, w)
+    assert recs["mapped"].sum() > 100
+
+
 def test_any_order_sort(ctx):
     """Region keys (hit.c:111-126) through the sorter's any-order levels + tie check, many long segments."""
     assert pc.check_sort_any(ctx, seed=5) >= 1
