@@ -992,7 +992,9 @@ struct rgb_lds {
 	int32_t pqs[RGB_PCAP], pqe[RGB_PCAP];        // primaries in list order: query interval
 	uint32_t psc[RGB_PCAP], pcn[RGB_PCAP], psub[RGB_PCAP], pns[RGB_PCAP];   // score, anchors, best secondary score, secondaries with >= as many anchors
 	int32_t sqs[RGB_PCAP], sqe[RGB_PCAP];        // the same intervals sorted by (start, end)
+	uint16_t sid[RGB_PCAP];                       // ... and their place in the list
 	uint32_t kk;
+	int32_t lmax;                                 // the longest primary: a primary that overlaps [si, ei) starts after si - lmax
 };
 
 __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, const float *logf_tab, uint32_t n_lo)
@@ -1007,7 +1009,7 @@ __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads
 	const rh_chain_head *heads = (const rh_chain_head*)(rr.ws + base * RH_WS_PER_ANCHOR);
 	const rh_mm128_t *zs = rr.zs + base;                             // keys in radix_sort_128x order (ascending)
 	const bool hard = (o.flag & RH_M_HARD_MLEVEL) != 0;
-	if (lane == 0) L.kk = 0;
+	if (lane == 0) { L.kk = 0; L.lmax = 0; }
 	__syncthreads();
 	for (int32_t i0 = 0; i0 < n_u; i0 += 64) {
 		const int32_t i = i0 + (int32_t)lane;
@@ -1023,27 +1025,38 @@ __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads
 		while (__ballot(pending)) {
 			const uint32_t kk = L.kk;
 			if (__ballot(need_eval)) {
-				int32_t reach = si, cov = 0, uncov = 0;
-				if (!hard) {
-					for (uint32_t j = 0; j < kk; ++j) {
-						const int32_t s = L.sqs[j], e = L.sqe[j];
-						if (need_eval && !(e <= si || s >= ei)) {
-							const int32_t cs = s < si ? si : s, ce = e > ei ? ei : e, from = cs > reach ? cs : reach;
-							if (ce > from) cov += ce - from;
-							if (ce > reach) reach = ce;
+				// Only the primaries that overlap the chain matter, and in the list sorted by start they sit in one stretch: those that
+				// start after si - (longest primary) and before ei.  A junk read's thousands of short chains overlap a handful of its
+				// hundreds of primaries each: a binary search and two short per-lane loops instead of two sweeps over the whole list.
+				if (need_eval) {
+					const int32_t from_s = si - L.lmax;
+					uint32_t lo = 0, hi = kk;                           // first j with sqs[j] > from_s
+					while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (L.sqs[mid] > from_s) hi = mid; else lo = mid + 1; }
+					int32_t reach = si, cov = 0, uncov = 0;
+					if (!hard) {
+						for (uint32_t j = lo; j < kk; ++j) {
+							const int32_t s = L.sqs[j], e = L.sqe[j];
+							if (s >= ei) break;
+							if (e > si) {
+								const int32_t cs = s < si ? si : s, ce = e > ei ? ei : e, from = cs > reach ? cs : reach;
+								if (ce > from) cov += ce - from;
+								if (ce > reach) reach = ce;
+							}
+						}
+						uncov = (ei - si) - cov;
+					}
+					int32_t first = 0x7FFFFFFF;                        // the first primary IN LIST ORDER that masks the chain (hit.c:231-246)
+					for (uint32_t j = lo; j < kk; ++j) {
+						const int32_t sj = L.sqs[j], ej = L.sqe[j];
+						if (sj >= ei) break;
+						if (ej > si) {
+							const int32_t mn = ej - sj < ei - si ? ej - sj : ei - si;
+							const int32_t mx = ej - sj > ei - si ? ej - sj : ei - si;
+							const int32_t ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj) : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
+							if ((float)ol / (float)mn - (float)uncov / (float)mx > o.mask_level && uncov <= o.mask_len) { const int32_t id = (int32_t)L.sid[j]; if (id < first) first = id; }
 						}
 					}
-					uncov = (ei - si) - cov;
-				}
-				if (need_eval) sel = -1;
-				for (uint32_t j = 0; j < kk; ++j) {
-					const int32_t sj = L.pqs[j], ej = L.pqe[j];
-					if (need_eval && sel < 0 && !(ej <= si || sj >= ei)) {
-						const int32_t mn = ej - sj < ei - si ? ej - sj : ei - si;
-						const int32_t mx = ej - sj > ei - si ? ej - sj : ei - si;
-						const int32_t ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj) : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
-						if ((float)ol / (float)mn - (float)uncov / (float)mx > o.mask_level && uncov <= o.mask_len) sel = (int32_t)j;
-					}
+					sel = first == 0x7FFFFFFF ? -1 : first;
 				}
 				need_eval = false;
 			}
@@ -1062,13 +1075,15 @@ __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads
 				for (uint32_t j = lane; j < kk; j += 64) below += (L.sqs[j] < fs || (L.sqs[j] == fs && L.sqe[j] <= fe)) ? 1u : 0u;
 				for (int d = 32; d > 0; d >>= 1) below += __shfl_xor(below, d);
 				int32_t ms[RGB_PCAP / 64], me[RGB_PCAP / 64];
+				uint16_t mi[RGB_PCAP / 64];
 #pragma unroll
-				for (int q = 0; q < RGB_PCAP / 64; ++q) { const uint32_t j = (uint32_t)q * 64u + lane; ms[q] = 0; me[q] = 0; if (j >= below && j < kk) { ms[q] = L.sqs[j]; me[q] = L.sqe[j]; } }
+				for (int q = 0; q < RGB_PCAP / 64; ++q) { const uint32_t j = (uint32_t)q * 64u + lane; ms[q] = 0; me[q] = 0; mi[q] = 0; if (j >= below && j < kk) { ms[q] = L.sqs[j]; me[q] = L.sqe[j]; mi[q] = L.sid[j]; } }
 				__syncthreads();
 #pragma unroll
-				for (int q = 0; q < RGB_PCAP / 64; ++q) { const uint32_t j = (uint32_t)q * 64u + lane; if (j >= below && j < kk) { L.sqs[j + 1] = ms[q]; L.sqe[j + 1] = me[q]; } }
+				for (int q = 0; q < RGB_PCAP / 64; ++q) { const uint32_t j = (uint32_t)q * 64u + lane; if (j >= below && j < kk) { L.sqs[j + 1] = ms[q]; L.sqe[j + 1] = me[q]; L.sid[j + 1] = mi[q]; } }
 				if (lane == 0) {
-					L.sqs[below] = fs; L.sqe[below] = fe;
+					L.sqs[below] = fs; L.sqe[below] = fe; L.sid[below] = (uint16_t)kk;
+					if (fe - fs > L.lmax) L.lmax = fe - fs;
 					L.pqs[kk] = fs; L.pqe[kk] = fe; L.psc[kk] = (uint32_t)fsc; L.pcn[kk] = (uint32_t)fcn; L.psub[kk] = 0; L.pns[kk] = 0;
 					L.kk = kk + 1;
 				}
