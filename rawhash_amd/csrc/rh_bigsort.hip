@@ -1006,6 +1006,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	static const bool trace = getenv("RH_BS_TRACE") != nullptr;   // development aid: per-level launch shapes and times on stderr
 	static const bool walk_old = getenv("RH_BS_WALK_OLD") != nullptr;   // development aid: the LDS-resident walkers instead of the scalar-token one
 	static const uint32_t tok_max = getenv("RH_BS_TOK_MAX") ? (uint32_t)strtoul(getenv("RH_BS_TOK_MAX"), nullptr, 10) : 0xFFFFFFFFu;
+	static const bool tok2 = !(getenv("RH_BS_TOK2") && atoi(getenv("RH_BS_TOK2")) == 0);   // two regions per lane for ranges with 65 .. 128 regions that have holes (the candidate sort's first level; measured +2 % on one stream)
 	static const bool tok4 = getenv("RH_BS_TOK4") != nullptr;       // development aid: four regions per lane for ranges with more than 64 regions that have holes
 	hipEvent_t ev[4] = {};
 	if (trace) for (auto &e : ev) (void)hipEventCreate(&e);
@@ -1037,9 +1038,10 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		const int tok = !lanes && !walk_old && t < (1ull << 32) && n_rng <= tok_max;   // scalar token, one lane per region (absolute hole addresses in 32 bits): levels too narrow for the walks to fill the chip
 		if (trace) (void)hipEventRecord(ev[1], s);
 		if (tok) {
-			RH_LAUNCH(k_bs_walk_wave, n_rng, 64, 0, s, C, 3u, tok4 ? 256u : 64u);   // two regions with holes: closed form (and, measured faster there, more than 64: one LDS-resident walker per wavefront)
+			RH_LAUNCH(k_bs_walk_wave, n_rng, 64, 0, s, C, 3u, tok4 ? 256u : tok2 ? 128u : 64u);   // two regions with holes: closed form (and, measured faster there, more than 128: one LDS-resident walker per wavefront)
 			RH_LAUNCH((k_bs_walk_tok<1>), n_rng, 64, 0, s, C, 3u, 64u);
-			if (tok4) RH_LAUNCH((k_bs_walk_tok<4>), n_rng, 64, 0, s, C, 65u, 256u);
+			if (tok2) RH_LAUNCH((k_bs_walk_tok<2>), n_rng, 64, 0, s, C, 65u, 128u);
+			if (tok4) RH_LAUNCH((k_bs_walk_tok<4>), n_rng, 64, 0, s, C, tok2 ? 129u : 65u, 256u);
 		} else {
 		RH_LAUNCH(k_bs_walk_wave, n_rng, 64, 0, s, C, lanes ? 3u : multi ? 3u : 1u, lanes ? 256u : multi ? (uint32_t)BS_MW_NHM : 0u);
 		if (multi) {	// walks per wavefront: so that the level takes about one wavefront per SIMD (a walk's step time does not depend on how many lanes walk)

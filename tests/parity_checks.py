@@ -298,6 +298,8 @@ def check_sort_big(ctx, seed=0, sizes=(20000, 33000, 9000), kinds=(0, 1, 2, 3, 4
             x[j] = rng.integers(14, 400, size=len(j), dtype=np.uint64)
         elif kind == 2:
             x = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+        elif kind == 5:    # chain scores as the candidate sort sees them: ~100 values of one byte (65 .. 128 regions with holes), many equal keys
+            x = (rng.integers(20, 20 + int(rng.integers(70, 128)), size=n, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, 1 << 10, size=n, dtype=np.uint64)
         elif kind == 3:    # three values of one byte, the rest equal
             x = (rng.integers(0, 3, size=n, dtype=np.uint64) << np.uint64(8 * int(rng.integers(1, 8)))) | np.uint64(7)
         else:

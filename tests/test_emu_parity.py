@@ -37,6 +37,7 @@ def test_exact_sort_multi_workgroup(ctx, emu_lib_smallcaps):
     """rh_bigsort.hip: segments longer than the LDS classes, at the production sizes of tiles / windows and with tiny ones
     (several levels, window refills of the token walk)."""
     pc.check_sort_big(ctx, seed=7, sizes=(20000, 12000, 9000, 8300, 8193))
+    pc.check_sort_big(ctx, seed=9, sizes=(15000, 9500), kinds=(5,))
     c = Context(0, lib=emu_lib_smallcaps)
     pc.check_sort_big(c, seed=8, sizes=(5000, 3000, 7000, 2500, 1500, 6000, 9000, 1100, 4000, 2000))
     c.close()

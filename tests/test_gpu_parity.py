@@ -100,6 +100,7 @@ def test_exact_sort_multi_workgroup(ctx):
     pc.check_sort_big(ctx, seed=11, sizes=(30000, 70000, 9000, 8193, 250000, 40000, 100000, 16385))
     pc.check_sort_big(ctx, seed=12, sizes=(1_200_000, 300_000), kinds=(0, 1))
     pc.check_sort_big(ctx, seed=13, sizes=(1_100_000,), kinds=(2,))
+    pc.check_sort_big(ctx, seed=15, sizes=(400_000, 90_000, 20_000), kinds=(5,))
     pc.check_sort_big(ctx, seed=14, sizes=tuple([30000 + 17 * i for i in range(300)]), kinds=(0, 1, 0, 0, 3))
 
 
