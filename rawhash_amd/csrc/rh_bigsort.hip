@@ -760,22 +760,24 @@ __global__ __launch_bounds__(64) void k_bs_walk_tok(bs_ctx C, uint32_t nh_lo, ui
 	const uint32_t nh = M.nh;
 	if (nh < nh_lo || nh > nh_hi) return;
 	const uint32_t beg = (uint32_t)C.rng[0][r].beg;                 // (the host takes this kernel only when every absolute hole address fits 32 bits)
-	uint32_t *dest = C.dest + beg;
 	// this lane's regions: q = lane + 64 t
 	bool on[RPL];
-	uint32_t jr[RPL], en[RPL], lim[RPL], head[RPL], nxt[RPL], ra[RPL], ld_n[RPL];   // next hole (index in the range), end of the region's holes, ring committed up to (absolute), digits at jr / jr + 1, LDS address of the digit at jr + 2
+	uint32_t jr[RPL], en[RPL], lim[RPL], head[RPL], ld_n[RPL];   // next hole and end of the region's holes (ABSOLUTE hole addresses: the ring slot of a hole is its low six bits), ring committed up to, digit at jr
 	uint4 la[RPL], lb[RPL];
 #pragma unroll
 	for (int t = 0; t < RPL; ++t) {
 		const uint32_t q = lane + 64u * (uint32_t)t;
 		on[t] = q < nh;
-		jr[t] = 0; en[t] = 0; lim[t] = 0; head[t] = 0; nxt[t] = 0; ra[t] = 0; ld_n[t] = 0; la[t] = uint4{0, 0, 0, 0}; lb[t] = uint4{0, 0, 0, 0};
-		if (on[t]) { const uint32_t dk = M.act[q]; jr[t] = M.hst[dk]; en[t] = M.hst[dk + 1u]; lim[t] = (beg + jr[t]) & ~15u; }
+		jr[t] = 0; en[t] = 0; lim[t] = 0; head[t] = 0; ld_n[t] = 0; la[t] = uint4{0, 0, 0, 0}; lb[t] = uint4{0, 0, 0, 0};
+		if (on[t]) { const uint32_t dk = M.act[q]; jr[t] = beg + M.hst[dk]; en[t] = beg + M.hst[dk + 1u]; lim[t] = jr[t] & ~15u; }
 	}
 	#define BS_TK_RING(t) ((uint32_t)(lane + 64u * (uint32_t)(t)) * (uint32_t)BS_MW_RING)
+	uint32_t ringb[RPL];
+#pragma unroll
+	for (int t = 0; t < RPL; ++t) ringb[t] = BS_TK_RING(t);
 	#define BS_TK_ISSUE() _Pragma("unroll") for (int t = 0; t < RPL; ++t) { \
 		ld_n[t] = 0; \
-		if (on[t]) { const uint32_t pa_ = (beg + jr[t]) & ~15u, lm_ = lim[t], ea_ = beg + en[t]; \
+		if (on[t]) { const uint32_t pa_ = jr[t] & ~15u, lm_ = lim[t], ea_ = en[t]; \
 		             if (lm_ < ea_ && lm_ + 16u - pa_ <= (uint32_t)BS_MW_RING) { ld_n[t] = 1; if (lm_ + 16u < ea_ && lm_ + 32u - pa_ <= (uint32_t)BS_MW_RING) ld_n[t] = 2; } \
 		             if (ld_n[t] >= 1) la[t] = *reinterpret_cast<const uint4*>(C.hd + lm_); \
 		             if (ld_n[t] >= 2) lb[t] = *reinterpret_cast<const uint4*>(C.hd + lm_ + 16u); } }
@@ -790,46 +792,46 @@ __global__ __launch_bounds__(64) void k_bs_walk_tok(bs_ctx C, uint32_t nh_lo, ui
 	BS_TK_ISSUE() BS_TK_COMMIT();                                    // rings full: 64 bytes from each region's first hole on
 #pragma unroll
 	for (int t = 0; t < RPL; ++t)
-		if (on[t]) { const uint32_t a_ = beg + jr[t]; head[t] = s_win[BS_TK_RING(t) + (a_ & 63u)]; nxt[t] = s_win[BS_TK_RING(t) + ((a_ + 1u) & 63u)]; ra[t] = BS_TK_RING(t) + ((a_ + 2u) & 63u); }
+		if (on[t]) head[t] = s_win[BS_TK_RING(t) | (jr[t] & 63u)];
 	BS_TK_ISSUE()
 	// The token.  The loop nest is the reference's (ksort.h:124-138): for each base region k, for each of its holes, chase the
 	// record found there until one that belongs to k turns up.
 	uint32_t k = 0, nlog = 0, per = BS_TK_PERIOD;
 	uint32_t logA = 0, logV = 0;
-	#define BS_TK_LOG(a_, v_) do { logA = rh_writelane(logA, (a_), nlog); logV = rh_writelane(logV, (v_), nlog); if (++nlog == 64u) { dest[logA] = logV; nlog = 0; } } while (0)
+	#define BS_TK_LOG(a_, v_) do { rh_writelane2(logA, logV, (a_), (v_), nlog); if (++nlog == 64u) { C.dest[logA] = logV - beg; nlog = 0; } } while (0)   /* (dest[] holds hole indices within the range) */
 	// pop region c_: d_ = the digit in its next hole, j_ = that hole; the region's lane moves on
 	#define BS_TK_POP(c_, d_, j_) do { \
-		const uint32_t l_ = (c_) & 63u, sl_ = RPL == 1 ? 0u : (c_) >> 6; \
+		const uint32_t l_ = RPL == 1 ? (c_) : (c_) & 63u, sl_ = RPL == 1 ? 0u : (c_) >> 6;   /* (one region per lane: c_ < nh <= 64) */ \
 		if (per == 0u) { BS_TK_COMMIT(); BS_TK_ISSUE() per = BS_TK_PERIOD; }   /* a period is over: commit the loads in flight, issue the next */ \
 		--per; \
 		d_ = BS_TK_READ(head, sl_, l_); j_ = BS_TK_READ(jr, sl_, l_); \
 		_Pragma("unroll") for (int t = 0; t < RPL; ++t) \
 			if (lane == l_ && sl_ == (uint32_t)t) { \
-				head[t] = nxt[t]; \
-				nxt[t] = s_win[ra[t]]; \
-				ra[t] = (ra[t] & ~63u) | ((ra[t] + 1u) & 63u); \
 				jr[t] += 1u; \
+				head[t] = s_win[rh_and_or(jr[t], 63u, ringb[t])];   /* (wanted at this region's next pop, at least a step away) */ \
 			} \
 		} while (0)
 	while (k < nh) {
 		const uint32_t lk = k & 63u, sk = RPL == 1 ? 0u : k >> 6;
 		const uint32_t endk = BS_TK_READ(en, sk, lk);
-		if (k) { const uint32_t jk = BS_TK_READ(jr, sk, lk); if (lane == 0) { const uint32_t dk = M.act[k]; M.J[dk] = jk - M.hst[dk]; } }   // arrivals so far = J
+		if (k) { const uint32_t jk = BS_TK_READ(jr, sk, lk); if (lane == 0) { const uint32_t dk = M.act[k]; M.J[dk] = jk - beg - M.hst[dk]; } }   // arrivals so far = J
 		while (BS_TK_READ(jr, sk, lk) < endk) {                      // until region k has no hole left (then the next one becomes the base)
-			uint32_t d, i0, j;
+			uint32_t d, i0, j, d2, j2;
 			BS_TK_POP(k, d, i0);                                      // the hole that starts a cycle (its record belongs elsewhere: d != k)
-			uint32_t prev = i0;
-			do {
-				const uint32_t c = d;
-				BS_TK_POP(c, d, j);
-				BS_TK_LOG(prev, j);                                   // the record carried from `prev` lands in this hole
-				prev = j;
-			} while (d != k);
-			BS_TK_LOG(prev, i0);                                      // ... and the one that belongs to k in the hole the cycle started from
+			j2 = i0;
+			for (;;) {	// (two steps an iteration: the carried values change names instead of registers)
+				BS_TK_POP(d, d2, j);
+				BS_TK_LOG(j2, j);                                     // the record carried from the previous hole lands in this one
+				if (d2 == k) break;
+				BS_TK_POP(d2, d, j2);
+				BS_TK_LOG(j, j2);
+				if (d == k) { j = j2; break; }
+			}
+			BS_TK_LOG(j, i0);                                         // ... and the one that belongs to k in the hole the cycle started from
 		}
 		++k;
 	}
-	if (lane < nlog) dest[logA] = logV;
+	if (lane < nlog) C.dest[logA] = logV - beg;
 	#undef BS_TK_LOG
 	#undef BS_TK_POP
 	#undef BS_TK_RING

@@ -31,7 +31,9 @@ __device__ __forceinline__ uint32_t rh_readlane(uint32_t v, uint32_t l) { return
 // v with lane l := val; val and l must be wave-uniform values produced by scalar instructions (the s_and / s_add of the
 // callers), which keeps clear of the "VALU-written SGPR as lane select" hazard the assembler cannot see inside asm
 __device__ __forceinline__ uint32_t rh_writelane(uint32_t v, uint32_t val, uint32_t l) { asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(l) : "m0"); return v; }   // (one SGPR + M0: constant-bus limit)
+__device__ __forceinline__ void rh_writelane2(uint32_t &a, uint32_t &b, uint32_t va, uint32_t vb, uint32_t l) { asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(a), "+v"(b) : "s"(va), "s"(vb), "s"(l) : "m0"); }   // two registers, same lane: one M0 load
 __device__ __forceinline__ uint32_t rh_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t rh_and_or(uint32_t a, uint32_t m, uint32_t o) { uint32_t r; asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(m), "v"(o)); return r; }   // (a & m) | o in one instruction
 // value of lane (l & ~1) / (l | 1) of each lane pair (DPP quad permutes: VALU speed, no LDS)
 __device__ __forceinline__ int32_t rh_quad_perm_0022(int32_t v) { return __builtin_amdgcn_mov_dpp(v, 0xA0, 0xF, 0xF, true); }
 __device__ __forceinline__ int32_t rh_quad_perm_1133(int32_t v) { return __builtin_amdgcn_mov_dpp(v, 0xF5, 0xF, 0xF, true); }
@@ -43,7 +45,9 @@ __device__ int32_t rh_quad_perm_0022(int32_t v);
 __device__ int32_t rh_quad_perm_1133(int32_t v);
 __device__ uint32_t rh_readlane(uint32_t v, uint32_t l);
 __device__ uint32_t rh_writelane(uint32_t v, uint32_t val, uint32_t l);
+__device__ void rh_writelane2(uint32_t &a, uint32_t &b, uint32_t va, uint32_t vb, uint32_t l);
 __device__ uint32_t rh_uniform(uint32_t v);
+__device__ uint32_t rh_and_or(uint32_t a, uint32_t m, uint32_t o);
 #endif
 
 // pin a wave-uniform 32-bit value to a scalar register here (phis of long uniform loops otherwise drift into VGPRs, and every

@@ -62,7 +62,9 @@ static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if 
 
 static inline unsigned rh_readlane(unsigned v, unsigned l) { return (unsigned)emu_shfl_bits(v, 5, l); }
 static inline unsigned rh_writelane(unsigned v, unsigned val, unsigned l) { return (threadIdx.x & 63u) == l ? val : v; }
+static inline void rh_writelane2(unsigned &a, unsigned &b, unsigned va, unsigned vb, unsigned l) { if ((threadIdx.x & 63u) == l) { a = va; b = vb; } }
 static inline unsigned rh_uniform(unsigned v) { return v; }
+static inline unsigned rh_and_or(unsigned a, unsigned m, unsigned o) { return (a & m) | o; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline unsigned rh_wave_shr1(unsigned v, unsigned first) { const unsigned up = (unsigned)emu_shfl_bits(v, 3, 1u); return (threadIdx.x & 63u) == 0 ? first : up; }
