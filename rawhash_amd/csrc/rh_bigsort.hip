@@ -1086,7 +1086,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		sj.src = C.buf[q >> 1]; sj.dst = jb.dst; sj.need_exact = nullptr; sj.n_max = pin[8 + q] < n_lo ? pin[8 + q] : n_lo;   // (an LDS class above the list's largest bucket would be a launch of blocks that all leave at once, each waiting for its LDS)
 		if ((q & 1) && !job32) { sj.kc_on = 1; sj.kc_lo = 32; sj.kc_mid = 0; sj.kc_hi = 0; }   // keys that differ below bit 32 only: 32-bit words in LDS
 		sj.big_alt = nullptr; sj.big_ws = nullptr;
-		sj.any_order = 0; sj.redo_skip = nullptr; sj.n_redo = nullptr;
+		sj.any_order = 0; sj.redo_skip = nullptr; sj.n_redo = nullptr; sj.cnt_rw = C.small_cnt[q];
 		if (rhk_sort_job(s, sj, all_exact, 1u)) return -1;
 	}
 	if (jb.any_order) {

@@ -159,6 +159,9 @@ struct rh_sort_job {
 	// redo_skip[a] = 0 for the segments that hold equal keys (the caller redoes them with any_order = 0 and skip = redo_skip),
 	// 1 for all others; *n_redo (host) = their number
 	uint8_t any_order; uint8_t *redo_skip; uint32_t *n_redo;
+	// cnt[] may be rewritten (the bucket lists of rh_bigsort.hip): the wavefront-per-segment sorter zeroes the count of a segment it
+	// has finished, so that the LDS classes launched after it pass over it
+	uint32_t *cnt_rw;
 };
 int rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n);   // segments with <= min_n records are left alone
 uint32_t rhk_sort_lds_max(const rh_sort_job &jb);                        // longest segment the LDS classes take for this job's keys

@@ -606,6 +606,148 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 	if (tid < SORT_TG && tid < L.n_tg && L.tg_fin[tid] != 0xFFFFu) dst[L.tg_fin[tid]] = src[L.tg_idx[tid]];   // settled by pop order
 }
 
+// Segments of up to RH_SORT_TINY records - klib sorts a range of <= 64 with its insertion sort (ksort.h:139-151), i.e. any STABLE
+// sort reproduces it, equal keys included.  A workgroup per such segment is a launch of millions of workgroups that each move a
+// dozen records (the region sort of an unmappable read ends in ~6000 buckets of ~10 chains): here ONE LANE takes a segment.  Keys
+// that agree above bit 26 (a bucket of the level-by-level sorter: always) are sorted as words (key bits << 5 | position) by a
+// bitonic network in the lane's registers, the position in the low bits making the order stable; other keys are ranked by
+// counting.  Records are read through the L1 (a wavefront's segments are neighbours in memory) and written once.
+#define RH_SORT_TINY 32
+__global__ __launch_bounds__(NT) void k_sort_tiny(rh_sort_job jb, uint32_t n_lo)
+{
+	const uint32_t a = blockIdx.x * NT + threadIdx.x;
+	uint32_t n = 0;
+	uint64_t base = 0;
+	if (a < jb.n_seg && !(jb.skip && jb.skip[a])) { base = jb.off[a]; n = jb.cnt ? jb.cnt[a] : (uint32_t)(jb.off[a + 1] - base); }
+	const bool mine = n > n_lo && n <= (uint32_t)RH_SORT_TINY;
+	if (__ballot(mine) == 0) return;
+	const rh_mm128_t *src = jb.src + base;
+	rh_mm128_t *dst = jb.dst + base;
+	uint32_t c[RH_SORT_TINY];
+	uint64_t k0 = 0, dif = 0;
+#pragma unroll
+	for (int j = 0; j < RH_SORT_TINY; ++j) {
+		c[j] = 0xFFFFFFFFu;
+		if (mine && (uint32_t)j < n) {
+			const uint64_t k = src[j].x;
+			if (j == 0) k0 = k;
+			dif |= k ^ k0;
+			c[j] = (uint32_t)k << 5 | (uint32_t)j;
+		}
+	}
+	const bool narrow = mine && (dif >> 27) == 0, wide = mine && !narrow;
+	bool tie = false;
+	if (__ballot(narrow)) {
+		if (__ballot(narrow && n > 16)) {
+#pragma unroll
+			for (int kk = 2; kk <= 32; kk <<= 1)
+#pragma unroll
+				for (int jj = kk >> 1; jj > 0; jj >>= 1)
+#pragma unroll
+					for (int i = 0; i < 32; ++i) {
+						const int l2 = i ^ jj;
+						if (l2 > i) { const uint32_t lo = c[i] < c[l2] ? c[i] : c[l2], hi = c[i] < c[l2] ? c[l2] : c[i]; if ((i & kk) == 0) { c[i] = lo; c[l2] = hi; } else { c[i] = hi; c[l2] = lo; } }
+					}
+		} else {
+#pragma unroll
+			for (int kk = 2; kk <= 16; kk <<= 1)
+#pragma unroll
+				for (int jj = kk >> 1; jj > 0; jj >>= 1)
+#pragma unroll
+					for (int i = 0; i < 16; ++i) {
+						const int l2 = i ^ jj;
+						if (l2 > i) { const uint32_t lo = c[i] < c[l2] ? c[i] : c[l2], hi = c[i] < c[l2] ? c[l2] : c[i]; if ((i & kk) == 0) { c[i] = lo; c[l2] = hi; } else { c[i] = hi; c[l2] = lo; } }
+					}
+		}
+		if (narrow) {
+#pragma unroll
+			for (int j = 0; j < RH_SORT_TINY; ++j) if ((uint32_t)j < n) {
+				dst[j] = src[c[j] & 31u];
+				if (j > 0 && (c[j] >> 5) == (c[j - 1] >> 5)) tie = true;
+			}
+		}
+	}
+	if (wide) {	// (rare: keys of a free-standing short segment) rank = records that sort before this one, earlier position first among equals
+		for (uint32_t j = 0; j < n; ++j) {
+			const rh_mm128_t rj = src[j];
+			uint32_t rank = 0;
+			for (uint32_t i = 0; i < n; ++i) { const uint64_t ki = src[i].x; rank += (ki < rj.x || (ki == rj.x && i < j)) ? 1u : 0u; if (ki == rj.x && i != j) tie = true; }
+			dst[rank] = rj;
+		}
+	}
+	if (mine && jb.need_exact) jb.need_exact[a] = tie ? 1 : 0;
+}
+
+// Buckets of the level-by-level sorter with 33 .. 256 records (the region sort of an unmappable read ends in hundreds of buckets
+// of ~100 chains: millions of them a round): ONE WAVEFRONT per bucket instead of a workgroup with its barriers.  A bucket's keys
+// agree above the byte it was split on; when they agree above bit 23 and no two are equal, the sorted order is unique and any
+// sort gives the reference's result: the lanes hold four words (key bits << 8 | position) each and run a bitonic network
+// (cross-lane steps by ds_bpermute).  Equal keys (adjacent after the sort) or wider keys: the bucket is left, untouched, to the LDS
+// block sorter and its exact passes; a finished bucket's count is zeroed so that those launches pass over it.
+#define RH_SORT_WAVE 256
+__global__ __launch_bounds__(NT) void k_sort_wave(rh_sort_job jb, uint32_t n_lo)
+{
+	constexpr int E = RH_SORT_WAVE / 64;
+	const uint32_t a = blockIdx.x * (NT / 64) + wave_id(), lane = lane_id();
+	if (a >= jb.n_seg) return;
+	const uint32_t n = rh_uniform(jb.cnt_rw[a]);
+	if (n <= n_lo || n > (uint32_t)RH_SORT_WAVE) return;
+	const uint64_t base = jb.off[a];
+	const rh_mm128_t *src = jb.src + base;
+	rh_mm128_t *dst = jb.dst + base;
+	uint32_t w[E];
+	uint64_t dif = 0;
+	const uint64_t first = src[0].x;
+#pragma unroll
+	for (int e = 0; e < E; ++e) {
+		const uint32_t i = lane + 64u * (uint32_t)e;
+		w[e] = 0xFFFFFFFFu;
+		if (i < n) { const uint64_t k = src[i].x; dif |= k ^ first; w[e] = (uint32_t)k << 8 | i; }
+	}
+	if (__ballot((dif >> 24) != 0)) return;                          // wider keys: the block sorter
+#pragma unroll
+	for (int k = 2; k <= RH_SORT_WAVE; k <<= 1) {
+#pragma unroll
+		for (int j = k >> 1; j > 0; j >>= 1) {
+			if (j >= 64) {	// partners in the same lane
+#pragma unroll
+				for (int e = 0; e < E; ++e) {
+					const int pe = e ^ (j >> 6);
+					if (pe > e) {
+						const bool up = ((64 * e) & k) == 0;
+						const uint32_t lo = w[e] < w[pe] ? w[e] : w[pe], hi = w[e] < w[pe] ? w[pe] : w[e];
+						w[e] = up ? lo : hi; w[pe] = up ? hi : lo;
+					}
+				}
+			} else {
+#pragma unroll
+				for (int e = 0; e < E; ++e) {
+					const uint32_t i = lane + 64u * (uint32_t)e;
+					const bool up = (i & (uint32_t)k) == 0, keep_min = ((lane & (uint32_t)j) == 0) == up;
+					const uint32_t p = __shfl_xor(w[e], j);
+					const uint32_t lo = w[e] < p ? w[e] : p, hi = w[e] < p ? p : w[e];
+					w[e] = keep_min ? lo : hi;
+				}
+			}
+		}
+	}
+	bool tie = false;
+#pragma unroll
+	for (int e = 0; e < E; ++e) {
+		const uint32_t i = lane + 64u * (uint32_t)e;
+		uint32_t prev = __shfl_up(w[e], 1);
+		if (e > 0) { const uint32_t last = rh_readlane(w[e > 0 ? e - 1 : 0], 63u); if (lane == 0) prev = last; }
+		if (i > 0 && i < n && (prev >> 8) == (w[e] >> 8)) tie = true;
+	}
+	if (__ballot(tie)) return;                                       // equal keys: the exact passes of the block sorter
+#pragma unroll
+	for (int e = 0; e < E; ++e) {
+		const uint32_t i = lane + 64u * (uint32_t)e;
+		if (i < n) dst[i] = src[w[e] & 255u];
+	}
+	if (lane == 0) jb.cnt_rw[a] = 0;
+}
+
 template <int CAP, class KT>
 static void launch_class(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t lo, uint32_t hi)
 {
@@ -621,6 +763,14 @@ int rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t 
 {
 	if (!jb.n_seg) return 0;
 	uint32_t top;
+	static const bool tiny_on = !(getenv("RH_SORT_TINY") && atoi(getenv("RH_SORT_TINY")) == 0);
+	if (tiny_on && min_n < (uint32_t)RH_SORT_TINY) {	// one lane per segment of up to 32 records
+		RH_LAUNCH(k_sort_tiny, (jb.n_seg + NT - 1) / NT, NT, 0, s, jb, min_n);
+		min_n = (uint32_t)RH_SORT_TINY;
+		if (jb.n_max && jb.n_max <= min_n) return 0;
+	}
+	static const bool wave_on = !(getenv("RH_SORT_WAVE") && atoi(getenv("RH_SORT_WAVE")) == 0);
+	if (wave_on && jb.cnt_rw && !jb.skip && min_n < (uint32_t)RH_SORT_WAVE) RH_LAUNCH(k_sort_wave, (jb.n_seg + NT / 64 - 1) / (NT / 64), NT, 0, s, jb, min_n);   // a wavefront per bucket of up to 256 records (the rest, and its leftovers, below)
 	if (sort_keys32(jb)) {
 		launch_class<RH_SORT_CAP0, uint32_t>(s, jb, all_exact, min_n, (uint32_t)RH_SORT_CAP0);
 		launch_class<RH_SORT32_CAP1, uint32_t>(s, jb, all_exact, (uint32_t)RH_SORT_CAP0, (uint32_t)RH_SORT32_CAP1);

@@ -236,11 +236,15 @@ def check_regions(ctx, wl, seed=0, n_reads=64, max_n=700):
     return checked, with_regs
 
 
-def check_sort(ctx, seed=0, n_seg=40, big=()):
-    """Exact unstable-permutation emulation of radix_sort_128x, with heavy key ties in every byte position."""
+def check_sort(ctx, seed=0, n_seg=40, big=(), tiny=False):
+    """Exact unstable-permutation emulation of radix_sort_128x, with heavy key ties in every byte position.
+    tiny: hundreds of segments of 0 .. 40 records (one lane per segment up to 32), every key kind."""
     rng = np.random.default_rng(seed)
     sizes = rng.integers(0, 900, size=n_seg)
     sizes[:8] = [0, 1, 64, 65, 4096, 4097, 3000, 5500]
+    if tiny:
+        sizes = rng.integers(0, 41, size=n_seg)
+        sizes[:10] = [2, 16, 17, 31, 32, 33, 1, 0, 3, 15]
     if len(big):
         sizes[8:8 + len(big)] = big             # beyond the LDS classes: the workgroup sorter on HBM scratch, all key kinds
     off = np.zeros(n_seg + 1, dtype=np.uint64)

@@ -31,6 +31,7 @@ def test_stage_chain(ctx, wl):
 
 def test_exact_sort(ctx):
     pc.check_sort(ctx, seed=1, n_seg=24)
+    pc.check_sort(ctx, seed=3, n_seg=330, tiny=True)
 
 
 def test_exact_sort_multi_workgroup(ctx, emu_lib_smallcaps):

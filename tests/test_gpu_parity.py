@@ -55,6 +55,7 @@ def test_stage_chain(ctx, wl):
 def test_exact_sort(ctx):
     pc.check_sort(ctx, seed=2, n_seg=400)
     pc.check_sort(ctx, seed=5, n_seg=40, big=(8193, 9000, 20000, 70000, 30000, 12345, 100000, 16384, 50000, 65537, 33333, 9999))
+    pc.check_sort(ctx, seed=6, n_seg=5000, tiny=True)
 
 
 def test_stage_regions(ctx, wl):
