@@ -39,7 +39,7 @@ extern "C" __attribute__((visibility("default"))) int rh_debug_kprof(unsigned lo
 struct sort_kc { uint32_t lo_bits, mid_bits, hi_bits; };
 
 template <int CAP, class KT>
-struct sort_lds {
+struct alignas(16) sort_lds {
 	KT key[CAP];                               // by original index; 32-bit words when the job says its keys fit (sort_kc)
 	uint16_t ia[CAP];                          // current arrangement: position -> original index
 	uint16_t xm[CAP];                          // scratch of a pass: gather map (position -> source position) or rank lists
@@ -300,7 +300,9 @@ RH_DEV void sort_split_range(sort_lds<CAP, KT> &L, uint32_t beg, uint32_t end, i
 	}
 	const uint64_t tm = __ballot(tied);
 	if (lane_id() == 0) L.w[wave_id()] = tm != 0;
-	diff = sort_key_spread(L, block_or64(diff, L.r64));       // (barriers inside publish L.w as well)
+	const bool exact = pass != SORT_FAST;
+	diff = block_or64(diff, L.r64);                           // (barriers inside publish L.w as well)
+	if (exact) diff = sort_key_spread(L, diff);               // (the fast pass works on the stored keys as they are: same order)
 	KPROF(1);
 	if (diff == 0) return;                                   // all keys equal: every remaining pass is an identity
 	// redo pass: a range without tied keys already has its (unique) final order from the fast pass -> nothing to do
@@ -308,13 +310,17 @@ RH_DEV void sort_split_range(sort_lds<CAP, KT> &L, uint32_t beg, uint32_t end, i
 		__syncthreads();                                     // every wave has read the flags before the next range's call rewrites them
 		return;
 	}
-	const bool exact = pass != SORT_FAST;
-	int s = (63 - __clzll(diff)) & ~7;
-	if (s > shift) s = shift;
+	// The byte the reference splits on - or, in the fast pass, the top eight DIFFERING bits wherever they start: a segment without
+	// equal keys has one sorted order, however it is reached, and a chromosome's worth of positions (27 bits) then falls into 256
+	// buckets of a dozen at once instead of 8 buckets that each need a pass of their own.
+	int s;
+	if (exact) { s = (63 - __clzll(diff)) & ~7; if (s > shift) s = shift; }
+	else { s = 63 - __clzll(diff) - 7; if (s < 0) s = 0; }
+	#define SORT_DIGIT(i_) (exact ? sort_digit(L, (i_), s) : (uint32_t)((uint64_t)L.key[L.ia[(i_)]] >> s) & 255u)
 	// digit histogram
 	L.cnt[tid] = 0;
 	__syncthreads();
-	for (uint32_t i = beg + tid; i < end; i += NT) atomicAdd(&L.cnt[sort_digit(L, i, s)], 1u);
+	for (uint32_t i = beg + tid; i < end; i += NT) atomicAdd(&L.cnt[SORT_DIGIT(i)], 1u);
 	__syncthreads();
 	const uint32_t my_cnt = L.cnt[tid];
 	uint32_t total;
@@ -326,7 +332,7 @@ RH_DEV void sort_split_range(sort_lds<CAP, KT> &L, uint32_t beg, uint32_t end, i
 	KPROF(2);
 	// permutation of the pass
 	if (!exact) {
-		for (uint32_t i = beg + tid; i < end; i += NT) { const uint32_t pos = atomicAdd(&L.head[sort_digit(L, i, s)], 1u); L.xm[pos] = (uint16_t)i; }
+		for (uint32_t i = beg + tid; i < end; i += NT) { const uint32_t pos = atomicAdd(&L.head[SORT_DIGIT(i)], 1u); L.xm[pos] = (uint16_t)i; }
 		__syncthreads();
 		KPROF(3);
 		sort_apply_gather<CAP, KT>(L, beg, end);
@@ -385,11 +391,12 @@ RH_DEV void sort_split_range(sort_lds<CAP, KT> &L, uint32_t beg, uint32_t end, i
 	}
 	// children: one bucket per thread
 	if (s > 0 && my_cnt > 1) {
-		if (my_cnt > 64) { const uint32_t k = atomicAdd(&L.n_rng[nxt], 1u); L.rng[nxt][k] = my_start | (my_start + my_cnt) << 16; L.rsh[nxt][k] = (uint8_t)(s - 8); }
+		if (my_cnt > 64) { const uint32_t k = atomicAdd(&L.n_rng[nxt], 1u); L.rng[nxt][k] = my_start | (my_start + my_cnt) << 16; L.rsh[nxt][k] = (uint8_t)(s >= 8 ? s - 8 : 0); }
 		else { const uint32_t e = my_start + my_cnt - 1; atomicOr(&L.sbit[my_start >> 5], 1u << (my_start & 31u)); atomicOr(&L.ebit[e >> 5], 1u << (e & 31u)); }
 	}
 	__syncthreads();
 	KPROF(7);
+	#undef SORT_DIGIT
 }
 
 // the whole radix sort of the n keys in L.key, from the input order, into L.ia
@@ -572,35 +579,67 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 #ifdef RH_KPROF
 	kp_t0 = clock64();
 #endif
-	for (uint32_t i0 = tid; i0 < n; i0 += 4 * NT) {
-		rh_mm128_t rv[4];
-#pragma unroll
-		for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; rv[u] = src[i < n ? L.ia[i] : 0u]; }
-#pragma unroll
-		for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; if (i < n) dst[i] = rv[u]; }
+	// equal keys among the sorted neighbours?  (before the write-out below takes the key array as its staging area)
+	uint32_t tie = 0;
+	if (mode == 0) {
+		for (uint32_t i = tid; i < n; i += NT) {
+			const uint32_t idx = L.ia[i];
+			const KT k = L.key[idx];
+			if ((i > 0 && L.key[L.ia[i - 1]] == k) || (i + 1 < n && L.key[L.ia[i + 1]] == k)) {
+				atomicOr(&L.tbit[idx >> 5], 1u << (idx & 31u));
+				L.tie = 1;
+				uint32_t gs = i;
+				while (gs > 0 && L.key[L.ia[gs - 1]] == k) --gs;
+				const uint32_t slot = atomicAdd(&L.n_tg, 1u);
+				if (slot < SORT_TG) { L.tg_idx[slot] = (uint16_t)idx; L.tg_pos[slot] = (uint16_t)gs; L.tg_fin[slot] = 0xFFFFu; }
+			}
+		}
+		__syncthreads();
+		tie = L.tie;
+		if (tid == 0 && jb.need_exact) jb.need_exact[a] = (uint8_t)tie;
+		KPROF(11);
 	}
-	KPROF(12);
-	if (mode != 0) return;
-	for (uint32_t i = tid; i < n; i += NT) {
-		const uint32_t idx = L.ia[i];
-		const KT k = L.key[idx];
-		if ((i > 0 && L.key[L.ia[i - 1]] == k) || (i + 1 < n && L.key[L.ia[i + 1]] == k)) {
-			atomicOr(&L.tbit[idx >> 5], 1u << (idx & 31u));
-			L.tie = 1;
-			uint32_t gs = i;
-			while (gs > 0 && L.key[L.ia[gs - 1]] == k) --gs;
-			const uint32_t slot = atomicAdd(&L.n_tg, 1u);
-			if (slot < SORT_TG) { L.tg_idx[slot] = (uint16_t)idx; L.tg_pos[slot] = (uint16_t)gs; L.tg_fin[slot] = 0xFFFFu; }
+	// Write-out.  dst[i] = src[ia[i]] straight from HBM is a 16-byte gather per record: with a thousand workgroups in flight the
+	// segments (64 KB each) have left the L2 by now, and random 64-byte sectors come in at a fraction of the sequential rate.  So
+	// the records are streamed once more, in order, through LDS - the key / arrangement / scratch arrays are done with and hold
+	// STG records at a time - and every thread picks the ones its output positions want (kept in registers) from there.
+	{
+		constexpr int K = (CAP + NT - 1) / NT;
+		constexpr uint32_t STG = (uint32_t)((sizeof(KT) + 4u) * (size_t)CAP / 16u);
+		uint16_t iav[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) { const uint32_t i = tid + (uint32_t)k * NT; iav[k] = i < n ? L.ia[i] : (uint16_t)0xFFFFu; }
+		__syncthreads();
+		rh_mm128_t *stage = reinterpret_cast<rh_mm128_t*>(&L);
+		for (uint32_t sb = 0; sb < n; sb += STG) {
+			const uint32_t m = n - sb < STG ? n - sb : STG;
+			for (uint32_t i0 = tid; i0 < m; i0 += 4 * NT) {
+				rh_mm128_t rv[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; rv[u] = src[sb + (i < m ? i : 0u)]; }
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; if (i < m) stage[i] = rv[u]; }
+			}
+			__syncthreads();
+#pragma unroll
+			for (int k = 0; k < K; ++k) {
+				const uint32_t rel = (uint32_t)iav[k] - sb;                 // (0xFFFF: no output position - never below sb + m, n <= CAP < 0xFFFF)
+				if (iav[k] != 0xFFFFu && rel < m) dst[tid + (uint32_t)k * NT] = stage[rel];
+			}
+			__syncthreads();
 		}
 	}
-	__syncthreads();
-	const uint32_t tie = L.tie;
-	if (tid == 0 && jb.need_exact) jb.need_exact[a] = (uint8_t)tie;
-	KPROF(11);
-	if (!tie) return;
+	KPROF(12);
+	if (mode != 0 || !tie) return;
 	// Equal keys: their order is the reference's cycle-leader permutation.  Redo the sort from the input order on the ranges
 	// that hold tied keys only; every other record already sits at its final place, and so does each group of equal keys
-	// as a whole - only the records inside the groups are rewritten.
+	// as a whole - only the records inside the groups are rewritten.  (The keys again: the staging above overwrote them.)
+	for (uint32_t i = tid; i < n; i += NT) {
+		const uint64_t x = src[i].x;
+		if (sizeof(KT) == 8) L.key[i] = (KT)x;
+		else L.key[i] = (KT)((x & ((1ull << kc.lo_bits) - 1ull)) | ((x >> 32) & ((1ull << kc.mid_bits) - 1ull)) << kc.lo_bits | (kc.hi_bits ? x >> 63 : 0ull) << (kc.lo_bits + kc.mid_bits));
+	}
+	__syncthreads();
 	sort_run<CAP, KT>(L, n, SORT_EXACT_TIED);
 	for (uint32_t i = tid; i < n; i += NT) { const uint32_t idx = L.ia[i]; if ((L.tbit[idx >> 5] >> (idx & 31u)) & 1u) dst[i] = src[idx]; }
 	if (tid < SORT_TG && tid < L.n_tg && L.tg_fin[tid] != 0xFFFFu) dst[L.tg_fin[tid]] = src[L.tg_idx[tid]];   // settled by pop order

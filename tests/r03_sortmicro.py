@@ -6,7 +6,7 @@ from rawhash_amd import api
 n_seg, seg = int(sys.argv[1]), int(sys.argv[2])
 rng = np.random.default_rng(5)
 a = np.zeros(n_seg * seg, dtype=api.MM128)
-a["x"] = rng.integers(0, 1 << 16, n_seg * seg, dtype=np.uint64) | (np.uint64(3) << np.uint64(32))
+a["x"] = rng.integers(0, 1 << int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 16, n_seg * seg, dtype=np.uint64) | (np.uint64(3) << np.uint64(32))   # argv[3]: key bits (16: heavy ties; 27: a position in a chromosome, hardly any)
 a["y"] = rng.integers(0, 1 << 40, n_seg * seg, dtype=np.uint64)
 off = (np.arange(n_seg + 1, dtype=np.uint64) * np.uint64(seg))
 ctx = api.Context(0)
