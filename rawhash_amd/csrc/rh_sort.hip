@@ -399,6 +399,59 @@ RH_DEV void sort_split_range(sort_lds<CAP, KT> &L, uint32_t beg, uint32_t end, i
 	#undef SORT_DIGIT
 }
 
+// Ranges of up to W records whose keys differ in their low 27 bits only: ONE LANE per range sorts the words
+// (key bits << 5 | position) in registers with a bitonic network - data-independent, no memory, and the position in the low bits
+// makes it stable.  The list: ns pairs (first position, length) in xm, from the front or (back) from the end; a range settled here
+// gets bit 15 of its length set, the others are left to the wavefront path.
+template <int CAP, class KT, int W>
+RH_DEV void sort_lane_ranges(sort_lds<CAP, KT> &L, uint32_t ns, bool back, int pass)
+{
+	const uint32_t tid = threadIdx.x;
+	for (uint32_t q0 = 0; q0 < ns; q0 += NT) {
+		const uint32_t q = q0 + tid, p = back ? (uint32_t)(CAP / 2) - 1u - q : q;
+		uint32_t b = 0, m = 0;
+		if (q < ns) { b = L.xm[2 * p]; m = L.xm[2 * p + 1]; }
+		bool mine = q < ns && m <= (uint32_t)W;
+		if (mine && (((uint64_t)L.key[L.ia[b]] ^ (uint64_t)L.key[L.ia[b + m - 1]]) >> 27) != 0) mine = false;   // cheap look before loading the range
+		if (__ballot(mine) == 0) continue;
+		uint32_t c[W];
+		uint64_t dif = 0, k0 = 0;
+		uint32_t tiedr = 0;
+#pragma unroll
+		for (int j = 0; j < W; ++j) {
+			c[j] = 0xFFFFFFFFu;
+			if (mine && (uint32_t)j < m) {
+				const uint32_t idx = L.ia[b + j];
+				const uint64_t k = (uint64_t)L.key[idx];
+				if (j == 0) k0 = k;
+				dif |= k ^ k0;
+				tiedr |= (L.tbit[idx >> 5] >> (idx & 31u)) & 1u;
+				c[j] = (uint32_t)k << 5 | (uint32_t)j;
+			}
+		}
+		if (mine && (dif >> 27) != 0) mine = false;               // keys differ above bit 26: the wavefront path
+		const bool skip = mine && pass == SORT_EXACT_TIED && !tiedr;   // final since the fast pass
+		if (mine) L.xm[2 * p + 1] = (uint16_t)(m | 0x8000u);          // settled here
+		if (__ballot(mine && !skip) == 0) continue;
+#pragma unroll
+		for (int kk = 2; kk <= W; kk <<= 1)
+#pragma unroll
+			for (int jj = kk >> 1; jj > 0; jj >>= 1)
+#pragma unroll
+				for (int i = 0; i < W; ++i) {
+					const int l2 = i ^ jj;
+					if (l2 > i) { const uint32_t lo = c[i] < c[l2] ? c[i] : c[l2], hi = c[i] < c[l2] ? c[l2] : c[i]; if ((i & kk) == 0) { c[i] = lo; c[l2] = hi; } else { c[i] = hi; c[l2] = lo; } }
+				}
+		if (mine && !skip) {	// the record that was at position (word & 31) moves to the word's rank; all reads before the first write
+			uint16_t nx[W];
+#pragma unroll
+			for (int j = 0; j < W; ++j) nx[j] = (uint32_t)j < m ? L.ia[b + (c[j] & 31u)] : (uint16_t)0;
+#pragma unroll
+			for (int j = 0; j < W; ++j) if ((uint32_t)j < m) L.ia[b + j] = nx[j];
+		}
+	}
+}
+
 // the whole radix sort of the n keys in L.key, from the input order, into L.ia
 template <int CAP, class KT>
 RH_DEV void sort_run(sort_lds<CAP, KT> &L, uint32_t n, int pass)
@@ -430,10 +483,13 @@ RH_DEV void sort_run(sort_lds<CAP, KT> &L, uint32_t n, int pass)
 	// bitonic network - data-independent, no memory, and the position in the low bits makes it stable.  The others (33..64
 	// records, keys differing high up) are ranked by a whole wavefront from its lanes' registers.
 	KPROF(8);
-	if (tid == 0) L.misc[0] = 0;
+	if (tid == 0) { L.misc[0] = 0; L.misc[1] = 0; }
 	__syncthreads();
+	// two lists of the ranges (first position, length) in xm, which is free between passes: up to 16 records from the front, longer
+	// ones from the back - a wavefront whose lanes all hold short ranges runs the 16-word network, a third of the 32-word one
+	constexpr uint32_t QC = CAP / 2;
 	const uint32_t nw32 = (n + 31) / 32;
-	for (uint32_t wi = tid; wi < nw32; wi += NT) {	// list of the ranges: first position, length (xm is free between passes)
+	for (uint32_t wi = tid; wi < nw32; wi += NT) {
 		uint32_t sb = L.sbit[wi];
 		while (sb) {
 			const uint32_t bit = (uint32_t)__builtin_ctz(sb);
@@ -442,70 +498,19 @@ RH_DEV void sort_run(sort_lds<CAP, KT> &L, uint32_t n, int pass)
 			uint32_t ew = L.ebit[wi] >> bit, e = b;
 			if (ew) e = b + (uint32_t)__builtin_ctz(ew);
 			else { uint32_t x = wi + 1; while ((ew = L.ebit[x]) == 0) ++x; e = x * 32 + (uint32_t)__builtin_ctz(ew); }
-			const uint32_t q = atomicAdd(&L.misc[0], 1u);
-			L.xm[2 * q] = (uint16_t)b; L.xm[2 * q + 1] = (uint16_t)(e - b + 1);
+			const uint32_t m = e - b + 1;
+			const uint32_t p = m <= 16u ? atomicAdd(&L.misc[0], 1u) : QC - 1u - atomicAdd(&L.misc[1], 1u);
+			L.xm[2 * p] = (uint16_t)b; L.xm[2 * p + 1] = (uint16_t)m;
 		}
 	}
 	__syncthreads();
-	const uint32_t ns = L.misc[0];
-	for (uint32_t q0 = 0; q0 < ns; q0 += NT) {
-		const uint32_t q = q0 + tid;
-		uint32_t b = 0, m = 0;
-		if (q < ns) { b = L.xm[2 * q]; m = L.xm[2 * q + 1]; }
-		bool mine = q < ns && m <= 32;
-		if (mine && (((uint64_t)L.key[L.ia[b]] ^ (uint64_t)L.key[L.ia[b + m - 1]]) >> 27) != 0) mine = false;   // cheap look before loading the range
-		if (__ballot(mine) == 0) continue;
-		uint32_t c[32];
-		uint64_t dif = 0, k0 = 0;
-		uint32_t tiedr = 0;
-#pragma unroll
-		for (int j = 0; j < 32; ++j) {
-			c[j] = 0xFFFFFFFFu;
-			if (mine && (uint32_t)j < m) {
-				const uint32_t idx = L.ia[b + j];
-				const uint64_t k = (uint64_t)L.key[idx];
-				if (j == 0) k0 = k;
-				dif |= k ^ k0;
-				tiedr |= (L.tbit[idx >> 5] >> (idx & 31u)) & 1u;
-				c[j] = (uint32_t)k << 5 | (uint32_t)j;
-			}
-		}
-		if (mine && (dif >> 27) != 0) mine = false;               // keys differ above bit 26: the wavefront path
-		const bool skip = mine && pass == SORT_EXACT_TIED && !tiedr;   // final since the fast pass
-		if (mine) L.xm[2 * q + 1] = (uint16_t)(m | 0x8000u);          // settled here
-		if (__ballot(mine && !skip) == 0) continue;
-		if (__ballot(mine && !skip && m > 16)) {
-#pragma unroll
-			for (int kk = 2; kk <= 32; kk <<= 1)
-#pragma unroll
-				for (int jj = kk >> 1; jj > 0; jj >>= 1)
-#pragma unroll
-					for (int i = 0; i < 32; ++i) {
-						const int l2 = i ^ jj;
-						if (l2 > i) { const uint32_t lo = c[i] < c[l2] ? c[i] : c[l2], hi = c[i] < c[l2] ? c[l2] : c[i]; if ((i & kk) == 0) { c[i] = lo; c[l2] = hi; } else { c[i] = hi; c[l2] = lo; } }
-					}
-		} else {
-#pragma unroll
-			for (int kk = 2; kk <= 16; kk <<= 1)
-#pragma unroll
-				for (int jj = kk >> 1; jj > 0; jj >>= 1)
-#pragma unroll
-					for (int i = 0; i < 16; ++i) {
-						const int l2 = i ^ jj;
-						if (l2 > i) { const uint32_t lo = c[i] < c[l2] ? c[i] : c[l2], hi = c[i] < c[l2] ? c[l2] : c[i]; if ((i & kk) == 0) { c[i] = lo; c[l2] = hi; } else { c[i] = hi; c[l2] = lo; } }
-					}
-		}
-		if (mine && !skip) {	// the record that was at position (word & 31) moves to the word's rank; all reads before the first write
-			uint16_t nx[32];
-#pragma unroll
-			for (int j = 0; j < 32; ++j) nx[j] = (uint32_t)j < m ? L.ia[b + (c[j] & 31u)] : (uint16_t)0;
-#pragma unroll
-			for (int j = 0; j < 32; ++j) if ((uint32_t)j < m) L.ia[b + j] = nx[j];
-		}
-	}
+	const uint32_t nsA = L.misc[0], nsB = L.misc[1];
+	sort_lane_ranges<CAP, KT, 16>(L, nsA, false, pass);
+	sort_lane_ranges<CAP, KT, 32>(L, nsB, true, pass);
 	__syncthreads();
 	const uint32_t wv = rh_uniform(wave_id());
-	for (uint32_t q = wv; q < ns; q += NT / 64) {
+	for (uint32_t qq = wv; qq < nsA + nsB; qq += NT / 64) {
+		const uint32_t q = qq < nsA ? qq : QC - 1u - (qq - nsA);
 		const uint32_t mm = rh_uniform((uint32_t)L.xm[2 * q + 1]);
 		if (mm & 0x8000u) continue;
 		const uint32_t b = rh_uniform((uint32_t)L.xm[2 * q]), m = mm, l = lane_id();
@@ -557,18 +562,22 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 #endif
 	const sort_kc kc = { jb.kc_lo, jb.kc_mid, jb.kc_hi };
 	if (tid == 0) L.kc = kc;
-	// (four loads in flight per thread: a workgroup's wall time is what its LDS footprint lets the CU overlap with three others)
-	for (uint32_t i0 = tid; i0 < n; i0 += 4 * NT) {
-		uint64_t xs[4];
+	// (every load of a thread in flight at once, up to 16: a workgroup's wall time is round trips to HBM, and what its LDS footprint
+	// lets the CU overlap with three others)
+	{
+		constexpr int KL = (CAP + NT - 1) / NT < 16 ? (CAP + NT - 1) / NT : 16;
+		for (uint32_t i0 = tid; i0 < n; i0 += (uint32_t)KL * NT) {
+			uint64_t xs[KL];
 #pragma unroll
-		for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; xs[u] = i < n ? src[i].x : 0ull; }
+			for (int u = 0; u < KL; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; xs[u] = i < n ? src[i].x : 0ull; }
 #pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const uint32_t i = i0 + (uint32_t)u * NT;
-			const uint64_t x = xs[u];
-			if (i >= n) continue;
-			if (sizeof(KT) == 8) L.key[i] = (KT)x;
-			else L.key[i] = (KT)((x & ((1ull << kc.lo_bits) - 1ull)) | ((x >> 32) & ((1ull << kc.mid_bits) - 1ull)) << kc.lo_bits | (kc.hi_bits ? x >> 63 : 0ull) << (kc.lo_bits + kc.mid_bits));
+			for (int u = 0; u < KL; ++u) {
+				const uint32_t i = i0 + (uint32_t)u * NT;
+				const uint64_t x = xs[u];
+				if (i >= n) continue;
+				if (sizeof(KT) == 8) L.key[i] = (KT)x;
+				else L.key[i] = (KT)((x & ((1ull << kc.lo_bits) - 1ull)) | ((x >> 32) & ((1ull << kc.mid_bits) - 1ull)) << kc.lo_bits | (kc.hi_bits ? x >> 63 : 0ull) << (kc.lo_bits + kc.mid_bits));
+			}
 		}
 	}
 	for (uint32_t i = tid; i < CAP / 32 + 3; i += NT) L.tbit[i] = 0;
@@ -613,12 +622,13 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 		rh_mm128_t *stage = reinterpret_cast<rh_mm128_t*>(&L);
 		for (uint32_t sb = 0; sb < n; sb += STG) {
 			const uint32_t m = n - sb < STG ? n - sb : STG;
-			for (uint32_t i0 = tid; i0 < m; i0 += 4 * NT) {
-				rh_mm128_t rv[4];
+			constexpr int KS = (int)((STG + NT - 1) / NT) < 8 ? (int)((STG + NT - 1) / NT) : 8;   // loads in flight per thread
+			for (uint32_t i0 = tid; i0 < m; i0 += (uint32_t)KS * NT) {
+				rh_mm128_t rv[KS];
 #pragma unroll
-				for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; rv[u] = src[sb + (i < m ? i : 0u)]; }
+				for (int u = 0; u < KS; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; rv[u] = src[sb + (i < m ? i : 0u)]; }
 #pragma unroll
-				for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; if (i < m) stage[i] = rv[u]; }
+				for (int u = 0; u < KS; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; if (i < m) stage[i] = rv[u]; }
 			}
 			__syncthreads();
 #pragma unroll

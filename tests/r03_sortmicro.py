@@ -14,3 +14,14 @@ for rep in range(3):
     t = time.time(); out = ctx.sort128x(a, off); print("rep", rep, time.time() - t, flush=True)
 x = out["x"].reshape(n_seg, seg)
 print("sorted", bool((np.diff(x.astype(np.int64), axis=1) >= 0).all()))
+if os.environ.get("RH_KPROF_PRINT"):   # library built with RH_HIPCC_EXTRA=-DRH_KPROF: shader-clock cycles per phase of k_sort_block, summed over workgroups
+    import ctypes
+    from rawhash_amd import _capi
+    lib = _capi.lib()
+    out = (ctypes.c_ulonglong * 32)()
+    lib.rh_debug_kprof.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    lib.rh_debug_kprof(out, 1)
+    names = {1: "diff / tie reduce", 2: "histogram + scan", 3: "fast scatter", 4: "apply gather", 5: "two buckets", 6: "cycle walk", 7: "children", 8: "(levels, incl. 1-7)", 9: "ranges <= 64", 10: "load keys", 11: "tie scan", 12: "write-out"}
+    tot = sum(out[i] for i in names if i != 8)
+    for i, nm in names.items():
+        print(f"{nm:22s} {out[i] / 1e6 / 3 / n_seg:10.4f} Mcyc per workgroup-equivalent x1e0 {100 * out[i] / max(tot, 1):5.1f}%")
