@@ -1033,6 +1033,8 @@ __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads
 					uint32_t lo = 0, hi = kk;                           // first j with sqs[j] > from_s
 					while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (L.sqs[mid] > from_s) hi = mid; else lo = mid + 1; }
 					int32_t reach = si, cov = 0, uncov = 0;
+					uint64_t ovm = 0;                                   // which of the 64 primaries from lo on overlap the chain (the sweep finds them; the masking test below looks at those only)
+					bool ov_far = hard;                                 // ... one further on does (or no sweep was made): the masking test scans the stretch itself
 					if (!hard) {
 						for (uint32_t j = lo; j < kk; ++j) {
 							const int32_t s = L.sqs[j], e = L.sqe[j];
@@ -1041,21 +1043,27 @@ __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads
 								const int32_t cs = s < si ? si : s, ce = e > ei ? ei : e, from = cs > reach ? cs : reach;
 								if (ce > from) cov += ce - from;
 								if (ce > reach) reach = ce;
+								if (j - lo < 64u) ovm |= 1ull << (j - lo); else ov_far = true;
 							}
 						}
 						uncov = (ei - si) - cov;
 					}
 					int32_t first = 0x7FFFFFFF;                        // the first primary IN LIST ORDER that masks the chain (hit.c:231-246)
-					for (uint32_t j = lo; j < kk; ++j) {
-						const int32_t sj = L.sqs[j], ej = L.sqe[j];
-						if (sj >= ei) break;
-						if (ej > si) {
-							const int32_t mn = ej - sj < ei - si ? ej - sj : ei - si;
-							const int32_t mx = ej - sj > ei - si ? ej - sj : ei - si;
-							const int32_t ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj) : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
-							if ((float)ol / (float)mn - (float)uncov / (float)mx > o.mask_level && uncov <= o.mask_len) { const int32_t id = (int32_t)L.sid[j]; if (id < first) first = id; }
+					#define RGB_MASK_TEST(j_) do { \
+						const int32_t sj = L.sqs[(j_)], ej = L.sqe[(j_)]; \
+						const int32_t mn = ej - sj < ei - si ? ej - sj : ei - si; \
+						const int32_t mx = ej - sj > ei - si ? ej - sj : ei - si; \
+						const int32_t ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj) : (ej < si ? 0 : ej < ei ? ej - si : ei - si); \
+						if ((float)ol / (float)mn - (float)uncov / (float)mx > o.mask_level && uncov <= o.mask_len) { const int32_t id = (int32_t)L.sid[(j_)]; if (id < first) first = id; } } while (0)
+					if (!ov_far) {
+						while (ovm) { const uint32_t j = lo + (uint32_t)__builtin_ctzll(ovm); ovm &= ovm - 1; RGB_MASK_TEST(j); }
+					} else {
+						for (uint32_t j = lo; j < kk; ++j) {
+							if (L.sqs[j] >= ei) break;
+							if (L.sqe[j] > si) RGB_MASK_TEST(j);
 						}
 					}
+					#undef RGB_MASK_TEST
 					sel = first == 0x7FFFFFFF ? -1 : first;
 				}
 				need_eval = false;

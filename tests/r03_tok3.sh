@@ -1,6 +1,6 @@
 #!/bin/bash
 # development aid: sort parity + one-stream / three-stream bench lines of the current build
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "sort" 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "sort or regions" 2>&1 | tail -2
 RH_SUB_BATCHES=1 timeout 300 python bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-h2d > gpurun_out/tok3_1s.json 2> gpurun_out/tok3.err < /dev/null
 timeout 300 python bench.py --steps 3 --warmup 1 --cpu-sample 2000 --no-h2d > gpurun_out/tok3_3s.json 2>> gpurun_out/tok3.err < /dev/null
 python - <<PY
