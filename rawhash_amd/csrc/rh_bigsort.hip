@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <vector>
 #include <cstdlib>
+#include <atomic>
 #include "rh_kernels.h"
 #include "rh_devutil.h"
 
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(NT) void k_bs_init(rh_sort_job jb, bs_ctx C)
 		if (tid == 0) { s_run[0] += tot_r; s_run[1] += tot_t; }
 		__syncthreads();
 	}
-	if (tid == 0) { C.hdr[0] = s_run[0]; C.hdr[1] = s_run[1]; C.hdr[2] = 0; C.hdr[3] = 0; C.hdr[4] = 0; C.hdr[5] = 0; C.hdr[6] = 0; C.hdr[7] = s_run[0] > C.rng_cap ? 1u : 0u; C.hdr[8] = 0; C.hdr[9] = 0; C.hdr[10] = 0; C.hdr[11] = 0; C.hdr[12] = 0; }
+	if (tid == 0) { C.hdr[0] = s_run[0]; C.hdr[1] = s_run[1]; C.hdr[2] = 0; C.hdr[3] = 0; C.hdr[4] = 0; C.hdr[5] = 0; C.hdr[6] = 0; C.hdr[7] = s_run[0] > C.rng_cap ? 1u : 0u; C.hdr[8] = 0; C.hdr[9] = 0; C.hdr[10] = 0; C.hdr[11] = 0; C.hdr[12] = 0; C.hdr[13] = 0; C.hdr[14] = 0; C.hdr[15] = 0; }
 }
 
 __global__ __launch_bounds__(NT) void k_bs_clear(bs_ctx C)
@@ -192,6 +193,73 @@ __global__ __launch_bounds__(NT) void k_bs_hist(bs_ctx C)
 	}
 	__syncthreads();
 	if (s_cnt[tid]) atomicAdd(&C.meta[r].cnt[tid], s_cnt[tid]);
+}
+
+// K1+K2 of level 0 in one read of the keys: the byte a job's first level splits on hardly ever changes between calls (the strand bit
+// of anchor keys, the second byte of chain scores), so the histogram and the digits are taken at the byte the previous call of this
+// kind of job found (`gs`) while the OR / AND are gathered; k_bs_fix0 redoes the ranges whose keys differ on another byte.
+__global__ __launch_bounds__(NT) void k_bs_hist0(bs_ctx C, int gs)
+{
+	__shared__ uint32_t s_r;
+	__shared__ uint32_t s_cnt[256];
+	__shared__ uint64_t s_red[2 * (NT / 64)];
+	const uint32_t n_rng = C.hdr[0], tid = threadIdx.x;
+	if (blockIdx.x >= C.hdr[1]) return;
+	const uint32_t r = bs_find_range(C, blockIdx.x, n_rng, &s_r);
+	const bs_range R = C.rng[0][r];
+	const uint32_t t0 = (blockIdx.x - R.tile0) * BS_TILE;
+	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
+	uint8_t *dg = C.dg + R.beg;
+	s_cnt[tid] = 0;
+	__syncthreads();
+	uint64_t vo = 0, va = ~0ull;
+#pragma unroll
+	for (int it = 0; it < BS_TILE_IT; ++it) {
+		const uint32_t p = t0 + (uint32_t)it * NT + tid;
+		if (p < R.n) {
+			const uint64_t k = src[p].x;
+			vo |= k; va &= k;
+			const uint32_t d = (uint32_t)(k >> gs) & 255u;
+			dg[p] = (uint8_t)d;
+			atomicAdd(&s_cnt[d], 1u);
+		}
+	}
+	for (int d = 32; d > 0; d >>= 1) { vo |= __shfl_xor(vo, d); va &= __shfl_xor(va, d); }
+	if (lane_id() == 0) { s_red[2 * wave_id()] = vo; s_red[2 * wave_id() + 1] = va; }
+	__syncthreads();
+	if (s_cnt[tid]) atomicAdd(&C.meta[r].cnt[tid], s_cnt[tid]);
+	if (tid == 0) {
+		for (uint32_t q = 1; q < NT / 64; ++q) { vo |= s_red[2 * q]; va &= s_red[2 * q + 1]; }
+		atomicOr((unsigned long long*)&C.meta[r].k_or, (unsigned long long)vo);
+		atomicAnd((unsigned long long*)&C.meta[r].k_and, (unsigned long long)va);
+	}
+}
+
+// level 0, one workgroup per range: hdr[14] = 1 + the byte shift some range of the level really splits on (what the host remembers
+// for the next job of this kind), and - after k_bs_hist0 - histogram and digits of a range that splits on another byte than `gs`
+// (hdr[13] counts them) redone from its keys
+__global__ __launch_bounds__(NT) void k_bs_fix0(bs_ctx C, int gs)
+{
+	__shared__ uint32_t s_cnt[256];
+	const uint32_t r = blockIdx.x, tid = threadIdx.x;
+	if (r >= C.hdr[0]) return;
+	const bs_range R = C.rng[0][r];
+	bs_meta &M = C.meta[r];
+	const int s = bs_level_shift(M, R.shift);
+	if (tid == 0 && s >= 0 && (s != gs || r == 0)) C.hdr[14] = (uint32_t)s + 1u;
+	if (gs < 0 || s == gs) return;
+	if (tid == 0) atomicAdd(&C.hdr[13], 1u);
+	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
+	uint8_t *dg = C.dg + R.beg;
+	s_cnt[tid] = 0;
+	__syncthreads();
+	for (uint32_t p = tid; p < R.n; p += NT) {
+		const uint32_t d = s < 0 ? 0u : (uint32_t)(src[p].x >> s) & 255u;
+		dg[p] = (uint8_t)d;
+		atomicAdd(&s_cnt[d], 1u);
+	}
+	__syncthreads();
+	M.cnt[tid] = s_cnt[tid];
 }
 
 // K2b: a range that came with its digits (has_dg) and turns out to agree on the byte they were taken from - its histogram has one
@@ -969,6 +1037,8 @@ __global__ __launch_bounds__(NT) void k_bs_next(bs_ctx C)
 }
 
 // ------------------------------------------------------------------------------------------------ host
+#define BS_KINDS 8
+static std::atomic<int> g_bs_guess[BS_KINDS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };   // per kind of job (rh_sort_job.kind): byte shift its first level split on last time
 size_t rhk_bigsort_ws_bytes(uint64_t total, uint32_t n_lo)
 {
 	const uint64_t t = total ? total : 1, lo = n_lo ? n_lo : 1;
@@ -1010,21 +1080,31 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	static const uint32_t tok_max = getenv("RH_BS_TOK_MAX") ? (uint32_t)strtoul(getenv("RH_BS_TOK_MAX"), nullptr, 10) : 0xFFFFFFFFu;
 	static const bool tok2 = !(getenv("RH_BS_TOK2") && atoi(getenv("RH_BS_TOK2")) == 0);   // two regions per lane for ranges with 65 .. 128 regions that have holes (the candidate sort's first level; measured +2 % on one stream)
 	static const bool tok4 = getenv("RH_BS_TOK4") != nullptr;       // development aid: four regions per lane for ranges with more than 64 regions that have holes
+	// the byte the first level of this kind of job split on last time (-1: not known yet; RH_BS_NO_GUESS: never used)
+	static const bool no_guess = getenv("RH_BS_NO_GUESS") != nullptr;   // development aid
+	const uint32_t kind = jb.kind < BS_KINDS ? jb.kind : 0u;
+	const int gs = no_guess ? -1 : g_bs_guess[kind].load(std::memory_order_relaxed);
+	uint32_t n_rng0 = 0;
 	hipEvent_t ev[4] = {};
 	if (trace) for (auto &e : ev) (void)hipEventCreate(&e);
 	for (int level = 0; level < 9; ++level) {
-		RH_HIP(hipMemcpyAsync(pin, C.hdr, 48, hipMemcpyDeviceToHost, s));
+		RH_HIP(hipMemcpyAsync(pin, C.hdr, 64, hipMemcpyDeviceToHost, s));
 		RH_HIP(hipStreamSynchronize(s));
 		const uint32_t n_rng = pin[0], n_tiles = pin[1];
+		if (level == 1 && pin[14] && (gs < 0 || 2u * pin[13] > n_rng0)) g_bs_guess[kind].store((int)pin[14] - 1, std::memory_order_relaxed);   // most ranges split elsewhere (or nothing was known): the next job of this kind starts from what this one found
 		if (pin[7]) { rh_set_error(pin[7] == 2 ? "segment sorter: a token walk made no progress" : "segment sorter: range / segment list overflow"); return -1; }
 		if (n_rng == 0) break;
 		if (trace) (void)hipEventRecord(ev[0], s);
 		C.dg = dgb[level & 1]; C.dg_next = dgb[(level & 1) ^ 1];
 		RH_LAUNCH(k_bs_tile_map, (n_tiles + NT - 1) / NT, NT, 0, s, C);
 		RH_LAUNCH(k_bs_clear, n_rng, NT, 0, s, C);
-		RH_LAUNCH(k_bs_diff, n_tiles, NT, 0, s, C);
-		RH_LAUNCH(k_bs_hist, n_tiles, NT, 0, s, C);
+		if (level == 0 && gs >= 0) RH_LAUNCH(k_bs_hist0, n_tiles, NT, 0, s, C, gs);   // OR / AND and the histogram at the remembered byte in one read of the keys
+		else {
+			RH_LAUNCH(k_bs_diff, n_tiles, NT, 0, s, C);
+			RH_LAUNCH(k_bs_hist, n_tiles, NT, 0, s, C);
+		}
 		if (level) RH_LAUNCH(k_bs_fix, n_rng, NT, 0, s, C);
+		else { RH_LAUNCH(k_bs_fix0, n_rng, NT, 0, s, C, gs); n_rng0 = n_rng; }
 		RH_LAUNCH(k_bs_plan, n_rng, NT, 0, s, C);
 		if (jb.any_order) {	// no holes, no walk: tiles reserve stretches of their buckets
 			RH_LAUNCH(k_bs_scatter_any, n_tiles, NT, 0, s, C);

@@ -162,6 +162,9 @@ struct rh_sort_job {
 	// cnt[] may be rewritten (the bucket lists of rh_bigsort.hip): the wavefront-per-segment sorter zeroes the count of a segment it
 	// has finished, so that the LDS classes launched after it pass over it
 	uint32_t *cnt_rw;
+	// which sort of the path this is (1 anchors, 2 chain candidates, 3 chains, 4 regions, 0 anything else): the multi-workgroup sorter
+	// remembers per kind the byte its first level split on (rh_bigsort.hip: k_bs_hist0)
+	uint8_t kind;
 };
 int rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n);   // segments with <= min_n records are left alone
 uint32_t rhk_sort_lds_max(const rh_sort_job &jb);                        // longest segment the LDS classes take for this job's keys

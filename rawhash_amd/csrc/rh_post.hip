@@ -1380,6 +1380,7 @@ int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 	// candidates (score, anchor index) -> reference order; scores are full of ties: exact permutation for every read
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_z, r.raw, r.zs, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 64, (uint8_t)(o.min_sc >= 0), 32, 0, 0, r.max_anchors };   // keys = scores >= min_sc: non-negative int32
 	sort_scratch(jb, r, r.prev_out);                               // (the carry staging is written by k_chain_gather, later)
+	jb.kind = 2;
 	return rhk_sort_job(s, jb, true, 0u);
 }
 
@@ -1391,6 +1392,7 @@ int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, co
 	RH_LAUNCH(k_chain_gather, r.n_act, NT, 0, s, r);
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };   // keys = first anchors
 	sort_scratch(jb, r, r.anc);                                    // (k_chain_gather has copied every chain out of the sorted anchors; k_chain_reorder rewrites them)
+	jb.kind = 3;
 	if (rhk_sort_job(s, jb, false, 0u)) return -1;
 	RH_LAUNCH(k_chain_reorder, r.n_act, NT, 0, s, rd, r);
 	return 0;
@@ -1405,6 +1407,7 @@ int rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd,
 	RH_LAUNCH(k_regions_prep, r.n_act, NT, 0, s, o, rd, r, (const uint8_t*)nullptr);
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, 0, 0, 0, 0, r.max_anchors };   // keys = hashed: full 64 bits
 	sort_scratch(jb, r, r.prev_out);                               // (the carried anchors have left the staging: the round loop packs them before this sort)
+	jb.kind = 4;
 	// The keys are score << 32 | (count ^ 32-bit hash): two of a read's chains agree on one with probability ~2^-32 per pair, so the
 	// long segments (unmappable reads: tens of thousands of chains) are placed without the token walks, the few reads that do hold
 	// equal keys are found afterwards and only they are sorted again with the exact passes (need_exact is idle here: rhk_regions

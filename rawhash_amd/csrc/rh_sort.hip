@@ -846,5 +846,6 @@ int rhk_sort(hipStream_t s, const rh_dev_round &r)
 {
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, nullptr, r.raw, r.anc, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 0, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };
 	sort_scratch(jb, r, r.zs);                                     // (the candidate array is idle until the chain DP has run)
+	jb.kind = 1;
 	return rhk_sort_job(s, jb, false, 0u);
 }
