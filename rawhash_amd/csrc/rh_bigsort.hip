@@ -413,10 +413,19 @@ __global__ __launch_bounds__(NT) void k_bs_count(bs_ctx C)
 	const uint32_t t0 = (blockIdx.x - R.tile0) * BS_TILE;
 	bs_cls q;
 	const uint32_t holes = bs_classify(C.dg + R.beg, s_start, t0, R.n, s_cw, q);
+	// (a wavefront's 64 consecutive positions lie in one region or two: one LDS atomic per region and wavefront, not one per
+	// in-place record on the same word)
 #pragma unroll
 	for (int it = 0; it < BS_TILE_IT; ++it) {
 		const uint32_t p = t0 + (uint32_t)it * NT + tid;
-		if (p < R.n && q.d[it] == q.b[it]) atomicAdd(&s_inpl[q.d[it]], 1u);
+		const bool inp = p < R.n && q.d[it] == q.b[it];
+		uint64_t m = __ballot(inp);
+		while (m) {
+			const uint32_t bl = (uint32_t)__shfl((int)q.b[it], __ffsll((unsigned long long)m) - 1);
+			const uint64_t same = __ballot(inp && q.b[it] == bl);
+			if (lane_id() == 0) atomicAdd(&s_inpl[bl], (uint32_t)__popcll(same));
+			m &= ~same;
+		}
 	}
 	__syncthreads();
 	if (s_inpl[tid]) atomicAdd(&C.meta[r].inpl[tid], s_inpl[tid]);
@@ -1085,6 +1094,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	const uint32_t kind = jb.kind < BS_KINDS ? jb.kind : 0u;
 	const int gs = no_guess ? -1 : g_bs_guess[kind].load(std::memory_order_relaxed);
 	uint32_t n_rng0 = 0;
+	static const int walk_reps = getenv("RH_BS_WALK_REPS") ? atoi(getenv("RH_BS_WALK_REPS")) : 1, scat_reps = getenv("RH_BS_SCAT_REPS") ? atoi(getenv("RH_BS_SCAT_REPS")) : 1;   // development aid: the (idempotent) walks / placement launched several times - what a pass costs the step with the other streams' kernels around it
 	hipEvent_t ev[4] = {};
 	if (trace) for (auto &e : ev) (void)hipEventCreate(&e);
 	for (int level = 0; level < 9; ++level) {
@@ -1119,6 +1129,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		const int lanes = n_rng >= (uint32_t)BS_LANES_MIN_RANGES, multi = !lanes && n_rng >= (uint32_t)BS_MULTI_MIN_RANGES && t < (1ull << 32);   // (k_bs_walk_multi keeps absolute hole addresses in 32 bits)
 		const int tok = !lanes && !walk_old && t < (1ull << 32) && n_rng <= tok_max;   // scalar token, one lane per region (absolute hole addresses in 32 bits): levels too narrow for the walks to fill the chip
 		if (trace) (void)hipEventRecord(ev[1], s);
+		for (int rep = 0; rep < walk_reps; ++rep)
 		if (tok) {
 			RH_LAUNCH(k_bs_walk_wave, n_rng, 64, 0, s, C, 3u, tok4 ? 256u : tok2 ? 128u : 64u);   // two regions with holes: closed form (and, measured faster there, more than 128: one LDS-resident walker per wavefront)
 			RH_LAUNCH((k_bs_walk_tok<1>), n_rng, 64, 0, s, C, 3u, 64u);
@@ -1138,6 +1149,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		}
 		}
 		if (trace) (void)hipEventRecord(ev[2], s);
+		for (int rep = 0; rep < scat_reps; ++rep)
 		RH_LAUNCH(k_bs_scatter, ((n_tiles + 7) / 8) * 8, NT, 0, s, C);
 		RH_LAUNCH(k_bs_next, 1, NT, 0, s, C);
 		if (trace) {
