@@ -1094,6 +1094,9 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	const uint32_t kind = jb.kind < BS_KINDS ? jb.kind : 0u;
 	const int gs = no_guess ? -1 : g_bs_guess[kind].load(std::memory_order_relaxed);
 	uint32_t n_rng0 = 0;
+	// Walk wavefronts live for milliseconds and there are more of them than wave slots: left alone they end up holding every slot of the
+	// chip and the other streams' bandwidth-bound kernels wait behind an issue-bound one.  Unused dynamic LDS caps them per CU.
+	static const uint32_t walk_lds = getenv("RH_BS_WALK_LDS") ? (uint32_t)strtoul(getenv("RH_BS_WALK_LDS"), nullptr, 10) : 0u;
 	static const int walk_reps = getenv("RH_BS_WALK_REPS") ? atoi(getenv("RH_BS_WALK_REPS")) : 1, scat_reps = getenv("RH_BS_SCAT_REPS") ? atoi(getenv("RH_BS_SCAT_REPS")) : 1;   // development aid: the (idempotent) walks / placement launched several times - what a pass costs the step with the other streams' kernels around it
 	hipEvent_t ev[4] = {};
 	if (trace) for (auto &e : ev) (void)hipEventCreate(&e);
@@ -1131,10 +1134,10 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		if (trace) (void)hipEventRecord(ev[1], s);
 		for (int rep = 0; rep < walk_reps; ++rep)
 		if (tok) {
-			RH_LAUNCH(k_bs_walk_wave, n_rng, 64, 0, s, C, 3u, tok4 ? 256u : tok2 ? 128u : 64u);   // two regions with holes: closed form (and, measured faster there, more than 128: one LDS-resident walker per wavefront)
-			RH_LAUNCH((k_bs_walk_tok<1>), n_rng, 64, 0, s, C, 3u, 64u);
-			if (tok2) RH_LAUNCH((k_bs_walk_tok<2>), n_rng, 64, 0, s, C, 65u, 128u);
-			if (tok4) RH_LAUNCH((k_bs_walk_tok<4>), n_rng, 64, 0, s, C, tok2 ? 129u : 65u, 256u);
+			RH_LAUNCH(k_bs_walk_wave, n_rng, 64, walk_lds, s, C, 3u, tok4 ? 256u : tok2 ? 128u : 64u);   // two regions with holes: closed form (and, measured faster there, more than 128: one LDS-resident walker per wavefront)
+			RH_LAUNCH((k_bs_walk_tok<1>), n_rng, 64, walk_lds, s, C, 3u, 64u);
+			if (tok2) RH_LAUNCH((k_bs_walk_tok<2>), n_rng, 64, walk_lds, s, C, 65u, 128u);
+			if (tok4) RH_LAUNCH((k_bs_walk_tok<4>), n_rng, 64, walk_lds, s, C, tok2 ? 129u : 65u, 256u);
 		} else {
 		RH_LAUNCH(k_bs_walk_wave, n_rng, 64, 0, s, C, lanes ? 3u : multi ? 3u : 1u, lanes ? 256u : multi ? (uint32_t)BS_MW_NHM : 0u);
 		if (multi) {	// walks per wavefront: so that the level takes about one wavefront per SIMD (a walk's step time does not depend on how many lanes walk)

@@ -639,7 +639,7 @@ void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 	if (!r.n_act) return;
 	if (o.max_iter <= CH_MAX_ITER) {
 		const uint32_t tiles = r.max_anchors > (uint32_t)CH_TILE ? (r.max_anchors + CH_TILE - 1) / CH_TILE : 1u;
-		RH_LAUNCH(k_chain_wave, r.n_act * tiles, 64, 0, s, o, r, tiles, tiles > 1 ? (uint32_t)CH_TILE : 0u);
+		RH_LAUNCH(k_chain_wave, r.n_act * tiles, 64, rh_wave_lds(), s, o, r, tiles, tiles > 1 ? (uint32_t)CH_TILE : 0u);
 	}
 	else RH_LAUNCH(k_chain_serial, (r.n_act + 63) / 64, 64, 0, s, o, r);
 }

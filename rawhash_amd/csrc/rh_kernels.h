@@ -1,6 +1,7 @@
 // Device-side data structures and kernel launch wrappers of the mapping path (gfx950).
 // Layout: batch-of-reads, structure-of-arrays, CSR offsets; no per-read allocation anywhere.
 #pragma once
+#include <cstdlib>
 #include "rh_gpu.h"
 #include "rh_core.h"
 #include "rh_index.h"
@@ -166,6 +167,9 @@ struct rh_sort_job {
 	// remembers per kind the byte its first level split on (rh_bigsort.hip: k_bs_hist0)
 	uint8_t kind;
 };
+// Unused dynamic LDS handed to the one-wavefront-per-read kernels (development knob RH_WAVE_LDS, bytes): their wavefronts live long, and
+// without a cap per CU they end up holding every wave slot while the other streams' bandwidth-bound kernels wait
+inline uint32_t rh_wave_lds() { static const uint32_t v = getenv("RH_WAVE_LDS") ? (uint32_t)strtoul(getenv("RH_WAVE_LDS"), nullptr, 10) : 0u; return v; }
 int rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n);   // segments with <= min_n records are left alone
 uint32_t rhk_sort_lds_max(const rh_sort_job &jb);                        // longest segment the LDS classes take for this job's keys
 size_t rhk_bigsort_ws_bytes(uint64_t total, uint32_t n_lo);

@@ -1387,7 +1387,7 @@ int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
 {
 	if (!r.n_act) return 0;
-	RH_LAUNCH(k_backtrack_spec, r.n_act, 64, 0, s, o, rd, r);
+	RH_LAUNCH(k_backtrack_spec, r.n_act, 64, rh_wave_lds(), s, o, rd, r);
 	// compact_a: chains gathered, put into the reference's order of their first anchor, written back
 	RH_LAUNCH(k_chain_gather, r.n_act, NT, 0, s, r);
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };   // keys = first anchors
@@ -1434,7 +1434,7 @@ void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, con
 	if (wave_ok) {
 		// one register slot (<= 64 primaries: nearly every read) first; the reads that overflow it again with all slots
 		RH_LAUNCH(k_regions_reg<1>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL, 0);
-		RH_LAUNCH(k_regions_batch, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL);   // reads with many chains / more than 64 primaries
+		RH_LAUNCH(k_regions_batch, r.n_act, 64, rh_wave_lds(), s, o, rd, r, logf_tab, (uint32_t)RG_SMALL);   // reads with many chains / more than 64 primaries
 		if (RGR_SLOTS > 1) RH_LAUNCH(k_regions_reg<RGR_SLOTS>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL, 1);
 		RH_LAUNCH(k_regions_wave<RGW_CAP0>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL);
 		RH_LAUNCH(k_regions_wave<RGW_CAP>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RGW_CAP0);
