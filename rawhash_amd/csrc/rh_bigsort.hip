@@ -826,7 +826,7 @@ __global__ __launch_bounds__(64) void k_bs_walk_multi(bs_ctx C)
 // Everything the token touches must stay wave-uniform: one lane-dependent branch out of the walk loop and the compiler keeps every
 // token register in a VGPR (a v_readfirstlane per use).
 #define BS_TK_PERIOD 32
-template <int RPL>
+template <int RPL, int ADV = 0>
 __global__ __launch_bounds__(64) void k_bs_walk_tok(bs_ctx C, uint32_t nh_lo, uint32_t nh_hi)
 {
 	static_assert(BS_TK_PERIOD == 32 && BS_MW_RING == 64, "the no-underflow argument above is for these");
@@ -852,6 +852,7 @@ __global__ __launch_bounds__(64) void k_bs_walk_tok(bs_ctx C, uint32_t nh_lo, ui
 	uint32_t ringb[RPL];
 #pragma unroll
 	for (int t = 0; t < RPL; ++t) ringb[t] = BS_TK_RING(t);
+	const uint32_t ringa0 = rh_lds_addr(s_win) + ringb[0];         // LDS byte address of this lane's first ring
 	#define BS_TK_ISSUE() _Pragma("unroll") for (int t = 0; t < RPL; ++t) { \
 		ld_n[t] = 0; \
 		if (on[t]) { const uint32_t pa_ = jr[t] & ~15u, lm_ = lim[t], ea_ = en[t]; \
@@ -875,18 +876,31 @@ __global__ __launch_bounds__(64) void k_bs_walk_tok(bs_ctx C, uint32_t nh_lo, ui
 	// record found there until one that belongs to k turns up.
 	uint32_t k = 0, nlog = 0, per = BS_TK_PERIOD;
 	uint32_t logA = 0, logV = 0;
-	#define BS_TK_LOG(a_, v_) do { rh_writelane2(logA, logV, (a_), (v_), nlog); if (++nlog == 64u) { C.dest[logA] = logV - beg; nlog = 0; } } while (0)   /* (dest[] holds hole indices within the range) */
+	// ADV (fewer instructions a pop - the walk is bound by the number of instructions a SIMD issues, whatever their kind):
+	//  * ONE log register.  dest[] of a cycle i0 -> j1 -> .. -> jm -> i0 is a chain (the record of a hole lands in the next hole popped), so the
+	//    holes are logged in pop order, a cycle as [i0 (marked in smask: nothing lands from the entry before it), j1, .., jm, i0], and a block is
+	//    stored as dest[entry t-1] = entry t (the lane below by a DPP shift, lane 0 from the previous block's last entry);
+	//  * one counter for the log block and the ring period: a block is 32 entries, and a cycle has one entry more than pops, so a period is at most
+	//    32 pops and the no-underflow argument above holds; the period check leaves the pop.
+	uint32_t carry = 0, smask = 0;
+	#define BS_TK_FLUSH1(n_) do { const uint32_t pv_ = rh_wave_shr1(logV, carry); if (lane < (n_) && !((smask >> lane) & 1u)) C.dest[pv_] = logV - beg; } while (0)
+	#define BS_TK_LOG(a_, v_) do { \
+		if (ADV) { logV = rh_writelane(logV, (v_), nlog); \
+		           if (__builtin_expect(++nlog == 32u, 0)) { BS_TK_COMMIT(); BS_TK_ISSUE() BS_TK_FLUSH1(32u); carry = rh_readlane(logV, 31u); smask = 0; nlog = 0; } } \
+		else { rh_writelane2(logA, logV, (a_), (v_), nlog); if (++nlog == 64u) { C.dest[logA] = logV - beg; nlog = 0; } } } while (0)   /* (dest[] holds hole indices within the range) */
 	// pop region c_: d_ = the digit in its next hole, j_ = that hole; the region's lane moves on
 	#define BS_TK_POP(c_, d_, j_) do { \
 		const uint32_t l_ = RPL == 1 ? (c_) : (c_) & 63u, sl_ = RPL == 1 ? 0u : (c_) >> 6;   /* (one region per lane: c_ < nh <= 64) */ \
-		if (per == 0u) { BS_TK_COMMIT(); BS_TK_ISSUE() per = BS_TK_PERIOD; }   /* a period is over: commit the loads in flight, issue the next */ \
-		--per; \
+		if (!ADV) { if (per == 0u) { BS_TK_COMMIT(); BS_TK_ISSUE() per = BS_TK_PERIOD; }   /* a period is over: commit the loads in flight, issue the next */ \
+		            --per; } \
+		if (RPL == 1 && ADV) rh_lds_wait(head[0]); \
 		d_ = BS_TK_READ(head, sl_, l_); j_ = BS_TK_READ(jr, sl_, l_); \
-		_Pragma("unroll") for (int t = 0; t < RPL; ++t) \
+		if (RPL == 1 && ADV) rh_tok_advance(jr[0], head[0], s_win + ringb[0], ringa0, l_, lane);   /* (rh_gpu.h) */ \
+		else { _Pragma("unroll") for (int t = 0; t < RPL; ++t) \
 			if (lane == l_ && sl_ == (uint32_t)t) { \
 				jr[t] += 1u; \
 				head[t] = s_win[rh_and_or(jr[t], 63u, ringb[t])];   /* (wanted at this region's next pop, at least a step away) */ \
-			} \
+			} } \
 		} while (0)
 	while (k < nh) {
 		const uint32_t lk = k & 63u, sk = RPL == 1 ? 0u : k >> 6;
@@ -895,6 +909,7 @@ __global__ __launch_bounds__(64) void k_bs_walk_tok(bs_ctx C, uint32_t nh_lo, ui
 		while (BS_TK_READ(jr, sk, lk) < endk) {                      // until region k has no hole left (then the next one becomes the base)
 			uint32_t d, i0, j, d2, j2;
 			BS_TK_POP(k, d, i0);                                      // the hole that starts a cycle (its record belongs elsewhere: d != k)
+			if (ADV) { smask |= 1u << nlog; BS_TK_LOG(0u, i0); }
 			j2 = i0;
 			for (;;) {	// (two steps an iteration: the carried values change names instead of registers)
 				BS_TK_POP(d, d2, j);
@@ -908,8 +923,9 @@ __global__ __launch_bounds__(64) void k_bs_walk_tok(bs_ctx C, uint32_t nh_lo, ui
 		}
 		++k;
 	}
-	if (lane < nlog) C.dest[logA] = logV - beg;
+	if (ADV) BS_TK_FLUSH1(nlog); else if (lane < nlog) C.dest[logA] = logV - beg;
 	#undef BS_TK_LOG
+	#undef BS_TK_FLUSH1
 	#undef BS_TK_POP
 	#undef BS_TK_RING
 	#undef BS_TK_ISSUE
@@ -1088,6 +1104,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	static const bool walk_old = getenv("RH_BS_WALK_OLD") != nullptr;   // development aid: the LDS-resident walkers instead of the scalar-token one
 	static const uint32_t tok_max = getenv("RH_BS_TOK_MAX") ? (uint32_t)strtoul(getenv("RH_BS_TOK_MAX"), nullptr, 10) : 0xFFFFFFFFu;
 	static const bool tok2 = !(getenv("RH_BS_TOK2") && atoi(getenv("RH_BS_TOK2")) == 0);   // two regions per lane for ranges with 65 .. 128 regions that have holes (the candidate sort's first level; measured +2 % on one stream)
+	static const bool tok_adv = !(getenv("RH_BS_TOK_ADV") && atoi(getenv("RH_BS_TOK_ADV")) == 0);   // RH_BS_TOK_ADV=0: development aid, the compiler-scheduled pop
 	static const bool tok4 = getenv("RH_BS_TOK4") != nullptr;       // development aid: four regions per lane for ranges with more than 64 regions that have holes
 	// the byte the first level of this kind of job split on last time (-1: not known yet; RH_BS_NO_GUESS: never used)
 	static const bool no_guess = getenv("RH_BS_NO_GUESS") != nullptr;   // development aid
@@ -1135,7 +1152,8 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		for (int rep = 0; rep < walk_reps; ++rep)
 		if (tok) {
 			RH_LAUNCH(k_bs_walk_wave, n_rng, 64, walk_lds, s, C, 3u, tok4 ? 256u : tok2 ? 128u : 64u);   // two regions with holes: closed form (and, measured faster there, more than 128: one LDS-resident walker per wavefront)
-			RH_LAUNCH((k_bs_walk_tok<1>), n_rng, 64, walk_lds, s, C, 3u, 64u);
+			if (tok_adv) RH_LAUNCH((k_bs_walk_tok<1, 1>), n_rng, 64, walk_lds, s, C, 3u, 64u);   // (fewer scalar instructions a pop: rh_tok_advance, one period counter)
+			else RH_LAUNCH((k_bs_walk_tok<1, 0>), n_rng, 64, walk_lds, s, C, 3u, 64u);
 			if (tok2) RH_LAUNCH((k_bs_walk_tok<2>), n_rng, 64, walk_lds, s, C, 65u, 128u);
 			if (tok4) RH_LAUNCH((k_bs_walk_tok<4>), n_rng, 64, walk_lds, s, C, tok2 ? 129u : 65u, 256u);
 		} else {

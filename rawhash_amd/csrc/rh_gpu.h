@@ -34,6 +34,24 @@ __device__ __forceinline__ uint32_t rh_writelane(uint32_t v, uint32_t val, uint3
 __device__ __forceinline__ void rh_writelane2(uint32_t &a, uint32_t &b, uint32_t va, uint32_t vb, uint32_t l) { asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(a), "+v"(b) : "s"(va), "s"(vb), "s"(l) : "m0"); }   // two registers, same lane: one M0 load
 __device__ __forceinline__ uint32_t rh_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t rh_and_or(uint32_t a, uint32_t m, uint32_t o) { uint32_t r; asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(m), "v"(o)); return r; }   // (a & m) | o in one instruction
+// The token walker's per-pop advance of ONE lane (l: wave-uniform, in an SGPR): jr += 1, head = LDS byte at ringa | (jr & 63).
+// v_cmpx selects the lane (EXEC written by the compare itself) and one s_mov restores EXEC - the walker runs with all 64 lanes
+// alive and in wave-uniform control flow - where `if (lane == l)` compiles to v_cmp + s_and_saveexec + s_cbranch_execz + s_or: the
+// walk is bound by SCALAR issue (one scalar unit per CU: an s_ instruction costs a SIMD four cycles), not by vector instructions.
+// The compiler does not see the LDS read: rh_lds_wait(head) before head is used.
+__device__ __forceinline__ void rh_tok_advance(uint32_t &jr, uint32_t &head, const uint8_t *, uint32_t ringa, uint32_t l, uint32_t lane)
+{
+	uint32_t ad;
+	asm volatile("v_cmpx_eq_u32_e32 vcc, %[l], %[ln]\n\t"
+	             "v_add_u32_e32 %[jr], 1, %[jr]\n\t"
+	             "v_and_or_b32 %[ad], %[jr], 63, %[ra]\n\t"
+	             "ds_read_u8 %[hd], %[ad]\n\t"
+	             "s_mov_b64 exec, -1"
+	             : [jr] "+v"(jr), [hd] "+v"(head), [ad] "=&v"(ad)
+	             : [l] "s"(l), [ln] "v"(lane), [ra] "v"(ringa) : "memory", "vcc");
+}
+__device__ __forceinline__ void rh_lds_wait(uint32_t &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)); }
+__device__ __forceinline__ uint32_t rh_lds_addr(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }   // byte offset of a __shared__ object in the workgroup's LDS
 // value of lane (l & ~1) / (l | 1) of each lane pair (DPP quad permutes: VALU speed, no LDS)
 __device__ __forceinline__ int32_t rh_quad_perm_0022(int32_t v) { return __builtin_amdgcn_mov_dpp(v, 0xA0, 0xF, 0xF, true); }
 __device__ __forceinline__ int32_t rh_quad_perm_1133(int32_t v) { return __builtin_amdgcn_mov_dpp(v, 0xF5, 0xF, 0xF, true); }
@@ -41,6 +59,9 @@ __device__ __forceinline__ int32_t rh_quad_perm_1133(int32_t v) { return __built
 __device__ __forceinline__ uint32_t rh_wave_shr1(uint32_t v, uint32_t first) { return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xF, 0xF, false); }
 #else
 __device__ uint32_t rh_wave_shr1(uint32_t v, uint32_t first);
+__device__ void rh_tok_advance(uint32_t &jr, uint32_t &head, const uint8_t *ring, uint32_t ringa, uint32_t l, uint32_t lane);
+__device__ void rh_lds_wait(uint32_t &v);
+__device__ uint32_t rh_lds_addr(const void *p);
 __device__ int32_t rh_quad_perm_0022(int32_t v);
 __device__ int32_t rh_quad_perm_1133(int32_t v);
 __device__ uint32_t rh_readlane(uint32_t v, uint32_t l);

@@ -65,6 +65,9 @@ static inline unsigned rh_writelane(unsigned v, unsigned val, unsigned l) { retu
 static inline void rh_writelane2(unsigned &a, unsigned &b, unsigned va, unsigned vb, unsigned l) { if ((threadIdx.x & 63u) == l) { a = va; b = vb; } }
 static inline unsigned rh_uniform(unsigned v) { return v; }
 static inline unsigned rh_and_or(unsigned a, unsigned m, unsigned o) { return (a & m) | o; }
+static inline void rh_tok_advance(unsigned &jr, unsigned &head, const unsigned char *ring, unsigned, unsigned l, unsigned lane) { if (lane == l) { jr += 1u; head = ring[jr & 63u]; } }
+static inline void rh_lds_wait(unsigned &) {}
+static inline unsigned rh_lds_addr(const void *) { return 0u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline unsigned rh_wave_shr1(unsigned v, unsigned first) { const unsigned up = (unsigned)emu_shfl_bits(v, 3, 1u); return (threadIdx.x & 63u) == 0 ? first : up; }
