@@ -31,6 +31,7 @@
 #define BS_TILE_IT 8                      // records per thread of a tile
 #endif
 #define BS_TILE (NT * BS_TILE_IT)
+#define BS_CW_WORDS ((BS_TILE_IT < 2 ? 2 : BS_TILE_IT) * (NT / 64))   // bs_classify's per-wavefront counts (at least two rows: the regions of a tile's two ends)
 #ifndef BS_WIN_BYTES
 #define BS_WIN_BYTES 4096                 // LDS of the token walk's stream windows (>= 512: two entries for each of 256 regions)
 #endif
@@ -364,7 +365,7 @@ RH_DEV uint32_t bs_region(const uint32_t *start, uint32_t p, uint32_t lo = 0, ui
 }
 
 // For the thread's BS_TILE_IT records of the tile (record `it` at position t0 + it * NT + tid): digit, region, and the
-// number of holes of the tile before it (position order).  s_cw: BS_TILE_IT * (NT / 64) words.  Returns the tile's holes.
+// number of holes of the tile before it (position order).  s_cw: BS_CW_WORDS words.  Returns the tile's holes.
 struct bs_cls { uint32_t d[BS_TILE_IT], b[BS_TILE_IT], hb[BS_TILE_IT]; };
 RH_DEV uint32_t bs_classify(const uint8_t *dg, const uint32_t *s_start, uint32_t t0, uint32_t n, uint32_t *s_cw, bs_cls &q)
 {
@@ -372,7 +373,18 @@ RH_DEV uint32_t bs_classify(const uint8_t *dg, const uint32_t *s_start, uint32_t
 	uint64_t bal[BS_TILE_IT];
 	// a tile lies in one region or a few: the regions of its ends (the same LDS words for every lane) bracket every record's
 	const uint32_t p_last = t0 + BS_TILE - 1u < n ? t0 + BS_TILE - 1u : n - 1u;
-	const uint32_t b_lo = bs_region(s_start, t0), b_hi = bs_region(s_start, p_last, b_lo, 256u);
+	// (region of p = number of buckets whose start is <= p, minus one: the starts do not decrease - one ballot per wavefront for each end
+	// instead of two binary searches of eight dependent LDS reads by every thread)
+	{
+		const uint32_t st = s_start[tid];
+		const uint64_t m_lo = __ballot(st <= t0), m_hi = __ballot(st <= p_last);
+		if (lane_id() == 0) { s_cw[w] = (uint32_t)__popcll(m_lo); s_cw[NT / 64 + w] = (uint32_t)__popcll(m_hi); }
+	}
+	__syncthreads();
+	uint32_t b_lo = 0, b_hi = 0;
+	for (uint32_t ww = 0; ww < NT / 64; ++ww) { b_lo += s_cw[ww]; b_hi += s_cw[NT / 64 + ww]; }
+	b_lo -= 1u; b_hi -= 1u;
+	__syncthreads();
 #pragma unroll
 	for (int it = 0; it < BS_TILE_IT; ++it) {
 		const uint32_t p = t0 + (uint32_t)it * NT + tid;
@@ -401,7 +413,7 @@ RH_DEV uint32_t bs_classify(const uint8_t *dg, const uint32_t *s_start, uint32_t
 __global__ __launch_bounds__(NT) void k_bs_count(bs_ctx C)
 {
 	__shared__ uint32_t s_r;
-	__shared__ uint32_t s_start[257], s_inpl[256], s_cw[BS_TILE_IT * (NT / 64)];
+	__shared__ uint32_t s_start[257], s_inpl[256], s_cw[BS_CW_WORDS];
 	const uint32_t n_rng = C.hdr[0], tid = threadIdx.x;
 	if (blockIdx.x >= C.hdr[1]) return;
 	const uint32_t r = bs_find_range(C, blockIdx.x, n_rng, &s_r);
@@ -465,7 +477,7 @@ __global__ __launch_bounds__(NT) void k_bs_scan(bs_ctx C)
 __global__ __launch_bounds__(NT) void k_bs_holes(bs_ctx C)
 {
 	__shared__ uint32_t s_r;
-	__shared__ uint32_t s_start[257], s_cw[BS_TILE_IT * (NT / 64)];
+	__shared__ uint32_t s_start[257], s_cw[BS_CW_WORDS];
 	const uint32_t n_rng = C.hdr[0], tid = threadIdx.x;
 	if (blockIdx.x >= C.hdr[1]) return;
 	const uint32_t r = bs_find_range(C, blockIdx.x, n_rng, &s_r);
@@ -937,7 +949,7 @@ __global__ __launch_bounds__(64) void k_bs_walk_tok(bs_ctx C, uint32_t nh_lo, ui
 __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 {
 	__shared__ uint32_t s_r;
-	__shared__ uint32_t s_start[257], s_hst[257], s_J[256], s_cw[BS_TILE_IT * (NT / 64)];
+	__shared__ uint32_t s_start[257], s_hst[257], s_J[256], s_cw[BS_CW_WORDS];
 	__shared__ uint8_t s_fate[256];
 	const uint32_t n_rng = C.hdr[0], tid = threadIdx.x;
 	// workgroup b runs on XCD b % 8: the tiles are dealt so that each XCD takes a contiguous eighth of them and a range's
