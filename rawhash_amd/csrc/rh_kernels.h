@@ -131,6 +131,9 @@ struct rh_dev_round {
 #endif
 
 // the same classes when the job's keys fit 32-bit words: 8 B of LDS per record
+#ifndef RH_SORT32_CAPH
+#define RH_SORT32_CAPH 2048     // ~21 KB: six workgroups per CU (the strand x target buckets of a human-scale chunk: ~1.9 k anchors)
+#endif
 #ifndef RH_SORT32_CAP1
 #define RH_SORT32_CAP1 4096     // ~38 KB: four workgroups per CU
 #endif

@@ -542,7 +542,7 @@ RH_DEV void sort_run(sort_lds<CAP, KT> &L, uint32_t n, int pass)
 // workgroups of a class that fit the 160 KB of LDS of a CU (1 KB allocation granules) = wavefronts per SIMD the compiler
 // has to leave registers for (4 wavefronts per workgroup, 4 SIMDs per CU)
 template <int CAP, class KT>
-constexpr int sort_wg_per_cu() { return (int)((160u * 1024u) / ((sizeof(sort_lds<CAP, KT>) + 1023u) / 1024u * 1024u)) < 4 ? (int)((160u * 1024u) / ((sizeof(sort_lds<CAP, KT>) + 1023u) / 1024u * 1024u)) : 4; }
+constexpr int sort_wg_per_cu() { return (int)((160u * 1024u) / ((sizeof(sort_lds<CAP, KT>) + 1023u) / 1024u * 1024u)) < (CAP <= 2048 ? 6 : 4) ? (int)((160u * 1024u) / ((sizeof(sort_lds<CAP, KT>) + 1023u) / 1024u * 1024u)) : (CAP <= 2048 ? 6 : 4); }
 
 template <int CAP, class KT>
 __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(rh_sort_job jb, uint32_t n_lo, uint32_t n_hi, int mode)
@@ -822,7 +822,8 @@ int rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t 
 	if (wave_on && jb.cnt_rw && !jb.skip && min_n < (uint32_t)RH_SORT_WAVE) RH_LAUNCH(k_sort_wave, (jb.n_seg + NT / 64 - 1) / (NT / 64), NT, 0, s, jb, min_n);   // a wavefront per bucket of up to 256 records (the rest, and its leftovers, below)
 	if (sort_keys32(jb)) {
 		launch_class<RH_SORT_CAP0, uint32_t>(s, jb, all_exact, min_n, (uint32_t)RH_SORT_CAP0);
-		launch_class<RH_SORT32_CAP1, uint32_t>(s, jb, all_exact, (uint32_t)RH_SORT_CAP0, (uint32_t)RH_SORT32_CAP1);
+		launch_class<RH_SORT32_CAPH, uint32_t>(s, jb, all_exact, (uint32_t)RH_SORT_CAP0, (uint32_t)RH_SORT32_CAPH);
+		launch_class<RH_SORT32_CAP1, uint32_t>(s, jb, all_exact, (uint32_t)RH_SORT32_CAPH, (uint32_t)RH_SORT32_CAP1);
 		launch_class<RH_SORT32_CAP2, uint32_t>(s, jb, all_exact, (uint32_t)RH_SORT32_CAP1, (uint32_t)RH_SORT32_CAP2);
 		launch_class<RH_SORT32_CAP3, uint32_t>(s, jb, all_exact, (uint32_t)RH_SORT32_CAP2, (uint32_t)RH_SORT32_CAP3);
 		top = (uint32_t)RH_SORT32_CAP3;
