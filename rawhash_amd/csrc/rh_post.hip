@@ -988,23 +988,29 @@ __global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads r
 #ifndef RGB_PCAP
 #define RGB_PCAP 1024      // primaries held in LDS
 #endif
+// PCAP: the kernel comes in three sizes of the primary list (RGB_PCAP / 4, / 2, / 1: 8.7, 17.4, 34.8 KB of LDS - a 64-thread workgroup of the
+// largest gets one wavefront per SIMD); a read goes to the smallest one that holds 1.25 x + 32 the primaries of its previous chunk (they
+// accumulate with the chains a read carries) and, should it overflow after all, again to the next
+template <int PCAP>
 struct rgb_lds {
-	int32_t pqs[RGB_PCAP], pqe[RGB_PCAP];        // primaries in list order: query interval
-	uint32_t psc[RGB_PCAP], pcn[RGB_PCAP], psub[RGB_PCAP], pns[RGB_PCAP];   // score, anchors, best secondary score, secondaries with >= as many anchors
-	int32_t sqs[RGB_PCAP], sqe[RGB_PCAP];        // the same intervals sorted by (start, end)
-	uint16_t sid[RGB_PCAP];                       // ... and their place in the list
+	int32_t pqs[PCAP], pqe[PCAP];        // primaries in list order: query interval
+	uint32_t psc[PCAP], pcn[PCAP], psub[PCAP], pns[PCAP];   // score, anchors, best secondary score, secondaries with >= as many anchors
+	int32_t sqs[PCAP], sqe[PCAP];        // the same intervals sorted by (start, end)
+	uint16_t sid[PCAP];                       // ... and their place in the list
 	uint32_t kk;
 	int32_t lmax;                                 // the longest primary: a primary that overlaps [si, ei) starts after si - lmax
 };
 
+template <int PCAP>
 __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, const float *logf_tab, uint32_t n_lo)
 {
-	__shared__ rgb_lds L;
+	__shared__ rgb_lds<PCAP> L;
 	const uint32_t a = blockIdx.x, lane = threadIdx.x;
 	if (a >= rr.n_act || rr.skip[a]) return;
 	const int32_t n_u = (int32_t)rr.n_u[a];
 	if (n_u <= (int32_t)n_lo || !rr.need_exact[a]) return;
 	const uint32_t r = rr.act[a];
+	if (PCAP < RGB_PCAP) { const uint32_t prev = (uint32_t)rd.ls_ncregs[r]; if (prev + prev / 4u + 32u > (uint32_t)PCAP) return; }   // (need_exact stays set: a larger instance follows)
 	const uint64_t base = rr.a_off[a];
 	const rh_chain_head *heads = (const rh_chain_head*)(rr.ws + base * RH_WS_PER_ANCHOR);
 	const rh_mm128_t *zs = rr.zs + base;                             // keys in radix_sort_128x order (ascending)
@@ -1076,19 +1082,19 @@ __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads
 				pending = false;
 			}
 			if (f < 64u) {	// chain i0 + f opens a new primary
-				if (kk >= (uint32_t)RGB_PCAP) return;                    // (need_exact stays set: the serial kernels take the read)
+				if (kk >= (uint32_t)PCAP) return;                    // (need_exact stays set: the serial kernels take the read)
 				const int32_t fs = __shfl(si, (int)f), fe = __shfl(ei, (int)f), fsc = __shfl(sci, (int)f), fcn = __shfl(cni, (int)f);
 				// its place in the intervals sorted by (start, end)
 				uint32_t below = 0;
 				for (uint32_t j = lane; j < kk; j += 64) below += (L.sqs[j] < fs || (L.sqs[j] == fs && L.sqe[j] <= fe)) ? 1u : 0u;
 				for (int d = 32; d > 0; d >>= 1) below += __shfl_xor(below, d);
-				int32_t ms[RGB_PCAP / 64], me[RGB_PCAP / 64];
-				uint16_t mi[RGB_PCAP / 64];
+				int32_t ms[(PCAP + 63) / 64], me[(PCAP + 63) / 64];
+				uint16_t mi[(PCAP + 63) / 64];
 #pragma unroll
-				for (int q = 0; q < RGB_PCAP / 64; ++q) { const uint32_t j = (uint32_t)q * 64u + lane; ms[q] = 0; me[q] = 0; mi[q] = 0; if (j >= below && j < kk) { ms[q] = L.sqs[j]; me[q] = L.sqe[j]; mi[q] = L.sid[j]; } }
+				for (int q = 0; q < (PCAP + 63) / 64; ++q) { const uint32_t j = (uint32_t)q * 64u + lane; ms[q] = 0; me[q] = 0; mi[q] = 0; if (j >= below && j < kk) { ms[q] = L.sqs[j]; me[q] = L.sqe[j]; mi[q] = L.sid[j]; } }
 				__syncthreads();
 #pragma unroll
-				for (int q = 0; q < RGB_PCAP / 64; ++q) { const uint32_t j = (uint32_t)q * 64u + lane; if (j >= below && j < kk) { L.sqs[j + 1] = ms[q]; L.sqe[j + 1] = me[q]; L.sid[j + 1] = mi[q]; } }
+				for (int q = 0; q < (PCAP + 63) / 64; ++q) { const uint32_t j = (uint32_t)q * 64u + lane; if (j >= below && j < kk) { L.sqs[j + 1] = ms[q]; L.sqe[j + 1] = me[q]; L.sid[j + 1] = mi[q]; } }
 				if (lane == 0) {
 					L.sqs[below] = fs; L.sqe[below] = fe; L.sid[below] = (uint16_t)kk;
 					if (fe - fs > L.lmax) L.lmax = fe - fs;
@@ -1434,7 +1440,9 @@ void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, con
 	if (wave_ok) {
 		// one register slot (<= 64 primaries: nearly every read) first; the reads that overflow it again with all slots
 		RH_LAUNCH(k_regions_reg<1>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL, 0);
-		RH_LAUNCH(k_regions_batch, r.n_act, 64, rh_wave_lds(), s, o, rd, r, logf_tab, (uint32_t)RG_SMALL);   // reads with many chains / more than 64 primaries
+		RH_LAUNCH(k_regions_batch<RGB_PCAP / 4>, r.n_act, 64, rh_wave_lds(), s, o, rd, r, logf_tab, (uint32_t)RG_SMALL);   // reads with many chains / more than 64 primaries
+		RH_LAUNCH(k_regions_batch<RGB_PCAP / 2>, r.n_act, 64, rh_wave_lds(), s, o, rd, r, logf_tab, (uint32_t)RG_SMALL);
+		RH_LAUNCH(k_regions_batch<RGB_PCAP>, r.n_act, 64, rh_wave_lds(), s, o, rd, r, logf_tab, (uint32_t)RG_SMALL);
 		if (RGR_SLOTS > 1) RH_LAUNCH(k_regions_reg<RGR_SLOTS>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL, 1);
 		RH_LAUNCH(k_regions_wave<RGW_CAP0>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RG_SMALL);
 		RH_LAUNCH(k_regions_wave<RGW_CAP>, r.n_act, 64, 0, s, o, rd, r, logf_tab, (uint32_t)RGW_CAP0);
