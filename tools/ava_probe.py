@@ -1,6 +1,6 @@
-"""Development aid: all-vs-all at scale on the GPU (python tests/ava_probe.py <genome_bp> <reads> [cpu_sample])."""
+"""Development aid: all-vs-all at scale on the GPU (python tools/ava_probe.py <genome_bp> <reads> [cpu_sample])."""
 import os, sys, time, tempfile, subprocess
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from rawhash_amd.api import SynthWorkload, MapOptions, Index, Context, paf_lines, strip_mt
 from conftest import AvaWorkload

@@ -1,4 +1,4 @@
-# occupancy caps of the long-lived one-wavefront kernels (unused dynamic LDS) against the 3-stream step.  Usage: bash tests/r03_occ.sh <tag>
+# occupancy caps of the long-lived one-wavefront kernels (unused dynamic LDS) against the 3-stream step.  Usage: bash tools/r03_occ.sh <tag>
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; O=$R/gpurun_out; TAG=${1:-occ}; mkdir -p $O
 cd $R

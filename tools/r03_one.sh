@@ -1,4 +1,4 @@
-# sorter parity + 3-stream bench + 1-stream kernel table of the build in the tree.  Usage: bash tests/r03_one.sh <tag> [kernel-name filter]
+# sorter parity + 3-stream bench + 1-stream kernel table of the build in the tree.  Usage: bash tools/r03_one.sh <tag> [kernel-name filter]
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; O=$R/gpurun_out; TAG=${1:-one}; PAT=${2:-k_bs_}; mkdir -p $O
 cd $R; timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "sort or golden or config2 or repeat or regions or human" 2>&1 | tail -2

@@ -1,4 +1,4 @@
-# round-3 probe: 3-stream bench (no CPU leg), 1-stream bench, 1-stream kernel table, sorter level trace.  Usage: bash tests/r03_probe.sh <tag> [pytest -k expr]
+# round-3 probe: 3-stream bench (no CPU leg), 1-stream bench, 1-stream kernel table, sorter level trace.  Usage: bash tools/r03_probe.sh <tag> [pytest -k expr]
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; O=$R/gpurun_out; mkdir -p $O; TAG=${1:-base}
 cd $R

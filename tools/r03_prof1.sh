@@ -1,4 +1,4 @@
-# 1-stream kernel table only.  Usage: bash tests/r03_prof1.sh <tag>
+# 1-stream kernel table only.  Usage: bash tools/r03_prof1.sh <tag>
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; O=$R/gpurun_out; TAG=${1:-x}
 RH_SUB_BATCHES=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profh_$TAG -o p -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-h2d > /dev/null 2>&1

@@ -1,4 +1,4 @@
-# sort parity on the GPU + 3-stream and 1-stream bench lines.  Usage: bash tests/r03_quick.sh <tag>
+# sort parity on the GPU + 3-stream and 1-stream bench lines.  Usage: bash tools/r03_quick.sh <tag>
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; O=$R/gpurun_out; TAG=${1:-q}; mkdir -p $O
 cd $R

@@ -1,4 +1,4 @@
-# what a sorter pass costs the 3-stream step: walks / placement launched twice (idempotent).  Usage: bash tests/r03_reps.sh <tag>
+# what a sorter pass costs the 3-stream step: walks / placement launched twice (idempotent).  Usage: bash tools/r03_reps.sh <tag>
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; O=$R/gpurun_out; TAG=${1:-reps}; mkdir -p $O
 cd $R

@@ -1,4 +1,4 @@
-# sub-batch streams sweep.  Usage: bash tests/r03_sub.sh <tag>
+# sub-batch streams sweep.  Usage: bash tools/r03_sub.sh <tag>
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; O=$R/gpurun_out; TAG=${1:-sub}; mkdir -p $O
 cd $R

@@ -1,4 +1,4 @@
-# sweep an environment variable over values with the 3-stream / 1-stream bench.  Usage: bash tests/r03_sweep.sh VAR v1 v2 ...
+# sweep an environment variable over values with the 3-stream / 1-stream bench.  Usage: bash tools/r03_sweep.sh VAR v1 v2 ...
 cd /root/repo; V=$1; shift
 for x in "$@"; do
   a=$(env $V=$x timeout 600 python bench.py --cpu-sample 0 --no-h2d 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")

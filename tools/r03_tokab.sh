@@ -1,4 +1,4 @@
-# sorter parity + 1-stream kernel table for the two token-walker pops (RH_BS_TOK_ADV=0: compiler-scheduled; 1: rh_tok_advance + one period counter).  Usage: bash tests/r03_tokab.sh <tag>
+# sorter parity + 1-stream kernel table for the two token-walker pops (RH_BS_TOK_ADV=0: compiler-scheduled; 1: rh_tok_advance + one period counter).  Usage: bash tools/r03_tokab.sh <tag>
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; O=$R/gpurun_out; TAG=${1:-tokab}; mkdir -p $O
 cd $R; timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "sort or golden or config2 or repeat" 2>&1 | tail -2; cd /tmp

@@ -1,4 +1,4 @@
-# per-round + per-sorter-level trace of one 1-stream step.  Usage: bash tests/r03_trace.sh <tag>
+# per-round + per-sorter-level trace of one 1-stream step.  Usage: bash tools/r03_trace.sh <tag>
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; O=$R/gpurun_out; TAG=${1:-tr}; mkdir -p $O
 cd $R
