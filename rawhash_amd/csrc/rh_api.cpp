@@ -354,6 +354,7 @@ int stage_anchors(rh_ctx *c, uint64_t total, rh_dev_round *rr, uint64_t room = 0
 	    c->ws.ensure(t * RH_WS_PER_ANCHOR + 4096, mg)) return -1;
 	rr->anc = c->anc.as<rh_mm128_t>(); rr->raw = c->raw_anc.as<rh_mm128_t>(); rr->zs = c->zs.as<rh_mm128_t>(); rr->prev_out = c->prev_stage.as<rh_mm128_t>();
 	rr->u = c->u.as<uint64_t>(); rr->ws = c->ws.as<unsigned char>();
+	rr->arena_n = t;
 	// segments longer than the LDS sort classes (large indexes): scratch of the multi-workgroup sorter
 	if (rr->max_anchors == 0 || rr->max_anchors > (uint32_t)RH_SORT_LDS_MIN_TOP) {
 		const size_t wsb = rhk_bigsort_ws_bytes(t, (uint32_t)RH_SORT_LDS_MIN_TOP);
@@ -791,6 +792,29 @@ int set_row_strides(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in)
 	return 0;
 }
 
+// 8-byte records through the sorters where key and payload fit one word (rh_rec_fmt, rh_kernels.h): the candidates of the backtrack
+// (score | anchor), the chain-order keys (first anchor's strand | target | position, chain number) and - when strand, target, position,
+// tandem flag and query position fit - the anchors themselves.  What does not fit keeps its 16-byte records.
+void set_rec8_formats(const rh_ctx *c, const rh_mapopt_t *mo, const rh_dev_opt &o, rh_dev_round *rr)
+{
+	rr->afmt = rh_rec_fmt{0, 0, 0, 0}; rr->cfmt = rh_rec_fmt{0, 0, 0, 0}; rr->aq_bits = 0; rr->z8 = 0;
+	static const bool off = getenv("RH_REC8") && atoi(getenv("RH_REC8")) == 0;   // RH_REC8=0: 16-byte records everywhere (comparison runs)
+	if (off) return;
+	rr->z8 = o.min_sc >= 0 ? 1 : 0;
+	rh_blob_header h;
+	memcpy(&h, c->header, sizeof(h));
+	const uint32_t lo = c->akey_lo, mid = c->akey_mid;
+	if (h.max_len == 0 || lo > 30 || mid > 31) return;             // (x keeps position bit 30 a second time at bit 31: zero below 2^30)
+	const uint32_t kb = 1u + lo + mid;
+	const uint32_t ib = 64u - kb < 31u ? 64u - kb : 31u;            // chain number below the key (checked against the slice's largest read)
+	if (ib >= 8u) rr->cfmt = rh_rec_fmt{1, (uint8_t)ib, (uint8_t)lo, (uint8_t)mid};
+	if (mo->flag & RH_M_ALL_CHAINS) return;                        // (k_expand_ava writes 16-byte anchors)
+	const uint64_t q_max = (mo->flag & RH_M_NO_ADAPTIVE) ? (uint64_t)c->ev_cap + 1u : ((uint64_t)mo->max_num_chunk + 1u) * c->ev_cap;   // query positions = events so far
+	uint32_t qb = 1;
+	while (qb < 32u && (1ull << qb) <= q_max) ++qb;
+	if (kb + 1u + qb <= 64u) { rr->afmt = rh_rec_fmt{1, (uint8_t)(qb + 1u), (uint8_t)lo, (uint8_t)mid}; rr->aq_bits = (uint8_t)qb; }
+}
+
 // rec_off != null: all-vs-all, a read may have several records (rec_off[r] .. rec_off[r + 1], n_reads + 1 offsets)
 int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out, uint64_t *rec_off = nullptr)
 {
@@ -836,6 +860,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 		if (stage_round(c, n_act, &rr)) return -1;
 		rr.act = c->act[cur].as<uint32_t>(); rr.chunk = chunk;
 		rr.akey_on = c->akey_on ? 1 : 0; rr.akey_lo = c->akey_lo; rr.akey_mid = c->akey_mid;
+		set_rec8_formats(c, mo, o, &rr);
 		rr.prev_in = c->carry[which ^ 1].as<rh_mm128_t>();
 		{ StageTimer t(c, ST_EV_NORM); rhk_events_norm(s, o, rd, rr); }
 		{ StageTimer t(c, ST_EV_PEAKS); rhk_events_peaks(s, o, rr); }
@@ -882,6 +907,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 				rs.max_anchors = mx;
 			}
 			if (stage_anchors(c, stotal, &rs, cuts.size() > 2 ? budget : 0)) return -1;
+			if (rs.cfmt.rec8 && (rs.max_anchors == 0 || (uint64_t)rs.max_anchors >= (1ull << rs.cfmt.shift))) rs.cfmt = rh_rec_fmt{0, 0, 0, 0};   // (a chain number must fit below the key)
 			if (cuts.size() > 2) c->arena_room = budget;
 			// the chained anchors the reads carry into their next chunk: staging arena -> dense carry buffer (all-vs-all: the
 			// reported chains, which the region stage leaves there)
@@ -897,7 +923,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 				return 0;
 			};
 			{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rs); }
-			{ StageTimer t(c, ST_SORT); if (rhk_sort(s, rs)) return -1; }
+			{ StageTimer t(c, ST_SORT); if (rhk_sort(s, c->dix, rs)) return -1; }
 			if (debug_rounds()) dump_round(c, chunk, n, rs);
 			if (chain_stages(c, s, o, rd, rs, true)) return -1;
 			if (!ava && pack_carry()) return -1;                      // (before the region sort: it borrows the staging arena)
@@ -1358,7 +1384,7 @@ extern "C" int rh_seed_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, const
 	if (stage_anchors(c, total, &rr)) return -1;
 	rr.prev_in = c->carry[1].as<rh_mm128_t>();
 	rhk_expand(s, o, c->dix, rd, rr);
-	if (rhk_sort(s, rr)) return -1;
+	if (rhk_sort(s, c->dix, rr)) return -1;
 	RH_HIP(hipStreamSynchronize(s));
 	RH_HIP(hipGetLastError());
 	if (total > anchors_cap) { rh_set_error("anchor buffer too small (%llu needed)", (unsigned long long)total); return -1; }
@@ -1452,7 +1478,7 @@ extern "C" int rh_sort128x_batch(rh_ctx *c, uint32_t n_seg, rh_mm128_t *a, const
 	if (stage_round(c, n_seg, &rr) || stage_anchors(c, total, &rr)) return -1;
 	std::vector<uint8_t> skip(n_seg ? n_seg : 1, 0);
 	if (h2d(rr.raw, a, total) || h2d(rr.a_off, offsets, (size_t)n_seg + 1) || h2d(rr.skip, skip.data(), n_seg)) return -1;
-	if (rhk_sort(c->stream, rr)) return -1;
+	if (rhk_sort(c->stream, c->dix, rr)) return -1;
 	RH_HIP(hipStreamSynchronize(c->stream));
 	RH_HIP(hipGetLastError());
 	if (total) RH_HIP(hipMemcpy(a, rr.anc, total * 16, hipMemcpyDeviceToHost));

@@ -63,8 +63,9 @@ struct bs_meta {
 enum { BS_EMPTY = 0, BS_FINAL = 1, BS_SMALL = 2, BS_BIG = 3 };
 
 struct bs_ctx {
-	rh_mm128_t *buf[2];                   // 0 = job source (overwritten), 1 = alt
-	rh_mm128_t *dst;
+	void *buf[2];                         // 0 = job source (overwritten), 1 = alt; records of the job's type (rh_mm128_t, or uint64_t: rf.rec8)
+	void *dst;
+	rh_rec_fmt rf;
 	bs_range *rng[2];                     // this level's ranges / next level's
 	bs_meta *meta;
 	uint32_t *tile_h;                     // per tile: holes -> (after the scan) holes of the range before the tile
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(NT) void k_bs_clear(bs_ctx C)
 }
 
 // ------------------------------------------------------------------------------------------------ K1: OR / AND of the keys
+template <class REC>
 __global__ __launch_bounds__(NT) void k_bs_diff(bs_ctx C)
 {
 	__shared__ uint32_t s_r;
@@ -141,12 +143,12 @@ __global__ __launch_bounds__(NT) void k_bs_diff(bs_ctx C)
 	const bs_range R = C.rng[0][r];
 	if (R.has_dg) return;
 	const uint32_t t0 = (blockIdx.x - R.tile0) * BS_TILE;
-	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
+	const REC *src = reinterpret_cast<const REC*>(C.buf[R.buf]) + R.beg;
 	uint64_t vo = 0, va = ~0ull;
 #pragma unroll
 	for (int it = 0; it < BS_TILE_IT; ++it) {
 		const uint32_t p = t0 + (uint32_t)it * NT + tid;
-		if (p < R.n) { const uint64_t k = src[p].x; vo |= k; va &= k; }
+		if (p < R.n) { const uint64_t k = rh_rec_ops<REC>::key(src[p], C.rf); vo |= k; va &= k; }
 	}
 	for (int d = 32; d > 0; d >>= 1) { vo |= __shfl_xor(vo, d); va &= __shfl_xor(va, d); }
 	if (lane_id() == 0) { s_red[2 * wave_id()] = vo; s_red[2 * wave_id() + 1] = va; }
@@ -168,6 +170,7 @@ RH_DEV int bs_level_shift(const bs_meta &M, uint32_t shift_max)
 }
 
 // ------------------------------------------------------------------------------------------------ K2: digits + histogram
+template <class REC>
 __global__ __launch_bounds__(NT) void k_bs_hist(bs_ctx C)
 {
 	__shared__ uint32_t s_r;
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(NT) void k_bs_hist(bs_ctx C)
 	const bs_range R = C.rng[0][r];
 	const int s = bs_level_shift(C.meta[r], R.shift);
 	const uint32_t t0 = (blockIdx.x - R.tile0) * BS_TILE;
-	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
+	const REC *src = reinterpret_cast<const REC*>(C.buf[R.buf]) + R.beg;
 	uint8_t *dg = C.dg + R.beg;
 	s_cnt[tid] = 0;
 	__syncthreads();
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(NT) void k_bs_hist(bs_ctx C)
 		if (p < R.n) {
 			uint32_t d;
 			if (R.has_dg) d = dg[p];
-			else { d = s < 0 ? 0u : (uint32_t)(src[p].x >> s) & 255u; dg[p] = (uint8_t)d; }
+			else { d = s < 0 ? 0u : (uint32_t)(rh_rec_ops<REC>::key(src[p], C.rf) >> s) & 255u; dg[p] = (uint8_t)d; }
 			atomicAdd(&s_cnt[d], 1u);
 		}
 	}
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(NT) void k_bs_hist(bs_ctx C)
 // K1+K2 of level 0 in one read of the keys: the byte a job's first level splits on hardly ever changes between calls (the strand bit
 // of anchor keys, the second byte of chain scores), so the histogram and the digits are taken at the byte the previous call of this
 // kind of job found (`gs`) while the OR / AND are gathered; k_bs_fix0 redoes the ranges whose keys differ on another byte.
+template <class REC>
 __global__ __launch_bounds__(NT) void k_bs_hist0(bs_ctx C, int gs)
 {
 	__shared__ uint32_t s_r;
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(NT) void k_bs_hist0(bs_ctx C, int gs)
 	const uint32_t r = bs_find_range(C, blockIdx.x, n_rng, &s_r);
 	const bs_range R = C.rng[0][r];
 	const uint32_t t0 = (blockIdx.x - R.tile0) * BS_TILE;
-	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
+	const REC *src = reinterpret_cast<const REC*>(C.buf[R.buf]) + R.beg;
 	uint8_t *dg = C.dg + R.beg;
 	s_cnt[tid] = 0;
 	__syncthreads();
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(NT) void k_bs_hist0(bs_ctx C, int gs)
 	for (int it = 0; it < BS_TILE_IT; ++it) {
 		const uint32_t p = t0 + (uint32_t)it * NT + tid;
 		if (p < R.n) {
-			const uint64_t k = src[p].x;
+			const uint64_t k = rh_rec_ops<REC>::key(src[p], C.rf);
 			vo |= k; va &= k;
 			const uint32_t d = (uint32_t)(k >> gs) & 255u;
 			dg[p] = (uint8_t)d;
@@ -239,6 +243,7 @@ __global__ __launch_bounds__(NT) void k_bs_hist0(bs_ctx C, int gs)
 // level 0, one workgroup per range: hdr[14] = 1 + the byte shift some range of the level really splits on (what the host remembers
 // for the next job of this kind), and - after k_bs_hist0 - histogram and digits of a range that splits on another byte than `gs`
 // (hdr[13] counts them) redone from its keys
+template <class REC>
 __global__ __launch_bounds__(NT) void k_bs_fix0(bs_ctx C, int gs)
 {
 	__shared__ uint32_t s_cnt[256];
@@ -250,12 +255,12 @@ __global__ __launch_bounds__(NT) void k_bs_fix0(bs_ctx C, int gs)
 	if (tid == 0 && s >= 0 && (s != gs || r == 0)) C.hdr[14] = (uint32_t)s + 1u;
 	if (gs < 0 || s == gs) return;
 	if (tid == 0) atomicAdd(&C.hdr[13], 1u);
-	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
+	const REC *src = reinterpret_cast<const REC*>(C.buf[R.buf]) + R.beg;
 	uint8_t *dg = C.dg + R.beg;
 	s_cnt[tid] = 0;
 	__syncthreads();
 	for (uint32_t p = tid; p < R.n; p += NT) {
-		const uint32_t d = s < 0 ? 0u : (uint32_t)(src[p].x >> s) & 255u;
+		const uint32_t d = s < 0 ? 0u : (uint32_t)(rh_rec_ops<REC>::key(src[p], C.rf) >> s) & 255u;
 		dg[p] = (uint8_t)d;
 		atomicAdd(&s_cnt[d], 1u);
 	}
@@ -266,6 +271,7 @@ __global__ __launch_bounds__(NT) void k_bs_fix0(bs_ctx C, int gs)
 // K2b: a range that came with its digits (has_dg) and turns out to agree on the byte they were taken from - its histogram has one
 // bucket - is the one case where the parent's differing bits said too much: its own keys are read after all (one workgroup per
 // range; rare - a target whose hits fall into one 16 Mbp stretch, a score byte with one value), OR / AND, histogram and digits redone
+template <class REC>
 __global__ __launch_bounds__(NT) void k_bs_fix(bs_ctx C)
 {
 	__shared__ uint64_t s_red[2 * (NT / 64)];
@@ -278,9 +284,9 @@ __global__ __launch_bounds__(NT) void k_bs_fix(bs_ctx C)
 	uint32_t nb;
 	(void)block_rank(M.cnt[tid] != 0, s_w, nb);
 	if (nb != 1 || R.n < 2) return;
-	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
+	const REC *src = reinterpret_cast<const REC*>(C.buf[R.buf]) + R.beg;
 	uint64_t vo = 0, va = ~0ull;
-	for (uint32_t p = tid; p < R.n; p += NT) { const uint64_t k = src[p].x; vo |= k; va &= k; }
+	for (uint32_t p = tid; p < R.n; p += NT) { const uint64_t k = rh_rec_ops<REC>::key(src[p], C.rf); vo |= k; va &= k; }
 	for (int d = 32; d > 0; d >>= 1) { vo |= __shfl_xor(vo, d); va &= __shfl_xor(va, d); }
 	if (lane_id() == 0) { s_red[2 * wave_id()] = vo; s_red[2 * wave_id() + 1] = va; }
 	__syncthreads();
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(NT) void k_bs_fix(bs_ctx C)
 	if (tid == 0) { M.k_or = vo; M.k_and = va; }
 	uint8_t *dg = C.dg + R.beg;
 	for (uint32_t p = tid; p < R.n; p += NT) {
-		const uint32_t d = s < 0 ? 0u : (uint32_t)(src[p].x >> s) & 255u;
+		const uint32_t d = s < 0 ? 0u : (uint32_t)(rh_rec_ops<REC>::key(src[p], C.rf) >> s) & 255u;
 		dg[p] = (uint8_t)d;
 		atomicAdd(&M.cnt[d], 1u);
 	}
@@ -946,6 +952,7 @@ __global__ __launch_bounds__(64) void k_bs_walk_tok(bs_ctx C, uint32_t nh_lo, ui
 }
 
 // ------------------------------------------------------------------------------------------------ K8: placement
+template <class REC>
 __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 {
 	__shared__ uint32_t s_r;
@@ -965,8 +972,8 @@ __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 	const uint32_t t0 = (tile - R.tile0) * BS_TILE, hbase = C.tile_h[tile];
 	bs_cls q;
 	bs_classify(C.dg + R.beg, s_start, t0, R.n, s_cw, q);
-	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
-	rh_mm128_t *out_alt = C.buf[R.buf ^ 1] + R.beg, *out_fin = C.dst + R.beg;
+	const REC *src = reinterpret_cast<const REC*>(C.buf[R.buf]) + R.beg;
+	REC *out_alt = reinterpret_cast<REC*>(C.buf[R.buf ^ 1]) + R.beg, *out_fin = reinterpret_cast<REC*>(C.dst) + R.beg;
 	const uint32_t *hp = C.hp + R.beg, *dest = C.dest + R.beg;
 	// the buckets that are next-level ranges get their digits now, while the record is in a register: the byte they will be
 	// split on is the highest one on which this range's keys differ below its own byte
@@ -985,10 +992,10 @@ __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 			if (jj < s_J[d]) np = jj == 0 ? s_start[d] : hp[j - 1] + 1u;
 			else np = hp[j];
 		}
-		const rh_mm128_t rec = src[p];
+		const REC rec = src[p];
 		const uint32_t ft = s_fate[d];
 		if (ft == BS_FINAL) out_fin[np] = rec; else out_alt[np] = rec;
-		if (ft == BS_BIG) dgn[np] = (uint8_t)(rec.x >> ps);
+		if (ft == BS_BIG) dgn[np] = (uint8_t)(rh_rec_ops<REC>::key(rec, C.rf) >> ps);
 	}
 }
 
@@ -996,6 +1003,7 @@ __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 // neither the holes nor the walk are needed): a tile counts its digits in LDS, reserves a stretch of every bucket it feeds with one
 // atomic on the range's cursor and drops its records there.  Which tile gets which stretch is decided by the scheduler - harmless
 // for distinct keys; segments that do hold equal keys are found afterwards (k_bs_tiecheck) and redone with the exact passes.
+template <class REC>
 __global__ __launch_bounds__(NT) void k_bs_scatter_any(bs_ctx C)
 {
 	__shared__ uint32_t s_r;
@@ -1020,8 +1028,8 @@ __global__ __launch_bounds__(NT) void k_bs_scatter_any(bs_ctx C)
 	__syncthreads();
 	if (s_cnt[tid]) s_base[tid] = atomicAdd(&M.inpl[tid], s_cnt[tid]);      // (inpl: zeroed by k_bs_clear, otherwise unused on this path)
 	__syncthreads();
-	const rh_mm128_t *src = C.buf[R.buf] + R.beg;
-	rh_mm128_t *out_alt = C.buf[R.buf ^ 1] + R.beg, *out_fin = C.dst + R.beg;
+	const REC *src = reinterpret_cast<const REC*>(C.buf[R.buf]) + R.beg;
+	REC *out_alt = reinterpret_cast<REC*>(C.buf[R.buf ^ 1]) + R.beg, *out_fin = reinterpret_cast<REC*>(C.dst) + R.beg;
 	uint8_t *dgn = C.dg_next + R.beg;
 	int ps = 0;
 	{ const uint64_t low = M.s > 0 ? (M.k_or & ~M.k_and) & ((1ull << M.s) - 1ull) : 0ull; if (low) ps = (63 - __clzll(low)) & ~7; }
@@ -1030,14 +1038,15 @@ __global__ __launch_bounds__(NT) void k_bs_scatter_any(bs_ctx C)
 		const uint32_t p = t0 + (uint32_t)it * NT + tid;
 		if (p >= R.n) continue;
 		const uint32_t np = s_start[d[it]] + s_base[d[it]] + lr[it], ft = s_fate[d[it]];
-		const rh_mm128_t rec = src[p];
+		const REC rec = src[p];
 		if (ft == BS_FINAL) out_fin[np] = rec; else out_alt[np] = rec;
-		if (ft == BS_BIG) dgn[np] = (uint8_t)(rec.x >> ps);
+		if (ft == BS_BIG) dgn[np] = (uint8_t)(rh_rec_ops<REC>::key(rec, C.rf) >> ps);
 	}
 }
 
 // after an any-order job: which of its long segments hold equal keys (neighbours in the sorted result)?  skip_out[a] = 0 for those
 // - the skip array of the exact re-run - and 1 for every other segment; hdr[12] counts them
+template <class REC>
 __global__ __launch_bounds__(NT) void k_bs_tiecheck(rh_sort_job jb, bs_ctx C)
 {
 	__shared__ uint32_t s_w[NT / 64];
@@ -1046,9 +1055,9 @@ __global__ __launch_bounds__(NT) void k_bs_tiecheck(rh_sort_job jb, bs_ctx C)
 	uint32_t n = 0;
 	if (!(jb.skip && jb.skip[a])) n = jb.cnt ? jb.cnt[a] : (uint32_t)(jb.off[a + 1] - jb.off[a]);
 	if (n <= C.n_lo) { if (tid == 0) jb.redo_skip[a] = 1; return; }
-	const rh_mm128_t *v = jb.dst + jb.off[a];
+	const REC *v = reinterpret_cast<const REC*>(jb.dst) + jb.off[a];
 	bool tie = false;
-	for (uint32_t i = tid; i + 1 < n; i += NT) tie |= v[i].x == v[i + 1].x;
+	for (uint32_t i = tid; i + 1 < n; i += NT) tie |= rh_rec_ops<REC>::key(v[i], jb.rf) == rh_rec_ops<REC>::key(v[i + 1], jb.rf);
 	uint32_t tot;
 	(void)block_rank(tie, s_w, tot);
 	if (tid == 0) { jb.redo_skip[a] = tot ? 0 : 1; if (tot) atomicAdd(&C.hdr[12], 1u); }
@@ -1095,7 +1104,9 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	if (!jb.n_seg || !jb.big_alt || !jb.big_ws || !jb.big_pin) { rh_set_error("segment sorter: no scratch for segments beyond the LDS classes"); return -1; }
 	const uint64_t t = jb.big_total ? jb.big_total : 1, lo = n_lo ? n_lo : 1;
 	bs_ctx C{};
-	C.buf[0] = const_cast<rh_mm128_t*>(jb.src); C.buf[1] = jb.big_alt; C.dst = jb.dst;
+	C.buf[0] = const_cast<rh_mm128_t*>(jb.src); C.buf[1] = jb.big_alt; C.dst = jb.dst; C.rf = jb.rf;
+	const bool r8 = jb.rf.rec8 != 0;
+	#define BS_LAUNCH_REC(kern, grid, ...) do { if (r8) RH_LAUNCH(kern<uint64_t>, grid, NT, 0, s, __VA_ARGS__); else RH_LAUNCH(kern<rh_mm128_t>, grid, NT, 0, s, __VA_ARGS__); } while (0)
 	C.n_lo = n_lo;
 	C.rng_cap = (uint32_t)(t / (lo + 1) + 2); C.small_cap = (uint32_t)(t / 8 + 256);
 	const uint64_t tiles_cap = t / BS_TILE + C.rng_cap + 2;
@@ -1140,16 +1151,16 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		C.dg = dgb[level & 1]; C.dg_next = dgb[(level & 1) ^ 1];
 		RH_LAUNCH(k_bs_tile_map, (n_tiles + NT - 1) / NT, NT, 0, s, C);
 		RH_LAUNCH(k_bs_clear, n_rng, NT, 0, s, C);
-		if (level == 0 && gs >= 0) RH_LAUNCH(k_bs_hist0, n_tiles, NT, 0, s, C, gs);   // OR / AND and the histogram at the remembered byte in one read of the keys
+		if (level == 0 && gs >= 0) BS_LAUNCH_REC(k_bs_hist0, n_tiles, C, gs);   // OR / AND and the histogram at the remembered byte in one read of the keys
 		else {
-			RH_LAUNCH(k_bs_diff, n_tiles, NT, 0, s, C);
-			RH_LAUNCH(k_bs_hist, n_tiles, NT, 0, s, C);
+			BS_LAUNCH_REC(k_bs_diff, n_tiles, C);
+			BS_LAUNCH_REC(k_bs_hist, n_tiles, C);
 		}
-		if (level) RH_LAUNCH(k_bs_fix, n_rng, NT, 0, s, C);
-		else { RH_LAUNCH(k_bs_fix0, n_rng, NT, 0, s, C, gs); n_rng0 = n_rng; }
+		if (level) BS_LAUNCH_REC(k_bs_fix, n_rng, C);
+		else { BS_LAUNCH_REC(k_bs_fix0, n_rng, C, gs); n_rng0 = n_rng; }
 		RH_LAUNCH(k_bs_plan, n_rng, NT, 0, s, C);
 		if (jb.any_order) {	// no holes, no walk: tiles reserve stretches of their buckets
-			RH_LAUNCH(k_bs_scatter_any, n_tiles, NT, 0, s, C);
+			BS_LAUNCH_REC(k_bs_scatter_any, n_tiles, C);
 			RH_LAUNCH(k_bs_next, 1, NT, 0, s, C);
 			bs_range *tmp2 = C.rng[0]; C.rng[0] = C.rng[1]; C.rng[1] = tmp2;
 			continue;
@@ -1183,7 +1194,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		}
 		if (trace) (void)hipEventRecord(ev[2], s);
 		for (int rep = 0; rep < scat_reps; ++rep)
-		RH_LAUNCH(k_bs_scatter, ((n_tiles + 7) / 8) * 8, NT, 0, s, C);
+		BS_LAUNCH_REC(k_bs_scatter, ((n_tiles + 7) / 8) * 8, C);
 		RH_LAUNCH(k_bs_next, 1, NT, 0, s, C);
 		if (trace) {
 			(void)hipEventRecord(ev[3], s); (void)hipEventSynchronize(ev[3]);
@@ -1208,17 +1219,18 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		if (!ns) continue;
 		rh_sort_job sj = jb;
 		sj.n_seg = ns; sj.skip = nullptr; sj.off = C.small_off[q]; sj.cnt = C.small_cnt[q];
-		sj.src = C.buf[q >> 1]; sj.dst = jb.dst; sj.need_exact = nullptr; sj.n_max = pin[8 + q] < n_lo ? pin[8 + q] : n_lo;   // (an LDS class above the list's largest bucket would be a launch of blocks that all leave at once, each waiting for its LDS)
+		sj.src = (const rh_mm128_t*)C.buf[q >> 1]; sj.dst = jb.dst; sj.need_exact = nullptr; sj.n_max = pin[8 + q] < n_lo ? pin[8 + q] : n_lo;   // (an LDS class above the list's largest bucket would be a launch of blocks that all leave at once, each waiting for its LDS)
 		if ((q & 1) && !job32) { sj.kc_on = 1; sj.kc_lo = 32; sj.kc_mid = 0; sj.kc_hi = 0; }   // keys that differ below bit 32 only: 32-bit words in LDS
 		sj.big_alt = nullptr; sj.big_ws = nullptr;
 		sj.any_order = 0; sj.redo_skip = nullptr; sj.n_redo = nullptr; sj.cnt_rw = C.small_cnt[q];
 		if (rhk_sort_job(s, sj, all_exact, 1u)) return -1;
 	}
 	if (jb.any_order) {
-		RH_LAUNCH(k_bs_tiecheck, jb.n_seg, NT, 0, s, jb, C);
+		BS_LAUNCH_REC(k_bs_tiecheck, jb.n_seg, jb, C);
 		RH_HIP(hipMemcpyAsync(pin, C.hdr + 12, 4, hipMemcpyDeviceToHost, s));
 		RH_HIP(hipStreamSynchronize(s));
 		if (jb.n_redo) *jb.n_redo = pin[0];
 	}
+	#undef BS_LAUNCH_REC
 	return 0;
 }

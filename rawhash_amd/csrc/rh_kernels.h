@@ -81,6 +81,21 @@ struct rh_dev_reads {
 	float *events; uint32_t ev_stride;   // RH_M_DTW_EVALUATE_CHAINS: the events of every processed chunk of every read (reg->events, rmap.cpp:237-241), ev_stride floats per read
 };
 
+// Records of a sort job: 16-byte rh_mm128_t (key = x, payload = y), or - when key and payload fit one word - 8-byte words
+//   key' << shift | payload,   key' = hi << (lo + mid) | mid << lo | lo   (the bit fields of the ORIGINAL 64-bit key  hi << 63 | mid << 32 | lo),
+// which halves every byte the sorters move.  The order is still the reference's radix_sort_128x permutation of the original keys: the
+// digits of a level are taken from the key rebuilt at its original bit positions (rh_rec8_key).
+struct rh_rec_fmt { uint8_t rec8, shift, lo, mid; };
+RH_HD inline uint64_t rh_rec8_key(uint64_t w, uint32_t shift, uint32_t lo, uint32_t mid)
+{
+	const uint64_t k = w >> shift;
+	return (k & ((1ull << lo) - 1ull)) | ((k >> lo) & ((1ull << mid) - 1ull)) << 32 | ((k >> (lo + mid)) & 1ull) << 63;
+}
+RH_HD inline uint64_t rh_rec8_pack_key(uint64_t x, uint32_t lo, uint32_t mid)   // key' of the original key x (whose fields fit lo / mid bits)
+{
+	return (x & ((1ull << lo) - 1ull)) | ((x >> 32) & ((1ull << mid) - 1ull)) << lo | (x >> 63) << (lo + mid);
+}
+
 // per-round work arrays indexed by active slot a in [0, n_act)
 struct rh_dev_round {
 	uint32_t max_anchors;                    // anchors of the largest active read this round (0 = unknown)
@@ -109,6 +124,11 @@ struct rh_dev_round {
 	float *dtw_ws; uint32_t dtw_stride;      // RH_M_DTW_EVALUATE_CHAINS: DP buffers, dtw_stride floats per active read
 	uint32_t *dtw_n; float *dtw_rec; const uint64_t *dtw_off; const int32_t *dtw_dec;   // regions per read; packed per-region values for the host's MAPQ; their offsets; the host's decisions (3 int32 per read)
 	uint64_t *counters;              // [0] events [1] seeds [2] hits [3] anchors [4] chained [5] samples used [6] chunks [7] chunks with more peaks than RH_EV_CAP (an error)
+	// 8-byte records through the sorters (rh_rec_fmt; all zero = 16-byte records everywhere: the stage-level calls):
+	//   afmt  anchors leave k_expand as  key' << shift | tandem << aq_bits | q_pos  (shift = aq_bits + 1; the span is the index's constant), are sorted
+	//         as such and expanded to 16 bytes by k_anchor_unpack;   cfmt  chain-order keys  key' << shift | chain;   z8  candidates  score << 32 | anchor
+	rh_rec_fmt afmt, cfmt; uint8_t aq_bits, z8;
+	uint64_t arena_n;                // anchors the 16-byte-per-anchor arenas (raw, anc, zs, prev_out) hold
 };
 
 // ---- LDS size classes of the block sorter (rh_sort.hip)
@@ -146,7 +166,7 @@ struct rh_dev_round {
 
 #define RH_SORT_LDS_MIN_TOP (RH_SORT32_CAP3 < RH_SORT_CAP4 ? RH_SORT32_CAP3 : RH_SORT_CAP4)   // segments longer than this may need rh_bigsort.hip
 
-// a batch of independent 16-byte-record segments to be put into radix_sort_128x order (rh_sort.hip)
+// a batch of independent record segments to be put into radix_sort_128x order (rh_sort.hip)
 struct rh_sort_job {
 	uint32_t n_seg; const uint8_t *skip; const uint64_t *off; const uint32_t *cnt;   // segment a = [off[a], off[a] + (cnt ? cnt[a] : off[a+1]-off[a]))
 	const rh_mm128_t *src; rh_mm128_t *dst; uint8_t *need_exact;
@@ -169,7 +189,13 @@ struct rh_sort_job {
 	// which sort of the path this is (1 anchors, 2 chain candidates, 3 chains, 4 regions, 0 anything else): the multi-workgroup sorter
 	// remembers per kind the byte its first level split on (rh_bigsort.hip: k_bs_hist0)
 	uint8_t kind;
+	// 8-byte records (see rh_rec_fmt): src / dst / big_alt then point to uint64_t arrays (same record offsets)
+	rh_rec_fmt rf;
 };
+// record access of the sorters, by record type
+template <class REC> struct rh_rec_ops;
+template <> struct rh_rec_ops<rh_mm128_t> { static RH_HD inline uint64_t key(const rh_mm128_t &r, const rh_rec_fmt &) { return r.x; } };
+template <> struct rh_rec_ops<uint64_t> { static RH_HD inline uint64_t key(const uint64_t &r, const rh_rec_fmt &f) { return rh_rec8_key(r, f.shift, f.lo, f.mid); } };
 // Unused dynamic LDS handed to the one-wavefront-per-read kernels (development knob RH_WAVE_LDS, bytes): their wavefronts live long, and
 // without a cap per CU they end up holding every wave slot while the other streams' bandwidth-bound kernels wait
 inline uint32_t rh_wave_lds() { static const uint32_t v = getenv("RH_WAVE_LDS") ? (uint32_t)strtoul(getenv("RH_WAVE_LDS"), nullptr, 10) : 0u; return v; }
@@ -188,7 +214,8 @@ void rhk_sketch(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, cons
 void rhk_probe(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_scan_anchors(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
-int rhk_sort(hipStream_t s, const rh_dev_round &r);
+int rhk_sort(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r);   // (r.afmt: one-word anchors, expanded into r.anc at the end)
+void rhk_anchor_unpack(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r, const uint64_t *sorted8);
 void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
 void rhk_chain_rmq(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r, const uint32_t *counts, int32_t max_dist, int32_t max_dist_inner, int32_t cap_rmq_size);   // mg_lchain_rmq (lchain.c:606); o.bw = the bandwidth of this pass
 int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);

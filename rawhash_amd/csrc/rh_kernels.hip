@@ -915,6 +915,11 @@ __global__ __launch_bounds__(NT) void k_expand(rh_dev_opt o, rh_dev_index ix, rh
 	const uint32_t q_off = rd.ev_off[r];
 	const uint64_t span = (uint64_t)(ix.sp.k + ix.sp.e - 1);
 	rh_mm128_t *anc = rr.raw + base;
+	// rr.afmt: the anchor as ONE word - key' (strand, target, position) above the tandem flag and the query position; the span is the
+	// index's constant and seg_id is 0, so nothing is lost (k_anchor_unpack) and the sorters move 8 bytes per anchor instead of 16
+	const bool pk = rr.afmt.rec8 != 0;
+	const uint32_t plo = rr.afmt.lo, pmid = rr.afmt.mid, psh = rr.afmt.shift, pqb = rr.aq_bits;
+	uint64_t *anc8 = reinterpret_cast<uint64_t*>(rr.raw) + base;
 	for (uint32_t j = tid; j < nn; j += NT) {
 		uint32_t lo = 0, hi = nm;   // largest s with s_pref[s] <= j
 		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pf[mid] <= j) lo = mid; else hi = mid; }
@@ -926,9 +931,32 @@ __global__ __launch_bounds__(NT) void k_expand(rh_dev_opt o, rh_dev_index ix, rh
 		if (hit & 1ull) p.x |= 1ull << 63;
 		p.y = span << 32 | (uint64_t)(uint32_t)((meta & 0x7FFFFFFFu) + q_off);   // seg_id (y >> 40) is 0 for reads
 		if (meta >> 31) p.y |= 1ull << 38;
+		if (pk) anc8[j] = rh_rec8_pack_key(p.x, plo, pmid) << psh | (uint64_t)(meta >> 31) << pqb | (uint64_t)(uint32_t)p.y;
+		else anc[j] = p;
+	}
+	if (pk) for (uint32_t j = tid; j < np; j += NT) { const rh_mm128_t p = pin[j]; anc8[nn + j] = rh_rec8_pack_key(p.x, plo, pmid) << psh | ((p.y >> 38) & 1ull) << pqb | (uint64_t)(uint32_t)p.y; }
+	else
+	for (uint32_t j = tid; j < np; j += NT) anc[nn + j] = pin[j];
+}
+
+// the sorted one-word anchors (rr.afmt) back as 16-byte records: rr.anc
+__global__ __launch_bounds__(NT) void k_anchor_unpack(rh_dev_index ix, rh_dev_round rr, const uint64_t *sorted8, uint32_t parts)
+{
+	const uint32_t a = blockIdx.x / parts, part = blockIdx.x % parts, tid = threadIdx.x;
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const uint64_t base = rr.a_off[a];
+	const uint32_t n = (uint32_t)(rr.a_off[a + 1] - base);
+	const uint64_t *src = sorted8 + base;
+	rh_mm128_t *anc = rr.anc + base;
+	const uint32_t plo = rr.afmt.lo, pmid = rr.afmt.mid, psh = rr.afmt.shift, pqb = rr.aq_bits;
+	const uint64_t span = (uint64_t)(ix.sp.k + ix.sp.e - 1), qmask = (1ull << pqb) - 1ull;
+	for (uint32_t j = part * NT + tid; j < n; j += parts * NT) {
+		const uint64_t w = src[j];
+		rh_mm128_t p;
+		p.x = rh_rec8_key(w, psh, plo, pmid);
+		p.y = span << 32 | (w & qmask) | ((w >> pqb) & 1ull) << 38;
 		anc[j] = p;
 	}
-	for (uint32_t j = tid; j < np; j += NT) anc[nn + j] = pin[j];
 }
 
 // ------------------------------------------------------------------------------------------------ all-vs-all (RH_M_ALL_CHAINS)
@@ -1220,6 +1248,12 @@ void rhk_probe(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const
 }
 void rhk_scan_anchors(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r) { RH_LAUNCH(k_scan_anchors, 1, 1024, 0, s, rd, r); }
 void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (!r.n_act) return; if (o.flag & RH_M_ALL_CHAINS) RH_LAUNCH(k_expand_ava, r.n_act, NT, 0, s, o, ix, rd, r); else RH_LAUNCH(k_expand, r.n_act, NT, 0, s, o, ix, rd, r); }
+void rhk_anchor_unpack(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r, const uint64_t *sorted8)
+{
+	if (!r.n_act) return;
+	const uint32_t parts = r.max_anchors ? cdiv(r.max_anchors, 16384u) : 4u;
+	RH_LAUNCH(k_anchor_unpack, r.n_act * parts, NT, 0, s, ix, r, sorted8, parts);
+}
 void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act_in, uint32_t n_in, uint32_t next_chunk, uint32_t *act_out, uint32_t *n_out)
 { RH_LAUNCH(k_compact_active, 1, 1024, 0, s, o, rd, act_in, n_in, next_chunk, act_out, n_out); }
 void rhk_rebase_offsets(hipStream_t s, const uint64_t *a_off, uint32_t n, uint64_t *out) { RH_LAUNCH(k_rebase_offsets, cdiv(n + 1, 256), 256, 0, s, a_off, n, out); }

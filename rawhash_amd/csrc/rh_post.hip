@@ -41,6 +41,7 @@ __global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
 	const int32_t *fp = (const int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR);   // {f, p} interleaved
 	rh_mm128_t *z = rr.raw + base;               // the unsorted anchor copy is dead after the anchor sort
+	uint64_t *z8 = reinterpret_cast<uint64_t*>(rr.raw) + base;   // rr.z8: 8-byte candidates  score << 32 | anchor
 	uint32_t *t4 = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)16 * n);   // backtrack's "touched" marks (1 B per anchor)
 	for (int32_t i = (int32_t)tid; i < (n + 3) / 4; i += NT) t4[i] = 0u;
 	uint32_t *claim = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)20 * n);   // k_backtrack_spec's per-anchor claim stamps
@@ -52,7 +53,10 @@ __global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 		const bool ok = i < n && fi >= o.min_sc;
 		uint32_t tot;
 		const uint32_t rk = block_rank(ok, s_w, tot);
-		if (ok) { rh_mm128_t e; e.x = (uint64_t)(int64_t)fi; e.y = (uint64_t)(uint32_t)i; z[nz + rk] = e; }
+		if (ok) {
+			if (rr.z8) z8[nz + rk] = (uint64_t)(uint32_t)fi << 32 | (uint64_t)(uint32_t)i;
+			else { rh_mm128_t e; e.x = (uint64_t)(int64_t)fi; e.y = (uint64_t)(uint32_t)i; z[nz + rk] = e; }
+		}
 		nz += tot;
 	}
 	if (tid == 0) rr.n_z[a] = nz;
@@ -86,13 +90,14 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 	uint8_t *t = (uint8_t*)(wsr + (size_t)16 * n);                  // "used" marks, zeroed by k_zbuild
 	uint32_t *claim = (uint32_t*)(wsr + (size_t)20 * n);            // stamps, zeroed by k_zbuild
 	const rh_mm128_t *zs = rr.zs + base;
+	const uint64_t *zs8 = reinterpret_cast<const uint64_t*>(rr.zs) + base;
 	uint64_t *u = rr.u + base;
 	const int32_t min_sc = o.min_sc, min_cnt = o.min_cnt, max_drop = o.bw;
 	int32_t n_u = 0, n_v = 0;
 	uint32_t epoch = 0;
 	for (int32_t kt = n_z; kt > 0; kt -= 64) {                     // candidates from the best score down (lchain.c:148)
 		const int32_t k = kt - 1 - (int32_t)lane;
-		const int32_t i0 = k >= 0 ? (int32_t)zs[k].y : 0;
+		const int32_t i0 = k >= 0 ? (rr.z8 ? (int32_t)(uint32_t)zs8[k] : (int32_t)zs[k].y) : 0;
 		bool pending = k >= 0, accepted = false;
 		int32_t r_cnt = 0, r_sc = 0;
 		int32_t pn1 = 0, pn2 = 0, pn3 = 0;                             // the first anchors of the path after i0 (most chains are this short)
@@ -244,6 +249,10 @@ __global__ __launch_bounds__(NT) void k_chain_gather(rh_dev_round rr)
 		}
 	}
 	__syncthreads();
+	if (rr.cfmt.rec8) {	// 8-byte keys: first-anchor x, packed, above the chain's number (its start offset stays in ck0)
+		uint64_t *w8 = reinterpret_cast<uint64_t*>(rr.raw) + base;
+		for (uint32_t i = tid; i < n_u; i += NT) w8[i] = rh_rec8_pack_key(pa[ck0[i]].x, rr.cfmt.lo, rr.cfmt.mid) << rr.cfmt.shift | (uint64_t)i;
+	} else
 	for (uint32_t i = tid; i < n_u; i += NT) { rh_mm128_t e; e.x = pa[ck0[i]].x; e.y = (uint64_t)ck0[i] << 32 | (uint64_t)i; w[i] = e; }
 }
 
@@ -264,11 +273,17 @@ __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_ro
 	uint64_t *u2 = (uint64_t*)(wsr + (size_t)40 * n);
 	uint64_t *u = rr.u + base;
 	const rh_mm128_t *pa = rr.prev_out + base, *w = rr.zs + base;   // w: sorted keys
+	const uint64_t *w8 = reinterpret_cast<const uint64_t*>(rr.zs) + base;
+	const bool c8 = rr.cfmt.rec8 != 0;
+	const uint64_t cmask = (1ull << rr.cfmt.shift) - 1ull;
+	const uint32_t *ck0 = (const uint32_t*)(wsr + (size_t)32 * n);   // start offsets in backtrack order (k_chain_gather)
+	#define CR_CHAIN(i_) (c8 ? (uint32_t)(w8[(i_)] & cmask) : (uint32_t)w[(i_)].y)
+	#define CR_FROM(i_) (c8 ? ck0[(uint32_t)(w8[(i_)] & cmask)] : (uint32_t)(w[(i_)].y >> 32))
 	uint32_t run = 0;
 	for (uint32_t i0 = 0; i0 < n_u; i0 += NT) {
 		const uint32_t i = i0 + tid;
 		uint64_t ui = 0;
-		if (i < n_u) { ui = u[(uint32_t)w[i].y]; u2[i] = ui; }
+		if (i < n_u) { ui = u[CR_CHAIN(i)]; u2[i] = ui; }
 		uint32_t tot;
 		const uint32_t ex = block_excl_scan((uint32_t)ui, s_w, tot);
 		if (i < n_u) dk[i] = run + ex;
@@ -281,14 +296,14 @@ __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_ro
 		for (uint32_t q = tid; q < n_v; q += NT) {
 			uint32_t lo = 0, hi = n_u;
 			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tab[mid] <= q) lo = mid; else hi = mid; }
-			an[q] = pa[(uint32_t)(w[lo].y >> 32) + (q - tab[lo])];
+			an[q] = pa[CR_FROM(lo) + (q - tab[lo])];
 		}
 	} else {	// one lane per chain (see k_chain_gather)
 		const uint32_t l = lane_id();
 		for (uint32_t i0 = wave_id() * 64u; i0 < n_u; i0 += NT) {
 			const uint32_t i = i0 + l;
 			uint32_t from = 0, to = 0, ni = 0;
-			if (i < n_u) { from = (uint32_t)(w[i].y >> 32); to = dk[i]; ni = (uint32_t)u2[i]; }
+			if (i < n_u) { from = CR_FROM(i); to = dk[i]; ni = (uint32_t)u2[i]; }
 			if (ni <= CG_SHORT) for (uint32_t j = 0; j < ni; ++j) an[to + j] = pa[from + j];
 			uint64_t longm = __ballot(ni > CG_SHORT);
 			while (longm) {
@@ -299,6 +314,8 @@ __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_ro
 			}
 		}
 	}
+	#undef CR_CHAIN
+	#undef CR_FROM
 	for (uint32_t i = tid; i < n_u; i += NT) u[i] = u2[i];
 	if (tid == 0) {
 		rd.n_prev[r] = n_v; rd.prev_off[r] = base;
@@ -1387,6 +1404,7 @@ int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_z, r.raw, r.zs, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 64, (uint8_t)(o.min_sc >= 0), 32, 0, 0, r.max_anchors };   // keys = scores >= min_sc: non-negative int32
 	sort_scratch(jb, r, r.prev_out);                               // (the carry staging is written by k_chain_gather, later)
 	jb.kind = 2;
+	if (r.z8) jb.rf = rh_rec_fmt{1, 32, 32, 0};                     // 8-byte candidates: key = the high word
 	return rhk_sort_job(s, jb, true, 0u);
 }
 
@@ -1399,6 +1417,7 @@ int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, co
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };   // keys = first anchors
 	sort_scratch(jb, r, r.anc);                                    // (k_chain_gather has copied every chain out of the sorted anchors; k_chain_reorder rewrites them)
 	jb.kind = 3;
+	jb.rf = r.cfmt;
 	if (rhk_sort_job(s, jb, false, 0u)) return -1;
 	RH_LAUNCH(k_chain_reorder, r.n_act, NT, 0, s, rd, r);
 	return 0;

@@ -544,7 +544,7 @@ RH_DEV void sort_run(sort_lds<CAP, KT> &L, uint32_t n, int pass)
 template <int CAP, class KT>
 constexpr int sort_wg_per_cu() { return (int)((160u * 1024u) / ((sizeof(sort_lds<CAP, KT>) + 1023u) / 1024u * 1024u)) < (CAP <= 2048 ? 6 : 4) ? (int)((160u * 1024u) / ((sizeof(sort_lds<CAP, KT>) + 1023u) / 1024u * 1024u)) : (CAP <= 2048 ? 6 : 4); }
 
-template <int CAP, class KT>
+template <int CAP, class KT, class REC>
 __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(rh_sort_job jb, uint32_t n_lo, uint32_t n_hi, int mode)
 {
 	__shared__ sort_lds<CAP, KT> L;
@@ -553,8 +553,9 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 	const uint64_t base = jb.off[a];
 	const uint32_t n = jb.cnt ? jb.cnt[a] : (uint32_t)(jb.off[a + 1] - base);
 	if (n <= n_lo || n > n_hi) return;
-	const rh_mm128_t *src = jb.src + base;
-	rh_mm128_t *dst = jb.dst + base;
+	const REC *src = reinterpret_cast<const REC*>(jb.src) + base;
+	REC *dst = reinterpret_cast<REC*>(jb.dst) + base;
+	const rh_rec_fmt rf = jb.rf;
 	KPROF_DECL;
 #ifdef RH_KPROF
 	if (tid == 0) L.prof = jb.scratch_skip == 0 ? 1u : 0u;      // profile the anchor sort only
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 		for (uint32_t i0 = tid; i0 < n; i0 += (uint32_t)KL * NT) {
 			uint64_t xs[KL];
 #pragma unroll
-			for (int u = 0; u < KL; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; xs[u] = i < n ? src[i].x : 0ull; }
+			for (int u = 0; u < KL; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; xs[u] = i < n ? rh_rec_ops<REC>::key(src[i], rf) : 0ull; }
 #pragma unroll
 			for (int u = 0; u < KL; ++u) {
 				const uint32_t i = i0 + (uint32_t)u * NT;
@@ -614,17 +615,17 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 	// STG records at a time - and every thread picks the ones its output positions want (kept in registers) from there.
 	{
 		constexpr int K = (CAP + NT - 1) / NT;
-		constexpr uint32_t STG = (uint32_t)((sizeof(KT) + 4u) * (size_t)CAP / 16u);
+		constexpr uint32_t STG = (uint32_t)((sizeof(KT) + 4u) * (size_t)CAP / sizeof(REC));
 		uint16_t iav[K];
 #pragma unroll
 		for (int k = 0; k < K; ++k) { const uint32_t i = tid + (uint32_t)k * NT; iav[k] = i < n ? L.ia[i] : (uint16_t)0xFFFFu; }
 		__syncthreads();
-		rh_mm128_t *stage = reinterpret_cast<rh_mm128_t*>(&L);
+		REC *stage = reinterpret_cast<REC*>(&L);
 		for (uint32_t sb = 0; sb < n; sb += STG) {
 			const uint32_t m = n - sb < STG ? n - sb : STG;
 			constexpr int KS = (int)((STG + NT - 1) / NT) < 8 ? (int)((STG + NT - 1) / NT) : 8;   // loads in flight per thread
 			for (uint32_t i0 = tid; i0 < m; i0 += (uint32_t)KS * NT) {
-				rh_mm128_t rv[KS];
+				REC rv[KS];
 #pragma unroll
 				for (int u = 0; u < KS; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; rv[u] = src[sb + (i < m ? i : 0u)]; }
 #pragma unroll
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 	// that hold tied keys only; every other record already sits at its final place, and so does each group of equal keys
 	// as a whole - only the records inside the groups are rewritten.  (The keys again: the staging above overwrote them.)
 	for (uint32_t i = tid; i < n; i += NT) {
-		const uint64_t x = src[i].x;
+		const uint64_t x = rh_rec_ops<REC>::key(src[i], rf);
 		if (sizeof(KT) == 8) L.key[i] = (KT)x;
 		else L.key[i] = (KT)((x & ((1ull << kc.lo_bits) - 1ull)) | ((x >> 32) & ((1ull << kc.mid_bits) - 1ull)) << kc.lo_bits | (kc.hi_bits ? x >> 63 : 0ull) << (kc.lo_bits + kc.mid_bits));
 	}
@@ -662,23 +663,25 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 // bitonic network in the lane's registers, the position in the low bits making the order stable; other keys are ranked by
 // counting.  Records are read through the L1 (a wavefront's segments are neighbours in memory) and written once.
 #define RH_SORT_TINY 32
+template <class REC>
 __global__ __launch_bounds__(NT) void k_sort_tiny(rh_sort_job jb, uint32_t n_lo)
 {
+	const rh_rec_fmt rf = jb.rf;
 	const uint32_t a = blockIdx.x * NT + threadIdx.x;
 	uint32_t n = 0;
 	uint64_t base = 0;
 	if (a < jb.n_seg && !(jb.skip && jb.skip[a])) { base = jb.off[a]; n = jb.cnt ? jb.cnt[a] : (uint32_t)(jb.off[a + 1] - base); }
 	const bool mine = n > n_lo && n <= (uint32_t)RH_SORT_TINY;
 	if (__ballot(mine) == 0) return;
-	const rh_mm128_t *src = jb.src + base;
-	rh_mm128_t *dst = jb.dst + base;
+	const REC *src = reinterpret_cast<const REC*>(jb.src) + base;
+	REC *dst = reinterpret_cast<REC*>(jb.dst) + base;
 	uint32_t c[RH_SORT_TINY];
 	uint64_t k0 = 0, dif = 0;
 #pragma unroll
 	for (int j = 0; j < RH_SORT_TINY; ++j) {
 		c[j] = 0xFFFFFFFFu;
 		if (mine && (uint32_t)j < n) {
-			const uint64_t k = src[j].x;
+			const uint64_t k = rh_rec_ops<REC>::key(src[j], rf);
 			if (j == 0) k0 = k;
 			dif |= k ^ k0;
 			c[j] = (uint32_t)k << 5 | (uint32_t)j;
@@ -718,9 +721,10 @@ __global__ __launch_bounds__(NT) void k_sort_tiny(rh_sort_job jb, uint32_t n_lo)
 	}
 	if (wide) {	// (rare: keys of a free-standing short segment) rank = records that sort before this one, earlier position first among equals
 		for (uint32_t j = 0; j < n; ++j) {
-			const rh_mm128_t rj = src[j];
+			const REC rj = src[j];
+			const uint64_t kj = rh_rec_ops<REC>::key(rj, rf);
 			uint32_t rank = 0;
-			for (uint32_t i = 0; i < n; ++i) { const uint64_t ki = src[i].x; rank += (ki < rj.x || (ki == rj.x && i < j)) ? 1u : 0u; if (ki == rj.x && i != j) tie = true; }
+			for (uint32_t i = 0; i < n; ++i) { const uint64_t ki = rh_rec_ops<REC>::key(src[i], rf); rank += (ki < kj || (ki == kj && i < j)) ? 1u : 0u; if (ki == kj && i != j) tie = true; }
 			dst[rank] = rj;
 		}
 	}
@@ -734,24 +738,26 @@ __global__ __launch_bounds__(NT) void k_sort_tiny(rh_sort_job jb, uint32_t n_lo)
 // (cross-lane steps by ds_bpermute).  Equal keys (adjacent after the sort) or wider keys: the bucket is left, untouched, to the LDS
 // block sorter and its exact passes; a finished bucket's count is zeroed so that those launches pass over it.
 #define RH_SORT_WAVE 256
+template <class REC>
 __global__ __launch_bounds__(NT) void k_sort_wave(rh_sort_job jb, uint32_t n_lo)
 {
+	const rh_rec_fmt rf = jb.rf;
 	constexpr int E = RH_SORT_WAVE / 64;
 	const uint32_t a = blockIdx.x * (NT / 64) + wave_id(), lane = lane_id();
 	if (a >= jb.n_seg) return;
 	const uint32_t n = rh_uniform(jb.cnt_rw[a]);
 	if (n <= n_lo || n > (uint32_t)RH_SORT_WAVE) return;
 	const uint64_t base = jb.off[a];
-	const rh_mm128_t *src = jb.src + base;
-	rh_mm128_t *dst = jb.dst + base;
+	const REC *src = reinterpret_cast<const REC*>(jb.src) + base;
+	REC *dst = reinterpret_cast<REC*>(jb.dst) + base;
 	uint32_t w[E];
 	uint64_t dif = 0;
-	const uint64_t first = src[0].x;
+	const uint64_t first = rh_rec_ops<REC>::key(src[0], rf);
 #pragma unroll
 	for (int e = 0; e < E; ++e) {
 		const uint32_t i = lane + 64u * (uint32_t)e;
 		w[e] = 0xFFFFFFFFu;
-		if (i < n) { const uint64_t k = src[i].x; dif |= k ^ first; w[e] = (uint32_t)k << 8 | i; }
+		if (i < n) { const uint64_t k = rh_rec_ops<REC>::key(src[i], rf); dif |= k ^ first; w[e] = (uint32_t)k << 8 | i; }
 	}
 	if (__ballot((dif >> 24) != 0)) return;                          // wider keys: the block sorter
 #pragma unroll
@@ -801,7 +807,8 @@ template <int CAP, class KT>
 static void launch_class(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t lo, uint32_t hi)
 {
 	if (jb.n_max && lo >= jb.n_max) return;                       // no segment reaches this class
-	RH_LAUNCH((k_sort_block<CAP, KT>), jb.n_seg, NT, 0, s, jb, lo, hi, all_exact ? 2 : 0);
+	if (jb.rf.rec8) RH_LAUNCH((k_sort_block<CAP, KT, uint64_t>), jb.n_seg, NT, 0, s, jb, lo, hi, all_exact ? 2 : 0);
+	else RH_LAUNCH((k_sort_block<CAP, KT, rh_mm128_t>), jb.n_seg, NT, 0, s, jb, lo, hi, all_exact ? 2 : 0);
 }
 
 static bool sort_keys32(const rh_sort_job &jb) { return jb.kc_on && (uint32_t)jb.kc_lo + jb.kc_mid + jb.kc_hi <= 32u && jb.kc_mid <= 24u; }
@@ -814,12 +821,16 @@ int rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t 
 	uint32_t top;
 	static const bool tiny_on = !(getenv("RH_SORT_TINY") && atoi(getenv("RH_SORT_TINY")) == 0);
 	if (tiny_on && min_n < (uint32_t)RH_SORT_TINY) {	// one lane per segment of up to 32 records
-		RH_LAUNCH(k_sort_tiny, (jb.n_seg + NT - 1) / NT, NT, 0, s, jb, min_n);
+		if (jb.rf.rec8) RH_LAUNCH(k_sort_tiny<uint64_t>, (jb.n_seg + NT - 1) / NT, NT, 0, s, jb, min_n);
+		else RH_LAUNCH(k_sort_tiny<rh_mm128_t>, (jb.n_seg + NT - 1) / NT, NT, 0, s, jb, min_n);
 		min_n = (uint32_t)RH_SORT_TINY;
 		if (jb.n_max && jb.n_max <= min_n) return 0;
 	}
 	static const bool wave_on = !(getenv("RH_SORT_WAVE") && atoi(getenv("RH_SORT_WAVE")) == 0);
-	if (wave_on && jb.cnt_rw && !jb.skip && min_n < (uint32_t)RH_SORT_WAVE) RH_LAUNCH(k_sort_wave, (jb.n_seg + NT / 64 - 1) / (NT / 64), NT, 0, s, jb, min_n);   // a wavefront per bucket of up to 256 records (the rest, and its leftovers, below)
+	if (wave_on && jb.cnt_rw && !jb.skip && min_n < (uint32_t)RH_SORT_WAVE) {
+		if (jb.rf.rec8) RH_LAUNCH(k_sort_wave<uint64_t>, (jb.n_seg + NT / 64 - 1) / (NT / 64), NT, 0, s, jb, min_n);
+		else RH_LAUNCH(k_sort_wave<rh_mm128_t>, (jb.n_seg + NT / 64 - 1) / (NT / 64), NT, 0, s, jb, min_n);
+	}   // a wavefront per bucket of up to 256 records (the rest, and its leftovers, below)
 	if (sort_keys32(jb)) {
 		launch_class<RH_SORT_CAP0, uint32_t>(s, jb, all_exact, min_n, (uint32_t)RH_SORT_CAP0);
 		launch_class<RH_SORT32_CAPH, uint32_t>(s, jb, all_exact, (uint32_t)RH_SORT_CAP0, (uint32_t)RH_SORT32_CAPH);
@@ -843,10 +854,17 @@ int rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t 
 static void sort_scratch(rh_sort_job &jb, const rh_dev_round &r, rh_mm128_t *idle) { jb.big_alt = idle; jb.big_ws = r.sort_ws; jb.big_ws_bytes = r.sort_ws_bytes; jb.big_pin = r.sort_pin; jb.big_total = r.sort_total; }
 
 // anchor sort of a chunk round: unsorted expand output -> reference order
-int rhk_sort(hipStream_t s, const rh_dev_round &r)
+int rhk_sort(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r)
 {
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, nullptr, r.raw, r.anc, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 0, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };
 	sort_scratch(jb, r, r.zs);                                     // (the candidate array is idle until the chain DP has run)
 	jb.kind = 1;
-	return rhk_sort_job(s, jb, false, 0u);
+	if (!r.afmt.rec8) return rhk_sort_job(s, jb, false, 0u);
+	// one-word anchors (k_expand): sorted from the first half of the 16-byte-per-anchor arena into its second half, then expanded
+	uint64_t *sorted8 = reinterpret_cast<uint64_t*>(r.raw) + r.arena_n;
+	jb.dst = reinterpret_cast<rh_mm128_t*>(sorted8);
+	jb.rf = r.afmt;
+	if (rhk_sort_job(s, jb, false, 0u)) return -1;
+	rhk_anchor_unpack(s, ix, r, sorted8);
+	return 0;
 }

@@ -1,0 +1,18 @@
+# sorter parity + 3-stream bench + 1-stream kernel table of the build in the tree.  Usage: bash tools/r04_one.sh <tag> [kernel-name filter]
+cd /tmp && export TMPDIR=/tmp
+R=/root/repo; O=$R/gpurun_out; TAG=${1:-one}; PAT=${2:-k_bs_}; mkdir -p $O
+cd $R; timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "sort or golden or config2 or repeat or regions or human" 2>&1 | tail -2
+timeout 600 python bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-h2d 2>/dev/null | tail -1 > $O/${TAG}_x.json
+python - <<PY
+import json
+d=json.load(open("$O/${TAG}_x.json")); print("3-stream", d["value"], d["ms_per_step"])
+PY
+cd /tmp; rm -rf /tmp/pf_$TAG
+RH_SUB_BATCHES=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_$TAG -o p -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-h2d > /dev/null 2>&1
+cp $(find /tmp/pf_$TAG -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats.csv
+python - <<PY
+import csv
+rows=list(csv.DictReader(open("$O/${TAG}_kernel_stats.csv")))
+tot=sum(float(r["TotalDurationNs"]) for r in rows if not r["Name"].startswith(("k_ix","k_synth")))/1e6
+print("1-stream total", round(tot), [ (r["Name"].replace("void ","")[:30], round(float(r["TotalDurationNs"])/1e6,1)) for r in rows if "$PAT" in r["Name"]])
+PY
