@@ -153,14 +153,19 @@ RH_API int  rh_index_adopt_blob(rh_ctx *ctx, const rh_index *idx_meta /* may be 
                                 const void *header /* from rank 0 */, int take_ownership);
 /* Single-process replication (a multi-threaded C/C++ host driving all GPUs of a node, one rh_ctx each): the resident index of
  * ctxs[0] is copied device-to-device (hipMemcpyPeer: xGMI where the GPUs are linked) into every other context, which adopts
- * it.  One process per GPU replicates with RCCL instead (rawhash_amd.dist / bench.py). */
+ * it.  Contexts on distinct devices: ONE collective, ncclBroadcast over RCCL (librccl.so.1, loaded at run time) in pieces of <= 1 GiB
+ * - the north star's "RCCL over xGMI only to broadcast the index at load", reachable from a single C/C++ process; RH_BCAST=peer, contexts
+ * that share a device, or a missing librccl fall back to a doubling tree of hipMemcpyPeerAsync copies.  One process per GPU replicates
+ * with RCCL through torch.distributed instead (rawhash_amd.dist / bench.py). */
 RH_API int  rh_index_bcast(rh_ctx *const *ctxs, int n);
+RH_API int  rh_index_bcast_path(void);            /* what the last rh_index_bcast went through: 1 RCCL, 2 peer copies, 0 none yet */
+RH_API int  rh_rccl_selftest(rh_ctx *ctx);         /* librccl loads, resolves, and a one-rank communicator broadcasts in place (one-GPU boxes) */
 
 /* ri_idx_gen rindex.c:900 on the GPU: sketches the targets, sorts and groups the seeds and fills the
  * HBM-resident table of this context directly (as rh_index_upload would), in seconds for a human-sized reference.
  * seqs[i] = the bases of target i in host memory (ACGTU in either case; anything else is an ambiguous base,
- * ri_seq_to_sig rsig.c:13-41), lens[i] < 2^31.  Minimiser indexes (w > 0) and signal-target indexes are built by
- * rh_index_build on the host.  The returned host object carries the header, target names/lengths and the occupancy
+ * ri_seq_to_sig rsig.c:13-41), lens[i] < 2^31.  Plain (w = 0) and minimiser (w > 0, ri_sketch_min rsketch.c:55-141) indexes are both
+ * built on the device; signal-target indexes by rh_index_build_signals_device below.  The returned host object carries the header, target names/lengths and the occupancy
  * statistics rh_mapopt_update needs; rh_index_download fetches keys and positions (for rh_index_get or to write a .ind
  * with rh_index_write). */
 RH_API rh_index *rh_index_build_device(rh_ctx *ctx, uint32_t n_seq, const char *const *names, const char *const *seqs, const uint32_t *lens,
@@ -262,7 +267,9 @@ RH_API int  rh_paf_format(const rh_index *idx, const rh_map_record_t *rec, const
 /* ------------------------------------------------------------------------------------------- read container */
 /* Reads from a file into the SoA batch (raw int16 + calibration: what step 0, ri_sig_read_frag rmap.cpp:601, hands to step 1):
  *   BLOW5 (binary SLOW5, hasindu2008/slow5lib file format 1.0.0 / 0.2.0 / 0.1.0; replaces ri_read_sig_slow5 rsig.c:478-533 +
- *          slow5lib): records uncompressed or zlib-compressed, signal uncompressed (zstd / svb-zd: refused with an error)
+ *          slow5lib): records uncompressed, zlib- or zstd-compressed (libzstd.so.1 is loaded at run time: a missing library is an
+ *          error), signal raw or svb-zd (StreamVByte of zig-zag deltas; ONE layout: u64 compressed byte count | u32 values | block -
+ *          anything else is refused).  Every length field is checked against the record / file before a buffer grows for it.
  *   RHR1  (own minimal container used by tests and the reference harness): magic, u32 n; per read: u32 name_len, name,
  *          u32 n_samples, f64 digitisation, f64 range, f64 offset, i16[n].
  * The format is recognised by its magic. */
@@ -276,7 +283,8 @@ RH_API int       rh_reads_pinned(const rh_reads *r);                          /*
 RH_API int       rh_reads_write(const char *path, uint32_t n, const char *const *names, const int16_t *samples,
                                 const uint64_t *offsets, double digitisation, double range, double offset);
 RH_API int       rh_reads_write_blow5(const char *path, uint32_t n, const char *const *names, const int16_t *samples, const uint64_t *offsets,
-                                      double digitisation, double range, double offset, double sampling_rate, int zlib_records);
+                                      double digitisation, double range, double offset, double sampling_rate, int compression);
+/* (compression & 0xFF = record compression: 0 none, 1 zlib, 2 zstd; bit 8 (0x100) = svb-zd signal compression) */
 
 /* ------------------------------------------------------------------------------------------- synthetic workload */
 /* Deterministic, integer-only generator (same bytes on any host): i.i.d. genome, 6-mer pore model ~N(90,12) pA,

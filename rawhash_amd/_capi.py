@@ -145,6 +145,7 @@ def _declare(lib):
         "rh_map_submit": (i32, [vp, P(MapOpt), P(ReadBatch), vp, u64, P(Ticket)]), "rh_map_wait": (i32, [vp, Ticket, P(u64)]),
         "rh_read_batch_to_host": (i32, [vp, P(ReadBatch), vp, vp, vp, vp]),
         "rh_pinned_alloc": (vp, [C.c_size_t]), "rh_pinned_free": (None, [vp]), "rh_index_bcast": (i32, [P(vp), i32]),
+        "rh_index_bcast_path": (i32, []), "rh_rccl_selftest": (i32, [vp]),
         "rh_map_last_stats": (i32, [vp, P(MapStats)]), "rh_stage_name": (cp, [i32]),
         "rh_events_batch": (i32, [vp, P(MapOpt), P(ReadBatch), u32, vp, u64, vp, vp]),
         "rh_sketch_batch": (i32, [vp, u32, vp, vp, vp, u64, vp]),

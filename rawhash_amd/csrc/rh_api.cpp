@@ -8,6 +8,8 @@
 #include <string>
 #include <thread>
 #include <cstdlib>
+#include <atomic>
+#include <dlfcn.h>
 
 namespace {
 
@@ -84,6 +86,7 @@ struct rh_ctx_s {
 	DevBuf events, dtw_ws, dtw_n, dtw_off, dtw_rec, dtw_dec;       // RH_M_DTW_EVALUATE_CHAINS: reads' events, DP buffers, per-region values for the host's MAPQ, its decisions
 	DevBuf name_rank, t_rank, rec_off;                            // all-vs-all: name ranks of the reads / of the targets, record offsets
 	uint64_t arena_room = 0;                                       // anchors the per-anchor arenas were sized for when a round was last cut into slices (the budget sticks to it)
+	uint32_t cs_stride = 2;                                        // chunk boundaries kept per read of the current batch: max_num_chunk + 1
 	uint32_t ev_row = RH_CHUNK_MAX + 64, ev_cap = RH_EV_CAP, whole = 0;   // strides of the per-read rows of the current batch (whole-read rounds: sized by its longest read)
 	DevBuf carry[2], carry_off, a_off_slice;                      // chained anchors carried into the next chunk, dense, ping-pong over the rounds
 	int share = 1;                                                 // sub-batches running concurrently on this device (memory budget per context)
@@ -138,7 +141,7 @@ static int chain_stages(rh_ctx *c, hipStream_t s, const rh_dev_opt &o, const rh_
 int fill_dev_opt(const rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
 {
 	if (mo->chunk_size == 0 || mo->chunk_size > RH_CHUNK_MAX) { rh_set_error("chunk_size %u not supported on the device (1..%d)", mo->chunk_size, RH_CHUNK_MAX); return -1; }
-	if (mo->max_num_chunk > RH_MAX_CHUNKS) { rh_set_error("max_num_chunk %u > %d not supported", mo->max_num_chunk, RH_MAX_CHUNKS); return -1; }
+	if (mo->max_num_chunk > (1u << 16)) { rh_set_error("max_num_chunk %u > 65536 not supported", mo->max_num_chunk); return -1; }
 	if ((mo->flag & RH_M_ALL_CHAINS) && !(mo->flag & RH_M_NO_ADAPTIVE)) { rh_set_error("all-chains output is built for whole-read rounds only (RH_M_ALL_CHAINS needs RH_M_NO_ADAPTIVE, as in the ava presets)"); return -1; }
 	if ((mo->flag & RH_M_NO_ADAPTIVE) && (mo->window_length1 > 15 || mo->window_length2 > 15)) { rh_set_error("whole-read rounds need segmentation windows <= 15"); return -1; }
 	if ((mo->flag & RH_M_ALL_CHAINS) && c->have_index && !c->dix.t_rank) { rh_set_error("all-vs-all mapping needs the name ranks of the targets (rh_index_set_target_ranks)"); return -1; }
@@ -309,11 +312,12 @@ int stage_reads(rh_ctx *c, const rh_read_batch_t *in, rh_dev_reads *rd)
 	size_t k = 0;
 	auto U32 = [&](uint32_t *&p, size_t cnt) { if (c->st[k].ensure(cnt * 4)) return -1; p = c->st[k].as<uint32_t>(); ++k; return 0; };
 	auto I32 = [&](int32_t *&p, size_t cnt) { if (c->st[k].ensure(cnt * 4)) return -1; p = c->st[k].as<int32_t>(); ++k; return 0; };
-	if (U32(rd->l_sig, n) || U32(rd->chunk_start, n * (RH_MAX_CHUNKS + 1)) || U32(rd->n_sum, n) || U32(rd->ev_off, n) || U32(rd->n_prev, n) || U32(rd->stop_chunk, n)) return -1;
+	if (U32(rd->l_sig, n) || U32(rd->chunk_start, n * (size_t)c->cs_stride) || U32(rd->n_sum, n) || U32(rd->ev_off, n) || U32(rd->n_prev, n) || U32(rd->stop_chunk, n)) return -1;
 	if (c->st[k].ensure(n * 8)) return -1; rd->sum = c->st[k++].as<double>();
 	if (c->st[k].ensure(n * 8)) return -1; rd->sum2 = c->st[k++].as<double>();
 	if (c->st[k].ensure(n * 8)) return -1; rd->prev_off = c->st[k++].as<uint64_t>();
 	if (c->st[k].ensure(n)) return -1; rd->done = c->st[k++].as<uint8_t>();
+	rd->cs_stride = c->cs_stride;
 	if (I32(rd->ls_ncregs, n) || I32(rd->ls_cnt, n) || I32(rd->ls_score, n) || I32(rd->ls_mapq, n) || I32(rd->ls_qs, n) || I32(rd->ls_qe, n) ||
 	    I32(rd->ls_rs, n) || I32(rd->ls_re, n) || I32(rd->ls_rid, n) || I32(rd->ls_rev, n)) return -1;
 	return 0;
@@ -777,6 +781,7 @@ void dump_round2(rh_ctx *c, uint32_t chunk, uint32_t n_act, const rh_dev_round &
 int set_row_strides(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in)
 {
 	c->whole = (mo->flag & RH_M_NO_ADAPTIVE) ? 1 : 0;
+	c->cs_stride = (c->whole ? 1u : (mo->max_num_chunk ? mo->max_num_chunk : 1u)) + 1u;
 	c->ev_row = RH_CHUNK_MAX + 64; c->ev_cap = RH_EV_CAP;
 	if (!c->whole) return 0;
 	const uint32_t R = in->n_reads;
@@ -1197,6 +1202,90 @@ extern "C" void *rh_pinned_alloc(size_t bytes)
 }
 extern "C" void rh_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
 
+// ---- RCCL, in process (north star: "RCCL over xGMI only to broadcast the index at load").  librccl.so.1 is loaded at run time, so the
+// library has no link-time dependency on it; the entry points used are the NCCL API as rccl.h declares it (ncclCommInitAll,
+// ncclGroupStart / End, ncclBroadcast, ncclCommDestroy).  One communicator per device of the contexts, one broadcast per <= 1 GiB piece
+// (a 45 GB blob exceeds what a single collective takes as an element count on some builds), every rank's call inside one group.
+namespace {
+struct Rccl {
+	void *h = nullptr;
+	int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+	int (*CommDestroy)(void *comm) = nullptr;
+	int (*GroupStart)() = nullptr;
+	int (*GroupEnd)() = nullptr;
+	int (*Broadcast)(const void *send, void *recv, size_t count, int dtype, int root, void *comm, hipStream_t s) = nullptr;
+	const char *(*GetErrorString)(int) = nullptr;
+	bool ok = false;
+	Rccl()
+	{
+		for (const char *nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+		if (!h) return;
+		CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+		GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart"); GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
+		Broadcast = (decltype(Broadcast))dlsym(h, "ncclBroadcast"); GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+		ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Broadcast;
+	}
+	const char *err(int rc) const { return GetErrorString ? GetErrorString(rc) : "?"; }
+};
+Rccl &rccl() { static Rccl r; return r; }
+const int kNcclUint8 = 1;                                          // ncclUint8 (rccl.h: ncclInt8 = 0, ncclUint8 = 1)
+
+// broadcast bytes of buf[0] (device devs[0]) into buf[i] (device devs[i]) - distinct devices.  0 done, 1 RCCL not available (the caller
+// falls back to peer copies), -1 failed (error set)
+int rccl_bcast(int n, const int *devs, void *const *buf, uint64_t bytes)
+{
+	Rccl &R = rccl();
+	if (!R.ok) return 1;
+	std::vector<void*> comms((size_t)n, nullptr);
+	int rc = R.CommInitAll(comms.data(), n, devs);
+	if (rc) { rh_set_error("ncclCommInitAll over %d devices failed: %s", n, R.err(rc)); return -1; }
+	std::vector<hipStream_t> st((size_t)n, nullptr);
+	int bad = 0;
+	for (int i = 0; i < n && !bad; ++i) if (hipSetDevice(devs[i]) != hipSuccess || hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) bad = 1;
+	uint64_t piece = 1ull << 30;
+	if (const char *e = getenv("RH_BCAST_PIECE_BYTES")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) piece = v; }
+	for (uint64_t at = 0; at < bytes && !bad; at += piece) {
+		const uint64_t len = bytes - at < piece ? bytes - at : piece;
+		if ((rc = R.GroupStart())) { bad = 1; break; }
+		for (int i = 0; i < n; ++i) {
+			(void)hipSetDevice(devs[i]);
+			unsigned char *p = (unsigned char*)buf[i] + at;
+			const int r2 = R.Broadcast(p, p, (size_t)len, kNcclUint8, 0, comms[i], st[i]);
+			if (r2) rc = r2;
+		}
+		const int r3 = R.GroupEnd();
+		if (rc || r3) { if (!rc) rc = r3; bad = 1; }
+	}
+	for (int i = 0; i < n; ++i) if (st[i]) { (void)hipSetDevice(devs[i]); if (hipStreamSynchronize(st[i]) != hipSuccess) bad = 1; (void)hipStreamDestroy(st[i]); }
+	for (int i = 0; i < n; ++i) if (comms[i]) (void)R.CommDestroy(comms[i]);
+	if (bad) { rh_set_error("RCCL broadcast of the index blob failed: %s", rc ? R.err(rc) : hipGetErrorString(hipGetLastError())); return -1; }
+	return 0;
+}
+} // namespace
+
+// what the last rh_index_bcast of this process went through: 0 nothing yet, 1 RCCL (ncclBroadcast), 2 peer copies (hipMemcpyPeerAsync tree)
+static std::atomic<int> g_bcast_path{0};
+extern "C" int rh_index_bcast_path(void) { return g_bcast_path.load(); }
+
+// librccl.so.1 loads, its entry points resolve and a one-rank communicator broadcasts in place on this context's device: what a one-GPU
+// box can check of the RCCL path (returns 0, or -1 with the reason)
+extern "C" int rh_rccl_selftest(rh_ctx *c)
+{
+	if (!rccl().ok) { rh_set_error("librccl.so.1 could not be loaded (or lacks the NCCL entry points)"); return -1; }
+	RH_HIP(hipSetDevice(c->device));
+	void *buf = nullptr;
+	RH_HIP(hipMalloc(&buf, 1 << 20));
+	RH_HIP(hipMemset(buf, 0x5A, 1 << 20));
+	const int dev = c->device;
+	const int rc = rccl_bcast(1, &dev, &buf, 1 << 20);
+	unsigned char probe[2] = {0, 0};
+	(void)hipMemcpy(probe, (unsigned char*)buf + (1 << 20) - 2, 2, hipMemcpyDeviceToHost);
+	(void)hipFree(buf);
+	if (rc) { if (rc > 0) rh_set_error("RCCL not available"); return -1; }
+	if (probe[0] != 0x5A || probe[1] != 0x5A) { rh_set_error("RCCL self-test: the buffer changed under a one-rank broadcast"); return -1; }
+	return 0;
+}
+
 extern "C" int rh_index_bcast(rh_ctx *const *ctxs, int n)
 {
 	if (n < 1 || need_index(ctxs[0])) return -1;
@@ -1210,8 +1299,28 @@ extern "C" int rh_index_bcast(rh_ctx *const *ctxs, int n)
 		d->blob_owned = true; d->have_index = false;
 		if (d->blob.ensure(h.bytes, false)) return -1;
 	}
+	// RCCL first (one ncclBroadcast per piece over the ring / tree RCCL builds on the xGMI links) when every context sits on its own
+	// device; RH_BCAST=peer, contexts sharing a device (tests on a one-GPU box) or a missing librccl take the peer-copy tree below
+	{
+		bool distinct = n >= 2;
+		for (int i = 0; i < n && distinct; ++i) for (int j = 0; j < i; ++j) if (ctxs[i]->device == ctxs[j]->device) { distinct = false; break; }
+		const char *mode = getenv("RH_BCAST");
+		if (distinct && !(mode && !strcmp(mode, "peer"))) {
+			std::vector<int> devs((size_t)n); std::vector<void*> bufs((size_t)n);
+			for (int i = 0; i < n; ++i) { devs[i] = ctxs[i]->device; bufs[i] = ctxs[i]->blob.p; }
+			const int r = rccl_bcast(n, devs.data(), bufs.data(), h.bytes);
+			if (r < 0) return -1;
+			if (r == 0) {
+				for (int i = 1; i < n; ++i) { RH_HIP(hipSetDevice(ctxs[i]->device)); if (bind_blob(ctxs[i], h)) return -1; }
+				RH_HIP(hipSetDevice(src->device));
+				g_bcast_path.store(1);
+				return 0;
+			}
+		}
+	}
 	// doubling tree 0 -> 1, {0,1} -> {2,3}, {0..3} -> {4..7}: every GPU that holds the blob feeds one that does not, each copy over
 	// its own point-to-point xGMI link, ceil(log2 n) rounds of one blob time instead of n - 1 copies out of GPU 0
+	g_bcast_path.store(2);
 	std::vector<hipStream_t> st((size_t)n, nullptr);
 	int rc = 0;
 	for (int have = 1; have < n && !rc; have *= 2) {
@@ -1266,8 +1375,8 @@ extern "C" int rh_events_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_b
 {
 	RH_HIP(hipSetDevice(c->device));
 	rh_mapopt_t m2 = *mo;
-	m2.max_num_chunk = RH_MAX_CHUNKS; m2.flag = 0; m2.bw_long = 0;
-	if (chunk >= RH_MAX_CHUNKS) { rh_set_error("chunk %u out of range", chunk); return -1; }
+	m2.max_num_chunk = chunk + 1 > 32u ? chunk + 1 : 32u; m2.flag = 0; m2.bw_long = 0;
+	c->cs_stride = m2.max_num_chunk + 1;
 	rh_dev_opt o;
 	if (fill_dev_opt(c, &m2, &o)) return -1;
 	o.min_events = 0;

@@ -35,19 +35,24 @@ __device__ __forceinline__ void rh_writelane2(uint32_t &a, uint32_t &b, uint32_t
 __device__ __forceinline__ uint32_t rh_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t rh_and_or(uint32_t a, uint32_t m, uint32_t o) { uint32_t r; asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(m), "v"(o)); return r; }   // (a & m) | o in one instruction
 // The token walker's per-pop advance of ONE lane (l: wave-uniform, in an SGPR): jr += 1, head = LDS byte at ringa | (jr & 63).
-// v_cmpx selects the lane (EXEC written by the compare itself) and one s_mov restores EXEC - the walker runs with all 64 lanes
-// alive and in wave-uniform control flow - where `if (lane == l)` compiles to v_cmp + s_and_saveexec + s_cbranch_execz + s_or: the
-// walk is bound by SCALAR issue (one scalar unit per CU: an s_ instruction costs a SIMD four cycles), not by vector instructions.
-// The compiler does not see the LDS read: rh_lds_wait(head) before head is used.
+// v_cmpx selects the lane (EXEC written by the compare itself); EXEC is saved before and restored after, whatever it was - where
+// `if (lane == l)` compiles to v_cmp + s_and_saveexec + s_cbranch_execz + s_or: the walk is bound by the number of instructions a SIMD
+// issues per pop, not by their kind.
+// The LDS read is ASYNCHRONOUS and the compiler does not know it: `head` is only defined after rh_lds_wait(head), which the walker
+// calls before the next v_readlane of it.  Nothing may read `head` in between - the compiler has no reason to (head is not used between
+// the two statements), and tests/test_abi.py::test_token_walker_isa_keeps_lds_read_private checks the generated code for it after every
+// build (a register copy or spill of `head` inside that window would read stale data); RH_BS_TOK_ADV=0 selects the compiler-scheduled pop.
 __device__ __forceinline__ void rh_tok_advance(uint32_t &jr, uint32_t &head, const uint8_t *, uint32_t ringa, uint32_t l, uint32_t lane)
 {
 	uint32_t ad;
-	asm volatile("v_cmpx_eq_u32_e32 vcc, %[l], %[ln]\n\t"
+	uint64_t sv;
+	asm volatile("s_mov_b64 %[sv], exec\n\t"
+	             "v_cmpx_eq_u32_e32 vcc, %[l], %[ln]\n\t"
 	             "v_add_u32_e32 %[jr], 1, %[jr]\n\t"
 	             "v_and_or_b32 %[ad], %[jr], 63, %[ra]\n\t"
 	             "ds_read_u8 %[hd], %[ad]\n\t"
-	             "s_mov_b64 exec, -1"
-	             : [jr] "+v"(jr), [hd] "+v"(head), [ad] "=&v"(ad)
+	             "s_mov_b64 exec, %[sv]"
+	             : [jr] "+v"(jr), [hd] "+v"(head), [ad] "=&v"(ad), [sv] "=&s"(sv)
 	             : [l] "s"(l), [ln] "v"(lane), [ra] "v"(ringa) : "memory", "vcc");
 }
 __device__ __forceinline__ void rh_lds_wait(uint32_t &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)); }

@@ -10,8 +10,12 @@
 
 #define RH_CHUNK_MAX   4096          // samples of one chunk held in LDS by the event kernel
 #define RH_EV_CAP      2048          // events per chunk: peaks are >= 2 samples apart (revent.c:140)
-#define RH_MAX_CHUNKS  32            // chunk boundaries kept per read
 #define RH_WS_PER_ANCHOR 64          // bytes of per-anchor scratch shared by DP / backtrack / compaction / regions (>= 128 B per chain: a chain has >= 2 anchors)
+// Layout of a read's scratch during DP and backtrack (n anchors): {f, p} pairs [0, 8 n) | v [8 n, 12 n) | "used" marks, one byte each [16 n, 17 n) |
+// claim stamps [20 n, 24 n).  Three arrays on purpose.  Measured on MI355X (human-scale step, k_backtrack_spec 234 ms): the marks inside a 16-byte
+// {f, p, claim, used} record -> 404 ms (every candidate starts with a look at its own mark, most are used already, and 64 byte marks share a sector
+// where 4 records do); the claim stamp inside a {f, p, claim, v} record with the marks apart -> 1051 ms (the stamps are L2 atomics: a read-modify-write
+// on the line every walker of the neighbourhood is loading f / p from).
 #define RH_LOGF_N      (1u << 20)    // host-libm logf() table for integer arguments (MAPQ parity, hit.c:525-533)
 #define RH_DEV_MAXW    16            // largest minimiser window the device sketch supports
 
@@ -70,7 +74,7 @@ struct rh_dev_reads {
 	const int16_t *raw; const uint64_t *off; const double *cal_off; const float *cal_scale;
 	const uint32_t *name_rank;       // all-vs-all: rank of the read's name among the target names (strcmp(q, t) >= 0 <=> name_rank >= t_rank[t])
 	uint32_t *l_sig;                 // filtered length (sl:i tag)
-	uint32_t *chunk_start;           // n_reads x (RH_MAX_CHUNKS+1): raw index of the first sample of chunk c
+	uint32_t *chunk_start; uint32_t cs_stride;   // n_reads x cs_stride (= max_num_chunk + 1): raw index of the first sample of chunk c
 	double *sum, *sum2; uint32_t *n_sum;   // running normalisation sums (rmap.cpp:412-413)
 	uint32_t *ev_off;                // events accepted so far (reg->offset)
 	uint32_t *n_prev; uint64_t *prev_off;  // carried chain anchors (reg->prev_anchors)

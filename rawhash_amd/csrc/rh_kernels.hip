@@ -70,8 +70,8 @@ __global__ __launch_bounds__(NT) void k_prefilter(rh_dev_opt o, rh_dev_reads rd)
 	const double coff = rd.cal_off[r];
 	const float cscale = rd.cal_scale[r];
 	const uint32_t f5 = rd.fast5;
-	uint32_t *cs = rd.chunk_start + (size_t)r * (RH_MAX_CHUNKS + 1);
-	for (uint32_t k = tid; k <= RH_MAX_CHUNKS; k += NT) cs[k] = n;
+	uint32_t *cs = rd.chunk_start + (size_t)r * rd.cs_stride;
+	for (uint32_t k = tid; k < rd.cs_stride; k += NT) cs[k] = n;
 	const uint32_t C = o.chunk_size;
 	const uint32_t per = ((n + (NT / 64) * 256u - 1) / ((NT / 64) * 256u)) * 256u;   // samples per wavefront, whole tiles
 	const uint32_t beg = w * per < n ? w * per : n, end = beg + per < n ? beg + per : n;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(NT) void k_prefilter(rh_dev_opt o, rh_dev_reads rd)
 				for (uint32_t k = 0; k < 4; ++k) {
 					if ((B[k] >> l) & 1ull) {
 						const uint32_t fi = before + lanes_below(B[k]);
-						if (fi % C == 0) { const uint32_t kk = fi / C; if (kk <= RH_MAX_CHUNKS) cs[kk] = base + k * 64 + l; }
+						if (fi % C == 0) { const uint32_t kk = fi / C; if (kk < rd.cs_stride) cs[kk] = base + k * 64 + l; }
 					}
 					before += (uint32_t)__popcll(B[k]);
 				}
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NT) void k_events_norm(rh_dev_opt o, rh_dev_reads r
 	const double coff = rd.cal_off[r];
 	const float cscale = rd.cal_scale[r];
 	const uint32_t f5 = rd.fast5;
-	const uint32_t *cs = rd.chunk_start + (size_t)r * (RH_MAX_CHUNKS + 1);
+	const uint32_t *cs = rd.chunk_start + (size_t)r * rd.cs_stride;
 	const uint32_t cs0 = cs[c], cs1 = cs[c + 1];
 	const uint32_t C = o.chunk_size;
 

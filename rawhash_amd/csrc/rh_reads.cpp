@@ -46,10 +46,14 @@ struct rh_reads_s {
 	std::vector<float> cal_scale;
 };
 
+// size of a regular file; anything else (a FIFO, a failed fstat) has no size to check lengths against: "unknown" = a bound no length
+// field reaches, and the absolute caps below (name length, samples per read, decompressed record size) are what limits an allocation
+static const uint64_t kSizeUnknown = 1ull << 62;
+static const uint64_t kMaxNameLen = 1u << 16, kMaxReadSamples = 1ull << 32, kMaxRecordBytes = 1ull << 33;
 static uint64_t file_size_of(FILE *fp)
 {
 	struct stat st;
-	return fstat(fileno(fp), &st) == 0 && st.st_size >= 0 ? (uint64_t)st.st_size : 0;
+	return fstat(fileno(fp), &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 0 ? (uint64_t)st.st_size : kSizeUnknown;
 }
 
 static rh_reads *reads_load_rhr(const char *path);
@@ -85,7 +89,7 @@ static rh_reads *reads_load_rhr(const char *path)
 	for (uint32_t i = 0; i < n; ++i) {
 		uint32_t l = 0, ns = 0; double dig = 0, range = 0, off = 0;
 		std::string name;
-		bool ok = fread(&l, 4, 1, fp) == 1 && (at += 4, (uint64_t)l <= fsize - at);      // lengths are checked against what is left of the file
+		bool ok = fread(&l, 4, 1, fp) == 1 && (at += 4, at <= fsize && (uint64_t)l <= fsize - at && (uint64_t)l <= kMaxNameLen);      // lengths are checked against what is left of the file
 		if (ok) { name.resize(l); ok = l == 0 || fread(&name[0], 1, l, fp) == l; at += l; }
 		ok = ok && fread(&ns, 4, 1, fp) == 1 && fread(&dig, 8, 1, fp) == 1 && fread(&range, 8, 1, fp) == 1 && fread(&off, 8, 1, fp) == 1;
 		at += 28;
@@ -116,13 +120,16 @@ static rh_reads *reads_load_rhr(const char *path)
 //   record      : record size (u64) | body (compressed as a whole: one zlib stream / one zstd frame per record):
 //                 read_id length (u16) | read_id | read_group (u32) | digitisation, offset, range, sampling_rate (f64 x 4)
 //                 | len_raw_signal (u64) | raw_signal | auxiliary fields (ignored here)
-//   raw_signal  : i16 x len, or with svb-zd: compressed byte count | u32 number of values | StreamVByte block of the
-//                 zig-zag-encoded first differences (x[0] - 0, x[1] - x[0], ...) of the samples widened to 32 bits.
+//   raw_signal  : i16 x len, or with svb-zd (SLOW5 specification 1.0.0, "BLOW5 signal compression"; slow5lib slow5_rec_to_mem / slow5_press.c
+//                 ptr_compress_svb_zd): compressed byte count (u64: slow5lib writes a size_t, 8 bytes on the 64-bit platforms it supports)
+//                 | u32 number of values | StreamVByte block of the zig-zag-encoded first differences (x[0] - 0, x[1] - x[0], ...) of the
+//                 samples widened to 32 bits; the count covers the u32 and the block.
 //                 StreamVByte (Lemire's 32-bit format): ceil(n / 4) control bytes, two bits per value (bytes used - 1, first value in
 //                 the low bits), then the values' 1 - 4 little-endian data bytes back to back.
 //   end of file : "5WOLB"
-// The width of the "compressed byte count" could not be checked against slow5lib here; the reader therefore accepts a u64, a u32 or
-// no count at all, whichever makes the block consistent (inner value count = len_raw_signal, decode consumes exactly the block).
+// ONE layout is accepted for the svb-zd signal - the u64 count above - and anything else is refused with an error: the value count must
+// equal len_raw_signal and the decode must consume exactly the counted bytes.  (Unpinned against slow5lib itself: no file written by
+// slow5tools exists in this image)
 #include <zlib.h>
 
 namespace {
@@ -215,7 +222,8 @@ static rh_reads *reads_load_blow5(const char *path)
 		if (got != 8) return fail(r, "truncated BLOW5 record");
 		at += 8;
 		uint64_t rsz; memcpy(&rsz, szb, 8);
-		if (at > fsize || rsz > fsize - at || rsz >= (1ull << 32)) return fail(r, "implausible BLOW5 record size");   // (records are one read: far below 4 GiB, which is also what zlib's 32-bit counters take)
+		if (at > fsize || rsz > fsize - at || rsz >= (1ull << 32)) return fail(r, "implausible BLOW5 record size");
+		const uint64_t body_cap = rsz * 256u + (1u << 20) < kMaxRecordBytes ? rsz * 256u + (1u << 20) : kMaxRecordBytes;   // a decompressed record: nothing compresses a read 256-fold   // (records are one read: far below 4 GiB, which is also what zlib's 32-bit counters take)
 		raw.resize(rsz);
 		if (rsz && fread(raw.data(), 1, rsz, fp) != rsz) return fail(r, "truncated BLOW5 record");
 		at += rsz;
@@ -229,7 +237,7 @@ static rh_reads *reads_load_blow5(const char *path)
 			size_t out = 0;
 			int rc;
 			do {
-				if (out == body.size()) body.resize(body.size() * 2);
+				if (out == body.size()) { if (body.size() >= body_cap) { inflateEnd(&zs); return fail(r, "corrupt zlib BLOW5 record (implausible expansion)"); } body.resize(body.size() * 2 < body_cap ? body.size() * 2 : body_cap); }
 				const size_t room = body.size() - out;
 				zs.next_out = body.data() + out; zs.avail_out = (uInt)(room < 0x40000000u ? room : 0x40000000u);
 				const uInt gave = zs.avail_out;
@@ -241,7 +249,7 @@ static rh_reads *reads_load_blow5(const char *path)
 			b = body.data(); blen = out;
 		} else if (rec_comp == 2) {	// one zstd frame per record
 			const unsigned long long full = zstd().content_size(raw.data(), rsz);
-			if (full == 0ull - 1 || full == 0ull - 2 || full > (1ull << 34)) return fail(r, "corrupt zstd BLOW5 record (frame size)");
+			if (full == 0ull - 1 || full == 0ull - 2 || full > body_cap) return fail(r, "corrupt zstd BLOW5 record (frame size)");   // (checked before anything is allocated for it)
 			body.resize((size_t)full + 8);
 			const size_t got2 = zstd().decompress(body.data(), body.size(), raw.data(), rsz);
 			if (zstd().is_error(got2) || got2 != full) return fail(r, "corrupt zstd BLOW5 record");
@@ -257,28 +265,25 @@ static rh_reads *reads_load_blow5(const char *path)
 		memcpy(&rg, b + pos, 4); pos += 4;
 		memcpy(&dig, b + pos, 8); pos += 8; memcpy(&off, b + pos, 8); pos += 8; memcpy(&range, b + pos, 8); pos += 8; memcpy(&rate, b + pos, 8); pos += 8;
 		memcpy(&ns, b + pos, 8); pos += 8;
-		if (ns > (1ull << 32)) return fail(r, "short BLOW5 record (signal)");
-		int16_t *dst = r->samples.grow(ns);
-		if (!dst) return fail(r, "out of memory for the sample staging buffer");
+		// the sample count is checked against what the record holds BEFORE the (page-locked) staging buffer grows for it
+		if (ns > kMaxReadSamples) return fail(r, "short BLOW5 record (signal)");
 		if (sig_comp == 0) {
-			if (!need(ns * 2)) return fail(r, "short BLOW5 record (signal)");
+			if (ns > (blen - pos) / 2) return fail(r, "short BLOW5 record (signal)");
+			int16_t *dst = r->samples.grow(ns);
+			if (!dst) return fail(r, "out of memory for the sample staging buffer");
 			if (ns) memcpy(dst, b + pos, ns * 2);
-		} else {	// svb-zd: [compressed byte count (u64 | u32 | absent)] u32 values | StreamVByte block - the count's width by consistency
-			bool done = false;
-			for (int width : {8, 4, 0}) {
-				size_t q = pos;
-				uint64_t cnt = 0;
-				if (width) { if (q + width > blen) continue; memcpy(&cnt, b + q, width); q += width; if (cnt < 4 || cnt > blen - q) continue; }
-				if (q + 4 > blen) continue;
-				uint32_t nv; memcpy(&nv, b + q, 4);
-				if (nv != ns) continue;
-				const size_t avail = width ? (size_t)cnt - 4 : blen - q - 4;
-				const size_t used = svb_zd_decode(b + q + 4, avail, nv, dst);
-				if ((ns && !used) || (width && used != avail)) continue;
-				done = true;
-				break;
-			}
-			if (!done) return fail(r, "corrupt svb-zd signal in a BLOW5 record");
+		} else {	// svb-zd: u64 compressed byte count | u32 values | StreamVByte block (see the format notes above)
+			uint64_t cnt = 0;
+			if (!need(8 + 4)) return fail(r, "short BLOW5 record (svb-zd signal)");
+			memcpy(&cnt, b + pos, 8);
+			if (cnt < 4 || cnt > blen - pos - 8) return fail(r, "corrupt svb-zd signal in a BLOW5 record: the compressed byte count (u64 in front of the signal) does not fit the record");
+			uint32_t nv; memcpy(&nv, b + pos + 8, 4);
+			if (nv != ns) return fail(r, "corrupt svb-zd signal in a BLOW5 record: value count differs from len_raw_signal");
+			if (ns > cnt - 4) return fail(r, "corrupt svb-zd signal in a BLOW5 record: more values than data bytes");   // (a value takes at least one data byte)
+			int16_t *dst = r->samples.grow(ns);
+			if (!dst) return fail(r, "out of memory for the sample staging buffer");
+			const size_t avail = (size_t)cnt - 4, used = svb_zd_decode(b + pos + 12, avail, nv, dst);
+			if ((ns && !used) || used != avail) return fail(r, "corrupt svb-zd signal in a BLOW5 record: the StreamVByte block does not end with the counted bytes");
 		}
 		(void)rg; (void)rate;
 		r->names.push_back(name);

@@ -78,71 +78,125 @@ def test_blow5_reader_round_trip(tmp_path, make_workload, product_lib):
         Reads.load(cut, lib=product_lib)
 
 
-def _svb_zd_block(x):
-    """StreamVByte (Lemire, 32-bit) of the zig-zag first differences of int16 samples, written from the published format - an
-    implementation independent of the library's: ceil(n/4) control bytes (2 bits per value = bytes - 1, first value lowest), then data."""
-    import struct
-    ctl, dat, prev = bytearray((len(x) + 3) // 4), bytearray(), 0
-    for i, v in enumerate(int(t) for t in x):
-        d = v - prev; prev = v
-        z = ((d << 1) ^ (d >> 31)) & 0xFFFFFFFF
-        nb = 1 if z < 1 << 8 else 2 if z < 1 << 16 else 3 if z < 1 << 24 else 4
-        ctl[i >> 2] |= (nb - 1) << ((i & 3) * 2)
-        dat += z.to_bytes(4, "little")[:nb]
-    return struct.pack("<I", len(x)) + bytes(ctl) + bytes(dat)
-
-
 def test_blow5_hand_assembled_fixtures(tmp_path, product_lib):
-    """BLOW5 files put together byte by byte from the published format (file header, records with auxiliary fields after the signal,
-    end marker) - not by the library's writer: raw and svb-zd signals (compressed byte count as u64, as u32, absent), uncompressed,
-    zlib (Python's zlib) and zstd (libzstd through ctypes) records; extreme sample values, an empty read, a one-sample read."""
-    import ctypes, struct, zlib
+    """BLOW5 files put together byte by byte from the published format (tests/blow5_fixtures.py: file header, records with auxiliary
+    fields after the signal, end marker) - not by the library's writer: raw and svb-zd signals, uncompressed, zlib (Python's zlib) and
+    zstd (libzstd through ctypes) records; extreme sample values, an empty read, a one-sample read.  The svb-zd signal has ONE accepted
+    layout (u64 compressed byte count | u32 values | StreamVByte block): a u32 count or no count is refused, not guessed at."""
     import numpy as np
-    from rawhash_amd.api import Reads
-    rng = np.random.default_rng(5)
-    reads = [("read-a", np.array([0, 1, -1, 32767, -32768, 300, 299, 301, -5000, 12345], dtype=np.int16), 8192.0, 6.0, 1402.882),
-             ("b", rng.integers(400, 700, size=4001).astype(np.int16), 2048.0, -3.5, 748.58),
-             ("empty", np.zeros(0, dtype=np.int16), 8192.0, 0.0, 1400.0),
-             ("one", np.array([-7], dtype=np.int16), 8192.0, 10.0, 1467.61),
-             ("walk", np.cumsum(rng.integers(-40, 41, size=1777)).astype(np.int16), 8192.0, 4.0, 1300.5)]
-    try:
-        zs = ctypes.CDLL("libzstd.so.1")
-        zs.ZSTD_compress.restype = ctypes.c_size_t; zs.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-        zs.ZSTD_compressBound.restype = ctypes.c_size_t; zs.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
-    except OSError:
-        zs = None
-
-    def zstd_frame(b):
-        cap = zs.ZSTD_compressBound(len(b)); out = ctypes.create_string_buffer(cap)
-        n = zs.ZSTD_compress(out, cap, b, len(b), 5)
-        return out.raw[:n]
-
-    aux = struct.pack("<Bdi", 7, 1234.5, -99)            # auxiliary fields follow the signal; a reader must not need them
+    import blow5_fixtures as B
+    from rawhash_amd.api import Reads, RhError
+    reads = B.sample_reads()
+    zs = B.load_zstd()
     n_files = 0
     for rec_comp in (0, 1, 2):
         if rec_comp == 2 and zs is None:
             continue
         for sig_comp, cnt_width in ((0, 0), (1, 8), (1, 4), (1, 0)):
-            text = b"#slow5_version\t0.2.0\n#num_read_groups\t1\n"
-            f = bytearray(b"BLOW5\1" + bytes([0, 2, 0, rec_comp, sig_comp]) + struct.pack("<I", 1))
-            f += bytes(64 - len(f)) + struct.pack("<I", len(text)) + text
-            for name, x, dig, off, ran in reads:
-                body = struct.pack("<H", len(name)) + name.encode() + struct.pack("<I4dQ", 0, dig, off, ran, 4000.0, len(x))
-                if sig_comp == 0:
-                    body += x.tobytes()
-                else:
-                    blk = _svb_zd_block(x)
-                    body += (struct.pack("<Q", len(blk)) if cnt_width == 8 else struct.pack("<I", len(blk)) if cnt_width == 4 else b"") + blk
-                body += aux
-                rec = body if rec_comp == 0 else zlib.compress(body) if rec_comp == 1 else zstd_frame(body)
-                f += struct.pack("<Q", len(rec)) + rec
-            f += b"5WOLB"
             p = str(tmp_path / f"fx_{rec_comp}_{sig_comp}_{cnt_width}.blow5")
-            open(p, "wb").write(bytes(f))
+            open(p, "wb").write(B.assemble(reads, rec_comp, sig_comp, cnt_width, zs))
+            if sig_comp == 1 and cnt_width != 8:
+                with pytest.raises(RhError, match="svb-zd"):
+                    Reads.load(p, lib=product_lib)
+                continue
             r = Reads.load(p, lib=product_lib)
             assert r.names == [q[0] for q in reads]
             for i, (name, x, dig, off, ran) in enumerate(reads):
                 assert np.array_equal(r.samples[int(r.offsets[i]):int(r.offsets[i + 1])], x), (p, name)
                 assert r.cal_offset[i] == off and r.cal_scale[i] == np.float32(ran / dig)
             n_files += 1
-    assert n_files >= 8
+    assert n_files >= 4
+
+
+def test_blow5_hostile_lengths_fail_before_allocating(tmp_path, product_lib):
+    """Length fields are checked against what the record / file holds BEFORE a buffer grows for them: a record that declares 2^32 - 1
+    samples, an svb-zd block that declares more values than it has bytes, a zstd frame that declares gigabytes - errors within
+    milliseconds, not allocations of (page-locked) gigabytes."""
+    import struct, time
+    import blow5_fixtures as B
+    from rawhash_amd.api import Reads, RhError
+    zs = B.load_zstd()
+    t0 = time.time()
+    for sig_comp in (0, 1):
+        f = B.header(0, sig_comp)
+        body = struct.pack("<H", 1) + b"x" + struct.pack("<I4dQ", 0, 8192.0, 0.0, 1400.0, 4000.0, (1 << 32) - 1)
+        body += (struct.pack("<QI", 8, (1 << 32) - 1) + bytes(4)) if sig_comp else bytes(16)
+        f += struct.pack("<Q", len(body)) + body + b"5WOLB"
+        p = str(tmp_path / f"hostile_{sig_comp}.blow5")
+        open(p, "wb").write(bytes(f))
+        with pytest.raises(RhError, match="signal"):
+            Reads.load(p, lib=product_lib)
+    if zs is not None:      # a valid frame header announcing 8 GiB of content (zstd frame format: magic, descriptor 0xE0 = single segment + 8-byte size)
+        frame = struct.pack("<IB", 0xFD2FB528, 0xE0) + struct.pack("<Q", 8 << 30) + bytes(8)
+        f = B.header(2, 0) + struct.pack("<Q", len(frame)) + frame + b"5WOLB"
+        p = str(tmp_path / "hostile_zstd.blow5")
+        open(p, "wb").write(bytes(f))
+        with pytest.raises(RhError, match="zstd"):
+            Reads.load(p, lib=product_lib)
+    # RHR1: a name length beyond the file
+    p = str(tmp_path / "hostile.rhr")
+    open(p, "wb").write(b"RHR1" + struct.pack("<II", 1, 0xFFFFFFF0) + b"abc")
+    with pytest.raises(RhError, match="truncated"):
+        Reads.load(p, lib=product_lib)
+    assert time.time() - t0 < 5.0
+
+
+def _walk_isa_hazards(asm_text, func):
+    """In the device assembly of `func`: for every ds_read_u8 issued by inline asm (the token walker's asynchronous read of the next
+    digit), follow every path until an s_waitcnt that waits for LDS (lgkmcnt(0)) and report instructions that touch the register being loaded."""
+    import re
+    lines = asm_text.splitlines()
+    beg = next(i for i, l in enumerate(lines) if l.startswith(func + ":"))
+    end = next(i for i in range(beg, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    ins, labels, in_asm = [], {}, False
+    for l in lines[beg + 1:end]:
+        t = l.split(";")[0].strip() if not l.strip().startswith(";;#") else l.strip()
+        if t.startswith(";;#ASMSTART"): in_asm = True; continue
+        if t.startswith(";;#ASMEND"): in_asm = False; continue
+        if not t or t.startswith("."):
+            m = re.match(r"^(\.LBB[0-9_]+):", t)
+            if m: labels[m.group(1)] = len(ins)
+            continue
+        ins.append((t, in_asm))
+    hazards, n_reads = [], 0
+    for i, (t, in_asm) in enumerate(ins):
+        m = re.match(r"ds_read_u8\s+(v\d+),", t)
+        if not (m and in_asm):
+            continue
+        n_reads += 1
+        reg = re.compile(r"\b" + m.group(1) + r"\b")
+        seen, stack = set(), [i + 1]
+        while stack:
+            j = stack.pop()
+            while j < len(ins) and j not in seen:
+                seen.add(j)
+                u = ins[j][0]
+                if u.startswith("s_waitcnt") and ("lgkmcnt(0)" in u or u.split()[-1] in ("0", "0x0")):
+                    break
+                if reg.search(u):
+                    hazards.append((t, u)); break
+                b = re.match(r"s_c?branch\w*\s+(\.LBB[0-9_]+)", u)
+                if b and b.group(1) in labels:
+                    stack.append(labels[b.group(1)])
+                    if u.startswith("s_branch"): break
+                if u.startswith("s_endpgm"): break
+                j += 1
+    return n_reads, hazards
+
+
+def test_token_walker_isa_keeps_lds_read_private(tmp_path):
+    """rh_tok_advance (rh_gpu.h) issues an LDS read the compiler does not know about; the value is defined only after rh_lds_wait.  The
+    generated gfx950 code of the default walker must not touch the loaded register between the read and the wait on any path - checked
+    on the compiler's output, so a toolchain that starts copying or spilling that register fails HERE instead of silently mis-sorting."""
+    import shutil, subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc in this environment")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "bs.s")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-x", "hip", "-I", os.path.join(root, "include"),
+           "--cuda-device-only", "-S", "-w", "-o", out, os.path.join(root, "rawhash_amd", "csrc", "rh_bigsort.hip")] + os.environ.get("RH_HIPCC_EXTRA", "").split()
+    subprocess.run(cmd, check=True)
+    n_reads, hazards = _walk_isa_hazards(open(out).read(), "_Z13k_bs_walk_tokILi1ELi1EEv6bs_ctxjj")
+    assert n_reads >= 2, "the walker's inline-asm LDS reads were not found: has the kernel been renamed?"
+    assert not hazards, f"the register of an in-flight LDS read is touched before the wait: {hazards[:3]}"

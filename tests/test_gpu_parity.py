@@ -183,6 +183,14 @@ def test_index_bcast_between_contexts(product_lib, wl):
     a.close(); b.close()
 
 
+def test_rccl_in_process_selftest(product_lib):
+    """The C/C++ host's own RCCL call site (rh_index_bcast -> ncclBroadcast through dlopen'ed librccl.so.1): the library loads, every
+    entry point resolves and a one-rank communicator broadcasts in place on this GPU - what a one-GPU box can run of that path."""
+    c = Context(0, lib=product_lib)
+    assert product_lib.rh_rccl_selftest(c.h) == 0, product_lib.rh_last_error().decode()
+    c.close()
+
+
 def test_index_bcast_across_devices(product_lib, wl):
     """rh_index_bcast between DISTINCT GPUs (hipMemcpyPeerAsync, doubling tree): needs >= 2 visible devices."""
     import ctypes as C
@@ -194,6 +202,7 @@ def test_index_bcast_across_devices(product_lib, wl):
     ctxs[0].upload(wl.index)
     arr = (C.c_void_p * n)(*[c.h for c in ctxs])
     assert product_lib.rh_index_bcast(arr, n) == 0
+    assert product_lib.rh_index_bcast_path() == 1, "distinct devices: the broadcast is expected to go through RCCL (ncclBroadcast)"
     want = ctxs[0].map_batch(wl.opts, wl.reads)
     for c in ctxs[1:]:
         assert np.array_equal(c.map_batch(wl.opts, wl.reads), want)
@@ -261,6 +270,26 @@ def test_blow5_file_maps_from_pinned_staging(ctx, wl, product_lib, tmp_path):
     assert f.pinned and f.names == wl.reads.names
     assert np.array_equal(ctx.map_batch(wl.opts, f.batch()), ctx.map_batch(wl.opts, wl.reads))
     f.close()
+
+
+def test_blow5_hand_assembled_file_maps(ctx, wl, product_lib, tmp_path):
+    """The independent evidence for the BLOW5 reader on the GPU box: a file assembled byte by byte from the published format
+    (tests/blow5_fixtures.py - Python's zlib / libzstd through ctypes / its own StreamVByte encoder, NOT the library's writer), zstd
+    and zlib records with svb-zd signals, loaded through rh_reads_load -> rh_reads_batch -> rh_map_batch: the records of the in-memory batch."""
+    import blow5_fixtures as B
+    from rawhash_amd.api import ReadsFile
+    cfg = wl.wl.cfg
+    n = min(len(wl.reads), 96)
+    rd = [(wl.reads.names[i], wl.reads.samples[int(wl.reads.offsets[i]):int(wl.reads.offsets[i + 1])], cfg.digitisation, cfg.offset, cfg.range) for i in range(n)]
+    want = ctx.map_batch(wl.opts, wl.reads.subset(list(range(n))))
+    zs = B.load_zstd()
+    for rec_comp in ((1, 2) if zs is not None else (1,)):
+        p = str(tmp_path / f"hand_{rec_comp}.blow5")
+        open(p, "wb").write(B.assemble(rd, rec_comp, 1, 8, zs))
+        f = ReadsFile(p, lib=product_lib)
+        assert f.names == wl.reads.names[:n]
+        assert np.array_equal(ctx.map_batch(wl.opts, f.batch()), want)
+        f.close()
 
 
 def test_batch_split_invariance(ctx, wl):
