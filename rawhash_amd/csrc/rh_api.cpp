@@ -741,7 +741,7 @@ extern "C" int rh_map_last_stats(rh_ctx *c, rh_map_stats_t *out) { *out = c->sta
 
 namespace {
 // RH_DEBUG_ROUNDS=1: per chunk round, the anchor-count distribution of the active reads and how many needed the exact sort
-bool debug_rounds() { static const bool on = getenv("RH_DEBUG_ROUNDS") != nullptr; return on; }
+bool debug_rounds() { static const bool on = RH_DEVENV("RH_DEBUG_ROUNDS") != nullptr; return on; }
 void dump_round(rh_ctx *c, uint32_t chunk, uint32_t n_act, const rh_dev_round &rr)
 {
 	std::vector<uint64_t> off((size_t)n_act + 1);
@@ -802,8 +802,8 @@ int set_row_strides(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in)
 // tandem flag and query position fit - the anchors themselves.  What does not fit keeps its 16-byte records.
 void set_rec8_formats(const rh_ctx *c, const rh_mapopt_t *mo, const rh_dev_opt &o, rh_dev_round *rr)
 {
-	rr->afmt = rh_rec_fmt{0, 0, 0, 0}; rr->cfmt = rh_rec_fmt{0, 0, 0, 0}; rr->aq_bits = 0; rr->z8 = 0;
-	static const bool off = getenv("RH_REC8") && atoi(getenv("RH_REC8")) == 0;   // RH_REC8=0: 16-byte records everywhere (comparison runs)
+	rr->afmt = rh_rec_fmt{0, 0, 0, 0}; rr->cfmt = rh_rec_fmt{0, 0, 0, 0}; rr->aq_bits = 0; rr->z8 = 0; rr->a_span = 0;
+	static const bool off = RH_DEVENV("RH_REC8") && atoi(RH_DEVENV("RH_REC8")) == 0;   // RH_REC8=0: 16-byte records everywhere (comparison runs)
 	if (off) return;
 	rr->z8 = o.min_sc >= 0 ? 1 : 0;
 	rh_blob_header h;
@@ -814,10 +814,14 @@ void set_rec8_formats(const rh_ctx *c, const rh_mapopt_t *mo, const rh_dev_opt &
 	const uint32_t ib = 64u - kb < 31u ? 64u - kb : 31u;            // chain number below the key (checked against the slice's largest read)
 	if (ib >= 8u) rr->cfmt = rh_rec_fmt{1, (uint8_t)ib, (uint8_t)lo, (uint8_t)mid};
 	if (mo->flag & RH_M_ALL_CHAINS) return;                        // (k_expand_ava writes 16-byte anchors)
+	// the serial / RMQ chaining kernels and the DTW alignment read 16-byte anchors: opt-in modes, left as they are
+	if ((mo->flag & (RH_M_RMQ | RH_M_DTW_EVALUATE_CHAINS)) || mo->bw_long > mo->bw || o.max_iter > 255) return;
+	const uint32_t span = (uint32_t)(c->dix.sp.k + c->dix.sp.e - 1);
+	if (span > 63u) return;
 	const uint64_t q_max = (mo->flag & RH_M_NO_ADAPTIVE) ? (uint64_t)c->ev_cap + 1u : ((uint64_t)mo->max_num_chunk + 1u) * c->ev_cap;   // query positions = events so far
 	uint32_t qb = 1;
 	while (qb < 32u && (1ull << qb) <= q_max) ++qb;
-	if (kb + 1u + qb <= 64u) { rr->afmt = rh_rec_fmt{1, (uint8_t)(qb + 1u), (uint8_t)lo, (uint8_t)mid}; rr->aq_bits = (uint8_t)qb; }
+	if (kb + 1u + qb <= 64u) { rr->afmt = rh_rec_fmt{1, (uint8_t)(qb + 1u), (uint8_t)lo, (uint8_t)mid}; rr->aq_bits = (uint8_t)qb; rr->a_span = (uint8_t)span; }
 }
 
 // rec_off != null: all-vs-all, a read may have several records (rec_off[r] .. rec_off[r + 1], n_reads + 1 offsets)
@@ -893,7 +897,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 				if (a_off_h[a] - a_off_h[lo] > budget && a - 1 > lo) { cuts.push_back(a - 1); lo = a - 1; }
 		}
 		cuts.push_back(n_act);
-		static const bool trace_rounds = getenv("RH_TRACE_ROUNDS") != nullptr;   // development aid
+		static const bool trace_rounds = RH_DEVENV("RH_TRACE_ROUNDS") != nullptr;   // development aid
 		if (trace_rounds) fprintf(stderr, "[ctx %p] round %u: %u reads, %llu anchors, budget %llu, %zu slice(s), %.1f ms since the call began\n", (void*)c, chunk, n_act,
 		                          (unsigned long long)total, (unsigned long long)budget, cuts.size() - 1, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
 		carry_used = 0;
@@ -923,7 +927,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 				RH_HIP(hipStreamSynchronize(s));
 				const uint64_t add = c->pin[4];
 				if (c->carry[which].ensure_keep((carry_used + add + 1) * 16, carry_used * 16, s)) return -1;
-				rhk_carry_copy(s, rd, rs.act, n, rs.prev_out, c->carry_off.as<uint64_t>(), c->carry[which].as<rh_mm128_t>());
+				rhk_carry_copy(s, rd, rs.act, n, rs.prev_out, c->carry_off.as<uint64_t>(), c->carry[which].as<rh_mm128_t>(), (rs.afmt.rec8 && !ava) ? 1 : 0);
 				carry_used += add;
 				return 0;
 			};

@@ -1123,21 +1123,21 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	if ((size_t)(p - jb.big_ws) > jb.big_ws_bytes) { rh_set_error("segment sorter: scratch of %zu bytes is too small (%zu needed)", jb.big_ws_bytes, (size_t)(p - jb.big_ws)); return -1; }
 	RH_LAUNCH(k_bs_init, 1, NT, 0, s, jb, C);
 	uint32_t *pin = (uint32_t*)jb.big_pin;
-	static const bool trace = getenv("RH_BS_TRACE") != nullptr;   // development aid: per-level launch shapes and times on stderr
-	static const bool walk_old = getenv("RH_BS_WALK_OLD") != nullptr;   // development aid: the LDS-resident walkers instead of the scalar-token one
-	static const uint32_t tok_max = getenv("RH_BS_TOK_MAX") ? (uint32_t)strtoul(getenv("RH_BS_TOK_MAX"), nullptr, 10) : 0xFFFFFFFFu;
-	static const bool tok2 = !(getenv("RH_BS_TOK2") && atoi(getenv("RH_BS_TOK2")) == 0);   // two regions per lane for ranges with 65 .. 128 regions that have holes (the candidate sort's first level; measured +2 % on one stream)
+	static const bool trace = RH_DEVENV("RH_BS_TRACE") != nullptr;   // development aid: per-level launch shapes and times on stderr
+	static const bool walk_old = RH_DEVENV("RH_BS_WALK_OLD") != nullptr;   // development aid: the LDS-resident walkers instead of the scalar-token one
+	static const uint32_t tok_max = RH_DEVENV("RH_BS_TOK_MAX") ? (uint32_t)strtoul(RH_DEVENV("RH_BS_TOK_MAX"), nullptr, 10) : 0xFFFFFFFFu;
+	static const bool tok2 = !(RH_DEVENV("RH_BS_TOK2") && atoi(RH_DEVENV("RH_BS_TOK2")) == 0);   // two regions per lane for ranges with 65 .. 128 regions that have holes (the candidate sort's first level; measured +2 % on one stream)
 	static const bool tok_adv = !(getenv("RH_BS_TOK_ADV") && atoi(getenv("RH_BS_TOK_ADV")) == 0);   // RH_BS_TOK_ADV=0: development aid, the compiler-scheduled pop
-	static const bool tok4 = getenv("RH_BS_TOK4") != nullptr;       // development aid: four regions per lane for ranges with more than 64 regions that have holes
+	static const bool tok4 = RH_DEVENV("RH_BS_TOK4") != nullptr;       // development aid: four regions per lane for ranges with more than 64 regions that have holes
 	// the byte the first level of this kind of job split on last time (-1: not known yet; RH_BS_NO_GUESS: never used)
-	static const bool no_guess = getenv("RH_BS_NO_GUESS") != nullptr;   // development aid
+	static const bool no_guess = RH_DEVENV("RH_BS_NO_GUESS") != nullptr;   // development aid
 	const uint32_t kind = jb.kind < BS_KINDS ? jb.kind : 0u;
 	const int gs = no_guess ? -1 : g_bs_guess[kind].load(std::memory_order_relaxed);
 	uint32_t n_rng0 = 0;
 	// Walk wavefronts live for milliseconds and there are more of them than wave slots: left alone they end up holding every slot of the
 	// chip and the other streams' bandwidth-bound kernels wait behind an issue-bound one.  Unused dynamic LDS caps them per CU.
-	static const uint32_t walk_lds = getenv("RH_BS_WALK_LDS") ? (uint32_t)strtoul(getenv("RH_BS_WALK_LDS"), nullptr, 10) : 0u;
-	static const int walk_reps = getenv("RH_BS_WALK_REPS") ? atoi(getenv("RH_BS_WALK_REPS")) : 1, scat_reps = getenv("RH_BS_SCAT_REPS") ? atoi(getenv("RH_BS_SCAT_REPS")) : 1;   // development aid: the (idempotent) walks / placement launched several times - what a pass costs the step with the other streams' kernels around it
+	static const uint32_t walk_lds = RH_DEVENV("RH_BS_WALK_LDS") ? (uint32_t)strtoul(RH_DEVENV("RH_BS_WALK_LDS"), nullptr, 10) : 0u;
+	static const int walk_reps = RH_DEVENV("RH_BS_WALK_REPS") ? atoi(RH_DEVENV("RH_BS_WALK_REPS")) : 1, scat_reps = RH_DEVENV("RH_BS_SCAT_REPS") ? atoi(RH_DEVENV("RH_BS_SCAT_REPS")) : 1;   // development aid: the (idempotent) walks / placement launched several times - what a pass costs the step with the other streams' kernels around it
 	hipEvent_t ev[4] = {};
 	if (trace) for (auto &e : ev) (void)hipEventCreate(&e);
 	for (int level = 0; level < 9; ++level) {

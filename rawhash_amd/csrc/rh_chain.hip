@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 	if (T0 >= n) return;
 	const int32_t T1 = tile_len && T0 + (int32_t)tile_len < n ? T0 + (int32_t)tile_len : n;
 	bool begun = T0 == 0;
-	const rh_mm128_t *an = rr.anc + base;
+	#define AN_(i) rh_an_ld(rr, rr.anc, base + (uint64_t)(i))
 	// DP output per anchor: {f, p} interleaved (one 8-byte record: the backtrack walk needs both per step), then v[]
 	int32_t *gfp = (int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR), *gv = gfp + 2 * (size_t)n;
 	int32_t max_dist_t = o.max_dist_t, max_dist_q = o.max_dist_q;
@@ -68,17 +68,17 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 	// Anchors are read once, 64 at a time (coalesced); the sequential walk below only touches registers (shuffles) and LDS.
 	int32_t st = 0, max_ii = -1, f_ii = 0, open_start = 0;
 	uint32_t xlo_ii = 0;
-	uint64_t x_before = T0 > 0 ? an[T0 - 1].x : 0ull;              // x of the anchor preceding the tile
+	uint64_t x_before = T0 > 0 ? AN_(T0 - 1).x : 0ull;             // x of the anchor preceding the tile
 	// software pipeline over the tiles: A = current, B = next (needed to size a cluster that runs over the tile edge), C in flight
 	uint64_t xB = 0, yB = 0, xC = 0, yC = 0;
-	if (T0 + (int32_t)lane < n) { xB = an[T0 + lane].x; yB = an[T0 + lane].y; }
-	if (T0 + 64 + (int32_t)lane < n) { xC = an[T0 + 64 + lane].x; yC = an[T0 + 64 + lane].y; }
+	if (T0 + (int32_t)lane < n) { const rh_mm128_t q = AN_(T0 + lane); xB = q.x; yB = q.y; }
+	if (T0 + 64 + (int32_t)lane < n) { const rh_mm128_t q = AN_(T0 + 64 + lane); xC = q.x; yC = q.y; }
 	for (int32_t i0 = T0; i0 < n; i0 += 64) {
 		const int32_t ii = i0 + (int32_t)lane;
 		const bool inb_r = ii < n;
 		const uint64_t x = xB, y = yB;
 		xB = xC; yB = yC;
-		if (ii + 128 < n) { xC = an[ii + 128].x; yC = an[ii + 128].y; } else { xC = 0; yC = 0; }
+		if (ii + 128 < n) { const rh_mm128_t q = AN_(ii + 128); xC = q.x; yC = q.y; } else { xC = 0; yC = 0; }
 		const uint64_t xprev = (uint64_t)rh_wave_shr1((uint32_t)(x >> 32), (uint32_t)(x_before >> 32)) << 32 | rh_wave_shr1((uint32_t)x, (uint32_t)x_before);
 		const bool start_r = inb_r && (ii == 0 || (x >> 32) != (xprev >> 32) || x > xprev + D64);
 		const uint64_t x_last = (uint64_t)rh_readlane((uint32_t)(x >> 32), 63u) << 32 | rh_readlane((uint32_t)x, 63u);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 			if (max_ii >= 0 && max_ii < end_j) {
 				uint32_t xj, yj; int32_t spj;
 				if (i - max_ii < CH_RING) { const uint32_t sl = (uint32_t)max_ii & (CH_RING - 1); xj = L.xlo[sl]; yj = L.ylo[sl]; spj = (int32_t)L.span[sl]; }
-				else { xj = (uint32_t)an[max_ii].x; yj = (uint32_t)an[max_ii].y; spj = (int32_t)((an[max_ii].y >> 32) & 63); }
+				else { const rh_mm128_t q = AN_(max_ii); xj = (uint32_t)q.x; yj = (uint32_t)q.y; spj = (int32_t)((q.y >> 32) & 63); }
 				const int32_t tmp = rh_pair_score_d((int32_t)yi_lo - (int32_t)yj, (int32_t)(xi_lo - xj), spj, max_dist_t, max_dist_q, bw, o.pen_gap, o.pen_skip);
 				if (tmp != RH_SCORE_NONE && max_f < tmp + f_ii) { max_f = tmp + f_ii; max_j = max_ii; }
 			}
@@ -280,6 +280,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 		x_before = x_last;
 		if (last_tile) break;
 	}
+	#undef AN_
 }
 
 // Fallback for max_chain_iter > CH_MAX_ITER: the plain serial loop, one read per lane.

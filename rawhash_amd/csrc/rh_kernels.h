@@ -128,12 +128,37 @@ struct rh_dev_round {
 	float *dtw_ws; uint32_t dtw_stride;      // RH_M_DTW_EVALUATE_CHAINS: DP buffers, dtw_stride floats per active read
 	uint32_t *dtw_n; float *dtw_rec; const uint64_t *dtw_off; const int32_t *dtw_dec;   // regions per read; packed per-region values for the host's MAPQ; their offsets; the host's decisions (3 int32 per read)
 	uint64_t *counters;              // [0] events [1] seeds [2] hits [3] anchors [4] chained [5] samples used [6] chunks [7] chunks with more peaks than RH_EV_CAP (an error)
-	// 8-byte records through the sorters (rh_rec_fmt; all zero = 16-byte records everywhere: the stage-level calls):
-	//   afmt  anchors leave k_expand as  key' << shift | tandem << aq_bits | q_pos  (shift = aq_bits + 1; the span is the index's constant), are sorted
-	//         as such and expanded to 16 bytes by k_anchor_unpack;   cfmt  chain-order keys  key' << shift | chain;   z8  candidates  score << 32 | anchor
-	rh_rec_fmt afmt, cfmt; uint8_t aq_bits, z8;
+	// 8-byte records (rh_rec_fmt; all zero = 16-byte records everywhere: the stage-level calls):
+	//   afmt  the ANCHORS OF THE ROUND are one word each,  key' << shift | tandem << aq_bits | q_pos  (shift = aq_bits + 1; a_span = the index's constant
+	//         span, seg_id = 0: nothing is lost): k_expand writes them so, the sort moves them so, and raw / anc / prev_in / prev_out / the carry
+	//         buffers hold them so - the kernels that need x and y take them apart in registers (rh_an_ld);
+	//   cfmt  chain-order keys  key' << shift | chain;   z8  candidates  score << 32 | anchor
+	rh_rec_fmt afmt, cfmt; uint8_t aq_bits, z8, a_span;
 	uint64_t arena_n;                // anchors the 16-byte-per-anchor arenas (raw, anc, zs, prev_out) hold
 };
+
+// anchor i of an anchor array of the round (rr.anc, rr.prev_in, rr.prev_out: absolute element index), whichever way the round keeps them
+RH_HD inline rh_mm128_t rh_anchor_unpack(uint64_t w, const rh_rec_fmt &f, uint32_t qb, uint32_t span)
+{
+	rh_mm128_t p;
+	p.x = rh_rec8_key(w, f.shift, f.lo, f.mid);
+	p.y = (uint64_t)span << 32 | (w & ((1ull << qb) - 1ull)) | ((w >> qb) & 1ull) << 38;
+	return p;
+}
+RH_HD inline uint64_t rh_anchor_pack(const rh_mm128_t &p, const rh_rec_fmt &f, uint32_t qb)
+{
+	return rh_rec8_pack_key(p.x, f.lo, f.mid) << f.shift | ((p.y >> 38) & 1ull) << qb | (uint64_t)(uint32_t)p.y;
+}
+RH_HD inline rh_mm128_t rh_an_ld(const rh_dev_round &rr, const rh_mm128_t *arr, uint64_t i)
+{
+	if (rr.afmt.rec8) return rh_anchor_unpack(reinterpret_cast<const uint64_t*>(arr)[i], rr.afmt, rr.aq_bits, rr.a_span);
+	return arr[i];
+}
+RH_HD inline void rh_an_cp(const rh_dev_round &rr, rh_mm128_t *dst, uint64_t di, const rh_mm128_t *src, uint64_t si)   // dst[di] = src[si]
+{
+	if (rr.afmt.rec8) reinterpret_cast<uint64_t*>(dst)[di] = reinterpret_cast<const uint64_t*>(src)[si];
+	else dst[di] = src[si];
+}
 
 // ---- LDS size classes of the block sorter (rh_sort.hip)
 // Size classes = LDS footprints (12 B per record + ~4.5 KB) chosen for whole workgroups per CU; the allocation granularity
@@ -202,7 +227,7 @@ template <> struct rh_rec_ops<rh_mm128_t> { static RH_HD inline uint64_t key(con
 template <> struct rh_rec_ops<uint64_t> { static RH_HD inline uint64_t key(const uint64_t &r, const rh_rec_fmt &f) { return rh_rec8_key(r, f.shift, f.lo, f.mid); } };
 // Unused dynamic LDS handed to the one-wavefront-per-read kernels (development knob RH_WAVE_LDS, bytes): their wavefronts live long, and
 // without a cap per CU they end up holding every wave slot while the other streams' bandwidth-bound kernels wait
-inline uint32_t rh_wave_lds() { static const uint32_t v = getenv("RH_WAVE_LDS") ? (uint32_t)strtoul(getenv("RH_WAVE_LDS"), nullptr, 10) : 0u; return v; }
+inline uint32_t rh_wave_lds() { static const uint32_t v = RH_DEVENV("RH_WAVE_LDS") ? (uint32_t)strtoul(RH_DEVENV("RH_WAVE_LDS"), nullptr, 10) : 0u; return v; }
 int rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n);   // segments with <= min_n records are left alone
 uint32_t rhk_sort_lds_max(const rh_sort_job &jb);                        // longest segment the LDS classes take for this job's keys
 size_t rhk_bigsort_ws_bytes(uint64_t total, uint32_t n_lo);
@@ -218,8 +243,7 @@ void rhk_sketch(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, cons
 void rhk_probe(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_scan_anchors(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
-int rhk_sort(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r);   // (r.afmt: one-word anchors, expanded into r.anc at the end)
-void rhk_anchor_unpack(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r, const uint64_t *sorted8);
+int rhk_sort(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r);   // (r.afmt: one-word anchors, raw -> anc as such)
 void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
 void rhk_chain_rmq(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r, const uint32_t *counts, int32_t max_dist, int32_t max_dist_inner, int32_t cap_rmq_size);   // mg_lchain_rmq (lchain.c:606); o.bw = the bandwidth of this pass
 int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
@@ -235,7 +259,7 @@ void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &
                         uint32_t *act_out, uint32_t *n_out);
 void rhk_rebase_offsets(hipStream_t s, const uint64_t *a_off, uint32_t n, uint64_t *out);
 void rhk_carry_scan(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, uint64_t used, uint64_t *dst_off, uint64_t *total_out);
-void rhk_carry_copy(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, const rh_mm128_t *staging, const uint64_t *dst_off, rh_mm128_t *carry);
+void rhk_carry_copy(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, const rh_mm128_t *staging, const uint64_t *dst_off, rh_mm128_t *carry, int words8);   // words8: the anchors are one word each
 void rhk_finalize(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, rh_map_record_t *rec);
 void rhk_seed_scan(hipStream_t s, const rh_dev_round &r, uint64_t *off);
 void rhk_seed_pack(hipStream_t s, const rh_dev_round &r, const uint64_t *off, uint32_t id0, uint32_t *hash_out, uint64_t *pos_out);   // target ids = id0 + read index

@@ -901,7 +901,7 @@ __global__ __launch_bounds__(NT) void k_expand(rh_dev_opt o, rh_dev_index ix, rh
 	const uint32_t np = rd.n_prev[r];
 	const rh_mm128_t *pin = rr.prev_in + rd.prev_off[r];
 	if (rr.skip[a]) {	// chunk dropped after event detection: carried anchors stay untouched (rmap.cpp:232-235)
-		for (uint32_t j = tid; j < np; j += NT) rr.prev_out[base + j] = pin[j];
+		for (uint32_t j = tid; j < np; j += NT) rh_an_cp(rr, rr.prev_out, base + j, rr.prev_in, rd.prev_off[r] + j);
 		__syncthreads();
 		if (tid == 0) rd.prev_off[r] = base;
 		return;
@@ -934,29 +934,9 @@ __global__ __launch_bounds__(NT) void k_expand(rh_dev_opt o, rh_dev_index ix, rh
 		if (pk) anc8[j] = rh_rec8_pack_key(p.x, plo, pmid) << psh | (uint64_t)(meta >> 31) << pqb | (uint64_t)(uint32_t)p.y;
 		else anc[j] = p;
 	}
-	if (pk) for (uint32_t j = tid; j < np; j += NT) { const rh_mm128_t p = pin[j]; anc8[nn + j] = rh_rec8_pack_key(p.x, plo, pmid) << psh | ((p.y >> 38) & 1ull) << pqb | (uint64_t)(uint32_t)p.y; }
+	if (pk) { const uint64_t *pin8 = reinterpret_cast<const uint64_t*>(rr.prev_in) + rd.prev_off[r]; for (uint32_t j = tid; j < np; j += NT) anc8[nn + j] = pin8[j]; }   // (carried anchors are words already)
 	else
 	for (uint32_t j = tid; j < np; j += NT) anc[nn + j] = pin[j];
-}
-
-// the sorted one-word anchors (rr.afmt) back as 16-byte records: rr.anc
-__global__ __launch_bounds__(NT) void k_anchor_unpack(rh_dev_index ix, rh_dev_round rr, const uint64_t *sorted8, uint32_t parts)
-{
-	const uint32_t a = blockIdx.x / parts, part = blockIdx.x % parts, tid = threadIdx.x;
-	if (a >= rr.n_act || rr.skip[a]) return;
-	const uint64_t base = rr.a_off[a];
-	const uint32_t n = (uint32_t)(rr.a_off[a + 1] - base);
-	const uint64_t *src = sorted8 + base;
-	rh_mm128_t *anc = rr.anc + base;
-	const uint32_t plo = rr.afmt.lo, pmid = rr.afmt.mid, psh = rr.afmt.shift, pqb = rr.aq_bits;
-	const uint64_t span = (uint64_t)(ix.sp.k + ix.sp.e - 1), qmask = (1ull << pqb) - 1ull;
-	for (uint32_t j = part * NT + tid; j < n; j += parts * NT) {
-		const uint64_t w = src[j];
-		rh_mm128_t p;
-		p.x = rh_rec8_key(w, psh, plo, pmid);
-		p.y = span << 32 | (w & qmask) | ((w >> pqb) & 1ull) << 38;
-		anc[j] = p;
-	}
 }
 
 // ------------------------------------------------------------------------------------------------ all-vs-all (RH_M_ALL_CHAINS)
@@ -1074,14 +1054,20 @@ __global__ __launch_bounds__(1024) void k_carry_scan(rh_dev_reads rd, const uint
 	uint64_t run = used + s_part[tid];
 	for (uint32_t i = b; i < e; ++i) { dst_off[i] = run; run += rd.n_prev[act[i]]; }
 }
-__global__ __launch_bounds__(NT) void k_carry_copy(rh_dev_reads rd, const uint32_t *act, uint32_t n, const rh_mm128_t *staging, const uint64_t *dst_off, rh_mm128_t *carry)
+__global__ __launch_bounds__(NT) void k_carry_copy(rh_dev_reads rd, const uint32_t *act, uint32_t n, const rh_mm128_t *staging, const uint64_t *dst_off, rh_mm128_t *carry, int words8)
 {
 	const uint32_t a = blockIdx.x;
 	if (a >= n) return;
 	const uint32_t r = act[a], np = rd.n_prev[r];
+	if (words8) {	// one-word anchors (rh_dev_round::afmt)
+		const uint64_t *src = reinterpret_cast<const uint64_t*>(staging) + rd.prev_off[r];
+		uint64_t *dst = reinterpret_cast<uint64_t*>(carry) + dst_off[a];
+		for (uint32_t j = threadIdx.x; j < np; j += NT) dst[j] = src[j];
+	} else {
 	const rh_mm128_t *src = staging + rd.prev_off[r];
 	rh_mm128_t *dst = carry + dst_off[a];
 	for (uint32_t j = threadIdx.x; j < np; j += NT) dst[j] = src[j];
+	}
 	__syncthreads();
 	if (threadIdx.x == 0) rd.prev_off[r] = dst_off[a];
 }
@@ -1248,17 +1234,11 @@ void rhk_probe(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const
 }
 void rhk_scan_anchors(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r) { RH_LAUNCH(k_scan_anchors, 1, 1024, 0, s, rd, r); }
 void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (!r.n_act) return; if (o.flag & RH_M_ALL_CHAINS) RH_LAUNCH(k_expand_ava, r.n_act, NT, 0, s, o, ix, rd, r); else RH_LAUNCH(k_expand, r.n_act, NT, 0, s, o, ix, rd, r); }
-void rhk_anchor_unpack(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r, const uint64_t *sorted8)
-{
-	if (!r.n_act) return;
-	const uint32_t parts = r.max_anchors ? cdiv(r.max_anchors, 16384u) : 4u;
-	RH_LAUNCH(k_anchor_unpack, r.n_act * parts, NT, 0, s, ix, r, sorted8, parts);
-}
 void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act_in, uint32_t n_in, uint32_t next_chunk, uint32_t *act_out, uint32_t *n_out)
 { RH_LAUNCH(k_compact_active, 1, 1024, 0, s, o, rd, act_in, n_in, next_chunk, act_out, n_out); }
 void rhk_rebase_offsets(hipStream_t s, const uint64_t *a_off, uint32_t n, uint64_t *out) { RH_LAUNCH(k_rebase_offsets, cdiv(n + 1, 256), 256, 0, s, a_off, n, out); }
 void rhk_carry_scan(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, uint64_t used, uint64_t *dst_off, uint64_t *total_out) { RH_LAUNCH(k_carry_scan, 1, 1024, 0, s, rd, act, n, used, dst_off, total_out); }
-void rhk_carry_copy(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, const rh_mm128_t *staging, const uint64_t *dst_off, rh_mm128_t *carry) { if (n) RH_LAUNCH(k_carry_copy, n, NT, 0, s, rd, act, n, staging, dst_off, carry); }
+void rhk_carry_copy(hipStream_t s, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, const rh_mm128_t *staging, const uint64_t *dst_off, rh_mm128_t *carry, int words8) { if (n) RH_LAUNCH(k_carry_copy, n, NT, 0, s, rd, act, n, staging, dst_off, carry, words8); }
 void rhk_finalize(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, rh_map_record_t *rec) { if (rd.n_reads) RH_LAUNCH(k_finalize, cdiv(rd.n_reads, 256), 256, 0, s, o, ix, rd, rec); }
 void rhk_seed_scan(hipStream_t s, const rh_dev_round &r, uint64_t *off) { RH_LAUNCH(k_seed_scan, 1, 1024, 0, s, r, off); }
 void rhk_seed_pack(hipStream_t s, const rh_dev_round &r, const uint64_t *off, uint32_t id0, uint32_t *hash_out, uint64_t *pos_out) { if (r.n_act) RH_LAUNCH(k_seed_pack, r.n_act, NT, 0, s, r, off, id0, hash_out, pos_out); }

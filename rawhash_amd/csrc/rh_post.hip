@@ -42,8 +42,8 @@ __global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 	const int32_t *fp = (const int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR);   // {f, p} interleaved
 	rh_mm128_t *z = rr.raw + base;               // the unsorted anchor copy is dead after the anchor sort
 	uint64_t *z8 = reinterpret_cast<uint64_t*>(rr.raw) + base;   // rr.z8: 8-byte candidates  score << 32 | anchor
-	uint32_t *t4 = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)16 * n);   // backtrack's "touched" marks (1 B per anchor)
-	for (int32_t i = (int32_t)tid; i < (n + 3) / 4; i += NT) t4[i] = 0u;
+	uint32_t *t4 = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)16 * n);   // backtrack's "used" marks: ONE BIT per anchor (k_backtrack_spec)
+	for (int32_t i = (int32_t)tid; i < (n + 31) / 32; i += NT) t4[i] = 0u;
 	uint32_t *claim = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)20 * n);   // k_backtrack_spec's per-anchor claim stamps
 	for (int32_t i = (int32_t)tid; i < n; i += NT) claim[i] = 0u;
 	uint32_t nz = 0;
@@ -87,7 +87,12 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
 	const int2 *fp = (const int2*)wsr;                              // .x = f, .y = p
 	int32_t *v = (int32_t*)wsr + 2 * (size_t)n;
-	uint8_t *t = (uint8_t*)(wsr + (size_t)16 * n);                  // "used" marks, zeroed by k_zbuild
+	// "used" marks, zeroed by k_zbuild: one BIT per anchor.  Every candidate starts with a look at its own mark, in score order - a random access
+	// per candidate, most of them already used: a read's marks are 1/8 of a byte array's sectors (22 KB for 175 k anchors: they stay in the L2 /
+	// MALL while the wavefront works through its candidates).  Set with L2 atomics, read at L2 (a wavefront's own earlier marks must be seen).
+	uint32_t *tb = (uint32_t*)(wsr + (size_t)16 * n);
+	#define BK_USED(i) ((__hip_atomic_load(&tb[(uint32_t)(i) >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> ((uint32_t)(i) & 31u)) & 1u)
+	#define BK_MARK(i) atomicOr(&tb[(uint32_t)(i) >> 5], 1u << ((uint32_t)(i) & 31u))
 	uint32_t *claim = (uint32_t*)(wsr + (size_t)20 * n);            // stamps, zeroed by k_zbuild
 	const rh_mm128_t *zs = rr.zs + base;
 	const uint64_t *zs8 = reinterpret_cast<const uint64_t*>(rr.zs) + base;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 			const uint32_t stamp = epoch << 6 | (63u - lane);
 			bool walked = false;
 			int32_t zx = 0, path = 0, max_s = 0, emit = 0;             // path = unused anchors reached after i0; emit = anchors i0 .. before max_i
-			if (pending && t[i0] == 0) {
+			if (pending && BK_USED(i0) == 0) {
 				walked = true;
 				int2 rec = fp[i0];
 				zx = rec.x;
@@ -117,9 +122,9 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 				for (;;) {	// mg_chain_bk_end (lchain.c:47-75): back until a used anchor, the start, or a score drop > max_drop
 					const int32_t i = rec.y;
 					int32_t sdrop = zx;
-					uint8_t ti = 0;
+					uint32_t ti = 0;
 					if (i >= 0) {
-						rec = fp[i]; ti = t[i]; sdrop = zx - rec.x;
+						rec = fp[i]; ti = BK_USED(i); sdrop = zx - rec.x;
 						if (ti == 0) {	// (a used anchor ends every walk that reaches it: nobody's to take, nothing to stamp)
 							if (!solo) atomicMax(&claim[i], stamp);
 							++path;
@@ -147,12 +152,12 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 			}
 			if (pending && !conflict) {
 				if (walked) {	// anchors i0 .. (exclusive) max_i form the chain; the marks stay even if it is rejected, as in the reference
-					if (emit >= 1) t[i0] = 1;
-					if (emit >= 2) t[pn1] = 1;
-					if (emit >= 3) t[pn2] = 1;
-					if (emit >= 4) t[pn3] = 1;
+					if (emit >= 1) BK_MARK(i0);
+					if (emit >= 2) BK_MARK(pn1);
+					if (emit >= 3) BK_MARK(pn2);
+					if (emit >= 4) BK_MARK(pn3);
 					int32_t x = pn3;
-					for (int32_t j = 4; j < emit; ++j) { x = fp[x].y; t[x] = 1; }
+					for (int32_t j = 4; j < emit; ++j) { x = fp[x].y; BK_MARK(x); }
 					accepted = max_s >= min_sc && emit > 0 && emit >= min_cnt;   // (score of the chain = the best drop seen = max_s)
 					r_cnt = emit; r_sc = max_s;
 				}
@@ -179,6 +184,8 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 		n_u += (int32_t)__popcll(am);
 		n_v += (int32_t)total;
 	}
+	#undef BK_USED
+	#undef BK_MARK
 	if (lane == 0) {
 		rr.n_u[a] = (uint32_t)n_u; rr.n_v[a] = (uint32_t)n_v;
 		if (n_u == 0) { rd.n_prev[r] = 0; rd.prev_off[r] = base; }
@@ -204,12 +211,11 @@ __global__ __launch_bounds__(NT) void k_chain_gather(rh_dev_round rr)
 	if (n_u == 0) return;
 	const uint64_t base = rr.a_off[a];
 	const uint32_t n = (uint32_t)(rr.a_off[a + 1] - base);
-	const rh_mm128_t *an = rr.anc + base;
 	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
 	const int32_t *v = (const int32_t*)wsr + 2 * (size_t)n;
 	uint32_t *ck0 = (uint32_t*)(wsr + (size_t)32 * n);               // n_u <= n start offsets
 	const uint64_t *u = rr.u + base;
-	rh_mm128_t *pa = rr.prev_out + base, *w = rr.raw + base;
+	rh_mm128_t *w = rr.raw + base;
 	uint32_t run = 0;
 	for (uint32_t i0 = 0; i0 < n_u; i0 += NT) {
 		const uint32_t i = i0 + tid, cnt = i < n_u ? (uint32_t)u[i] : 0u;
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(NT) void k_chain_gather(rh_dev_round rr)
 			uint32_t lo = 0, hi = n_u;                               // chain whose [ck0, ck0 + cnt) holds slot q
 			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tab[mid] <= q) lo = mid; else hi = mid; }
 			const uint32_t k0 = tab[lo], ni = (uint32_t)u[lo];
-			pa[q] = an[v[k0 + (ni - (q - k0) - 1)]];
+			rh_an_cp(rr, rr.prev_out, base + q, rr.anc, base + (uint32_t)v[k0 + (ni - (q - k0) - 1)]);
 		}
 	} else {
 		// thousands of chains (an unmappable read on a large index: ~2 anchors per chain): one lane per chain copies its few
@@ -238,22 +244,22 @@ __global__ __launch_bounds__(NT) void k_chain_gather(rh_dev_round rr)
 			const uint32_t i = i0 + l;
 			uint32_t k0 = 0, ni = 0;
 			if (i < n_u) { k0 = ck0[i]; ni = (uint32_t)u[i]; }
-			if (ni <= CG_SHORT) for (uint32_t j = 0; j < ni; ++j) pa[k0 + j] = an[v[k0 + (ni - j - 1)]];
+			if (ni <= CG_SHORT) for (uint32_t j = 0; j < ni; ++j) rh_an_cp(rr, rr.prev_out, base + k0 + j, rr.anc, base + (uint32_t)v[k0 + (ni - j - 1)]);
 			uint64_t longm = __ballot(ni > CG_SHORT);
 			while (longm) {
 				const int src = __ffsll((unsigned long long)longm) - 1;
 				longm &= longm - 1;
 				const uint32_t kk = __shfl(k0, src), nn = __shfl(ni, src);
-				for (uint32_t j = l; j < nn; j += 64) pa[kk + j] = an[v[kk + (nn - j - 1)]];
+				for (uint32_t j = l; j < nn; j += 64) rh_an_cp(rr, rr.prev_out, base + kk + j, rr.anc, base + (uint32_t)v[kk + (nn - j - 1)]);
 			}
 		}
 	}
 	__syncthreads();
 	if (rr.cfmt.rec8) {	// 8-byte keys: first-anchor x, packed, above the chain's number (its start offset stays in ck0)
 		uint64_t *w8 = reinterpret_cast<uint64_t*>(rr.raw) + base;
-		for (uint32_t i = tid; i < n_u; i += NT) w8[i] = rh_rec8_pack_key(pa[ck0[i]].x, rr.cfmt.lo, rr.cfmt.mid) << rr.cfmt.shift | (uint64_t)i;
+		for (uint32_t i = tid; i < n_u; i += NT) w8[i] = rh_rec8_pack_key(rh_an_ld(rr, rr.prev_out, base + ck0[i]).x, rr.cfmt.lo, rr.cfmt.mid) << rr.cfmt.shift | (uint64_t)i;
 	} else
-	for (uint32_t i = tid; i < n_u; i += NT) { rh_mm128_t e; e.x = pa[ck0[i]].x; e.y = (uint64_t)ck0[i] << 32 | (uint64_t)i; w[i] = e; }
+	for (uint32_t i = tid; i < n_u; i += NT) { rh_mm128_t e; e.x = rh_an_ld(rr, rr.prev_out, base + ck0[i]).x; e.y = (uint64_t)ck0[i] << 32 | (uint64_t)i; w[i] = e; }
 }
 
 __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_round rr)
@@ -267,12 +273,11 @@ __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_ro
 	const uint32_t n_u = rr.n_u[a], n_v = rr.n_v[a];
 	if (n_u == 0) { if (tid == 0) { rd.n_prev[r] = 0; rd.prev_off[r] = base; } return; }
 	const uint32_t n = (uint32_t)(rr.a_off[a + 1] - base);
-	rh_mm128_t *an = rr.anc + base;
 	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
 	uint32_t *dk = (uint32_t*)(wsr + (size_t)36 * n);                // destination offsets in sorted order
 	uint64_t *u2 = (uint64_t*)(wsr + (size_t)40 * n);
 	uint64_t *u = rr.u + base;
-	const rh_mm128_t *pa = rr.prev_out + base, *w = rr.zs + base;   // w: sorted keys
+	const rh_mm128_t *w = rr.zs + base;                            // w: sorted keys
 	const uint64_t *w8 = reinterpret_cast<const uint64_t*>(rr.zs) + base;
 	const bool c8 = rr.cfmt.rec8 != 0;
 	const uint64_t cmask = (1ull << rr.cfmt.shift) - 1ull;
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_ro
 		for (uint32_t q = tid; q < n_v; q += NT) {
 			uint32_t lo = 0, hi = n_u;
 			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tab[mid] <= q) lo = mid; else hi = mid; }
-			an[q] = pa[CR_FROM(lo) + (q - tab[lo])];
+			rh_an_cp(rr, rr.anc, base + q, rr.prev_out, base + CR_FROM(lo) + (q - tab[lo]));
 		}
 	} else {	// one lane per chain (see k_chain_gather)
 		const uint32_t l = lane_id();
@@ -304,13 +309,13 @@ __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_ro
 			const uint32_t i = i0 + l;
 			uint32_t from = 0, to = 0, ni = 0;
 			if (i < n_u) { from = CR_FROM(i); to = dk[i]; ni = (uint32_t)u2[i]; }
-			if (ni <= CG_SHORT) for (uint32_t j = 0; j < ni; ++j) an[to + j] = pa[from + j];
+			if (ni <= CG_SHORT) for (uint32_t j = 0; j < ni; ++j) rh_an_cp(rr, rr.anc, base + to + j, rr.prev_out, base + from + j);
 			uint64_t longm = __ballot(ni > CG_SHORT);
 			while (longm) {
 				const int src = __ffsll((unsigned long long)longm) - 1;
 				longm &= longm - 1;
 				const uint32_t ff = __shfl(from, src), tt = __shfl(to, src), nn = __shfl(ni, src);
-				for (uint32_t j = l; j < nn; j += 64) an[tt + j] = pa[ff + j];
+				for (uint32_t j = l; j < nn; j += 64) rh_an_cp(rr, rr.anc, base + tt + j, rr.prev_out, base + ff + j);
 			}
 		}
 	}
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(64) void k_regions(rh_dev_opt o, rh_dev_reads rd, r
 	__syncthreads();
 	for (int32_t i = (int32_t)lane; i < n_u; i += 64) {
 		const uint32_t k = L.k0[i], cnt = (uint32_t)L.u[i];
-		const rh_mm128_t f0 = an[k], f1 = an[k + cnt - 1];
+		const rh_mm128_t f0 = rh_an_ld(rr, rr.anc, base + k), f1 = rh_an_ld(rr, rr.anc, base + k + cnt - 1);
 		rh_chain_head h; h.x0 = f0.x; h.y0 = f0.y; h.x1 = (int32_t)f1.x; h.y1 = (int32_t)f1.y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
 		L.ch[i] = h;
 	}
@@ -596,7 +601,8 @@ __global__ void k_regions_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, co
 	uint32_t k = 0;
 	for (int32_t i = 0; i < n_u; ++i) {
 		const uint32_t cnt = (uint32_t)u[i];
-		rh_chain_head h; h.x0 = an[k].x; h.y0 = an[k].y; h.x1 = (int32_t)an[k + cnt - 1].x; h.y1 = (int32_t)an[k + cnt - 1].y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
+		const rh_mm128_t f0 = rh_an_ld(rr, rr.anc, base + k), f1 = rh_an_ld(rr, rr.anc, base + k + cnt - 1);
+		rh_chain_head h; h.x0 = f0.x; h.y0 = f0.y; h.x1 = (int32_t)f1.x; h.y1 = (int32_t)f1.y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
 		ch[i] = h;
 		k += cnt;
 	}
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(NT) void k_regions_prep(rh_dev_opt o, rh_dev_reads 
 		uint32_t tot;
 		const uint32_t k = carry + block_excl_scan(cnt, s_w, tot);
 		if (i < n_u) {
-			const rh_mm128_t f0 = an[k], f1 = an[k + cnt - 1];
+			const rh_mm128_t f0 = rh_an_ld(rr, rr.anc, base + k), f1 = rh_an_ld(rr, rr.anc, base + k + cnt - 1);
 			rh_chain_head h; h.x0 = f0.x; h.y0 = f0.y; h.x1 = (int32_t)f1.x; h.y1 = (int32_t)f1.y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
 			heads[i] = h;
 			const uint32_t hh = (uint32_t)rh_mix64_nomask((rh_mix64_nomask(f0.x) + rh_mix64_nomask(f0.y)) ^ (uint64_t)hash);
@@ -1334,7 +1340,8 @@ __global__ void k_regions_dtw(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh
 	uint32_t k = 0;
 	for (int32_t i = 0; i < n_u; ++i) {
 		const uint32_t cnt = (uint32_t)u[i];
-		rh_chain_head h; h.x0 = an[k].x; h.y0 = an[k].y; h.x1 = (int32_t)an[k + cnt - 1].x; h.y1 = (int32_t)an[k + cnt - 1].y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
+		const rh_mm128_t f0 = rh_an_ld(rr, rr.anc, base + k), f1 = rh_an_ld(rr, rr.anc, base + k + cnt - 1);
+		rh_chain_head h; h.x0 = f0.x; h.y0 = f0.y; h.x1 = (int32_t)f1.x; h.y1 = (int32_t)f1.y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
 		ch[i] = h;
 		k += cnt;
 	}
@@ -1437,12 +1444,12 @@ int rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd,
 	// long segments (unmappable reads: tens of thousands of chains) are placed without the token walks, the few reads that do hold
 	// equal keys are found afterwards and only they are sorted again with the exact passes (need_exact is idle here: rhk_regions
 	// resets it).  RH_RSORT_EXACT=1 (development aid) takes the exact passes for every read.
-	static const bool exact_all = getenv("RH_RSORT_EXACT") != nullptr;
+	static const bool exact_all = RH_DEVENV("RH_RSORT_EXACT") != nullptr;
 	if (exact_all) return rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL);
 	uint32_t n_redo = 0;
 	jb.any_order = 1; jb.redo_skip = r.need_exact; jb.n_redo = &n_redo;
 	if (rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL)) return -1;
-	static const bool trace = getenv("RH_BS_TRACE") != nullptr;
+	static const bool trace = RH_DEVENV("RH_BS_TRACE") != nullptr;
 	if (trace) fprintf(stderr, "RSORT any-order: %u of %u reads hold equal region keys and are redone\n", n_redo, r.n_act);
 	if (!n_redo) return 0;
 	RH_LAUNCH(k_regions_prep, r.n_act, NT, 0, s, o, rd, r, (const uint8_t*)r.need_exact);   // their keys again (the sorter overwrote its input)

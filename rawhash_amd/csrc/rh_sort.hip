@@ -819,14 +819,14 @@ int rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t 
 {
 	if (!jb.n_seg) return 0;
 	uint32_t top;
-	static const bool tiny_on = !(getenv("RH_SORT_TINY") && atoi(getenv("RH_SORT_TINY")) == 0);
+	static const bool tiny_on = !(RH_DEVENV("RH_SORT_TINY") && atoi(RH_DEVENV("RH_SORT_TINY")) == 0);
 	if (tiny_on && min_n < (uint32_t)RH_SORT_TINY) {	// one lane per segment of up to 32 records
 		if (jb.rf.rec8) RH_LAUNCH(k_sort_tiny<uint64_t>, (jb.n_seg + NT - 1) / NT, NT, 0, s, jb, min_n);
 		else RH_LAUNCH(k_sort_tiny<rh_mm128_t>, (jb.n_seg + NT - 1) / NT, NT, 0, s, jb, min_n);
 		min_n = (uint32_t)RH_SORT_TINY;
 		if (jb.n_max && jb.n_max <= min_n) return 0;
 	}
-	static const bool wave_on = !(getenv("RH_SORT_WAVE") && atoi(getenv("RH_SORT_WAVE")) == 0);
+	static const bool wave_on = !(RH_DEVENV("RH_SORT_WAVE") && atoi(RH_DEVENV("RH_SORT_WAVE")) == 0);
 	if (wave_on && jb.cnt_rw && !jb.skip && min_n < (uint32_t)RH_SORT_WAVE) {
 		if (jb.rf.rec8) RH_LAUNCH(k_sort_wave<uint64_t>, (jb.n_seg + NT / 64 - 1) / (NT / 64), NT, 0, s, jb, min_n);
 		else RH_LAUNCH(k_sort_wave<rh_mm128_t>, (jb.n_seg + NT / 64 - 1) / (NT / 64), NT, 0, s, jb, min_n);
@@ -859,12 +859,7 @@ int rhk_sort(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r)
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, nullptr, r.raw, r.anc, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 0, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };
 	sort_scratch(jb, r, r.zs);                                     // (the candidate array is idle until the chain DP has run)
 	jb.kind = 1;
-	if (!r.afmt.rec8) return rhk_sort_job(s, jb, false, 0u);
-	// one-word anchors (k_expand): sorted from the first half of the 16-byte-per-anchor arena into its second half, then expanded
-	uint64_t *sorted8 = reinterpret_cast<uint64_t*>(r.raw) + r.arena_n;
-	jb.dst = reinterpret_cast<rh_mm128_t*>(sorted8);
-	jb.rf = r.afmt;
-	if (rhk_sort_job(s, jb, false, 0u)) return -1;
-	rhk_anchor_unpack(s, ix, r, sorted8);
-	return 0;
+	jb.rf = r.afmt;                                                // (one-word anchors stay one word: r.raw -> r.anc as uint64_t arrays)
+	(void)ix;
+	return rhk_sort_job(s, jb, false, 0u);
 }

@@ -11,12 +11,13 @@ SRC = os.path.join(ROOT, "tests", "cabi", "rawhash2_step1.cpp")
 
 
 SRC_AVA = os.path.join(ROOT, "tests", "cabi", "rawhash2_ava.cpp")
+SRC_MULTI = os.path.join(ROOT, "tests", "cabi", "rawhash2_multigpu.cpp")
 
 
 def build_consumer(out_dir, product_lib, src=SRC):
     exe = os.path.join(str(out_dir), os.path.splitext(os.path.basename(src))[0])
     libdir = os.path.join(ROOT, "rawhash_amd")
-    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
                     "-L", libdir, "-lrawhash_amd", f"-Wl,-rpath,{libdir}"], check=True)
     return exe
 
@@ -64,3 +65,28 @@ def test_consumer_prints_the_golden_paf(tmp_path, product_lib):
         p = subprocess.run([exe, "sensitive", w.ind, rhr, per], capture_output=True, text=True)
         assert p.returncode == 0, p.stderr
         assert [strip_mt(x) for x in p.stdout.splitlines()] == golden.expected_paf(case)
+
+
+def test_multigpu_consumer_builds_with_plain_gxx(tmp_path, product_lib):
+    exe = build_consumer(tmp_path, product_lib, SRC_MULTI)
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 2 and "usage" in p.stderr
+
+
+@pytest.mark.gpu
+def test_multigpu_consumer_prints_the_golden_paf(tmp_path, product_lib):
+    """INTEGRATION.md section 4 as a program: one process, one context + host thread per GPU, rh_index_bcast, reads sharded, PAF in
+    read order = the reference's golden.  One context per visible GPU (N = 1 on the test box; RCCL when N > 1), and three contexts
+    sharing the devices round-robin so that the sharded flow and the replication run on a one-GPU box too."""
+    import golden
+    from rawhash_amd import strip_mt
+    exe = build_consumer(tmp_path, product_lib, SRC_MULTI)
+    case = [c for c in golden.cases() if c["name"] == "small_sensitive"][0]
+    w = golden.build_case(case, tmp_path / "wl", product_lib)
+    rhr = os.path.join(str(tmp_path), "reads.rhr")
+    w.reads.write(rhr, w.wl.cfg.digitisation, w.wl.cfg.range, w.wl.cfg.offset)
+    for n_ctx in ("0", "3"):
+        p = subprocess.run([exe, "sensitive", w.ind, rhr, n_ctx], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        assert [strip_mt(x) for x in p.stdout.splitlines()] == golden.expected_paf(case)
+        assert "context(s)" in p.stderr
