@@ -42,8 +42,8 @@ __global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 	const int32_t *fp = (const int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR);   // {f, p} interleaved
 	rh_mm128_t *z = rr.raw + base;               // the unsorted anchor copy is dead after the anchor sort
 	uint64_t *z8 = reinterpret_cast<uint64_t*>(rr.raw) + base;   // rr.z8: 8-byte candidates  score << 32 | anchor
-	uint32_t *t4 = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)16 * n);   // backtrack's "used" marks: ONE BIT per anchor (k_backtrack_spec)
-	for (int32_t i = (int32_t)tid; i < (n + 31) / 32; i += NT) t4[i] = 0u;
+	uint32_t *t4 = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)16 * n);   // backtrack's "touched" marks (1 B per anchor)
+	for (int32_t i = (int32_t)tid; i < (n + 3) / 4; i += NT) t4[i] = 0u;
 	uint32_t *claim = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)20 * n);   // k_backtrack_spec's per-anchor claim stamps
 	for (int32_t i = (int32_t)tid; i < n; i += NT) claim[i] = 0u;
 	uint32_t nz = 0;
@@ -87,12 +87,10 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
 	const int2 *fp = (const int2*)wsr;                              // .x = f, .y = p
 	int32_t *v = (int32_t*)wsr + 2 * (size_t)n;
-	// "used" marks, zeroed by k_zbuild: one BIT per anchor.  Every candidate starts with a look at its own mark, in score order - a random access
-	// per candidate, most of them already used: a read's marks are 1/8 of a byte array's sectors (22 KB for 175 k anchors: they stay in the L2 /
-	// MALL while the wavefront works through its candidates).  Set with L2 atomics, read at L2 (a wavefront's own earlier marks must be seen).
-	uint32_t *tb = (uint32_t*)(wsr + (size_t)16 * n);
-	#define BK_USED(i) ((__hip_atomic_load(&tb[(uint32_t)(i) >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> ((uint32_t)(i) & 31u)) & 1u)
-	#define BK_MARK(i) atomicOr(&tb[(uint32_t)(i) >> 5], 1u << ((uint32_t)(i) & 31u))
+	// "used" marks, zeroed by k_zbuild: one BYTE per anchor, plain loads and stores through the L1.  Every candidate starts with a look at its own
+	// mark (a random access, most of them used already).  Measured alternatives (human-scale step, this kernel 228 ms): marks inside a 16-byte
+	// {f, p, claim, used} record 404 ms; one BIT per anchor set with L2 atomics and read at L2 576 ms - the L1 serves most of these looks.
+	uint8_t *t = (uint8_t*)(wsr + (size_t)16 * n);
 	uint32_t *claim = (uint32_t*)(wsr + (size_t)20 * n);            // stamps, zeroed by k_zbuild
 	const rh_mm128_t *zs = rr.zs + base;
 	const uint64_t *zs8 = reinterpret_cast<const uint64_t*>(rr.zs) + base;
@@ -114,7 +112,7 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 			const uint32_t stamp = epoch << 6 | (63u - lane);
 			bool walked = false;
 			int32_t zx = 0, path = 0, max_s = 0, emit = 0;             // path = unused anchors reached after i0; emit = anchors i0 .. before max_i
-			if (pending && BK_USED(i0) == 0) {
+			if (pending && t[i0] == 0) {
 				walked = true;
 				int2 rec = fp[i0];
 				zx = rec.x;
@@ -122,9 +120,9 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 				for (;;) {	// mg_chain_bk_end (lchain.c:47-75): back until a used anchor, the start, or a score drop > max_drop
 					const int32_t i = rec.y;
 					int32_t sdrop = zx;
-					uint32_t ti = 0;
+					uint8_t ti = 0;
 					if (i >= 0) {
-						rec = fp[i]; ti = BK_USED(i); sdrop = zx - rec.x;
+						rec = fp[i]; ti = t[i]; sdrop = zx - rec.x;
 						if (ti == 0) {	// (a used anchor ends every walk that reaches it: nobody's to take, nothing to stamp)
 							if (!solo) atomicMax(&claim[i], stamp);
 							++path;
@@ -152,12 +150,12 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 			}
 			if (pending && !conflict) {
 				if (walked) {	// anchors i0 .. (exclusive) max_i form the chain; the marks stay even if it is rejected, as in the reference
-					if (emit >= 1) BK_MARK(i0);
-					if (emit >= 2) BK_MARK(pn1);
-					if (emit >= 3) BK_MARK(pn2);
-					if (emit >= 4) BK_MARK(pn3);
+					if (emit >= 1) t[i0] = 1;
+					if (emit >= 2) t[pn1] = 1;
+					if (emit >= 3) t[pn2] = 1;
+					if (emit >= 4) t[pn3] = 1;
 					int32_t x = pn3;
-					for (int32_t j = 4; j < emit; ++j) { x = fp[x].y; BK_MARK(x); }
+					for (int32_t j = 4; j < emit; ++j) { x = fp[x].y; t[x] = 1; }
 					accepted = max_s >= min_sc && emit > 0 && emit >= min_cnt;   // (score of the chain = the best drop seen = max_s)
 					r_cnt = emit; r_sc = max_s;
 				}
@@ -184,8 +182,6 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 		n_u += (int32_t)__popcll(am);
 		n_v += (int32_t)total;
 	}
-	#undef BK_USED
-	#undef BK_MARK
 	if (lane == 0) {
 		rr.n_u[a] = (uint32_t)n_u; rr.n_v[a] = (uint32_t)n_v;
 		if (n_u == 0) { rd.n_prev[r] = 0; rd.prev_off[r] = base; }
