@@ -553,7 +553,7 @@ extern "C" int rh_index_upload(rh_ctx *c, const rh_index *ix)
 			so[2 * i + 1] = so[2 * i] + (i < ix->sigF.size() ? ix->sigF[i].size() : 0);
 			so[2 * i + 2] = so[2 * i + 1] + (i < ix->sigR.size() ? ix->sigR[i].size() : 0);
 		}
-		h.bytes += so.size() * 8 + (so.back() ? so.back() : 1) * 4;
+		h.bytes += so.size() * 8 + (so.back() + 2) * 4;              // (+ two floats of zero padding: the DTW's global border reads one element past a signal, as the reference does)
 	}
 	h.lg_buckets = lg; h.n_seq = (uint32_t)ix->lens.size(); h.flag = ix->flag;
 	h.max_len = 0;
@@ -568,6 +568,7 @@ extern "C" int rh_index_upload(rh_ctx *c, const rh_index *ix)
 	if (h.sig_off) {
 		RH_HIP(hipMemcpy(base + h.sig_off, so.data(), so.size() * 8, hipMemcpyHostToDevice));
 		unsigned char *data = base + h.sig_off + so.size() * 8;
+		RH_HIP(hipMemset(data + so.back() * 4, 0, 8));
 		for (size_t i = 0; i < ix->lens.size(); ++i) {
 			if (i < ix->sigF.size() && !ix->sigF[i].empty()) RH_HIP(hipMemcpy(data + so[2 * i] * 4, ix->sigF[i].data(), ix->sigF[i].size() * 4, hipMemcpyHostToDevice));
 			if (i < ix->sigR.size() && !ix->sigR[i].empty()) RH_HIP(hipMemcpy(data + so[2 * i + 1] * 4, ix->sigR[i].data(), ix->sigR[i].size() * 4, hipMemcpyHostToDevice));
@@ -606,6 +607,10 @@ extern "C" int rh_index_adopt_blob(rh_ctx *c, const rh_index *, void *dev_ptr, u
 		const bool ok = tb != ~0ull && (h.table_off & 15) == 0 && (h.pos_off & 7) == 0 && (h.len_off & 3) == 0 &&
 		                h.table_off + tb <= h.pos_off && h.n_pos <= (h.bytes >> 3) && h.pos_off + h.n_pos * 8 <= h.len_off && h.len_off + (uint64_t)h.n_seq * 4 <= h.bytes;
 		if (!ok) { rh_set_error("index blob header is inconsistent (offsets / sizes)"); return -1; }
+		// --store-sig signals behind the lengths: [u64 so[2 n + 1] | floats]; 0 = none (a header from a build before the field existed holds 0 there)
+		if (h.sig_off != 0 && !((h.sig_off & 7) == 0 && h.sig_off >= h.len_off + (uint64_t)h.n_seq * 4 && h.sig_off + ((uint64_t)2 * h.n_seq + 1) * 8 <= h.bytes)) {
+			rh_set_error("index blob header is inconsistent (stored-signal offset)"); return -1;
+		}
 	}
 	if (c->blob_owned) c->blob.release();
 	c->blob.p = dev_ptr; c->blob.cap = bytes; c->blob_owned = take_ownership != 0;
@@ -619,7 +624,6 @@ extern "C" rh_index *rh_index_build_device(rh_ctx *c, uint32_t n_seq, const char
 	if (index_replaceable(c, "rh_index_build_device")) return nullptr;
 	if (hipSetDevice(c->device) != hipSuccess) { rh_set_error("hipSetDevice failed"); return nullptr; }
 	if (io->flag & RH_I_SIG_TARGET) { rh_set_error("signal-target (Rawsamble) indexes are built by rh_index_build_signals"); return nullptr; }
-	if (io->flag & RH_I_STORE_SIG) { rh_set_error("--store-sig indexes (target signals for DTW re-scoring) are built on the host: rh_index_build"); return nullptr; }
 	if (io->w < 0 || io->w > RH_DEV_MAXW) { rh_set_error("minimiser window w = %d outside what the device sketch maps with (0..%d)", io->w, RH_DEV_MAXW); return nullptr; }
 	if (io->e < 1 || io->e > 16 || io->q < 1 || io->q * io->e > 64 || io->k < 1 || io->k > 12) { rh_set_error("unsupported index parameters e=%d q=%d k=%d", io->e, io->q, io->k); return nullptr; }
 	std::unique_ptr<rh_index_s> ix(new rh_index_s());
@@ -729,6 +733,22 @@ extern "C" int rh_index_download(rh_ctx *c, rh_index *ix, int n_threads)
 	const size_t nk = ent.size();
 	ix->key_hash.resize(nk); ix->key_n.resize(nk); ix->key_val.resize(nk);
 	for (size_t i = 0; i < nk; ++i) { ix->key_hash[i] = ent[i].hash; ix->key_n[i] = ent[i].n; ix->key_val[i] = ent[i].val; }
+	if (h.sig_off && (ix->flag & RH_I_STORE_SIG)) {	// --store-sig: the targets' signals, for rh_index_write (rindex.c:590-598)
+		std::vector<uint64_t> so((size_t)2 * h.n_seq + 1);
+		const unsigned char *sb = c->blob.as<unsigned char>() + h.sig_off;
+		RH_HIP(hipMemcpy(so.data(), sb, so.size() * 8, hipMemcpyDeviceToHost));
+		const bool rev = !(ix->flag & RH_I_NO_REV_TARGET);
+		ix->sigF.assign(h.n_seq, std::vector<float>()); ix->sigR.clear();
+		if (rev) ix->sigR.assign(h.n_seq, std::vector<float>());
+		for (uint32_t i = 0; i < h.n_seq; ++i) {
+			ix->sigF[i].resize(so[2 * (size_t)i + 1] - so[2 * (size_t)i]);
+			if (!ix->sigF[i].empty()) RH_HIP(hipMemcpy(ix->sigF[i].data(), sb + so.size() * 8 + so[2 * (size_t)i] * 4, ix->sigF[i].size() * 4, hipMemcpyDeviceToHost));
+			if (rev) {
+				ix->sigR[i].resize(so[2 * (size_t)i + 2] - so[2 * (size_t)i + 1]);
+				if (!ix->sigR[i].empty()) RH_HIP(hipMemcpy(ix->sigR[i].data(), sb + so.size() * 8 + so[2 * (size_t)i + 1] * 4, ix->sigR[i].size() * 4, hipMemcpyDeviceToHost));
+			}
+		}
+	}
 	return 0;
 }
 

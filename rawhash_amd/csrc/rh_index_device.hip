@@ -484,6 +484,21 @@ int rhk_index_build_device(hipStream_t s, uint32_t n_seq, const char *const *seq
 	for (int q = 0; q < 2; ++q) if (dMask[q].alloc((size_t)max_words * 4) || dPrefix[q].alloc((size_t)max_words * 4) || dCode[q].alloc((size_t)max_ev + 64) || dPos[q].alloc((size_t)max_ev * 4 + 16)) return -1;
 	if (dPc.alloc((size_t)max_words * 4) || dIn.alloc((size_t)max_blocks * 4) || dOut.alloc((size_t)max_blocks * 4) || dFlag.alloc(max_blocks) || dSums.alloc(((size_t)(io->w > 0 ? max_ev : max_words) / 2048 + 4) * 8) || dScal.alloc(64)) return -1;
 	RH_HIP(hipMemcpyAsync(dModel.p, model.data(), model.size() * 4, hipMemcpyHostToDevice, s));
+	// RH_I_STORE_SIG (--store-sig, rindex.c:133-160, 590-598): the levels k_ix_levels computes ARE the targets' expected signals - kept, strand
+	// after strand, and laid out behind the target lengths as [u64 so[2 n + 1] | floats] (what rh_index_upload lays out for a host-built index)
+	const bool store_sig = (io->flag & RH_I_STORE_SIG) != 0;
+	std::vector<uint64_t> so;
+	DevMem dSig;
+	if (store_sig) {
+		so.assign((size_t)2 * n_seq + 1, 0);
+		for (uint32_t i = 0; i < n_seq; ++i) {
+			const uint64_t ne = lens[i] >= (uint32_t)k ? lens[i] - k + 1 : 0;
+			so[2 * (size_t)i + 1] = so[2 * (size_t)i] + ne;
+			so[2 * (size_t)i + 2] = so[2 * (size_t)i + 1] + (n_strands == 2 ? ne : 0);
+		}
+		if (dSig.alloc((so.back() + 2) * 4)) return -1;
+		RH_HIP(hipMemsetAsync(dSig.p, 0, (so.back() + 2) * 4, s));    // (two floats of zero padding: the DTW's global border looks one element past a signal, as the reference does)
+	}
 	uint64_t n_seeds = 0;
 	uint64_t *scal = nullptr;
 	RH_HIP(hipHostMalloc((void**)&scal, 64, 0));
@@ -519,6 +534,7 @@ int rhk_index_build_device(hipStream_t s, uint32_t n_seq, const char *const *seq
 		uint32_t kept[2] = {0, 0}, seeds[2] = {0, 0};
 		for (int st = 0; st < n_strands; ++st) {
 			RH_LAUNCH(k_ix_levels, (n_ev + NT - 1) / NT, NT, 0, s, dSeq.as<char>(), len, st, k, dModel.as<float>(), R, dLv.as<float>(), n_ev);
+			if (store_sig) RH_HIP(hipMemcpyAsync(dSig.as<float>() + so[2 * (size_t)id + st], dLv.p, (size_t)n_ev * 4, hipMemcpyDeviceToDevice, s));
 			RH_LAUNCH(k_ix_keep, (n_blocks + 63) / 64, 64, 0, s, dLv.as<float>(), n_ev, io->diff, dIn.as<float>(), dOut.as<float>(), dMask[st].as<uint32_t>(), (const uint8_t*)nullptr, n_blocks);
 			for (int iter = 0;; ++iter) {
 				RH_HIP(hipMemsetAsync(dScal.p, 0, 8, s));
@@ -569,13 +585,24 @@ int rhk_index_build_device(hipStream_t s, uint32_t n_seq, const char *const *seq
 	for (int q = 0; q < 2; ++q) { dMask[q].release(); dPrefix[q].release(); dCode[q].release(); dPos[q].release(); }
 	void *hp = dH[0].p, *yp = dY[0].p;
 	dH[0].p = nullptr; dY[0].p = nullptr;                         // (handed over)
-	return rhk_index_assemble(s, hp, yp, n_seeds, n_seq, lens, max_len, io, hdr, blob_out, occ_hist, n_keys_out, io->w > 0);
+	const uint64_t extra = store_sig ? 8 + so.size() * 8 + (so.back() + 2) * 4 : 0;
+	if (rhk_index_assemble(s, hp, yp, n_seeds, n_seq, lens, max_len, io, hdr, blob_out, occ_hist, n_keys_out, io->w > 0, extra)) return -1;
+	if (store_sig) {
+		unsigned char *bp = (unsigned char*)*blob_out;
+		hdr->bytes = (hdr->bytes + 7) & ~7ull;
+		hdr->sig_off = hdr->bytes;
+		RH_HIP(hipMemcpyAsync(bp + hdr->sig_off, so.data(), so.size() * 8, hipMemcpyHostToDevice, s));
+		RH_HIP(hipMemcpyAsync(bp + hdr->sig_off + so.size() * 8, dSig.p, (so.back() + 2) * 4, hipMemcpyDeviceToDevice, s));
+		RH_HIP(hipStreamSynchronize(s));
+		hdr->bytes += so.size() * 8 + (so.back() + 2) * 4;
+	}
+	return 0;
 }
 
 // Seeds (32-bit hash, position word) in target order -> resident blob [table | positions | target lengths].  Takes ownership
 // of the two device arrays (hipMalloc'ed, n_seeds + 1 entries).
 int rhk_index_assemble(hipStream_t s, void *seed_hash, void *seed_pos, uint64_t n_seeds, uint32_t n_seq, const uint32_t *lens, uint32_t max_len,
-                       const rh_idxopt_t *io, rh_blob_header *hdr, void **blob_out, std::vector<uint32_t> &occ_hist, uint64_t *n_keys_out, bool sort_pos)
+                       const rh_idxopt_t *io, rh_blob_header *hdr, void **blob_out, std::vector<uint32_t> &occ_hist, uint64_t *n_keys_out, bool sort_pos, uint64_t extra_bytes)
 {
 	const rh_sketch_par sp = {io->e, io->w, io->q, io->k, io->diff, io->fine_min, io->fine_max, io->fine_range};
 	DevMem dH[2], dY[2], dSums, dScal;
@@ -634,7 +661,7 @@ int rhk_index_assemble(hipStream_t s, void *seed_hash, void *seed_pos, uint64_t 
 	hdr->lg_buckets = lg; hdr->n_seq = n_seq; hdr->flag = io->flag; hdr->sp = sp; hdr->max_len = max_len;
 	DevMem blob, dHist;
 	const uint32_t occ_bins = 1u << 20;
-	if (blob.alloc(hdr->bytes) || dHist.alloc((size_t)occ_bins * 4)) return -1;
+	if (blob.alloc(hdr->bytes + extra_bytes) || dHist.alloc((size_t)occ_bins * 4)) return -1;   // (extra_bytes: room behind the lengths - the caller's --store-sig signals)
 	unsigned char *bp = blob.as<unsigned char>();
 	RH_HIP(hipMemsetAsync(bp + hdr->table_off, 0, hdr->pos_off, s));
 	RH_HIP(hipMemsetAsync(dHist.p, 0, (size_t)occ_bins * 4, s));

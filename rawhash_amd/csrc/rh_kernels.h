@@ -48,7 +48,7 @@ int rhk_index_build_device(hipStream_t s, uint32_t n_seq, const char *const *seq
                            const rh_idxopt_t *io, rh_blob_header *hdr, void **blob_out, std::vector<uint32_t> &occ_hist, uint64_t *n_keys_out, int n_threads);
 
 int rhk_index_assemble(hipStream_t s, void *seed_hash, void *seed_pos, uint64_t n_seeds, uint32_t n_seq, const uint32_t *lens, uint32_t max_len,
-                       const rh_idxopt_t *io, rh_blob_header *hdr, void **blob_out, std::vector<uint32_t> &occ_hist, uint64_t *n_keys_out, bool sort_pos = false);   // sort_pos: the seeds are not in position order yet
+                       const rh_idxopt_t *io, rh_blob_header *hdr, void **blob_out, std::vector<uint32_t> &occ_hist, uint64_t *n_keys_out, bool sort_pos = false, uint64_t extra_bytes = 0);   // sort_pos: the seeds are not in position order yet; extra_bytes: room left behind the blob
 
 // scalar parameters every kernel may need
 struct rh_dev_opt {

@@ -89,6 +89,22 @@ def test_dtw_rescoring(make_workload, product_lib, gpu_ctx_factory, mapopt):
     assert recs["mapped"].sum() > 100
 
 
+def test_device_index_store_sig_and_dtw(make_workload, product_lib, gpu_ctx_factory, tmp_path):
+    """--store-sig on the DEVICE index builder (the levels k_ix_levels computes, laid out as rindex.c:590-598 writes them): the .ind written
+    from the device-built index is the host builder's byte for byte (which tests/test_oracle.py pins to the reference's, --store-sig
+    included), and DTW re-scoring against the device-built, never-uploaded index prints the oracle's PAF."""
+    from rawhash_amd.api import Index
+    w = make_workload(n_reads=200, n_samples=20_000, idxflag=0x10, mapopt={"flag": 0x40})
+    c = gpu_ctx_factory()
+    dev = Index.build_device(c, w.fasta, w.model, w.opts, n_threads=8)
+    dev.download(c)
+    out = str(tmp_path / "device_store_sig.ind")
+    dev.write(out)
+    assert open(out, "rb").read() == open(w.ind, "rb").read(), "device-built --store-sig .ind differs from the host builder's"
+    recs = pc.check_e2e(c, w)                      # (the context serves reads from the index it has just built)
+    assert recs["mapped"].sum() > 60
+
+
 def test_any_order_sort(ctx):
     """Region keys (hit.c:111-126) through the sorter's any-order levels + tie check, many long segments."""
     assert pc.check_sort_any(ctx, seed=5) >= 1
