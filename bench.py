@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads of the CPU-baseline sample (0 = skip, -1 = the workload's default)")
     ap.add_argument("--no-h2d", dest="h2d", action="store_false", help="skip the PCIe-inclusive measurement (batches in pinned host memory)")
     ap.add_argument("--dry-run", action="store_true", help="parse the launch (arguments + torch.distributed environment), print the plan as JSON and exit before touching a GPU")
+    ap.add_argument("--mapopt", default="", choices=["", "rmq", "bw_long", "dtw"],
+                    help="secondary lines for the chaining variants of SURVEY 8 f4: rmq = --rmq (mg_lchain_rmq), bw_long = --bw-long 2000 (RMQ re-chaining), "
+                         "dtw = --dtw-evaluate-chains on a --store-sig index (built on the device)")
     ap.add_argument("--cpu-threads", default="", help="thread counts of the CPU sweep, comma separated (default: cores/8 .. cores)")
     args = ap.parse_args()
     if args.workload == "ava":
@@ -119,6 +122,14 @@ def main():
     cores = os.cpu_count() or 8
     wl = SynthWorkload(chrom_len=chrom_len, n_chrom=n_chrom, n_samples=args.samples, junk_per_1024=args.junk)
     opts = MapOptions(preset)
+    ref_env = {}                                   # the same option for the reference harness (oracle/ref_harness.cpp reads it from the environment)
+    if args.mapopt == "rmq":
+        opts.mo.flag |= 0x2; ref_env = {"RH_RMQ": "1"}
+    elif args.mapopt == "bw_long":
+        opts.mo.bw_long = 2000; ref_env = {"RH_BW_LONG": "2000"}
+    elif args.mapopt == "dtw":
+        opts.io.flag |= 0x10; opts.mo.flag |= 0x40; ref_env = {"RH_STORE_SIG": "1", "RH_DTW": "1"}
+    args.ref_env = ref_env
     port = os.environ.get("MASTER_PORT", "0")
     shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
     workdir = os.path.join(shm, f"rawhash_amd_bench_{port}_{os.getppid() if world > 1 else os.getpid()}")
@@ -215,7 +226,7 @@ def main():
         dev_ms = sum(kernels.values())
         n_streams = int(os.environ.get("RH_SUB_BATCHES", "3"))
         out = {
-            "metric": f"reads/sec mapped ({wl_name} index resident in HBM)", "value": round(value, 1), "unit": "reads/s",
+            "metric": f"reads/sec mapped ({wl_name} index resident in HBM" + (f", {args.mapopt}" if args.mapopt else "") + ")", "value": round(value, 1), "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16 signal; fp32/fp64 events; u64/i32 seeding+chaining", "data": "synthetic",
             "config": {"workload": f"{wl_name}: synthetic genome {n_chrom} x {chrom_len} bp + {args.reads} synthetic R9.4 reads/GPU x {args.samples} samples, preset {preset}, "
@@ -476,7 +487,7 @@ def cpu_baseline(ctx, index, opts, wl, model, workdir, preset, recs, args, cores
         for nm, ev, ts in passes:
             with open(paf, "w") as fo:
                 p = subprocess.run([O.REF_HARNESS, "map", preset, ind, rhr, ",".join(str(t) for t in ts)], stdout=fo, stderr=subprocess.PIPE, text=True, timeout=3000,
-                                   env=dict(os.environ, **ev))
+                                   env=dict(os.environ, **ev, **getattr(args, "ref_env", {})))
             rr = [(int(t), float(sec)) for sec, t in re.findall(r"map phase ([0-9.]+) s, threads (\d+)", p.stderr)]
             if p.returncode != 0 or not rr:
                 notes.append(f"{nm}: harness rc {p.returncode}")

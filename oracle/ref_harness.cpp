@@ -107,6 +107,7 @@ static void apply_overrides(ri_idxopt_t *ipt, ri_mapopt_t *opt)
 	if ((s = getenv("RH_MAX_CHUNKS"))) opt->max_num_chunk = atoi(s);
 	if ((s = getenv("RH_CHUNK_SIZE"))) opt->chunk_size = atoi(s);
 	if ((s = getenv("RH_MIN_MAPQ"))) opt->min_mapq = atoi(s);
+	if ((s = getenv("RH_MIN_ANCHORS"))) opt->min_num_anchors = atoi(s);              // --min-anchors (main.cpp:19)
 	if ((s = getenv("RH_MID_OCC"))) opt->mid_occ = atoi(s);
 	if ((s = getenv("RH_W"))) ipt->w = atoi(s);
 	if ((s = getenv("RH_E"))) ipt->e = atoi(s);

@@ -86,6 +86,7 @@ struct rh_ctx_s {
 	DevBuf events, dtw_ws, dtw_n, dtw_off, dtw_rec, dtw_dec;       // RH_M_DTW_EVALUATE_CHAINS: reads' events, DP buffers, per-region values for the host's MAPQ, its decisions
 	DevBuf name_rank, t_rank, rec_off;                            // all-vs-all: name ranks of the reads / of the targets, record offsets
 	uint64_t arena_room = 0;                                       // anchors the per-anchor arenas were sized for when a round was last cut into slices (the budget sticks to it)
+	uint32_t ws_stride = RH_WS_PER_ANCHOR;                         // bytes of per-anchor scratch of the current batch (doubled when min_num_anchors < 2)
 	uint32_t cs_stride = 2;                                        // chunk boundaries kept per read of the current batch: max_num_chunk + 1
 	uint32_t ev_row = RH_CHUNK_MAX + 64, ev_cap = RH_EV_CAP, whole = 0;   // strides of the per-read rows of the current batch (whole-read rounds: sized by its longest read)
 	DevBuf carry[2], carry_off, a_off_slice;                      // chained anchors carried into the next chunk, dense, ping-pong over the rounds
@@ -138,9 +139,11 @@ void stage_timers_collect(rh_ctx *c)
 // if bw_long > bw, the chained anchors are chained AGAIN by the RMQ variant with the long bandwidth (same backtrack / compaction)
 static int chain_stages(rh_ctx *c, hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &rr, bool timed);
 
-int fill_dev_opt(const rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
+int fill_dev_opt(rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
 {
-	if (mo->chunk_size == 0 || mo->chunk_size > RH_CHUNK_MAX) { rh_set_error("chunk_size %u not supported on the device (1..%d)", mo->chunk_size, RH_CHUNK_MAX); return -1; }
+	c->ws_stride = mo->min_num_anchors < 2 ? 2 * RH_WS_PER_ANCHOR : RH_WS_PER_ANCHOR;   // (chains of one anchor: the region stage keeps 128 B per chain)
+	if (mo->chunk_size == 0 || mo->chunk_size >= (1u << 26)) { rh_set_error("chunk_size %u not supported on the device (1..2^26-1)", mo->chunk_size); return -1; }
+	if (!(mo->flag & RH_M_NO_ADAPTIVE) && mo->chunk_size > RH_CHUNK_MAX && (mo->window_length1 > 15 || mo->window_length2 > 15)) { rh_set_error("chunks of more than %d samples need segmentation windows <= 15", RH_CHUNK_MAX); return -1; }
 	if (mo->max_num_chunk > (1u << 16)) { rh_set_error("max_num_chunk %u > 65536 not supported", mo->max_num_chunk); return -1; }
 	if ((mo->flag & RH_M_ALL_CHAINS) && !(mo->flag & RH_M_NO_ADAPTIVE)) { rh_set_error("all-chains output is built for whole-read rounds only (RH_M_ALL_CHAINS needs RH_M_NO_ADAPTIVE, as in the ava presets)"); return -1; }
 	if ((mo->flag & RH_M_NO_ADAPTIVE) && (mo->window_length1 > 15 || mo->window_length2 > 15)) { rh_set_error("whole-read rounds need segmentation windows <= 15"); return -1; }
@@ -150,7 +153,7 @@ int fill_dev_opt(const rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
 		if (c->have_index && !c->dix.sig) { rh_set_error("DTW re-scoring needs the targets' signals: build the index with RH_I_STORE_SIG (--store-sig) and upload it (rh_index_upload)"); return -1; }
 		if (mo->dtw_border_constraint > 1u || mo->dtw_fill_method > 1u) { rh_set_error("DTW border constraint %u / fill method %u not supported (global | sparse, full | banded)", mo->dtw_border_constraint, mo->dtw_fill_method); return -1; }
 	}
-	if (mo->min_num_anchors < 2) { rh_set_error("min_num_anchors < 2 is not supported on the device (the per-anchor scratch assumes chains of at least two anchors)"); return -1; }
+	if (mo->min_num_anchors < 1) { rh_set_error("min_num_anchors %d < 1", mo->min_num_anchors); return -1; }
 	if (mo->window_length1 > 64 || mo->window_length2 > 64) { rh_set_error("segmentation windows > 64 not supported"); return -1; }
 	memset(o, 0, sizeof(*o));
 	o->chunk_size = mo->chunk_size; o->max_num_chunk = mo->max_num_chunk; o->min_events = mo->min_events;
@@ -355,9 +358,9 @@ int stage_anchors(rh_ctx *c, uint64_t total, rh_dev_round *rr, uint64_t room = 0
 	const size_t t = total > room ? (total ? total : 1) : room;
 	const bool mg = room == 0;                                     // (budget-sized arenas: no growth margin)
 	if (c->anc.ensure(t * 16, mg) || c->raw_anc.ensure(t * 16, mg) || c->zs.ensure(t * 16, mg) || c->prev_stage.ensure(t * 16, mg) || c->u.ensure(t * 8, mg) ||
-	    c->ws.ensure(t * RH_WS_PER_ANCHOR + 4096, mg)) return -1;
+	    c->ws.ensure(t * c->ws_stride + 4096, mg)) return -1;
 	rr->anc = c->anc.as<rh_mm128_t>(); rr->raw = c->raw_anc.as<rh_mm128_t>(); rr->zs = c->zs.as<rh_mm128_t>(); rr->prev_out = c->prev_stage.as<rh_mm128_t>();
-	rr->u = c->u.as<uint64_t>(); rr->ws = c->ws.as<unsigned char>();
+	rr->u = c->u.as<uint64_t>(); rr->ws = c->ws.as<unsigned char>(); rr->ws_stride = c->ws_stride;
 	rr->arena_n = t;
 	// segments longer than the LDS sort classes (large indexes): scratch of the multi-workgroup sorter
 	if (rr->max_anchors == 0 || rr->max_anchors > (uint32_t)RH_SORT_LDS_MIN_TOP) {
@@ -369,7 +372,7 @@ int stage_anchors(rh_ctx *c, uint64_t total, rh_dev_round *rr, uint64_t room = 0
 	return 0;
 }
 // bytes of device memory a slice needs per anchor (the arrays above + the sorter's tables)
-const size_t kBytesPerAnchor = 16 * 4 + 8 + RH_WS_PER_ANCHOR + 18;
+size_t bytes_per_anchor(const rh_ctx *c) { return 16 * 4 + 8 + (size_t)c->ws_stride + 18; }
 
 // anchors one slice of a round may hold: what is free on the device (plus what this context's arenas hold already), shared
 // by the sub-batches running concurrently; RH_ARENA_MAX_BYTES caps the per-anchor scratch (shared devices, tests)
@@ -387,7 +390,7 @@ uint64_t slice_budget(rh_ctx *c)
 		// for the dense carry buffers and the per-read arrays), but never less than the arenas hold: they stay as they are
 		const double may_use = (double)(avail / (size_t)(c->share > 0 ? c->share : 1)) + (double)held;
 		const double use = 0.75 * may_use > (double)held ? 0.75 * may_use : (double)held;
-		budget = (uint64_t)(use / (double)kBytesPerAnchor);
+		budget = (uint64_t)(use / (double)bytes_per_anchor(c));
 		if (budget < (1u << 16)) return 0;                          // the device is full (other contexts / processes hold it)
 		// The arenas were sized for a budget once: a slightly larger one (the free memory moves by rounding and by what the other
 		// sub-batches hold at the moment) must not re-allocate tens of gigabytes on a nearly full device - that takes seconds.
@@ -803,6 +806,12 @@ int set_row_strides(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in)
 	c->whole = (mo->flag & RH_M_NO_ADAPTIVE) ? 1 : 0;
 	c->cs_stride = (c->whole ? 1u : (mo->max_num_chunk ? mo->max_num_chunk : 1u)) + 1u;
 	c->ev_row = RH_CHUNK_MAX + 64; c->ev_cap = RH_EV_CAP;
+	if (!c->whole && mo->chunk_size > RH_CHUNK_MAX) {	// chunks beyond the LDS-resident event kernels: the rows-in-HBM kernels of the whole-read rounds, a chunk at a time
+		c->whole = 1;
+		c->ev_row = (uint32_t)(((uint64_t)mo->chunk_size + 64 + 63) & ~63ull);
+		c->ev_cap = c->ev_row / 2 + 2;
+		return 0;
+	}
 	if (!c->whole) return 0;
 	const uint32_t R = in->n_reads;
 	std::vector<uint64_t> off_h;
@@ -868,7 +877,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 	{ StageTimer t(c, ST_H2D); if (stage_reads(c, in, &rd)) return -1; }
 	const bool dtw = (mo->flag & RH_M_DTW_EVALUATE_CHAINS) != 0;
 	if (dtw) {	// every read keeps the events of all its processed chunks
-		rd.ev_stride = (mo->flag & RH_M_NO_ADAPTIVE) ? c->ev_cap : mo->max_num_chunk * (uint32_t)RH_EV_CAP;
+		rd.ev_stride = (mo->flag & RH_M_NO_ADAPTIVE) ? c->ev_cap : mo->max_num_chunk * c->ev_cap;
 		if (c->events.ensure((size_t)R * rd.ev_stride * 4)) return -1;
 		rd.events = c->events.as<float>();
 	}

@@ -123,7 +123,7 @@ struct rh_dev_round {
 	const rh_mm128_t *prev_in; rh_mm128_t *prev_out;
 	uint64_t *u; uint32_t *n_u, *n_v;        // chains: score<<32 | count
 	rh_mm128_t *zs; uint32_t *n_z;           // backtrack candidates (score, anchor) in radix_sort_128x order
-	unsigned char *ws;               // RH_WS_PER_ANCHOR bytes per anchor
+	unsigned char *ws; uint32_t ws_stride;   // ws_stride bytes of scratch per anchor: RH_WS_PER_ANCHOR, twice that when chains may have a single anchor (min_num_anchors < 2: the region stage needs 128 B per chain)
 	unsigned char *sort_ws; size_t sort_ws_bytes; void *sort_pin; uint64_t sort_total;   // tables of the multi-workgroup segment sorter (rh_bigsort.hip); its second record array is an arena idle at the time
 	float *dtw_ws; uint32_t dtw_stride;      // RH_M_DTW_EVALUATE_CHAINS: DP buffers, dtw_stride floats per active read
 	uint32_t *dtw_n; float *dtw_rec; const uint64_t *dtw_off; const int32_t *dtw_dec;   // regions per read; packed per-region values for the host's MAPQ; their offsets; the host's decisions (3 int32 per read)

@@ -667,8 +667,13 @@ __global__ __launch_bounds__(NT) void k_events_norm_whole(rh_dev_opt o, rh_dev_r
 	if (a >= rr.n_act) return;
 	const uint32_t r = rr.act[a];
 	const uint64_t o0 = rd.off[r];
-	const uint32_t n_raw = (uint32_t)(rd.off[r + 1] - o0);
-	const int16_t *raw = rd.raw + o0;
+	// the round's stretch of the raw signal, [chunk_start[c], chunk_start[c + 1]): the whole read (RH_M_NO_ADAPTIVE), or - adaptive rounds whose
+	// chunk_size is beyond the LDS-resident kernels - the raw samples of chunk rr.chunk
+	const uint32_t *cs = rd.chunk_start + (size_t)r * rd.cs_stride;
+	// (whole reads: k_prefilter ran with chunk_size = 2^30, so chunk 0 is [first sample that passes the pA filter, end of the read))
+	const uint32_t r_lo = cs[rr.chunk];
+	const uint32_t n_raw = cs[rr.chunk + 1] - r_lo;
+	const int16_t *raw = rd.raw + o0 + r_lo;
 	const double coff = rd.cal_off[r];
 	const float cscale = rd.cal_scale[r];
 	const uint32_t f5 = rd.fast5;

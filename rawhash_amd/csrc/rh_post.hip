@@ -39,12 +39,12 @@ __global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 	if (rr.skip[a]) { if (tid == 0) rr.n_z[a] = 0; return; }
 	const uint64_t base = rr.a_off[a];
 	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
-	const int32_t *fp = (const int32_t*)(rr.ws + base * RH_WS_PER_ANCHOR);   // {f, p} interleaved
+	const int32_t *fp = (const int32_t*)(rr.ws + base * rr.ws_stride);   // {f, p} interleaved
 	rh_mm128_t *z = rr.raw + base;               // the unsorted anchor copy is dead after the anchor sort
 	uint64_t *z8 = reinterpret_cast<uint64_t*>(rr.raw) + base;   // rr.z8: 8-byte candidates  score << 32 | anchor
-	uint32_t *t4 = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)16 * n);   // backtrack's "touched" marks (1 B per anchor)
+	uint32_t *t4 = (uint32_t*)(rr.ws + base * rr.ws_stride + (size_t)16 * n);   // backtrack's "touched" marks (1 B per anchor)
 	for (int32_t i = (int32_t)tid; i < (n + 3) / 4; i += NT) t4[i] = 0u;
-	uint32_t *claim = (uint32_t*)(rr.ws + base * RH_WS_PER_ANCHOR + (size_t)20 * n);   // k_backtrack_spec's per-anchor claim stamps
+	uint32_t *claim = (uint32_t*)(rr.ws + base * rr.ws_stride + (size_t)20 * n);   // k_backtrack_spec's per-anchor claim stamps
 	for (int32_t i = (int32_t)tid; i < n; i += NT) claim[i] = 0u;
 	uint32_t nz = 0;
 	for (int32_t i0 = 0; i0 < n; i0 += NT) {                        // (a workgroup per read: an unmappable read on a large index has 10^5 anchors)
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 	const uint64_t base = rr.a_off[a];
 	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
 	const int32_t n_z = (int32_t)rr.n_z[a];
-	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
+	unsigned char *wsr = rr.ws + base * rr.ws_stride;
 	const int2 *fp = (const int2*)wsr;                              // .x = f, .y = p
 	int32_t *v = (int32_t*)wsr + 2 * (size_t)n;
 	// "used" marks, zeroed by k_zbuild: one BYTE per anchor, plain loads and stores through the L1.  Every candidate starts with a look at its own
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NT) void k_chain_gather(rh_dev_round rr)
 	if (n_u == 0) return;
 	const uint64_t base = rr.a_off[a];
 	const uint32_t n = (uint32_t)(rr.a_off[a + 1] - base);
-	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
+	unsigned char *wsr = rr.ws + base * rr.ws_stride;
 	const int32_t *v = (const int32_t*)wsr + 2 * (size_t)n;
 	uint32_t *ck0 = (uint32_t*)(wsr + (size_t)32 * n);               // n_u <= n start offsets
 	const uint64_t *u = rr.u + base;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_ro
 	const uint32_t n_u = rr.n_u[a], n_v = rr.n_v[a];
 	if (n_u == 0) { if (tid == 0) { rd.n_prev[r] = 0; rd.prev_off[r] = base; } return; }
 	const uint32_t n = (uint32_t)(rr.a_off[a + 1] - base);
-	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
+	unsigned char *wsr = rr.ws + base * rr.ws_stride;
 	uint32_t *dk = (uint32_t*)(wsr + (size_t)36 * n);                // destination offsets in sorted order
 	uint64_t *u2 = (uint64_t*)(wsr + (size_t)40 * n);
 	uint64_t *u = rr.u + base;
@@ -587,7 +587,7 @@ __global__ void k_regions_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, co
 	if (only_flagged && !rr.need_exact[a]) return;
 	const rh_mm128_t *an = rr.anc + base;
 	const uint64_t *u = rr.u + base;
-	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;           // 64 B per anchor >= 128 B per chain (min_cnt >= 2)
+	unsigned char *wsr = rr.ws + base * rr.ws_stride;           // 64 B per anchor >= 128 B per chain (min_cnt >= 2)
 	rh_reg *rg = (rh_reg*)wsr;
 	rh_chain_head *ch = (rh_chain_head*)(wsr + (size_t)64 * n_u);
 	rh_mm128_t *z = (rh_mm128_t*)(wsr + (size_t)96 * n_u);
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(NT) void k_regions_prep(rh_dev_opt o, rh_dev_reads 
 	const uint64_t base = rr.a_off[a];
 	const rh_mm128_t *an = rr.anc + base;
 	const uint64_t *u = rr.u + base;
-	rh_chain_head *heads = (rh_chain_head*)(rr.ws + base * RH_WS_PER_ANCHOR);
+	rh_chain_head *heads = (rh_chain_head*)(rr.ws + base * rr.ws_stride);
 	rh_mm128_t *z = rr.raw + base;
 	uint32_t hash = 0;
 	hash ^= rh_wang32(rd.ev_off[r] + rr.n_ev[a]) + rh_wang32(11u);
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 	if (!rr.need_exact[a]) return;                                   // done by k_regions_reg
 	const uint32_t r = rr.act[a];
 	const uint64_t base = rr.a_off[a];
-	const rh_chain_head *heads = (const rh_chain_head*)(rr.ws + base * RH_WS_PER_ANCHOR);
+	const rh_chain_head *heads = (const rh_chain_head*)(rr.ws + base * rr.ws_stride);
 	const rh_mm128_t *zs = rr.zs + base;                             // keys in radix_sort_128x order (ascending)
 	bool unfit = false;
 	KPROF_DECL;
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads r
 	if (!only_flagged && P < RGR_SLOTS && n_u > RGR_DIRECT) { if (lane == 0) rr.need_exact[a] = 1; return; }
 	const uint32_t r = rr.act[a];
 	const uint64_t base = rr.a_off[a];
-	const rh_chain_head *heads = (const rh_chain_head*)(rr.ws + base * RH_WS_PER_ANCHOR);
+	const rh_chain_head *heads = (const rh_chain_head*)(rr.ws + base * rr.ws_stride);
 	const rh_mm128_t *zs = rr.zs + base;                             // keys in radix_sort_128x order (ascending)
 	const bool hard = (o.flag & RH_M_HARD_MLEVEL) != 0;
 	int32_t pqs[P], pqe[P], psc[P], pcn[P], psub[P], pns[P];
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads
 	const uint32_t r = rr.act[a];
 	if (PCAP < RGB_PCAP) { const uint32_t prev = (uint32_t)rd.ls_ncregs[r]; if (prev + prev / 4u + 32u > (uint32_t)PCAP) return; }   // (need_exact stays set: a larger instance follows)
 	const uint64_t base = rr.a_off[a];
-	const rh_chain_head *heads = (const rh_chain_head*)(rr.ws + base * RH_WS_PER_ANCHOR);
+	const rh_chain_head *heads = (const rh_chain_head*)(rr.ws + base * rr.ws_stride);
 	const rh_mm128_t *zs = rr.zs + base;                             // keys in radix_sort_128x order (ascending)
 	const bool hard = (o.flag & RH_M_HARD_MLEVEL) != 0;
 	if (lane == 0) { L.kk = 0; L.lmax = 0; }
@@ -1268,6 +1268,20 @@ RH_DEV float dtw_banded(const float *a, uint32_t a_length, const float *b, uint3
 	if (excl) res -= dtw_dist(a[a_length - 1], b[b_length - 1]);
 	return res;
 }
+// one alignment of the "sparse" border constraint: the stretch between anchors `part` and `part + 1` of a chain (rmap.cpp:171-196).  *fits = false
+// (and nothing computed) when the DP does not fit `cap` floats of `dp`.
+RH_DEV float dtw_part(const rh_dev_opt &o, const rh_mm128_t *anchors, uint32_t part, uint32_t parts, const float *ref, const float *ev, float *dp, uint32_t cap, uint32_t *qlen_out, bool *fits)
+{
+	const rh_mm128_t sa = anchors[part], ea = anchors[part + 1];
+	const float *rv = ref + (uint32_t)sa.x; const uint32_t rlen = (uint32_t)ea.x - (uint32_t)sa.x + 1u;
+	const float *qv = ev + (uint32_t)sa.y; const uint32_t qlen = (uint32_t)ea.y - (uint32_t)sa.y + 1u;
+	const bool excl = part != parts - 1u;
+	*qlen_out = qlen; *fits = true;
+	float sub;
+	if (o.dtw_fill == 0u) { if (qlen > cap) { *fits = false; return 0.0f; } sub = dtw_full(qv, qlen, rv, rlen, excl, dp); }
+	else { int band = (int)((float)qlen * o.dtw_band_frac); if (band < 1) band = 1; sub = dtw_banded(qv, qlen, rv, rlen, band, excl, dp, cap); if (sub != sub) { *fits = false; return 0.0f; } }
+	return sub;
+}
 // align_chain rmap.cpp:128-208.  Returns the alignment score (-1e10: abandoned); *bad set if the DP buffers were too small.
 RH_DEV float dtw_align_chain(const rh_dev_opt &o, const rh_reg &c, const rh_mm128_t *anchors, const float *ref, const float *ev, float min_score, float *dp, uint32_t dp_cap, bool *bad)
 {
@@ -1314,11 +1328,24 @@ __global__ __launch_bounds__(NT) void k_events_append(rh_dev_reads rd, rh_dev_ro
 
 // one read per lane: regions up to mm_select_sub (the serial core on HBM scratch, as k_regions_big), then the alignment score of every kept
 // region in order (rmap.cpp:355-374).  Leaves rg[] in the read's scratch, rr.dtw_n[a] = regions kept (0x80000000 | .. on a buffer overflow)
-__global__ void k_regions_dtw(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh_dev_round rr)
+// One WAVEFRONT per read.  The region core (up to mm_select_sub) is lane 0's; the alignments of a region under the default "sparse" border
+// constraint - one small DP between every two consecutive anchors of the chain, independent of each other - are dealt to the 64 lanes, each
+// with DTW_LANE_CAP floats of LDS for its DP (a stretch that needs more is lane 0's afterwards, in the read's global buffer); lane 0 then adds
+// the costs up IN PART ORDER (fp32 sums are order dependent) and applies the reference's running early exit (rmap.cpp:176), so the score is the
+// serial one bit for bit.  (One lane per read, 64 reads of divergent control flow per wavefront: 886 reads/s on the E. coli-scale run against
+// 21 k for the CPU reference.)
+#ifndef DTW_LANE_CAP
+#define DTW_LANE_CAP 48
+#endif
+__global__ __launch_bounds__(64) void k_regions_dtw(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh_dev_round rr)
 {
-	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	__shared__ float s_dp[64 * DTW_LANE_CAP];
+	__shared__ float s_sub[64];
+	__shared__ uint32_t s_ql[64];
+	__shared__ int32_t s_n;
+	const uint32_t a = blockIdx.x, lane = threadIdx.x;
 	if (a >= rr.n_act) return;
-	rr.dtw_n[a] = 0;
+	if (lane == 0) rr.dtw_n[a] = 0;
 	if (rr.skip[a]) return;
 	const uint32_t r = rr.act[a];
 	const uint64_t base = rr.a_off[a];
@@ -1326,41 +1353,77 @@ __global__ void k_regions_dtw(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh
 	if (n_u == 0) return;
 	const rh_mm128_t *an = rr.anc + base;
 	const uint64_t *u = rr.u + base;
-	unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;           // 64 B per anchor >= 128 B per chain (min_cnt >= 2)
+	unsigned char *wsr = rr.ws + base * rr.ws_stride;           // 64 B per anchor >= 128 B per chain (min_cnt >= 2)
 	rh_reg *rg = (rh_reg*)wsr;
 	rh_chain_head *ch = (rh_chain_head*)(wsr + (size_t)64 * n_u);
 	rh_mm128_t *z = (rh_mm128_t*)(wsr + (size_t)96 * n_u);
 	uint64_t *cov = (uint64_t*)(wsr + (size_t)112 * n_u);
 	int32_t *w = (int32_t*)(wsr + (size_t)120 * n_u), *tmp = (int32_t*)(wsr + (size_t)124 * n_u);
 	uint32_t *cw = (uint32_t*)rg;
-	uint32_t k = 0;
-	for (int32_t i = 0; i < n_u; ++i) {
-		const uint32_t cnt = (uint32_t)u[i];
-		const rh_mm128_t f0 = rh_an_ld(rr, rr.anc, base + k), f1 = rh_an_ld(rr, rr.anc, base + k + cnt - 1);
-		rh_chain_head h; h.x0 = f0.x; h.y0 = f0.y; h.x1 = (int32_t)f1.x; h.y1 = (int32_t)f1.y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
-		ch[i] = h;
-		k += cnt;
+	if (lane == 0) {
+		uint32_t k = 0;
+		for (int32_t i = 0; i < n_u; ++i) {
+			const uint32_t cnt = (uint32_t)u[i];
+			const rh_mm128_t f0 = rh_an_ld(rr, rr.anc, base + k), f1 = rh_an_ld(rr, rr.anc, base + k + cnt - 1);
+			rh_chain_head h; h.x0 = f0.x; h.y0 = f0.y; h.x1 = (int32_t)f1.x; h.y1 = (int32_t)f1.y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
+			ch[i] = h;
+			k += cnt;
+		}
+		int stop;
+		s_n = regions_core(o, n_u, u, ch, rg, z, cov, w, tmp, cw, rr.rep_len[a], rr.n_ev[a], rd.ev_off[r], nullptr, &stop, true);
 	}
-	int stop;
-	const int32_t n_regs = regions_core(o, n_u, u, ch, rg, z, cov, w, tmp, cw, rr.rep_len[a], rr.n_ev[a], rd.ev_off[r], nullptr, &stop, true);
+	RH_WG_FENCE();
+	__syncthreads();
+	const int32_t n_regs = s_n;
 	// alignment scores go where the chain heads were (4 B per region; the heads are not needed any more)
 	float *ascore = (float*)ch;
 	const float *ev = rd.events + (size_t)r * rd.ev_stride;
 	float *dp = rr.dtw_ws + (size_t)a * rr.dtw_stride;
 	bool bad = false;
-	float best = 0.0f;
+	float best = 0.0f;                                               // (lane 0's; the other lanes never read it)
 	for (int32_t i = 0; i < n_regs; ++i) {
-		const rh_reg &c = rg[i];
+		const rh_reg c = rg[i];
 		const float *ref = ix.sig + ix.sig_off[2 * (size_t)c.rid + (c.rev ? 1u : 0u)];
-		float as = dtw_align_chain(o, c, an + c.as, ref, ev, best, dp, rr.dtw_stride, &bad);
-		if (as >= o.dtw_min_score) { if (as > best) best = as; }
-		else if (as < o.dtw_min_score && as < 0.0f) as = o.dtw_min_score > 0.0f ? 0.0f : o.dtw_min_score;
-		ascore[i] = as;
+		float as = 0.0f;
+		if (o.dtw_border == 0u) { if (lane == 0) as = dtw_align_chain(o, c, an + c.as, ref, ev, best, dp, rr.dtw_stride, &bad); }   // one alignment over the whole chain: serial
+		else {
+			const uint32_t parts = (uint32_t)c.cnt - 1u;
+			float cost = 0.0f, cur_max = (float)(uint32_t)(c.qe - c.qs + 1) * o.dtw_match_bonus;
+			uint32_t n_aligned = 0;
+			bool gone = false;
+			for (uint32_t p0 = 0; p0 < parts; p0 += 64) {             // (wave-uniform: `gone` is broadcast below)
+				const uint32_t part = p0 + lane;
+				if (part < parts) {
+					bool fits; uint32_t ql;
+					const float sub = dtw_part(o, an + c.as, part, parts, ref, ev, s_dp + (size_t)lane * DTW_LANE_CAP, (uint32_t)DTW_LANE_CAP, &ql, &fits);
+					s_sub[lane] = fits ? sub : __uint_as_float(0x7FC00000u); s_ql[lane] = ql;
+				}
+				__syncthreads();
+				if (lane == 0) {
+					const uint32_t m = parts - p0 < 64u ? parts - p0 : 64u;
+					for (uint32_t q = 0; q < m && !gone; ++q) {
+						if (cur_max < best) { gone = true; break; }           // rmap.cpp:176: the chain cannot beat the best alignment so far any more
+						float sub = s_sub[q];
+						if (sub != sub) { bool fits; uint32_t ql; sub = dtw_part(o, an + c.as, p0 + q, parts, ref, ev, dp, rr.dtw_stride, &ql, &fits); if (!fits) { bad = true; sub = 0.0f; } }
+						cost += sub; cur_max -= sub; n_aligned += s_ql[q];
+					}
+					s_n = gone ? -1 : n_regs;
+				}
+				__syncthreads();
+				if (s_n < 0) break;
+			}
+			if (lane == 0) { as = gone ? -1e10f : (float)n_aligned * o.dtw_match_bonus - cost; s_n = n_regs; }
+			__syncthreads();
+		}
+		if (lane == 0) {
+			if (as >= o.dtw_min_score) { if (as > best) best = as; }
+			else if (as < o.dtw_min_score && as < 0.0f) as = o.dtw_min_score > 0.0f ? 0.0f : o.dtw_min_score;
+			ascore[i] = as;
+		}
 	}
-	rr.dtw_n[a] = (uint32_t)n_regs | (bad ? 0x80000000u : 0u);
+	if (lane == 0) rr.dtw_n[a] = (uint32_t)n_regs | (bad ? 0x80000000u : 0u);
 }
 
-// per region what the host needs for mm_set_mapq (hit.c:502-539) and the decision (rmap.cpp:423-500): 8 floats / ints each, packed
 __global__ __launch_bounds__(NT) void k_dtw_pack(rh_dev_round rr)
 {
 	const uint32_t a = blockIdx.x;
@@ -1369,7 +1432,7 @@ __global__ __launch_bounds__(NT) void k_dtw_pack(rh_dev_round rr)
 	if (!n) return;
 	const uint64_t base = rr.a_off[a];
 	const int32_t n_u = (int32_t)rr.n_u[a];
-	const unsigned char *wsr = rr.ws + base * RH_WS_PER_ANCHOR;
+	const unsigned char *wsr = rr.ws + base * rr.ws_stride;
 	const rh_reg *rg = (const rh_reg*)wsr;
 	const float *ascore = (const float*)(wsr + (size_t)64 * n_u);
 	int32_t *out = (int32_t*)rr.dtw_rec + rr.dtw_off[a] * 8;
@@ -1389,7 +1452,7 @@ __global__ void k_dtw_commit(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
 	if (rr.skip[a]) { rd.ls_ncregs[r] = 0; return; }                // chunk dropped: creg stays NULL (rmap.cpp:232-235, :419)
 	const uint32_t n = rr.dtw_n[a] & 0x7FFFFFFFu;
 	if (!n) { regions_commit(o, rd, rr, a, r, 0, nullptr, 0); return; }
-	const rh_reg *rg = (const rh_reg*)(rr.ws + rr.a_off[a] * RH_WS_PER_ANCHOR);
+	const rh_reg *rg = (const rh_reg*)(rr.ws + rr.a_off[a] * rr.ws_stride);
 	rh_reg sel = rg[rr.dtw_dec[3 * (size_t)a]];
 	sel.mapq = (uint32_t)rr.dtw_dec[3 * (size_t)a + 1];
 	regions_commit(o, rd, rr, a, r, (int32_t)n, &sel, rr.dtw_dec[3 * (size_t)a + 2]);
@@ -1476,6 +1539,6 @@ void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, con
 }
 
 void rhk_events_append(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_append, r.n_act, NT, 0, s, rd, r); }
-void rhk_regions_dtw(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_regions_dtw, (r.n_act + 63) / 64, 64, 0, s, o, ix, rd, r); }
+void rhk_regions_dtw(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_regions_dtw, r.n_act, 64, 0, s, o, ix, rd, r); }
 void rhk_dtw_pack(hipStream_t s, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_dtw_pack, r.n_act, NT, 0, s, r); }
 void rhk_dtw_commit(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_dtw_commit, (r.n_act + 63) / 64, 64, 0, s, o, rd, r); }

@@ -43,6 +43,16 @@ CASES = [
     {"name": "small_fast_dtw_global", "env": {"RH_STORE_SIG": "1", "RH_DTW": "1", "RH_DTW_BORDER": "0"}, "workload": dict(preset="fast", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=96, junk=150, noise=150_000, read_seed=42, idxflag=0x10, mapopt={"flag": 0x40, "dtw_border_constraint": 0})},
     {"name": "small_sensitive_dtw_full", "env": {"RH_STORE_SIG": "1", "RH_DTW": "1", "RH_DTW_FILL": "0", "RH_DTW_MIN_SCORE": "5"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=96, junk=150, noise=150_000, read_seed=43, idxflag=0x10, mapopt={"flag": 0x40, "dtw_fill_method": 0, "dtw_min_score": 5.0})},
     {"name": "config3_dmel_144M_384", "gpu_only": True, "workload": dict(preset="sensitive", chrom_len=24_000_000, n_chrom=6, n_samples=40_000, n_reads=384, junk=102, noise=0, read_seed=3)},
+    # f4 at the configurations' index sizes: --rmq and --bw-long on the 144 Mbp / 6-target index of config 3 (30 k anchors per chunk), DTW re-scoring
+    # on the 4.6 Mbp index of config 1 (--store-sig)
+    {"name": "config3_dmel_144M_rmq", "gpu_only": True, "env": {"RH_RMQ": "1"}, "workload": dict(preset="sensitive", chrom_len=24_000_000, n_chrom=6, n_samples=40_000, n_reads=128, junk=102, noise=0, read_seed=5, mapopt={"flag": 2})},
+    {"name": "config3_dmel_144M_bw_long", "gpu_only": True, "env": {"RH_BW_LONG": "2000"}, "workload": dict(preset="sensitive", chrom_len=24_000_000, n_chrom=6, n_samples=40_000, n_reads=128, junk=102, noise=0, read_seed=6, mapopt={"bw_long": 2000})},
+    # option values beyond the device path's former limits: chunks of 8000 samples (the rows-in-HBM event kernels, a chunk at a time), 40 chunks
+    # of 1000 samples (more than 32 chunk boundaries per read), chains of a single anchor (--min-anchors 1: 128 B of region scratch per anchor)
+    {"name": "small_sensitive_chunk8000", "env": {"RH_CHUNK_SIZE": "8000"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=40_000, n_reads=96, junk=150, noise=150_000, read_seed=61, mapopt={"chunk_size": 8000})},
+    {"name": "small_sensitive_40chunks", "env": {"RH_CHUNK_SIZE": "1000", "RH_MAX_CHUNKS": "40"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=40_000, n_reads=96, junk=150, noise=150_000, read_seed=62, mapopt={"chunk_size": 1000, "max_num_chunk": 40})},
+    {"name": "small_sensitive_min_anchors1", "env": {"RH_MIN_ANCHORS": "1"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=96, junk=150, noise=150_000, read_seed=63, mapopt={"min_num_anchors": 1})},
+    {"name": "config1_ecoli_4p6M_dtw", "env": {"RH_STORE_SIG": "1", "RH_DTW": "1"}, "workload": dict(preset="sensitive", chrom_len=4_600_000, n_chrom=1, n_samples=40_000, n_reads=300, junk=102, noise=0, read_seed=7, idxflag=0x10, mapopt={"flag": 0x40})},
 ]
 
 
@@ -64,6 +74,8 @@ REPEAT_CASES = [
     {"name": "repeat_fast_2M", "workload": dict(preset="fast", n_chrom=2, chrom_len=1_000_000, n_reads=120, genome_seed=45, read_seed=47)},
     {"name": "repeat_faster_2M", "workload": dict(preset="faster", n_chrom=2, chrom_len=1_000_000, n_reads=120, genome_seed=55, read_seed=57)},   # minimisers (w = 3) over tandem repeats: equal minima
     {"name": "repeat_rich_52M", "gpu_only": True, "workload": dict(preset="sensitive", n_chrom=4, chrom_len=13_000_000, n_reads=200, genome_seed=51, read_seed=53)},
+    # f4 on repeat-rich input, chunks of more than 8192 anchors: RMQ chaining with ties everywhere
+    {"name": "repeat_rich_52M_rmq", "gpu_only": True, "env": {"RH_RMQ": "1"}, "workload": dict(preset="sensitive", n_chrom=4, chrom_len=13_000_000, n_reads=96, genome_seed=51, read_seed=59, mapopt={"flag": 2})},
 ]
 
 
@@ -103,8 +115,9 @@ def main():
         with tempfile.TemporaryDirectory() as d:
             w = RepeatWorkload(d, lib, **case["workload"])
             ref_ind = os.path.join(d, "refbuilt.ind")
-            subprocess.run([O.REF_HARNESS, "index", w.preset, w.fasta, w.model, ref_ind, "8"], check=True, stderr=subprocess.DEVNULL)
-            out = subprocess.run([O.REF_HARNESS, "map", w.preset, ref_ind, w.rhr, "8"], check=True, capture_output=True, text=True).stdout
+            env = dict(os.environ, **case.get("env", {}))
+            subprocess.run([O.REF_HARNESS, "index", w.preset, w.fasta, w.model, ref_ind, "8"], check=True, stderr=subprocess.DEVNULL, env=env)
+            out = subprocess.run([O.REF_HARNESS, "map", w.preset, ref_ind, w.rhr, "8"], check=True, capture_output=True, text=True, env=env).stdout
             lines = [O.strip_mt(l) for l in out.splitlines()]
             assert len(lines) == len(w.reads)
             with open(os.path.join(HERE, case["name"] + ".paf"), "w") as f:

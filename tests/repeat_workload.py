@@ -103,7 +103,7 @@ def simulate_reads(chroms, levels, seed=43, n_reads=200, n_samples=40_000, digit
 class RepeatWorkload:
     """Directory with the repeat-rich FASTA, the pore model and the simulated reads (+ .rhr file for the reference harness)."""
 
-    def __init__(self, directory, lib, preset="sensitive", n_chrom=4, chrom_len=13_000_000, n_reads=200, genome_seed=41, read_seed=43):
+    def __init__(self, directory, lib, preset="sensitive", n_chrom=4, chrom_len=13_000_000, n_reads=200, genome_seed=41, read_seed=43, mapopt=None):
         from rawhash_amd.api import SynthWorkload, MapOptions
         self.dir, self.preset = str(directory), preset
         os.makedirs(self.dir, exist_ok=True)
@@ -117,4 +117,9 @@ class RepeatWorkload:
         self.rhr = os.path.join(self.dir, "reads.rhr")
         self.reads.write(self.rhr, cfg.digitisation, cfg.range, cfg.offset)
         self.opts = MapOptions(preset, lib=lib)
+        for k, v in dict(mapopt or {}).items():     # rh_mapopt_t fields on top of the preset ("flag" is OR-ed in): --rmq, --bw-long
+            if k == "flag":
+                self.opts.mo.flag |= v
+            else:
+                setattr(self.opts.mo, k, v)
         self.index = None
