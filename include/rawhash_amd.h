@@ -248,9 +248,14 @@ RH_API int  rh_chain_batch(rh_ctx *ctx, const rh_mapopt_t *mo, uint32_t n_reads,
                            rh_mm128_t *prev_out /* the *_a copy = next chunk's prev_anchors, may be NULL */);
 /* mm_gen_regs + mm_set_parent + mm_select_sub + mm_set_mapq (hit.c:100-367, 502-539) on top of rh_chain_batch's chains, as ri_map_frag
    runs them (rmap.cpp:346-377); qlen[r] = reg->offset + n_events seeds the region hash.  summary: 10 int32 per read =
-   {n_cregs, cnt, score, mapq, qs, qe, rs, re, rid, rev} of creg[0] (what the mapping decision and the record are built from) */
+   {n_cregs, cnt, score, mapq, qs, qe, rs, re, rid, rev} of creg[0] (what the mapping decision and the record are built from).
+   regs (may be NULL; then regs_cap / reg_offsets are ignored): EVERY kept region of every read, 18 int32 each in the order of the reference's
+   mm_reg1_t dump {id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0, mapq, rev, hash} (chain.h:27-44; `as` relative to the
+   read's chained anchors), read r's regions at reg_offsets[r] .. reg_offsets[r + 1].  Of mo->flag the stage honours RH_M_RMQ, RH_M_ALL_CHAINS
+   (mm_select_sub skipped, rmap.cpp:353) and RH_M_HARD_MLEVEL; mo->best_n > 0 keeps secondaries (hit.c:338-367). */
 RH_API int  rh_regions_batch(rh_ctx *ctx, const rh_mapopt_t *mo, uint32_t n_reads, const rh_mm128_t *anchors, const uint64_t *anchor_offsets,
-                             const int32_t *rep_len, const uint32_t *qlen, int32_t *summary);
+                             const int32_t *rep_len, const uint32_t *qlen, int32_t *summary,
+                             int32_t *regs, uint64_t regs_cap, uint64_t *reg_offsets);
 /* radix_sort_128x ksort.h:101-151 (exact, unstable permutation) on independent segments */
 RH_API int  rh_sort128x_batch(rh_ctx *ctx, uint32_t n_seg, rh_mm128_t *a, const uint64_t *offsets);
 /* the same sort the way the region keys of mm_gen_regs (hit.c:111-126: score << 32 | count ^ 32-bit hash, practically never equal) take

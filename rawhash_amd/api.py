@@ -391,16 +391,23 @@ class Context:
         _check(self._l.rh_chain_batch(self.h, C.byref(opts.mo), n, ptr(an), ptr(ao), ptr(ch), cap, ptr(co), ptr(u), cap, ptr(uo), ptr(pv)), self._l)
         return ch[: int(co[n])], co, u[: int(uo[n])], uo, pv[: int(co[n])]
 
-    def regions(self, opts, anchors, a_off, rep_len, qlen):
-        """Chains of sorted anchors -> regions: (n, 10) int32 = n_cregs, cnt, score, mapq, qs, qe, rs, re, rid, rev of creg[0]."""
+    def regions(self, opts, anchors, a_off, rep_len, qlen, all_regions=False):
+        """Chains of sorted anchors -> regions: (n, 10) int32 = n_cregs, cnt, score, mapq, qs, qe, rs, re, rid, rev of creg[0];
+        all_regions: also every kept region, (k, 18) int32 in the reference's field order, and their (n + 1) offsets."""
         n = len(a_off) - 1
         an = np.ascontiguousarray(anchors, dtype=MM128)
         ao = np.ascontiguousarray(a_off, dtype=np.uint64)
         rl = np.ascontiguousarray(rep_len, dtype=np.int32)
         ql = np.ascontiguousarray(qlen, dtype=np.uint32)
         out = np.zeros((max(n, 1), 10), dtype=np.int32)
-        _check(self._l.rh_regions_batch(self.h, C.byref(opts.mo), n, ptr(an), ptr(ao), ptr(rl), ptr(ql), ptr(out)), self._l)
-        return out[:n]
+        if not all_regions:
+            _check(self._l.rh_regions_batch(self.h, C.byref(opts.mo), n, ptr(an), ptr(ao), ptr(rl), ptr(ql), ptr(out), None, 0, None), self._l)
+            return out[:n]
+        cap = max(len(an), 1)
+        regs = np.zeros((cap, 18), dtype=np.int32)
+        ro = np.zeros(n + 1, dtype=np.uint64)
+        _check(self._l.rh_regions_batch(self.h, C.byref(opts.mo), n, ptr(an), ptr(ao), ptr(rl), ptr(ql), ptr(out), ptr(regs), cap, ptr(ro)), self._l)
+        return out[:n], regs[: int(ro[n])], ro
 
     def sort128x(self, arr, offsets):
         a = np.ascontiguousarray(arr, dtype=MM128).copy()

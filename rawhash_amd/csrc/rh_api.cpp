@@ -1576,7 +1576,8 @@ extern "C" int rh_chain_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, cons
 }
 
 extern "C" int rh_regions_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, const rh_mm128_t *anchors, const uint64_t *anchor_offsets,
-                                const int32_t *rep_len, const uint32_t *qlen, int32_t *summary /* R x 10 */)
+                                const int32_t *rep_len, const uint32_t *qlen, int32_t *summary /* R x 10 */,
+                                int32_t *regs /* 18 per kept region, may be NULL */, uint64_t regs_cap, uint64_t *reg_offsets /* R + 1 */)
 {
 	// chain -> backtrack -> compact (as rh_chain_batch) and then the region stage of a round: keys + sort (hit.c:111-126), parents,
 	// secondaries dropped, MAPQ (hit.c:195-367, 502-539); summary[r] = {n_cregs, cnt, score, mapq, qs, qe, rs, re, rid, rev} of region 0
@@ -1585,6 +1586,7 @@ extern "C" int rh_regions_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, co
 	rh_mapopt_t m2 = *mo; m2.flag = mo->flag & RH_M_RMQ;   // (the chaining variant stays: --rmq / --bw-long at stage level)
 	rh_dev_opt o;
 	if (fill_dev_opt(c, &m2, &o)) return -1;
+	o.flag |= mo->flag & (RH_M_ALL_CHAINS | RH_M_HARD_MLEVEL);   // region-stage switches: mm_select_sub skipped (rmap.cpp:353), hit.c:136's hard mask level
 	rh_dev_reads rd;
 	if (stage_state_only(c, R, &rd)) return -1;
 	rh_dev_round rr{};
@@ -1601,6 +1603,9 @@ extern "C" int rh_regions_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, co
 	hipStream_t s = c->stream;
 	if (chain_stages(c, s, o, rd, rr, false)) return -1;
 	if (rhk_regions_sort(s, o, rd, rr)) return -1;
+	DevBuf reg_all;                                                  // every kept region, where the kernels leave it: read r's k-th at (anchor_offsets[r] + k) * 18
+	struct Rel { DevBuf &b; ~Rel() { b.release(); } } rel{reg_all};
+	if (regs) { if (reg_all.ensure((size_t)(total ? total : 1) * 18 * 4, false)) return -1; rr.reg_out = reg_all.as<int32_t>(); }
 	rhk_regions(s, o, rd, rr, c->logf_tab.as<float>());
 	RH_HIP(hipStreamSynchronize(s));
 	RH_HIP(hipGetLastError());
@@ -1608,6 +1613,19 @@ extern "C" int rh_regions_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, co
 	const int32_t *src[10] = { rd.ls_ncregs, rd.ls_cnt, rd.ls_score, rd.ls_mapq, rd.ls_qs, rd.ls_qe, rd.ls_rs, rd.ls_re, rd.ls_rid, rd.ls_rev };
 	for (int k = 0; k < 10; ++k) if (d2h(f[k], src[k], R)) return -1;
 	for (uint32_t r = 0; r < R; ++r) for (int k = 0; k < 10; ++k) summary[(size_t)r * 10 + k] = f[k][r];
+	if (regs) {
+		std::vector<int32_t> all;
+		if (d2h(all, reg_all.as<int32_t>(), (size_t)total * 18)) return -1;
+		uint64_t n = 0;
+		for (uint32_t r = 0; r < R; ++r) {
+			reg_offsets[r] = n;
+			const uint64_t k = (uint64_t)(f[0][r] > 0 ? f[0][r] : 0);
+			if (n + k > regs_cap) { rh_set_error("rh_regions_batch: more than %llu kept regions", (unsigned long long)regs_cap); return -1; }
+			if (k) memcpy(regs + n * 18, all.data() + anchor_offsets[r] * 18, (size_t)k * 18 * 4);
+			n += k;
+		}
+		reg_offsets[R] = n;
+	}
 	return 0;
 }
 

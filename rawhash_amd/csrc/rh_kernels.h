@@ -135,6 +135,7 @@ struct rh_dev_round {
 	//   cfmt  chain-order keys  key' << shift | chain;   z8  candidates  score << 32 | anchor
 	rh_rec_fmt afmt, cfmt; uint8_t aq_bits, z8, a_span;
 	uint64_t arena_n;                // anchors the 16-byte-per-anchor arenas (raw, anc, zs, prev_out) hold
+	int32_t *reg_out;                // stage-level call only (rh_regions_batch): 18 int32 per kept region, region k of active read a at (a_off[a] + k) * 18; null on the mapping path
 };
 
 // anchor i of an anchor array of the round (rr.anc, rr.prev_in, rr.prev_out: absolute element index), whichever way the round keeps them

@@ -331,6 +331,40 @@ struct rh_reg {
 };
 struct rh_chain_head { uint64_t x0, y0; int32_t x1, y1, cnt, k; };   // first anchor, low words of the last anchor
 
+// Stage-level export of kept region k of a read (rh_regions_batch; rr.reg_out is null on the mapping path, which needs creg[0], the count and two sums only):
+// the reference's region record in the field order of its dump, {id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0, mapq, rev, hash};
+// mlen / blen (mm_cal_fuzzy_len hit.c:10-29) are read by nothing on the path and are therefore computed here, from the chain's anchors
+RH_DEV void reg_export(const rh_dev_round &rr, uint64_t base, int32_t k, const rh_reg &q)
+{
+	int32_t mlen = 0, blen = 0;
+	if (q.cnt > 0) {
+		rh_mm128_t p = rh_an_ld(rr, rr.anc, base + (uint32_t)q.as);
+		mlen = blen = (int32_t)((p.y >> 32) & 63u);
+		for (int32_t i = 1; i < q.cnt; ++i) {
+			const rh_mm128_t c = rh_an_ld(rr, rr.anc, base + (uint32_t)q.as + (uint32_t)i);
+			const int32_t span = (int32_t)((c.y >> 32) & 63u), tl = (int32_t)c.x - (int32_t)p.x, ql = (int32_t)c.y - (int32_t)p.y;
+			blen += tl > ql ? tl : ql;
+			mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
+			mlen += tl < ql ? tl : ql;
+			p = c;
+		}
+	}
+	int32_t *w = rr.reg_out + (base + (uint64_t)(uint32_t)k) * 18u;
+	w[0] = q.id; w[1] = q.cnt; w[2] = q.rid; w[3] = q.score; w[4] = q.qs; w[5] = q.qe; w[6] = q.rs; w[7] = q.re; w[8] = q.parent; w[9] = q.subsc;
+	w[10] = q.as; w[11] = mlen; w[12] = blen; w[13] = q.n_sub; w[14] = q.score0; w[15] = (int32_t)q.mapq; w[16] = (int32_t)q.rev; w[17] = (int32_t)q.hash;
+}
+// ... of a primary of the kernels that keep primaries only (best_n = 0): sorted region `i` (descending score) that became kept region k
+RH_DEV void reg_export_primary(const rh_dev_round &rr, uint64_t base, int32_t n_u, int32_t k, int32_t i, int32_t subsc, int32_t n_sub, int32_t mapq)
+{
+	const rh_mm128_t zi = (rr.zs + base)[n_u - 1 - i];
+	const rh_chain_head h = ((const rh_chain_head*)(rr.ws + base * rr.ws_stride))[(uint32_t)zi.y];
+	rh_reg q;
+	q.id = k; q.parent = k; q.cnt = h.cnt; q.as = h.k; q.score = q.score0 = (int32_t)(zi.x >> 32); q.hash = (uint32_t)zi.x;
+	q.rev = (uint32_t)(h.x0 >> 63); q.rid = (int32_t)(h.x0 << 1 >> 33); q.rs = (int32_t)h.x0; q.re = h.x1 + 1; q.qs = (int32_t)h.y0; q.qe = h.y1 + 1;
+	q.subsc = subsc; q.n_sub = n_sub; q.mapq = (uint32_t)mapq;
+	reg_export(rr, base, k, q);
+}
+
 RH_DEV float logf_int(int32_t v, const float *tab) { return (v >= 0 && (uint32_t)v < RH_LOGF_N) ? tab[v] : logf((float)v); }
 
 // hit.c:312-336
@@ -571,6 +605,7 @@ __global__ __launch_bounds__(64) void k_regions(rh_dev_opt o, rh_dev_reads rd, r
 		int stop;
 		const int32_t n_regs = regions_core(o, n_u, L.u, L.ch, L.rg, L.z, L.cov, L.w, L.tmp, L.cw, rr.rep_len[a], rr.n_ev[a], rd.ev_off[r], logf_tab, &stop);
 		regions_commit(o, rd, rr, a, r, n_regs, &L.rg[0], (o.flag & RH_M_ALL_CHAINS) ? 0 : stop);
+		if (rr.reg_out) for (int32_t i = 0; i < n_regs; ++i) reg_export(rr, base, i, L.rg[i]);
 		if (o.flag & RH_M_ALL_CHAINS) regions_commit_ava(o, rd, rr, a, r, n_regs, L.rg);
 	}
 }
@@ -605,6 +640,7 @@ __global__ void k_regions_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, co
 	int stop;
 	const int32_t n_regs = regions_core(o, n_u, u, ch, rg, z, cov, w, tmp, cw, rr.rep_len[a], rr.n_ev[a], rd.ev_off[r], logf_tab, &stop);
 	regions_commit(o, rd, rr, a, r, n_regs, &rg[0], (o.flag & RH_M_ALL_CHAINS) ? 0 : stop);
+	if (rr.reg_out) for (int32_t i = 0; i < n_regs; ++i) reg_export(rr, base, i, rg[i]);
 	if (o.flag & RH_M_ALL_CHAINS) regions_commit_ava(o, rd, rr, a, r, n_regs, rg);
 }
 
@@ -776,6 +812,7 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 			mq -= (int32_t)(4.343f * logf_int(L.pns[k] + 1, logf_tab) + .499f);
 			mq = mq > 0 ? mq : 0;
 			mq = mq < 60 ? mq : 60;
+			if (rr.reg_out) reg_export_primary(rr, base, n_u, k, (int32_t)L.w[k], L.psub[k], L.pns[k], mq);
 		}
 		if (k0 == 0) mapq0 = __shfl(mq, 0);
 		int32_t v = mq;
@@ -935,6 +972,7 @@ __global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads r
 					if ((uint32_t)sel == (uint32_t)p * 64u + lane) { if (psub[p] < sci) psub[p] = sci; if (cni >= pcn[p]) ++pns[p]; }
 			} else {
 				if (kk >= PRIM_CAP) { overflow = true; break; }
+				if (rr.reg_out && lane == 0) rr.reg_out[(base + kk) * 18u] = i0 + (int32_t)t;   // (stage-level export: which sorted region the primary is)
 #pragma unroll
 				for (int p = 0; p < P; ++p)
 					if (kk == (uint32_t)p * 64u + lane) { pqs[p] = si; pqe[p] = ei; psc[p] = sci; pcn[p] = cni; psub[p] = 0; pns[p] = 0; }
@@ -965,6 +1003,7 @@ __global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads r
 			mq -= (int32_t)(4.343f * logf_int(pns[p] + 1, logf_tab) + .499f);
 			mq = mq > 0 ? mq : 0;
 			mq = mq < 60 ? mq : 60;
+			if (rr.reg_out) { __threadfence_block(); const int32_t k = p * 64 + (int32_t)lane; reg_export_primary(rr, base, n_u, k, rr.reg_out[(base + (uint32_t)k) * 18u], psub[p], pns[p], mq); }
 		}
 		if (p == 0) mapq0 = (int32_t)rh_readlane((uint32_t)mq, 0);
 		int32_t v = mq;
@@ -1118,6 +1157,7 @@ __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads
 					L.sqs[below] = fs; L.sqe[below] = fe; L.sid[below] = (uint16_t)kk;
 					if (fe - fs > L.lmax) L.lmax = fe - fs;
 					L.pqs[kk] = fs; L.pqe[kk] = fe; L.psc[kk] = (uint32_t)fsc; L.pcn[kk] = (uint32_t)fcn; L.psub[kk] = 0; L.pns[kk] = 0;
+					if (rr.reg_out) rr.reg_out[(base + kk) * 18u] = i0 + (int32_t)f;   // (stage-level export: which sorted region the primary is)
 					L.kk = kk + 1;
 				}
 				if (lane == f) pending = false;
@@ -1147,6 +1187,7 @@ __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads
 			mq -= (int32_t)(4.343f * logf_int((int32_t)L.pns[k] + 1, logf_tab) + .499f);
 			mq = mq > 0 ? mq : 0;
 			mq = mq < 60 ? mq : 60;
+			if (rr.reg_out) { __threadfence_block(); reg_export_primary(rr, base, n_u, k, rr.reg_out[(base + (uint32_t)k) * 18u], (int32_t)L.psub[k], (int32_t)L.pns[k], mq); }
 		}
 		if (k0 == 0) mapq0 = __shfl(mq, 0);
 		int32_t v = mq;

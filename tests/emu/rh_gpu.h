@@ -37,6 +37,7 @@ unsigned long long emu_shfl_down_bits(unsigned long long bits, unsigned delta);
 unsigned long long emu_shfl_bits(unsigned long long bits, int op, unsigned par);   // op: 2 down, 3 up, 4 xor, 5 idx
 #define __syncthreads() emu_syncthreads()
 static inline void __threadfence() {}
+static inline void __threadfence_block() {}
 #define RH_WG_FENCE() ((void)0)
 #define __ballot(p) emu_ballot((p) ? 1 : 0)
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

@@ -194,9 +194,14 @@ def check_chain_synthetic(ctx, wl, seed=0, n_reads=64, max_n=700):
     return len(an), len(och), len(ou)
 
 
-def oracle_regions(wl, ch, co, u, uo, rep_len, qlen):
-    """hit.c:100-367, 502-539 on the oracle's chains: (regs (k, 18) int32, offsets)."""
+def oracle_regions(wl, ch, co, u, uo, rep_len, qlen, variant=None):
+    """hit.c:100-367, 502-539 on the oracle's chains: (regs (k, 18) int32, offsets).  variant: map options to override ("flag" is OR-ed in)."""
     _, mo = wl.oracle()
+    for k, v in (variant or {}).items():
+        if k == "flag":
+            mo.flag |= v
+        else:
+            setattr(mo, k, v)
     n = len(co) - 1
     cap = len(u) + 16
     regs = np.zeros((cap, 18), dtype=np.int32)
@@ -207,10 +212,18 @@ def oracle_regions(wl, ch, co, u, uo, rep_len, qlen):
     return regs[: int(ro[n])], ro
 
 
+REG_FIELDS = ("id", "cnt", "rid", "score", "qs", "qe", "rs", "re", "parent", "subsc", "as", "mlen", "blen", "n_sub", "score0", "mapq", "rev", "hash")
+# region-stage variants: the default selection (secondaries dropped: the primaries-only kernels), secondaries kept (best_n > 0: the serial
+# core's mm_select_sub + mm_sync_regs), all-vs-all (mm_select_sub skipped, rmap.cpp:353), the hard mask level of mm_set_parent (hit.c:136)
+REG_VARIANTS = ({}, {"best_n": 5}, {"flag": 0x2000}, {"flag": 0x4}, {"best_n": 2, "pri_ratio": 0.8})
+
+
 def check_regions(ctx, wl, seed=0, n_reads=64, max_n=700):
     """a17-a19 at stage level: region keys + exact sort (mm_gen_regs), parents / secondaries (mm_set_parent, mm_select_sub) and
     MAPQ (mm_set_mapq) of the device against the oracle, on the chunk-0 anchors of the workload's reads and on the adversarial
-    anchor sets (hundreds of chains per read, many equal scores): n_cregs and every field of creg[0] the record is built from."""
+    anchor sets (hundreds of chains per read, many equal scores): n_cregs, the summary of creg[0] the record is built from, and
+    ALL 18 FIELDS OF EVERY KEPT REGION (the order of the reference's mm_reg1_t dump), under every variant of REG_VARIANTS."""
+    import copy
     ev, eoff = oracle_events(wl, 0)
     osd, oso = oracle_seeds(wl, ev, eoff)
     n = len(oso) - 1
@@ -219,20 +232,35 @@ def check_regions(ctx, wl, seed=0, n_reads=64, max_n=700):
     san, sao = synthetic_anchor_sets(seed, n_reads, max_n)
     rng = np.random.default_rng(seed + 1)
     sets.append((san, sao, rng.integers(0, 400, size=len(sao) - 1).astype(np.int32), rng.integers(100, 3000, size=len(sao) - 1).astype(np.uint32)))
-    checked = with_regs = 0
+    checked = with_regs = n_regions = 0
     for an, ao, rep, qlen in sets:
         och, oco, ou, ouo, _ = oracle_chains(wl, an, ao)
-        regs, ro = oracle_regions(wl, och, oco, ou, ouo, rep, qlen)
-        got = ctx.regions(wl.opts, an, ao, rep, qlen)
-        for r in range(len(ao) - 1):
-            k0, k1 = int(ro[r]), int(ro[r + 1])
-            assert got[r, 0] == k1 - k0, f"read {r}: n_cregs {got[r, 0]} != {k1 - k0}"
-            if k1 > k0:
-                q = regs[k0]     # id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0, mapq, rev, hash
-                want = [q[1], q[3], q[15], q[4], q[5], q[6], q[7], q[2], q[16]]
-                assert list(got[r, 1:]) == [int(v) for v in want], f"read {r}: creg[0] {list(got[r, 1:])} != {want}"
-                with_regs += 1
-            checked += 1
+        for variant in REG_VARIANTS:
+            regs, ro = oracle_regions(wl, och, oco, ou, ouo, rep, qlen, variant)
+            opts = copy.copy(wl.opts)
+            opts.mo = type(wl.opts.mo).from_buffer_copy(wl.opts.mo)
+            for k, v in variant.items():
+                if k == "flag":
+                    opts.mo.flag |= v
+                else:
+                    setattr(opts.mo, k, v)
+            got, gregs, gro = ctx.regions(opts, an, ao, rep, qlen, all_regions=True)
+            for r in range(len(ao) - 1):
+                k0, k1 = int(ro[r]), int(ro[r + 1])
+                assert got[r, 0] == k1 - k0, f"{variant} read {r}: n_cregs {got[r, 0]} != {k1 - k0}"
+                assert int(gro[r + 1]) - int(gro[r]) == k1 - k0
+                if k1 > k0:
+                    q = regs[k0]     # id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0, mapq, rev, hash
+                    want = [q[1], q[3], q[15], q[4], q[5], q[6], q[7], q[2], q[16]]
+                    assert list(got[r, 1:]) == [int(v) for v in want], f"{variant} read {r}: creg[0] {list(got[r, 1:])} != {want}"
+                    g = gregs[int(gro[r]): int(gro[r + 1])]
+                    if not np.array_equal(g, regs[k0:k1]):
+                        bad = np.argwhere(g != regs[k0:k1])[0]
+                        raise AssertionError(f"{variant} read {r}: region {bad[0]} of {k1 - k0}, field {REG_FIELDS[bad[1]]}: device {g[bad[0]].tolist()} != oracle {regs[k0 + bad[0]].tolist()}")
+                    with_regs += 1
+                    n_regions += k1 - k0
+                checked += 1
+    assert n_regions > with_regs, "no read with more than one kept region: the per-region comparison did not see a secondary or a second primary"
     return checked, with_regs
 
 
