@@ -188,7 +188,7 @@ def main():
     # each sub-batch its slice on its own stream (the upload of one overlaps the kernels of the others).  Reported next to
     # `value`, never instead of it.  (RH_BENCH_IN_FLIGHT=2 keeps two steps in flight with rh_map_submit / rh_map_wait, what
     # kt_pipeline does in the reference; on one GPU it halves each batch's arena share and measured slower, see DESIGN.md.)
-    elapsed_h2d = None
+    elapsed_h2d = elapsed_full = None
     if args.h2d:
         host = host_copy(ctx, batch, args)
         sync()
@@ -205,14 +205,24 @@ def main():
             recs_h = ctx.map_wait(pending.pop(0))
         sync()
         elapsed_h2d = time.perf_counter() - t0
-        assert (recs_h["mapped"] == recs["mapped"]).all()
+        assert (recs_h["mapped"] == recs["mapped"]).all() and (recs_h["tag_sl"] == recs["tag_sl"]).all()
+        # ... and without the reader's counts: the whole int16 batch is uploaded before the rounds start (a few steps, for the record)
+        n_full = min(args.steps, 3)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n_full):
+            recs_f = ctx.map_batch(opts, host["batch_full_upload"])
+        sync()
+        elapsed_full = (time.perf_counter() - t0) / n_full
+        assert (recs_f["mapped"] == recs["mapped"]).all()
         ctx._l.rh_pinned_free(host["pin"])
     if world > 1:
         import torch
-        t = torch.tensor([elapsed, elapsed_h2d or 0.0], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed, elapsed_h2d or 0.0, elapsed_full or 0.0], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0].item())
         elapsed_h2d = float(t[1].item()) or None
+        elapsed_full = float(t[2].item()) or None
 
     if rank == 0:
         acc["n_samples_raw"] = args.reads * args.samples * args.steps
@@ -234,6 +244,9 @@ def main():
                        "reads_per_gpu": args.reads, "samples_per_read": args.samples, "mid_occ": int(opts.mo.mid_occ), "parallelism": f"reads sharded x{world}, index replicated"},
             "value_h2d_included": None if not elapsed_h2d else round(total_reads / elapsed_h2d, 1),
             "ms_per_step_h2d_included": None if not elapsed_h2d else round(1e3 * elapsed_h2d / args.steps, 3),
+            "value_h2d_full_upload": None if not elapsed_full else round(args.reads * world / elapsed_full, 1),
+            "h2d_note": "value_h2d_included: batch in page-locked host memory with the reader's per-read filtered counts (rh_read_batch_t.n_filtered), the device fetches "
+                        "the stretches of signal the rounds consume; value_h2d_full_upload: no counts, the whole int16 batch is uploaded first",
             "gsamples_per_s_consumed": round(acc["n_samples_used"] * world / elapsed / 1e9, 4),
             "gsamples_per_s_input": round(args.reads * args.samples * world * args.steps / elapsed / 1e9, 4),
             "mapped_fraction": round(n_mapped / args.reads, 4),
@@ -436,7 +449,12 @@ def host_copy(ctx, batch, args):
     if l.rh_read_batch_to_host(ctx.h, C.byref(batch), pin + offs[0], pin + offs[1], pin + offs[2], pin + offs[3]) != 0:
         raise RuntimeError(_capi.last_error(l))
     b = _capi.ReadBatch(n, pin + offs[0], pin + offs[1], pin + offs[2], pin + offs[3], None, 0)
-    return {"pin": pin, "batch": b}
+    # what a reader knows when it has decoded a read (ri_read_sig's l_sig, rsig.c:496-503; rh_reads_* count while they stage): with it the
+    # device fetches only the stretches of signal the rounds consume.  Counted here, outside the timed region, like the file loading of the CPU baseline.
+    nf = _capi.count_filtered(b, lib=l)
+    b_counted = _capi.ReadBatch(n, pin + offs[0], pin + offs[1], pin + offs[2], pin + offs[3], None, 0, 0, nf.ctypes.data)
+    b_counted._keep = nf
+    return {"pin": pin, "batch": b_counted, "batch_full_upload": b}
 
 
 def pmc_traffic(stage, args, launches_per_step):

@@ -108,6 +108,13 @@ typedef struct rh_read_batch_s {
 	                                     (raw + (float)cal_offset) * cal_scale is float arithmetic, and a sample that passes the
 	                                     30 < pA < 200 test is truncated to int16 before it becomes the float signal.  0: the
 	                                     SLOW5 / POD5 readers (rsig.c:452, :497: double offset, no truncation) */
+	const uint32_t *n_filtered;       /* optional (host array, NULL = not known): per read, how many samples pass the reader's 30 < pA < 200 filter -
+	                                     what ri_read_sig leaves as l_sig (rsig.c:496-503) and the sl:i tag prints.  A reader that counts while it
+	                                     decodes (rh_reads_batch does; rh_count_filtered for other sources) lets the device FETCH ONLY THE SIGNAL THE
+	                                     ROUNDS CONSUME when samples[] is page-locked (rh_pinned_alloc, rh_reads_*): a read that maps stops after
+	                                     one or two chunks (rmap.cpp:425/498), the rest of its signal never crosses PCIe.  Values that are not the
+	                                     true counts fail the call loudly where the device sees the whole read.  Like every per-read array it has to
+	                                     be offset together with `offsets` when a caller slices a batch by hand. */
 } rh_read_batch_t;
 
 typedef struct rh_index_s rh_index;  /* host-side parsed .ind (flattened) */
@@ -285,6 +292,9 @@ RH_API uint32_t  rh_reads_n(const rh_reads *r);
 RH_API const char *rh_reads_name(const rh_reads *r, uint32_t i);
 RH_API int       rh_reads_batch(const rh_reads *r, rh_read_batch_t *out);   /* views into r; valid until destroy */
 RH_API int       rh_reads_pinned(const rh_reads *r);                          /* 1: the samples sit in page-locked memory (uploads at PCIe speed, no staging copy) */
+/* the reader's pA filter as a count (rsig.c:496-503; FAST5 arithmetic rsig.c:363-374 with in->fast5_ingest): out[r] = l_sig of read r of a HOST
+   batch - what rh_read_batch_t::n_filtered wants - for callers whose own reader does not count.  n_threads <= 0: up to 32 host threads */
+RH_API int       rh_count_filtered(const rh_read_batch_t *in, uint32_t *out, int n_threads);
 RH_API int       rh_reads_write(const char *path, uint32_t n, const char *const *names, const int16_t *samples,
                                 const uint64_t *offsets, double digitisation, double range, double offset);
 RH_API int       rh_reads_write_blow5(const char *path, uint32_t n, const char *const *names, const int16_t *samples, const uint64_t *offsets,

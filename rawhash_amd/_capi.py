@@ -74,6 +74,7 @@ class ReadBatch(C.Structure):
         ("name_rank", C.c_void_p),
         ("samples_on_device", C.c_int),
         ("fast5_ingest", C.c_int),
+        ("n_filtered", C.c_void_p),
     ]
 
 
@@ -101,7 +102,7 @@ def ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def make_batch(samples, offsets, cal_offset=None, cal_scale=None, name_rank=None, keep=None, fast5=False):
+def make_batch(samples, offsets, cal_offset=None, cal_scale=None, name_rank=None, keep=None, fast5=False, n_filtered=None):
     """Build a ReadBatch view over numpy arrays; the arrays are returned too so callers keep them alive."""
     samples = np.ascontiguousarray(samples, dtype=np.int16)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -109,9 +110,19 @@ def make_batch(samples, offsets, cal_offset=None, cal_scale=None, name_rank=None
     co = None if cal_offset is None else np.ascontiguousarray(cal_offset, dtype=np.float64)
     cs = None if cal_scale is None else np.ascontiguousarray(cal_scale, dtype=np.float32)
     nr = None if name_rank is None else np.ascontiguousarray(name_rank, dtype=np.uint32)
-    b = ReadBatch(n, ptr(samples), ptr(offsets), ptr(co), ptr(cs), ptr(nr), 0, 1 if fast5 else 0)
-    b._keep = (samples, offsets, co, cs, nr)
+    nf = None if n_filtered is None else np.ascontiguousarray(n_filtered, dtype=np.uint32)
+    b = ReadBatch(n, ptr(samples), ptr(offsets), ptr(co), ptr(cs), ptr(nr), 0, 1 if fast5 else 0, ptr(nf))
+    b._keep = (samples, offsets, co, cs, nr, nf)
     return b
+
+
+def count_filtered(batch, n_threads=0, lib=None):
+    """rh_count_filtered: the reader's pA filter as per-read counts (what ReadBatch.n_filtered wants) of a host batch."""
+    l = lib or globals()["lib"]()
+    out = np.zeros(max(batch.n_reads, 1), dtype=np.uint32)
+    if l.rh_count_filtered(C.byref(batch), ptr(out), n_threads) != 0:
+        raise RuntimeError(last_error(l))
+    return out[: batch.n_reads]
 
 
 _lib = None
@@ -156,6 +167,7 @@ def _declare(lib):
         "rh_paf_format": (i32, [vp, P(MapRecord), cp, C.c_double, cp, C.c_size_t]),
         "rh_reads_load": (vp, [cp]), "rh_reads_destroy": (None, [vp]), "rh_reads_n": (u32, [vp]),
         "rh_reads_name": (cp, [vp, u32]), "rh_reads_batch": (i32, [vp, P(ReadBatch)]), "rh_reads_pinned": (i32, [vp]),
+        "rh_count_filtered": (i32, [P(ReadBatch), vp, i32]),
         "rh_reads_write": (i32, [cp, u32, P(cp), vp, vp, C.c_double, C.c_double, C.c_double]),
         "rh_reads_write_blow5": (i32, [cp, u32, P(cp), vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, i32]),
         "rh_synth_cfg_init": (None, [P(SynthCfg)]), "rh_synth_write_model": (i32, [P(SynthCfg), cp]),

@@ -78,6 +78,8 @@ struct rh_ctx_s {
 	DevBuf logf_tab;
 	// batch state + per-round arenas (grow only)
 	DevBuf raw, off, cal_off, cal_scale;
+	DevBuf res_len, cnt_res, new_len, lsig_given;                 // consumed-prefix staging (rh_read_batch_t::n_filtered + page-locked samples): see k_need / k_fetch
+	const int16_t *lazy_host = nullptr; uint32_t lazy_maxlen = 0; uint64_t lazy_fetched = 0;   // the batch's samples[] as the device sees it; its longest read
 	DevBuf st[24];
 	DevBuf act[2], n_act_dev;
 	DevBuf zbuf, t1buf, t2buf, n_norm, peaks, n_peaks;
@@ -282,19 +284,40 @@ static int chain_stages(rh_ctx *c, hipStream_t s, const rh_dev_opt &o, const rh_
 }
 
 // upload (or adopt) the read batch; fills rd with device pointers and allocates the per-read state
-int stage_reads(rh_ctx *c, const rh_read_batch_t *in, rh_dev_reads *rd)
+int stage_reads(rh_ctx *c, const rh_read_batch_t *in, rh_dev_reads *rd, bool allow_lazy = false)
 {
 	const uint32_t R = in->n_reads;
 	memset(rd, 0, sizeof(*rd));
 	rd->n_reads = R;
 	rd->fast5 = in->fast5_ingest ? 1u : 0u;
+	c->lazy_host = nullptr;
 	if (in->samples_on_device) {
 		if (!in->cal_offset || !in->cal_scale) { rh_set_error("device batches must carry cal_offset and cal_scale"); return -1; }
 		rd->raw = in->samples; rd->off = in->offsets; rd->cal_off = in->cal_offset; rd->cal_scale = in->cal_scale;
 	} else {
 		const uint64_t first = R ? in->offsets[0] : 0, total = R ? in->offsets[R] - first : 0;   // a slice keeps absolute offsets
-		if (c->raw.ensure(total * 2 + 2) || c->off.ensure((size_t)(R + 1) * 8) || c->cal_off.ensure((size_t)(R + 1) * 8) || c->cal_scale.ensure((size_t)(R + 1) * 4)) return -1;
-		if (total) RH_HIP(hipMemcpyAsync(c->raw.p, in->samples + first, total * 2, hipMemcpyHostToDevice, c->stream));
+		if (c->raw.ensure(total * 2 + 32) || c->off.ensure((size_t)(R + 1) * 8) || c->cal_off.ensure((size_t)(R + 1) * 8) || c->cal_scale.ensure((size_t)(R + 1) * 4)) return -1;
+		// Consumed-prefix staging: the caller knows every read's filtered length (its reader counted while decoding) and the samples lie in
+		// page-locked memory the device can read -> nothing is copied here; the rounds fetch the stretches they consume (ensure_resident).
+		size_t place = 0;
+		if (allow_lazy && in->n_filtered && R) {
+			if (c->lsig_given.ensure((size_t)R * 4)) return -1;
+			RH_HIP(hipMemcpyAsync(c->lsig_given.p, in->n_filtered, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
+			rd->l_sig_given = c->lsig_given.as<uint32_t>();            // (checked against the filter's own count wherever the device sees a whole read)
+			hipPointerAttribute_t at;
+			if (total && hipPointerGetAttributes(&at, in->samples) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
+				c->lazy_host = (const int16_t*)at.devicePointer;
+				place = (size_t)((uintptr_t)(c->lazy_host + first) & 15u);   // same misalignment on both sides: k_fetch copies aligned 16-byte words
+				uint64_t mx = 0;
+				for (uint32_t r = 0; r < R; ++r) { const uint64_t l = in->offsets[r + 1] - in->offsets[r]; if (l > mx) mx = l; }
+				c->lazy_maxlen = (uint32_t)mx; c->lazy_fetched = 0;
+				if (c->res_len.ensure((size_t)R * 4) || c->cnt_res.ensure((size_t)R * 4) || c->new_len.ensure((size_t)R * 4)) return -1;
+				RH_HIP(hipMemsetAsync(c->res_len.p, 0, (size_t)R * 4, c->stream)); RH_HIP(hipMemsetAsync(c->cnt_res.p, 0, (size_t)R * 4, c->stream));
+				rd->res_len = c->res_len.as<uint32_t>(); rd->cnt_res = c->cnt_res.as<uint32_t>();
+			} else (void)hipGetLastError();                            // (pageable memory: the whole batch is copied, as without n_filtered)
+		}
+		int16_t *const d0 = (int16_t*)((char*)c->raw.p + place);
+		if (total && !c->lazy_host) RH_HIP(hipMemcpyAsync(d0, in->samples + first, total * 2, hipMemcpyHostToDevice, c->stream));
 		RH_HIP(hipMemcpyAsync(c->off.p, in->offsets, (size_t)(R + 1) * 8, hipMemcpyHostToDevice, c->stream));
 		std::vector<double> co(R, 0.0); std::vector<float> cs(R, 1.0f);
 		if (in->cal_offset) memcpy(co.data(), in->cal_offset, (size_t)R * 8);
@@ -304,7 +327,7 @@ int stage_reads(rh_ctx *c, const rh_read_batch_t *in, rh_dev_reads *rd)
 			RH_HIP(hipMemcpyAsync(c->cal_scale.p, cs.data(), (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
 		}
 		RH_HIP(hipStreamSynchronize(c->stream));   // co/cs are stack-owned
-		rd->raw = c->raw.as<int16_t>() - first; rd->off = c->off.as<uint64_t>(); rd->cal_off = c->cal_off.as<double>(); rd->cal_scale = c->cal_scale.as<float>();
+		rd->raw = d0 - first; rd->raw_w = d0 - first; rd->off = c->off.as<uint64_t>(); rd->cal_off = c->cal_off.as<double>(); rd->cal_scale = c->cal_scale.as<float>();
 	}
 	if (in->name_rank) {
 		if (c->name_rank.ensure((size_t)(R + 1) * 4)) return -1;
@@ -854,6 +877,27 @@ void set_rec8_formats(const rh_ctx *c, const rh_mapopt_t *mo, const rh_dev_opt &
 }
 
 // rec_off != null: all-vs-all, a read may have several records (rec_off[r] .. rec_off[r + 1], n_reads + 1 offsets)
+// Consumed-prefix staging: before round `chunk`, every active read must hold the chunk's raw samples in HBM (k_need's condition).  The reads that
+// lack them are extended by the device itself from the caller's page-locked samples - two and a quarter chunks ahead in rounds 0 and 1 (a read
+// that maps is done by then), the whole rest from round 2 on (what is still active then runs to max_num_chunk) - and re-ranked by k_prefilter.
+int ensure_resident(rh_ctx *c, hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act, uint32_t n_act, uint32_t chunk)
+{
+	const uint64_t ahead = 2ull * o.chunk_size + o.chunk_size / 4 + 64;
+	uint32_t grow = (chunk < 2 && ahead < c->lazy_maxlen) ? (uint32_t)ahead : 0xFFFFFFFFu;
+	uint32_t *n_need = c->n_act_dev.as<uint32_t>() + 8;
+	for (;;) {
+		RH_HIP(hipMemsetAsync(n_need, 0, 4, s));
+		rhk_need(s, o, rd, act, n_act, chunk, grow, c->new_len.as<uint32_t>(), n_need);
+		RH_HIP(hipMemcpyAsync(c->pin + 6, n_need, 4, hipMemcpyDeviceToHost, s));
+		RH_HIP(hipStreamSynchronize(s));
+		const uint32_t needy = (uint32_t)c->pin[6];
+		if (!needy) return 0;
+		rhk_fetch(s, rd, c->lazy_host, act, n_act, c->new_len.as<uint32_t>(), grow < c->lazy_maxlen ? grow : c->lazy_maxlen);
+		rhk_prefilter(s, o, rd, act, n_act, 0, c->counters.as<unsigned long long>() + 8);
+		grow = 0xFFFFFFFFu;                                           // (a stretch that was not enough: many samples outside 30 .. 200 pA - the whole read next)
+	}
+}
+
 int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, rh_map_record_t *out, uint64_t out_cap, uint64_t *n_out, uint64_t *rec_off = nullptr)
 {
 	*n_out = 0;
@@ -874,7 +918,8 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 	const auto t_begin = std::chrono::steady_clock::now();
 	hipStream_t s = c->stream;
 	rh_dev_reads rd;
-	{ StageTimer t(c, ST_H2D); if (stage_reads(c, in, &rd)) return -1; }
+	{ StageTimer t(c, ST_H2D); if (stage_reads(c, in, &rd, !(mo->flag & RH_M_NO_ADAPTIVE))) return -1; }
+	const bool lazy = rd.res_len != nullptr;
 	const bool dtw = (mo->flag & RH_M_DTW_EVALUATE_CHAINS) != 0;
 	if (dtw) {	// every read keeps the events of all its processed chunks
 		rd.ev_stride = (mo->flag & RH_M_NO_ADAPTIVE) ? c->ev_cap : mo->max_num_chunk * c->ev_cap;
@@ -883,7 +928,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 	}
 	if (c->act[0].ensure((size_t)R * 4) || c->act[1].ensure((size_t)R * 4) || c->n_act_dev.ensure(64) || c->carry[0].ensure(16) || c->carry[1].ensure(16) || c->counters.ensure(16 * 8) || c->rec.ensure((size_t)R * sizeof(rh_map_record_t))) return -1;
 	RH_HIP(hipMemsetAsync(c->counters.p, 0, 16 * 8, s));
-	{ StageTimer t(c, ST_PREFILTER); rhk_prefilter(s, o, rd); }
+	{ StageTimer t(c, ST_PREFILTER); rhk_prefilter(s, o, rd, nullptr, 0, 1, c->counters.as<unsigned long long>() + 8); }   // (consumed-prefix staging: nothing resident yet - state set up, lengths taken from the caller)
 	int cur = 0;
 	{ StageTimer t(c, ST_COMPACT); rhk_compact_active(s, o, rd, nullptr, R, 0, c->act[cur].as<uint32_t>(), c->n_act_dev.as<uint32_t>()); }
 	if (!c->pin) RH_HIP(hipHostMalloc((void**)&c->pin, 256, 0));
@@ -897,6 +942,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 		rh_dev_round rr{};
 		if (stage_round(c, n_act, &rr)) return -1;
 		rr.act = c->act[cur].as<uint32_t>(); rr.chunk = chunk;
+		if (lazy) { StageTimer t(c, ST_H2D); if (ensure_resident(c, s, o, rd, rr.act, n_act, chunk)) return -1; }
 		rr.akey_on = c->akey_on ? 1 : 0; rr.akey_lo = c->akey_lo; rr.akey_mid = c->akey_mid;
 		set_rec8_formats(c, mo, o, &rr);
 		rr.prev_in = c->carry[which ^ 1].as<rh_mm128_t>();
@@ -1001,6 +1047,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 		c->stats.n_events = cnt[0]; c->stats.n_seeds = cnt[1]; c->stats.n_hits = cnt[2]; c->stats.n_anchors = cnt[3]; c->stats.n_chained = cnt[4];
 		c->stats.n_samples_used = cnt[5]; c->stats.n_chunks = cnt[6];
 		if (cnt[7]) { rh_set_error("%llu chunk(s) hold more than %d event boundaries: beyond the per-chunk arrays of the device path", (unsigned long long)cnt[7], RH_EV_CAP); return -1; }
+		if (cnt[8]) { rh_set_error("rh_read_batch_t::n_filtered is wrong for %llu read(s): not the number of samples the pA filter (rsig.c:496-503) leaves of them", (unsigned long long)cnt[8]); return -1; }
 	}
 	RH_HIP(hipStreamSynchronize(s));                                // the last stop event
 	stage_timers_collect(c);
@@ -1036,7 +1083,8 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 	if (!(mo->flag & RH_M_NO_ADAPTIVE)) {
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-			const size_t per_read = (size_t)(RH_CHUNK_MAX + 64) * 12 + (size_t)RH_EV_CAP * 44 + 4096;
+			size_t per_read = (size_t)(RH_CHUNK_MAX + 64) * 12 + (size_t)RH_EV_CAP * 44 + 4096;
+			if (mo->flag & RH_M_DTW_EVALUATE_CHAINS) per_read += (size_t)mo->max_num_chunk * RH_EV_CAP * 4 * 5 + 256;   // reg->events of every chunk + the DP buffers (4 x the events so far), see dtw_regions_stage
 			size_t mine = holds_arenas(c) ? c->zbuf.cap + c->t1buf.cap + c->t2buf.cap + c->sx.cap + c->sy.cap + c->m_val.cap : 0;
 			const uint64_t lim = (uint64_t)(((double)free_b / (c->share > 0 ? c->share : 1) + (double)mine) / 3.0 / (double)per_read);
 			uint32_t cap = lim > 0xFFFFFFFFull ? 0xFFFFFFFFu : (lim < 4096 ? 4096u : (uint32_t)lim);
@@ -1065,6 +1113,7 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 		if (in->cal_offset) b.cal_offset = in->cal_offset + done;
 		if (in->cal_scale) b.cal_scale = in->cal_scale + done;
 		if (in->name_rank) b.name_rank = in->name_rank + done;
+		if (in->n_filtered) b.n_filtered = in->n_filtered + done;
 		g_oom = false;
 		if (map_batch_once(c, mo, &b, out + done, m, &n)) {
 			if (!g_oom || slice < 2) return -1;
@@ -1131,6 +1180,7 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 			if (in->cal_offset) b.cal_offset = in->cal_offset + lo[g];
 			if (in->cal_scale) b.cal_scale = in->cal_scale + lo[g];
 			if (in->name_rank) b.name_rank = in->name_rank + lo[g];
+			if (in->n_filtered) b.n_filtered = in->n_filtered + lo[g];
 			uint64_t n = 0;
 			const bool saved = lc->is_sub;
 			lc->is_sub = true;                                      // no further splitting
@@ -1738,6 +1788,7 @@ extern "C" int rh_map_batch_multi(rh_ctx *c, const rh_mapopt_t *mo, const rh_rea
 		if (in->cal_offset) b.cal_offset = in->cal_offset + done;
 		if (in->cal_scale) b.cal_scale = in->cal_scale + done;
 		b.name_rank = in->name_rank ? in->name_rank + done : nullptr;
+		b.n_filtered = in->n_filtered ? in->n_filtered + done : nullptr;
 		tmp_off.assign((size_t)m + 1, 0);
 		uint64_t n = 0;
 		if (map_batch_once(c, mo, &b, out + n_total, out_cap - n_total, &n, tmp_off.data())) return -1;

@@ -74,6 +74,10 @@ struct rh_dev_reads {
 	const int16_t *raw; const uint64_t *off; const double *cal_off; const float *cal_scale;
 	const uint32_t *name_rank;       // all-vs-all: rank of the read's name among the target names (strcmp(q, t) >= 0 <=> name_rank >= t_rank[t])
 	uint32_t *l_sig;                 // filtered length (sl:i tag)
+	// consumed-prefix staging (rh_read_batch_t::n_filtered given, samples in page-locked host memory): only res_len[r] raw samples of read r are in
+	// HBM yet (k_fetch brings more, k_need says who lacks the round's chunk); the read's filtered length comes from the caller, cnt_res[r] counts the
+	// survivors of the resident stretch.  All null / 0 when the whole batch was uploaded or handed over on the device.
+	uint32_t *res_len, *cnt_res; const uint32_t *l_sig_given; int16_t *raw_w;
 	uint32_t *chunk_start; uint32_t cs_stride;   // n_reads x cs_stride (= max_num_chunk + 1): raw index of the first sample of chunk c
 	double *sum, *sum2; uint32_t *n_sum;   // running normalisation sums (rmap.cpp:412-413)
 	uint32_t *ev_off;                // events accepted so far (reg->offset)
@@ -235,7 +239,9 @@ size_t rhk_bigsort_ws_bytes(uint64_t total, uint32_t n_lo);
 int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n_lo);
 
 // kernel launchers (rh_kernels.hip)
-void rhk_prefilter(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd);
+void rhk_prefilter(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act = nullptr, uint32_t n = 0, int init = 1, unsigned long long *bad = nullptr);
+void rhk_need(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, uint32_t chunk, uint32_t grow, uint32_t *new_len, uint32_t *n_need);
+void rhk_fetch(hipStream_t s, const rh_dev_reads &rd, const int16_t *host_samples, const uint32_t *act, uint32_t n, const uint32_t *new_len, uint32_t max_span);
 void rhk_events_norm(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_events_peaks(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
 void rhk_events_means(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);

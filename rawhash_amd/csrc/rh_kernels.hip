@@ -59,13 +59,16 @@ RH_DEV uint32_t pa_tile_count(const int16_t *raw, uint32_t base, uint32_t end, d
 #ifndef PF_TILES
 #define PF_TILES 2048          // tiles of 256 samples whose counts fit LDS (reads up to 512 k samples)
 #endif
-__global__ __launch_bounds__(NT) void k_prefilter(rh_dev_opt o, rh_dev_reads rd)
+// act / init / bad: consumed-prefix staging (rh_dev_reads::res_len) runs the kernel again over the reads k_fetch has just extended - the active list,
+// per-read state left alone - on the res_len[r] samples that are resident; *bad counts the reads whose caller-given filtered length is not what
+// the whole signal holds.
+__global__ __launch_bounds__(NT) void k_prefilter(rh_dev_opt o, rh_dev_reads rd, const uint32_t *act, int init, unsigned long long *bad)
 {
 	__shared__ uint32_t s_tot[NT / 64];
 	__shared__ uint16_t s_tc[PF_TILES];
-	const uint32_t r = blockIdx.x, tid = threadIdx.x, w = wave_id(), l = lane_id();
+	const uint32_t r = act ? act[blockIdx.x] : blockIdx.x, tid = threadIdx.x, w = wave_id(), l = lane_id();
 	const uint64_t o0 = rd.off[r], n64 = rd.off[r + 1] - o0;
-	const uint32_t n = (uint32_t)n64;
+	const uint32_t n = rd.res_len ? rd.res_len[r] : (uint32_t)n64;
 	const int16_t *raw = rd.raw + o0;
 	const double coff = rd.cal_off[r];
 	const float cscale = rd.cal_scale[r];
@@ -109,10 +112,71 @@ __global__ __launch_bounds__(NT) void k_prefilter(rh_dev_opt o, rh_dev_reads rd)
 		run += tc;
 	}
 	if (tid == 0) {
-		rd.l_sig[r] = total;
-		rd.sum[r] = 0.0; rd.sum2[r] = 0.0; rd.n_sum[r] = 0; rd.ev_off[r] = 0; rd.n_prev[r] = 0; rd.prev_off[r] = 0;
-		rd.done[r] = 0; rd.stop_chunk[r] = 0; rd.ls_ncregs[r] = 0;
+		if (rd.res_len) {
+			rd.cnt_res[r] = total;
+			rd.l_sig[r] = rd.l_sig_given[r];
+			if (n == (uint32_t)n64 && total != rd.l_sig_given[r]) atomicAdd(bad, 1ull);
+		} else {
+			rd.l_sig[r] = total;
+			if (rd.l_sig_given && total != rd.l_sig_given[r]) atomicAdd(bad, 1ull);
+		}
+		if (init) {
+			rd.sum[r] = 0.0; rd.sum2[r] = 0.0; rd.n_sum[r] = 0; rd.ev_off[r] = 0; rd.n_prev[r] = 0; rd.prev_off[r] = 0;
+			rd.done[r] = 0; rd.stop_chunk[r] = 0; rd.ls_ncregs[r] = 0;
+		}
 	}
+}
+
+// ------------------------------------------------------------------------------------------------ consumed-prefix staging
+// A read that maps stops after one or two chunks (rmap.cpp:425/498), so most of a batch's raw signal is never looked at - except by the pA
+// filter of the reader, whose survivor count is the sl:i tag (rsig.c:496-503).  A caller whose reader counted while it decoded
+// (rh_read_batch_t::n_filtered) and left the samples in page-locked memory gets them fetched over PCIe BY THE DEVICE, stretch by stretch as the
+// rounds need them: k_need marks the active reads whose resident stretch does not hold chunk `chunk` yet (the chunk's samples and the first one
+// of the next chunk: cnt_res >= (chunk + 1) * chunk_size + 1, or the whole read) and says how far to extend them, k_fetch copies, k_prefilter
+// re-ranks the extended reads.
+__global__ __launch_bounds__(256) void k_need(rh_dev_opt o, rh_dev_reads rd, const uint32_t *act, uint32_t n, uint32_t chunk, uint32_t grow, uint32_t *new_len, uint32_t *n_need)
+{
+	const uint32_t a = blockIdx.x * 256u + threadIdx.x;
+	if (a >= n) return;
+	const uint32_t r = act ? act[a] : a;
+	const uint32_t len = (uint32_t)(rd.off[r + 1] - rd.off[r]), res = rd.res_len[r];
+	const uint64_t want = ((uint64_t)chunk + 1ull) * (uint64_t)o.chunk_size + 1ull;
+	const bool need = res < len && (uint64_t)rd.cnt_res[r] < want;
+	uint32_t to = res;
+	if (need) { to = (uint64_t)res + grow < (uint64_t)len ? res + grow : len; atomicAdd(n_need, 1u); }
+	new_len[r] = to;
+}
+
+#define FETCH_VEC 1024u       // 16-byte words per workgroup (16 KB)
+__global__ __launch_bounds__(256) void k_fetch(rh_dev_reads rd, const int16_t *host, const uint32_t *act, uint32_t n, const uint32_t *new_len, uint32_t gy)
+{
+	const uint32_t a = blockIdx.x / gy, by = blockIdx.x % gy, tid = threadIdx.x;   // gy workgroups per read, 16 KB each
+	if (a >= n) return;
+	const uint32_t r = act ? act[a] : a;
+	const uint32_t from = rd.res_len[r], to = new_len[r];
+	if (to <= from) return;
+	const uint64_t o0 = rd.off[r];
+	const int16_t *src = host + o0;                                 // page-locked host memory, read across PCIe
+	int16_t *dst = rd.raw_w + o0;                                   // (same misalignment as src: stage_reads places the buffer so)
+	const uint32_t mis = (uint32_t)(((uintptr_t)(src + from) & 15u) >> 1);
+	uint32_t head = mis ? 8u - mis : 0u;
+	if (head > to - from) head = to - from;
+	const uint32_t i0 = from + head, nvec = (to - i0) >> 3, tail0 = i0 + (nvec << 3);
+	if (by == 0) {
+		if (tid < head) dst[from + tid] = src[from + tid];
+		if (tid >= 64u && tid - 64u < to - tail0) dst[tail0 + tid - 64u] = src[tail0 + tid - 64u];
+	}
+	const uint32_t v0 = by * FETCH_VEC, v1 = v0 + FETCH_VEC < nvec ? v0 + FETCH_VEC : nvec;
+	const uint4 *sv = reinterpret_cast<const uint4*>(src + i0);
+	uint4 *dv = reinterpret_cast<uint4*>(dst + i0);
+	for (uint32_t v = v0 + tid; v < v1; v += 256u) dv[v] = sv[v];
+}
+__global__ __launch_bounds__(256) void k_fetch_commit(rh_dev_reads rd, const uint32_t *act, uint32_t n, const uint32_t *new_len)
+{
+	const uint32_t a = blockIdx.x * 256u + threadIdx.x;
+	if (a >= n) return;
+	const uint32_t r = act ? act[a] : a;
+	rd.res_len[r] = new_len[r];
 }
 
 // number of chunk iterations the read goes through if no decision stops it (loop bounds of rmap.cpp:415)
@@ -1211,7 +1275,23 @@ __global__ void k_synth_reads(rh_synth_cfg_t c, const int32_t *level16, uint64_t
 // ------------------------------------------------------------------------------------------------ launchers
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-void rhk_prefilter(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd) { if (rd.n_reads) RH_LAUNCH(k_prefilter, rd.n_reads, NT, 0, s, o, rd); }
+void rhk_prefilter(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, int init, unsigned long long *bad)
+{
+	const uint32_t g = act ? n : rd.n_reads;
+	if (g) RH_LAUNCH(k_prefilter, g, NT, 0, s, o, rd, act, init, bad);
+}
+void rhk_need(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act, uint32_t n, uint32_t chunk, uint32_t grow, uint32_t *new_len, uint32_t *n_need)
+{
+	if (n) RH_LAUNCH(k_need, (n + 255) / 256, 256, 0, s, o, rd, act, n, chunk, grow, new_len, n_need);
+}
+void rhk_fetch(hipStream_t s, const rh_dev_reads &rd, const int16_t *host_samples, const uint32_t *act, uint32_t n, const uint32_t *new_len, uint32_t max_span)
+{
+	if (!n) return;
+	uint32_t gy = (max_span / 8u + FETCH_VEC - 1u) / FETCH_VEC;
+	if (gy == 0) gy = 1;
+	RH_LAUNCH(k_fetch, n * gy, 256, 0, s, rd, host_samples, act, n, new_len, gy);
+	RH_LAUNCH(k_fetch_commit, (n + 255) / 256, 256, 0, s, rd, act, n, new_len);
+}
 void rhk_events_norm(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
 {
 	if (!r.n_act) return;

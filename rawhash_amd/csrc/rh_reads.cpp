@@ -9,6 +9,7 @@
 #include <exception>
 #include <dlfcn.h>
 #include <sys/stat.h>
+#include <thread>
 
 extern "C" void *rh_pinned_alloc(size_t bytes);
 extern "C" void rh_pinned_free(void *p);
@@ -44,6 +45,7 @@ struct rh_reads_s {
 	std::vector<uint64_t> offsets;
 	std::vector<double> cal_offset;
 	std::vector<float> cal_scale;
+	std::vector<uint32_t> n_filtered;      // samples of each read that pass the reader's pA filter (rsig.c:496-503): the read's l_sig, counted here on the host
 };
 
 // size of a regular file; anything else (a FIFO, a failed fstat) has no size to check lengths against: "unknown" = a bound no length
@@ -67,8 +69,14 @@ extern "C" rh_reads *rh_reads_load(const char *path)
 		if (!fp) { rh_set_error("cannot open %s", path); return 0; }
 		const size_t got = fread(magic, 1, 6, fp);
 		fclose(fp);
-		if (got == 6 && !memcmp(magic, "BLOW5\1", 6)) return reads_load_blow5(path);
-		return reads_load_rhr(path);
+		rh_reads *r = (got == 6 && !memcmp(magic, "BLOW5\1", 6)) ? reads_load_blow5(path) : reads_load_rhr(path);
+		if (r) {	// what ri_read_sig knows when it returns (l_sig): lets rh_map_batch fetch only the signal its rounds consume
+			rh_read_batch_t b;
+			rh_reads_batch(r, &b);
+			r->n_filtered.assign(b.n_reads ? b.n_reads : 1, 0);
+			if (rh_count_filtered(&b, r->n_filtered.data(), 0)) { rh_reads_destroy(r); return 0; }
+		}
+		return r;
 	}
 	catch (const std::exception &e) { rh_set_error("%s: %s", path, e.what()); return 0; }   // (bad_alloc must not cross the C ABI)
 }
@@ -369,6 +377,42 @@ extern "C" int rh_reads_batch(const rh_reads *r, rh_read_batch_t *out)
 	out->offsets = r->offsets.data();
 	out->cal_offset = r->cal_offset.data();
 	out->cal_scale = r->cal_scale.data();
+	out->n_filtered = r->n_filtered.empty() ? nullptr : r->n_filtered.data();
+	return 0;
+}
+
+// The reader's filter as a count (rsig.c:496-503 / :363-374: pA = (raw + offset) * scale kept iff 30 < pA < 200; the same arithmetic as
+// raw_to_pa of the device, rh_kernels.hip): out[r] = l_sig of read r.  n_threads <= 0: as many as the host has, at most 32.
+extern "C" int rh_count_filtered(const rh_read_batch_t *in, uint32_t *out, int n_threads)
+{
+	if (in->samples_on_device) { rh_set_error("rh_count_filtered: host batches only"); return -1; }
+	const uint32_t R = in->n_reads;
+	if (n_threads <= 0) { n_threads = (int)std::thread::hardware_concurrency(); if (n_threads > 32) n_threads = 32; if (n_threads < 1) n_threads = 1; }
+	if ((uint32_t)n_threads > R) n_threads = R ? (int)R : 1;
+	auto work = [&](uint32_t r0, uint32_t r1) {
+		for (uint32_t r = r0; r < r1; ++r) {
+			const int16_t *p = in->samples + in->offsets[r];
+			const uint64_t n = in->offsets[r + 1] - in->offsets[r];
+			const double co = in->cal_offset ? in->cal_offset[r] : 0.0;
+			const float cs = in->cal_scale ? in->cal_scale[r] : 1.0f;
+			uint32_t k = 0;
+			if (in->fast5_ingest) { const float fo = (float)co; for (uint64_t i = 0; i < n; ++i) { const float pa = ((float)p[i] + fo) * cs; k += (pa > 30.0f && pa < 200.0f) ? 1u : 0u; } }
+			else for (uint64_t i = 0; i < n; ++i) { const float pa = (float)(((double)p[i] + co) * (double)cs); k += (pa > 30.0f && pa < 200.0f) ? 1u : 0u; }
+			out[r] = k;
+		}
+	};
+	std::vector<std::thread> th;
+	// (contiguous blocks of reads of about equal sample counts)
+	const uint64_t tot = R ? in->offsets[R] - in->offsets[0] : 0;
+	uint32_t r0 = 0;
+	for (int t = 0; t < n_threads; ++t) {
+		uint32_t r1 = r0;
+		const uint64_t upto = in->offsets ? in->offsets[0] + tot * (uint64_t)(t + 1) / (uint64_t)n_threads : 0;
+		while (r1 < R && (t == n_threads - 1 || in->offsets[r1 + 1] <= upto)) ++r1;
+		if (r1 > r0) th.emplace_back(work, r0, r1);
+		r0 = r1;
+	}
+	for (auto &x : th) x.join();
 	return 0;
 }
 

@@ -51,6 +51,7 @@ int main(int argc, char **argv)
 			if (hi == lo) return;
 			rh_read_batch_t b = all;
 			b.n_reads = hi - lo; b.offsets = all.offsets + lo; b.cal_offset = all.cal_offset + lo; b.cal_scale = all.cal_scale + lo;
+			if (all.n_filtered) b.n_filtered = all.n_filtered + lo;
 			uint64_t got = 0;
 			rc[g] = rh_map_batch(ctx[g], &mo, &b, rec.data() + lo, hi - lo, &got);
 			if (rc[g]) err[g] = rh_last_error();                     // (the error text is per thread)

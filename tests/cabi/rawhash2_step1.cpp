@@ -46,6 +46,7 @@ int main(int argc, char **argv)
 			const uint32_t m = n - next < per ? n - next : per;
 			f.b = all; f.b.n_reads = m; f.b.offsets = all.offsets + next;
 			f.b.cal_offset = all.cal_offset + next; f.b.cal_scale = all.cal_scale + next;
+			if (all.n_filtered) f.b.n_filtered = all.n_filtered + next;   // (the reader's l_sig per read: the device then fetches only the signal the rounds consume)
 			f.first = next;
 			if (rh_map_submit(ctx, &mo, &f.b, rec.data() + next, m, &f.t)) return fail("rh_map_submit");
 			f.on = true; next += m;

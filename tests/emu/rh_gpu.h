@@ -98,6 +98,9 @@ static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = (size_t)1 <<
 enum { hipErrorOutOfMemory = 2 };
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : 2; }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+enum { hipMemoryTypeHost = 0 };
+struct hipPointerAttribute_t { int type; void *devicePointer, *hostPointer; };
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p) { a->type = hipMemoryTypeHost; a->devicePointer = (void*)p; a->hostPointer = (void*)p; return hipSuccess; }   // (the emulator's "device" reads any host memory)
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyPeer(void *d, int, const void *s, int, size_t n) { memcpy(d, s, n); return hipSuccess; }

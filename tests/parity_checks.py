@@ -488,6 +488,65 @@ def check_e2e(ctx, wl, reads=None):
     return recs
 
 
+def check_consumed_prefix_staging(ctx, wl, pinned=False, seed=0):
+    """rh_read_batch_t::n_filtered + page-locked samples: the device fetches only the stretches of signal the rounds consume (k_need / k_fetch /
+    k_prefilter again).  The records must be those of the same batch uploaded whole - which check_e2e pins to the oracle - also for reads with so
+    many samples outside 30 .. 200 pA that the stretch fetched ahead does not hold the round's chunk (the top-up loop), for a slice that does
+    not start at offset 0, and a wrong count must fail the call."""
+    from rawhash_amd import _capi
+    from rawhash_amd.api import Reads, RhError
+    l = ctx._l
+    rng = np.random.default_rng(seed)
+    smp = wl.reads.samples.copy()
+    off = wl.reads.offsets
+    n = len(off) - 1
+    for r in range(0, n, 3):            # every third read: stretches of out-of-range samples (dropped by the filter), up to 70 % of a stretch of the read
+        b, e = int(off[r]), int(off[r + 1])
+        for _ in range(int(rng.integers(1, 6))):
+            a = int(rng.integers(b, e)); m = int(rng.integers(50, 9000))
+            idx = np.arange(a, min(a + m, e))
+            idx = idx[rng.random(len(idx)) < rng.uniform(0.2, 0.7)]
+            smp[idx] = rng.choice(np.array([-32768, 32767], dtype=np.int16), size=len(idx))
+    reads = Reads(smp, off, wl.reads.names, wl.reads.cal_offset, wl.reads.cal_scale)
+    check_e2e(ctx, wl, reads)           # (the odd reads map like the oracle says when uploaded whole)
+    want = ctx.map_batch(wl.opts, reads)
+    pin = None
+    try:
+        if pinned:
+            pin = l.rh_pinned_alloc(max(len(smp), 1) * 2 + 64)
+            assert pin
+            host = np.ctypeslib.as_array(C.cast(pin + 6, C.POINTER(C.c_int16)), shape=(max(len(smp), 1),))   # (+ 6 bytes: not 16-byte aligned)
+            host[: len(smp)] = smp
+        else:
+            host = smp
+        plain = _capi.make_batch(host[: len(smp)], off, reads.cal_offset, reads.cal_scale)
+        nf = _capi.count_filtered(plain, n_threads=3, lib=l)
+        assert nf.sum() < len(smp) and nf.sum() > 0
+        counted = _capi.make_batch(host[: len(smp)], off, reads.cal_offset, reads.cal_scale, n_filtered=nf)
+        got = ctx.map_batch(wl.opts, counted)
+        assert got.tobytes() == want.tobytes(), "records differ between whole-batch upload and consumed-prefix staging"
+        assert (got["tag_sl"] == nf.astype(np.int32)).all()
+        lo = n // 3                      # a slice of the batch: absolute offsets that do not start at 0
+        part = _capi.make_batch(host[: len(smp)], off[lo:], reads.cal_offset[lo:], reads.cal_scale[lo:], n_filtered=nf[lo:])
+        got = ctx.map_batch(wl.opts, part)
+        w2 = want[lo:].copy(); w2["read_idx"] -= lo
+        assert got.tobytes() == w2.tobytes(), "slice: records differ"
+        bad = nf.copy()
+        unm = np.flatnonzero(want["mapped"] == 0)
+        assert len(unm), "the workload has no unmappable read (one whose whole signal the device gets to see)"
+        bad[unm[0]] += 1
+        wrong = _capi.make_batch(host[: len(smp)], off, reads.cal_offset, reads.cal_scale, n_filtered=bad)
+        try:
+            ctx.map_batch(wl.opts, wrong)
+            raise AssertionError("a wrong n_filtered went unnoticed")
+        except RhError as e:
+            assert "n_filtered" in str(e)
+    finally:
+        if pin:
+            l.rh_pinned_free(pin)
+    return int((want["mapped"] == 1).sum())
+
+
 def check_ava(lib, case, directory, oracle_threads=4):
     """Rawsamble on the device path of `lib`: the signal-target index built from the reads must be the reference's .ind byte
     for byte (golden hash of the file `ref_harness sigindex` wrote), the oracle on that file and the device's all-vs-all

@@ -108,6 +108,10 @@ def test_end_to_end_paf(ctx, wl):
     assert recs["mapped"].sum() > 0 and (recs["mapped"] == 0).sum() > 0   # both outcomes exercised
 
 
+def test_consumed_prefix_staging(ctx, wl):
+    assert pc.check_consumed_prefix_staging(ctx, wl, seed=3) > 0
+
+
 @pytest.mark.parametrize("preset", ["fast", "faster", "viral"])
 def test_presets(make_workload, emu_lib, preset):
     w = make_workload(lib=emu_lib, preset=preset, n_reads=6 if preset == "viral" else 16, n_samples=12_000)   # (viral: dense index, thousands of anchors per chunk - slow under the emulator)

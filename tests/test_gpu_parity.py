@@ -64,6 +64,13 @@ def test_stage_regions(ctx, wl):
     assert checked > 300 and with_regs > 150
 
 
+def test_consumed_prefix_staging(ctx, wl):
+    """rh_read_batch_t::n_filtered + page-locked samples: the device fetches the stretches of signal the rounds consume straight from host memory
+    (k_need / k_fetch); records identical to the whole-batch upload, which is pinned to the oracle; a wrong count fails the call."""
+    assert pc.check_consumed_prefix_staging(ctx, wl, pinned=True, seed=5) > 0
+    assert pc.check_consumed_prefix_staging(ctx, wl, pinned=False, seed=6) > 0   # pageable memory: the batch is copied whole, the counts are only checked
+
+
 @pytest.mark.parametrize("mapopt", [{"flag": 2}, {"flag": 2, "rmq_size_cap": 40, "rmq_inner_dist": 300}, {"bw_long": 2000}, {"flag": 2, "bw_long": 1500}],
                          ids=lambda m: "_".join(f"{k}{v}" for k, v in m.items()))
 def test_rmq_chaining(make_workload, product_lib, gpu_ctx_factory, mapopt):
