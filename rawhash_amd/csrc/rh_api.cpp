@@ -1007,7 +1007,12 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 				return 0;
 			};
 			{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rs); }
-			{ StageTimer t(c, ST_SORT); if (rhk_sort(s, c->dix, rs)) return -1; }
+			{	// (all-vs-all keeps the exact passes for all: k_expand_ava has no second run)
+				StageTimer t(c, ST_SORT);
+				std::function<int(const uint8_t*)> again;
+				if (!ava) again = [&](const uint8_t *mask) { rhk_expand(s, o, c->dix, rd, rs, mask); return 0; };
+				if (rhk_sort(s, c->dix, rs, again)) return -1;
+			}
 			if (debug_rounds()) dump_round(c, chunk, n, rs);
 			if (chain_stages(c, s, o, rd, rs, true)) return -1;
 			if (!ava && pack_carry()) return -1;                      // (before the region sort: it borrows the staging arena)
@@ -1576,7 +1581,7 @@ extern "C" int rh_seed_batch(rh_ctx *c, const rh_mapopt_t *mo, uint32_t R, const
 	if (stage_anchors(c, total, &rr)) return -1;
 	rr.prev_in = c->carry[1].as<rh_mm128_t>();
 	rhk_expand(s, o, c->dix, rd, rr);
-	if (rhk_sort(s, c->dix, rr)) return -1;
+	if (rhk_sort(s, c->dix, rr, [&](const uint8_t *mask) { rhk_expand(s, o, c->dix, rd, rr, mask); return 0; })) return -1;
 	RH_HIP(hipStreamSynchronize(s));
 	RH_HIP(hipGetLastError());
 	if (total > anchors_cap) { rh_set_error("anchor buffer too small (%llu needed)", (unsigned long long)total); return -1; }
@@ -1688,7 +1693,8 @@ extern "C" int rh_sort128x_batch(rh_ctx *c, uint32_t n_seg, rh_mm128_t *a, const
 	if (stage_round(c, n_seg, &rr) || stage_anchors(c, total, &rr)) return -1;
 	std::vector<uint8_t> skip(n_seg ? n_seg : 1, 0);
 	if (h2d(rr.raw, a, total) || h2d(rr.a_off, offsets, (size_t)n_seg + 1) || h2d(rr.skip, skip.data(), n_seg)) return -1;
-	if (rhk_sort(c->stream, c->dix, rr)) return -1;
+	// (as the round loop runs it: long segments in any order first, those that hold equal keys again - from the caller's records - with the exact passes)
+	if (rhk_sort(c->stream, c->dix, rr, [&](const uint8_t *) { return h2d(rr.raw, a, total); })) return -1;
 	RH_HIP(hipStreamSynchronize(c->stream));
 	RH_HIP(hipGetLastError());
 	if (total) RH_HIP(hipMemcpy(a, rr.anc, total * 16, hipMemcpyDeviceToHost));

@@ -7,6 +7,7 @@
 #include "rh_index.h"
 #include "rh_synth_core.h"
 #include <vector>
+#include <functional>
 
 #define RH_CHUNK_MAX   4096          // samples of one chunk held in LDS by the event kernel
 #define RH_EV_CAP      2048          // events per chunk: peaks are >= 2 samples apart (revent.c:140)
@@ -249,8 +250,8 @@ inline void rhk_events(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &r
 void rhk_sketch(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_probe(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_scan_anchors(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r);
-void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
-int rhk_sort(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r);   // (r.afmt: one-word anchors, raw -> anc as such)
+void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r, const uint8_t *skip2 = nullptr);   // skip2: only the reads with skip2[a] == 0 (and not r.skip[a]), again
+int rhk_sort(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r, const std::function<int(const uint8_t*)> &reexpand = {});   // (r.afmt: one-word anchors, raw -> anc as such)
 void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);
 void rhk_chain_rmq(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r, const uint32_t *counts, int32_t max_dist, int32_t max_dist_inner, int32_t cap_rmq_size);   // mg_lchain_rmq (lchain.c:606); o.bw = the bandwidth of this pass
 int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r);

@@ -960,11 +960,12 @@ __global__ __launch_bounds__(1024) void k_scan_anchors(rh_dev_reads rd, rh_dev_r
 // ------------------------------------------------------------------------------------------------ k_expand
 // One block per active read: output anchor j finds its seed by binary search in the occurrence prefix (LDS), gathers the
 // 8-byte position word (the random HBM reads of the path) and writes the 16-byte anchor coalesced.
-__global__ __launch_bounds__(NT) void k_expand(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh_dev_round rr)
+__global__ __launch_bounds__(NT) void k_expand(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, rh_dev_round rr, const uint8_t *skip2)
 {
 	__shared__ uint32_t s_pref[RH_EV_CAP + 1];
 	const uint32_t a = blockIdx.x, tid = threadIdx.x;
 	if (a >= rr.n_act) return;
+	if (skip2 && skip2[a]) return;                                 // (a second run for the reads whose any-order sort found equal keys: rhk_sort; never a dropped chunk)
 	const uint32_t r = rr.act[a];
 	const uint64_t base = rr.a_off[a];
 	const uint32_t np = rd.n_prev[r];
@@ -1318,7 +1319,7 @@ void rhk_probe(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const
 	if (o.flag & RH_M_ALL_CHAINS) RH_LAUNCH(k_ava_count, r.n_act, NT, 0, s, o, ix, rd, r);
 }
 void rhk_scan_anchors(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r) { RH_LAUNCH(k_scan_anchors, 1, 1024, 0, s, rd, r); }
-void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (!r.n_act) return; if (o.flag & RH_M_ALL_CHAINS) RH_LAUNCH(k_expand_ava, r.n_act, NT, 0, s, o, ix, rd, r); else RH_LAUNCH(k_expand, r.n_act, NT, 0, s, o, ix, rd, r); }
+void rhk_expand(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r, const uint8_t *skip2) { if (!r.n_act) return; if (o.flag & RH_M_ALL_CHAINS) RH_LAUNCH(k_expand_ava, r.n_act, NT, 0, s, o, ix, rd, r); else RH_LAUNCH(k_expand, r.n_act, NT, 0, s, o, ix, rd, r, skip2); }
 void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act_in, uint32_t n_in, uint32_t next_chunk, uint32_t *act_out, uint32_t *n_out)
 { RH_LAUNCH(k_compact_active, 1, 1024, 0, s, o, rd, act_in, n_in, next_chunk, act_out, n_out); }
 void rhk_rebase_offsets(hipStream_t s, const uint64_t *a_off, uint32_t n, uint64_t *out) { RH_LAUNCH(k_rebase_offsets, cdiv(n + 1, 256), 256, 0, s, a_off, n, out); }

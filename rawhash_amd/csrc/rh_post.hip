@@ -196,6 +196,17 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 #ifndef CG_CAP
 #define CG_CAP 2048
 #endif
+// sort keys of a read's chains (first-anchor x; lchain.c:262-266) from the gathered chains in the carry staging -> rr.raw
+RH_DEV void chain_keys(const rh_dev_round &rr, uint64_t base, uint32_t n_u, const uint32_t *ck0, uint32_t tid)
+{
+	if (rr.cfmt.rec8) {	// 8-byte keys: first-anchor x, packed, above the chain's number (its start offset stays in ck0)
+		uint64_t *w8 = reinterpret_cast<uint64_t*>(rr.raw) + base;
+		for (uint32_t i = tid; i < n_u; i += NT) w8[i] = rh_rec8_pack_key(rh_an_ld(rr, rr.prev_out, base + ck0[i]).x, rr.cfmt.lo, rr.cfmt.mid) << rr.cfmt.shift | (uint64_t)i;
+	} else {
+		rh_mm128_t *w = rr.raw + base;
+		for (uint32_t i = tid; i < n_u; i += NT) { rh_mm128_t e; e.x = rh_an_ld(rr, rr.prev_out, base + ck0[i]).x; e.y = (uint64_t)ck0[i] << 32 | (uint64_t)i; w[i] = e; }
+	}
+}
 #define CG_SHORT 8            // anchors a lane copies on its own when a read has more than CG_CAP chains
 __global__ __launch_bounds__(NT) void k_chain_gather(rh_dev_round rr)
 {
@@ -251,11 +262,19 @@ __global__ __launch_bounds__(NT) void k_chain_gather(rh_dev_round rr)
 		}
 	}
 	__syncthreads();
-	if (rr.cfmt.rec8) {	// 8-byte keys: first-anchor x, packed, above the chain's number (its start offset stays in ck0)
-		uint64_t *w8 = reinterpret_cast<uint64_t*>(rr.raw) + base;
-		for (uint32_t i = tid; i < n_u; i += NT) w8[i] = rh_rec8_pack_key(rh_an_ld(rr, rr.prev_out, base + ck0[i]).x, rr.cfmt.lo, rr.cfmt.mid) << rr.cfmt.shift | (uint64_t)i;
-	} else
-	for (uint32_t i = tid; i < n_u; i += NT) { rh_mm128_t e; e.x = rh_an_ld(rr, rr.prev_out, base + ck0[i]).x; e.y = (uint64_t)ck0[i] << 32 | (uint64_t)i; w[i] = e; }
+	chain_keys(rr, base, n_u, ck0, tid);
+}
+
+// the chain-order keys of the reads with skip2[a] == 0 once more, from the gathered chains (the sorter overwrote its input): rhk_backtrack's exact re-run
+__global__ __launch_bounds__(NT) void k_chain_keys(rh_dev_round rr, const uint8_t *skip2)
+{
+	const uint32_t a = blockIdx.x, tid = threadIdx.x;
+	if (a >= rr.n_act || rr.skip[a] || skip2[a]) return;
+	const uint32_t n_u = rr.n_u[a];
+	if (n_u == 0) return;
+	const uint64_t base = rr.a_off[a];
+	const uint32_t n = (uint32_t)(rr.a_off[a + 1] - base);
+	chain_keys(rr, base, n_u, (const uint32_t*)(rr.ws + base * rr.ws_stride + (size_t)32 * n), tid);
 }
 
 __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_round rr)
@@ -1525,7 +1544,21 @@ int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, co
 	sort_scratch(jb, r, r.anc);                                    // (k_chain_gather has copied every chain out of the sorted anchors; k_chain_reorder rewrites them)
 	jb.kind = 3;
 	jb.rf = r.cfmt;
-	if (rhk_sort_job(s, jb, false, 0u)) return -1;
+	// Two chains agree on the key only where two anchors of the read do (see rhk_sort): long lists - an unmappable read on a large index has tens
+	// of thousands of chains - are placed level by level in any order, the reads whose chains do hold equal keys get their keys again and the exact passes
+	static const bool exact_all = RH_DEVENV("RH_CSORT_EXACT") != nullptr;   // development aid: the exact passes for every read
+	if (exact_all || (jb.n_max && jb.n_max <= rhk_sort_lds_max(jb))) { if (rhk_sort_job(s, jb, false, 0u)) return -1; }   // (nothing beyond the LDS classes: their fast pass / tie redo is exact already)
+	else {
+		uint32_t n_redo = 0;
+		jb.any_order = 1; jb.redo_skip = r.need_exact; jb.n_redo = &n_redo;   // (need_exact: idle between the candidate sort and the region stage)
+		RH_HIP(hipMemsetAsync(r.need_exact, 1, r.n_act, s));
+		if (rhk_sort_job(s, jb, false, 0u)) return -1;
+		if (n_redo) {
+			RH_LAUNCH(k_chain_keys, r.n_act, NT, 0, s, r, (const uint8_t*)r.need_exact);
+			jb.any_order = 0; jb.redo_skip = nullptr; jb.n_redo = nullptr; jb.skip = r.need_exact;
+			if (rhk_sort_job(s, jb, false, 0u)) return -1;
+		}
+	}
 	RH_LAUNCH(k_chain_reorder, r.n_act, NT, 0, s, rd, r);
 	return 0;
 }

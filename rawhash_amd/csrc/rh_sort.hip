@@ -853,13 +853,30 @@ int rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t 
 
 static void sort_scratch(rh_sort_job &jb, const rh_dev_round &r, rh_mm128_t *idle) { jb.big_alt = idle; jb.big_ws = r.sort_ws; jb.big_ws_bytes = r.sort_ws_bytes; jb.big_pin = r.sort_pin; jb.big_total = r.sort_total; }
 
-// anchor sort of a chunk round: unsorted expand output -> reference order
-int rhk_sort(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r)
+// anchor sort of a chunk round: unsorted expand output -> reference order.
+// Anchor keys (strand, target, position) are equal only where two seeds of the read's chunks share a hash - measured on the human-scale batch:
+// 0.2 % of the reads in round 0, 15 % of the unmappable reads by round 9, carried anchors accumulating - and the sorted order of a segment
+// without equal keys is unique.  So, when the caller can restore its input (`reexpand`), the segments beyond the LDS classes are first placed
+// level by level in ANY order (no hole lists, no token walk: rh_sort_job::any_order), k_bs_tiecheck finds the segments that do hold equal
+// keys, and only those are expanded again and sorted with the exact passes.  reexpand(mask): r.raw of every segment a with mask[a] == 0 as it
+// was before the call.  Without it: the exact passes for all.
+int rhk_sort(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r, const std::function<int(const uint8_t*)> &reexpand)
 {
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, nullptr, r.raw, r.anc, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 0, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };
 	sort_scratch(jb, r, r.zs);                                     // (the candidate array is idle until the chain DP has run)
 	jb.kind = 1;
 	jb.rf = r.afmt;                                                // (one-word anchors stay one word: r.raw -> r.anc as uint64_t arrays)
 	(void)ix;
+	static const bool exact_all = RH_DEVENV("RH_ASORT_EXACT") != nullptr;   // development aid: the exact passes for every read
+	if (!reexpand || exact_all || (jb.n_max && jb.n_max <= rhk_sort_lds_max(jb))) return rhk_sort_job(s, jb, false, 0u);   // (nothing beyond the LDS classes: their fast pass / tie redo is exact already)
+	uint32_t n_redo = 0;
+	jb.any_order = 1; jb.redo_skip = r.need_exact2; jb.n_redo = &n_redo;
+	RH_HIP(hipMemsetAsync(r.need_exact2, 1, r.n_act, s));
+	if (rhk_sort_job(s, jb, false, 0u)) return -1;
+	static const bool trace = RH_DEVENV("RH_BS_TRACE") != nullptr;
+	if (trace) fprintf(stderr, "ASORT any-order: chunk %u: %u of %u reads hold equal anchor keys and are redone\n", r.chunk, n_redo, r.n_act);
+	if (!n_redo) return 0;
+	if (reexpand(r.need_exact2)) return -1;
+	jb.any_order = 0; jb.redo_skip = nullptr; jb.n_redo = nullptr; jb.skip = r.need_exact2;   // (covers r.skip: the check marks skipped segments "no redo")
 	return rhk_sort_job(s, jb, false, 0u);
 }
