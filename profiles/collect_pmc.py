@@ -21,7 +21,7 @@ SAMPLES, JUNK = 40000, 102
 # every kernel of the mapping path belongs to a stage of bench.py's table (prefix match on the kernel name)
 STAGE_OF = [("k_prefilter", "prefilter"), ("k_events_norm", "events_norm"), ("k_events_tstat", "events_norm"), ("k_events_peaks", "events_peaks"), ("k_events_means", "events_means"),
             ("k_sketch", "sketch"), ("k_probe", "probe"), ("k_scan_anchors", "scan"), ("k_rebase_offsets", "scan"), ("k_expand", "expand"), ("k_chain_wave", "chain"), ("k_chain_serial", "chain"), ("k_chain_rmq", "chain"), ("k_events_append", "events_means"), ("k_regions_dtw", "regions"), ("k_dtw_", "regions"),
-            ("k_zbuild", "zsort"), ("k_backtrack_spec", "backtrack"), ("k_chain_gather", "backtrack"), ("k_chain_reorder", "backtrack"),
+            ("k_zbuild", "zsort"), ("k_backtrack_spec", "backtrack"), ("k_chain_gather", "backtrack"), ("k_chain_reorder", "backtrack"), ("k_chain_keys", "backtrack"), ("k_need", "prefilter"), ("k_fetch", "prefilter"),
             ("k_regions_prep", "rsort"), ("k_regions", "regions"), ("k_carry_", "compact"), ("k_compact_active", "compact"), ("k_finalize", "finalize")]
 NOT_PATH = ("k_synth_reads", "k_ix_", "__amd_rocclr")           # bench set-up (read generator, index construction, runtime copies)
 
