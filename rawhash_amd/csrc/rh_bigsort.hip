@@ -332,7 +332,8 @@ __global__ __launch_bounds__(NT) void k_bs_plan(bs_ctx C)
 	// Buckets for the block sorter go to one of two lists of the copy that holds them: 32-bit LDS keys when the bucket's keys
 	// agree on every bit from bit 32 up and that class takes a bucket of this size, 64-bit keys otherwise.  One atomic per
 	// wavefront and list (ranked by ballot): a level has up to a million such buckets.
-	const bool small = fate == BS_SMALL, narrow = small && s <= 32 && c <= (uint32_t)RH_SORT32_CAP3;
+	// (keys ordered with their upper fields moved up, rh_rec_fmt::up: the original key's bits from 32 up are this key's bits from `up` up)
+	const bool small = fate == BS_SMALL, narrow = small && s <= (C.rf.up ? (int)C.rf.up : 32) && c <= (uint32_t)RH_SORT32_CAP3;
 #pragma unroll
 	for (int w = 0; w < 2; ++w) {
 		const bool mine = small && (narrow == (w == 1));
@@ -1105,6 +1106,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	const uint64_t t = jb.big_total ? jb.big_total : 1, lo = n_lo ? n_lo : 1;
 	bs_ctx C{};
 	C.buf[0] = const_cast<rh_mm128_t*>(jb.src); C.buf[1] = jb.big_alt; C.dst = jb.dst; C.rf = jb.rf;
+	C.rf.up = (jb.any_order && jb.rf.rec8) ? jb.any_up : 0;      // (only the levels of this file order by the packed key; the block sorter and the check take the keys as they are)
 	const bool r8 = jb.rf.rec8 != 0;
 	#define BS_LAUNCH_REC(kern, grid, ...) do { if (r8) RH_LAUNCH(kern<uint64_t>, grid, NT, 0, s, __VA_ARGS__); else RH_LAUNCH(kern<rh_mm128_t>, grid, NT, 0, s, __VA_ARGS__); } while (0)
 	C.n_lo = n_lo;
@@ -1221,7 +1223,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		sj.n_seg = ns; sj.skip = nullptr; sj.off = C.small_off[q]; sj.cnt = C.small_cnt[q];
 		sj.src = (const rh_mm128_t*)C.buf[q >> 1]; sj.dst = jb.dst; sj.need_exact = nullptr; sj.n_max = pin[8 + q] < n_lo ? pin[8 + q] : n_lo;   // (an LDS class above the list's largest bucket would be a launch of blocks that all leave at once, each waiting for its LDS)
 		if ((q & 1) && !job32) { sj.kc_on = 1; sj.kc_lo = 32; sj.kc_mid = 0; sj.kc_hi = 0; }   // keys that differ below bit 32 only: 32-bit words in LDS
-		sj.big_alt = nullptr; sj.big_ws = nullptr;
+		sj.big_alt = nullptr; sj.big_ws = nullptr; sj.rf.up = 0;       // (the block sorter takes its keys at their original positions)
 		sj.any_order = 0; sj.redo_skip = nullptr; sj.n_redo = nullptr; sj.cnt_rw = C.small_cnt[q];
 		if (rhk_sort_job(s, sj, all_exact, 1u)) return -1;
 	}

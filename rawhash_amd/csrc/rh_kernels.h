@@ -94,7 +94,13 @@ struct rh_dev_reads {
 //   key' << shift | payload,   key' = hi << (lo + mid) | mid << lo | lo   (the bit fields of the ORIGINAL 64-bit key  hi << 63 | mid << 32 | lo),
 // which halves every byte the sorters move.  The order is still the reference's radix_sort_128x permutation of the original keys: the
 // digits of a level are taken from the key rebuilt at its original bit positions (rh_rec8_key).
-struct rh_rec_fmt { uint8_t rec8, shift, lo, mid; };
+// up != 0 (the multi-workgroup levels of any-order jobs only, rh_sort_job::any_up): the sorter orders by the packed key with its upper fields
+// (strand, target) moved up to bit 63 and the position left at the bottom, (k >> lo) << up | (k & low mask), k = w >> shift - the same order as the
+// original key's (the fields keep their significance), but the first level's byte then holds strand AND target: a human-scale chunk's anchors split 48
+// ways in ONE placement instead of 2 ways (byte 7) and then 24 (byte 4), into the same ~1.9 k-record buckets the block sorter likes (measured: moving two
+// position bits up as well - 192 buckets of ~460 - costs more in the block sorter than the placement saves).  Exact jobs never set it: their levels have
+// to be the reference's bytes.
+struct rh_rec_fmt { uint8_t rec8, shift, lo, mid, up; };
 RH_HD inline uint64_t rh_rec8_key(uint64_t w, uint32_t shift, uint32_t lo, uint32_t mid)
 {
 	const uint64_t k = w >> shift;
@@ -218,6 +224,7 @@ struct rh_sort_job {
 	// redo_skip[a] = 0 for the segments that hold equal keys (the caller redoes them with any_order = 0 and skip = redo_skip),
 	// 1 for all others; *n_redo (host) = their number
 	uint8_t any_order; uint8_t *redo_skip; uint32_t *n_redo;
+	uint8_t any_up;                          // 8-byte records of an any-order job: rh_rec_fmt::up of its multi-workgroup levels (0: the levels are the original key's bytes)
 	// cnt[] may be rewritten (the bucket lists of rh_bigsort.hip): the wavefront-per-segment sorter zeroes the count of a segment it
 	// has finished, so that the LDS classes launched after it pass over it
 	uint32_t *cnt_rw;
@@ -230,7 +237,7 @@ struct rh_sort_job {
 // record access of the sorters, by record type
 template <class REC> struct rh_rec_ops;
 template <> struct rh_rec_ops<rh_mm128_t> { static RH_HD inline uint64_t key(const rh_mm128_t &r, const rh_rec_fmt &) { return r.x; } };
-template <> struct rh_rec_ops<uint64_t> { static RH_HD inline uint64_t key(const uint64_t &r, const rh_rec_fmt &f) { return rh_rec8_key(r, f.shift, f.lo, f.mid); } };
+template <> struct rh_rec_ops<uint64_t> { static RH_HD inline uint64_t key(const uint64_t &r, const rh_rec_fmt &f) { if (!f.up) return rh_rec8_key(r, f.shift, f.lo, f.mid); const uint64_t k = r >> f.shift; return (k >> f.lo) << f.up | (k & ((1ull << f.lo) - 1ull)); } };
 // Unused dynamic LDS handed to the one-wavefront-per-read kernels (development knob RH_WAVE_LDS, bytes): their wavefronts live long, and
 // without a cap per CU they end up holding every wave slot while the other streams' bandwidth-bound kernels wait
 inline uint32_t rh_wave_lds() { static const uint32_t v = RH_DEVENV("RH_WAVE_LDS") ? (uint32_t)strtoul(RH_DEVENV("RH_WAVE_LDS"), nullptr, 10) : 0u; return v; }

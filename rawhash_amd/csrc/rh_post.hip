@@ -1551,6 +1551,7 @@ int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, co
 	else {
 		uint32_t n_redo = 0;
 		jb.any_order = 1; jb.redo_skip = r.need_exact; jb.n_redo = &n_redo;   // (need_exact: idle between the candidate sort and the region stage)
+		if (jb.rf.rec8) jb.any_up = (uint8_t)(64u - ((uint32_t)jb.rf.mid + 1u));   // (rh_rec_fmt::up)
 		RH_HIP(hipMemsetAsync(r.need_exact, 1, r.n_act, s));
 		if (rhk_sort_job(s, jb, false, 0u)) return -1;
 		if (n_redo) {

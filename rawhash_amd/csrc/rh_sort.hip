@@ -871,6 +871,7 @@ int rhk_sort(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r, const
 	if (!reexpand || exact_all || (jb.n_max && jb.n_max <= rhk_sort_lds_max(jb))) return rhk_sort_job(s, jb, false, 0u);   // (nothing beyond the LDS classes: their fast pass / tie redo is exact already)
 	uint32_t n_redo = 0;
 	jb.any_order = 1; jb.redo_skip = r.need_exact2; jb.n_redo = &n_redo;
+	if (jb.rf.rec8) jb.any_up = (uint8_t)(64u - ((uint32_t)jb.rf.mid + 1u));   // any order: the levels need not be the reference's bytes (rh_rec_fmt::up)
 	RH_HIP(hipMemsetAsync(r.need_exact2, 1, r.n_act, s));
 	if (rhk_sort_job(s, jb, false, 0u)) return -1;
 	static const bool trace = RH_DEVENV("RH_BS_TRACE") != nullptr;
