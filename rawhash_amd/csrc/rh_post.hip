@@ -31,6 +31,8 @@ extern "C" __attribute__((visibility("default"))) int rh_debug_kprof_post(unsign
 #endif
 
 // ------------------------------------------------------------------------------------------------ k_zbuild
+// candidates without a predecessor are passed over by the backtrack (see k_zbuild): plain chaining, one-word anchors (one span), chains of >= 2 anchors
+RH_DEV bool bt_lone_on(const rh_dev_opt &o, const rh_dev_round &rr) { return o.min_cnt >= 2 && rr.afmt.rec8 && !(o.flag & RH_M_RMQ) && !(o.bw_long > o.bw); }
 __global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 {
 	__shared__ uint32_t s_w[NT / 64];
@@ -46,7 +48,15 @@ __global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 	for (int32_t i = (int32_t)tid; i < (n + 3) / 4; i += NT) t4[i] = 0u;
 	uint32_t *claim = (uint32_t*)(rr.ws + base * rr.ws_stride + (size_t)20 * n);   // k_backtrack_spec's per-anchor claim stamps
 	for (int32_t i = (int32_t)tid; i < n; i += NT) claim[i] = 0u;
-	uint32_t nz = 0;
+	// A candidate WITHOUT A PREDECESSOR - most anchors of an unmappable read - is a chain of one anchor: with min_num_anchors >= 2
+	// mg_chain_backtrack marks it used and drops it (lchain.c:148-170), and nobody ever looks at that mark: an anchor that chains onto another scores
+	// more than its own span (mg_lchain_dp starts max_f at the span and takes a predecessor only if that beats it, lchain.c:443, 463, 489), every anchor of the round has the
+	// same span (one-word anchors: rr.afmt), so everything whose path could lead here scores more than this candidate and has been processed
+	// before it.  It has to be sorted with the others - it is part of the permutation - but the backtrack passes over it: bit 31 of the
+	// candidate's anchor word says so.  (Measured and rejected: the weaker, span-independent form "... that is nobody's predecessor either" with a
+	// marking pass over the predecessors here - k_zbuild 47 -> 110 ms for 46 ms less in k_backtrack_spec.)
+	const bool lone_on = bt_lone_on(o, rr);
+	uint32_t nz = 0, n_lone = 0;
 	for (int32_t i0 = 0; i0 < n; i0 += NT) {                        // (a workgroup per read: an unmappable read on a large index has 10^5 anchors)
 		const int32_t i = i0 + (int32_t)tid;
 		const int32_t fi = i < n ? fp[2 * i] : INT32_MIN;
@@ -54,12 +64,16 @@ __global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 		uint32_t tot;
 		const uint32_t rk = block_rank(ok, s_w, tot);
 		if (ok) {
-			if (rr.z8) z8[nz + rk] = (uint64_t)(uint32_t)fi << 32 | (uint64_t)(uint32_t)i;
-			else { rh_mm128_t e; e.x = (uint64_t)(int64_t)fi; e.y = (uint64_t)(uint32_t)i; z[nz + rk] = e; }
+			const uint32_t lone = (lone_on && fp[2 * i + 1] < 0) ? 0x80000000u : 0u;
+			if (rr.z8) z8[nz + rk] = (uint64_t)(uint32_t)fi << 32 | (uint64_t)((uint32_t)i | lone);
+			else { rh_mm128_t e; e.x = (uint64_t)(int64_t)fi; e.y = (uint64_t)((uint32_t)i | lone); z[nz + rk] = e; }
 		}
 		nz += tot;
+		if (lone_on) { uint32_t lt; (void)block_rank(ok && fp[2 * i + 1] < 0, s_w, lt); n_lone += lt; }
 	}
-	if (tid == 0) rr.n_z[a] = nz;
+	// (they all score their span, less than any candidate with a predecessor: the first n_lone of the sorted candidates - the backtrack stops there;
+	// n_v is the backtrack's to write, its input until then)
+	if (tid == 0) { rr.n_z[a] = nz; if (lone_on) rr.n_v[a] = n_lone; }
 }
 
 // ------------------------------------------------------------------------------------------------ backtrack
@@ -98,10 +112,12 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 	const int32_t min_sc = o.min_sc, min_cnt = o.min_cnt, max_drop = o.bw;
 	int32_t n_u = 0, n_v = 0;
 	uint32_t epoch = 0;
-	for (int32_t kt = n_z; kt > 0; kt -= 64) {                     // candidates from the best score down (lchain.c:148)
+	const int32_t n_lone = bt_lone_on(o, rr) ? (int32_t)rr.n_v[a] : 0;   // candidates without a predecessor: the lowest scores, passed over (k_zbuild)
+	for (int32_t kt = n_z; kt > n_lone; kt -= 64) {                // candidates from the best score down (lchain.c:148)
 		const int32_t k = kt - 1 - (int32_t)lane;
-		const int32_t i0 = k >= 0 ? (rr.z8 ? (int32_t)(uint32_t)zs8[k] : (int32_t)zs[k].y) : 0;
-		bool pending = k >= 0, accepted = false;
+		const uint32_t w0 = k >= 0 ? (rr.z8 ? (uint32_t)zs8[k] : (uint32_t)zs[k].y) : 0u;
+		const int32_t i0 = (int32_t)(w0 & 0x7FFFFFFFu);
+		bool pending = k >= 0 && !(w0 >> 31), accepted = false;     // (bit 31: a chain of one anchor that nothing else touches - k_zbuild)
 		int32_t r_cnt = 0, r_sc = 0;
 		int32_t pn1 = 0, pn2 = 0, pn3 = 0;                             // the first anchors of the path after i0 (most chains are this short)
 		for (;;) {

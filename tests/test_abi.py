@@ -47,6 +47,28 @@ def test_no_cpu_fallback(product_lib):
         Context(0)
 
 
+def test_count_filtered_is_the_readers_l_sig(make_workload, product_lib):
+    """rh_count_filtered (what rh_read_batch_t::n_filtered wants) = the sl:i tag the oracle prints (ri_read_sig's l_sig, rsig.c:496-503), with
+    samples outside 30 .. 200 pA in the signal, in both ingest arithmetics, for any thread count; the BLOW5 / RHR loaders deliver it with the batch."""
+    import numpy as np
+    import oracle_lib as O
+    from rawhash_amd.api import Reads
+    w = make_workload(n_reads=40, n_samples=9_000)
+    rng = np.random.default_rng(11)
+    smp = w.reads.samples.copy()
+    idx = rng.integers(0, len(smp), size=len(smp) // 7)
+    smp[idx] = rng.choice(np.array([-32768, -5000, 32767], dtype=np.int16), size=len(idx))
+    for fast5 in (False, True):
+        reads = Reads(smp, w.reads.offsets, w.reads.names, w.reads.cal_offset, w.reads.cal_scale, fast5=fast5)
+        oix, mo = w.oracle()
+        recs = O.map_batch(oix, mo, reads.batch(), n_threads=2)
+        want = np.array([r["tag_sl"] for r in recs], dtype=np.uint32)
+        for nt in (1, 3, 0):
+            got = _capi.count_filtered(reads.batch(), n_threads=nt, lib=product_lib)
+            assert (got == want).all(), (fast5, nt)
+        assert want.sum() < len(smp)
+
+
 def test_blow5_reader_round_trip(tmp_path, make_workload, product_lib):
     """BLOW5 records (uncompressed, zlib, zstd) x signals (raw, svb-zd) decode into the same raw int16 batch + calibration as the
     RHR1 container; a truncated file and an unknown compression code are errors, not crashes."""
