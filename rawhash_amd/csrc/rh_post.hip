@@ -69,8 +69,9 @@ __global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 			else { rh_mm128_t e; e.x = (uint64_t)(int64_t)fi; e.y = (uint64_t)((uint32_t)i | lone); z[nz + rk] = e; }
 		}
 		nz += tot;
-		if (lone_on) { uint32_t lt; (void)block_rank(ok && fp[2 * i + 1] < 0, s_w, lt); n_lone += lt; }
+		if (lone_on && ok && fp[2 * i + 1] < 0) ++n_lone;              // (this thread's; summed below)
 	}
+	if (lone_on) { uint32_t lt; (void)block_excl_scan(n_lone, s_w, lt); n_lone = lt; }
 	// (they all score their span, less than any candidate with a predecessor: the first n_lone of the sorted candidates - the backtrack stops there;
 	// n_v is the backtrack's to write, its input until then)
 	if (tid == 0) { rr.n_z[a] = nz; if (lone_on) rr.n_v[a] = n_lone; }
