@@ -75,7 +75,17 @@ struct bs_ctx {
 	uint64_t *small_off[4]; uint32_t *small_cnt[4];   // segments for the block sorter, by (copy that holds them) * 2 + (keys differ below bit 32 only)
 	uint32_t *hdr;                        // [0] ranges of this level [1] tiles [2..5] block-sorter segments per list [6] next level's ranges [7] error [8..11] largest segment per list
 	uint32_t small_cap, rng_cap, n_lo;
+	// any-order jobs (rh_sort_job::redo_skip): equal keys end up in one bucket whatever the order, so whoever finishes a bucket knows - a final
+	// bucket of more than one record (k_bs_plan), or the block sorter's tie flag of a bucket (small_tie, read by k_bs_tie_map) - and clears
+	// redo_skip of the segment the bucket lies in (found by position in seg_off): no pass over the sorted records to look for equal neighbours
+	const uint64_t *seg_off; uint32_t seg_n; uint8_t *redo_skip; uint8_t *small_tie[4];
 };
+RH_DEV void bs_mark_tie(const bs_ctx &C, uint64_t pos)
+{
+	uint32_t lo = 0, hi = C.seg_n;                                  // the last segment that starts at or before pos
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (C.seg_off[mid] <= pos) lo = mid; else hi = mid; }
+	C.redo_skip[lo] = 0;
+}
 
 // the range a tile belongs to: looked up once per level (k_bs_tile_map), not by every kernel of the level (a binary search over
 // the ranges is ~14 dependent loads by one lane while its workgroup waits)
@@ -328,6 +338,7 @@ __global__ __launch_bounds__(NT) void k_bs_plan(bs_ctx C)
 		else if (c <= C.n_lo) fate = BS_SMALL;
 		else fate = BS_BIG;
 	}
+	if (C.redo_skip && fate == BS_FINAL && c > 1) bs_mark_tie(C, R.beg + st);   // (any order: a final bucket of several records = equal keys)
 	const uint8_t alt = R.buf ^ 1;
 	// Buckets for the block sorter go to one of two lists of the copy that holds them: 32-bit LDS keys when the bucket's keys
 	// agree on every bit from bit 32 up and that class takes a bucket of this size, 64-bit keys otherwise.  One atomic per
@@ -1003,7 +1014,7 @@ __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 // K8': placement in any order (jobs whose keys are almost never equal: the sorted order of a segment without ties is unique, so
 // neither the holes nor the walk are needed): a tile counts its digits in LDS, reserves a stretch of every bucket it feeds with one
 // atomic on the range's cursor and drops its records there.  Which tile gets which stretch is decided by the scheduler - harmless
-// for distinct keys; segments that do hold equal keys are found afterwards (k_bs_tiecheck) and redone with the exact passes.
+// for distinct keys; segments that do hold equal keys are found where their buckets finish (bs_mark_tie) and redone with the exact passes.
 template <class REC>
 __global__ __launch_bounds__(NT) void k_bs_scatter_any(bs_ctx C)
 {
@@ -1045,23 +1056,24 @@ __global__ __launch_bounds__(NT) void k_bs_scatter_any(bs_ctx C)
 	}
 }
 
-// after an any-order job: which of its long segments hold equal keys (neighbours in the sorted result)?  skip_out[a] = 0 for those
-// - the skip array of the exact re-run - and 1 for every other segment; hdr[12] counts them
-template <class REC>
-__global__ __launch_bounds__(NT) void k_bs_tiecheck(rh_sort_job jb, bs_ctx C)
+// after the block sorter has finished an any-order job's small buckets: the segments of the buckets it found equal keys in
+__global__ __launch_bounds__(NT) void k_bs_tie_map(bs_ctx C, int q, uint32_t ns)
+{
+	const uint32_t b = blockIdx.x * NT + threadIdx.x;
+	if (b < ns && C.small_tie[q][b]) bs_mark_tie(C, C.small_off[q][b]);
+}
+// ... and how many segments that makes: hdr[12]
+__global__ __launch_bounds__(NT) void k_bs_tie_count(bs_ctx C)
 {
 	__shared__ uint32_t s_w[NT / 64];
-	const uint32_t a = blockIdx.x, tid = threadIdx.x;
-	if (a >= jb.n_seg) return;
-	uint32_t n = 0;
-	if (!(jb.skip && jb.skip[a])) n = jb.cnt ? jb.cnt[a] : (uint32_t)(jb.off[a + 1] - jb.off[a]);
-	if (n <= C.n_lo) { if (tid == 0) jb.redo_skip[a] = 1; return; }
-	const REC *v = reinterpret_cast<const REC*>(jb.dst) + jb.off[a];
-	bool tie = false;
-	for (uint32_t i = tid; i + 1 < n; i += NT) tie |= rh_rec_ops<REC>::key(v[i], jb.rf) == rh_rec_ops<REC>::key(v[i + 1], jb.rf);
-	uint32_t tot;
-	(void)block_rank(tie, s_w, tot);
-	if (tid == 0) { jb.redo_skip[a] = tot ? 0 : 1; if (tot) atomicAdd(&C.hdr[12], 1u); }
+	uint32_t run = 0;
+	for (uint32_t a0 = 0; a0 < C.seg_n; a0 += NT) {
+		const uint32_t a = a0 + threadIdx.x;
+		uint32_t tot;
+		(void)block_rank(a < C.seg_n && C.redo_skip[a] == 0, s_w, tot);
+		run += tot;
+	}
+	if (threadIdx.x == 0) C.hdr[12] = run;
 }
 
 // K9: the next level's ranges get their tile numbers; they become "this level"
@@ -1096,7 +1108,7 @@ size_t rhk_bigsort_ws_bytes(uint64_t total, uint32_t n_lo)
 	b += 2 * ((tiles * 4 + 255) & ~(size_t)255);
 	b += 3 * ((t + 128 + 255) & ~(size_t)255);                      // dg (two: this level's and the next one's), hd
 	b += 2 * ((t * 4 + 255) & ~(size_t)255);                       // hp, dest
-	b += 4 * ((small_cap * 8 + 255) & ~(size_t)255) + 4 * ((small_cap * 4 + 255) & ~(size_t)255);
+	b += 4 * ((small_cap * 8 + 255) & ~(size_t)255) + 4 * ((small_cap * 4 + 255) & ~(size_t)255) + 4 * ((small_cap + 255) & ~(size_t)255);
 	return b;
 }
 
@@ -1121,7 +1133,8 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	uint8_t *dgb[2] = { (uint8_t*)take(t + 128), (uint8_t*)take(t + 128) };
 	C.hd = (uint8_t*)take(t + 128);   // (+64: the lane walkers read whole aligned words around a pointer)
 	C.hp = (uint32_t*)take(t * 4); C.dest = (uint32_t*)take(t * 4);
-	for (int q = 0; q < 4; ++q) { C.small_off[q] = (uint64_t*)take((size_t)C.small_cap * 8); C.small_cnt[q] = (uint32_t*)take((size_t)C.small_cap * 4); }
+	for (int q = 0; q < 4; ++q) { C.small_off[q] = (uint64_t*)take((size_t)C.small_cap * 8); C.small_cnt[q] = (uint32_t*)take((size_t)C.small_cap * 4); C.small_tie[q] = (uint8_t*)take((size_t)C.small_cap); }
+	C.seg_off = jb.off; C.seg_n = jb.n_seg; C.redo_skip = jb.any_order ? jb.redo_skip : nullptr;
 	if ((size_t)(p - jb.big_ws) > jb.big_ws_bytes) { rh_set_error("segment sorter: scratch of %zu bytes is too small (%zu needed)", jb.big_ws_bytes, (size_t)(p - jb.big_ws)); return -1; }
 	RH_LAUNCH(k_bs_init, 1, NT, 0, s, jb, C);
 	uint32_t *pin = (uint32_t*)jb.big_pin;
@@ -1221,14 +1234,16 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		if (!ns) continue;
 		rh_sort_job sj = jb;
 		sj.n_seg = ns; sj.skip = nullptr; sj.off = C.small_off[q]; sj.cnt = C.small_cnt[q];
-		sj.src = (const rh_mm128_t*)C.buf[q >> 1]; sj.dst = jb.dst; sj.need_exact = nullptr; sj.n_max = pin[8 + q] < n_lo ? pin[8 + q] : n_lo;   // (an LDS class above the list's largest bucket would be a launch of blocks that all leave at once, each waiting for its LDS)
+		sj.src = (const rh_mm128_t*)C.buf[q >> 1]; sj.dst = jb.dst; sj.need_exact = C.redo_skip ? C.small_tie[q] : nullptr; sj.n_max = pin[8 + q] < n_lo ? pin[8 + q] : n_lo;   // (an LDS class above the list's largest bucket would be a launch of blocks that all leave at once, each waiting for its LDS)
 		if ((q & 1) && !job32) { sj.kc_on = 1; sj.kc_lo = 32; sj.kc_mid = 0; sj.kc_hi = 0; }   // keys that differ below bit 32 only: 32-bit words in LDS
 		sj.big_alt = nullptr; sj.big_ws = nullptr; sj.rf.up = 0;       // (the block sorter takes its keys at their original positions)
 		sj.any_order = 0; sj.redo_skip = nullptr; sj.n_redo = nullptr; sj.cnt_rw = C.small_cnt[q];
+		if (C.redo_skip) RH_HIP(hipMemsetAsync(C.small_tie[q], 0, ns, s));
 		if (rhk_sort_job(s, sj, all_exact, 1u)) return -1;
+		if (C.redo_skip) RH_LAUNCH(k_bs_tie_map, (ns + NT - 1) / NT, NT, 0, s, C, q, ns);
 	}
 	if (jb.any_order) {
-		BS_LAUNCH_REC(k_bs_tiecheck, jb.n_seg, jb, C);
+		RH_LAUNCH(k_bs_tie_count, 1, NT, 0, s, C);
 		RH_HIP(hipMemcpyAsync(pin, C.hdr + 12, 4, hipMemcpyDeviceToHost, s));
 		RH_HIP(hipStreamSynchronize(s));
 		if (jb.n_redo) *jb.n_redo = pin[0];

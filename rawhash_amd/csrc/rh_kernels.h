@@ -221,7 +221,7 @@ struct rh_sort_job {
 	rh_mm128_t *big_alt; unsigned char *big_ws; size_t big_ws_bytes; void *big_pin; uint64_t big_total;
 	// keys that are almost never equal (hashed): a sorted order without ties is unique, so the segments beyond the LDS classes are
 	// placed level by level in ANY order (no token walk); afterwards every segment is checked for equal neighbours:
-	// redo_skip[a] = 0 for the segments that hold equal keys (the caller redoes them with any_order = 0 and skip = redo_skip),
+	// redo_skip[a] (set to 1 by the caller) = 0 for the segments that hold equal keys (the caller redoes them with any_order = 0 and skip = redo_skip),
 	// 1 for all others; *n_redo (host) = their number
 	uint8_t any_order; uint8_t *redo_skip; uint32_t *n_redo;
 	uint8_t any_up;                          // 8-byte records of an any-order job: rh_rec_fmt::up of its multi-workgroup levels (0: the levels are the original key's bytes)

@@ -366,6 +366,22 @@ struct rh_reg {
 	uint32_t mapq, rev, hash;
 };
 struct rh_chain_head { uint64_t x0, y0; int32_t x1, y1, cnt, k; };   // first anchor, low words of the last anchor
+// A region sort record's payload (k_regions_prep): what mm_set_parent looks at of a chain - query interval and anchor count - travels with the key,
+//   y = chain (26 bits) | cnt (6) << 26 | qs (16) << 32 | qe (16) << 48,
+// so the region kernels stream the sorted keys instead of gathering a 32-byte head per chain (k_regions_batch: 359 GB of 64-byte sectors a step for
+// 16 bytes each).  cnt = 63: something does not fit (>= 63 anchors, a coordinate >= 65536): look at the head after all.
+#define RG_IDX(y_) ((uint32_t)(y_) & 0x3FFFFFFu)
+RH_DEV uint64_t rg_pack(uint32_t chain, uint32_t cnt, int64_t qs, int64_t qe)
+{
+	if (cnt >= 63u || qs < 0 || qe < 0 || qs >= 65536 || qe >= 65536) return (uint64_t)chain | 63ull << 26;
+	return (uint64_t)chain | (uint64_t)cnt << 26 | (uint64_t)qs << 32 | (uint64_t)qe << 48;
+}
+RH_DEV void rg_unpack(uint64_t y, const rh_chain_head *heads, int32_t &qs, int32_t &qe, int32_t &cnt)
+{
+	const uint32_t c6 = (uint32_t)(y >> 26) & 63u;
+	if (c6 != 63u) { cnt = (int32_t)c6; qs = (int32_t)((y >> 32) & 0xFFFFu); qe = (int32_t)(y >> 48); }
+	else { const rh_chain_head *h = heads + RG_IDX(y); cnt = h->cnt; qs = (int32_t)h->y0; qe = h->y1 + 1; }
+}
 
 // Stage-level export of kept region k of a read (rh_regions_batch; rr.reg_out is null on the mapping path, which needs creg[0], the count and two sums only):
 // the reference's region record in the field order of its dump, {id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0, mapq, rev, hash};
@@ -393,7 +409,7 @@ RH_DEV void reg_export(const rh_dev_round &rr, uint64_t base, int32_t k, const r
 RH_DEV void reg_export_primary(const rh_dev_round &rr, uint64_t base, int32_t n_u, int32_t k, int32_t i, int32_t subsc, int32_t n_sub, int32_t mapq)
 {
 	const rh_mm128_t zi = (rr.zs + base)[n_u - 1 - i];
-	const rh_chain_head h = ((const rh_chain_head*)(rr.ws + base * rr.ws_stride))[(uint32_t)zi.y];
+	const rh_chain_head h = ((const rh_chain_head*)(rr.ws + base * rr.ws_stride))[RG_IDX(zi.y)];
 	rh_reg q;
 	q.id = k; q.parent = k; q.cnt = h.cnt; q.as = h.k; q.score = q.score0 = (int32_t)(zi.x >> 32); q.hash = (uint32_t)zi.x;
 	q.rev = (uint32_t)(h.x0 >> 63); q.rid = (int32_t)(h.x0 << 1 >> 33); q.rs = (int32_t)h.x0; q.re = h.x1 + 1; q.qs = (int32_t)h.y0; q.qe = h.y1 + 1;
@@ -715,7 +731,7 @@ __global__ __launch_bounds__(NT) void k_regions_prep(rh_dev_opt o, rh_dev_reads 
 			rh_chain_head h; h.x0 = f0.x; h.y0 = f0.y; h.x1 = (int32_t)f1.x; h.y1 = (int32_t)f1.y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
 			heads[i] = h;
 			const uint32_t hh = (uint32_t)rh_mix64_nomask((rh_mix64_nomask(f0.x) + rh_mix64_nomask(f0.y)) ^ (uint64_t)hash);
-			rh_mm128_t e; e.x = ui ^ (uint64_t)hh; e.y = (uint64_t)(uint32_t)i;
+			rh_mm128_t e; e.x = ui ^ (uint64_t)hh; e.y = rg_pack((uint32_t)i, cnt, (int64_t)(int32_t)f0.y, (int64_t)(int32_t)f1.y + 1);
 			z[i] = e;
 		}
 		carry += tot;
@@ -752,10 +768,11 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 	KPROF_DECL;
 	for (int32_t i = (int32_t)lane; i < n_u; i += 64) {
 		const rh_mm128_t zi = zs[n_u - 1 - i];                      // descending: larger score first (hit.c:124-126)
-		const rh_chain_head h = heads[(uint32_t)zi.y];
+		int32_t hqs, hqe, hcnt;
+		rg_unpack(zi.y, heads, hqs, hqe, hcnt);
 		const uint32_t score = (uint32_t)(zi.x >> 32);
-		if (score >= (1u << 20) || (uint32_t)h.cnt >= (1u << 12)) unfit = true;
-		L.sc[i] = score | (uint32_t)h.cnt << 20; L.qs[i] = (int32_t)h.y0; L.qe[i] = h.y1 + 1;
+		if (score >= (1u << 20) || (uint32_t)hcnt >= (1u << 12)) unfit = true;
+		L.sc[i] = score | (uint32_t)hcnt << 20; L.qs[i] = hqs; L.qe[i] = hqe;
 	}
 	if (__ballot(unfit)) { if (lane == 0) rr.need_exact[a] = 1; return; }   // does not fit the packed layout: serial kernel
 	__syncthreads();
@@ -869,7 +886,7 @@ __global__ __launch_bounds__(64) void k_regions_wave(rh_dev_opt o, rh_dev_reads 
 			const float weighted = o.w_bestq * r_bestq + o.w_bestmq * r_bestmq + o.w_bestmc * r_bestmc;
 			if (weighted >= o.w_threshold) stop = 1;
 		}
-		const rh_chain_head h = heads[(uint32_t)zs[n_u - 1].y];
+		const rh_chain_head h = heads[RG_IDX(zs[n_u - 1].y)];
 		rh_reg best;
 		best.cnt = h.cnt; best.score = score0; best.mapq = (uint32_t)mapq0;
 		best.qs = (int32_t)h.y0; best.qe = h.y1 + 1; best.rs = (int32_t)h.x0; best.re = h.x1 + 1;
@@ -923,16 +940,14 @@ __global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads r
 	int32_t nqs = 0, nqe = 0, nsc = 0, ncn = 0;
 	if ((int32_t)lane < n_u) {
 		const rh_mm128_t zi = zs[n_u - 1 - (int32_t)lane];
-		const rh_chain_head *h = heads + (uint32_t)zi.y;
-		nsc = (int32_t)(zi.x >> 32); nqs = (int32_t)h->y0; nqe = h->y1 + 1; ncn = h->cnt;
+		nsc = (int32_t)(zi.x >> 32); rg_unpack(zi.y, heads, nqs, nqe, ncn);
 	}
 	for (int32_t i0 = 0; i0 < n_u && !overflow; i0 += 64) {
 		const int32_t tqs = nqs, tqe = nqe, tsc = nsc, tcn = ncn;
 		const int32_t inext = i0 + 64 + (int32_t)lane;
 		if (inext < n_u) {	// next tile's loads fly while this tile is processed
 			const rh_mm128_t zi = zs[n_u - 1 - inext];
-			const rh_chain_head *h = heads + (uint32_t)zi.y;
-			nsc = (int32_t)(zi.x >> 32); nqs = (int32_t)h->y0; nqe = h->y1 + 1; ncn = h->cnt;
+			nsc = (int32_t)(zi.x >> 32); rg_unpack(zi.y, heads, nqs, nqe, ncn);
 		}
 		const uint32_t nt = (uint32_t)(n_u - i0 < 64 ? n_u - i0 : 64);
 		for (uint32_t t = 0; t < nt; ++t) {
@@ -1060,7 +1075,7 @@ __global__ __launch_bounds__(64) void k_regions_reg(rh_dev_opt o, rh_dev_reads r
 			const float weighted = o.w_bestq * r_bestq + o.w_bestmq * r_bestmq + o.w_bestmc * r_bestmc;
 			if (weighted >= o.w_threshold) stop = 1;
 		}
-		const rh_chain_head h = heads[(uint32_t)zs[n_u - 1].y];
+		const rh_chain_head h = heads[RG_IDX(zs[n_u - 1].y)];
 		rh_reg best;
 		best.cnt = h.cnt; best.score = score0; best.mapq = (uint32_t)mapq0;
 		best.qs = (int32_t)h.y0; best.qe = h.y1 + 1; best.rs = (int32_t)h.x0; best.re = h.x1 + 1;
@@ -1117,8 +1132,7 @@ __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads
 		bool pending = i < n_u;
 		if (pending) {
 			const rh_mm128_t zi = zs[n_u - 1 - i];                    // descending: larger score first (hit.c:124-126)
-			const rh_chain_head *h = heads + (uint32_t)zi.y;
-			sci = (int32_t)(zi.x >> 32); si = (int32_t)h->y0; ei = h->y1 + 1; cni = h->cnt;
+			sci = (int32_t)(zi.x >> 32); rg_unpack(zi.y, heads, si, ei, cni);
 		}
 		bool need_eval = pending;
 		int32_t sel = -1;
@@ -1244,7 +1258,7 @@ __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads
 			const float weighted = o.w_bestq * r_bestq + o.w_bestmq * r_bestmq + o.w_bestmc * r_bestmc;
 			if (weighted >= o.w_threshold) stop = 1;
 		}
-		const rh_chain_head h = heads[(uint32_t)zs[n_u - 1].y];
+		const rh_chain_head h = heads[RG_IDX(zs[n_u - 1].y)];
 		rh_reg best;
 		best.cnt = h.cnt; best.score = score0; best.mapq = (uint32_t)mapq0;
 		best.qs = (int32_t)h.y0; best.qe = h.y1 + 1; best.rs = (int32_t)h.x0; best.re = h.x1 + 1;
@@ -1587,6 +1601,7 @@ static bool regions_wave_ok(const rh_dev_opt &o) { return o.best_n == 0 && o.pri
 int rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
 {
 	if (!r.n_act || !regions_wave_ok(o)) return 0;
+	if (r.max_anchors > 0x3FFFFFFu) { rh_set_error("a read with %u anchors in one round: beyond the 2^26 chains a region sort record numbers", r.max_anchors); return -1; }
 	RH_LAUNCH(k_regions_prep, r.n_act, NT, 0, s, o, rd, r, (const uint8_t*)nullptr);
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, 0, 0, 0, 0, r.max_anchors };   // keys = hashed: full 64 bits
 	sort_scratch(jb, r, r.prev_out);                               // (the carried anchors have left the staging: the round loop packs them before this sort)
@@ -1599,6 +1614,7 @@ int rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd,
 	if (exact_all) return rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL);
 	uint32_t n_redo = 0;
 	jb.any_order = 1; jb.redo_skip = r.need_exact; jb.n_redo = &n_redo;
+	RH_HIP(hipMemsetAsync(r.need_exact, 1, r.n_act, s));           // (1 = no redo; the sorter clears the reads whose chains hold equal keys)
 	if (rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL)) return -1;
 	static const bool trace = RH_DEVENV("RH_BS_TRACE") != nullptr;
 	if (trace) fprintf(stderr, "RSORT any-order: %u of %u reads hold equal region keys and are redone\n", n_redo, r.n_act);

@@ -857,7 +857,7 @@ static void sort_scratch(rh_sort_job &jb, const rh_dev_round &r, rh_mm128_t *idl
 // Anchor keys (strand, target, position) are equal only where two seeds of the read's chunks share a hash - measured on the human-scale batch:
 // 0.2 % of the reads in round 0, 15 % of the unmappable reads by round 9, carried anchors accumulating - and the sorted order of a segment
 // without equal keys is unique.  So, when the caller can restore its input (`reexpand`), the segments beyond the LDS classes are first placed
-// level by level in ANY order (no hole lists, no token walk: rh_sort_job::any_order), k_bs_tiecheck finds the segments that do hold equal
+// level by level in ANY order (no hole lists, no token walk: rh_sort_job::any_order), whoever finishes a bucket reports the segments that do hold equal
 // keys, and only those are expanded again and sorted with the exact passes.  reexpand(mask): r.raw of every segment a with mask[a] == 0 as it
 // was before the call.  Without it: the exact passes for all.
 int rhk_sort(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r, const std::function<int(const uint8_t*)> &reexpand)
