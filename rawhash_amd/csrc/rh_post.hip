@@ -57,19 +57,27 @@ __global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 	// marking pass over the predecessors here - k_zbuild 47 -> 110 ms for 46 ms less in k_backtrack_spec.)
 	const bool lone_on = bt_lone_on(o, rr);
 	uint32_t nz = 0, n_lone = 0;
-	for (int32_t i0 = 0; i0 < n; i0 += NT) {                        // (a workgroup per read: an unmappable read on a large index has 10^5 anchors)
-		const int32_t i = i0 + (int32_t)tid;
-		const int32_t fi = i < n ? fp[2 * i] : INT32_MIN;
-		const bool ok = i < n && fi >= o.min_sc;
+	const int2 *fp2 = reinterpret_cast<const int2*>(fp);            // .x = f, .y = p
+	constexpr int ZB = 4;                                           // consecutive anchors per thread and step: a quarter of the barriers, 32-byte loads
+	for (int32_t i0 = 0; i0 < n; i0 += NT * ZB) {                   // (a workgroup per read: an unmappable read on a large index has 10^5 anchors)
+		const int32_t ib = i0 + (int32_t)tid * ZB;
+		int2 rec[ZB];
+		bool ok[ZB];
+		uint32_t cnt = 0;
+#pragma unroll
+		for (int k = 0; k < ZB; ++k) { rec[k].x = 0; rec[k].y = 0; if (ib + k < n) rec[k] = fp2[ib + k]; ok[k] = ib + k < n && rec[k].x >= o.min_sc; cnt += ok[k] ? 1u : 0u; }
 		uint32_t tot;
-		const uint32_t rk = block_rank(ok, s_w, tot);
-		if (ok) {
-			const uint32_t lone = (lone_on && fp[2 * i + 1] < 0) ? 0x80000000u : 0u;
-			if (rr.z8) z8[nz + rk] = (uint64_t)(uint32_t)fi << 32 | (uint64_t)((uint32_t)i | lone);
-			else { rh_mm128_t e; e.x = (uint64_t)(int64_t)fi; e.y = (uint64_t)((uint32_t)i | lone); z[nz + rk] = e; }
+		uint32_t pos = nz + block_excl_scan(cnt, s_w, tot);
+#pragma unroll
+		for (int k = 0; k < ZB; ++k) {
+			if (!ok[k]) continue;
+			const uint32_t lone = (lone_on && rec[k].y < 0) ? 0x80000000u : 0u;
+			if (lone) ++n_lone;                                        // (this thread's; summed below)
+			if (rr.z8) z8[pos] = (uint64_t)(uint32_t)rec[k].x << 32 | (uint64_t)((uint32_t)(ib + k) | lone);
+			else { rh_mm128_t e; e.x = (uint64_t)(int64_t)rec[k].x; e.y = (uint64_t)((uint32_t)(ib + k) | lone); z[pos] = e; }
+			++pos;
 		}
 		nz += tot;
-		if (lone_on && ok && fp[2 * i + 1] < 0) ++n_lone;              // (this thread's; summed below)
 	}
 	if (lone_on) { uint32_t lt; (void)block_excl_scan(n_lone, s_w, lt); n_lone = lt; }
 	// (they all score their span, less than any candidate with a predecessor: the first n_lone of the sorted candidates - the backtrack stops there;
