@@ -109,6 +109,7 @@ struct rh_ctx_s {
 	int n_sub = 1;
 	bool is_sub = false;
 	uint32_t slice_hint = 0;                                       // reads per slice that fitted the device last time (0 = whole batches fit)
+	size_t mem_allow = 0;                                          // bytes of device memory this (sub-batch) context may hold for a batch: an equal part of what rh_map_batch found free for all of them (0: on its own)
 };
 
 namespace {
@@ -399,6 +400,7 @@ size_t bytes_per_anchor(const rh_ctx *c) { return 16 * 4 + 8 + (size_t)c->ws_str
 
 // anchors one slice of a round may hold: what is free on the device (plus what this context's arenas hold already), shared
 // by the sub-batches running concurrently; RH_ARENA_MAX_BYTES caps the per-anchor scratch (shared devices, tests)
+size_t ctx_bytes_held(rh_ctx *c);
 uint64_t slice_budget(rh_ctx *c)
 {
 	size_t free_b = 0, total_b = 0;
@@ -411,7 +413,11 @@ uint64_t slice_budget(rh_ctx *c)
 		const size_t avail = free_b > reserve ? free_b - reserve : 0;
 		// three quarters of what this context may use (its share of the free memory + what its arenas hold already; the rest is
 		// for the dense carry buffers and the per-read arrays), but never less than the arenas hold: they stay as they are
-		const double may_use = (double)(avail / (size_t)(c->share > 0 ? c->share : 1)) + (double)held;
+		// A sub-batch context has an allowance - its equal part of what rh_map_batch found for all of them (whoever asked first used to get
+		// three times the arenas of whoever asked last, and the call waited for the slowest) -: three quarters of what its other buffers (signal,
+		// per-read rows: up to a third, map_batch_single) leave of it go to the anchor arenas, the rest is for the dense carry buffers, which grow with the rounds.
+		const size_t other = c->mem_allow ? ctx_bytes_held(c) - held : 0;   // what this context holds besides the anchor arenas: the batch's signal, the per-read rows, the carry buffers
+		const double may_use = c->mem_allow ? (c->mem_allow > other ? (double)(c->mem_allow - other) : 0.0) : (double)(avail / (size_t)(c->share > 0 ? c->share : 1)) + (double)held;
 		const double use = 0.75 * may_use > (double)held ? 0.75 * may_use : (double)held;
 		budget = (uint64_t)(use / (double)bytes_per_anchor(c));
 		if (budget < (1u << 16)) return 0;                          // the device is full (other contexts / processes hold it)
@@ -451,6 +457,18 @@ void release_arenas(rh_ctx *c)
 	for (DevBuf &b : c->st) b.release();
 	c->arena_room = 0;
 	for (rh_ctx *sc : c->subs) release_arenas(sc);
+}
+// device bytes of the per-batch buffers of ONE context (not its sub-batch contexts)
+size_t ctx_bytes_held(rh_ctx *c)
+{
+	DevBuf *all[] = {&c->raw, &c->off, &c->cal_off, &c->cal_scale, &c->act[0], &c->act[1], &c->zbuf, &c->t1buf, &c->t2buf, &c->n_norm, &c->peaks, &c->n_peaks, &c->ev, &c->n_ev, &c->skip, &c->sx, &c->sy,
+	                 &c->n_seed, &c->m_val, &c->m_n, &c->m_meta, &c->m_pref, &c->n_match, &c->n_new, &c->rep_len, &c->a_off, &c->anc, &c->raw_anc, &c->zs, &c->n_z, &c->need_exact, &c->need_exact2, &c->prev_stage,
+	                 &c->carry[0], &c->carry[1], &c->carry_off, &c->a_off_slice, &c->u, &c->n_u, &c->n_v, &c->ws, &c->sort_ws, &c->rec,
+	                 &c->events, &c->dtw_ws, &c->dtw_n, &c->dtw_off, &c->dtw_rec, &c->dtw_dec, &c->res_len, &c->cnt_res, &c->new_len, &c->lsig_given};
+	size_t b = 0;
+	for (DevBuf *d : all) b += d->cap;
+	for (DevBuf &d : c->st) b += d.cap;
+	return b;
 }
 bool holds_arenas(const rh_ctx *c)
 {
@@ -1091,7 +1109,8 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 			size_t per_read = (size_t)(RH_CHUNK_MAX + 64) * 12 + (size_t)RH_EV_CAP * 44 + 4096;
 			if (mo->flag & RH_M_DTW_EVALUATE_CHAINS) per_read += (size_t)mo->max_num_chunk * RH_EV_CAP * 4 * 5 + 256;   // reg->events of every chunk + the DP buffers (4 x the events so far), see dtw_regions_stage
 			size_t mine = holds_arenas(c) ? c->zbuf.cap + c->t1buf.cap + c->t2buf.cap + c->sx.cap + c->sy.cap + c->m_val.cap : 0;
-			const uint64_t lim = (uint64_t)(((double)free_b / (c->share > 0 ? c->share : 1) + (double)mine) / 3.0 / (double)per_read);
+			const uint64_t lim = c->mem_allow ? (uint64_t)((double)c->mem_allow / 3.0 / (double)per_read)
+			                                  : (uint64_t)(((double)free_b / (c->share > 0 ? c->share : 1) + (double)mine) / 3.0 / (double)per_read);
 			uint32_t cap = lim > 0xFFFFFFFFull ? 0xFFFFFFFFu : (lim < 4096 ? 4096u : (uint32_t)lim);
 			if (const char *e = getenv("RH_CALL_READS_MAX")) { const uint32_t m = (uint32_t)strtoul(e, nullptr, 10); if (m && m < cap) cap = m; }   // (tests)
 			call_cap = cap;                                             // one hipMemGetInfo snapshot: a limit of this call only, never remembered
@@ -1170,6 +1189,19 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 		sc->akey_on = c->akey_on; sc->akey_lo = c->akey_lo; sc->akey_mid = c->akey_mid;
 		sc->logf_tab.p = c->logf_tab.p; sc->logf_tab.cap = c->logf_tab.cap; sc->logf_tab.owned = false;
 	}
+	// what the sub-batches of this call may hold, in equal parts: the free memory and what their buffers hold already, less a reserve for the
+	// runtime (kernel scratch, queues: it allocates at dispatch time and aborts the process when that fails)
+	size_t allow = 0;
+	{
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+			size_t held = 0;
+			for (int g = 0; g < n_sub; ++g) held += ctx_bytes_held(g == 0 ? c : c->subs[g - 1]);
+			const size_t reserve = total_b / 24 > ((size_t)3 << 30) ? total_b / 24 : ((size_t)3 << 30);
+			const size_t avail = (free_b > reserve ? free_b - reserve : 0) / (size_t)(c->flight_mult > 0 ? c->flight_mult : 1) + held;   // (batches in flight share the free part)
+			allow = avail / (size_t)n_sub;
+		}
+	}
 	const auto t_begin = std::chrono::steady_clock::now();
 	std::vector<int> rc(n_sub, 0);
 	std::vector<std::string> err(n_sub);
@@ -1190,8 +1222,9 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 			const bool saved = lc->is_sub;
 			lc->is_sub = true;                                      // no further splitting
 			lc->share = n_sub * c->flight_mult;                     // the device's memory is shared by the sub-batches (of every batch in flight)
+			lc->mem_allow = allow;
 			rc[g] = map_batch_single(lc, mo, &b, out + lo[g], b.n_reads, &n);
-			lc->is_sub = saved;
+			lc->is_sub = saved; lc->mem_allow = 0;
 			if (rc[g]) err[g] = rh_last_error();
 			else for (uint32_t i = 0; i < b.n_reads; ++i) out[lo[g] + i].read_idx += lo[g];
 		});
