@@ -1303,8 +1303,15 @@ RH_DEV float dtw_full(const float *a, uint32_t a_len, const float *b, uint32_t b
 	return excl ? dp[a_len - 1] - dtw_dist(a[a_len - 1], b[b_len - 1]) : dp[a_len - 1];
 }
 // DTW_global_slantedbanded_antidiagonalwise dtw.cpp:273-523; store: 3 * dpsize floats.  Returns NaN if the buffers do not fit `cap`.
-RH_DEV float dtw_banded(const float *a, uint32_t a_length, const float *b, uint32_t b_length, int band_radius, bool excl, float *store, uint32_t cap)
+// WAVE: all 64 lanes of a (one-wavefront) workgroup call it with the same arguments and share the work the way the reference's AVX code does - the
+// cells of an anti-diagonal only read the two anti-diagonals before it, so they go to the lanes, a barrier between anti-diagonals; every cell is the
+// same expression on the same operands as in the serial form (stale cells outside the clipped range included: nobody writes them), so the result is
+// the serial one bit for bit.  A stretch between two anchors of a noise chain spans hundreds of events (E. coli-scale run: 8 % of the stretches are
+// longer than 256 events and hold 76 % of all anti-diagonals), and one lane walked each of them.
+template <bool WAVE>
+RH_DEV float dtw_banded_t(const float *a, uint32_t a_length, const float *b, uint32_t b_length, int band_radius, bool excl, float *store, uint32_t cap, uint32_t lane)
 {
+	const int L0 = WAVE ? (int)lane : 0, LS = WAVE ? 64 : 1;
 	if (a_length < b_length) { const float *tv = a; const uint32_t tl = a_length; a = b; a_length = b_length; b = tv; b_length = tl; }
 	const int extra = (int)(((a_length - b_length) * (uint32_t)band_radius + a_length - 1u) / a_length);
 	band_radius += extra;
@@ -1313,12 +1320,15 @@ RH_DEV float dtw_banded(const float *a, uint32_t a_length, const float *b, uint3
 	const int dpsize = plen > slen ? plen : slen;
 	if ((uint64_t)dpsize * 3u > cap) return __uint_as_float(0x7FC00000u);
 	float *dp0 = store, *dp1 = store + dpsize, *dp2 = store + 2 * dpsize, *tmp;
-	for (int i = 0; i < dpsize * 3; ++i) store[i] = 1e10f;
+	if (WAVE) { RH_WG_FENCE(); __syncthreads(); }                    // (the buffers may hold what an earlier call of the wavefront left)
+	for (int i = L0; i < dpsize * 3; i += LS) store[i] = 1e10f;
+	if (WAVE) { RH_WG_FENCE(); __syncthreads(); }
 	int center_row = 0;
 	{	// iteration 0: the top left corner
 		const int off = plen / 2;
-		if (0 < (int)b_length && 0 < (int)a_length) { if (primary_larger) dp2[off] = dtw_dist(a[0], b[0]); else dp2[off + 1] = dtw_dist(a[0], b[0]); }
+		if (L0 == 0 && 0 < (int)b_length && 0 < (int)a_length) { if (primary_larger) dp2[off] = dtw_dist(a[0], b[0]); else dp2[off + 1] = dtw_dist(a[0], b[0]); }
 		tmp = dp0; dp0 = dp1; dp1 = dp2; dp2 = tmp;
+		if (WAVE) { RH_WG_FENCE(); __syncthreads(); }
 	}
 	bool prev_inc = false;
 	for (int it = 1; (uint32_t)it < a_length; ++it) {
@@ -1329,7 +1339,7 @@ RH_DEV float dtw_banded(const float *a, uint32_t a_length, const float *b, uint3
 			const int si = center_column + slen / 2 - 1, sj = center_row - slen / 2;
 			int o0 = 0; if (si - (int)a_length + 1 > o0) o0 = si - (int)a_length + 1; if (-sj > o0) o0 = -sj;
 			int o1 = slen; if (si + 1 < o1) o1 = si + 1; if ((int)b_length - sj < o1) o1 = (int)b_length - sj;
-			for (int off = o0; off < o1; ++off) {
+			for (int off = o0 + L0; off < o1; off += LS) {
 				const int i = si - off, j = sj + off;
 				float top, topleft, left;
 				if (primary_larger) { top = dp1[off]; topleft = dp0[off]; left = dp1[off + 1]; }
@@ -1342,11 +1352,12 @@ RH_DEV float dtw_banded(const float *a, uint32_t a_length, const float *b, uint3
 				dp2[off] = dtw_min3(top, left, topleft) + dtw_dist(a[i], b[j]);
 			}
 			tmp = dp0; dp0 = dp1; dp1 = dp2; dp2 = tmp;
+			if (WAVE) { RH_WG_FENCE(); __syncthreads(); }
 		}
 		const int si = center_column + plen / 2, sj = center_row - plen / 2;
 		int o0 = 0; if (si - (int)a_length + 1 > o0) o0 = si - (int)a_length + 1; if (-sj > o0) o0 = -sj;
 		int o1 = plen; if (si + 1 < o1) o1 = si + 1; if ((int)b_length - sj < o1) o1 = (int)b_length - sj;
-		for (int off = o0; off < o1; ++off) {
+		for (int off = o0 + L0; off < o1; off += LS) {
 			const int i = si - off, j = sj + off;
 			const bool is_first = off == 0, is_last = off == plen - 1;
 			float top, topleft, left;
@@ -1361,11 +1372,16 @@ RH_DEV float dtw_banded(const float *a, uint32_t a_length, const float *b, uint3
 			}
 		}
 		tmp = dp0; dp0 = dp1; dp1 = dp2; dp2 = tmp;
+		if (WAVE) { RH_WG_FENCE(); __syncthreads(); }
 		prev_inc = inc;
 	}
 	float res = primary_larger ? dp1[plen / 2] : dp1[plen / 2 + 1];
 	if (excl) res -= dtw_dist(a[a_length - 1], b[b_length - 1]);
 	return res;
+}
+RH_DEV float dtw_banded(const float *a, uint32_t a_length, const float *b, uint32_t b_length, int band_radius, bool excl, float *store, uint32_t cap)
+{
+	return dtw_banded_t<false>(a, a_length, b, b_length, band_radius, excl, store, cap, 0u);
 }
 // one alignment of the "sparse" border constraint: the stretch between anchors `part` and `part + 1` of a chain (rmap.cpp:171-196).  *fits = false
 // (and nothing computed) when the DP does not fit `cap` floats of `dp`.
@@ -1379,6 +1395,28 @@ RH_DEV float dtw_part(const rh_dev_opt &o, const rh_mm128_t *anchors, uint32_t p
 	float sub;
 	if (o.dtw_fill == 0u) { if (qlen > cap) { *fits = false; return 0.0f; } sub = dtw_full(qv, qlen, rv, rlen, excl, dp); }
 	else { int band = (int)((float)qlen * o.dtw_band_frac); if (band < 1) band = 1; sub = dtw_banded(qv, qlen, rv, rlen, band, excl, dp, cap); if (sub != sub) { *fits = false; return 0.0f; } }
+	return sub;
+}
+// ... by the whole wavefront (a long stretch, left over by the lanes' pass): the banded DP in `lds`, or - a band that does not fit it - in the read's
+// global buffer, cooperative either way; the full matrix stays lane 0's.  Lane 0's return value is the one that counts.
+#ifndef DTW_COOP_MIN
+#define DTW_COOP_MIN 48u      // stretches of more events than this (the longer side) are the wavefront's, shorter ones a lane's
+#endif
+RH_DEV float dtw_part_wave(const rh_dev_opt &o, const rh_mm128_t *anchors, uint32_t part, uint32_t parts, const float *ref, const float *ev, float *lds, uint32_t lds_cap, float *gdp, uint32_t g_cap, uint32_t lane, bool *bad)
+{
+	const rh_mm128_t sa = anchors[part], ea = anchors[part + 1];
+	const float *rv = ref + (uint32_t)sa.x; const uint32_t rlen = (uint32_t)ea.x - (uint32_t)sa.x + 1u;
+	const float *qv = ev + (uint32_t)sa.y; const uint32_t qlen = (uint32_t)ea.y - (uint32_t)sa.y + 1u;
+	const bool excl = part != parts - 1u;
+	if (o.dtw_fill == 0u) {
+		float sub = 0.0f;
+		if (lane == 0) { if (qlen > g_cap) *bad = true; else sub = dtw_full(qv, qlen, rv, rlen, excl, gdp); }
+		return sub;
+	}
+	int band = (int)((float)qlen * o.dtw_band_frac); if (band < 1) band = 1;
+	float sub = dtw_banded_t<true>(qv, qlen, rv, rlen, band, excl, lds, lds_cap, lane);
+	if (sub != sub) sub = dtw_banded_t<true>(qv, qlen, rv, rlen, band, excl, gdp, g_cap, lane);
+	if (sub != sub) { *bad = true; sub = 0.0f; }
 	return sub;
 }
 // align_chain rmap.cpp:128-208.  Returns the alignment score (-1e10: abandoned); *bad set if the DP buffers were too small.
@@ -1441,7 +1479,8 @@ __global__ __launch_bounds__(64) void k_regions_dtw(rh_dev_opt o, rh_dev_index i
 	__shared__ float s_dp[64 * DTW_LANE_CAP];
 	__shared__ float s_sub[64];
 	__shared__ uint32_t s_ql[64];
-	__shared__ int32_t s_n;
+	__shared__ int32_t s_n, s_flag;
+	__shared__ float s_best;
 	const uint32_t a = blockIdx.x, lane = threadIdx.x;
 	if (a >= rr.n_act) return;
 	if (lane == 0) rr.dtw_n[a] = 0;
@@ -1484,7 +1523,20 @@ __global__ __launch_bounds__(64) void k_regions_dtw(rh_dev_opt o, rh_dev_index i
 		const rh_reg c = rg[i];
 		const float *ref = ix.sig + ix.sig_off[2 * (size_t)c.rid + (c.rev ? 1u : 0u)];
 		float as = 0.0f;
-		if (o.dtw_border == 0u) { if (lane == 0) as = dtw_align_chain(o, c, an + c.as, ref, ev, best, dp, rr.dtw_stride, &bad); }   // one alignment over the whole chain: serial
+		if (o.dtw_border == 0u && o.dtw_fill != 0u) {	// one alignment over the whole chain (rmap.cpp:141-170), its band across the lanes
+			if (lane == 0) s_best = best;
+			__syncthreads();
+			const uint32_t rlen = (uint32_t)(c.re - c.rs + 1), qlen = (uint32_t)(c.qe - c.qs + 1);
+			if ((float)qlen * o.dtw_match_bonus < s_best) as = -1e10f;
+			else {
+				int band = (int)((float)qlen * o.dtw_band_frac); if (band < 1) band = 1;
+				float cost = dtw_banded_t<true>(ev + c.qs, qlen, ref + c.rs, rlen, band, false, s_dp, 64u * (uint32_t)DTW_LANE_CAP, lane);
+				if (cost != cost) cost = dtw_banded_t<true>(ev + c.qs, qlen, ref + c.rs, rlen, band, false, dp, rr.dtw_stride, lane);
+				if (cost != cost) { bad = true; as = 0.0f; } else as = (float)qlen * o.dtw_match_bonus - cost;
+			}
+			__syncthreads();
+		}
+		else if (o.dtw_border == 0u) { if (lane == 0) as = dtw_align_chain(o, c, an + c.as, ref, ev, best, dp, rr.dtw_stride, &bad); }   // ... full matrix: serial
 		else {
 			const uint32_t parts = (uint32_t)c.cnt - 1u;
 			float cost = 0.0f, cur_max = (float)(uint32_t)(c.qe - c.qs + 1) * o.dtw_match_bonus;
@@ -1492,22 +1544,29 @@ __global__ __launch_bounds__(64) void k_regions_dtw(rh_dev_opt o, rh_dev_index i
 			bool gone = false;
 			for (uint32_t p0 = 0; p0 < parts; p0 += 64) {             // (wave-uniform: `gone` is broadcast below)
 				const uint32_t part = p0 + lane;
-				if (part < parts) {
-					bool fits; uint32_t ql;
-					const float sub = dtw_part(o, an + c.as, part, parts, ref, ev, s_dp + (size_t)lane * DTW_LANE_CAP, (uint32_t)DTW_LANE_CAP, &ql, &fits);
-					s_sub[lane] = fits ? sub : __uint_as_float(0x7FC00000u); s_ql[lane] = ql;
+				if (part < parts) {	// the lanes' pass: short stretches, one each, in the lane's 48 floats of LDS; long ones are left (NaN) for the wavefront
+					const rh_mm128_t sa = (an + c.as)[part], ea = (an + c.as)[part + 1];
+					const uint32_t rl = (uint32_t)ea.x - (uint32_t)sa.x + 1u, ql0 = (uint32_t)ea.y - (uint32_t)sa.y + 1u;
+					if (o.dtw_fill != 0u && (rl > DTW_COOP_MIN || ql0 > DTW_COOP_MIN)) { s_sub[lane] = __uint_as_float(0x7FC00000u); s_ql[lane] = ql0; }
+					else {
+						bool fits; uint32_t ql;
+						const float sub = dtw_part(o, an + c.as, part, parts, ref, ev, s_dp + (size_t)lane * DTW_LANE_CAP, (uint32_t)DTW_LANE_CAP, &ql, &fits);
+						s_sub[lane] = fits ? sub : __uint_as_float(0x7FC00000u); s_ql[lane] = ql;
+					}
 				}
 				__syncthreads();
-				if (lane == 0) {
-					const uint32_t m = parts - p0 < 64u ? parts - p0 : 64u;
-					for (uint32_t q = 0; q < m && !gone; ++q) {
-						if (cur_max < best) { gone = true; break; }           // rmap.cpp:176: the chain cannot beat the best alignment so far any more
-						float sub = s_sub[q];
-						if (sub != sub) { bool fits; uint32_t ql; sub = dtw_part(o, an + c.as, p0 + q, parts, ref, ev, dp, rr.dtw_stride, &ql, &fits); if (!fits) { bad = true; sub = 0.0f; } }
-						cost += sub; cur_max -= sub; n_aligned += s_ql[q];
-					}
-					s_n = gone ? -1 : n_regs;
+				// in part order (fp32 sums are order dependent), with the reference's running early exit; a stretch still open is computed now, by all lanes
+				const uint32_t m = parts - p0 < 64u ? parts - p0 : 64u;
+				for (uint32_t q = 0; q < m; ++q) {
+					if (lane == 0) s_flag = cur_max < best ? 1 : 0;         // rmap.cpp:176: the chain cannot beat the best alignment so far any more
+					__syncthreads();
+					if (s_flag) { gone = true; break; }
+					float sub = s_sub[q];
+					if (sub != sub) sub = dtw_part_wave(o, an + c.as, p0 + q, parts, ref, ev, s_dp, 64u * (uint32_t)DTW_LANE_CAP, dp, rr.dtw_stride, lane, &bad);
+					if (lane == 0) { cost += sub; cur_max -= sub; n_aligned += s_ql[q]; }
+					__syncthreads();
 				}
+				if (lane == 0) s_n = gone ? -1 : n_regs;
 				__syncthreads();
 				if (s_n < 0) break;
 			}
