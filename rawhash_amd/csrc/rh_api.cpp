@@ -1011,6 +1011,9 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 			if (stage_anchors(c, stotal, &rs, cuts.size() > 2 ? budget : 0)) return -1;
 			if (rs.cfmt.rec8 && (rs.max_anchors == 0 || (uint64_t)rs.max_anchors >= (1ull << rs.cfmt.shift))) rs.cfmt = rh_rec_fmt{0, 0, 0, 0};   // (a chain number must fit below the key)
 			if (cuts.size() > 2) c->arena_room = budget;
+			// compact_a's copy of the chains back over the anchors is left out where nothing reads it: the region stage takes the chains' ends from where
+			// they were gathered (not: DTW - it aligns along the chains -, re-chaining, all-vs-all, the serial region kernels' own sort, chains of one anchor)
+			rs.lazy_reorder = (!dtw && !ava && !(o.bw_long > o.bw) && o.min_cnt >= 2 && rhk_regions_fast_ok(o) && !debug_rounds()) ? 1 : 0;
 			// the chained anchors the reads carry into their next chunk: staging arena -> dense carry buffer (all-vs-all: the
 			// reported chains, which the region stage leaves there)
 			auto pack_carry = [&]() -> int {

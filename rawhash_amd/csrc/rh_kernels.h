@@ -146,6 +146,7 @@ struct rh_dev_round {
 	//   cfmt  chain-order keys  key' << shift | chain;   z8  candidates  score << 32 | anchor
 	rh_rec_fmt afmt, cfmt; uint8_t aq_bits, z8, a_span;
 	uint64_t arena_n;                // anchors the 16-byte-per-anchor arenas (raw, anc, zs, prev_out) hold
+	uint8_t lazy_reorder;            // the mapping path's default mode: compact_a's last copy (chains back over the anchor slice in sorted order) is left out - all the region stage reads of it are the first and last anchor of every chain, which it takes from the gathered chains in the carry staging (k_chain_reorder leaves where each sorted chain starts there)
 	int32_t *reg_out;                // stage-level call only (rh_regions_batch): 18 int32 per kept region, region k of active read a at (a_off[a] + k) * 18; null on the mapping path
 };
 
@@ -268,6 +269,7 @@ void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, con
 // RH_M_DTW_EVALUATE_CHAINS: regions + DTW scores (device), MAPQ and decision (host: logf of a float), commit (device)
 void rhk_events_append(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_regions_dtw(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
+bool rhk_regions_fast_ok(const rh_dev_opt &o);   // the primaries-only region kernels apply (default selection: secondaries dropped, not all-chains)
 void rhk_dtw_pack(hipStream_t s, const rh_dev_round &r);
 void rhk_dtw_commit(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act_in, uint32_t n_in, uint32_t next_chunk,

@@ -302,6 +302,17 @@ __global__ __launch_bounds__(NT) void k_chain_keys(rh_dev_round rr, const uint8_
 	chain_keys(rr, base, n_u, (const uint32_t*)(rr.ws + base * rr.ws_stride + (size_t)32 * n), tid);
 }
 
+// rr.lazy_reorder: where sorted chain i starts among the gathered chains of the read (carry staging, rr.prev_out): 4 bytes per chain in the read's scratch, behind
+// the offsets / counts of compact_a (ck0 at 32 n, dk at 36 n, u2 at 40 n: chains have >= 2 anchors, so each ends before the next begins); k_regions_prep writes its
+// heads below 16 n, the serial region kernels read all of it before their core's arrays (from 32 n on at most) are written
+RH_DEV uint32_t *chain_from(const rh_dev_round &rr, uint64_t base, uint32_t n) { return reinterpret_cast<uint32_t*>(rr.ws + base * rr.ws_stride + (size_t)48 * n); }
+// first and last anchor of sorted chain i (k = its offset among the read's chained anchors in sorted order, cnt = its length)
+RH_DEV void chain_ends(const rh_dev_round &rr, uint64_t base, uint32_t n, uint32_t i, uint32_t k, uint32_t cnt, rh_mm128_t &f0, rh_mm128_t &f1)
+{
+	if (rr.lazy_reorder) { const uint32_t fr = chain_from(rr, base, n)[i]; f0 = rh_an_ld(rr, rr.prev_out, base + fr); f1 = rh_an_ld(rr, rr.prev_out, base + fr + cnt - 1); }
+	else { f0 = rh_an_ld(rr, rr.anc, base + k); f1 = rh_an_ld(rr, rr.anc, base + k + cnt - 1); }
+}
+
 __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_round rr)
 {
 	__shared__ uint32_t s_w[NT / 64];
@@ -336,6 +347,10 @@ __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_ro
 	}
 	__syncthreads();
 	const uint32_t *tab = dk;
+	if (rr.lazy_reorder) {	// no copy: the region stage finds the chains where they were gathered
+		uint32_t *fk = chain_from(rr, base, n);
+		for (uint32_t i = tid; i < n_u; i += NT) fk[i] = CR_FROM(i);
+	} else {
 	if (n_u <= CG_CAP) { for (uint32_t i = tid; i < n_u; i += NT) s_off[i] = dk[i]; tab = s_off; __syncthreads(); }
 	if (n_u <= CG_CAP) {
 		for (uint32_t q = tid; q < n_v; q += NT) {
@@ -358,6 +373,7 @@ __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_ro
 				for (uint32_t j = l; j < nn; j += 64) rh_an_cp(rr, rr.anc, base + tt + j, rr.prev_out, base + ff + j);
 			}
 		}
+	}
 	}
 	#undef CR_CHAIN
 	#undef CR_FROM
@@ -654,9 +670,14 @@ __global__ __launch_bounds__(64) void k_regions(rh_dev_opt o, rh_dev_reads rd, r
 	__syncthreads();
 	if (lane == 0) { uint32_t k = 0; for (int32_t i = 0; i < n_u; ++i) { L.k0[i] = k; k += (uint32_t)L.u[i]; } }
 	__syncthreads();
+	const uint32_t n_an = (uint32_t)(rr.a_off[a + 1] - base);
+	// (rr.lazy_reorder: the gathered chains of a read with a long chain list may have served the region sort as scratch by now - k_regions_prep took its heads before)
+	const bool from_prep = rr.lazy_reorder && n_u > RG_SMALL;
 	for (int32_t i = (int32_t)lane; i < n_u; i += 64) {
 		const uint32_t k = L.k0[i], cnt = (uint32_t)L.u[i];
-		const rh_mm128_t f0 = rh_an_ld(rr, rr.anc, base + k), f1 = rh_an_ld(rr, rr.anc, base + k + cnt - 1);
+		if (from_prep) { L.ch[i] = ((const rh_chain_head*)(rr.ws + base * rr.ws_stride))[i]; continue; }
+		rh_mm128_t f0, f1;
+		chain_ends(rr, base, n_an, (uint32_t)i, k, cnt, f0, f1);
 		rh_chain_head h; h.x0 = f0.x; h.y0 = f0.y; h.x1 = (int32_t)f1.x; h.y1 = (int32_t)f1.y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
 		L.ch[i] = h;
 	}
@@ -690,11 +711,17 @@ __global__ void k_regions_big(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, co
 	int32_t *w = (int32_t*)(wsr + (size_t)120 * n_u), *tmp = (int32_t*)(wsr + (size_t)124 * n_u);
 	uint32_t *cw = (uint32_t*)rg;                                    // the sort runs before rg[] is populated
 	uint32_t k = 0;
+	const uint32_t n_an = (uint32_t)(rr.a_off[a + 1] - base);
+	const bool from_prep = rr.lazy_reorder && n_u > RG_SMALL;          // (see k_regions; the heads lie where rg[] goes: copied first)
 	for (int32_t i = 0; i < n_u; ++i) {
 		const uint32_t cnt = (uint32_t)u[i];
-		const rh_mm128_t f0 = rh_an_ld(rr, rr.anc, base + k), f1 = rh_an_ld(rr, rr.anc, base + k + cnt - 1);
-		rh_chain_head h; h.x0 = f0.x; h.y0 = f0.y; h.x1 = (int32_t)f1.x; h.y1 = (int32_t)f1.y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
-		ch[i] = h;
+		if (from_prep) { rh_chain_head h = ((const rh_chain_head*)wsr)[i]; ch[i] = h; }
+		else {
+			rh_mm128_t f0, f1;
+			chain_ends(rr, base, n_an, (uint32_t)i, k, cnt, f0, f1);
+			rh_chain_head h; h.x0 = f0.x; h.y0 = f0.y; h.x1 = (int32_t)f1.x; h.y1 = (int32_t)f1.y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
+			ch[i] = h;
+		}
 		k += cnt;
 	}
 	int stop;
@@ -735,7 +762,11 @@ __global__ __launch_bounds__(NT) void k_regions_prep(rh_dev_opt o, rh_dev_reads 
 		uint32_t tot;
 		const uint32_t k = carry + block_excl_scan(cnt, s_w, tot);
 		if (i < n_u) {
-			const rh_mm128_t f0 = rh_an_ld(rr, rr.anc, base + k), f1 = rh_an_ld(rr, rr.anc, base + k + cnt - 1);
+			rh_mm128_t f0, f1;
+			if (skip2 && rr.lazy_reorder) {	// the keys once more (exact re-run): the heads are there - and the gathered chains may have been the first sort's scratch
+				const rh_chain_head h0 = heads[i];
+				f0.x = h0.x0; f0.y = h0.y0; f1.x = (uint64_t)(uint32_t)h0.x1; f1.y = (uint64_t)(uint32_t)h0.y1;
+			} else chain_ends(rr, base, (uint32_t)(rr.a_off[a + 1] - base), (uint32_t)i, k, cnt, f0, f1);
 			rh_chain_head h; h.x0 = f0.x; h.y0 = f0.y; h.x1 = (int32_t)f1.x; h.y1 = (int32_t)f1.y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
 			heads[i] = h;
 			const uint32_t hh = (uint32_t)rh_mix64_nomask((rh_mix64_nomask(f0.x) + rh_mix64_nomask(f0.y)) ^ (uint64_t)hash);
@@ -1663,6 +1694,7 @@ int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, co
 }
 
 static bool regions_wave_ok(const rh_dev_opt &o) { return o.best_n == 0 && o.pri_ratio > 0.0f && !(o.flag & RH_M_ALL_CHAINS); }
+bool rhk_regions_fast_ok(const rh_dev_opt &o) { return regions_wave_ok(o); }
 
 // chain heads + hashed keys of reads with many chains, put into the reference's order (hit.c:111-126)
 int rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
