@@ -396,7 +396,7 @@ int stage_anchors(rh_ctx *c, uint64_t total, rh_dev_round *rr, uint64_t room = 0
 	return 0;
 }
 // bytes of device memory a slice needs per anchor (the arrays above + the sorter's tables)
-size_t bytes_per_anchor(const rh_ctx *c) { return 16 * 4 + 8 + (size_t)c->ws_stride + 18; }
+size_t bytes_per_anchor(const rh_ctx *c) { return 16 * 4 + 8 + (size_t)c->ws_stride + 23; }
 
 // anchors one slice of a round may hold: what is free on the device (plus what this context's arenas hold already), shared
 // by the sub-batches running concurrently; RH_ARENA_MAX_BYTES caps the per-anchor scratch (shared devices, tests)

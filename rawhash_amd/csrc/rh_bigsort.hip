@@ -35,6 +35,30 @@
 #ifndef BS_WIN_BYTES
 #define BS_WIN_BYTES 4096                 // LDS of the token walk's stream windows (>= 512: two entries for each of 256 regions)
 #endif
+// the block-parallel walk (K7' below)
+#ifndef PW_MIN_HOLES
+#define PW_MIN_HOLES 4096                 // ranges with fewer holes stay with the serial walkers
+#endif
+#ifndef PW_MIN_C0
+#define PW_MIN_C0 512                     // ... and so do ranges whose first region starts fewer cycles than this,
+#endif
+#ifndef PW_MAX_CYCLE
+#define PW_MAX_CYCLE 8                    // ... or whose cycles would be longer than this on average (holes / cycles of the first region)
+#endif
+#ifndef PW_MIN_PAR
+#define PW_MIN_PAR 16                     // a base region with fewer cycles left is walked by one lane on the spot
+#endif
+#ifndef PW_WIN_CAP
+#define PW_WIN_CAP 12288                  // holes of one work item of k_bs_pw_walk (their digits are staged in LDS; 16-bit window addresses)
+#endif
+#ifdef RH_DEV
+#define PW_STAT(i, n) atomicAdd(&C.hdr[20 + (i)], (uint32_t)(n))   // development builds: [20] blocks walked by one lane, [21] ranges out of slots, [22] ring misses, [23] cycles walked by one lane
+#else
+#define PW_STAT(i, n) ((void)0)
+#endif
+#ifndef PW_RING_BYTES
+#define PW_RING_BYTES 8192                // LDS of k_bs_pw_count's digit rings, shared by the regions of its class
+#endif
 
 struct bs_range {
 	uint64_t beg;                         // absolute record offset of the range in the job's arrays
@@ -59,6 +83,7 @@ struct bs_meta {
 	uint8_t act[256], dmap[256];          // regions with holes, renumbered 0 .. nh-1 in digit order: dense -> digit, digit -> dense
 	int32_t s;                            // byte shift of this level (-1: all keys equal)
 	uint32_t nh;
+	uint32_t pw, pw_off, pw_slots;        // block-parallel walk (k_bs_pw_count / k_bs_pw_walk): 0 or rounds per block; the range's snapshot slots in C.pw_snap (word offset, number)
 };
 enum { BS_EMPTY = 0, BS_FINAL = 1, BS_SMALL = 2, BS_BIG = 3 };
 
@@ -79,7 +104,11 @@ struct bs_ctx {
 	// bucket of more than one record (k_bs_plan), or the block sorter's tie flag of a bucket (small_tie, read by k_bs_tie_map) - and clears
 	// redo_skip of the segment the bucket lies in (found by position in seg_off): no pass over the sorted records to look for equal neighbours
 	const uint64_t *seg_off; uint32_t seg_n; uint8_t *redo_skip; uint8_t *small_tie[4];
+	// block-parallel walk: pointer snapshots (pw_words 32-bit words, handed out per range by k_bs_scan through hdr[18]) and the blocks grouped
+	// into work items for k_bs_pw_walk, two lists (ranges with up to 64 / up to 256 regions that have holes; counted in hdr[16], hdr[17])
+	uint32_t *pw_snap; uint32_t pw_words; struct bs_pw_item *pw_items[2]; uint32_t pw_item_cap;
 };
+struct bs_pw_item { uint32_t r, slot0, nb, pad; };
 RH_DEV void bs_mark_tie(const bs_ctx &C, uint64_t pos)
 {
 	uint32_t lo = 0, hi = C.seg_n;                                  // the last segment that starts at or before pos
@@ -127,7 +156,7 @@ __global__ __launch_bounds__(NT) void k_bs_init(rh_sort_job jb, bs_ctx C)
 		if (tid == 0) { s_run[0] += tot_r; s_run[1] += tot_t; }
 		__syncthreads();
 	}
-	if (tid == 0) { C.hdr[0] = s_run[0]; C.hdr[1] = s_run[1]; C.hdr[2] = 0; C.hdr[3] = 0; C.hdr[4] = 0; C.hdr[5] = 0; C.hdr[6] = 0; C.hdr[7] = s_run[0] > C.rng_cap ? 1u : 0u; C.hdr[8] = 0; C.hdr[9] = 0; C.hdr[10] = 0; C.hdr[11] = 0; C.hdr[12] = 0; C.hdr[13] = 0; C.hdr[14] = 0; C.hdr[15] = 0; }
+	if (tid == 0) { C.hdr[0] = s_run[0]; C.hdr[1] = s_run[1]; C.hdr[2] = 0; C.hdr[3] = 0; C.hdr[4] = 0; C.hdr[5] = 0; C.hdr[6] = 0; C.hdr[7] = s_run[0] > C.rng_cap ? 1u : 0u; C.hdr[8] = 0; C.hdr[9] = 0; C.hdr[10] = 0; C.hdr[11] = 0; C.hdr[12] = 0; C.hdr[13] = 0; C.hdr[14] = 0; C.hdr[15] = 0; C.hdr[16] = 0; C.hdr[17] = 0; C.hdr[18] = 0; C.hdr[19] = 0; }
 }
 
 __global__ __launch_bounds__(NT) void k_bs_clear(bs_ctx C)
@@ -136,6 +165,7 @@ __global__ __launch_bounds__(NT) void k_bs_clear(bs_ctx C)
 	if (r >= C.hdr[0]) return;
 	bs_meta &M = C.meta[r];
 	M.cnt[tid] = 0; M.inpl[tid] = 0;
+	if (r == 0 && tid < 8) C.hdr[16 + tid] = 0;                      // (the level's work items and snapshot cursor of the block-parallel walk)
 	// a range whose digits came with it: its keys are not read again; the parent's differing bits stand in for its own (their
 	// highest byte is the byte the digits were taken from; k_bs_fix looks at the keys if the range turns out to agree on it)
 	if (tid == 0) { const bs_range R = C.rng[0][r]; if (R.has_dg) { M.k_or = R.dmask; M.k_and = 0; } else { M.k_or = 0; M.k_and = ~0ull; } }
@@ -488,7 +518,30 @@ __global__ __launch_bounds__(NT) void k_bs_scan(bs_ctx C)
 	M.dmap[tid] = (uint8_t)q;
 	if (m != 0) M.act[q] = (uint8_t)tid;
 	M.J[tid] = 0;
-	if (tid == 0) { M.hst[256] = total; M.nh = nh; }
+	// Block-parallel walk (k_bs_pw_count / k_bs_pw_walk below) for the ranges whose first region starts a sizeable share of the cycles - the
+	// candidates of the backtrack: the chains of one anchor all have the lowest score.  The range gets its snapshot slots here.
+	__shared__ uint32_t s_c0;
+	if (m != 0 && q == 0) s_c0 = m;
+	__syncthreads();
+	if (tid == 0) {
+		M.hst[256] = total; M.nh = nh;
+		uint32_t pw = 0, off = 0, slots = 0;
+		if (C.pw_snap && nh >= 3 && nh <= 256 && total >= (uint32_t)PW_MIN_HOLES && s_c0 >= (uint32_t)PW_MIN_C0 && (uint64_t)s_c0 * PW_MAX_CYCLE >= total && R.beg + total < (1ull << 32)) {
+			const uint32_t bstride = (nh + 64u) / 64u;               // rounds per block: a snapshot is nh + 1 words
+			// snapshot slots: a cycle has >= 2 holes, so the first region's c0 cycles pop >= 2 c0 holes and the later base regions start at most
+			// (holes - 2 c0) / 2 cycles; those of them that get blocks (>= PW_MIN_PAR cycles) end in a partial block and may cost a closing snapshot
+			const uint32_t rest = total - 2u * s_c0 < total ? total - 2u * s_c0 : 0u, later = rest / (2u * (uint32_t)PW_MIN_PAR);
+			const uint32_t nph = later < nh - 1u ? later : nh - 1u;
+			slots = (total - s_c0) / (64u * bstride) + 2u * nph + 4u;
+#ifdef PW_TEST_FEW_SLOTS
+			slots = slots / 8u + 3u;                                  // (test builds: ranges run out of slots and finish with one lane)
+#endif
+			const uint32_t need = slots * (nh + 1u);
+			const unsigned long long o64 = atomicAdd(reinterpret_cast<unsigned long long*>(C.hdr + 18), (unsigned long long)need);   // (hdr[18..19]: one 64-bit cursor)
+			if (o64 + need <= (unsigned long long)C.pw_words) { pw = bstride; off = (uint32_t)o64; }
+		}
+		M.pw = pw; M.pw_off = off; M.pw_slots = slots;
+	}
 }
 
 // K6: the holes in position order: digit of the record, position
@@ -553,7 +606,7 @@ __global__ __launch_bounds__(64) void k_bs_walk_lanes(bs_ctx C, uint32_t nh_lo)
 	const uint32_t lane = threadIdx.x, r = blockIdx.x * L + lane, n_rng = C.hdr[0];
 	bool mine = lane < (uint32_t)L && r < n_rng;
 	uint32_t nh = 0;
-	if (mine) { nh = C.meta[r].nh; mine = nh > nh_lo && nh <= (uint32_t)NHM && nh > 2; }
+	if (mine) { nh = C.meta[r].nh; mine = nh > nh_lo && nh <= (uint32_t)NHM && nh > 2 && !C.meta[r].pw; }
 	if (__ballot(mine) == 0) return;
 	const bs_range R = C.rng[0][mine ? r : 0];
 	bs_meta &M = C.meta[mine ? r : 0];
@@ -644,7 +697,7 @@ __global__ __launch_bounds__(64) void k_bs_walk_wave(bs_ctx C, uint32_t skip_lo,
 	const bs_range R = C.rng[0][r];
 	bs_meta &M = C.meta[r];
 	const uint32_t nh = M.nh;
-	if (nh == 0 || (nh >= skip_lo && nh <= skip_hi)) return;
+	if (nh == 0 || (nh >= skip_lo && nh <= skip_hi) || M.pw) return;                // (M.pw: the block-parallel walk's)
 	for (uint32_t q = lane; q < nh; q += 64) { const uint32_t dk = M.act[q]; s_h0[q] = M.hst[dk]; s_end[q] = M.hst[dk + 1u]; }
 	__syncthreads();
 	const uint8_t *hd = C.hd + R.beg;
@@ -742,7 +795,7 @@ __global__ __launch_bounds__(64) void k_bs_walk_multi(bs_ctx C)
 	const uint32_t lane = threadIdx.x, n_rng = C.hdr[0], r0 = blockIdx.x * G;
 	if (lane < (uint32_t)G) {
 		uint32_t nh = 0, beg = 0;
-		if (r0 + lane < n_rng) { nh = C.meta[r0 + lane].nh; beg = C.rng[0][r0 + lane].beg; if (nh < 3 || nh > (uint32_t)NHM) nh = 0; }
+		if (r0 + lane < n_rng) { nh = C.meta[r0 + lane].nh; beg = C.rng[0][r0 + lane].beg; if (nh < 3 || nh > (uint32_t)NHM || C.meta[r0 + lane].pw) nh = 0; }
 		s_nh[lane] = nh; s_beg[lane] = beg;
 	}
 	__syncthreads();
@@ -865,7 +918,7 @@ __global__ __launch_bounds__(64) void k_bs_walk_tok(bs_ctx C, uint32_t nh_lo, ui
 	if (r >= C.hdr[0]) return;
 	bs_meta &M = C.meta[r];
 	const uint32_t nh = M.nh;
-	if (nh < nh_lo || nh > nh_hi) return;
+	if (nh < nh_lo || nh > nh_hi || M.pw) return;
 	const uint32_t beg = (uint32_t)C.rng[0][r].beg;                 // (the host takes this kernel only when every absolute hole address fits 32 bits)
 	// this lane's regions: q = lane + 64 t
 	bool on[RPL];
@@ -961,6 +1014,277 @@ __global__ __launch_bounds__(64) void k_bs_walk_tok(bs_ctx C, uint32_t nh_lo, ui
 	#undef BS_TK_ISSUE
 	#undef BS_TK_COMMIT
 	#undef BS_TK_READ
+}
+
+
+// ------------------------------------------------------------------------------------------------ K7': the block-parallel walk
+// The token walk is a ROTOR WALK: every region hands its holes out in position order, whoever arrives.  Seen from one base region k it is
+// a sequence of cycles - pop k's next hole, follow the record found there to its region, pop that region's next hole, ... until a record
+// of k turns up - and the networks of that kind are ABELIAN: if several cycles are followed at the same time, in any interleaving, every
+// region has popped exactly as many holes at the end as if they had been followed one after the other (each region serves its arrivals in
+// its own fixed order, so the NUMBER of pops per region does not depend on the schedule; only who gets which hole does).  So
+//   * k_bs_pw_count (one wavefront per range) follows 64 cycles at a time, one per lane, popping with LDS atomics: the pointers of all
+//     regions after every 64 (128, ...) cycles - "snapshots" - are exact although the pops in between were handed out in the wrong order;
+//   * k_bs_pw_walk walks every block of cycles between two snapshots again, serially and therefore in the reference's order, but ALL BLOCKS
+//     AT ONCE, one lane per block (64 blocks = one work item per wavefront, the digits of the item's stretch of every region staged in LDS,
+//     the lane's private pointers as 16-bit window addresses): this pass writes dest[].
+// Phases (base regions) with a handful of cycles, a block that pops more holes than an item's window takes, and whatever is left when a
+// range runs out of snapshot slots are walked by one lane of k_bs_pw_count itself.  A range qualifies (k_bs_scan) when its first region
+// starts many short cycles: the backtrack candidates, whose lowest score - the chains of one anchor - holds half the records, so that
+// every second hole elsewhere ends a cycle (measured at human scale: 6 500 - 19 000 ranges of 50 000 - 240 000 holes per level; the
+// serial walkers took one wavefront 60 - 120 ns per hole and the level as long as its longest range).
+template <int NHM>
+__global__ __launch_bounds__(64) void k_bs_pw_count(bs_ctx C)
+{
+	static_assert(PW_RING_BYTES / NHM >= 16 && PW_WIN_CAP < 65000, "a ring takes 16-byte chunks; window addresses are 16 bits");
+	constexpr int RPL = NHM / 64, RING = PW_RING_BYTES / NHM, NCH = 4 / RPL, CLS = NHM > 64 ? 1 : 0;   // regions per lane; bytes of a region's digit ring; 16-byte chunks it may take per round
+	__shared__ __attribute__((aligned(16))) uint8_t s_ring[NHM * RING];
+	__shared__ uint32_t s_ptr[NHM], s_lim[NHM], s_end[NHM];            // next hole, digits in the ring up to, end of the region's holes (absolute hole addresses)
+	__shared__ uint32_t s_pops, s_err;
+	const uint32_t lane = threadIdx.x, r = blockIdx.x;
+	if (r >= C.hdr[0]) return;
+	bs_meta &M = C.meta[r];
+	const uint32_t bstride = M.pw, nh = M.nh;
+	if (!bstride || nh > (uint32_t)NHM || (CLS == 1 && nh <= 64u)) return;
+	const uint32_t beg = (uint32_t)C.rng[0][r].beg, stride = nh + 1u, n_slots = M.pw_slots, n_holes = M.hst[256];
+	uint32_t *snap = C.pw_snap + M.pw_off;
+	const uint8_t *hd = C.hd;
+	uint32_t *dest = C.dest;
+	bool on[RPL];
+	uint32_t ld_n[RPL];
+	uint4 ch[RPL][NCH];
+#pragma unroll
+	for (int t = 0; t < RPL; ++t) {
+		const uint32_t q = lane + 64u * (uint32_t)t;
+		on[t] = q < nh; ld_n[t] = 0;
+#pragma unroll
+		for (int c = 0; c < NCH; ++c) ch[t][c] = uint4{0, 0, 0, 0};
+		if (on[t]) { const uint32_t dk = M.act[q], p0 = beg + M.hst[dk]; s_ptr[q] = p0; s_end[q] = beg + M.hst[dk + 1u]; s_lim[q] = p0 & ~15u; }
+	}
+	if (lane == 0) { s_pops = 0; s_err = 0; }
+	__syncthreads();
+	// A region's ring holds the digits of the holes [lim - RING, lim) at slot (address & (RING - 1)); chunks are requested at the start of a
+	// round and stored at its end, and never reach beyond (pointer at request time, rounded down) + RING: nothing a later pop needs is overwritten.
+	// (macros, not lambdas: a closure that captures the chunk registers by reference keeps them in scratch memory)
+	#define PW_ISSUE() do { _Pragma("unroll") for (int t = 0; t < RPL; ++t) { \
+		ld_n[t] = 0; \
+		if (on[t]) { const uint32_t q_ = lane + 64u * (uint32_t)t, lm_ = s_lim[q_], en_ = s_end[q_], top_ = (s_ptr[q_] & ~15u) + (uint32_t)RING; \
+			_Pragma("unroll") for (int c = 0; c < NCH; ++c) { const uint32_t a_ = lm_ + 16u * (uint32_t)c; \
+				if (a_ < en_ && a_ + 16u <= top_) { ch[t][c] = *reinterpret_cast<const uint4*>(hd + a_); ld_n[t] = (uint32_t)c + 1u; } } } } } while (0)
+	#define PW_COMMIT() do { _Pragma("unroll") for (int t = 0; t < RPL; ++t) { \
+		if (on[t] && ld_n[t]) { const uint32_t q_ = lane + 64u * (uint32_t)t, lm_ = s_lim[q_]; \
+			_Pragma("unroll") for (int c = 0; c < NCH; ++c) \
+				if ((uint32_t)c < ld_n[t]) *reinterpret_cast<uint4*>(s_ring + q_ * (uint32_t)RING + ((lm_ + 16u * (uint32_t)c) & (uint32_t)(RING - 1))) = ch[t][c]; \
+			s_lim[q_] = lm_ + 16u * ld_n[t]; } } } while (0)
+	#define PW_REFILL() do { PW_ISSUE(); PW_COMMIT(); __syncthreads(); } while (0)
+	// one lane, ncyc cycles of base region k from the pointers as they stand, in the reference's order (ksort.h:124-138)
+	auto serial = [&](uint32_t k, uint32_t ncyc) RH_INLINE_LAMBDA {
+		if (lane == 0) {
+			uint32_t steps = 0;
+			for (uint32_t c = 0; c < ncyc && !s_err; ++c) {
+				const uint32_t i0 = s_ptr[k];
+				s_ptr[k] = i0 + 1u;
+				uint32_t i = i0, q = k;
+				for (;;) {
+					const uint32_t lm = s_lim[q];
+					const uint32_t d = (uint32_t)(lm - 1u - i) < (uint32_t)RING ? s_ring[q * (uint32_t)RING + (i & (uint32_t)(RING - 1))] : hd[i];   // the digit in hole i of region q
+					if (d == k) break;
+					if (d >= nh || s_ptr[d] >= s_end[d] || ++steps > n_holes) { s_err = 1; break; }
+					const uint32_t j = s_ptr[d];
+					s_ptr[d] = j + 1u;
+					dest[i] = j - beg;
+					i = j; q = d;
+				}
+				dest[i] = i0 - beg;
+			}
+		}
+		__syncthreads();
+	};
+	for (int f = 0; f < RING / (16 * NCH); ++f) PW_REFILL();
+	uint32_t slot = 0, it_slot0 = 0, it_nb = 0, it_pops = 0;       // (wave-uniform)
+	auto emit = [&]() RH_INLINE_LAMBDA {
+		if (lane == 0 && it_nb) {
+			const uint32_t ix = atomicAdd(&C.hdr[16 + CLS], 1u);
+			if (ix < C.pw_item_cap) { bs_pw_item I; I.r = r; I.slot0 = it_slot0; I.nb = it_nb; I.pad = 0; C.pw_items[CLS][ix] = I; }
+			else C.hdr[7] = 1;
+		}
+		it_nb = 0; it_pops = 0;
+	};
+	auto snapshot = [&](uint32_t sl, uint32_t kword) RH_INLINE_LAMBDA {
+#pragma unroll
+		for (int t = 0; t < RPL; ++t) if (on[t]) { const uint32_t q = lane + 64u * (uint32_t)t; snap[(size_t)sl * stride + q] = s_ptr[q]; }
+		if (lane == 0) snap[(size_t)sl * stride + nh] = kword;
+		__syncthreads();                                               // (every lane has read its pointers before lane 0 moves the base region's)
+	};
+	auto close_item = [&]() RH_INLINE_LAMBDA { if (it_nb) { snapshot(slot, 0u); ++slot; emit(); } };   // the pointers as they stand end the open item
+	bool over = false;
+	for (uint32_t k = 0; k < nh; ++k) {
+		uint32_t kp = rh_uniform(s_ptr[k]);
+		const uint32_t endk = rh_uniform(s_end[k]);
+		if (k && lane == 0) { const uint32_t dk = M.act[k]; M.J[dk] = kp - beg - M.hst[dk]; }   // arrivals so far = J
+		while (kp < endk) {
+			if (over || endk - kp < (uint32_t)PW_MIN_PAR || slot + 2u > n_slots) {
+				if (endk - kp >= (uint32_t)PW_MIN_PAR && !over) { over = true; if (lane == 0) PW_STAT(1, 1); }   // out of snapshot slots: the rest of the range is one lane's
+				close_item();
+				while (kp < endk) {
+					const uint32_t n = endk - kp < 64u ? endk - kp : 64u;
+					serial(k, n);
+					if (lane == 0) PW_STAT(3, n);
+					if (s_err) { if (lane == 0) C.hdr[7] = 2; return; }
+					kp += n;
+					PW_REFILL();
+				}
+				break;
+			}
+			// a block: bstride rounds of up to 64 cycles, one per lane
+			const uint32_t bslot = slot++;
+			snapshot(bslot, k);
+			uint32_t ncy = 0, bad_d = 0;
+			uint32_t d_nxt = lane < endk - kp ? (uint32_t)hd[kp + lane] : 0u;   // the digits in the holes that start this round's cycles (always requested a round ahead)
+			for (uint32_t rr = 0; rr < bstride && kp < endk; ++rr) {
+				const uint32_t nch = endk - kp < 64u ? endk - kp : 64u;
+				bool live = lane < nch, parked = false;
+				uint32_t d = d_nxt, pj = 0;
+				RH_VALUE_READY(d);                                         // (its load is waited for HERE: no wait for memory inside the loop below, where the ring chunks are in flight)
+				d_nxt = kp + 64u + lane < endk ? (uint32_t)hd[kp + 64u + lane] : 0u;
+				PW_ISSUE();
+				if (lane == 0) s_ptr[k] = kp + nch;
+				for (uint32_t itn = 0;;) {
+					for (; __ballot(live); ++itn) {
+						if (itn > n_holes) { bad_d = 1; live = false; parked = false; continue; }   // (cannot happen with consistent hole lists: every pop uses up a hole)
+						if (live) {
+							const uint32_t j = atomicAdd(&s_ptr[d], 1u);
+							const bool miss = j >= s_lim[d];
+							const uint32_t dn = s_ring[d * (uint32_t)RING + (j & (uint32_t)(RING - 1))];
+							if (miss) { parked = true; pj = j; live = false; PW_STAT(2, 1); }   // beyond what the ring holds (a region popped more than it was refilled): the lane waits below
+							else { bad_d |= dn >= nh ? 1u : 0u; live = dn != k && dn < nh; d = dn; }
+						}
+					}
+					if (!__ballot(parked)) break;
+					if (parked) {                                           // ... for the digit from memory, and goes on (any interleaving of the cycles is as good as any other)
+						const uint32_t dn = hd[pj];
+						parked = false; bad_d |= dn >= nh ? 1u : 0u; live = dn != k && dn < nh; d = dn;
+					}
+				}
+				__syncthreads();
+				PW_COMMIT();
+				kp += nch; ncy += nch;
+			}
+			if (bad_d) s_err = 1;
+			// holes this block popped: the sum of the pointers' advances
+			{
+				uint32_t adv = 0;
+#pragma unroll
+				for (int t = 0; t < RPL; ++t) if (on[t]) { const uint32_t q = lane + 64u * (uint32_t)t; adv += s_ptr[q] - snap[(size_t)bslot * stride + q]; }
+				if (adv) atomicAdd(&s_pops, adv);
+			}
+			__syncthreads();
+			const uint32_t bp = rh_uniform(s_pops);
+			bool bad = s_err != 0;
+#pragma unroll
+			for (int t = 0; t < RPL; ++t) if (on[t]) { const uint32_t q = lane + 64u * (uint32_t)t; bad |= s_ptr[q] > s_end[q]; }
+			__syncthreads();
+			if (lane == 0) s_pops = 0;
+			if (__ballot(bad)) { if (lane == 0) C.hdr[7] = 2; return; }
+			if (bp > (uint32_t)PW_WIN_CAP) {
+				// more holes than an item's window takes: the open item ends where this block began (its snapshot), and the block is walked
+				// again by one lane from there
+				emit();
+				if (lane == 0) PW_STAT(0, 1);
+#pragma unroll
+				for (int t = 0; t < RPL; ++t) if (on[t]) { const uint32_t q = lane + 64u * (uint32_t)t, p0 = snap[(size_t)bslot * stride + q]; s_ptr[q] = p0; s_lim[q] = p0 & ~15u; }
+				__syncthreads();
+				for (int f = 0; f < RING / (16 * NCH); ++f) PW_REFILL();
+				for (uint32_t c0 = 0; c0 < ncy; c0 += 64u) {
+					serial(k, ncy - c0 < 64u ? ncy - c0 : 64u);
+					if (s_err) { if (lane == 0) C.hdr[7] = 2; return; }
+					PW_REFILL();
+				}
+			} else {
+				if (it_nb == 64u || it_pops + bp > (uint32_t)PW_WIN_CAP) emit();   // (the open item ends at this block's snapshot, which follows its last one)
+				if (it_nb == 0) it_slot0 = bslot;
+				++it_nb; it_pops += bp;
+			}
+		}
+	}
+	close_item();
+	#undef PW_ISSUE
+	#undef PW_COMMIT
+	#undef PW_REFILL
+}
+
+template <int NHM>
+__global__ __launch_bounds__(64) void k_bs_pw_walk(bs_ctx C)
+{
+	constexpr int RPL = NHM / 64, CS = 66, CLS = NHM > 64 ? 1 : 0;       // CS: row of one region's 64 pointers, padded (bank conflicts of the transposed set-up)
+	__shared__ uint16_t s_cnt[NHM * CS];                               // [region][block]: the block's next hole of the region, as a window address
+	__shared__ uint8_t s_win[PW_WIN_CAP + 16];
+	__shared__ uint32_t s_wb[NHM], s_woff[NHM + 1], s_jadj[NHM];      // first hole of the item's stretch, where the stretch starts in the window, window address -> hole index within the range
+	const uint32_t lane = threadIdx.x;
+	uint32_t n_items = C.hdr[16 + CLS];
+	if (n_items > C.pw_item_cap) n_items = C.pw_item_cap;
+	for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+		const bs_pw_item I = C.pw_items[CLS][it];
+		const bs_meta &M = C.meta[I.r];
+		const uint32_t nh = M.nh, stride = nh + 1u, nb = I.nb, beg = (uint32_t)C.rng[0][I.r].beg;
+		const uint32_t *S = C.pw_snap + M.pw_off + (size_t)I.slot0 * stride;
+		uint32_t run = 0;
+#pragma unroll
+		for (int t = 0; t < RPL; ++t) {
+			const uint32_t q = lane + 64u * (uint32_t)t;
+			uint32_t wb = 0, len = 0;
+			if (q < nh) { wb = S[q]; len = S[(size_t)nb * stride + q] - wb; }
+			uint32_t inc = len;
+			for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d); if (lane >= (uint32_t)d) inc += u; }
+			const uint32_t tot = __shfl(inc, 63);
+			if (q < nh) { const uint32_t wo = run + inc - len; s_wb[q] = wb; s_woff[q] = wo; s_jadj[q] = wb - beg - wo; }
+			run += tot;
+		}
+		if (lane == 0) s_woff[nh] = run;
+		__syncthreads();
+		if (run > (uint32_t)PW_WIN_CAP || nb == 0 || nb > 64u) { if (lane == 0) C.hdr[7] = 2; __syncthreads(); continue; }
+		// the digits of the item's holes
+#pragma unroll 4
+		for (uint32_t q = 0; q < nh; ++q) {
+			const uint32_t wb = s_wb[q], wo = s_woff[q], len = s_woff[q + 1u] - wo;
+			for (uint32_t o = lane; o < len; o += 64u) s_win[wo + o] = C.hd[wb + o];
+		}
+		// every block's pointers at its start
+#pragma unroll 4
+		for (uint32_t b = 0; b < nb; ++b) {
+#pragma unroll
+			for (int t = 0; t < RPL; ++t) {
+				const uint32_t q = lane + 64u * (uint32_t)t;
+				if (q < nh) s_cnt[q * (uint32_t)CS + b] = (uint16_t)(s_woff[q] + (S[(size_t)b * stride + q] - s_wb[q]));
+			}
+		}
+		__syncthreads();
+		bool live = lane < nb;
+		uint32_t k = 0, kend = 0;
+		if (live) {
+			k = S[(size_t)lane * stride + nh];
+			if (k >= nh) { k = 0; live = false; }
+			else kend = s_woff[k] + (S[(size_t)(lane + 1u) * stride + k] - s_wb[k]);   // the block's last cycle starts before the next block's first
+		}
+		uint32_t d = 0, i = 0, i0 = 0, steps = 0;
+		bool inchase = false;
+		while (__ballot(live)) {
+			if (live) {
+				const uint32_t q = inchase ? d : k;
+				const uint32_t a = s_cnt[q * (uint32_t)CS + lane];
+				if ((!inchase && a >= kend) || a >= run || ++steps > (uint32_t)PW_WIN_CAP + 64u) live = false;   // (past the window: inconsistent snapshots - k_bs_pw_count reports those)
+				else {
+					s_cnt[q * (uint32_t)CS + lane] = (uint16_t)(a + 1u);
+					const uint32_t dn = s_win[a], j = a + s_jadj[q];
+					if (inchase) C.dest[beg + i] = j; else i0 = j;
+					i = j;
+					if (dn == k) { C.dest[beg + j] = i0; inchase = false; }
+					else { d = dn < nh ? dn : k; inchase = true; }
+				}
+			}
+		}
+		__syncthreads();
+	}
 }
 
 // ------------------------------------------------------------------------------------------------ K8: placement
@@ -1109,6 +1433,9 @@ size_t rhk_bigsort_ws_bytes(uint64_t total, uint32_t n_lo)
 	b += 3 * ((t + 128 + 255) & ~(size_t)255);                      // dg (two: this level's and the next one's), hd
 	b += 2 * ((t * 4 + 255) & ~(size_t)255);                       // hp, dest
 	b += 4 * ((small_cap * 8 + 255) & ~(size_t)255) + 4 * ((small_cap * 4 + 255) & ~(size_t)255) + 4 * ((small_cap + 255) & ~(size_t)255);
+	const uint64_t pw_items = t / 64 + 2 * rng_cap + 16;            // block-parallel walk: snapshots (4 bytes per record), work items
+	b += ((t + 64) * 4 + 255) & ~(size_t)255;
+	b += 2 * ((pw_items * sizeof(bs_pw_item) + 255) & ~(size_t)255);
 	return b;
 }
 
@@ -1134,6 +1461,14 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	C.hd = (uint8_t*)take(t + 128);   // (+64: the lane walkers read whole aligned words around a pointer)
 	C.hp = (uint32_t*)take(t * 4); C.dest = (uint32_t*)take(t * 4);
 	for (int q = 0; q < 4; ++q) { C.small_off[q] = (uint64_t*)take((size_t)C.small_cap * 8); C.small_cnt[q] = (uint32_t*)take((size_t)C.small_cap * 4); C.small_tie[q] = (uint8_t*)take((size_t)C.small_cap); }
+	static const bool pw_on = !(getenv("RH_BS_PW") && atoi(getenv("RH_BS_PW")) == 0);   // RH_BS_PW=0: the serial token walkers for every range (A/B aid)
+	{
+		const uint64_t pww = t + 64;
+		uint32_t *sn = (uint32_t*)take((size_t)pww * 4);
+		C.pw_item_cap = (uint32_t)(t / 64 + 2 * (uint64_t)C.rng_cap + 16);
+		for (int q = 0; q < 2; ++q) C.pw_items[q] = (bs_pw_item*)take((size_t)C.pw_item_cap * sizeof(bs_pw_item));
+		C.pw_snap = pw_on && !jb.any_order && t < (1ull << 32) ? sn : nullptr; C.pw_words = (uint32_t)(pww < 0xFFFFFFFFull ? pww : 0xFFFFFFFFull);
+	}
 	C.seg_off = jb.off; C.seg_n = jb.n_seg; C.redo_skip = jb.any_order ? jb.redo_skip : nullptr;
 	if ((size_t)(p - jb.big_ws) > jb.big_ws_bytes) { rh_set_error("segment sorter: scratch of %zu bytes is too small (%zu needed)", jb.big_ws_bytes, (size_t)(p - jb.big_ws)); return -1; }
 	RH_LAUNCH(k_bs_init, 1, NT, 0, s, jb, C);
@@ -1207,6 +1542,29 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 			RH_LAUNCH((k_bs_walk_lanes<256, 8>), (n_rng + 7) / 8, 64, 0, s, C, 64u);   // LDS: 24 B per region and walker (36 / 48 / 48 KB)
 		}
 		}
+		if (C.pw_snap) {	// the ranges k_bs_scan gave snapshot slots: pointers after every block of cycles, then all blocks walked at once
+			RH_LAUNCH((k_bs_pw_count<64>), n_rng, 64, 0, s, C);
+			RH_LAUNCH((k_bs_pw_count<256>), n_rng, 64, 0, s, C);
+			const uint32_t gb = C.pw_item_cap < 16384u ? C.pw_item_cap : 16384u;
+			RH_LAUNCH((k_bs_pw_walk<64>), gb, 64, 0, s, C);
+			RH_LAUNCH((k_bs_pw_walk<256>), gb, 64, 0, s, C);
+			if (RH_DEVENV("RH_BS_PW_CHECK")) {	// development aid: every hole of every range has its dest[]
+				(void)hipStreamSynchronize(s);
+				std::vector<bs_meta> mv(n_rng); std::vector<bs_range> rv(n_rng);
+				(void)hipMemcpy(mv.data(), C.meta, (size_t)n_rng * sizeof(bs_meta), hipMemcpyDeviceToHost); (void)hipMemcpy(rv.data(), C.rng[0], (size_t)n_rng * sizeof(bs_range), hipMemcpyDeviceToHost);
+				uint32_t pwh[8]; (void)hipMemcpy(pwh, C.hdr + 16, 32, hipMemcpyDeviceToHost);
+				fprintf(stderr, "PW level %d: items %u + %u, words %u; blocks by one lane %u, ranges out of slots %u, ring misses %u, cycles by one lane %u\n", level, pwh[0], pwh[1], pwh[2], pwh[4], pwh[5], pwh[6], pwh[7]);
+				for (uint32_t r = 0; r < n_rng; ++r) {
+					if (!mv[r].pw) continue;
+					const uint32_t nhl = mv[r].hst[256];
+					std::vector<uint32_t> dv(nhl); std::vector<uint8_t> seen(nhl, 0);
+					(void)hipMemcpy(dv.data(), C.dest + rv[r].beg, (size_t)nhl * 4, hipMemcpyDeviceToHost);
+					uint64_t bad = 0, dup = 0;
+					for (uint32_t i = 0; i < nhl; ++i) { if (dv[i] >= nhl) ++bad; else if (seen[dv[i]]++) ++dup; }
+					fprintf(stderr, "PW range %u: n %u holes %u nh %u pw %u slots %u: dest out of range %llu, duplicate targets %llu\n", r, rv[r].n, nhl, mv[r].nh, mv[r].pw, mv[r].pw_slots, (unsigned long long)bad, (unsigned long long)dup);
+				}
+			}
+		}
 		if (trace) (void)hipEventRecord(ev[2], s);
 		for (int rep = 0; rep < scat_reps; ++rep)
 		BS_LAUNCH_REC(k_bs_scatter, ((n_tiles + 7) / 8) * 8, C);
@@ -1217,7 +1575,11 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 			(void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]); (void)hipEventElapsedTime(&c, ev[2], ev[3]);
 			// records by the number of regions with holes of their range: <= 2 (closed form), 3..24, 25..64, 65..128, more
 			std::vector<uint32_t> nhv(n_rng); std::vector<bs_range> rv(n_rng);
-			{ std::vector<bs_meta> mv(n_rng); (void)hipMemcpy(mv.data(), C.meta, (size_t)n_rng * sizeof(bs_meta), hipMemcpyDeviceToHost); for (uint32_t r = 0; r < n_rng; ++r) nhv[r] = mv[r].nh; }
+			uint64_t pw_rng = 0, pw_holes = 0, all_holes = 0; uint32_t pwh[4] = {0, 0, 0, 0};
+			{ std::vector<bs_meta> mv(n_rng); (void)hipMemcpy(mv.data(), C.meta, (size_t)n_rng * sizeof(bs_meta), hipMemcpyDeviceToHost); for (uint32_t r = 0; r < n_rng; ++r) { nhv[r] = mv[r].nh; all_holes += mv[r].hst[256]; if (mv[r].pw) { ++pw_rng; pw_holes += mv[r].hst[256]; } } }
+			(void)hipMemcpy(pwh, C.hdr + 16, 16, hipMemcpyDeviceToHost);
+			fprintf(stderr, "BS level %d block-parallel walk: %llu of %u ranges, %llu of %llu holes, items %u + %u, snapshot words %llu of %u\n", level, (unsigned long long)pw_rng, n_rng,
+			        (unsigned long long)pw_holes, (unsigned long long)all_holes, pwh[0], pwh[1], (unsigned long long)pwh[2] | (unsigned long long)pwh[3] << 32, C.pw_words);
 			(void)hipMemcpy(rv.data(), C.rng[0], (size_t)n_rng * sizeof(bs_range), hipMemcpyDeviceToHost);
 			uint64_t bins[5] = {0, 0, 0, 0, 0};
 			for (uint32_t r = 0; r < n_rng; ++r) bins[nhv[r] <= 2 ? 0 : nhv[r] <= 24 ? 1 : nhv[r] <= 64 ? 2 : nhv[r] <= 128 ? 3 : 4] += rv[r].n;

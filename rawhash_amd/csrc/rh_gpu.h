@@ -9,6 +9,7 @@
 #define RH_HD __host__ __device__
 #define RH_DEV __device__ __forceinline__
 #define RH_WAVE 64
+#define RH_INLINE_LAMBDA __attribute__((always_inline))   // a device lambda that captures register arrays by reference: out of line they would live in scratch
 
 void rh_set_error(const char *fmt, ...);
 
@@ -33,6 +34,9 @@ __device__ __forceinline__ uint32_t rh_readlane(uint32_t v, uint32_t l) { return
 __device__ __forceinline__ uint32_t rh_writelane(uint32_t v, uint32_t val, uint32_t l) { asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(l) : "m0"); return v; }   // (one SGPR + M0: constant-bus limit)
 __device__ __forceinline__ void rh_writelane2(uint32_t &a, uint32_t &b, uint32_t va, uint32_t vb, uint32_t l) { asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(a), "+v"(b) : "s"(va), "s"(vb), "s"(l) : "m0"); }   // two registers, same lane: one M0 load
 __device__ __forceinline__ uint32_t rh_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// the value is in its register from here on: a load that produces it is waited for at this point, not at its first use (a loop that keeps
+// other loads in flight must not be the place where the compiler waits for memory)
+#define RH_VALUE_READY(x) asm volatile("" : "+v"(x))
 __device__ __forceinline__ uint32_t rh_and_or(uint32_t a, uint32_t m, uint32_t o) { uint32_t r; asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(m), "v"(o)); return r; }   // (a & m) | o in one instruction
 // The token walker's per-pop advance of ONE lane (l: wave-uniform, in an SGPR): jr += 1, head = LDS byte at ringa | (jr & 63).
 // v_cmpx selects the lane (EXEC written by the compare itself); EXEC is saved before and restored after, whatever it was - where
@@ -73,6 +77,7 @@ __device__ uint32_t rh_readlane(uint32_t v, uint32_t l);
 __device__ uint32_t rh_writelane(uint32_t v, uint32_t val, uint32_t l);
 __device__ void rh_writelane2(uint32_t &a, uint32_t &b, uint32_t va, uint32_t vb, uint32_t l);
 __device__ uint32_t rh_uniform(uint32_t v);
+#define RH_VALUE_READY(x) ((void)0)
 __device__ uint32_t rh_and_or(uint32_t a, uint32_t m, uint32_t o);
 #endif
 

@@ -15,6 +15,8 @@
 #define RH_HD
 #define RH_DEV static inline
 #define RH_WAVE 64
+#define RH_INLINE_LAMBDA
+#define RH_VALUE_READY(x) ((void)0)
 #define __global__
 #define __device__
 #define __host__

@@ -332,6 +332,14 @@ def check_sort_big(ctx, seed=0, sizes=(20000, 33000, 9000), kinds=(0, 1, 2, 3, 4
             x = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
         elif kind == 5:    # chain scores as the candidate sort sees them: ~100 values of one byte (65 .. 128 regions with holes), many equal keys
             x = (rng.integers(20, 20 + int(rng.integers(70, 128)), size=n, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, 1 << 10, size=n, dtype=np.uint64)
+        elif kind in (6, 7, 8):    # backtrack candidates at human scale: the chains of one anchor (lowest score) are 30 - 60 % of the records, the rest
+            # spread over tens (6), up to 200 (7: more than 64 regions) or 300 values (8: two levels) - the block-parallel walk of rh_bigsort.hip
+            lone, hi = {6: (0.5, 60), 7: (0.3, 215), 8: (0.6, 315)}[kind]
+            x = np.full(n, 15, dtype=np.uint64)
+            m = rng.random(n) >= lone
+            x[m] = rng.integers(16, hi, size=int(m.sum()), dtype=np.uint64)
+            if i % 2:          # skewed scores: most chains have two anchors
+                x[m & (rng.random(n) < 0.5)] = 17
         elif kind == 3:    # three values of one byte, the rest equal
             x = (rng.integers(0, 3, size=n, dtype=np.uint64) << np.uint64(8 * int(rng.integers(1, 8)))) | np.uint64(7)
         else:

@@ -44,6 +44,18 @@ def test_exact_sort_multi_workgroup(ctx, emu_lib_smallcaps):
     c.close()
 
 
+def test_exact_sort_block_parallel_walk(ctx, emu_lib_smallcaps):
+    """rh_bigsort.hip, k_bs_pw_count / k_bs_pw_walk: backtrack-candidate keys (the lowest score holds half the records), whose token walk is
+    done block-parallel - pointer snapshots from 64 cycles followed at once, then every block walked in the reference's order, all at once.
+    Production sizes, and a build with a tiny window / few snapshot slots / small rings (blocks walked by one lane, ranges that run out of
+    slots, ring misses)."""
+    pc.check_sort_big(ctx, seed=11, sizes=(30000, 50000, 12000, 9000), kinds=(6,))
+    pc.check_sort_big(ctx, seed=12, sizes=(40000, 21000), kinds=(7, 8))
+    c = Context(0, lib=emu_lib_smallcaps)
+    pc.check_sort_big(c, seed=13, sizes=(5000, 3000, 7000, 2500, 9000, 4000), kinds=(6, 7, 8))
+    c.close()
+
+
 def test_any_order_sort(ctx):
     """Region keys (hit.c:111-126) through the sorter's any-order levels + tie check."""
     assert pc.check_sort_any(ctx, seed=3) >= 1

@@ -128,6 +128,15 @@ def test_exact_sort_multi_workgroup(ctx):
     pc.check_sort_big(ctx, seed=14, sizes=tuple([30000 + 17 * i for i in range(300)]), kinds=(0, 1, 0, 0, 3))
 
 
+def test_exact_sort_block_parallel_walk(ctx):
+    """rh_bigsort.hip, k_bs_pw_count / k_bs_pw_walk: backtrack-candidate keys at the sizes of a human-scale chunk (10^5 candidates a read,
+    half of them chains of one anchor = the lowest score), one and two levels, up to 64 and up to 256 regions with holes, hundreds of
+    ranges at once - the exact permutation of radix_sort_128x from snapshots of 64 cycles followed at once + all blocks walked at once."""
+    pc.check_sort_big(ctx, seed=21, sizes=(110_000, 60_000, 240_000, 9_000, 30_000), kinds=(6,))
+    pc.check_sort_big(ctx, seed=22, sizes=(150_000, 80_000, 33_000), kinds=(7, 8, 6))
+    pc.check_sort_big(ctx, seed=23, sizes=tuple([40_000 + 173 * i for i in range(200)]), kinds=(6, 6, 7, 8, 1))
+
+
 def test_index_built_on_device(product_lib, tmp_path):
     """rh_index_build_device = the host builder (pinned to the reference by tests/test_oracle.py): keys, counts, position
     lists, mid_occ; targets with gaps / lower case / shorter than a seed; then a 6 Mbp reference (thousands of filter blocks)."""
