@@ -40,24 +40,22 @@
 #define PW_MIN_HOLES 4096                 // ranges with fewer holes stay with the serial walkers
 #endif
 #ifndef PW_MIN_C0
-#define PW_MIN_C0 512                     // ... and so do ranges whose first region starts fewer cycles than this,
-#endif
-#ifndef PW_MAX_CYCLE
-#define PW_MAX_CYCLE 8                    // ... or whose cycles would be longer than this on average (holes / cycles of the first region)
-#endif
-#ifndef PW_MIN_PAR
-#define PW_MIN_PAR 16                     // a base region with fewer cycles left is walked by one lane on the spot
+#define PW_MIN_C0 64                      // ... and so do ranges whose first region starts fewer cycles than this
 #endif
 #ifndef PW_WIN_CAP
 #define PW_WIN_CAP 12288                  // holes of one work item of k_bs_pw_walk (their digits are staged in LDS; 16-bit window addresses)
 #endif
+#ifndef PW_BLK_HOLES
+#define PW_BLK_HOLES (PW_WIN_CAP / 3)     // holes a block of cycles should pop at most (expected: cycles per round x average cycle length)
+#endif
+#define PW_MIN_CPR 4                      // fewest cycles followed at a time
 #ifdef RH_DEV
-#define PW_STAT(i, n) atomicAdd(&C.hdr[20 + (i)], (uint32_t)(n))   // development builds: [20] blocks walked by one lane, [21] ranges out of slots, [22] ring misses, [23] cycles walked by one lane
+#define PW_STAT(i, n) atomicAdd(&C.hdr[20 + (i)], (uint32_t)(n))   // development builds: [20] blocks walked by one lane, [21] ranges out of slots, [22] window misses, [23] cycles walked by one lane, [24] window reloads
 #else
 #define PW_STAT(i, n) ((void)0)
 #endif
 #ifndef PW_RING_BYTES
-#define PW_RING_BYTES 8192                // LDS of k_bs_pw_count's digit rings, shared by the regions of its class
+#define PW_RING_BYTES 8192                // LDS of k_bs_pw_count's digit windows, shared by the regions in proportion to their holes
 #endif
 
 struct bs_range {
@@ -83,7 +81,7 @@ struct bs_meta {
 	uint8_t act[256], dmap[256];          // regions with holes, renumbered 0 .. nh-1 in digit order: dense -> digit, digit -> dense
 	int32_t s;                            // byte shift of this level (-1: all keys equal)
 	uint32_t nh;
-	uint32_t pw, pw_off, pw_slots;        // block-parallel walk (k_bs_pw_count / k_bs_pw_walk): 0 or rounds per block; the range's snapshot slots in C.pw_snap (word offset, number)
+	uint32_t pw, pw_ncpr, pw_off, pw_slots;   // block-parallel walk (k_bs_pw_count / k_bs_pw_walk): 0 or cycles per block; cycles followed at a time; the range's snapshot slots in C.pw_snap (word offset, number)
 };
 enum { BS_EMPTY = 0, BS_FINAL = 1, BS_SMALL = 2, BS_BIG = 3 };
 
@@ -525,22 +523,26 @@ __global__ __launch_bounds__(NT) void k_bs_scan(bs_ctx C)
 	__syncthreads();
 	if (tid == 0) {
 		M.hst[256] = total; M.nh = nh;
-		uint32_t pw = 0, off = 0, slots = 0;
-		if (C.pw_snap && nh >= 3 && nh <= 256 && total >= (uint32_t)PW_MIN_HOLES && s_c0 >= (uint32_t)PW_MIN_C0 && (uint64_t)s_c0 * PW_MAX_CYCLE >= total && R.beg + total < (1ull << 32)) {
-			const uint32_t bstride = (nh + 64u) / 64u;               // rounds per block: a snapshot is nh + 1 words
-			// snapshot slots: a cycle has >= 2 holes, so the first region's c0 cycles pop >= 2 c0 holes and the later base regions start at most
-			// (holes - 2 c0) / 2 cycles; those of them that get blocks (>= PW_MIN_PAR cycles) end in a partial block and may cost a closing snapshot
-			const uint32_t rest = total - 2u * s_c0 < total ? total - 2u * s_c0 : 0u, later = rest / (2u * (uint32_t)PW_MIN_PAR);
-			const uint32_t nph = later < nh - 1u ? later : nh - 1u;
-			slots = (total - s_c0) / (64u * bstride) + 2u * nph + 4u;
+		uint32_t pw = 0, ncpr = 0, off = 0, slots = 0;
+		if (C.pw_snap && nh >= 3 && nh <= 256 && total >= (uint32_t)PW_MIN_HOLES && s_c0 >= (uint32_t)PW_MIN_C0 && R.beg + total < (1ull << 32)) {
+			const uint32_t len = total / s_c0;                         // average cycle length if the first region's cycles were all (>= 2: a cycle pops its own hole and one that ends it)
+			ncpr = 64u;                                               // cycles followed at a time: fewer when they are long (one lane walks a block again)
+			while (ncpr > (uint32_t)PW_MIN_CPR && ncpr * len > (uint32_t)PW_BLK_HOLES) ncpr >>= 1;
+			uint32_t rounds = (2u * (nh + 1u) + ncpr * len - 1u) / (ncpr * len);   // rounds per block: a snapshot (nh + 1 words) for at least twice as many holes
+			if (rounds > 16u) rounds = 16u;
+			const uint32_t bc = ncpr * rounds;
+			// snapshot slots: an estimate (the later base regions start cycles too) - a range that runs out finishes with one lane
+			uint32_t cyc = 2u * s_c0 + nh;
+			if (cyc > total / 2u) cyc = total / 2u;
+			slots = cyc / bc + 4u;
 #ifdef PW_TEST_FEW_SLOTS
 			slots = slots / 8u + 3u;                                  // (test builds: ranges run out of slots and finish with one lane)
 #endif
 			const uint32_t need = slots * (nh + 1u);
 			const unsigned long long o64 = atomicAdd(reinterpret_cast<unsigned long long*>(C.hdr + 18), (unsigned long long)need);   // (hdr[18..19]: one 64-bit cursor)
-			if (o64 + need <= (unsigned long long)C.pw_words) { pw = bstride; off = (uint32_t)o64; }
+			if (ncpr * len <= 2u * (uint32_t)PW_BLK_HOLES && o64 + need <= (unsigned long long)C.pw_words) { pw = bc; off = (uint32_t)o64; }
 		}
-		M.pw = pw; M.pw_off = off; M.pw_slots = slots;
+		M.pw = pw; M.pw_ncpr = ncpr; M.pw_off = off; M.pw_slots = slots;
 	}
 }
 
@@ -1020,74 +1022,91 @@ __global__ __launch_bounds__(64) void k_bs_walk_tok(bs_ctx C, uint32_t nh_lo, ui
 // ------------------------------------------------------------------------------------------------ K7': the block-parallel walk
 // The token walk is a ROTOR WALK: every region hands its holes out in position order, whoever arrives.  Seen from one base region k it is
 // a sequence of cycles - pop k's next hole, follow the record found there to its region, pop that region's next hole, ... until a record
-// of k turns up - and the networks of that kind are ABELIAN: if several cycles are followed at the same time, in any interleaving, every
-// region has popped exactly as many holes at the end as if they had been followed one after the other (each region serves its arrivals in
-// its own fixed order, so the NUMBER of pops per region does not depend on the schedule; only who gets which hole does).  So
-//   * k_bs_pw_count (one wavefront per range) follows 64 cycles at a time, one per lane, popping with LDS atomics: the pointers of all
-//     regions after every 64 (128, ...) cycles - "snapshots" - are exact although the pops in between were handed out in the wrong order;
+// of k turns up - and networks of that kind are ABELIAN: if several cycles of one base region are followed at the same time, in any
+// interleaving, every region has popped exactly as many holes at the end as if they had been followed one after the other (each region
+// serves its arrivals in its own fixed order, so the NUMBER of pops per region does not depend on the schedule; only who gets which hole does).  So
+//   * k_bs_pw_count (one wavefront per range) follows up to 64 cycles at a time, one per lane, popping with LDS atomics: the pointers of all
+//     regions after every block of cycles - "snapshots" - are exact although the pops in between were handed out in the wrong order;
 //   * k_bs_pw_walk walks every block of cycles between two snapshots again, serially and therefore in the reference's order, but ALL BLOCKS
-//     AT ONCE, one lane per block (64 blocks = one work item per wavefront, the digits of the item's stretch of every region staged in LDS,
-//     the lane's private pointers as 16-bit window addresses): this pass writes dest[].
-// Phases (base regions) with a handful of cycles, a block that pops more holes than an item's window takes, and whatever is left when a
-// range runs out of snapshot slots are walked by one lane of k_bs_pw_count itself.  A range qualifies (k_bs_scan) when its first region
-// starts many short cycles: the backtrack candidates, whose lowest score - the chains of one anchor - holds half the records, so that
-// every second hole elsewhere ends a cycle (measured at human scale: 6 500 - 19 000 ranges of 50 000 - 240 000 holes per level; the
-// serial walkers took one wavefront 60 - 120 ns per hole and the level as long as its longest range).
+//     AT ONCE, one lane per block (up to 64 blocks = one work item per wavefront, the digits of the item's stretch of every region staged in
+//     LDS, the lane's private pointers as 16-bit window addresses): this pass writes dest[].
+// A block is a fixed number of cycles (fewer per round and per block the longer the range's cycles are: k_bs_scan) and runs across base regions;
+// a block that pops more holes than an item's window takes, and whatever is left when a range runs out of snapshot slots, are walked by one
+// lane of k_bs_pw_count itself.  Measured at human scale (one level of the backtrack candidates' sort: 6 500 - 19 000 ranges of 10 000 -
+// 40 000 holes, the lowest score - the chains of one anchor - holding most records, so that every second hole elsewhere ends a cycle; the
+// exact re-sorts of the reads with equal anchor keys: 24 or 256 evenly filled regions, up to 10^5 holes): the serial walkers took one
+// wavefront 60 - 250 ns per hole and a level as long as its longest range.
+#define PW_CHUNKS (PW_RING_BYTES / 16)
+#define PW_NLD (PW_CHUNKS / 64)
 template <int NHM>
 __global__ __launch_bounds__(64) void k_bs_pw_count(bs_ctx C)
 {
-	static_assert(PW_RING_BYTES / NHM >= 16 && PW_WIN_CAP < 65000, "a ring takes 16-byte chunks; window addresses are 16 bits");
-	constexpr int RPL = NHM / 64, RING = PW_RING_BYTES / NHM, NCH = 4 / RPL, CLS = NHM > 64 ? 1 : 0;   // regions per lane; bytes of a region's digit ring; 16-byte chunks it may take per round
-	__shared__ __attribute__((aligned(16))) uint8_t s_ring[NHM * RING];
-	__shared__ uint32_t s_ptr[NHM], s_lim[NHM], s_end[NHM];            // next hole, digits in the ring up to, end of the region's holes (absolute hole addresses)
+	static_assert(PW_CHUNKS >= 256 && PW_CHUNKS % 64 == 0 && (PW_RING_BYTES & (PW_RING_BYTES - 1)) == 0 && PW_WIN_CAP < 65000, "a chunk for each of 256 regions; window addresses are 16 bits");
+	constexpr int RPL = NHM / 64, CLS = NHM > 64 ? 1 : 0;
+	// every region's window: the digits of its holes [wst, lim) at s_win[hole + off]; capacities in proportion to the regions' holes
+	__shared__ __attribute__((aligned(16))) uint8_t s_win[PW_RING_BYTES];
+	__shared__ uint32_t s_ptr[NHM], s_end[NHM], s_lim[NHM], s_off[NHM], s_wst[NHM], s_base[NHM];   // next hole, end of the region's holes, window end (absolute hole addresses); window offset; window start; its place in s_win
+	__shared__ uint8_t s_map[PW_CHUNKS];                              // 16-byte chunk of s_win -> region
 	__shared__ uint32_t s_pops, s_err;
 	const uint32_t lane = threadIdx.x, r = blockIdx.x;
 	if (r >= C.hdr[0]) return;
 	bs_meta &M = C.meta[r];
-	const uint32_t bstride = M.pw, nh = M.nh;
-	if (!bstride || nh > (uint32_t)NHM || (CLS == 1 && nh <= 64u)) return;
+	const uint32_t bcyc = M.pw, nh = M.nh, ncpr = M.pw_ncpr;
+	if (!bcyc || nh > (uint32_t)NHM || (CLS == 1 && nh <= 64u)) return;
 	const uint32_t beg = (uint32_t)C.rng[0][r].beg, stride = nh + 1u, n_slots = M.pw_slots, n_holes = M.hst[256];
 	uint32_t *snap = C.pw_snap + M.pw_off;
 	const uint8_t *hd = C.hd;
 	uint32_t *dest = C.dest;
 	bool on[RPL];
-	uint32_t ld_n[RPL];
-	uint4 ch[RPL][NCH];
+	uint32_t cap[RPL], wbase[RPL], thr[RPL], snp[RPL];
+	uint32_t used = 0;
+	{
+		const uint32_t mc = (uint32_t)PW_CHUNKS >= 2u * nh ? 2u : 1u, extra = (uint32_t)PW_CHUNKS - mc * nh;
+		uint32_t run = 0;
 #pragma unroll
-	for (int t = 0; t < RPL; ++t) {
-		const uint32_t q = lane + 64u * (uint32_t)t;
-		on[t] = q < nh; ld_n[t] = 0;
-#pragma unroll
-		for (int c = 0; c < NCH; ++c) ch[t][c] = uint4{0, 0, 0, 0};
-		if (on[t]) { const uint32_t dk = M.act[q], p0 = beg + M.hst[dk]; s_ptr[q] = p0; s_end[q] = beg + M.hst[dk + 1u]; s_lim[q] = p0 & ~15u; }
+		for (int t = 0; t < RPL; ++t) {
+			const uint32_t q = lane + 64u * (uint32_t)t;
+			on[t] = q < nh; cap[t] = 0; wbase[t] = 0; thr[t] = 0; snp[t] = 0;
+			uint32_t nc = 0;
+			if (on[t]) {
+				const uint32_t dk = M.act[q], h0 = M.hst[dk], h1 = M.hst[dk + 1u];
+				s_ptr[q] = beg + h0; s_end[q] = beg + h1;
+				nc = mc + (uint32_t)((uint64_t)extra * (h1 - h0) / n_holes);
+			}
+			uint32_t inc = nc;
+			for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t u = __shfl_up(inc, dd); if (lane >= (uint32_t)dd) inc += u; }
+			const uint32_t tot = __shfl(inc, 63);
+			if (on[t]) {
+				cap[t] = 16u * nc; wbase[t] = 16u * (run + inc - nc); s_base[q] = wbase[t];
+				thr[t] = cap[t] / 8u < 4u ? 4u : cap[t] / 8u > 64u ? 64u : cap[t] / 8u;
+				for (uint32_t c = 0; c < nc; ++c) s_map[run + inc - nc + c] = (uint8_t)q;
+			}
+			run += tot;
+		}
+		used = run;
 	}
 	if (lane == 0) { s_pops = 0; s_err = 0; }
 	__syncthreads();
-	// A region's ring holds the digits of the holes [lim - RING, lim) at slot (address & (RING - 1)); chunks are requested at the start of a
-	// round and stored at its end, and never reach beyond (pointer at request time, rounded down) + RING: nothing a later pop needs is overwritten.
-	// (macros, not lambdas: a closure that captures the chunk registers by reference keeps them in scratch memory)
-	#define PW_ISSUE() do { _Pragma("unroll") for (int t = 0; t < RPL; ++t) { \
-		ld_n[t] = 0; \
-		if (on[t]) { const uint32_t q_ = lane + 64u * (uint32_t)t, lm_ = s_lim[q_], en_ = s_end[q_], top_ = (s_ptr[q_] & ~15u) + (uint32_t)RING; \
-			_Pragma("unroll") for (int c = 0; c < NCH; ++c) { const uint32_t a_ = lm_ + 16u * (uint32_t)c; \
-				if (a_ < en_ && a_ + 16u <= top_) { ch[t][c] = *reinterpret_cast<const uint4*>(hd + a_); ld_n[t] = (uint32_t)c + 1u; } } } } } while (0)
-	#define PW_COMMIT() do { _Pragma("unroll") for (int t = 0; t < RPL; ++t) { \
-		if (on[t] && ld_n[t]) { const uint32_t q_ = lane + 64u * (uint32_t)t, lm_ = s_lim[q_]; \
-			_Pragma("unroll") for (int c = 0; c < NCH; ++c) \
-				if ((uint32_t)c < ld_n[t]) *reinterpret_cast<uint4*>(s_ring + q_ * (uint32_t)RING + ((lm_ + 16u * (uint32_t)c) & (uint32_t)(RING - 1))) = ch[t][c]; \
-			s_lim[q_] = lm_ + 16u * ld_n[t]; } } } while (0)
-	#define PW_REFILL() do { PW_ISSUE(); PW_COMMIT(); __syncthreads(); } while (0)
-	// one lane, ncyc cycles of base region k from the pointers as they stand, in the reference's order (ksort.h:124-138)
-	auto serial = [&](uint32_t k, uint32_t ncyc) RH_INLINE_LAMBDA {
+	// every region's window reloaded from its pointer on (all lanes, PW_NLD 16-byte loads each, in flight together: one trip to memory)
+	#define PW_EVENT() do { \
+		_Pragma("unroll") for (int t = 0; t < RPL; ++t) if (on[t]) { const uint32_t q_ = lane + 64u * (uint32_t)t; s_wst[q_] = s_ptr[q_] & ~15u; } \
+		__syncthreads(); \
+		uint4 v_[PW_NLD]; \
+		_Pragma("unroll") for (int i = 0; i < PW_NLD; ++i) { v_[i] = uint4{0, 0, 0, 0}; const uint32_t c_ = lane + 64u * (uint32_t)i; \
+			if (c_ < used) { const uint32_t q_ = s_map[c_], a_ = s_wst[q_] + (16u * c_ - s_base[q_]); if (a_ < s_end[q_]) v_[i] = *reinterpret_cast<const uint4*>(hd + a_); } } \
+		_Pragma("unroll") for (int i = 0; i < PW_NLD; ++i) { const uint32_t c_ = lane + 64u * (uint32_t)i; if (c_ < used) *reinterpret_cast<uint4*>(s_win + 16u * c_) = v_[i]; } \
+		_Pragma("unroll") for (int t = 0; t < RPL; ++t) if (on[t]) { const uint32_t q_ = lane + 64u * (uint32_t)t, w_ = s_wst[q_]; s_lim[q_] = w_ + cap[t]; s_off[q_] = wbase[t] - w_; } \
+		__syncthreads(); PW_STAT(4, lane == 0 ? 1 : 0); } while (0)
+	// one lane, the cycles of base region k from the pointers as they stand until k's pointer reaches `until`, in the reference's order (ksort.h:124-138)
+	auto serial = [&](uint32_t k, uint32_t until) RH_INLINE_LAMBDA {
 		if (lane == 0) {
 			uint32_t steps = 0;
-			for (uint32_t c = 0; c < ncyc && !s_err; ++c) {
+			while (s_ptr[k] < until && !s_err) {
 				const uint32_t i0 = s_ptr[k];
 				s_ptr[k] = i0 + 1u;
 				uint32_t i = i0, q = k;
 				for (;;) {
-					const uint32_t lm = s_lim[q];
-					const uint32_t d = (uint32_t)(lm - 1u - i) < (uint32_t)RING ? s_ring[q * (uint32_t)RING + (i & (uint32_t)(RING - 1))] : hd[i];   // the digit in hole i of region q
+					const uint32_t d = i < s_lim[q] && i >= s_wst[q] ? (uint32_t)s_win[(i + s_off[q]) & (uint32_t)(PW_RING_BYTES - 1)] : (uint32_t)hd[i];   // the digit in hole i of region q
 					if (d == k) break;
 					if (d >= nh || s_ptr[d] >= s_end[d] || ++steps > n_holes) { s_err = 1; break; }
 					const uint32_t j = s_ptr[d];
@@ -1100,7 +1119,18 @@ __global__ __launch_bounds__(64) void k_bs_pw_count(bs_ctx C)
 		}
 		__syncthreads();
 	};
-	for (int f = 0; f < RING / (16 * NCH); ++f) PW_REFILL();
+	auto serial_until = [&](uint32_t k, uint32_t until) RH_INLINE_LAMBDA {   // ... in stretches of 64 cycles, the windows reloaded in between
+		for (;;) {
+			const uint32_t p = rh_uniform(s_ptr[k]);
+			const bool stop = p >= until || s_err;
+			__syncthreads();                                           // (every lane has looked before lane 0 walks on)
+			if (stop) break;
+			serial(k, until - p < 64u ? until : p + 64u);
+			PW_STAT(3, lane == 0 ? (until - p < 64u ? until - p : 64u) : 0);
+			PW_EVENT();
+		}
+	};
+	PW_EVENT();
 	uint32_t slot = 0, it_slot0 = 0, it_nb = 0, it_pops = 0;       // (wave-uniform)
 	auto emit = [&]() RH_INLINE_LAMBDA {
 		if (lane == 0 && it_nb) {
@@ -1112,105 +1142,102 @@ __global__ __launch_bounds__(64) void k_bs_pw_count(bs_ctx C)
 	};
 	auto snapshot = [&](uint32_t sl, uint32_t kword) RH_INLINE_LAMBDA {
 #pragma unroll
-		for (int t = 0; t < RPL; ++t) if (on[t]) { const uint32_t q = lane + 64u * (uint32_t)t; snap[(size_t)sl * stride + q] = s_ptr[q]; }
+		for (int t = 0; t < RPL; ++t) if (on[t]) { const uint32_t q = lane + 64u * (uint32_t)t; snp[t] = s_ptr[q]; snap[(size_t)sl * stride + q] = snp[t]; }
 		if (lane == 0) snap[(size_t)sl * stride + nh] = kword;
 		__syncthreads();                                               // (every lane has read its pointers before lane 0 moves the base region's)
 	};
-	auto close_item = [&]() RH_INLINE_LAMBDA { if (it_nb) { snapshot(slot, 0u); ++slot; emit(); } };   // the pointers as they stand end the open item
-	bool over = false;
+	auto close_item = [&](uint32_t kword) RH_INLINE_LAMBDA { if (it_nb) { snapshot(slot, kword); ++slot; emit(); } };   // the pointers as they stand end the open item
+	bool over = false, blk_open = false;
+	uint32_t blk_cyc = 0, blk_slot = 0, blk_k = 0;
+	uint32_t cur_k = 0, cur_kp = 0;                                  // (where the walk stands: for the block that has to be walked again)
+	// the open block is complete: the holes it popped = the sum of the pointers' advances.  false: inconsistent hole lists
+	auto close_block = [&]() RH_INLINE_LAMBDA -> bool {
+		{
+			uint32_t adv = 0;
+#pragma unroll
+			for (int t = 0; t < RPL; ++t) if (on[t]) { const uint32_t q = lane + 64u * (uint32_t)t; adv += s_ptr[q] - snp[t]; }
+			if (adv) atomicAdd(&s_pops, adv);
+		}
+		__syncthreads();
+		const uint32_t bp = rh_uniform(s_pops);
+		bool bad = s_err != 0;
+#pragma unroll
+		for (int t = 0; t < RPL; ++t) if (on[t]) { const uint32_t q = lane + 64u * (uint32_t)t; bad |= s_ptr[q] > s_end[q]; }
+		__syncthreads();
+		if (lane == 0) s_pops = 0;
+		if (__ballot(bad)) return false;
+		blk_open = false;
+		if (bp > (uint32_t)PW_WIN_CAP) {
+			// more holes than an item's window takes: the open item ends where this block began (its snapshot), and the block is walked
+			// again by one lane from there
+			emit();
+			if (lane == 0) PW_STAT(0, 1);
+#pragma unroll
+			for (int t = 0; t < RPL; ++t) if (on[t]) { const uint32_t q = lane + 64u * (uint32_t)t; s_ptr[q] = snp[t]; }
+			__syncthreads();
+			PW_EVENT();
+			for (uint32_t kk = blk_k; kk <= cur_k; ++kk) serial_until(kk, kk < cur_k ? rh_uniform(s_end[kk]) : cur_kp);
+			if (s_err) return false;
+		} else {
+			if (it_nb == 64u || it_pops + bp > (uint32_t)PW_WIN_CAP) emit();   // (the open item ends at this block's snapshot, which follows its last one)
+			if (it_nb == 0) it_slot0 = blk_slot;
+			++it_nb; it_pops += bp;
+		}
+		return true;
+	};
 	for (uint32_t k = 0; k < nh; ++k) {
 		uint32_t kp = rh_uniform(s_ptr[k]);
 		const uint32_t endk = rh_uniform(s_end[k]);
 		if (k && lane == 0) { const uint32_t dk = M.act[k]; M.J[dk] = kp - beg - M.hst[dk]; }   // arrivals so far = J
 		while (kp < endk) {
-			if (over || endk - kp < (uint32_t)PW_MIN_PAR || slot + 2u > n_slots) {
-				if (endk - kp >= (uint32_t)PW_MIN_PAR && !over) { over = true; if (lane == 0) PW_STAT(1, 1); }   // out of snapshot slots: the rest of the range is one lane's
-				close_item();
-				while (kp < endk) {
-					const uint32_t n = endk - kp < 64u ? endk - kp : 64u;
-					serial(k, n);
-					if (lane == 0) PW_STAT(3, n);
+			if (!blk_open) {
+				if (over || slot + 2u > n_slots) {                        // out of snapshot slots: the rest of the range is one lane's
+					if (!over) { over = true; if (lane == 0) PW_STAT(1, 1); close_item(k); }
+					serial_until(k, endk);
 					if (s_err) { if (lane == 0) C.hdr[7] = 2; return; }
-					kp += n;
-					PW_REFILL();
+					break;
 				}
-				break;
+				blk_slot = slot++; blk_k = k; blk_cyc = 0; blk_open = true;
+				snapshot(blk_slot, k);
 			}
-			// a block: bstride rounds of up to 64 cycles, one per lane
-			const uint32_t bslot = slot++;
-			snapshot(bslot, k);
-			uint32_t ncy = 0, bad_d = 0;
-			uint32_t d_nxt = lane < endk - kp ? (uint32_t)hd[kp + lane] : 0u;   // the digits in the holes that start this round's cycles (always requested a round ahead)
-			for (uint32_t rr = 0; rr < bstride && kp < endk; ++rr) {
-				const uint32_t nch = endk - kp < 64u ? endk - kp : 64u;
-				bool live = lane < nch, parked = false;
-				uint32_t d = d_nxt, pj = 0;
-				RH_VALUE_READY(d);                                         // (its load is waited for HERE: no wait for memory inside the loop below, where the ring chunks are in flight)
-				d_nxt = kp + 64u + lane < endk ? (uint32_t)hd[kp + 64u + lane] : 0u;
-				PW_ISSUE();
-				if (lane == 0) s_ptr[k] = kp + nch;
-				for (uint32_t itn = 0;;) {
-					for (; __ballot(live); ++itn) {
-						if (itn > n_holes) { bad_d = 1; live = false; parked = false; continue; }   // (cannot happen with consistent hole lists: every pop uses up a hole)
-						if (live) {
-							const uint32_t j = atomicAdd(&s_ptr[d], 1u);
-							const bool miss = j >= s_lim[d];
-							const uint32_t dn = s_ring[d * (uint32_t)RING + (j & (uint32_t)(RING - 1))];
-							if (miss) { parked = true; pj = j; live = false; PW_STAT(2, 1); }   // beyond what the ring holds (a region popped more than it was refilled): the lane waits below
-							else { bad_d |= dn >= nh ? 1u : 0u; live = dn != k && dn < nh; d = dn; }
-						}
-					}
-					if (!__ballot(parked)) break;
-					if (parked) {                                           // ... for the digit from memory, and goes on (any interleaving of the cycles is as good as any other)
-						const uint32_t dn = hd[pj];
-						parked = false; bad_d |= dn >= nh ? 1u : 0u; live = dn != k && dn < nh; d = dn;
-					}
+			// a round: up to ncpr cycles, one per lane
+			const uint32_t nch = endk - kp < ncpr ? endk - kp : ncpr;
+			{
+				bool need = false;
+#pragma unroll
+				for (int t = 0; t < RPL; ++t) if (on[t]) { const uint32_t q = lane + 64u * (uint32_t)t, lm = s_lim[q]; need |= (int32_t)(lm - s_ptr[q]) < (int32_t)(q == k ? 64u : thr[t]) && lm < s_end[q]; }
+				if (__ballot(need)) PW_EVENT();
+			}
+			bool live = lane < nch, parked = false;
+			uint32_t d = k, pj = 0, bad_d = 0;
+			auto take = [&](uint32_t dd, uint32_t j) RH_INLINE_LAMBDA {   // the digit in hole j of region dd: the cycle ends, goes on to that region, or waits for memory
+				const bool miss = j >= s_lim[dd];
+				const uint32_t dn = s_win[(j + s_off[dd]) & (uint32_t)(PW_RING_BYTES - 1)];
+				if (miss) { parked = true; pj = j; live = false; PW_STAT(2, 1); }   // beyond the window (a region popped more than expected): the lane waits below
+				else { bad_d |= dn >= nh ? 1u : 0u; live = dn != k && dn < nh; d = dn; }
+			};
+			if (live) take(k, kp + lane);
+			if (lane == 0) s_ptr[k] = kp + nch;
+			for (uint32_t itn = 0;;) {
+				for (; __ballot(live); ++itn) {
+					if (itn > n_holes) { bad_d = 1; live = false; parked = false; continue; }   // (cannot happen with consistent hole lists: every pop uses up a hole)
+					if (live) take(d, atomicAdd(&s_ptr[d], 1u));
 				}
-				__syncthreads();
-				PW_COMMIT();
-				kp += nch; ncy += nch;
+				if (!__ballot(parked)) break;
+				if (parked) {                                               // ... for the digit from memory, and goes on (any interleaving of the cycles is as good as any other)
+					const uint32_t dn = hd[pj];
+					parked = false; bad_d |= dn >= nh ? 1u : 0u; live = dn != k && dn < nh; d = dn;
+				}
 			}
 			if (bad_d) s_err = 1;
-			// holes this block popped: the sum of the pointers' advances
-			{
-				uint32_t adv = 0;
-#pragma unroll
-				for (int t = 0; t < RPL; ++t) if (on[t]) { const uint32_t q = lane + 64u * (uint32_t)t; adv += s_ptr[q] - snap[(size_t)bslot * stride + q]; }
-				if (adv) atomicAdd(&s_pops, adv);
-			}
 			__syncthreads();
-			const uint32_t bp = rh_uniform(s_pops);
-			bool bad = s_err != 0;
-#pragma unroll
-			for (int t = 0; t < RPL; ++t) if (on[t]) { const uint32_t q = lane + 64u * (uint32_t)t; bad |= s_ptr[q] > s_end[q]; }
-			__syncthreads();
-			if (lane == 0) s_pops = 0;
-			if (__ballot(bad)) { if (lane == 0) C.hdr[7] = 2; return; }
-			if (bp > (uint32_t)PW_WIN_CAP) {
-				// more holes than an item's window takes: the open item ends where this block began (its snapshot), and the block is walked
-				// again by one lane from there
-				emit();
-				if (lane == 0) PW_STAT(0, 1);
-#pragma unroll
-				for (int t = 0; t < RPL; ++t) if (on[t]) { const uint32_t q = lane + 64u * (uint32_t)t, p0 = snap[(size_t)bslot * stride + q]; s_ptr[q] = p0; s_lim[q] = p0 & ~15u; }
-				__syncthreads();
-				for (int f = 0; f < RING / (16 * NCH); ++f) PW_REFILL();
-				for (uint32_t c0 = 0; c0 < ncy; c0 += 64u) {
-					serial(k, ncy - c0 < 64u ? ncy - c0 : 64u);
-					if (s_err) { if (lane == 0) C.hdr[7] = 2; return; }
-					PW_REFILL();
-				}
-			} else {
-				if (it_nb == 64u || it_pops + bp > (uint32_t)PW_WIN_CAP) emit();   // (the open item ends at this block's snapshot, which follows its last one)
-				if (it_nb == 0) it_slot0 = bslot;
-				++it_nb; it_pops += bp;
-			}
+			kp += nch; blk_cyc += nch;
+			if (blk_cyc >= bcyc) { cur_k = k; cur_kp = kp; if (!close_block()) { if (lane == 0) C.hdr[7] = 2; return; } }
 		}
 	}
-	close_item();
-	#undef PW_ISSUE
-	#undef PW_COMMIT
-	#undef PW_REFILL
+	if (blk_open) { cur_k = nh - 1u; cur_kp = rh_uniform(s_ptr[nh - 1u]); if (!close_block()) { if (lane == 0) C.hdr[7] = 2; return; } }
+	close_item(nh);
+	#undef PW_EVENT
 }
 
 template <int NHM>
@@ -1220,6 +1247,7 @@ __global__ __launch_bounds__(64) void k_bs_pw_walk(bs_ctx C)
 	__shared__ uint16_t s_cnt[NHM * CS];                               // [region][block]: the block's next hole of the region, as a window address
 	__shared__ uint8_t s_win[PW_WIN_CAP + 16];
 	__shared__ uint32_t s_wb[NHM], s_woff[NHM + 1], s_jadj[NHM];      // first hole of the item's stretch, where the stretch starts in the window, window address -> hole index within the range
+	__shared__ uint16_t s_wend[NHM];                                   // window address of the end of the region's holes (0xFFFF: beyond the item's stretch)
 	const uint32_t lane = threadIdx.x;
 	uint32_t n_items = C.hdr[16 + CLS];
 	if (n_items > C.pw_item_cap) n_items = C.pw_item_cap;
@@ -1232,12 +1260,12 @@ __global__ __launch_bounds__(64) void k_bs_pw_walk(bs_ctx C)
 #pragma unroll
 		for (int t = 0; t < RPL; ++t) {
 			const uint32_t q = lane + 64u * (uint32_t)t;
-			uint32_t wb = 0, len = 0;
-			if (q < nh) { wb = S[q]; len = S[(size_t)nb * stride + q] - wb; }
+			uint32_t wb = 0, len = 0, en = 0;
+			if (q < nh) { wb = S[q]; len = S[(size_t)nb * stride + q] - wb; en = beg + M.hst[M.act[q] + 1u]; }
 			uint32_t inc = len;
 			for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d); if (lane >= (uint32_t)d) inc += u; }
 			const uint32_t tot = __shfl(inc, 63);
-			if (q < nh) { const uint32_t wo = run + inc - len; s_wb[q] = wb; s_woff[q] = wo; s_jadj[q] = wb - beg - wo; }
+			if (q < nh) { const uint32_t wo = run + inc - len; s_wb[q] = wb; s_woff[q] = wo; s_jadj[q] = wb - beg - wo; s_wend[q] = en - wb <= len ? (uint16_t)(wo + (en - wb)) : (uint16_t)0xFFFFu; }
 			run += tot;
 		}
 		if (lane == 0) s_woff[nh] = run;
@@ -1259,27 +1287,33 @@ __global__ __launch_bounds__(64) void k_bs_pw_walk(bs_ctx C)
 			}
 		}
 		__syncthreads();
+		// a block: from its first base region, every base region's remaining cycles until the region the next block starts in, and that one's
+		// up to the next block's pointer
 		bool live = lane < nb;
-		uint32_t k = 0, kend = 0;
+		uint32_t k = 0, kend = 0, kfin = 0;
 		if (live) {
-			k = S[(size_t)lane * stride + nh];
-			if (k >= nh) { k = 0; live = false; }
-			else kend = s_woff[k] + (S[(size_t)(lane + 1u) * stride + k] - s_wb[k]);   // the block's last cycle starts before the next block's first
+			k = S[(size_t)lane * stride + nh]; kend = S[(size_t)(lane + 1u) * stride + nh];
+			if (k >= nh || kend > nh || kend < k) live = false;
+			else if (kend < nh) kfin = s_woff[kend] + (S[(size_t)(lane + 1u) * stride + kend] - s_wb[kend]);
 		}
 		uint32_t d = 0, i = 0, i0 = 0, steps = 0;
 		bool inchase = false;
 		while (__ballot(live)) {
 			if (live) {
-				const uint32_t q = inchase ? d : k;
-				const uint32_t a = s_cnt[q * (uint32_t)CS + lane];
-				if ((!inchase && a >= kend) || a >= run || ++steps > (uint32_t)PW_WIN_CAP + 64u) live = false;   // (past the window: inconsistent snapshots - k_bs_pw_count reports those)
+				if (!inchase && k >= kend && (k >= nh || s_cnt[k * (uint32_t)CS + lane] >= kfin)) live = false;
+				else if (!inchase && k < kend && s_cnt[k * (uint32_t)CS + lane] >= s_wend[k]) ++k;   // this base region is complete: the next one
 				else {
-					s_cnt[q * (uint32_t)CS + lane] = (uint16_t)(a + 1u);
-					const uint32_t dn = s_win[a], j = a + s_jadj[q];
-					if (inchase) C.dest[beg + i] = j; else i0 = j;
-					i = j;
-					if (dn == k) { C.dest[beg + j] = i0; inchase = false; }
-					else { d = dn < nh ? dn : k; inchase = true; }
+					const uint32_t q = inchase ? d : k;
+					const uint32_t a = s_cnt[q * (uint32_t)CS + lane];
+					if (a >= run || ++steps > (uint32_t)PW_WIN_CAP + 64u) live = false;   // (past the window: inconsistent snapshots - k_bs_pw_count reports those)
+					else {
+						s_cnt[q * (uint32_t)CS + lane] = (uint16_t)(a + 1u);
+						const uint32_t dn = s_win[a], j = a + s_jadj[q];
+						if (inchase) C.dest[beg + i] = j; else i0 = j;
+						i = j;
+						if (dn == k) { C.dest[beg + j] = i0; inchase = false; }
+						else { d = dn < nh ? dn : k; inchase = true; }
+					}
 				}
 			}
 		}
@@ -1488,7 +1522,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	// chip and the other streams' bandwidth-bound kernels wait behind an issue-bound one.  Unused dynamic LDS caps them per CU.
 	static const uint32_t walk_lds = RH_DEVENV("RH_BS_WALK_LDS") ? (uint32_t)strtoul(RH_DEVENV("RH_BS_WALK_LDS"), nullptr, 10) : 0u;
 	static const int walk_reps = RH_DEVENV("RH_BS_WALK_REPS") ? atoi(RH_DEVENV("RH_BS_WALK_REPS")) : 1, scat_reps = RH_DEVENV("RH_BS_SCAT_REPS") ? atoi(RH_DEVENV("RH_BS_SCAT_REPS")) : 1;   // development aid: the (idempotent) walks / placement launched several times - what a pass costs the step with the other streams' kernels around it
-	hipEvent_t ev[4] = {};
+	hipEvent_t ev[5] = {};
 	if (trace) for (auto &e : ev) (void)hipEventCreate(&e);
 	for (int level = 0; level < 9; ++level) {
 		RH_HIP(hipMemcpyAsync(pin, C.hdr, 64, hipMemcpyDeviceToHost, s));
@@ -1542,6 +1576,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 			RH_LAUNCH((k_bs_walk_lanes<256, 8>), (n_rng + 7) / 8, 64, 0, s, C, 64u);   // LDS: 24 B per region and walker (36 / 48 / 48 KB)
 		}
 		}
+		if (trace) (void)hipEventRecord(ev[4], s);
 		if (C.pw_snap) {	// the ranges k_bs_scan gave snapshot slots: pointers after every block of cycles, then all blocks walked at once
 			RH_LAUNCH((k_bs_pw_count<64>), n_rng, 64, 0, s, C);
 			RH_LAUNCH((k_bs_pw_count<256>), n_rng, 64, 0, s, C);
@@ -1562,6 +1597,17 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 					uint64_t bad = 0, dup = 0;
 					for (uint32_t i = 0; i < nhl; ++i) { if (dv[i] >= nhl) ++bad; else if (seen[dv[i]]++) ++dup; }
 					fprintf(stderr, "PW range %u: n %u holes %u nh %u pw %u slots %u: dest out of range %llu, duplicate targets %llu\n", r, rv[r].n, nhl, mv[r].nh, mv[r].pw, mv[r].pw_slots, (unsigned long long)bad, (unsigned long long)dup);
+					// the walk itself, on the host (ksort.h:124-138 on the hole lists)
+					std::vector<uint8_t> hdv(nhl); (void)hipMemcpy(hdv.data(), C.hd + rv[r].beg, nhl, hipMemcpyDeviceToHost);
+					const uint32_t nhr = mv[r].nh; std::vector<uint32_t> pt(nhr), en(nhr), want(nhl, 0xFFFFFFFFu);
+					for (uint32_t q = 0; q < nhr; ++q) { pt[q] = mv[r].hst[mv[r].act[q]]; en[q] = mv[r].hst[mv[r].act[q] + 1u]; }
+					for (uint32_t k = 0; k < nhr; ++k) while (pt[k] < en[k]) { const uint32_t i0 = pt[k]++; uint32_t i = i0, d = hdv[i0]; while (d != k) { const uint32_t j = pt[d]++; want[i] = j; i = j; d = hdv[j]; } want[i] = i0; }
+					uint32_t nbad = 0;
+					for (uint32_t i = 0; i < nhl; ++i) if (dv[i] != want[i]) { if (nbad++ < 6) { uint32_t q = 0; while (q + 1 < nhr && mv[r].hst[mv[r].act[q + 1]] <= i) ++q; fprintf(stderr, "   hole %u (region %u, its hole %u): dest %u, the walk says %u\n", i, q, i - mv[r].hst[mv[r].act[q]], dv[i], want[i]); } }
+					if (nbad) { fprintf(stderr, "   %u holes differ; snapshots:\n", nbad);
+						std::vector<uint32_t> sv((size_t)mv[r].pw_slots * (nhr + 1)); (void)hipMemcpy(sv.data(), C.pw_snap + mv[r].pw_off, sv.size() * 4, hipMemcpyDeviceToHost);
+						for (uint32_t sl = 0; sl < mv[r].pw_slots && sl < 12; ++sl) { fprintf(stderr, "   slot %u k %u:", sl, sv[(size_t)sl * (nhr + 1) + nhr]); for (uint32_t q = 0; q < nhr && q < 6; ++q) fprintf(stderr, " %u", sv[(size_t)sl * (nhr + 1) + q] - (uint32_t)rv[r].beg); fprintf(stderr, "\n"); }
+						for (int cl = 0; cl < 2; ++cl) { std::vector<bs_pw_item> iv(pwh[cl]); (void)hipMemcpy(iv.data(), C.pw_items[cl], iv.size() * sizeof(bs_pw_item), hipMemcpyDeviceToHost); for (auto &I : iv) if (I.r == r) fprintf(stderr, "   item: slot0 %u nb %u\n", I.slot0, I.nb); } }
 				}
 			}
 		}
@@ -1573,13 +1619,19 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 			(void)hipEventRecord(ev[3], s); (void)hipEventSynchronize(ev[3]);
 			float a = 0, b = 0, c = 0;
 			(void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]); (void)hipEventElapsedTime(&c, ev[2], ev[3]);
+			float bpw = 0; (void)hipEventElapsedTime(&bpw, ev[4], ev[2]);
 			// records by the number of regions with holes of their range: <= 2 (closed form), 3..24, 25..64, 65..128, more
 			std::vector<uint32_t> nhv(n_rng); std::vector<bs_range> rv(n_rng);
 			uint64_t pw_rng = 0, pw_holes = 0, all_holes = 0; uint32_t pwh[4] = {0, 0, 0, 0};
-			{ std::vector<bs_meta> mv(n_rng); (void)hipMemcpy(mv.data(), C.meta, (size_t)n_rng * sizeof(bs_meta), hipMemcpyDeviceToHost); for (uint32_t r = 0; r < n_rng; ++r) { nhv[r] = mv[r].nh; all_holes += mv[r].hst[256]; if (mv[r].pw) { ++pw_rng; pw_holes += mv[r].hst[256]; } } }
+			uint64_t why[6][2] = {}; uint32_t max_h = 0, max_h_pw = 0;   // ranges / holes left to the serial walkers, by reason: <= 2 regions, few holes, few cycles of the first region, long cycles, more than 256 regions / no slots
+			{ std::vector<bs_meta> mv(n_rng); (void)hipMemcpy(mv.data(), C.meta, (size_t)n_rng * sizeof(bs_meta), hipMemcpyDeviceToHost); for (uint32_t r = 0; r < n_rng; ++r) { nhv[r] = mv[r].nh; const uint32_t P = mv[r].hst[256]; all_holes += P; if (mv[r].pw) { ++pw_rng; pw_holes += P; if (P > max_h_pw) max_h_pw = P; } else {
+				const uint32_t c0 = mv[r].nh ? mv[r].hst[mv[r].act[0] + 1u] - mv[r].hst[mv[r].act[0]] : 0u;
+				const int w = mv[r].nh <= 2 ? 0 : P < (uint32_t)PW_MIN_HOLES ? 1 : c0 < (uint32_t)PW_MIN_C0 ? 2 : 4;
+				++why[w][0]; why[w][1] += P; if (w && P > max_h) max_h = P; } } }
 			(void)hipMemcpy(pwh, C.hdr + 16, 16, hipMemcpyDeviceToHost);
-			fprintf(stderr, "BS level %d block-parallel walk: %llu of %u ranges, %llu of %llu holes, items %u + %u, snapshot words %llu of %u\n", level, (unsigned long long)pw_rng, n_rng,
-			        (unsigned long long)pw_holes, (unsigned long long)all_holes, pwh[0], pwh[1], (unsigned long long)pwh[2] | (unsigned long long)pwh[3] << 32, C.pw_words);
+			fprintf(stderr, "BS level %d block-parallel walk %.3f ms: %llu of %u ranges, %llu of %llu holes (largest %u), items %u + %u, snapshot words %llu of %u; serial: <=2 regions %llu/%llu, few holes %llu/%llu, few cycles %llu/%llu, long cycles %llu/%llu, no slots %llu/%llu, largest %u\n", level, bpw, (unsigned long long)pw_rng, n_rng,
+			        (unsigned long long)pw_holes, (unsigned long long)all_holes, max_h_pw, pwh[0], pwh[1], (unsigned long long)pwh[2] | (unsigned long long)pwh[3] << 32, C.pw_words,
+			        (unsigned long long)why[0][0], (unsigned long long)why[0][1], (unsigned long long)why[1][0], (unsigned long long)why[1][1], (unsigned long long)why[2][0], (unsigned long long)why[2][1], (unsigned long long)why[3][0], (unsigned long long)why[3][1], (unsigned long long)why[4][0], (unsigned long long)why[4][1], max_h);
 			(void)hipMemcpy(rv.data(), C.rng[0], (size_t)n_rng * sizeof(bs_range), hipMemcpyDeviceToHost);
 			uint64_t bins[5] = {0, 0, 0, 0, 0};
 			for (uint32_t r = 0; r < n_rng; ++r) bins[nhv[r] <= 2 ? 0 : nhv[r] <= 24 ? 1 : nhv[r] <= 64 ? 2 : nhv[r] <= 128 ? 3 : 4] += rv[r].n;
