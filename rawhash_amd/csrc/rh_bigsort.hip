@@ -49,13 +49,16 @@
 #define PW_BLK_HOLES (PW_WIN_CAP / 3)     // holes a block of cycles should pop at most (expected: cycles per round x average cycle length)
 #endif
 #define PW_MIN_CPR 4                      // fewest cycles followed at a time
+#ifndef PW_MAX_CYCLE
+#define PW_MAX_CYCLE 8                    // ranges whose cycles are longer than this on average stay with the serial walkers (measured at human scale: evenly filled regions - the exact re-sorts of reads with equal anchor keys, 24 targets or 256 values of a position byte - gain nothing: a block of their cycles is thousands of holes for one lane)
+#endif
 #ifdef RH_DEV
 #define PW_STAT(i, n) atomicAdd(&C.hdr[20 + (i)], (uint32_t)(n))   // development builds: [20] blocks walked by one lane, [21] ranges out of slots, [22] window misses, [23] cycles walked by one lane, [24] window reloads
 #else
 #define PW_STAT(i, n) ((void)0)
 #endif
 #ifndef PW_RING_BYTES
-#define PW_RING_BYTES 8192                // LDS of k_bs_pw_count's digit windows, shared by the regions in proportion to their holes
+#define PW_RING_BYTES 4096                // LDS of k_bs_pw_count's digit windows, shared by the regions in proportion to their holes
 #endif
 
 struct bs_range {
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(NT) void k_bs_clear(bs_ctx C)
 	if (r >= C.hdr[0]) return;
 	bs_meta &M = C.meta[r];
 	M.cnt[tid] = 0; M.inpl[tid] = 0;
-	if (r == 0 && tid < 8) C.hdr[16 + tid] = 0;                      // (the level's work items and snapshot cursor of the block-parallel walk)
+	if (r == 0 && tid < 12) C.hdr[16 + tid] = 0;                      // (the level's work items and snapshot cursor of the block-parallel walk)
 	// a range whose digits came with it: its keys are not read again; the parent's differing bits stand in for its own (their
 	// highest byte is the byte the digits were taken from; k_bs_fix looks at the keys if the range turns out to agree on it)
 	if (tid == 0) { const bs_range R = C.rng[0][r]; if (R.has_dg) { M.k_or = R.dmask; M.k_and = 0; } else { M.k_or = 0; M.k_and = ~0ull; } }
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(NT) void k_bs_scan(bs_ctx C)
 	if (tid == 0) {
 		M.hst[256] = total; M.nh = nh;
 		uint32_t pw = 0, ncpr = 0, off = 0, slots = 0;
-		if (C.pw_snap && nh >= 3 && nh <= 256 && total >= (uint32_t)PW_MIN_HOLES && s_c0 >= (uint32_t)PW_MIN_C0 && R.beg + total < (1ull << 32)) {
+		if (C.pw_snap && nh >= 3 && nh <= 256 && total >= (uint32_t)PW_MIN_HOLES && s_c0 >= (uint32_t)PW_MIN_C0 && (uint64_t)s_c0 * PW_MAX_CYCLE >= total && R.beg + total < (1ull << 32)) {
 			const uint32_t len = total / s_c0;                         // average cycle length if the first region's cycles were all (>= 2: a cycle pops its own hole and one that ends it)
 			ncpr = 64u;                                               // cycles followed at a time: fewer when they are long (one lane walks a block again)
 			while (ncpr > (uint32_t)PW_MIN_CPR && ncpr * len > (uint32_t)PW_BLK_HOLES) ncpr >>= 1;
@@ -1622,14 +1625,14 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 			float bpw = 0; (void)hipEventElapsedTime(&bpw, ev[4], ev[2]);
 			// records by the number of regions with holes of their range: <= 2 (closed form), 3..24, 25..64, 65..128, more
 			std::vector<uint32_t> nhv(n_rng); std::vector<bs_range> rv(n_rng);
-			uint64_t pw_rng = 0, pw_holes = 0, all_holes = 0; uint32_t pwh[4] = {0, 0, 0, 0};
+			uint64_t pw_rng = 0, pw_holes = 0, all_holes = 0; uint32_t pwh[12] = {};
 			uint64_t why[6][2] = {}; uint32_t max_h = 0, max_h_pw = 0;   // ranges / holes left to the serial walkers, by reason: <= 2 regions, few holes, few cycles of the first region, long cycles, more than 256 regions / no slots
 			{ std::vector<bs_meta> mv(n_rng); (void)hipMemcpy(mv.data(), C.meta, (size_t)n_rng * sizeof(bs_meta), hipMemcpyDeviceToHost); for (uint32_t r = 0; r < n_rng; ++r) { nhv[r] = mv[r].nh; const uint32_t P = mv[r].hst[256]; all_holes += P; if (mv[r].pw) { ++pw_rng; pw_holes += P; if (P > max_h_pw) max_h_pw = P; } else {
 				const uint32_t c0 = mv[r].nh ? mv[r].hst[mv[r].act[0] + 1u] - mv[r].hst[mv[r].act[0]] : 0u;
-				const int w = mv[r].nh <= 2 ? 0 : P < (uint32_t)PW_MIN_HOLES ? 1 : c0 < (uint32_t)PW_MIN_C0 ? 2 : 4;
+				const int w = mv[r].nh <= 2 ? 0 : P < (uint32_t)PW_MIN_HOLES ? 1 : c0 < (uint32_t)PW_MIN_C0 ? 2 : (uint64_t)c0 * PW_MAX_CYCLE < P ? 3 : 4;
 				++why[w][0]; why[w][1] += P; if (w && P > max_h) max_h = P; } } }
-			(void)hipMemcpy(pwh, C.hdr + 16, 16, hipMemcpyDeviceToHost);
-			fprintf(stderr, "BS level %d block-parallel walk %.3f ms: %llu of %u ranges, %llu of %llu holes (largest %u), items %u + %u, snapshot words %llu of %u; serial: <=2 regions %llu/%llu, few holes %llu/%llu, few cycles %llu/%llu, long cycles %llu/%llu, no slots %llu/%llu, largest %u\n", level, bpw, (unsigned long long)pw_rng, n_rng,
+			(void)hipMemcpy(pwh, C.hdr + 16, 48, hipMemcpyDeviceToHost);
+			fprintf(stderr, "BS level %d block-parallel walk %.3f ms [blocks by one lane %u, out of slots %u, window misses %u, cycles by one lane %u, window reloads %u]: %llu of %u ranges, %llu of %llu holes (largest %u), items %u + %u, snapshot words %llu of %u; serial: <=2 regions %llu/%llu, few holes %llu/%llu, few cycles %llu/%llu, long cycles %llu/%llu, no slots %llu/%llu, largest %u\n", level, bpw, pwh[4], pwh[5], pwh[6], pwh[7], pwh[8], (unsigned long long)pw_rng, n_rng,
 			        (unsigned long long)pw_holes, (unsigned long long)all_holes, max_h_pw, pwh[0], pwh[1], (unsigned long long)pwh[2] | (unsigned long long)pwh[3] << 32, C.pw_words,
 			        (unsigned long long)why[0][0], (unsigned long long)why[0][1], (unsigned long long)why[1][0], (unsigned long long)why[1][1], (unsigned long long)why[2][0], (unsigned long long)why[2][1], (unsigned long long)why[3][0], (unsigned long long)why[3][1], (unsigned long long)why[4][0], (unsigned long long)why[4][1], max_h);
 			(void)hipMemcpy(rv.data(), C.rng[0], (size_t)n_rng * sizeof(bs_range), hipMemcpyDeviceToHost);
