@@ -68,7 +68,8 @@ struct bs_range {
 	uint8_t buf;                          // which copy holds it: 0 = job source, 1 = alt
 	uint8_t shift;                        // highest byte shift this level may split on
 	uint8_t has_dg;                       // its digits were written by the placement of the level above (at the byte predicted from dmask)
-	uint8_t pad[5];
+	uint8_t exact;                        // this level's passes on the range reproduce the reference's permutation (hole lists + walk); 0: placed in any order (no equal keys in it)
+	uint8_t pad[4];
 	uint64_t dmask;                       // has_dg: bits on which the keys of the PARENT range differ below the parent's byte - a superset of this range's
 };
 
@@ -105,16 +106,31 @@ struct bs_ctx {
 	// bucket of more than one record (k_bs_plan), or the block sorter's tie flag of a bucket (small_tie, read by k_bs_tie_map) - and clears
 	// redo_skip of the segment the bucket lies in (found by position in seg_off): no pass over the sorted records to look for equal neighbours
 	const uint64_t *seg_off; uint32_t seg_n; uint8_t *redo_skip; uint8_t *small_tie[4];
+	// ... and sets a bit for every 64 positions of the sorted order the bucket covers (tie_bits; tie_path: the exact re-run of those segments, which
+	// reads them - a child range is exact only if its interval holds a marked position)
+	unsigned long long *tie_bits; uint8_t tie_path, any_order;
 	// block-parallel walk: pointer snapshots (pw_words 32-bit words, handed out per range by k_bs_scan through hdr[18]) and the blocks grouped
 	// into work items for k_bs_pw_walk, two lists (ranges with up to 64 / up to 256 regions that have holes; counted in hdr[16], hdr[17])
 	uint32_t *pw_snap; uint32_t pw_words; struct bs_pw_item *pw_items[2]; uint32_t pw_item_cap;
 };
 struct bs_pw_item { uint32_t r, slot0, nb, pad; };
-RH_DEV void bs_mark_tie(const bs_ctx &C, uint64_t pos)
+RH_DEV void bs_mark_tie(const bs_ctx &C, uint64_t pos, uint32_t len)
 {
 	uint32_t lo = 0, hi = C.seg_n;                                  // the last segment that starts at or before pos
 	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (C.seg_off[mid] <= pos) lo = mid; else hi = mid; }
 	C.redo_skip[lo] = 0;
+	if (C.tie_bits) for (uint64_t g = pos >> 6; g <= (pos + (len ? len - 1u : 0u)) >> 6; ++g) atomicOr(&C.tie_bits[g >> 6], 1ull << (g & 63u));
+}
+RH_DEV bool bs_has_tie(const bs_ctx &C, uint64_t pos, uint32_t len)   // a marked position in [pos, pos + len)
+{
+	const uint64_t g0 = pos >> 6, g1 = (pos + (len ? len - 1u : 0u)) >> 6;
+	for (uint64_t w = g0 >> 6; w <= g1 >> 6; ++w) {
+		unsigned long long m = ~0ull;
+		if (w == g0 >> 6) m &= ~0ull << (g0 & 63u);
+		if (w == g1 >> 6) m &= ~0ull >> (63u - (g1 & 63u));
+		if (C.tie_bits[w] & m) return true;
+	}
+	return false;
 }
 
 // the range a tile belongs to: looked up once per level (k_bs_tile_map), not by every kernel of the level (a binary search over
@@ -149,8 +165,8 @@ __global__ __launch_bounds__(NT) void k_bs_init(rh_sort_job jb, bs_ctx C)
 		const uint32_t tk = block_excl_scan(big ? (n + BS_TILE - 1) / BS_TILE : 0u, s_w, tot_t);
 		if (big) {
 			bs_range q;
-			q.beg = jb.off[a]; q.n = n; q.tile0 = s_run[1] + tk; q.buf = 0; q.shift = 56; q.has_dg = 0; q.dmask = 0;
-			for (int i = 0; i < 5; ++i) q.pad[i] = 0;
+			q.beg = jb.off[a]; q.n = n; q.tile0 = s_run[1] + tk; q.buf = 0; q.shift = 56; q.has_dg = 0; q.dmask = 0; q.exact = C.any_order ? 0 : 1;
+			for (int i = 0; i < 4; ++i) q.pad[i] = 0;
 			if (s_run[0] + rk < C.rng_cap) C.rng[0][s_run[0] + rk] = q;
 		}
 		__syncthreads();
@@ -369,7 +385,7 @@ __global__ __launch_bounds__(NT) void k_bs_plan(bs_ctx C)
 		else if (c <= C.n_lo) fate = BS_SMALL;
 		else fate = BS_BIG;
 	}
-	if (C.redo_skip && fate == BS_FINAL && c > 1) bs_mark_tie(C, R.beg + st);   // (any order: a final bucket of several records = equal keys)
+	if (C.redo_skip && fate == BS_FINAL && c > 1) bs_mark_tie(C, R.beg + st, c);   // (any order: a final bucket of several records = equal keys)
 	const uint8_t alt = R.buf ^ 1;
 	// Buckets for the block sorter go to one of two lists of the copy that holds them: 32-bit LDS keys when the bucket's keys
 	// agree on every bit from bit 32 up and that class takes a bucket of this size, 64-bit keys otherwise.  One atomic per
@@ -398,7 +414,8 @@ __global__ __launch_bounds__(NT) void k_bs_plan(bs_ctx C)
 		if (k < C.rng_cap) {
 			bs_range q;
 			q.beg = R.beg + st; q.n = c; q.tile0 = 0; q.buf = alt; q.shift = (uint8_t)(s - 8); q.has_dg = 1; q.dmask = low;
-			for (int i = 0; i < 5; ++i) q.pad[i] = 0;
+			q.exact = R.exact && (!C.tie_path || bs_has_tie(C, R.beg + st, c)) ? 1 : 0;   // (the way to the equal keys only)
+			for (int i = 0; i < 4; ++i) q.pad[i] = 0;
 			C.rng[1][k] = q;
 		} else C.hdr[7] = 1;
 	}
@@ -467,6 +484,7 @@ __global__ __launch_bounds__(NT) void k_bs_count(bs_ctx C)
 	if (blockIdx.x >= C.hdr[1]) return;
 	const uint32_t r = bs_find_range(C, blockIdx.x, n_rng, &s_r);
 	const bs_range R = C.rng[0][r];
+	if (!R.exact) return;
 	const bs_meta &M = C.meta[r];
 	s_start[tid] = M.start[tid]; s_inpl[tid] = 0;
 	if (tid == 0) s_start[256] = M.start[256];
@@ -501,6 +519,7 @@ __global__ __launch_bounds__(NT) void k_bs_scan(bs_ctx C)
 	if (r >= C.hdr[0]) return;
 	const bs_range R = C.rng[0][r];
 	bs_meta &M = C.meta[r];
+	if (!R.exact) { if (tid == 0) { M.nh = 0; M.pw = 0; M.hst[256] = 0; } return; }   // (placed in any order: nothing to walk)
 	const uint32_t nt = (R.n + BS_TILE - 1) / BS_TILE;
 	uint32_t run = 0;
 	for (uint32_t i0 = 0; i0 < nt; i0 += NT) {
@@ -558,6 +577,7 @@ __global__ __launch_bounds__(NT) void k_bs_holes(bs_ctx C)
 	if (blockIdx.x >= C.hdr[1]) return;
 	const uint32_t r = bs_find_range(C, blockIdx.x, n_rng, &s_r);
 	const bs_range R = C.rng[0][r];
+	if (!R.exact) return;
 	const bs_meta &M = C.meta[r];
 	__shared__ uint8_t s_dmap[256];
 	s_start[tid] = M.start[tid]; s_dmap[tid] = M.dmap[tid];
@@ -1338,6 +1358,7 @@ __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 	if (tile >= C.hdr[1]) return;
 	const uint32_t r = bs_find_range(C, tile, n_rng, &s_r);
 	const bs_range R = C.rng[0][r];
+	if (!R.exact) return;
 	const bs_meta &M = C.meta[r];
 	s_start[tid] = M.start[tid]; s_hst[tid] = M.hst[tid]; s_J[tid] = M.J[tid]; s_fate[tid] = M.fate[tid];
 	if (tid == 0) { s_start[256] = M.start[256]; s_hst[256] = M.hst[256]; }
@@ -1386,6 +1407,7 @@ __global__ __launch_bounds__(NT) void k_bs_scatter_any(bs_ctx C)
 	if (tile >= C.hdr[1]) return;
 	const uint32_t r = bs_find_range(C, tile, n_rng, &s_r);
 	const bs_range R = C.rng[0][r];
+	if (R.exact) return;
 	bs_meta &M = C.meta[r];
 	s_start[tid] = M.start[tid]; s_fate[tid] = M.fate[tid]; s_cnt[tid] = 0;
 	__syncthreads();
@@ -1421,7 +1443,7 @@ __global__ __launch_bounds__(NT) void k_bs_scatter_any(bs_ctx C)
 __global__ __launch_bounds__(NT) void k_bs_tie_map(bs_ctx C, int q, uint32_t ns)
 {
 	const uint32_t b = blockIdx.x * NT + threadIdx.x;
-	if (b < ns && C.small_tie[q][b]) bs_mark_tie(C, C.small_off[q][b]);
+	if (b < ns && C.small_tie[q][b]) bs_mark_tie(C, C.small_off[q][b], C.small_cnt[q][b] ? C.small_cnt[q][b] : C.n_lo);   // (a count the block sorter has cleared: no bucket is longer than n_lo)
 }
 // ... and how many segments that makes: hdr[12]
 __global__ __launch_bounds__(NT) void k_bs_tie_count(bs_ctx C)
@@ -1464,6 +1486,7 @@ size_t rhk_bigsort_ws_bytes(uint64_t total, uint32_t n_lo)
 	const uint64_t t = total ? total : 1, lo = n_lo ? n_lo : 1;
 	const uint64_t rng_cap = t / (lo + 1) + 2, small_cap = t / 8 + 256, tiles = t / BS_TILE + rng_cap + 2;
 	size_t b = 256;                                                // hdr
+	b += ((t / 512 + 64) + 255) & ~(size_t)255;                     // tie_bits: one bit per 64 positions
 	b += 2 * ((rng_cap * sizeof(bs_range) + 255) & ~(size_t)255);
 	b += (rng_cap * sizeof(bs_meta) + 255) & ~(size_t)255;
 	b += 2 * ((tiles * 4 + 255) & ~(size_t)255);
@@ -1491,6 +1514,10 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	unsigned char *p = jb.big_ws;
 	auto take = [&](size_t bytes) { unsigned char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
 	C.hdr = (uint32_t*)take(256);
+	unsigned long long *tie_bits = (unsigned long long*)take((size_t)(t / 512 + 64));   // (first, so that the exact re-run of an any-order job finds it where that job left it)
+	C.any_order = jb.any_order ? 1 : 0; C.tie_path = !jb.any_order && jb.tie_path ? 1 : 0;
+	C.tie_bits = (jb.any_order && jb.redo_skip) || C.tie_path ? tie_bits : nullptr;
+	if (jb.any_order && C.tie_bits) RH_HIP(hipMemsetAsync(tie_bits, 0, (size_t)(t / 512 + 64), s));
 	C.rng[0] = (bs_range*)take((size_t)C.rng_cap * sizeof(bs_range)); C.rng[1] = (bs_range*)take((size_t)C.rng_cap * sizeof(bs_range));
 	C.meta = (bs_meta*)take((size_t)C.rng_cap * sizeof(bs_meta));
 	C.tile_h = (uint32_t*)take(tiles_cap * 4); C.tile_rng = (uint32_t*)take(tiles_cap * 4);
@@ -1546,8 +1573,8 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		if (level) BS_LAUNCH_REC(k_bs_fix, n_rng, C);
 		else { BS_LAUNCH_REC(k_bs_fix0, n_rng, C, gs); n_rng0 = n_rng; }
 		RH_LAUNCH(k_bs_plan, n_rng, NT, 0, s, C);
-		if (jb.any_order) {	// no holes, no walk: tiles reserve stretches of their buckets
-			BS_LAUNCH_REC(k_bs_scatter_any, n_tiles, C);
+		if (jb.any_order || C.tie_path) BS_LAUNCH_REC(k_bs_scatter_any, n_tiles, C);   // no holes, no walk: tiles reserve stretches of their buckets (tie_path: the ranges off the way to the equal keys)
+		if (jb.any_order) {
 			RH_LAUNCH(k_bs_next, 1, NT, 0, s, C);
 			bs_range *tmp2 = C.rng[0]; C.rng[0] = C.rng[1]; C.rng[1] = tmp2;
 			continue;

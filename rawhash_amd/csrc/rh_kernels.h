@@ -232,6 +232,10 @@ struct rh_sort_job {
 	// which sort of the path this is (1 anchors, 2 chain candidates, 3 chains, 4 regions, 0 anything else): the multi-workgroup sorter
 	// remembers per kind the byte its first level split on (rh_bigsort.hip: k_bs_hist0)
 	uint8_t kind;
+	// the exact re-run of the segments an any-order job found equal keys in (skip = its redo_skip): that job also left, in the sorter's scratch, WHERE in the
+	// sorted order the equal keys lie, and the re-run takes its exact passes only along the way to them - a range of a level (an interval of the sorted order)
+	// that holds no equal keys has one sorted order and is placed in any order again.  Only right after that job, on the same scratch.
+	uint8_t tie_path;
 	// 8-byte records (see rh_rec_fmt): src / dst / big_alt then point to uint64_t arrays (same record offsets)
 	rh_rec_fmt rf;
 };

@@ -1685,7 +1685,7 @@ int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, co
 		if (rhk_sort_job(s, jb, false, 0u)) return -1;
 		if (n_redo) {
 			RH_LAUNCH(k_chain_keys, r.n_act, NT, 0, s, r, (const uint8_t*)r.need_exact);
-			jb.any_order = 0; jb.redo_skip = nullptr; jb.n_redo = nullptr; jb.skip = r.need_exact;
+			jb.any_order = 0; jb.redo_skip = nullptr; jb.n_redo = nullptr; jb.skip = r.need_exact; jb.tie_path = 1;
 			if (rhk_sort_job(s, jb, false, 0u)) return -1;
 		}
 	}
@@ -1719,7 +1719,7 @@ int rhk_regions_sort(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd,
 	if (trace) fprintf(stderr, "RSORT any-order: %u of %u reads hold equal region keys and are redone\n", n_redo, r.n_act);
 	if (!n_redo) return 0;
 	RH_LAUNCH(k_regions_prep, r.n_act, NT, 0, s, o, rd, r, (const uint8_t*)r.need_exact);   // their keys again (the sorter overwrote its input)
-	jb.any_order = 0; jb.redo_skip = nullptr; jb.n_redo = nullptr; jb.skip = r.need_exact;   // (covers r.skip: the check marks skipped reads "no redo")
+	jb.any_order = 0; jb.redo_skip = nullptr; jb.n_redo = nullptr; jb.skip = r.need_exact; jb.tie_path = 1;   // (covers r.skip: the check marks skipped reads "no redo")
 	return rhk_sort_job(s, jb, false, (uint32_t)RG_SMALL);
 }
 

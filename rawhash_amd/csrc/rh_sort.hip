@@ -878,6 +878,6 @@ int rhk_sort(hipStream_t s, const rh_dev_index &ix, const rh_dev_round &r, const
 	if (trace) fprintf(stderr, "ASORT any-order: chunk %u: %u of %u reads hold equal anchor keys and are redone\n", r.chunk, n_redo, r.n_act);
 	if (!n_redo) return 0;
 	if (reexpand(r.need_exact2)) return -1;
-	jb.any_order = 0; jb.redo_skip = nullptr; jb.n_redo = nullptr; jb.skip = r.need_exact2;   // (covers r.skip: the check marks skipped segments "no redo")
+	jb.any_order = 0; jb.redo_skip = nullptr; jb.n_redo = nullptr; jb.skip = r.need_exact2; jb.tie_path = 1;   // (covers r.skip: the check marks skipped segments "no redo")
 	return rhk_sort_job(s, jb, false, 0u);
 }

@@ -340,6 +340,15 @@ def check_sort_big(ctx, seed=0, sizes=(20000, 33000, 9000), kinds=(0, 1, 2, 3, 4
             x[m] = rng.integers(16, hi, size=int(m.sum()), dtype=np.uint64)
             if i % 2:          # skewed scores: most chains have two anchors
                 x[m & (rng.random(n) < 0.5)] = 17
+        elif kind in (9, 10):    # one to three pairs / triples of equal keys among otherwise distinct ones: the any-order pass + the exact re-run that
+            # takes its exact passes only on the way to the equal keys (rh_sort_job::tie_path); 9 anchor keys, 10 region keys (score << 32 | hash)
+            if kind == 9:
+                x = (rng.integers(0, 2, size=n, dtype=np.uint64) << np.uint64(63)) | (rng.integers(0, 24, size=n, dtype=np.uint64) << np.uint64(32)) | rng.permutation(np.unique(rng.integers(0, 1 << 27, size=2 * n + 64, dtype=np.uint64)))[:n]
+            else:
+                x = (rng.integers(40, 200, size=n, dtype=np.uint64) << np.uint64(32)) | rng.permutation(np.unique(rng.integers(0, 1 << 30, size=2 * n + 64, dtype=np.uint64)))[:n]
+            for _ in range(int(rng.integers(1, 4))):
+                j = rng.integers(0, n, size=int(rng.integers(2, 4)))
+                x[j] = x[j[0]]
         elif kind == 3:    # three values of one byte, the rest equal
             x = (rng.integers(0, 3, size=n, dtype=np.uint64) << np.uint64(8 * int(rng.integers(1, 8)))) | np.uint64(7)
         else:

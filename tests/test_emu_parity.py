@@ -53,7 +53,14 @@ def test_exact_sort_block_parallel_walk(ctx, emu_lib_smallcaps):
     pc.check_sort_big(ctx, seed=12, sizes=(40000, 21000), kinds=(7, 8))
     c = Context(0, lib=emu_lib_smallcaps)
     pc.check_sort_big(c, seed=13, sizes=(5000, 3000, 7000, 2500, 9000, 4000), kinds=(6, 7, 8))
+    pc.check_sort_big(c, seed=14, sizes=(6000, 2600, 9000, 3100), kinds=(9, 10))   # a few equal keys: exact passes only on the way to them
     c.close()
+
+
+def test_exact_sort_tie_path(ctx):
+    """Segments with one to three groups of equal keys among distinct ones (anchor keys, region keys): the any-order pass marks where the equal keys lie,
+    the exact re-run walks only the ranges on the way to them and places the rest in any order again - result = radix_sort_128x's permutation."""
+    pc.check_sort_big(ctx, seed=15, sizes=(40000, 26000, 90000, 12000), kinds=(9, 10))
 
 
 def test_any_order_sort(ctx):
