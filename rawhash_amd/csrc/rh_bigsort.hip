@@ -69,7 +69,7 @@ struct bs_range {
 	uint8_t shift;                        // highest byte shift this level may split on
 	uint8_t has_dg;                       // its digits were written by the placement of the level above (at the byte predicted from dmask)
 	uint8_t exact;                        // this level's passes on the range reproduce the reference's permutation (hole lists + walk); 0: placed in any order (no equal keys in it)
-	uint8_t pad[4];
+	uint32_t dead;                        // the range starts with this many records that nobody reads once sorted (rh_sort_job::dead_cnt): all one key, the lowest
 	uint64_t dmask;                       // has_dg: bits on which the keys of the PARENT range differ below the parent's byte - a superset of this range's
 };
 
@@ -165,8 +165,7 @@ __global__ __launch_bounds__(NT) void k_bs_init(rh_sort_job jb, bs_ctx C)
 		const uint32_t tk = block_excl_scan(big ? (n + BS_TILE - 1) / BS_TILE : 0u, s_w, tot_t);
 		if (big) {
 			bs_range q;
-			q.beg = jb.off[a]; q.n = n; q.tile0 = s_run[1] + tk; q.buf = 0; q.shift = 56; q.has_dg = 0; q.dmask = 0; q.exact = C.any_order ? 0 : 1;
-			for (int i = 0; i < 4; ++i) q.pad[i] = 0;
+			q.beg = jb.off[a]; q.n = n; q.tile0 = s_run[1] + tk; q.buf = 0; q.shift = 56; q.has_dg = 0; q.dmask = 0; q.exact = C.any_order ? 0 : 1; q.dead = jb.dead_cnt && !C.any_order ? jb.dead_cnt[a] : 0u;
 			if (s_run[0] + rk < C.rng_cap) C.rng[0][s_run[0] + rk] = q;
 		}
 		__syncthreads();
@@ -415,7 +414,7 @@ __global__ __launch_bounds__(NT) void k_bs_plan(bs_ctx C)
 			bs_range q;
 			q.beg = R.beg + st; q.n = c; q.tile0 = 0; q.buf = alt; q.shift = (uint8_t)(s - 8); q.has_dg = 1; q.dmask = low;
 			q.exact = R.exact && (!C.tie_path || bs_has_tie(C, R.beg + st, c)) ? 1 : 0;   // (the way to the equal keys only)
-			for (int i = 0; i < 4; ++i) q.pad[i] = 0;
+			q.dead = st == 0 ? R.dead : 0u;                             // (the lowest keys are in the first bucket that is not empty)
 			C.rng[1][k] = q;
 		} else C.hdr[7] = 1;
 	}
@@ -1369,6 +1368,9 @@ __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 	const REC *src = reinterpret_cast<const REC*>(C.buf[R.buf]) + R.beg;
 	REC *out_alt = reinterpret_cast<REC*>(C.buf[R.buf ^ 1]) + R.beg, *out_fin = reinterpret_cast<REC*>(C.dst) + R.beg;
 	const uint32_t *hp = C.hp + R.beg, *dest = C.dest + R.beg;
+	// records nobody reads once sorted (bs_range::dead): when their bucket - the first that is not empty - is final and holds just them, they stay where they are
+	uint32_t dead_b = 256u;
+	if (R.dead) { const uint32_t b0 = bs_region(s_start, 0u); if (s_fate[b0] == BS_FINAL && s_start[b0 + 1u] - s_start[b0] == R.dead) dead_b = b0; }
 	// the buckets that are next-level ranges get their digits now, while the record is in a register: the byte they will be
 	// split on is the highest one on which this range's keys differ below its own byte
 	uint8_t *dgn = C.dg_next + R.beg;
@@ -1379,6 +1381,7 @@ __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 		const uint32_t p = t0 + (uint32_t)it * NT + tid;
 		if (p >= R.n) continue;
 		const uint32_t d = q.d[it], b = q.b[it], hb = hbase + q.hb[it];
+		if (d == dead_b) continue;
 		uint32_t np;
 		if (d == b) np = p + ((hb - s_hst[b]) < s_J[b] ? 1u : 0u);
 		else {
@@ -1680,7 +1683,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		sj.n_seg = ns; sj.skip = nullptr; sj.off = C.small_off[q]; sj.cnt = C.small_cnt[q];
 		sj.src = (const rh_mm128_t*)C.buf[q >> 1]; sj.dst = jb.dst; sj.need_exact = C.redo_skip ? C.small_tie[q] : nullptr; sj.n_max = pin[8 + q] < n_lo ? pin[8 + q] : n_lo;   // (an LDS class above the list's largest bucket would be a launch of blocks that all leave at once, each waiting for its LDS)
 		if ((q & 1) && !job32) { sj.kc_on = 1; sj.kc_lo = 32; sj.kc_mid = 0; sj.kc_hi = 0; }   // keys that differ below bit 32 only: 32-bit words in LDS
-		sj.big_alt = nullptr; sj.big_ws = nullptr; sj.rf.up = 0;       // (the block sorter takes its keys at their original positions)
+		sj.big_alt = nullptr; sj.big_ws = nullptr; sj.dead_cnt = nullptr; sj.rf.up = 0;       // (the block sorter takes its keys at their original positions)
 		sj.any_order = 0; sj.redo_skip = nullptr; sj.n_redo = nullptr; sj.cnt_rw = C.small_cnt[q];
 		if (C.redo_skip) RH_HIP(hipMemsetAsync(C.small_tie[q], 0, ns, s));
 		if (rhk_sort_job(s, sj, all_exact, 1u)) return -1;

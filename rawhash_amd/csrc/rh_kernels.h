@@ -236,6 +236,10 @@ struct rh_sort_job {
 	// sorted order the equal keys lie, and the re-run takes its exact passes only along the way to them - a range of a level (an interval of the sorted order)
 	// that holds no equal keys has one sorted order and is placed in any order again.  Only right after that job, on the same scratch.
 	uint8_t tie_path;
+	// dead_cnt[a] records of segment a - its lowest keys, all equal - are never looked at in the sorted order (the backtrack candidates without a
+	// predecessor: k_zbuild): they take part in the permutation like any other record, but the multi-workgroup sorter does not move them once their
+	// bucket is final (their stretch of dst stays unwritten).  Null: none.
+	const uint32_t *dead_cnt;
 	// 8-byte records (see rh_rec_fmt): src / dst / big_alt then point to uint64_t arrays (same record offsets)
 	rh_rec_fmt rf;
 };

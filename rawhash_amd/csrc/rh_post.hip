@@ -32,7 +32,7 @@ extern "C" __attribute__((visibility("default"))) int rh_debug_kprof_post(unsign
 
 // ------------------------------------------------------------------------------------------------ k_zbuild
 // candidates without a predecessor are passed over by the backtrack (see k_zbuild): plain chaining, one-word anchors (one span), chains of >= 2 anchors
-RH_DEV bool bt_lone_on(const rh_dev_opt &o, const rh_dev_round &rr) { return o.min_cnt >= 2 && rr.afmt.rec8 && !(o.flag & RH_M_RMQ) && !(o.bw_long > o.bw); }
+RH_HD inline bool bt_lone_on(const rh_dev_opt &o, const rh_dev_round &rr) { return o.min_cnt >= 2 && rr.afmt.rec8 && !(o.flag & RH_M_RMQ) && !(o.bw_long > o.bw); }
 __global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 {
 	__shared__ uint32_t s_w[NT / 64];
@@ -124,9 +124,9 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 	const int32_t n_lone = bt_lone_on(o, rr) ? (int32_t)rr.n_v[a] : 0;   // candidates without a predecessor: the lowest scores, passed over (k_zbuild)
 	for (int32_t kt = n_z; kt > n_lone; kt -= 64) {                // candidates from the best score down (lchain.c:148)
 		const int32_t k = kt - 1 - (int32_t)lane;
-		const uint32_t w0 = k >= 0 ? (rr.z8 ? (uint32_t)zs8[k] : (uint32_t)zs[k].y) : 0u;
+		const uint32_t w0 = k >= n_lone ? (rr.z8 ? (uint32_t)zs8[k] : (uint32_t)zs[k].y) : 0x80000000u;   // (the first n_lone sorted candidates are not there to be read: the sorter leaves their stretch unwritten, rh_sort_job::dead_cnt)
 		const int32_t i0 = (int32_t)(w0 & 0x7FFFFFFFu);
-		bool pending = k >= 0 && !(w0 >> 31), accepted = false;     // (bit 31: a chain of one anchor that nothing else touches - k_zbuild)
+		bool pending = k >= n_lone && !(w0 >> 31), accepted = false;     // (bit 31: a chain of one anchor that nothing else touches - k_zbuild)
 		int32_t r_cnt = 0, r_sc = 0;
 		int32_t pn1 = 0, pn2 = 0, pn3 = 0;                             // the first anchors of the path after i0 (most chains are this short)
 		for (;;) {
@@ -1660,6 +1660,7 @@ int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 	sort_scratch(jb, r, r.prev_out);                               // (the carry staging is written by k_chain_gather, later)
 	jb.kind = 2;
 	if (r.z8) jb.rf = rh_rec_fmt{1, 32, 32, 0};                     // 8-byte candidates: key = the high word
+	if (bt_lone_on(o, r)) jb.dead_cnt = r.n_v;                      // the candidates without a predecessor (k_zbuild): the backtrack stops before them
 	return rhk_sort_job(s, jb, true, 0u);
 }
 

@@ -1,7 +1,7 @@
 # sorter / golden parity on the GPU, the 3-stream bench line and the 1-stream kernel table of the build in the tree.  Usage: bash tools/r05_one.sh <tag> [kernel-name filter]
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; O=$R/gpurun_out; TAG=${1:-one}; PAT=${2:-k_bs_}; mkdir -p $O
-cd $R; timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "sort or golden or config2 or repeat or regions or human" 2>&1 | tail -3
+cd $R; timeout 420 python -m pytest tests/test_gpu_parity.py -m gpu -x -q --timeout 200 -k "sort or golden or config2 or repeat or regions or human" 2>&1 | tail -3
 timeout 600 python bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-h2d 2>/dev/null | tail -1 > $O/${TAG}_x.json
 python - <<PY
 import json
