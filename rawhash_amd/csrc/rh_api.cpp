@@ -157,6 +157,7 @@ int fill_dev_opt(rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
 		if (mo->dtw_border_constraint > 1u || mo->dtw_fill_method > 1u) { rh_set_error("DTW border constraint %u / fill method %u not supported (global | sparse, full | banded)", mo->dtw_border_constraint, mo->dtw_fill_method); return -1; }
 	}
 	if (mo->min_num_anchors < 1) { rh_set_error("min_num_anchors %d < 1", mo->min_num_anchors); return -1; }
+	if ((mo->flag & RH_M_ALL_CHAINS) && mo->min_num_anchors < 2) { rh_set_error("all-chains output with chains of one anchor (min_num_anchors %d) is not supported: a read's reported chains are staged in one 16-byte slot per anchor, two words per chain", mo->min_num_anchors); return -1; }
 	if (mo->window_length1 > 64 || mo->window_length2 > 64) { rh_set_error("segmentation windows > 64 not supported"); return -1; }
 	memset(o, 0, sizeof(*o));
 	o->chunk_size = mo->chunk_size; o->max_num_chunk = mo->max_num_chunk; o->min_events = mo->min_events;
@@ -1503,6 +1504,9 @@ extern "C" int rh_events_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_b
 	c->cs_stride = m2.max_num_chunk + 1;
 	rh_dev_opt o;
 	if (fill_dev_opt(c, &m2, &o)) return -1;
+	// (this stage-level call runs the LDS-resident chunk kernels with a chunk's row strides, whatever the context mapped last)
+	if (m2.chunk_size > RH_CHUNK_MAX) { rh_set_error("rh_events_batch: chunks of more than %d samples are only supported through rh_map_batch", RH_CHUNK_MAX); return -1; }
+	if (set_row_strides(c, &m2, in)) return -1;
 	o.min_events = 0;
 	const uint32_t R = in->n_reads;
 	hipStream_t s = c->stream;

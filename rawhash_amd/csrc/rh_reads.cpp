@@ -231,7 +231,9 @@ static rh_reads *reads_load_blow5(const char *path)
 		at += 8;
 		uint64_t rsz; memcpy(&rsz, szb, 8);
 		if (at > fsize || rsz > fsize - at || rsz >= (1ull << 32)) return fail(r, "implausible BLOW5 record size");
-		const uint64_t body_cap = rsz * 256u + (1u << 20) < kMaxRecordBytes ? rsz * 256u + (1u << 20) : kMaxRecordBytes;   // a decompressed record: nothing compresses a read 256-fold   // (records are one read: far below 4 GiB, which is also what zlib's 32-bit counters take)
+		// a decompressed record: deflate expands at most ~1032-fold (a long flat signal does compress that well), zstd is bounded by the record limit; records are
+		// one read - far below 4 GiB, which is also what zlib's 32-bit counters take
+		const uint64_t body_cap = rsz * 1040u + (1u << 20) < kMaxRecordBytes ? rsz * 1040u + (1u << 20) : kMaxRecordBytes;
 		raw.resize(rsz);
 		if (rsz && fread(raw.data(), 1, rsz, fp) != rsz) return fail(r, "truncated BLOW5 record");
 		at += rsz;
