@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MAX_CALL_READS = 262_144   # --reads beyond this: the set is generated and mapped shard by shard (bench_big_set)
 
 WORKLOADS = {
     #          chrom_len, n_chrom, preset, reads/GPU, cpu sample, name
@@ -79,6 +80,8 @@ def main():
     ap.add_argument("--mapopt", default="", choices=["", "rmq", "bw_long", "dtw"],
                     help="secondary lines for the chaining variants of SURVEY 8 f4: rmq = --rmq (mg_lchain_rmq), bw_long = --bw-long 2000 (RMQ re-chaining), "
                          "dtw = --dtw-evaluate-chains on a --store-sig index (built on the device)")
+    ap.add_argument("--pool", type=int, default=4, help="distinct read batches kept resident and mapped in turn (a step never maps the batch of the step before)")
+    ap.add_argument("--shard", type=int, default=65_536, help="--reads beyond what one call takes: reads per rh_map_batch call (the set is generated shard by shard)")
     ap.add_argument("--cpu-threads", default="", help="thread counts of the CPU sweep, comma separated (default: cores/8 .. cores)")
     args = ap.parse_args()
     if args.workload == "ava":
@@ -154,8 +157,14 @@ def main():
         dist.barrier()                                     # the model file is there
         keep.append(replicate_index(ctx, opts, None, device=f"cuda:{local_rank}"))
         dist.barrier()
-    # this rank's shard of the read set, generated straight into HBM
-    batch = wl.reads_device(ctx, model, rank * args.reads, args.reads)
+    if args.reads > MAX_CALL_READS:
+        return bench_big_set(args, ctx, wl, opts, index, model, workdir, preset, wl_name, n_chrom, chrom_len, rank, world, cores)
+    # this rank's shard of the read set, generated straight into HBM: `pool` distinct batches, mapped in turn (batch b = reads
+    # [(b * world + rank) * reads, +reads) of the synthetic set; each lives in the buffers of a context of its own that never maps)
+    n_pool = max(1, min(args.pool, args.steps + args.warmup))
+    gens = [ctx] + [Context(local_rank) for _ in range(n_pool - 1)]
+    batches = [wl.reads_device(g, model, (b * world + rank) * args.reads, args.reads) for b, g in enumerate(gens)]
+    batch = batches[0]
     t_setup = time.time() - t_setup
 
     def sync():
@@ -165,15 +174,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    recs = None
+    recs = None                                # the records of batch 0 = the first reads of the set: what the CPU sample and the upload-inclusive legs map
+    turn = 0
     for _ in range(args.warmup):
-        recs = ctx.map_batch(opts, batch)
+        r_ = ctx.map_batch(opts, batches[turn % n_pool])
+        if turn % n_pool == 0:
+            recs = r_
+        turn += 1
     acc = {}
     stage_ms, stage_n = {}, {}
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        recs = ctx.map_batch(opts, batch)      # synchronous: returns after the records are back on the host
+        r_ = ctx.map_batch(opts, batches[turn % n_pool])      # synchronous: returns after the records are back on the host
+        if turn % n_pool == 0:
+            recs = r_
+        turn += 1
         st = ctx.stats()
         for k, v in st.items():
             if k not in ("stages", "ms_total"):
@@ -183,12 +199,16 @@ def main():
             stage_n[k] = stage_n.get(k, 0) + n
     sync()
     elapsed = time.perf_counter() - t0
+    if recs is None:
+        recs = ctx.map_batch(opts, batch)
+    for g in gens[1:]:
+        g.close()                              # (the other batches' buffers go before the upload-inclusive legs and the index download)
     n_mapped = int(recs["mapped"].sum())
     # The same steps with the batch handed over in (page-locked) HOST memory: every step uploads the int16 signal over PCIe,
     # each sub-batch its slice on its own stream (the upload of one overlaps the kernels of the others).  Reported next to
     # `value`, never instead of it.  (RH_BENCH_IN_FLIGHT=2 keeps two steps in flight with rh_map_submit / rh_map_wait, what
     # kt_pipeline does in the reference; on one GPU it halves each batch's arena share and measured slower, see DESIGN.md.)
-    elapsed_h2d = elapsed_full = None
+    elapsed_h2d = elapsed_full = count_s = None
     if args.h2d:
         host = host_copy(ctx, batch, args)
         sync()
@@ -206,6 +226,7 @@ def main():
         sync()
         elapsed_h2d = time.perf_counter() - t0
         assert (recs_h["mapped"] == recs["mapped"]).all() and (recs_h["tag_sl"] == recs["tag_sl"]).all()
+        count_s = host["count_s"]
         # ... and without the reader's counts: the whole int16 batch is uploaded before the rounds start (a few steps, for the record)
         n_full = min(args.steps, 3)
         sync()
@@ -245,6 +266,11 @@ def main():
             "value_h2d_included": None if not elapsed_h2d else round(total_reads / elapsed_h2d, 1),
             "ms_per_step_h2d_included": None if not elapsed_h2d else round(1e3 * elapsed_h2d / args.steps, 3),
             "value_h2d_full_upload": None if not elapsed_full else round(args.reads * world / elapsed_full, 1),
+            "count_filtered_s_per_batch": None if count_s is None else round(count_s, 4),   # the reader's pass that produces n_filtered (rh_count_filtered, host, one thread per the library's default): outside the timed region
+            "value_h2d_included_with_counting": None if not elapsed_h2d or count_s is None else round(total_reads / (elapsed_h2d + count_s * args.steps), 1),
+            "metric_note": "`value` = the task contract's number (the int16 signal resident in HBM when the timed region starts); SURVEY.md 8(d) words the metric with the "
+                           "host-to-device copy of the batches INCLUDED: that is `value_h2d_included`",
+            "batches": f"{n_pool} distinct batches of {args.reads} reads per GPU resident in HBM, mapped in turn (no step maps the batch of the step before)",
             "h2d_note": "value_h2d_included: batch in page-locked host memory with the reader's per-read filtered counts (rh_read_batch_t.n_filtered), the device fetches "
                         "the stretches of signal the rounds consume; value_h2d_full_upload: no counts, the whole int16 batch is uploaded first",
             "gsamples_per_s_consumed": round(acc["n_samples_used"] * world / elapsed / 1e9, 4),
@@ -253,7 +279,7 @@ def main():
             "chunks_per_read": round(acc["n_chunks"] / acc["n_reads"], 3),
             "anchors_per_chunk": round(acc["n_anchors"] / max(acc["n_chunks"], 1), 1),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom, args, stage_n[dom] / args.steps),
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom, args, stage_n[dom] / args.steps), "traffic_source": pmc_source(args),
                          "avg_launch_ms": round(stage_ms[dom] / stage_n[dom], 4), "launches": stage_n[dom],
                          "algorithmic_bytes_per_launch": int(dom_bytes / stage_n[dom]),
                          "concurrent_streams": n_streams,
@@ -277,6 +303,96 @@ def main():
     if rank == 0:
         import shutil
         shutil.rmtree(workdir, ignore_errors=True)
+
+
+def bench_big_set(args, ctx, wl, opts, index, model, workdir, preset, wl_name, n_chrom, chrom_len, rank, world, cores):
+    """`--reads N` beyond one call (BASELINE config 4's per-GPU share: 10 M reads / 8 GPUs = 1.25 M): the set is produced shard by shard the way a reader
+    would hand it over - generated, brought to page-locked host memory with the per-read filtered counts - and every shard is mapped by one rh_map_batch
+    call FROM HOST MEMORY (the upload is inside the timed region; generation, the copy to the host and the counting are the reader's, outside it).
+    value = reads / sum of the calls' times.  The CPU sample is 16 blocks of reads spread evenly over the whole set, PAF compared with the reference's."""
+    import copy
+    import numpy as np
+    import oracle_lib as O
+    from rawhash_amd import paf_lines, strip_mt
+    from rawhash_amd.api import Reads
+    if world != 1:
+        sys.exit("--reads beyond one call is a one-GPU measurement (the per-GPU share of a sharded set)")
+    N, shard = args.reads, max(1024, args.shard)
+    n_blocks = 16
+    blk = max(1, (args.cpu_sample if args.cpu_sample > 0 else 4096) // n_blocks)
+    starts = [min(N - blk, k * (N // n_blocks) + (N // n_blocks) // 3) for k in range(n_blocks)]     # (not the shards' first reads)
+    got_recs = {}
+    t_calls, t_count, t_reader, per_call = 0.0, 0.0, 0.0, []
+    acc, n_mapped = {}, 0
+    ctx.map_batch(opts, wl.reads_device(ctx, model, 0, min(shard, 8192)))      # warm-up: arenas, kernels
+    for s0 in range(0, N, shard):
+        n = min(shard, N - s0)
+        t0 = time.perf_counter()
+        b = wl.reads_device(ctx, model, s0, n)
+        a2 = copy.copy(args); a2.reads = n
+        host = host_copy(ctx, b, a2)
+        t_reader += time.perf_counter() - t0
+        t_count += host["count_s"]
+        t0 = time.perf_counter()
+        recs = ctx.map_batch(opts, host["batch"])
+        dt = time.perf_counter() - t0
+        t_calls += dt
+        per_call.append(round(1e3 * dt, 1))
+        n_mapped += int(recs["mapped"].sum())
+        for k, v in ctx.stats().items():
+            if k not in ("stages", "ms_total"):
+                acc[k] = acc.get(k, 0) + v
+        for st in starts:
+            lo, hi = max(st, s0), min(st + blk, s0 + n)
+            if lo < hi:
+                got_recs.setdefault(st, []).append(recs[lo - s0:hi - s0].copy())
+        ctx._l.rh_pinned_free(host["pin"])
+    value = N / t_calls
+    path_bytes = 2 * acc["n_samples_used"] + 16 * acc["n_seeds"] + 8 * acc["n_hits"] + 32 * acc["n_anchors"] + 16 * acc["n_chained"] + 64 * acc["n_reads"]
+    out = {"metric": f"reads/sec mapped ({wl_name} index resident in HBM), {N} reads in {len(per_call)} consecutive calls from host memory", "value": round(value, 1), "unit": "reads/s",
+           "n_gpus": 1, "steps": len(per_call), "warmup": 1, "ms_per_step": round(1e3 * t_calls / len(per_call), 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "int16 signal; fp32/fp64 events; u64/i32 seeding+chaining", "data": "synthetic",
+           "config": {"workload": f"{wl_name}: synthetic genome {n_chrom} x {chrom_len} bp, {N} synthetic R9.4 reads x {args.samples} samples (BASELINE config 4's share of one of 8 GPUs), preset {preset}, "
+                                  f"{args.junk}/1024 unmappable reads, index built on the device and resident in HBM ({index.n_keys} keys, {index.n_positions} positions); every call gets "
+                                  f"{shard} reads in page-locked host memory with the reader's filtered counts and fetches the signal it consumes over PCIe inside the timed region",
+                      "reads_total": N, "reads_per_call": shard, "samples_per_read": args.samples, "mid_occ": int(opts.mo.mid_occ)},
+           "metric_note": "a `step` here is one rh_map_batch call on one shard of the set; value = upload-inclusive (SURVEY.md 8(d)'s wording of the metric)",
+           "ms_per_call": per_call, "reader_s_total": round(t_reader, 1), "count_filtered_s_total": round(t_count, 2),
+           "value_with_counting": round(N / (t_calls + t_count), 1),
+           "mapped_fraction": round(n_mapped / N, 4), "chunks_per_read": round(acc["n_chunks"] / acc["n_reads"], 3),
+           "path": {"algorithmic_GB_total": round(path_bytes / 1e9, 2), "achieved_GBs": round(path_bytes / t_calls / 1e9, 3), "frac_of_hbm_peak": round(path_bytes / t_calls / 1e9 / HBM_PEAK_GBS, 5)}}
+    if args.cpu_sample != 0 and O.have_reference():
+        try:
+            t0 = time.time()
+            index.download(ctx, n_threads=min(cores, 64))
+            ind = os.path.join(workdir, "ref.ind")
+            index.write(ind)
+            parts = [wl.reads(model, st, blk, n_threads=min(cores, 64), with_names=True) for st in starts]
+            off = np.zeros(n_blocks * blk + 1, dtype=np.uint64)
+            off[1:] = np.cumsum(np.concatenate([np.diff(p.offsets.astype(np.int64)) for p in parts]))
+            sample = Reads(np.concatenate([p.samples for p in parts]), off, sum((p.names for p in parts), []), parts[0].cal_offset[0], parts[0].cal_scale[0])
+            got = [strip_mt(x) for x in paf_lines(index, np.concatenate([np.concatenate(got_recs[st]) for st in starts]), sample.names)]
+            rhr, paf = os.path.join(workdir, "cpu_sample.rhr"), os.path.join(workdir, "ref.paf")
+            sample.write(rhr, wl.cfg.digitisation, wl.cfg.range, wl.cfg.offset)
+            sweep = [int(x) for x in args.cpu_threads.split(",")] if args.cpu_threads else sorted({max(1, cores // 16), max(1, cores // 8)})
+            with open(paf, "w") as fo:
+                p = subprocess.run([O.REF_HARNESS, "map", preset, ind, rhr, ",".join(str(t) for t in sweep)], stdout=fo, stderr=subprocess.PIPE, text=True, timeout=3000)
+            runs = [(int(t), float(sec)) for sec, t in re.findall(r"map phase ([0-9.]+) s, threads (\d+)", p.stderr)]
+            with open(paf) as f:
+                want = [O.strip_mt(x) for x in f]
+            bt, bs = min(runs, key=lambda r: r[1])
+            out["cpu_baseline"] = {"value": round(len(sample) / bs, 1), "unit": "reads/s", "cores": cores, "threads": bt, "kind": "reference",
+                                   "sample": f"{n_blocks} blocks of {blk} reads spread over the {N} (first reads {starts[0]}, {starts[1]}, ... {starts[-1]}), map phase {bs:.2f} s, unmodified RawHash2 sources (oracle/Makefile)",
+                                   "thread_sweep_reads_per_s": {str(t): round(len(sample) / sec, 1) for t, sec in runs}, "paf_sha1": hashlib.sha1("\n".join(want).encode()).hexdigest()}
+            out["paf_sample_identical"] = got == want
+            if got != want:
+                out["cpu_baseline"]["paf_lines_differing"] = sum(1 for a, b in zip(got, want) if a != b) + abs(len(got) - len(want))
+        except Exception as e:
+            out["cpu_baseline_error"] = repr(e)[:300]
+    print(json.dumps(out), flush=True)
+    ctx.close()
+    import shutil
+    shutil.rmtree(workdir, ignore_errors=True)
 
 
 def bench_ava(args):
@@ -451,10 +567,25 @@ def host_copy(ctx, batch, args):
     b = _capi.ReadBatch(n, pin + offs[0], pin + offs[1], pin + offs[2], pin + offs[3], None, 0)
     # what a reader knows when it has decoded a read (ri_read_sig's l_sig, rsig.c:496-503; rh_reads_* count while they stage): with it the
     # device fetches only the stretches of signal the rounds consume.  Counted here, outside the timed region, like the file loading of the CPU baseline.
+    t0 = time.perf_counter()
     nf = _capi.count_filtered(b, lib=l)
+    t_count = time.perf_counter() - t0
     b_counted = _capi.ReadBatch(n, pin + offs[0], pin + offs[1], pin + offs[2], pin + offs[3], None, 0, 0, nf.ctypes.data)
     b_counted._keep = nf
-    return {"pin": pin, "batch": b_counted, "batch_full_upload": b}
+    return {"pin": pin, "batch": b_counted, "batch_full_upload": b, "count_s": t_count}
+
+
+def pmc_source(args):
+    """Where roofline.traffic comes from: NOT measured in this run - a file the builder committed (rocprofv3 --pmc passes of the same command)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    if d.get("workload") != args.workload or d.get("reads") != args.reads or d.get("samples") != args.samples or d.get("junk") != args.junk:
+        return None
+    return {"file": "profiles/pmc_traffic.json", "measured_in_this_run": False, "made_by": "profiles/collect_pmc.py (builder-run rocprofv3 --pmc passes of this command, one stream)",
+            "code_state": d.get("commit"), "round": d.get("round")}
 
 
 def pmc_traffic(stage, args, launches_per_step):
@@ -537,6 +668,28 @@ def cpu_baseline(ctx, index, opts, wl, model, workdir, preset, recs, args, cores
                     "paf_sha1": hashlib.sha1("\n".join(want).encode()).hexdigest()}
             if not identical:
                 base["paf_lines_differing"] = sum(1 for a, b in zip(got, want) if a != b) + abs(len(got) - len(want))
+            # the same sources with the stock vector flags (src/Makefile:7 has -march=native; oracle/Makefile ref_v4 builds -march=x86-64-v4 in its place - the binary is
+            # made in a container whose CPU is not this host's): the other denominator of the GPU / CPU ratio, at the best thread counts of the sweep above
+            try:
+                if os.path.exists(O.REF_HARNESS_V4) and "avx512f" in open("/proc/cpuinfo").read():
+                    ts = sorted({t for rr in runs.values() for t, _ in sorted(rr, key=lambda r: r[1])[:2]})
+                    with open(paf, "w") as fo:
+                        p = subprocess.run([O.REF_HARNESS_V4, "map", preset, ind, rhr, ",".join(str(t) for t in ts)], stdout=fo, stderr=subprocess.PIPE, text=True, timeout=3000,
+                                           env=dict(os.environ, **passes[[nm for nm, _, _ in passes].index(best_nm)][1], **getattr(args, "ref_env", {})))
+                    rr = [(int(t), float(sec)) for sec, t in re.findall(r"map phase ([0-9.]+) s, threads (\d+)", p.stderr)]
+                    if p.returncode == 0 and rr:
+                        bt, bs = min(rr, key=lambda r: r[1])
+                        with open(paf) as f:
+                            w4 = [O.strip_mt(x) for x in f]
+                        base["value_stock_flags"] = round(n / bs, 1)
+                        base["stock_flags"] = {"flags": "-O3 -march=x86-64-v4 -ffp-contract=off (for the stock -march=native)", "threads": bt, "memory_policy": best_nm,
+                                               "thread_sweep_reads_per_s": {str(t): round(n / sec, 1) for t, sec in rr}, "paf_identical_to_portable_build": w4 == want}
+                    else:
+                        base["stock_flags"] = {"error": f"harness rc {p.returncode}"}
+                else:
+                    base["stock_flags"] = {"error": "no AVX-512 host or no oracle/_ref/ref_harness_v4"}
+            except Exception as e:
+                base["stock_flags"] = {"error": repr(e)[:200]}
             return base, identical
     oix = O.OracleIndex(ind)
     _, mo = O.preset(preset)

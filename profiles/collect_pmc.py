@@ -82,7 +82,7 @@ def main():
         e["bytes"] += v["read_bytes"] + v["write_bytes"]
     for e in stages.values():
         e["bytes_per_step"] = e["bytes"]          # the profiled command runs exactly one step
-    out = {"workload": WORKLOAD, "reads": READS, "samples": SAMPLES, "junk": JUNK, "note": "read bytes = 2 x FETCH_SIZE KiB (gfx950), write bytes = WRITE_SIZE KiB; one stream (RH_SUB_BATCHES=1)",
+    out = {"workload": WORKLOAD, "reads": READS, "samples": SAMPLES, "junk": JUNK, "commit": os.environ.get("RH_COMMIT"), "round": 5, "note": "read bytes = 2 x FETCH_SIZE KiB (gfx950), write bytes = WRITE_SIZE KiB; one stream (RH_SUB_BATCHES=1)",
            "path_bytes_per_step": sum(e["bytes"] for e in stages.values()), "unattributed_kernels": unattributed, "setup_bytes": setup["bytes"],
            "kernels": kernels, "stages": stages}
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:

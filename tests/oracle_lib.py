@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "librh_oracle.so")
 REF_HARNESS = os.path.join(ORACLE_DIR, "_ref", "ref_harness")
+REF_HARNESS_V4 = os.path.join(ORACLE_DIR, "_ref", "ref_harness_v4")   # the same sources with -march=x86-64-v4 (the stock -march=native stand-in): timing only
 
 _lib = None
 

@@ -93,6 +93,10 @@ def test_oracle_vs_reference_paf_and_index(make_workload, tmp_path, preset):
     # (2) the reference also maps with the product-written .ind (format compatibility), same PAF
     out2 = subprocess.run([O.REF_HARNESS, "map", preset, w.ind, rhr, "4"], check=True, capture_output=True, text=True).stdout
     assert out2.splitlines() and [O.strip_mt(l) for l in out2.splitlines()] == [O.strip_mt(l) for l in out.splitlines()]
+    # (2b) the harness built with the stock vector flags (-march=x86-64-v4 for -march=native; bench.py times it) prints the same PAF
+    if os.path.exists(O.REF_HARNESS_V4) and "avx512f" in open("/proc/cpuinfo").read():
+        out3 = subprocess.run([O.REF_HARNESS_V4, "map", preset, ref_ind, rhr, "4"], check=True, capture_output=True, text=True).stdout
+        assert [O.strip_mt(l) for l in out3.splitlines()] == [O.strip_mt(l) for l in out.splitlines()]
     # (3) index contents: reference-built index dumped by the reference == product-built index
     dump = str(tmp_path / "idx.bin")
     subprocess.run([O.REF_HARNESS, "idxdump", ref_ind, dump], check=True, stderr=subprocess.DEVNULL)
