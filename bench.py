@@ -211,9 +211,12 @@ def main():
     elapsed_h2d = elapsed_full = count_s = None
     if args.h2d:
         host = host_copy(ctx, batch, args)
+        pending, depth = [], int(os.environ.get("RH_BENCH_IN_FLIGHT", "1"))
+        if depth > 1:                              # the batch slots' contexts allocate their arenas on their first call (seconds): untimed, like the warm-up steps above
+            for t_ in [ctx.map_submit(opts, host["batch"]) for _ in range(depth)]:
+                ctx.map_wait(t_)
         sync()
         t0 = time.perf_counter()
-        pending, depth = [], int(os.environ.get("RH_BENCH_IN_FLIGHT", "1"))
         for _ in range(args.steps):
             if depth <= 1:
                 recs_h = ctx.map_batch(opts, host["batch"])
