@@ -161,7 +161,7 @@ def main():
         return bench_big_set(args, ctx, wl, opts, index, model, workdir, preset, wl_name, n_chrom, chrom_len, rank, world, cores)
     # this rank's shard of the read set, generated straight into HBM: `pool` distinct batches, mapped in turn (batch b = reads
     # [(b * world + rank) * reads, +reads) of the synthetic set; each lives in the buffers of a context of its own that never maps)
-    n_pool = max(1, min(args.pool, args.steps + args.warmup))
+    n_pool = max(1, min(args.pool, args.steps + args.warmup, int(24e9 // (2 * args.reads * args.samples)) or 1))   # (at most ~24 GB of resident batches: the anchor arenas take what is free)
     gens = [ctx] + [Context(local_rank) for _ in range(n_pool - 1)]
     batches = [wl.reads_device(g, model, (b * world + rank) * args.reads, args.reads) for b, g in enumerate(gens)]
     batch = batches[0]

@@ -314,6 +314,7 @@ typedef struct rh_synth_cfg_s {
 } rh_synth_cfg_t;
 RH_API void rh_synth_cfg_init(rh_synth_cfg_t *c);
 RH_API int  rh_synth_write_model(const rh_synth_cfg_t *c, const char *path);
+RH_API int  rh_synth_write_model_k(const rh_synth_cfg_t *c, const char *path, int k);   /* a model of 4^k levels (4 .. 12; 6 = rh_synth_write_model; R10: 9); the read generators take k from the file */
 RH_API int  rh_synth_write_fasta(const rh_synth_cfg_t *c, const char *path);
 /* bases of chromosome `chrom` ("chr<chrom+1>") into out[0 .. chrom_len): the same sequence rh_synth_write_fasta writes */
 RH_API int  rh_synth_genome(const rh_synth_cfg_t *c, uint32_t chrom, char *out, int n_threads);

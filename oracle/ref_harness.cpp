@@ -122,6 +122,12 @@ static void apply_overrides(ri_idxopt_t *ipt, ri_mapopt_t *opt)
 	if ((s = getenv("RH_DTW_FILL"))) opt->dtw_fill_method = (uint32_t)atoi(s);      // --dtw-fill-method full = 0 | banded = 1 (:384)
 	if ((s = getenv("RH_DTW_BAND_FRAC"))) opt->dtw_band_radius_frac = (float)atof(s);
 	if ((s = getenv("RH_DTW_MIN_SCORE"))) opt->dtw_min_score = (float)atof(s);      // --dtw-min-score (:390)
+	if ((s = getenv("RH_R10")) && atoi(s)) {                                       // --r10 (main.cpp:396-406), field for field
+		ipt->k = 9;
+		ipt->window_length1 = 3; ipt->window_length2 = 6; ipt->threshold1 = 6.5f; ipt->threshold2 = 4.0f; ipt->peak_height = 0.2f;
+		opt->window_length1 = 3; opt->window_length2 = 6; opt->threshold1 = 6.5f; opt->threshold2 = 4.0f; opt->peak_height = 0.2f;
+		opt->chain_gap_scale = 1.2f;
+	}
 }
 
 static int set_presets(const char *preset, ri_idxopt_t *ipt, ri_mapopt_t *opt)

@@ -170,7 +170,7 @@ def _declare(lib):
         "rh_count_filtered": (i32, [P(ReadBatch), vp, i32]),
         "rh_reads_write": (i32, [cp, u32, P(cp), vp, vp, C.c_double, C.c_double, C.c_double]),
         "rh_reads_write_blow5": (i32, [cp, u32, P(cp), vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, i32]),
-        "rh_synth_cfg_init": (None, [P(SynthCfg)]), "rh_synth_write_model": (i32, [P(SynthCfg), cp]),
+        "rh_synth_cfg_init": (None, [P(SynthCfg)]), "rh_synth_write_model": (i32, [P(SynthCfg), cp]), "rh_synth_write_model_k": (i32, [P(SynthCfg), cp, i32]),
         "rh_synth_write_fasta": (i32, [P(SynthCfg), cp]),
         "rh_synth_reads": (i32, [P(SynthCfg), cp, u64, u32, vp, vp, i32]),
         "rh_synth_reads_device": (i32, [vp, P(SynthCfg), cp, u64, u32, P(ReadBatch)]),

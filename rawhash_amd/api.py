@@ -448,8 +448,9 @@ class SynthWorkload:
     """Deterministic synthetic genome / pore model / reads, generated by the C library."""
 
     def __init__(self, chrom_len=4_600_000, n_chrom=1, n_samples=40_000, junk_per_1024=0, noise_q24=0,
-                 model_seed=1, genome_seed=2, read_seed=3, lib=None):
+                 model_seed=1, genome_seed=2, read_seed=3, lib=None, k=6):
         self._l = lib or _capi.lib()
+        self.k = k                          # k-mers of the pore model write_reference writes (6: R9.4; 9: R10)
         c = SynthCfg()
         self._l.rh_synth_cfg_init(C.byref(c))
         c.chrom_len, c.n_chrom, c.n_samples = chrom_len, n_chrom, n_samples
@@ -460,7 +461,7 @@ class SynthWorkload:
     def write_reference(self, directory):
         os.makedirs(directory, exist_ok=True)
         model, fasta = os.path.join(directory, "model.txt"), os.path.join(directory, "ref.fa")
-        _check(self._l.rh_synth_write_model(C.byref(self.cfg), os.fsencode(model)), self._l)
+        _check(self._l.rh_synth_write_model_k(C.byref(self.cfg), os.fsencode(model), self.k), self._l)
         _check(self._l.rh_synth_write_fasta(C.byref(self.cfg), os.fsencode(fasta)), self._l)
         return fasta, model
 

@@ -1777,7 +1777,7 @@ extern "C" int rh_synth_reads_device(rh_ctx *c, const rh_synth_cfg_t *cfg, const
 	const size_t nn = n ? n : 1;
 	if (c->sy_samples.ensure(nn * cfg->n_samples * 2) || c->sy_off.ensure((nn + 1) * 8) || c->sy_cal_off.ensure(nn * 8) || c->sy_cal_scale.ensure(nn * 4) || c->sy_levels.ensure(level16.size() * 4)) return -1;
 	RH_HIP(hipMemcpy(c->sy_levels.p, level16.data(), level16.size() * 4, hipMemcpyHostToDevice));
-	rhk_synth_reads(c->stream, *cfg, c->sy_levels.as<int32_t>(), first, n, c->sy_samples.as<int16_t>(), c->sy_off.as<uint64_t>(), c->sy_cal_off.as<double>(), c->sy_cal_scale.as<float>());
+	rhk_synth_reads(c->stream, *cfg, c->sy_levels.as<int32_t>(), rh_synth_model_k(level16.size()), first, n, c->sy_samples.as<int16_t>(), c->sy_off.as<uint64_t>(), c->sy_cal_off.as<double>(), c->sy_cal_scale.as<float>());
 	RH_HIP(hipStreamSynchronize(c->stream));
 	RH_HIP(hipGetLastError());
 	memset(out, 0, sizeof(*out));

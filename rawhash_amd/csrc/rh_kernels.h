@@ -290,4 +290,4 @@ void rhk_seed_scan(hipStream_t s, const rh_dev_round &r, uint64_t *off);
 void rhk_seed_pack(hipStream_t s, const rh_dev_round &r, const uint64_t *off, uint32_t id0, uint32_t *hash_out, uint64_t *pos_out);   // target ids = id0 + read index
 void rhk_ava_rec_scan(hipStream_t s, const rh_dev_reads &rd, uint64_t *rec_off);
 void rhk_finalize_ava(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_mm128_t *maps, const uint64_t *rec_off, rh_map_record_t *rec);
-void rhk_synth_reads(hipStream_t s, const rh_synth_cfg_t &c, const int32_t *level16, uint64_t first, uint32_t n, int16_t *samples, uint64_t *off, double *cal_off, float *cal_scale);
+void rhk_synth_reads(hipStream_t s, const rh_synth_cfg_t &c, const int32_t *level16, uint32_t k, uint64_t first, uint32_t n, int16_t *samples, uint64_t *off, double *cal_off, float *cal_scale);

@@ -1262,7 +1262,7 @@ __global__ void k_finalize_ava(rh_dev_opt o, rh_dev_index ix, rh_dev_reads rd, c
 
 // ------------------------------------------------------------------------------------------------ k_synth_reads
 // Bench/test support: the synthetic read generator of rh_synth_core.h, one read per lane, writing straight into HBM.
-__global__ void k_synth_reads(rh_synth_cfg_t c, const int32_t *level16, uint64_t first, uint32_t n, int16_t *samples, uint64_t *off, double *cal_off, float *cal_scale)
+__global__ void k_synth_reads(rh_synth_cfg_t c, const int32_t *level16, uint32_t k, uint64_t first, uint32_t n, int16_t *samples, uint64_t *off, double *cal_off, float *cal_scale)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i == 0) off[n] = (uint64_t)n * c.n_samples;
@@ -1270,7 +1270,7 @@ __global__ void k_synth_reads(rh_synth_cfg_t c, const int32_t *level16, uint64_t
 	off[i] = (uint64_t)i * c.n_samples;
 	cal_off[i] = c.offset;
 	cal_scale[i] = (float)(c.range / c.digitisation);
-	rh_sy_generate(c, level16, first + i, samples + (size_t)i * c.n_samples);
+	rh_sy_generate(c, level16, k, first + i, samples + (size_t)i * c.n_samples);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -1331,5 +1331,5 @@ void rhk_seed_pack(hipStream_t s, const rh_dev_round &r, const uint64_t *off, ui
 void rhk_ava_rec_scan(hipStream_t s, const rh_dev_reads &rd, uint64_t *rec_off) { RH_LAUNCH(k_ava_rec_scan, 1, 1024, 0, s, rd, rec_off); }
 void rhk_finalize_ava(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_mm128_t *maps, const uint64_t *rec_off, rh_map_record_t *rec)
 { if (rd.n_reads) RH_LAUNCH(k_finalize_ava, cdiv(rd.n_reads, 256), 256, 0, s, o, ix, rd, maps, rec_off, rec); }
-void rhk_synth_reads(hipStream_t s, const rh_synth_cfg_t &c, const int32_t *level16, uint64_t first, uint32_t n, int16_t *samples, uint64_t *off, double *cal_off, float *cal_scale)
-{ if (n) RH_LAUNCH(k_synth_reads, cdiv(n, 64), 64, 0, s, c, level16, first, n, samples, off, cal_off, cal_scale); }
+void rhk_synth_reads(hipStream_t s, const rh_synth_cfg_t &c, const int32_t *level16, uint32_t k, uint64_t first, uint32_t n, int16_t *samples, uint64_t *off, double *cal_off, float *cal_scale)
+{ if (n) RH_LAUNCH(k_synth_reads, cdiv(n, 64), 64, 0, s, c, level16, k, first, n, samples, off, cal_off, cal_scale); }

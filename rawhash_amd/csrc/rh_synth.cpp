@@ -35,20 +35,22 @@ static double model_level(const rh_synth_cfg_t *c, uint32_t kmer)
 	return 90.0 + 12.0 * (double)s / 37837.2;
 }
 
-extern "C" int rh_synth_write_model(const rh_synth_cfg_t *c, const char *path)
+extern "C" int rh_synth_write_model_k(const rh_synth_cfg_t *c, const char *path, int k)
 {
+	if (k < 4 || k > 12) { rh_set_error("synthetic pore model: k = %d (4 .. 12)", k); return -1; }
 	FILE *fp = fopen(path, "w");
 	if (!fp) { rh_set_error("cannot write %s", path); return -1; }
 	fprintf(fp, "kmer\tlevel_mean\tlevel_stdv\n");
-	for (uint32_t i = 0; i < (1u << (2 * SY_K)); ++i) {
-		char km[SY_K + 1];
-		for (int j = 0; j < SY_K; ++j) km[j] = "ACGT"[(i >> (2 * (SY_K - 1 - j))) & 3];
-		km[SY_K] = 0;
+	for (uint32_t i = 0; i < (1u << (2 * k)); ++i) {
+		char km[16];
+		for (int j = 0; j < k; ++j) km[j] = "ACGT"[(i >> (2 * (k - 1 - j))) & 3];
+		km[k] = 0;
 		fprintf(fp, "%s\t%.4f\t1.5000\n", km, model_level(c, i));
 	}
 	fclose(fp);
 	return 0;
 }
+extern "C" int rh_synth_write_model(const rh_synth_cfg_t *c, const char *path) { return rh_synth_write_model_k(c, path, SY_K); }
 
 extern "C" int rh_synth_write_fasta(const rh_synth_cfg_t *c, const char *path)
 {
@@ -110,19 +112,23 @@ static int load_model_levels(const char *path, std::vector<float> &lev)
 		lev.push_back(strtof(t + 1, 0));
 	}
 	fclose(fp);
-	if (lev.size() != (1u << (2 * SY_K))) { rh_set_error("model %s: expected %u k-mers, got %zu", path, 1u << (2 * SY_K), lev.size()); return -1; }
+	int k = 0;
+	while (k <= 12 && ((size_t)1 << (2 * k)) < lev.size()) ++k;
+	if (k < 4 || k > 12 || ((size_t)1 << (2 * k)) != lev.size()) { rh_set_error("model %s: %zu k-mers is not 4^k for a k of 4 .. 12", path, lev.size()); return -1; }
 	return 0;
 }
 
-static void synth_one(const rh_synth_cfg_t *c, const int32_t *level16, uint64_t idx, int16_t *out, char *name64)
+static void synth_one(const rh_synth_cfg_t *c, const int32_t *level16, uint32_t k, uint64_t idx, int16_t *out, char *name64)
 {
 	if (name64) {
 		const rh_sy_origin o = rh_sy_read_origin(*c, idx);
 		if (o.junk) snprintf(name64, 64, "r%llu_junk", (unsigned long long)idx);
 		else snprintf(name64, 64, "r%llu_chr%u_%u_%c", (unsigned long long)idx, o.chrom + 1, o.pos, o.strand ? '-' : '+');
 	}
-	rh_sy_generate(*c, level16, idx, out);
+	rh_sy_generate(*c, level16, k, idx, out);
 }
+
+uint32_t rh_synth_model_k(size_t n_levels) { uint32_t k = 0; while (((size_t)1 << (2 * k)) < n_levels) ++k; return k; }   // (a table of 4^k levels)
 
 int rh_synth_level_table(const rh_synth_cfg_t *c, const char *model_path, std::vector<int32_t> &level16)
 {
@@ -142,11 +148,12 @@ extern "C" int rh_synth_reads(const rh_synth_cfg_t *c, const char *model_path, u
 	if (rh_synth_level_table(c, model_path, level16) < 0) return -1;
 	if (n_threads < 1) n_threads = 1;
 	if ((uint32_t)n_threads > n) n_threads = n ? n : 1;
+	const uint32_t k = rh_synth_model_k(level16.size());
 	std::vector<std::thread> th;
 	for (int t = 0; t < n_threads; ++t)
 		th.emplace_back([=, &level16]() {
 			for (uint32_t i = t; i < n; i += n_threads)
-				synth_one(c, level16.data(), first + i, samples + (size_t)i * c->n_samples, names64 ? names64 + (size_t)i * 64 : 0);
+				synth_one(c, level16.data(), k, first + i, samples + (size_t)i * c->n_samples, names64 ? names64 + (size_t)i * 64 : 0);
 		});
 	for (auto &t : th) t.join();
 	return 0;

@@ -5,7 +5,7 @@
 #include "rawhash_amd.h"
 #include <cstdint>
 
-#define RH_SY_K 6
+#define RH_SY_K 6                    // k-mers of the default pore model (R9.4); a model file of 4^k lines sets its own k (R10: 9)
 
 RH_HD inline uint64_t rh_sy_mix64(uint64_t x)
 {
@@ -45,12 +45,12 @@ RH_HD inline uint32_t rh_sy_neg_log2_q8(uint32_t u)
 }
 
 // level16[kmer] = model level in raw ADC units x 16
-RH_HD inline void rh_sy_generate(const rh_synth_cfg_t &c, const int32_t *level16, uint64_t idx, int16_t *out)
+RH_HD inline void rh_sy_generate(const rh_synth_cfg_t &c, const int32_t *level16, uint32_t k, uint64_t idx, int16_t *out)
 {
 	const rh_sy_origin o = rh_sy_read_origin(c, idx);
 	const uint32_t span = rh_sy_span(c.n_samples);
 	const uint32_t noise_q24 = c.noise_q24 ? c.noise_q24 : 62152u;
-	const uint32_t kmask = (1u << (2 * RH_SY_K)) - 1;
+	const uint32_t kmask = (1u << (2 * k)) - 1;
 	uint32_t kmer = 0, s = 0;
 	for (uint32_t j = 0; j < span && s < c.n_samples; ++j) {
 		uint32_t b;
@@ -58,7 +58,7 @@ RH_HD inline void rh_sy_generate(const rh_synth_cfg_t &c, const int32_t *level16
 		else if (!o.strand) b = rh_sy_genome_base(c.genome_seed, o.chrom, o.pos + j);
 		else b = 3 - rh_sy_genome_base(c.genome_seed, o.chrom, o.pos + span - 1 - j);
 		kmer = ((kmer << 2) | b) & kmask;
-		if (j + 1 < (uint32_t)RH_SY_K) continue;
+		if (j + 1 < k) continue;
 		const uint64_t hd = rh_sy_rand3(c.read_seed + 2, idx, j);
 		const uint32_t e = rh_sy_neg_log2_q8((uint32_t)(hd & 0xFFFF) + 1) + rh_sy_neg_log2_q8((uint32_t)((hd >> 16) & 0xFFFF) + 1);
 		uint32_t dwell = (e * 790u + (1u << 15)) >> 16;

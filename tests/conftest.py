@@ -46,15 +46,19 @@ class Workload:
     """Synthetic reference + index + reads, generated from seeds by the product library's host code."""
 
     def __init__(self, directory, lib, preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=12_000, n_reads=48,
-                 junk=150, noise=150_000, read_seed=3, index_lib=None, build_index=True, no_adaptive=False, fast5=False, mapopt=None, idxflag=0):
+                 junk=150, noise=150_000, read_seed=3, index_lib=None, build_index=True, no_adaptive=False, fast5=False, mapopt=None, idxflag=0, r10=False):
         from rawhash_amd.api import SynthWorkload, MapOptions, Index
         self.dir, self.preset = str(directory), preset
+        # r10: `--r10` (main.cpp:396-406) - 9-mers (a pore model of 4^9 levels), segmentation windows 3 / 6, thresholds 6.5 / 4.0, peak height 0.2, gap scale 1.2
         self.wl = SynthWorkload(chrom_len=chrom_len, n_chrom=n_chrom, n_samples=n_samples, junk_per_1024=junk, noise_q24=noise,
-                                read_seed=read_seed, lib=lib)
+                                read_seed=read_seed, lib=lib, k=9 if r10 else 6)
         self.fasta, self.model = self.wl.write_reference(self.dir)
         self.opts = MapOptions(preset, lib=lib)
         self.no_adaptive = no_adaptive
         self.mapopt = dict(mapopt or {})        # rh_mapopt_t fields set on top of the preset ("flag" is OR-ed in): --rmq, --bw-long ...
+        if r10:
+            self.mapopt.update(window_length1=3, window_length2=6, threshold1=6.5, threshold2=4.0, peak_height=0.2, chain_gap_scale=1.2)
+            self.opts.io.k = 9
         if no_adaptive:
             self.opts.mo.flag |= 0x20           # RH_M_NO_ADAPTIVE: one round over the whole read
         self._apply_mapopt(self.opts.mo)

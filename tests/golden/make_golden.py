@@ -52,6 +52,9 @@ CASES = [
     {"name": "small_sensitive_chunk8000", "env": {"RH_CHUNK_SIZE": "8000"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=40_000, n_reads=96, junk=150, noise=150_000, read_seed=61, mapopt={"chunk_size": 8000})},
     {"name": "small_sensitive_40chunks", "env": {"RH_CHUNK_SIZE": "1000", "RH_MAX_CHUNKS": "40"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=40_000, n_reads=96, junk=150, noise=150_000, read_seed=62, mapopt={"chunk_size": 1000, "max_num_chunk": 40})},
     {"name": "small_sensitive_min_anchors1", "env": {"RH_MIN_ANCHORS": "1"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=96, junk=150, noise=150_000, read_seed=63, mapopt={"min_num_anchors": 1})},
+    # `--r10` (main.cpp:396-406): k = 9 (a pore model of 4^9 levels, span e + 8), segmentation windows 3 / 6, thresholds 6.5 / 4.0, peak height 0.2, gap scale 1.2
+    {"name": "small_r10", "env": {"RH_R10": "1"}, "workload": dict(preset="sensitive", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=160, junk=150, noise=150_000, read_seed=71, r10=True)},
+    {"name": "small_r10_fast", "env": {"RH_R10": "1"}, "workload": dict(preset="fast", chrom_len=300_000, n_chrom=2, n_samples=20_000, n_reads=120, junk=150, noise=150_000, read_seed=72, r10=True)},
     {"name": "config1_ecoli_4p6M_dtw", "env": {"RH_STORE_SIG": "1", "RH_DTW": "1"}, "workload": dict(preset="sensitive", chrom_len=4_600_000, n_chrom=1, n_samples=40_000, n_reads=300, junk=102, noise=0, read_seed=7, idxflag=0x10, mapopt={"flag": 0x40})},
 ]
 

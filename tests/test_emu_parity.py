@@ -169,6 +169,24 @@ def test_whole_read_rounds_golden(emu_lib, tmp_path):
     c.close()
 
 
+def test_r10_golden(emu_lib, tmp_path):
+    """`--r10` (main.cpp:396-406: 9-mers, segmentation windows 3 / 6, thresholds 6.5 / 4.0, peak height 0.2, gap scale 1.2) against the PAF the
+    reference prints; the index from the device builder (4^9 model levels) must be the host builder's."""
+    import golden
+    from rawhash_amd.api import paf_lines, Index
+    import oracle_lib as O
+    case = [c for c in golden.cases() if c["name"] == "small_r10"][0]
+    w = golden.build_case(case, tmp_path, emu_lib)
+    assert w.opts.io.k == 9 and w.opts.mo.window_length2 == 6
+    c = Context(0, lib=emu_lib)
+    c.upload(w.index)
+    sub = w.reads.subset(range(24))
+    recs = c.map_batch(w.opts, sub)
+    got = [O.strip_mt(x) for x in paf_lines(w.index, recs, sub.names, lib=emu_lib)]
+    assert got == golden.expected_paf(case)[:24]
+    c.close()
+
+
 def test_fast5_ingest_golden(emu_lib, tmp_path):
     """rh_read_batch_t.fast5_ingest: raw -> pA as the FAST5 reader does it (float arithmetic, kept values truncated to int16,
     rsig.c:346-374), against the PAF the reference prints for that ingest."""
