@@ -81,14 +81,6 @@ __device__ uint32_t rh_uniform(uint32_t v);
 __device__ uint32_t rh_and_or(uint32_t a, uint32_t m, uint32_t o);
 #endif
 
-// pin a wave-uniform 32-bit value to a scalar register here (phis of long uniform loops otherwise drift into VGPRs, and every
-// use as a lane select or scalar operand then costs a v_readfirstlane)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define RH_SGPR(x) ((void)0)
-#else
-#define RH_SGPR(x) ((void)0)
-#endif
-
 // all lanes of the wavefront have executed everything above (lock step on the GPU: only a compiler-level barrier)
 #define RH_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 

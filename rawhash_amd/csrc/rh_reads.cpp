@@ -2,6 +2,8 @@
 // scale = (float)(range/digitisation)} exactly as ri_read_sig_slow5 derives them (rsig.c:494).
 //   BLOW5 (binary SLOW5): what the reference reads through slow5lib (rsig.c:170-206, 478-533) - uncompressed, zlib and zstd records,
 //                         raw or svb-zd (StreamVByte zig-zag delta) signals
+//   SLOW5 (text)        : the same records as tab-separated lines (slow5_open takes either, rsig.c:170-207): header lines (#..., @...), the column
+//                         names on the last of them, raw_signal a comma-separated list
 //   RHR1                : the repo's own trivial container (tests, the reference harness)
 // Samples are decoded straight into ONE page-locked staging buffer (hipHostMalloc; plain memory when no HIP runtime answers, e.g. in
 // the CPU test suite), so rh_map_batch / rh_map_submit upload them at PCIe speed without an intermediate copy.
@@ -60,16 +62,17 @@ static uint64_t file_size_of(FILE *fp)
 
 static rh_reads *reads_load_rhr(const char *path);
 static rh_reads *reads_load_blow5(const char *path);
+static rh_reads *reads_load_slow5_text(const char *path);
 
 extern "C" rh_reads *rh_reads_load(const char *path)
 {
 	try {
-		char magic[6] = {0};
+		char magic[15] = {0};
 		FILE *fp = fopen(path, "rb");
 		if (!fp) { rh_set_error("cannot open %s", path); return 0; }
-		const size_t got = fread(magic, 1, 6, fp);
+		const size_t got = fread(magic, 1, 14, fp);
 		fclose(fp);
-		rh_reads *r = (got == 6 && !memcmp(magic, "BLOW5\1", 6)) ? reads_load_blow5(path) : reads_load_rhr(path);
+		rh_reads *r = (got >= 6 && !memcmp(magic, "BLOW5\1", 6)) ? reads_load_blow5(path) : (got == 14 && !memcmp(magic, "#slow5_version", 14)) ? reads_load_slow5_text(path) : reads_load_rhr(path);
 		if (r) {	// what ri_read_sig knows when it returns (l_sig): lets rh_map_batch fetch only the signal its rounds consume
 			rh_read_batch_t b;
 			rh_reads_batch(r, &b);
@@ -113,6 +116,81 @@ static rh_reads *reads_load_rhr(const char *path)
 		r->cal_offset.push_back(off);
 		r->cal_scale.push_back((float)(range / dig));
 	}
+	fclose(fp);
+	return r;
+}
+
+// ---------------------------------------------------------------------------------------------------- SLOW5 (text)
+// The ASCII form of the format slow5lib reads (what `slow5tools view` prints; ri_read_sig_slow5 takes the same fields from either form, rsig.c:478-533):
+//   #slow5_version<TAB>x.y.z, #num_read_groups<TAB>n, @attribute lines, a line of column types (#char*<TAB>uint32_t ...), a line of column names
+//   (#read_id<TAB>read_group<TAB>digitisation<TAB>offset<TAB>range<TAB>sampling_rate<TAB>len_raw_signal<TAB>raw_signal[<TAB>auxiliary fields]), then one
+//   line per read with raw_signal as comma-separated integers.  Columns are found by name; auxiliary fields are skipped.
+static rh_reads *reads_load_slow5_text(const char *path)
+{
+	FILE *fp = fopen(path, "rb");
+	if (!fp) { rh_set_error("cannot open %s", path); return 0; }
+	rh_reads *r = new rh_reads_s();
+	r->offsets.push_back(0);
+	auto fail = [&](const char *what, uint64_t line_no) -> rh_reads* { rh_set_error("%s: line %llu: %s", path, (unsigned long long)line_no, what); fclose(fp); delete r; return (rh_reads*)0; };
+	char *line = nullptr; size_t cap = 0; ssize_t len;
+	int c_id = -1, c_dig = -1, c_off = -1, c_rng = -1, c_len = -1, c_sig = -1, n_cols = 0;
+	uint64_t line_no = 0;
+	bool have_cols = false;
+	struct Free { char *&p; ~Free() { free(p); } } free_line{line};
+	while ((len = getline(&line, &cap, fp)) >= 0) {
+		++line_no;
+		while (len > 0 && (line[len - 1] == '\n' || line[len - 1] == '\r')) line[--len] = 0;
+		if (len == 0) continue;
+		if (line[0] == '@') continue;                                  // read-group attributes
+		if (line[0] == '#') {
+			if (!strncmp(line, "#read_id", 8) && (line[8] == '\t' || line[8] == 0)) {	// the column names
+				int col = 0;
+				for (char *tok = line + 1, *nx; tok; tok = nx, ++col) {
+					nx = strchr(tok, '\t');
+					if (nx) *nx++ = 0;
+					if (!strcmp(tok, "read_id")) c_id = col; else if (!strcmp(tok, "digitisation")) c_dig = col; else if (!strcmp(tok, "offset")) c_off = col;
+					else if (!strcmp(tok, "range")) c_rng = col; else if (!strcmp(tok, "len_raw_signal")) c_len = col; else if (!strcmp(tok, "raw_signal")) c_sig = col;
+				}
+				n_cols = col;
+				if (c_id < 0 || c_dig < 0 || c_off < 0 || c_rng < 0 || c_len < 0 || c_sig < 0) return fail("a primary column (read_id, digitisation, offset, range, len_raw_signal, raw_signal) is missing", line_no);
+				have_cols = true;
+			}
+			continue;                                                   // version, read groups, column types
+		}
+		if (!have_cols) return fail("a record before the column names", line_no);
+		const char *f_id = nullptr, *f_sig = nullptr; double dig = 0, off = 0, rng = 0; uint64_t ns = 0;
+		int col = 0;
+		for (char *tok = line, *nx; tok; tok = nx, ++col) {
+			nx = strchr(tok, '\t');
+			if (nx) *nx++ = 0;
+			if (col == c_id) f_id = tok; else if (col == c_sig) f_sig = tok;
+			else if (col == c_dig) dig = strtod(tok, nullptr); else if (col == c_off) off = strtod(tok, nullptr); else if (col == c_rng) rng = strtod(tok, nullptr);
+			else if (col == c_len) ns = strtoull(tok, nullptr, 10);
+		}
+		if (col < n_cols && col <= c_sig) return fail("fewer fields than columns", line_no);
+		if (!f_id || !f_sig) return fail("no read_id / raw_signal field", line_no);
+		if (strlen(f_id) > kMaxNameLen || ns >= kMaxReadSamples || !(dig > 0)) return fail("implausible read (name length, signal length, digitisation)", line_no);
+		int16_t *dst = r->samples.grow(ns);
+		if (ns && !dst) return fail("out of memory", line_no);
+		uint64_t k = 0;
+		if (!(f_sig[0] == '.' && f_sig[1] == 0))
+			for (const char *p = f_sig; *p;) {
+				char *e;
+				const long v = strtol(p, &e, 10);
+				if (e == p) return fail("raw_signal is not a comma-separated list of integers", line_no);
+				if (v < -32768 || v > 32767) return fail("a raw_signal value beyond int16", line_no);
+				if (k < ns) dst[k] = (int16_t)v;
+				++k;
+				p = *e == ',' ? e + 1 : e;
+				if (*e && *e != ',') return fail("raw_signal is not a comma-separated list of integers", line_no);
+			}
+		if (k != ns) return fail("raw_signal does not hold len_raw_signal values", line_no);
+		r->names.push_back(f_id);
+		r->offsets.push_back(r->samples.n);
+		r->cal_offset.push_back(off);
+		r->cal_scale.push_back((float)(rng / dig));
+	}
+	if (!have_cols) return fail("no column names (#read_id ...)", line_no);
 	fclose(fp);
 	return r;
 }

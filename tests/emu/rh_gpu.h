@@ -77,7 +77,6 @@ static inline unsigned rh_wave_shr1(unsigned v, unsigned first) { const unsigned
 static inline int rh_quad_perm_0022(int v) { return (int)emu_shfl_bits((unsigned)v, 5, (threadIdx.x & 63u) & ~1u); }
 static inline int rh_quad_perm_1133(int v) { return (int)emu_shfl_bits((unsigned)v, 5, (threadIdx.x & 63u) | 1u); }
 #define RH_WAVE_SYNC() ((void)emu_ballot(1))
-#define RH_SGPR(x) ((void)0)
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))

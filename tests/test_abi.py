@@ -130,6 +130,49 @@ def test_blow5_hand_assembled_fixtures(tmp_path, product_lib):
     assert n_files >= 4
 
 
+def test_slow5_text_hand_assembled_fixture(tmp_path, product_lib):
+    """A text .slow5 file written line by line from the published format (what `slow5tools view` prints: version / read-group header lines, the
+    column types, the column names, one tab-separated line per read with raw_signal as a comma-separated list, auxiliary columns behind it) -
+    slow5_open takes the text form like the binary one (rsig.c:170-207).  The same reads as the BLOW5 fixtures; columns are found by NAME (a
+    second file has them in another order); malformed records are refused with the line number."""
+    import numpy as np
+    import blow5_fixtures as B
+    from rawhash_amd.api import Reads, RhError
+    reads = B.sample_reads()
+    hdr = ["#slow5_version\t0.2.0", "#num_read_groups\t1", "@asic_id\t420", "@exp_start_time\t2024-01-01T00:00:00Z", "@sample_frequency\t4000"]
+
+    def text(order, aux=True, crlf=False):
+        cols = {"read_id": "char*", "read_group": "uint32_t", "digitisation": "double", "offset": "double", "range": "double", "sampling_rate": "double",
+                "len_raw_signal": "uint64_t", "raw_signal": "int16_t*"}
+        names = list(order) + (["channel_number", "read_number"] if aux else [])
+        types = [cols[c] for c in order] + (["char*", "int32_t"] if aux else [])
+        lines = hdr + ["#" + "\t".join(types), "#" + "\t".join(names)]
+        for i, (name, x, dig, off, ran) in enumerate(reads):
+            val = {"read_id": name, "read_group": "0", "digitisation": repr(float(dig)), "offset": repr(float(off)), "range": repr(float(ran)), "sampling_rate": "4000",
+                   "len_raw_signal": str(len(x)), "raw_signal": ",".join(str(int(v)) for v in x) if len(x) else "."}
+            lines.append("\t".join([val[c] for c in order] + ([str(100 + i), str(i)] if aux else [])))
+        return ("\r\n" if crlf else "\n").join(lines) + "\n"
+
+    std = ["read_id", "read_group", "digitisation", "offset", "range", "sampling_rate", "len_raw_signal", "raw_signal"]
+    other = ["read_id", "len_raw_signal", "raw_signal", "range", "read_group", "offset", "sampling_rate", "digitisation"]
+    for k, (order, aux, crlf) in enumerate(((std, True, False), (std, False, True), (other, True, False))):
+        p = str(tmp_path / f"fx{k}.slow5")
+        open(p, "w", newline="").write(text(order, aux, crlf))
+        r = Reads.load(p, lib=product_lib)
+        assert r.names == [q[0] for q in reads]
+        for i, (name, x, dig, off, ran) in enumerate(reads):
+            assert np.array_equal(r.samples[int(r.offsets[i]):int(r.offsets[i + 1])], x), (p, name)
+            assert r.cal_offset[i] == off and r.cal_scale[i] == np.float32(ran / dig)
+    good = text(std).splitlines()
+    for bad, msg in ((good[:7] + [good[7].replace("\t" + str(len(reads[0][1])) + "\t", "\t" + str(len(reads[0][1]) + 1) + "\t", 1)] + good[8:], "len_raw_signal"),
+                     (good[:6] + good[7:], "column names"),
+                     (good[:7] + [good[7].rsplit("\t", 3)[0] + "\t1,2,x,4\t1\t1"] + good[8:], "comma-separated")):
+        p = str(tmp_path / "bad.slow5")
+        open(p, "w").write("\n".join(bad) + "\n")
+        with pytest.raises(RhError, match=msg):
+            Reads.load(p, lib=product_lib)
+
+
 def test_blow5_hostile_lengths_fail_before_allocating(tmp_path, product_lib):
     """Length fields are checked against what the record / file holds BEFORE a buffer grows for them: a record that declares 2^32 - 1
     samples, an svb-zd block that declares more values than it has bytes, a zstd frame that declares gigabytes - errors within
