@@ -327,7 +327,7 @@ def bench_big_set(args, ctx, wl, opts, index, model, workdir, preset, wl_name, n
     got_recs = {}
     t_calls, t_count, t_reader, per_call = 0.0, 0.0, 0.0, []
     acc, n_mapped = {}, 0
-    ctx.map_batch(opts, wl.reads_device(ctx, model, 0, min(shard, 8192)))      # warm-up: arenas, kernels
+    ctx.map_batch(opts, wl.reads_device(ctx, model, N, min(shard, N)))      # warm-up (reads beyond the set): arenas as the calls need them, kernels
     for s0 in range(0, N, shard):
         n = min(shard, N - s0)
         t0 = time.perf_counter()
@@ -374,7 +374,9 @@ def bench_big_set(args, ctx, wl, opts, index, model, workdir, preset, wl_name, n
             off = np.zeros(n_blocks * blk + 1, dtype=np.uint64)
             off[1:] = np.cumsum(np.concatenate([np.diff(p.offsets.astype(np.int64)) for p in parts]))
             sample = Reads(np.concatenate([p.samples for p in parts]), off, sum((p.names for p in parts), []), parts[0].cal_offset[0], parts[0].cal_scale[0])
-            got = [strip_mt(x) for x in paf_lines(index, np.concatenate([np.concatenate(got_recs[st]) for st in starts]), sample.names)]
+            srecs = np.concatenate([np.concatenate(got_recs[st]) for st in starts])
+            srecs["read_idx"] = np.arange(len(srecs), dtype=srecs["read_idx"].dtype)       # (they were numbered within their calls)
+            got = [strip_mt(x) for x in paf_lines(index, srecs, sample.names)]
             rhr, paf = os.path.join(workdir, "cpu_sample.rhr"), os.path.join(workdir, "ref.paf")
             sample.write(rhr, wl.cfg.digitisation, wl.cfg.range, wl.cfg.offset)
             sweep = [int(x) for x in args.cpu_threads.split(",")] if args.cpu_threads else sorted({max(1, cores // 16), max(1, cores // 8)})

@@ -98,9 +98,15 @@ __global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 //   3. the others walk again next round, now seeing the new marks.  The best pending lane always commits.
 // When the batch is settled the accepted chains get their slots in u[] / v[] by a prefix sum in candidate order.  The
 // dependent loads of 64 walks are in flight together, where the serial walk paid one memory round trip per step.
-__global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
+// BT = 64: one wavefront per read.  BT = 256 (round 5): a WORKGROUP per read, 256 candidates per round - the reads of the late rounds are fewer than the chip has
+// wave slots (6 500 unmappable reads of 10^5 candidates each) and a read's batches are a serial chain of ~10 us rounds, so the kernel took as long as
+// its slowest read; four wavefronts walk four times the candidates per round (same CU, same L1: the marks stay plain loads and stores).
+template <int BT>
+__global__ __launch_bounds__(BT) void k_backtrack_spec(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
 {
-	const uint32_t a = blockIdx.x, lane = threadIdx.x;
+	constexpr int SH = BT > 64 ? 8 : 6;                              // stamp = round << SH | priority
+	__shared__ uint32_t s_w[BT / 64 + 1];
+	const uint32_t a = blockIdx.x, lane = threadIdx.x;               // ("lane" = the candidate's place in the batch, 0 = best score)
 	if (a >= rr.n_act) return;
 	if (rr.skip[a]) { if (lane == 0) { rr.n_u[a] = 0; rr.n_v[a] = 0; } return; }
 	const uint32_t r = rr.act[a];
@@ -122,7 +128,8 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 	int32_t n_u = 0, n_v = 0;
 	uint32_t epoch = 0;
 	const int32_t n_lone = bt_lone_on(o, rr) ? (int32_t)rr.n_v[a] : 0;   // candidates without a predecessor: the lowest scores, passed over (k_zbuild)
-	for (int32_t kt = n_z; kt > n_lone; kt -= 64) {                // candidates from the best score down (lchain.c:148)
+	__syncthreads();                                                // (n_v[a] is this kernel's to write at the end: every wavefront has read it first)
+	for (int32_t kt = n_z; kt > n_lone; kt -= BT) {                // candidates from the best score down (lchain.c:148)
 		const int32_t k = kt - 1 - (int32_t)lane;
 		const uint32_t w0 = k >= n_lone ? (rr.z8 ? (uint32_t)zs8[k] : (uint32_t)zs[k].y) : 0x80000000u;   // (the first n_lone sorted candidates are not there to be read: the sorter leaves their stretch unwritten, rh_sort_job::dead_cnt)
 		const int32_t i0 = (int32_t)(w0 & 0x7FFFFFFFu);
@@ -130,11 +137,13 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 		int32_t r_cnt = 0, r_sc = 0;
 		int32_t pn1 = 0, pn2 = 0, pn3 = 0;                             // the first anchors of the path after i0 (most chains are this short)
 		for (;;) {
-			const uint64_t pend = __ballot(pending);
-			if (!pend) break;
-			const bool solo = (pend & (pend - 1)) == 0;               // a single pending lane has nobody to collide with
+			uint32_t n_pend;
+			if (BT == 64) n_pend = (uint32_t)__popcll(__ballot(pending));
+			else (void)block_rank(pending, s_w, n_pend);
+			if (!n_pend) break;
+			const bool solo = n_pend == 1;                            // a single pending lane has nobody to collide with
 			++epoch;
-			const uint32_t stamp = epoch << 6 | (63u - lane);
+			const uint32_t stamp = epoch << SH | ((uint32_t)BT - 1u - lane);
 			bool walked = false;
 			int32_t zx = 0, path = 0, max_s = 0, emit = 0;             // path = unused anchors reached after i0; emit = anchors i0 .. before max_i
 			if (pending && t[i0] == 0) {
@@ -190,13 +199,12 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 			__syncthreads();                                          // the new marks are in before anybody walks again (one CU, one L1)
 		}
 		// slots in candidate order
-		const uint64_t am = __ballot(accepted);
-		uint32_t inc = accepted ? (uint32_t)r_cnt : 0u;
-		for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(inc, d); if (lane >= (uint32_t)d) inc += up; }
-		const uint32_t total = __shfl(inc, 63);
+		uint32_t n_acc, total;
+		const uint32_t my_rank = block_rank(accepted, s_w, n_acc);
+		const uint32_t my_off = block_excl_scan(accepted ? (uint32_t)r_cnt : 0u, s_w, total);
 		if (accepted) {
-			u[n_u + (int32_t)lanes_below(am)] = (uint64_t)(uint32_t)r_sc << 32 | (uint64_t)(uint32_t)r_cnt;
-			const int32_t off = n_v + (int32_t)(inc - (uint32_t)r_cnt);
+			u[n_u + (int32_t)my_rank] = (uint64_t)(uint32_t)r_sc << 32 | (uint64_t)(uint32_t)r_cnt;
+			const int32_t off = n_v + (int32_t)my_off;
 			v[off] = i0;
 			if (r_cnt >= 2) v[off + 1] = pn1;
 			if (r_cnt >= 3) v[off + 2] = pn2;
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(64) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 			int32_t x = pn3;
 			for (int32_t j = 4; j < r_cnt; ++j) { x = fp[x].y; v[off + j] = x; }
 		}
-		n_u += (int32_t)__popcll(am);
+		n_u += (int32_t)n_acc;
 		n_v += (int32_t)total;
 	}
 	if (lane == 0) {
@@ -1667,7 +1675,9 @@ int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
 {
 	if (!r.n_act) return 0;
-	RH_LAUNCH(k_backtrack_spec, r.n_act, 64, rh_wave_lds(), s, o, rd, r);
+	static const bool bt_wave = getenv("RH_BT_WAVE") != nullptr;     // RH_BT_WAVE=1: one wavefront per read (A/B aid)
+	if (bt_wave) RH_LAUNCH(k_backtrack_spec<64>, r.n_act, 64, rh_wave_lds(), s, o, rd, r);
+	else RH_LAUNCH(k_backtrack_spec<256>, r.n_act, 256, rh_wave_lds(), s, o, rd, r);
 	// compact_a: chains gathered, put into the reference's order of their first anchor, written back
 	RH_LAUNCH(k_chain_gather, r.n_act, NT, 0, s, r);
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };   // keys = first anchors
