@@ -7,7 +7,7 @@ echo "[" > $O/r05_batchsize.json; first=1
 for n in $SIZES; do
   steps=$(( 262144 / n )); [ $steps -lt 3 ] && steps=3; [ $steps -gt 16 ] && steps=16
   for fl in 1 2; do [ $fl = 2 ] && [ $n -gt 65536 ] && continue
-    RH_BENCH_IN_FLIGHT=$fl timeout 900 python bench.py --reads $n --steps $steps --warmup 1 --cpu-sample 0 2>/dev/null | tail -1 > $O/bsz.json
+    GPU_MAX_HW_QUEUES=8 RH_BENCH_IN_FLIGHT=$fl timeout 900 python bench.py --reads $n --steps $steps --warmup 1 --cpu-sample 0 2>/dev/null | tail -1 > $O/bsz.json
     python - <<PY
 import json
 d=json.load(open("$O/bsz.json"))
