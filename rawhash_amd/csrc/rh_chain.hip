@@ -342,23 +342,35 @@ __global__ void k_chain_serial(rh_dev_opt o, rh_dev_round rr)
 // per read, the AVL tree as index arrays in the read's scratch (node id = anchor index), every operation the klib way (insertion
 // with a single re-balancing point, deletion by in-order successor, the two rotations with their subtree-minimum updates).
 // An opt-in, accuracy-for-speed mode of the reference (--rmq, --bw-long); serial per read by construction.
+// Node arrays are indexed by node id = anchor index.  Round 5: the live nodes of a read are the anchors within max_dist of the current one - a window of
+// consecutive indices - so where that window never exceeds RQ_RING nodes (k_chain_rmq finds out first) the arrays are RINGS IN LDS (index & mask) instead
+// of arrays in the read's scratch in HBM, and a node's priority and query position are cached beside them: a tree operation is ~40 dependent loads per anchor,
+// 1 - 2 us each from HBM under load, ~100 ns from LDS.
+template <class V> struct rq_arr { V *p; uint32_t mask; __device__ __forceinline__ V &operator[](int32_t i) const { return p[(uint32_t)i & mask]; } };
 struct rq_tree {
-	int32_t *l, *r, *s; uint32_t *sz; int8_t *bal;               // children, subtree minimum (node id), subtree size, balance factor
+	rq_arr<int32_t> l, r, s; rq_arr<uint32_t> sz; rq_arr<int8_t> bal;   // children, subtree minimum (node id), subtree size, balance factor
 	int32_t root;
 };
+#ifndef RQ_RING
+#define RQ_RING 128                                                // nodes of a tree held in LDS (a power of two); 46 bytes per node for both trees: 5.9 KB a wavefront, 24 wavefronts per CU
+#endif
+#ifndef RQ_RING_BIG
+#define RQ_RING_BIG 1024                                           // ... for the reads whose window is wider (a second launch, 47 KB a wavefront); wider still: the arrays in HBM
+#endif
 #define RQ_NIL (-1)
 #define RQ_FAKE (-2)                                                // the stand-in parent of the root during a deletion (krmq.h:247)
 #define RQ_DEPTH 64
 
-struct rq_env { const rh_mm128_t *an; const int32_t *fp; float pen_gap; };
-RH_DEV double rq_pri(const rq_env &E, int32_t j)
+struct rq_env { const rh_mm128_t *an; const int32_t *fp; float pen_gap; double *pri; int32_t *yk; uint32_t mask; int32_t *pp0, *pp1; int8_t *pb0, *pb1; };   // pp / pb: the search paths of an operation (RQ_DEPTH entries each, in LDS: as local arrays they cost the kernel 357 VGPRs - one wavefront per SIMD - and scratch memory on every step)   // pri / yk: LDS rings of the live nodes' priorities and query positions (null: computed from an / fp)
+RH_DEV double rq_pri_of(const rq_env &E, int32_t j)
 {
 	const double g = 0.5 * (double)E.pen_gap;                     // (0.5 * chn_pen_gap) * (x + y): the reference's association (lchain.c:672)
 	return -((double)E.fp[2 * j] + g * (double)((int32_t)E.an[j].x + (int32_t)E.an[j].y));
 }
+RH_DEV double rq_pri(const rq_env &E, int32_t j) { return E.pri ? E.pri[(uint32_t)j & E.mask] : rq_pri_of(E, j); }
 RH_DEV int rq_cmp_key(int32_t ya, int64_t ia, const rq_env &E, int32_t b)	// lc_elem_cmp (lchain.c:539) of key (ya, ia) against node b
 {
-	const int32_t yb = (int32_t)E.an[b].y;
+	const int32_t yb = E.yk ? E.yk[(uint32_t)b & E.mask] : (int32_t)E.an[b].y;
 	return ya < yb ? -1 : ya > yb ? 1 : (ia > (int64_t)b) - (ia < (int64_t)b);
 }
 RH_DEV int32_t &rq_child(rq_tree &T, int32_t &fake_l, int32_t p, int which) { return p == RQ_FAKE ? fake_l : (which ? T.r[p] : T.l[p]); }
@@ -406,10 +418,10 @@ RH_DEV int32_t rq_rotate2(rq_tree &T, const rq_env &E, int32_t p, int dir)	// (a
 }
 RH_DEV void rq_insert(rq_tree &T, const rq_env &E, int32_t x)	// krmq.h:194-242 (x is never present already: node ids are anchor indices)
 {
-	uint8_t stack[RQ_DEPTH];
-	int32_t path[RQ_DEPTH];
+	uint8_t *stack = reinterpret_cast<uint8_t*>(E.pb0);
+	int32_t *path = E.pp0;
 	int32_t fk = RQ_NIL;
-	const int32_t yx = (int32_t)E.an[x].y;
+	const int32_t yx = E.yk ? E.yk[(uint32_t)x & E.mask] : (int32_t)E.an[x].y;
 	int32_t bp = T.root, bq = RQ_NIL, p, q;
 	int which = 0, top = 0, path_len = 0;
 	for (p = bp, q = bq; p != RQ_NIL; q = p, p = rq_child(T, fk, p, which)) {
@@ -441,10 +453,10 @@ RH_DEV int32_t rq_find(const rq_tree &T, const rq_env &E, int32_t y, int64_t i)	
 }
 RH_DEV void rq_erase(rq_tree &T, const rq_env &E, int32_t x)	// krmq.h:244-327, x in the tree
 {
-	int32_t path[RQ_DEPTH];
-	uint8_t dir[RQ_DEPTH];
+	int32_t *path = E.pp0;
+	uint8_t *dir = reinterpret_cast<uint8_t*>(E.pb0);
 	int32_t fake_l = T.root;                                      // fake.p[0] = root, fake.p[1] = 0
-	const int32_t yx = (int32_t)E.an[x].y;
+	const int32_t yx = E.yk ? E.yk[(uint32_t)x & E.mask] : (int32_t)E.an[x].y;
 	int d = 0, c;
 	int32_t p;
 	for (c = -1, p = RQ_FAKE; c; c = rq_cmp_key(yx, x, E, p)) {
@@ -497,8 +509,8 @@ RH_DEV void rq_erase(rq_tree &T, const rq_env &E, int32_t x)	// krmq.h:244-327, 
 }
 RH_DEV int32_t rq_rmq(const rq_tree &T, const rq_env &E, int32_t ylo, int64_t ilo, int32_t yup, int64_t iup)	// closed interval, krmq.h:110-150
 {
-	int32_t path[2][RQ_DEPTH];
-	int8_t pcmp[2][RQ_DEPTH];
+	int32_t *path[2] = { E.pp0, E.pp1 };
+	int8_t *pcmp[2] = { E.pb0, E.pb1 };
 	int plen[2] = {0, 0}, i, c;
 	if (T.root == RQ_NIL) return RQ_NIL;
 	int32_t p = T.root;
@@ -542,10 +554,12 @@ RH_DEV int32_t rq_sc_simple(const rh_mm128_t &ai, const rh_mm128_t &aj, float pe
 // other (SIMT divergence) while the chip holds a few hundred wavefronts; a wavefront per read keeps every SIMD busy with independent walks instead
 // (E. coli-scale --rmq: 5.7 k reads/s with a lane per read, CPU reference 21 k).  counts[a] (optional) = anchors of read a when they are not
 // a_off[a + 1] - a_off[a] (the re-chaining of chains)
-__global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr, const uint32_t *counts, int32_t max_dist_in, int32_t max_dist_inner_in, int32_t cap_rmq_size)
+template <int RING, int PASS>
+__global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr, const uint32_t *counts, int32_t max_dist_in, int32_t max_dist_inner_in, int32_t cap_rmq_size, uint8_t *wide)
 {
 	const uint32_t a = blockIdx.x;
 	if (threadIdx.x != 0 || a >= rr.n_act || rr.skip[a]) return;
+	if (PASS == 1 && !wide[a]) return;                              // (done by the first launch)
 	const uint64_t base = rr.a_off[a];
 	const int32_t n_lay = (int32_t)(rr.a_off[a + 1] - base);         // the segment: what the later stages lay their arrays out by
 	const int32_t n = counts ? (int32_t)counts[a] : n_lay;           // the anchors to chain (the chained anchors of the first pass when re-chaining)
@@ -553,18 +567,46 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 	const rh_mm128_t *an = rr.anc + base;
 	int32_t *fp = (int32_t*)(rr.ws + base * rr.ws_stride), *v = fp + 2 * (size_t)n_lay, *t = v + n_lay;   // {f,p} interleaved, as the DP kernels leave them
 	// the two trees behind f / p / v / t in the read's scratch: 2 x 17 bytes per anchor (RH_WS_PER_ANCHOR = 64 covers 16 + 34)
-	rq_tree T[2];
+	__shared__ int32_t s_tree[2][4][RING];
+	__shared__ int8_t s_bal[2][RING];
+	__shared__ double s_pri[RING];
+	__shared__ int32_t s_yk[RING];
+	__shared__ int32_t s_pp[2][RQ_DEPTH];
+	__shared__ int8_t s_pb[2][RQ_DEPTH];
+	// the widest window of live nodes this read will have: anchors [st, i) with st as the loop below moves it (the size cap only evicts more)
+	bool ring;
 	{
+		int32_t md = max_dist_in < o.bw ? o.bw : max_dist_in, st0 = 0, widest = 0;
+		for (int32_t i = 0; i < n && widest < RING; ++i) {
+			const uint64_t xi = an[i].x;
+			if (i - st0 + 1 > widest) widest = i - st0 + 1;             // (the anchors before i are inserted before the far ones are evicted)
+			while (st0 < i && (xi >> 32 != an[st0].x >> 32 || xi > an[st0].x + (uint64_t)md)) ++st0;
+		}
+		ring = widest < RING;
+	}
+	if (PASS == 0) { wide[a] = ring ? 0 : 1; if (!ring) return; }     // a wider window: the second launch's
+	rq_tree T[2];
+	if (ring) {
+		const uint32_t m = (uint32_t)RING - 1u;
+		for (int k = 0; k < 2; ++k) {
+			T[k].l = rq_arr<int32_t>{s_tree[k][0], m}; T[k].r = rq_arr<int32_t>{s_tree[k][1], m}; T[k].s = rq_arr<int32_t>{s_tree[k][2], m};
+			T[k].sz = rq_arr<uint32_t>{reinterpret_cast<uint32_t*>(s_tree[k][3]), m}; T[k].bal = rq_arr<int8_t>{s_bal[k], m}; T[k].root = RQ_NIL;
+		}
+	} else {
 		int32_t *w = t + n_lay;
-		for (int k = 0; k < 2; ++k) { T[k].l = w; T[k].r = w + n_lay; T[k].s = w + 2 * (size_t)n_lay; T[k].sz = (uint32_t*)(w + 3 * (size_t)n_lay); w += 4 * (size_t)n_lay; T[k].root = RQ_NIL; }
+		const uint32_t m = 0xFFFFFFFFu;
+		for (int k = 0; k < 2; ++k) {
+			T[k].l = rq_arr<int32_t>{w, m}; T[k].r = rq_arr<int32_t>{w + n_lay, m}; T[k].s = rq_arr<int32_t>{w + 2 * (size_t)n_lay, m};
+			T[k].sz = rq_arr<uint32_t>{(uint32_t*)(w + 3 * (size_t)n_lay), m}; w += 4 * (size_t)n_lay; T[k].root = RQ_NIL;
+		}
 		int8_t *b = (int8_t*)w;
-		T[0].bal = b; T[1].bal = b + n_lay;
+		T[0].bal = rq_arr<int8_t>{b, m}; T[1].bal = rq_arr<int8_t>{b + n_lay, m};
 	}
 	// positions beyond the anchors of this pass: never a backtrack candidate, never a predecessor
 	for (int32_t i = n; i < n_lay; ++i) { fp[2 * i] = INT32_MIN / 2; fp[2 * i + 1] = -1; v[i] = INT32_MIN / 2; }
 	#define F_(i) fp[2 * (i)]
 	#define P_(i) fp[2 * (i) + 1]
-	const rq_env E = { an, fp, o.pen_gap };
+	const rq_env E = { an, fp, o.pen_gap, ring ? s_pri : nullptr, ring ? s_yk : nullptr, (uint32_t)RING - 1u, s_pp[0], s_pp[1], s_pb[0], s_pb[1] };
 	const int32_t bw = o.bw;
 	int32_t max_dist = max_dist_in, max_dist_inner = max_dist_inner_in;
 	if (max_dist < bw) max_dist = bw;
@@ -575,7 +617,10 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 		const rh_mm128_t ai = an[i];
 		int32_t max_j = -1, max_f = (int32_t)((ai.y >> 32) & 63);
 		if (i0 < i && an[i0].x != ai.x) {	// add in-range anchors
-			for (int32_t j = i0; j < i; ++j) { rq_insert(T[0], E, j); if (max_dist_inner > 0) rq_insert(T[1], E, j); }
+			for (int32_t j = i0; j < i; ++j) {
+				if (ring) { s_pri[(uint32_t)j & E.mask] = rq_pri_of(E, j); s_yk[(uint32_t)j & E.mask] = (int32_t)an[j].y; }   // (f[j] is final: j < i)
+				rq_insert(T[0], E, j); if (max_dist_inner > 0) rq_insert(T[1], E, j);
+			}
 			i0 = i;
 		}
 		while (st < i && (ai.x >> 32 != an[st].x >> 32 || ai.x > an[st].x + (uint64_t)max_dist || (T[0].root != RQ_NIL && T[0].sz[T[0].root] > (uint32_t)cap_rmq_size))) {
@@ -600,7 +645,7 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 				int32_t lo = RQ_NIL;
 				for (int32_t p = T[1].root; p != RQ_NIL;) { const int c = rq_cmp_key(ys, (int64_t)n, E, p); if (c < 0) p = T[1].l[p]; else if (c > 0) { lo = p; p = T[1].r[p]; } else { lo = p; break; } }
 				if (lo != RQ_NIL) {
-					int32_t stack[RQ_DEPTH];
+					int32_t *stack = E.pp0;
 					int top = -1;
 					for (int32_t p = T[1].root; p != RQ_NIL;) { stack[++top] = p; const int c = rq_cmp_key((int32_t)an[lo].y, (int64_t)lo, E, p); if (c < 0) p = T[1].l[p]; else if (c > 0) p = T[1].r[p]; else break; }
 					while (top >= 0) {
@@ -635,7 +680,9 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 void rhk_chain_rmq(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r, const uint32_t *counts, int32_t max_dist, int32_t max_dist_inner, int32_t cap_rmq_size)
 {
 	if (!r.n_act) return;
-	RH_LAUNCH(k_chain_rmq, r.n_act, 64, 0, s, o, r, counts, max_dist, max_dist_inner, cap_rmq_size);
+	// (need_exact2 is idle between the anchor sort and the chain-order sort: here it says which reads' windows did not fit the small rings)
+	RH_LAUNCH((k_chain_rmq<RQ_RING, 0>), r.n_act, 64, 0, s, o, r, counts, max_dist, max_dist_inner, cap_rmq_size, r.need_exact2);
+	RH_LAUNCH((k_chain_rmq<RQ_RING_BIG, 1>), r.n_act, 64, 0, s, o, r, counts, max_dist, max_dist_inner, cap_rmq_size, r.need_exact2);
 }
 
 void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)

@@ -106,6 +106,18 @@ def test_rmq_chaining(make_workload, emu_lib, mapopt):
     c.close()
 
 
+def test_rmq_tree_storage_classes(make_workload, emu_lib_smallcaps):
+    """The RMQ trees live in LDS rings where a read's window of live nodes fits (RQ_RING nodes; a second launch with RQ_RING_BIG for wider windows) and in
+    the read's scratch in HBM beyond that: a build with rings of 8 / 32 nodes sends reads through all three on small inputs."""
+    w = make_workload(lib=emu_lib_smallcaps, n_reads=14, n_samples=12_000, mapopt={"flag": 2})
+    c = Context(0, lib=emu_lib_smallcaps)
+    c.upload(w.index)
+    n_an, n_ch, n_u = pc.check_chain_synthetic(c, w, seed=6, n_reads=24, max_n=400)
+    assert n_ch > 0 and n_u > 0
+    pc.check_e2e(c, w)
+    c.close()
+
+
 DTW_VARIANTS = [{"flag": 0x40}, {"flag": 0x40, "dtw_border_constraint": 0}, {"flag": 0x40, "dtw_fill_method": 0, "dtw_min_score": 5.0},
                 {"flag": 0x40, "dtw_border_constraint": 0, "dtw_fill_method": 0}]
 
