@@ -351,17 +351,20 @@ struct rq_tree {
 	rq_arr<int32_t> l, r, s; rq_arr<uint32_t> sz; rq_arr<int8_t> bal;   // children, subtree minimum (node id), subtree size, balance factor
 	int32_t root;
 };
+#ifndef RQ_RING_S
+#define RQ_RING_S 64                                               // the narrowest class: 4.9 KB a wavefront, 32 wavefronts per CU (the walk is one lane following pointers: resident wavefronts are what hides its latency)
+#endif
 #ifndef RQ_RING
-#define RQ_RING 128                                                // nodes of a tree held in LDS (a power of two); 46 bytes per node for both trees: 5.9 KB a wavefront, 24 wavefronts per CU
+#define RQ_RING 128                                                // nodes of a tree held in LDS (a power of two); 66 bytes per node - both trees, priority, anchor, {f, p} -: 8.4 KB a wavefront, 18 wavefronts per CU
 #endif
 #ifndef RQ_RING_BIG
-#define RQ_RING_BIG 1024                                           // ... for the reads whose window is wider (a second launch, 47 KB a wavefront); wider still: the arrays in HBM
+#define RQ_RING_BIG 512                                            // ... for the reads whose window is wider (a second launch, 34 KB a wavefront); wider still: the arrays in HBM
 #endif
 #define RQ_NIL (-1)
 #define RQ_FAKE (-2)                                                // the stand-in parent of the root during a deletion (krmq.h:247)
 #define RQ_DEPTH 64
 
-struct rq_env { const rh_mm128_t *an; const int32_t *fp; float pen_gap; double *pri; int32_t *yk; uint32_t mask; int32_t *pp0, *pp1; int8_t *pb0, *pb1; };   // pp / pb: the search paths of an operation (RQ_DEPTH entries each, in LDS: as local arrays they cost the kernel 357 VGPRs - one wavefront per SIMD - and scratch memory on every step)   // pri / yk: LDS rings of the live nodes' priorities and query positions (null: computed from an / fp)
+struct rq_env { const rh_mm128_t *an; const int32_t *fp; float pen_gap; double *pri; uint64_t *ay; uint32_t mask; int32_t *pp0, *pp1; int8_t *pb0, *pb1; };   // pp / pb: the search paths of an operation (RQ_DEPTH entries each, in LDS: as local arrays they cost the kernel 357 VGPRs - one wavefront per SIMD - and scratch memory on every step)   // pri / ay: LDS rings of the live nodes' priorities and y words (null: computed from an / fp)
 RH_DEV double rq_pri_of(const rq_env &E, int32_t j)
 {
 	const double g = 0.5 * (double)E.pen_gap;                     // (0.5 * chn_pen_gap) * (x + y): the reference's association (lchain.c:672)
@@ -370,7 +373,7 @@ RH_DEV double rq_pri_of(const rq_env &E, int32_t j)
 RH_DEV double rq_pri(const rq_env &E, int32_t j) { return E.pri ? E.pri[(uint32_t)j & E.mask] : rq_pri_of(E, j); }
 RH_DEV int rq_cmp_key(int32_t ya, int64_t ia, const rq_env &E, int32_t b)	// lc_elem_cmp (lchain.c:539) of key (ya, ia) against node b
 {
-	const int32_t yb = E.yk ? E.yk[(uint32_t)b & E.mask] : (int32_t)E.an[b].y;
+	const int32_t yb = E.ay ? (int32_t)E.ay[(uint32_t)b & E.mask] : (int32_t)E.an[b].y;
 	return ya < yb ? -1 : ya > yb ? 1 : (ia > (int64_t)b) - (ia < (int64_t)b);
 }
 RH_DEV int32_t &rq_child(rq_tree &T, int32_t &fake_l, int32_t p, int which) { return p == RQ_FAKE ? fake_l : (which ? T.r[p] : T.l[p]); }
@@ -421,7 +424,7 @@ RH_DEV void rq_insert(rq_tree &T, const rq_env &E, int32_t x)	// krmq.h:194-242 
 	uint8_t *stack = reinterpret_cast<uint8_t*>(E.pb0);
 	int32_t *path = E.pp0;
 	int32_t fk = RQ_NIL;
-	const int32_t yx = E.yk ? E.yk[(uint32_t)x & E.mask] : (int32_t)E.an[x].y;
+	const int32_t yx = E.ay ? (int32_t)E.ay[(uint32_t)x & E.mask] : (int32_t)E.an[x].y;
 	int32_t bp = T.root, bq = RQ_NIL, p, q;
 	int which = 0, top = 0, path_len = 0;
 	for (p = bp, q = bq; p != RQ_NIL; q = p, p = rq_child(T, fk, p, which)) {
@@ -456,7 +459,7 @@ RH_DEV void rq_erase(rq_tree &T, const rq_env &E, int32_t x)	// krmq.h:244-327, 
 	int32_t *path = E.pp0;
 	uint8_t *dir = reinterpret_cast<uint8_t*>(E.pb0);
 	int32_t fake_l = T.root;                                      // fake.p[0] = root, fake.p[1] = 0
-	const int32_t yx = E.yk ? E.yk[(uint32_t)x & E.mask] : (int32_t)E.an[x].y;
+	const int32_t yx = E.ay ? (int32_t)E.ay[(uint32_t)x & E.mask] : (int32_t)E.an[x].y;
 	int d = 0, c;
 	int32_t p;
 	for (c = -1, p = RQ_FAKE; c; c = rq_cmp_key(yx, x, E, p)) {
@@ -554,12 +557,43 @@ RH_DEV int32_t rq_sc_simple(const rh_mm128_t &ai, const rh_mm128_t &aj, float pe
 // other (SIMT divergence) while the chip holds a few hundred wavefronts; a wavefront per read keeps every SIMD busy with independent walks instead
 // (E. coli-scale --rmq: 5.7 k reads/s with a lane per read, CPU reference 21 k).  counts[a] (optional) = anchors of read a when they are not
 // a_off[a + 1] - a_off[a] (the re-chaining of chains)
-template <int RING, int PASS>
-__global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr, const uint32_t *counts, int32_t max_dist_in, int32_t max_dist_inner_in, int32_t cap_rmq_size, uint8_t *wide)
+// The widest window of live nodes each read will have - anchors [st, i) with st as the walk below moves it (the size cap only evicts more) - sorted into the
+// storage class that holds it: 0 / 1 / 2 = LDS rings of RQ_RING_S / RQ_RING / RQ_RING_BIG nodes, 3 = the arrays in HBM.  The anchors are sorted by x, so
+// "first anchor still in range of anchor i - 1" is a binary search: a lane per anchor, 64 at a time.
+__global__ __launch_bounds__(64) void k_rmq_class(rh_dev_opt o, rh_dev_round rr, const uint32_t *counts, int32_t max_dist_in, uint8_t *cls)
 {
 	const uint32_t a = blockIdx.x;
-	if (threadIdx.x != 0 || a >= rr.n_act || rr.skip[a]) return;
-	if (PASS == 1 && !wide[a]) return;                              // (done by the first launch)
+	if (a >= rr.n_act || rr.skip[a]) return;
+	const uint64_t base = rr.a_off[a];
+	const int32_t n_lay = (int32_t)(rr.a_off[a + 1] - base), n = counts ? (int32_t)counts[a] : n_lay;
+	const rh_mm128_t *an = rr.anc + base;
+	const uint64_t md = (uint64_t)(max_dist_in < o.bw ? o.bw : max_dist_in);
+	__shared__ uint32_t s_widest;
+	if (threadIdx.x == 0) s_widest = 1;
+	__syncthreads();
+	uint32_t widest = 1;
+	for (int32_t i = 1 + (int32_t)threadIdx.x; i < n; i += 64) {
+		const uint64_t xs = an[i - 1].x;
+		int32_t lo = 0, hi = i - 1;                                     // st after anchor i - 1: the first j with an[j] on xs's target and xs <= an[j].x + md (j = i - 1 is)
+		while (lo < hi) {
+			const int32_t m = (lo + hi) >> 1;
+			const uint64_t xm = an[m].x;
+			if (xs >> 32 == xm >> 32 && xs <= xm + md) hi = m; else lo = m + 1;
+		}
+		const uint32_t w = (uint32_t)(i - lo + 1);                      // (the anchors before i are inserted before the far ones are evicted)
+		if (w > widest) widest = w;
+	}
+	atomicMax(&s_widest, widest);
+	__syncthreads();
+	if (threadIdx.x == 0) { const uint32_t w = s_widest; cls[a] = w < RQ_RING_S ? 0 : w < RQ_RING ? 1 : w < RQ_RING_BIG ? 2 : 3; }
+}
+
+// (the storage is a property of the launch - RING nodes in LDS, or RING = 0: the arrays in HBM - so that the compiler sees LDS addresses, not pointers that may be either)
+template <int RING, int CLS>
+__global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr, const uint32_t *counts, int32_t max_dist_in, int32_t max_dist_inner_in, int32_t cap_rmq_size, const uint8_t *cls)
+{
+	const uint32_t a = blockIdx.x;
+	if (threadIdx.x != 0 || a >= rr.n_act || rr.skip[a] || cls[a] != CLS) return;
 	const uint64_t base = rr.a_off[a];
 	const int32_t n_lay = (int32_t)(rr.a_off[a + 1] - base);         // the segment: what the later stages lay their arrays out by
 	const int32_t n = counts ? (int32_t)counts[a] : n_lay;           // the anchors to chain (the chained anchors of the first pass when re-chaining)
@@ -567,24 +601,15 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 	const rh_mm128_t *an = rr.anc + base;
 	int32_t *fp = (int32_t*)(rr.ws + base * rr.ws_stride), *v = fp + 2 * (size_t)n_lay, *t = v + n_lay;   // {f,p} interleaved, as the DP kernels leave them
 	// the two trees behind f / p / v / t in the read's scratch: 2 x 17 bytes per anchor (RH_WS_PER_ANCHOR = 64 covers 16 + 34)
-	__shared__ int32_t s_tree[2][4][RING];
-	__shared__ int8_t s_bal[2][RING];
-	__shared__ double s_pri[RING];
-	__shared__ int32_t s_yk[RING];
+	constexpr bool ring = RING > 0;
+	constexpr int NR = ring ? RING : 1;
+	__shared__ int32_t s_tree[2][4][NR];
+	__shared__ int8_t s_bal[2][NR];
+	__shared__ double s_pri[NR];
+	__shared__ uint64_t s_ay[NR], s_ax[NR];                         // ... and the nodes' anchors and {f, p}: what the walk down the inner tree reads of every node it passes
+	__shared__ int32_t s_f[NR], s_p[NR];
 	__shared__ int32_t s_pp[2][RQ_DEPTH];
 	__shared__ int8_t s_pb[2][RQ_DEPTH];
-	// the widest window of live nodes this read will have: anchors [st, i) with st as the loop below moves it (the size cap only evicts more)
-	bool ring;
-	{
-		int32_t md = max_dist_in < o.bw ? o.bw : max_dist_in, st0 = 0, widest = 0;
-		for (int32_t i = 0; i < n && widest < RING; ++i) {
-			const uint64_t xi = an[i].x;
-			if (i - st0 + 1 > widest) widest = i - st0 + 1;             // (the anchors before i are inserted before the far ones are evicted)
-			while (st0 < i && (xi >> 32 != an[st0].x >> 32 || xi > an[st0].x + (uint64_t)md)) ++st0;
-		}
-		ring = widest < RING;
-	}
-	if (PASS == 0) { wide[a] = ring ? 0 : 1; if (!ring) return; }     // a wider window: the second launch's
 	rq_tree T[2];
 	if (ring) {
 		const uint32_t m = (uint32_t)RING - 1u;
@@ -606,7 +631,7 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 	for (int32_t i = n; i < n_lay; ++i) { fp[2 * i] = INT32_MIN / 2; fp[2 * i + 1] = -1; v[i] = INT32_MIN / 2; }
 	#define F_(i) fp[2 * (i)]
 	#define P_(i) fp[2 * (i) + 1]
-	const rq_env E = { an, fp, o.pen_gap, ring ? s_pri : nullptr, ring ? s_yk : nullptr, (uint32_t)RING - 1u, s_pp[0], s_pp[1], s_pb[0], s_pb[1] };
+	const rq_env E = { an, fp, o.pen_gap, ring ? s_pri : nullptr, ring ? s_ay : nullptr, (uint32_t)RING - 1u, s_pp[0], s_pp[1], s_pb[0], s_pb[1] };
 	const int32_t bw = o.bw;
 	int32_t max_dist = max_dist_in, max_dist_inner = max_dist_inner_in;
 	if (max_dist < bw) max_dist = bw;
@@ -618,7 +643,7 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 		int32_t max_j = -1, max_f = (int32_t)((ai.y >> 32) & 63);
 		if (i0 < i && an[i0].x != ai.x) {	// add in-range anchors
 			for (int32_t j = i0; j < i; ++j) {
-				if (ring) { s_pri[(uint32_t)j & E.mask] = rq_pri_of(E, j); s_yk[(uint32_t)j & E.mask] = (int32_t)an[j].y; }   // (f[j] is final: j < i)
+				if (ring) { const uint32_t sl = (uint32_t)j & E.mask; const rh_mm128_t aj = an[j]; s_pri[sl] = rq_pri_of(E, j); s_ax[sl] = aj.x; s_ay[sl] = aj.y; s_f[sl] = F_(j); s_p[sl] = P_(j); }   // (f[j], p[j] are final: j < i)
 				rq_insert(T[0], E, j); if (max_dist_inner > 0) rq_insert(T[1], E, j);
 			}
 			i0 = i;
@@ -633,11 +658,16 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 				++st_inner;
 			}
 		}
+		#define NF_(j_) (ring ? s_f[(uint32_t)(j_) & E.mask] : F_(j_))
+		#define NP_(j_) (ring ? s_p[(uint32_t)(j_) & E.mask] : P_(j_))
+		#define NY_(j_) (ring ? (int32_t)s_ay[(uint32_t)(j_) & E.mask] : (int32_t)an[j_].y)
+		#define NA_(v_, j_) rh_mm128_t v_; if (ring) { v_.x = s_ax[(uint32_t)(j_) & E.mask]; v_.y = s_ay[(uint32_t)(j_) & E.mask]; } else v_ = an[j_]
 		const int32_t q = rq_rmq(T[0], E, (int32_t)ai.y - max_dist, (int64_t)INT32_MAX, (int32_t)ai.y, 0);
 		if (q != RQ_NIL) {
 			int32_t exact, width, n_skip = 0;
 			int32_t j = q;
-			int32_t sc = F_(j) + rq_sc_simple(ai, an[j], o.pen_gap, o.pen_skip, &exact, &width);
+			NA_(aq, j);
+			int32_t sc = NF_(j) + rq_sc_simple(ai, aq, o.pen_gap, o.pen_skip, &exact, &width);
 			if (width <= bw && sc > max_f) { max_f = sc; max_j = j; }
 			if (!exact && T[1].root != RQ_NIL && (int32_t)ai.y > 0) {
 				// krmq_interval for (y - 1, n): the greatest element below it; then walk down the keys from there (krmq_itr_find + itr_prev)
@@ -647,17 +677,18 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 				if (lo != RQ_NIL) {
 					int32_t *stack = E.pp0;
 					int top = -1;
-					for (int32_t p = T[1].root; p != RQ_NIL;) { stack[++top] = p; const int c = rq_cmp_key((int32_t)an[lo].y, (int64_t)lo, E, p); if (c < 0) p = T[1].l[p]; else if (c > 0) p = T[1].r[p]; else break; }
+					for (int32_t p = T[1].root; p != RQ_NIL;) { stack[++top] = p; const int c = rq_cmp_key(NY_(lo), (int64_t)lo, E, p); if (c < 0) p = T[1].l[p]; else if (c > 0) p = T[1].r[p]; else break; }
 					while (top >= 0) {
 						const int32_t qq = stack[top];
-						if ((int32_t)an[qq].y < (int32_t)ai.y - max_dist_inner) break;
+						if (NY_(qq) < (int32_t)ai.y - max_dist_inner) break;
 						j = qq;
 						int32_t width2;
-						sc = F_(j) + rq_sc_simple(ai, an[j], o.pen_gap, o.pen_skip, nullptr, &width2);
+						NA_(aw, j);
+						sc = NF_(j) + rq_sc_simple(ai, aw, o.pen_gap, o.pen_skip, nullptr, &width2);
 						if (width2 <= bw) {
 							if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
 							else if (t[j] == i) { if (++n_skip > o.max_skip) break; }
-							if (P_(j) >= 0) t[P_(j)] = i;
+							{ const int32_t pj = NP_(j); if (pj >= 0) t[pj] = i; }
 						}
 						// krmq_itr_prev
 						int32_t p = T[1].l[stack[top]];
@@ -672,6 +703,10 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 		}
 		F_(i) = max_f; P_(i) = max_j;
 		v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
+		#undef NF_
+		#undef NP_
+		#undef NY_
+		#undef NA_
 	}
 	#undef F_
 	#undef P_
@@ -680,9 +715,12 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 void rhk_chain_rmq(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r, const uint32_t *counts, int32_t max_dist, int32_t max_dist_inner, int32_t cap_rmq_size)
 {
 	if (!r.n_act) return;
-	// (need_exact2 is idle between the anchor sort and the chain-order sort: here it says which reads' windows did not fit the small rings)
-	RH_LAUNCH((k_chain_rmq<RQ_RING, 0>), r.n_act, 64, 0, s, o, r, counts, max_dist, max_dist_inner, cap_rmq_size, r.need_exact2);
-	RH_LAUNCH((k_chain_rmq<RQ_RING_BIG, 1>), r.n_act, 64, 0, s, o, r, counts, max_dist, max_dist_inner, cap_rmq_size, r.need_exact2);
+	// (need_exact2 is idle between the anchor sort and the chain-order sort: here it holds each read's storage class)
+	RH_LAUNCH(k_rmq_class, r.n_act, 64, 0, s, o, r, counts, max_dist, r.need_exact2);
+	RH_LAUNCH((k_chain_rmq<RQ_RING_S, 0>), r.n_act, 64, 0, s, o, r, counts, max_dist, max_dist_inner, cap_rmq_size, r.need_exact2);
+	RH_LAUNCH((k_chain_rmq<RQ_RING, 1>), r.n_act, 64, 0, s, o, r, counts, max_dist, max_dist_inner, cap_rmq_size, r.need_exact2);
+	RH_LAUNCH((k_chain_rmq<RQ_RING_BIG, 2>), r.n_act, 64, 0, s, o, r, counts, max_dist, max_dist_inner, cap_rmq_size, r.need_exact2);
+	RH_LAUNCH((k_chain_rmq<0, 3>), r.n_act, 64, 0, s, o, r, counts, max_dist, max_dist_inner, cap_rmq_size, r.need_exact2);
 }
 
 void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)

@@ -107,8 +107,8 @@ def test_rmq_chaining(make_workload, emu_lib, mapopt):
 
 
 def test_rmq_tree_storage_classes(make_workload, emu_lib_smallcaps):
-    """The RMQ trees live in LDS rings where a read's window of live nodes fits (RQ_RING nodes; a second launch with RQ_RING_BIG for wider windows) and in
-    the read's scratch in HBM beyond that: a build with rings of 8 / 32 nodes sends reads through all three on small inputs."""
+    """The RMQ trees live in LDS rings where a read's window of live nodes fits (three classes: RQ_RING_S / RQ_RING / RQ_RING_BIG nodes, a launch each) and in
+    the read's scratch in HBM beyond that: a build with rings of 4 / 8 / 32 nodes sends reads through all four on small inputs."""
     w = make_workload(lib=emu_lib_smallcaps, n_reads=14, n_samples=12_000, mapopt={"flag": 2})
     c = Context(0, lib=emu_lib_smallcaps)
     c.upload(w.index)
