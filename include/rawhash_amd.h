@@ -113,7 +113,9 @@ typedef struct rh_read_batch_s {
 	                                     decodes (rh_reads_batch does; rh_count_filtered for other sources) lets the device FETCH ONLY THE SIGNAL THE
 	                                     ROUNDS CONSUME when samples[] is page-locked (rh_pinned_alloc, rh_reads_*): a read that maps stops after
 	                                     one or two chunks (rmap.cpp:425/498), the rest of its signal never crosses PCIe.  Values that are not the
-	                                     true counts fail the call loudly where the device sees the whole read.  Like every per-read array it has to
+	                                     true counts fail the call loudly where the device sees the whole read - and ONLY there: for a read that maps after one or two
+	                                     chunks the count is UNCHECKED INPUT (it still bounds the chunk loop and is what sl:i prints), and with samples[]
+	                                     in pageable memory every count is checked.  Like every per-read array it has to
 	                                     be offset together with `offsets` when a caller slices a batch by hand. */
 } rh_read_batch_t;
 
