@@ -1174,6 +1174,9 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 	const uint32_t R = in->n_reads;
 	int n_sub = c->n_sub;
 	while (n_sub > 1 && R / (uint32_t)n_sub < 2048u) --n_sub;
+	// RMQ chaining: a launch lasts as long as its longest read (one wavefront per read, k_chain_rmq) and three streams of such launches did not overlap
+	// (D. mel scale, 8 000 / 48 000 reads a call: 1 stream 2.11 k / 7.38 k reads/s, 2: 2.15 k / 7.02 k, 3: 1.18 k / 4.52 k; E. coli scale, 20 000: 29.0 k, 31.1 k, 18.0 k)
+	if (((mo->flag & RH_M_RMQ) || mo->bw_long > mo->bw) && n_sub > 2 && !getenv("RH_SUB_BATCHES")) n_sub = 2;
 	if (n_sub <= 1 || c->is_sub) { if (!c->is_sub) c->share = c->flight_mult; return map_batch_single(c, mo, in, out, out_cap, n_out); }
 	*n_out = 0;
 	if (need_index(c)) return -1;
