@@ -365,11 +365,12 @@ struct rq_tree {
 #define RQ_DEPTH 64
 
 struct rq_env { const rh_mm128_t *an; const int32_t *fp; float pen_gap; double *pri; uint64_t *ay; uint32_t mask; int32_t *pp0, *pp1; int8_t *pb0, *pb1; };   // pp / pb: the search paths of an operation (RQ_DEPTH entries each, in LDS: as local arrays they cost the kernel 357 VGPRs - one wavefront per SIMD - and scratch memory on every step)   // pri / ay: LDS rings of the live nodes' priorities and y words (null: computed from an / fp)
-RH_DEV double rq_pri_of(const rq_env &E, int32_t j)
+RH_DEV double rq_pri_val(float pen_gap, int32_t f, uint64_t x, uint64_t y)
 {
-	const double g = 0.5 * (double)E.pen_gap;                     // (0.5 * chn_pen_gap) * (x + y): the reference's association (lchain.c:672)
-	return -((double)E.fp[2 * j] + g * (double)((int32_t)E.an[j].x + (int32_t)E.an[j].y));
+	const double g = 0.5 * (double)pen_gap;                       // (0.5 * chn_pen_gap) * (x + y): the reference's association (lchain.c:672)
+	return -((double)f + g * (double)((int32_t)x + (int32_t)y));
 }
+RH_DEV double rq_pri_of(const rq_env &E, int32_t j) { return rq_pri_val(E.pen_gap, E.fp[2 * j], E.an[j].x, E.an[j].y); }
 RH_DEV double rq_pri(const rq_env &E, int32_t j) { return E.pri ? E.pri[(uint32_t)j & E.mask] : rq_pri_of(E, j); }
 RH_DEV int rq_cmp_key(int32_t ya, int64_t ia, const rq_env &E, int32_t b)	// lc_elem_cmp (lchain.c:539) of key (ya, ia) against node b
 {
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 	__shared__ int8_t s_bal[2][NR];
 	__shared__ double s_pri[NR];
 	__shared__ uint64_t s_ay[NR], s_ax[NR];                         // ... and the nodes' anchors and {f, p}: what the walk down the inner tree reads of every node it passes
-	__shared__ int32_t s_f[NR], s_p[NR];
+	__shared__ int32_t s_f[NR], s_p[NR], s_v[NR], s_t[NR];          // (s_t: the mark "seen in iteration i" of the inner walk - compared with the current i only, so a slot's older values never match)
 	__shared__ int32_t s_pp[2][RQ_DEPTH];
 	__shared__ int8_t s_pb[2][RQ_DEPTH];
 	rq_tree T[2];
@@ -636,25 +637,32 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 	int32_t max_dist = max_dist_in, max_dist_inner = max_dist_inner_in;
 	if (max_dist < bw) max_dist = bw;
 	if (max_dist_inner <= 0 || max_dist_inner >= max_dist) max_dist_inner = 0;
-	for (int32_t i = 0; i < n; ++i) t[i] = 0;
+	// Ring classes: everything the walk reads again lives in the rings, filled as the walk arrives at an anchor (x, y) and leaves it (f, p, v) - the window
+	// [st, i] has fewer than RING anchors (k_rmq_class), so slot i & mask is free when i arrives -, and the next anchor is loaded one iteration ahead:
+	// no load from HBM is waited for inside an iteration (there were five or six in a row: an[i], an[i0], an[st], an[st_inner], t[j], f[j] / p[j] / v[max_j]).
+	if (!ring) for (int32_t i = 0; i < n; ++i) t[i] = 0;
+	else for (int32_t k = 0; k < NR; ++k) s_t[k] = -1;
+	#define AX_(j_) (ring ? s_ax[(uint32_t)(j_) & E.mask] : an[j_].x)
 	int32_t i0 = 0, st = 0, st_inner = 0;
+	rh_mm128_t nxt = an[0];
 	for (int32_t i = 0; i < n; ++i) {
-		const rh_mm128_t ai = an[i];
+		const rh_mm128_t ai = ring ? nxt : an[i];
+		if (ring) { if (i + 1 < n) nxt = an[i + 1]; s_ax[(uint32_t)i & E.mask] = ai.x; s_ay[(uint32_t)i & E.mask] = ai.y; }
 		int32_t max_j = -1, max_f = (int32_t)((ai.y >> 32) & 63);
-		if (i0 < i && an[i0].x != ai.x) {	// add in-range anchors
+		if (i0 < i && AX_(i0) != ai.x) {	// add in-range anchors
 			for (int32_t j = i0; j < i; ++j) {
-				if (ring) { const uint32_t sl = (uint32_t)j & E.mask; const rh_mm128_t aj = an[j]; s_pri[sl] = rq_pri_of(E, j); s_ax[sl] = aj.x; s_ay[sl] = aj.y; s_f[sl] = F_(j); s_p[sl] = P_(j); }   // (f[j], p[j] are final: j < i)
+				if (ring) { const uint32_t sl = (uint32_t)j & E.mask; s_pri[sl] = rq_pri_val(o.pen_gap, s_f[sl], s_ax[sl], s_ay[sl]); }   // (f[j] is final: j < i)
 				rq_insert(T[0], E, j); if (max_dist_inner > 0) rq_insert(T[1], E, j);
 			}
 			i0 = i;
 		}
-		while (st < i && (ai.x >> 32 != an[st].x >> 32 || ai.x > an[st].x + (uint64_t)max_dist || (T[0].root != RQ_NIL && T[0].sz[T[0].root] > (uint32_t)cap_rmq_size))) {
-			if (rq_find(T[0], E, (int32_t)an[st].y, st) != RQ_NIL) rq_erase(T[0], E, st);
+		while (st < i && (ai.x >> 32 != AX_(st) >> 32 || ai.x > AX_(st) + (uint64_t)max_dist || (T[0].root != RQ_NIL && T[0].sz[T[0].root] > (uint32_t)cap_rmq_size))) {
+			if (rq_find(T[0], E, ring ? (int32_t)s_ay[(uint32_t)st & E.mask] : (int32_t)an[st].y, st) != RQ_NIL) rq_erase(T[0], E, st);
 			++st;
 		}
 		if (max_dist_inner > 0) {
-			while (st_inner < i && (ai.x >> 32 != an[st_inner].x >> 32 || ai.x > an[st_inner].x + (uint64_t)max_dist_inner || (T[1].root != RQ_NIL && T[1].sz[T[1].root] > (uint32_t)cap_rmq_size))) {
-				if (rq_find(T[1], E, (int32_t)an[st_inner].y, st_inner) != RQ_NIL) rq_erase(T[1], E, st_inner);
+			while (st_inner < i && (ai.x >> 32 != AX_(st_inner) >> 32 || ai.x > AX_(st_inner) + (uint64_t)max_dist_inner || (T[1].root != RQ_NIL && T[1].sz[T[1].root] > (uint32_t)cap_rmq_size))) {
+				if (rq_find(T[1], E, ring ? (int32_t)s_ay[(uint32_t)st_inner & E.mask] : (int32_t)an[st_inner].y, st_inner) != RQ_NIL) rq_erase(T[1], E, st_inner);
 				++st_inner;
 			}
 		}
@@ -687,8 +695,8 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 						sc = NF_(j) + rq_sc_simple(ai, aw, o.pen_gap, o.pen_skip, nullptr, &width2);
 						if (width2 <= bw) {
 							if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
-							else if (t[j] == i) { if (++n_skip > o.max_skip) break; }
-							{ const int32_t pj = NP_(j); if (pj >= 0) t[pj] = i; }
+							else if ((ring ? s_t[(uint32_t)j & E.mask] : t[j]) == i) { if (++n_skip > o.max_skip) break; }
+							{ const int32_t pj = NP_(j); if (pj >= 0) { if (!ring) t[pj] = i; else if (pj > i - NR) s_t[(uint32_t)pj & E.mask] = i; } }   // (a mark on an anchor RING or more behind is never read: the walk meets live nodes only)
 						}
 						// krmq_itr_prev
 						int32_t p = T[1].l[stack[top]];
@@ -702,12 +710,16 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 			}
 		}
 		F_(i) = max_f; P_(i) = max_j;
-		v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
+		int32_t vi = max_f;
+		if (max_j >= 0) { const int32_t vj = ring ? s_v[(uint32_t)max_j & E.mask] : v[max_j]; if (vj > max_f) vi = vj; }   // (max_j is a live node)
+		v[i] = vi;
+		if (ring) { const uint32_t sl = (uint32_t)i & E.mask; s_f[sl] = max_f; s_p[sl] = max_j; s_v[sl] = vi; }
 		#undef NF_
 		#undef NP_
 		#undef NY_
 		#undef NA_
 	}
+	#undef AX_
 	#undef F_
 	#undef P_
 }
