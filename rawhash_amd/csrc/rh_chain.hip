@@ -657,12 +657,12 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 			i0 = i;
 		}
 		while (st < i && (ai.x >> 32 != AX_(st) >> 32 || ai.x > AX_(st) + (uint64_t)max_dist || (T[0].root != RQ_NIL && T[0].sz[T[0].root] > (uint32_t)cap_rmq_size))) {
-			if (rq_find(T[0], E, ring ? (int32_t)s_ay[(uint32_t)st & E.mask] : (int32_t)an[st].y, st) != RQ_NIL) rq_erase(T[0], E, st);
+			if (st < i0) rq_erase(T[0], E, st);                          // krmq_find, then krmq_erase (lchain.c:688-690): anchor st is in the tree iff it was inserted - st < i0 -, since nothing else erases
 			++st;
 		}
 		if (max_dist_inner > 0) {
 			while (st_inner < i && (ai.x >> 32 != AX_(st_inner) >> 32 || ai.x > AX_(st_inner) + (uint64_t)max_dist_inner || (T[1].root != RQ_NIL && T[1].sz[T[1].root] > (uint32_t)cap_rmq_size))) {
-				if (rq_find(T[1], E, ring ? (int32_t)s_ay[(uint32_t)st_inner & E.mask] : (int32_t)an[st_inner].y, st_inner) != RQ_NIL) rq_erase(T[1], E, st_inner);
+				if (st_inner < i0) rq_erase(T[1], E, st_inner);
 				++st_inner;
 			}
 		}
