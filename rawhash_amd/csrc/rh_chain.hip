@@ -377,7 +377,10 @@ RH_DEV int rq_cmp_key(int32_t ya, int64_t ia, const rq_env &E, int32_t b)	// lc_
 	const int32_t yb = E.ay ? (int32_t)E.ay[(uint32_t)b & E.mask] : (int32_t)E.an[b].y;
 	return ya < yb ? -1 : ya > yb ? 1 : (ia > (int64_t)b) - (ia < (int64_t)b);
 }
-RH_DEV int32_t &rq_child(rq_tree &T, int32_t &fake_l, int32_t p, int which) { return p == RQ_FAKE ? fake_l : (which ? T.r[p] : T.l[p]); }
+// (no references that may be to the fake root's local OR to a ring: such a pointer is generic, and every access through it a flat instruction)
+RH_DEV int32_t &rq_kid(const rq_tree &T, int32_t p, int which) { return which ? T.r[p] : T.l[p]; }
+RH_DEV int32_t rq_child_get(const rq_tree &T, int32_t fake_l, int32_t p, int which) { return p == RQ_FAKE ? fake_l : rq_kid(T, p, which); }
+RH_DEV void rq_child_set(const rq_tree &T, int32_t &fake_l, int32_t p, int which, int32_t v) { if (p == RQ_FAKE) fake_l = v; else rq_kid(T, p, which) = v; }
 RH_DEV uint32_t rq_csize(const rq_tree &T, int32_t p, int which) { const int32_t c = which ? T.r[p] : T.l[p]; return c == RQ_NIL ? 0u : T.sz[c]; }
 RH_DEV void rq_update_min(rq_tree &T, const rq_env &E, int32_t p, int32_t q, int32_t r)	// krmq.h:154-157
 {
@@ -388,31 +391,29 @@ RH_DEV void rq_update_min(rq_tree &T, const rq_env &E, int32_t p, int32_t q, int
 RH_DEV int32_t rq_rotate1(rq_tree &T, const rq_env &E, int32_t p, int dir)	// (a,(b,c)q)p => ((a,b)p,c)q   krmq.h:159-170
 {
 	const int opp = 1 - dir;
-	int32_t fk = RQ_NIL;
-	const int32_t q = rq_child(T, fk, p, opp), s = T.s[p];
+	const int32_t q = rq_kid(T, p, opp), s = T.s[p];
 	const uint32_t size_p = T.sz[p];
 	T.sz[p] -= T.sz[q] - rq_csize(T, q, dir);
 	T.sz[q] = size_p;
-	rq_update_min(T, E, p, rq_child(T, fk, p, dir), rq_child(T, fk, q, dir));
+	rq_update_min(T, E, p, rq_kid(T, p, dir), rq_kid(T, q, dir));
 	T.s[q] = s;
-	rq_child(T, fk, p, opp) = rq_child(T, fk, q, dir);
-	rq_child(T, fk, q, dir) = p;
+	rq_kid(T, p, opp) = rq_kid(T, q, dir);
+	rq_kid(T, q, dir) = p;
 	return q;
 }
 RH_DEV int32_t rq_rotate2(rq_tree &T, const rq_env &E, int32_t p, int dir)	// (a,((b,c)r,d)q)p => ((a,b)p,(c,d)q)r   krmq.h:172-192
 {
 	const int opp = 1 - dir;
-	int32_t fk = RQ_NIL;
-	const int32_t q = rq_child(T, fk, p, opp), r = rq_child(T, fk, q, dir), s = T.s[p];
+	const int32_t q = rq_kid(T, p, opp), r = rq_kid(T, q, dir), s = T.s[p];
 	const uint32_t size_x_dir = rq_csize(T, r, dir);
 	T.sz[r] = T.sz[p];
 	T.sz[p] -= T.sz[q] - size_x_dir;
 	T.sz[q] -= size_x_dir + 1u;
-	rq_update_min(T, E, p, rq_child(T, fk, p, dir), rq_child(T, fk, r, dir));
-	rq_update_min(T, E, q, rq_child(T, fk, q, opp), rq_child(T, fk, r, opp));
+	rq_update_min(T, E, p, rq_kid(T, p, dir), rq_kid(T, r, dir));
+	rq_update_min(T, E, q, rq_kid(T, q, opp), rq_kid(T, r, opp));
 	T.s[r] = s;
-	rq_child(T, fk, p, opp) = rq_child(T, fk, r, dir); rq_child(T, fk, r, dir) = p;
-	rq_child(T, fk, q, dir) = rq_child(T, fk, r, opp); rq_child(T, fk, r, opp) = q;
+	rq_kid(T, p, opp) = rq_kid(T, r, dir); rq_kid(T, r, dir) = p;
+	rq_kid(T, q, dir) = rq_kid(T, r, opp); rq_kid(T, r, opp) = q;
 	const int b1 = dir == 0 ? +1 : -1;
 	if (T.bal[r] == b1) { T.bal[q] = 0; T.bal[p] = (int8_t)-b1; }
 	else if (T.bal[r] == 0) { T.bal[q] = 0; T.bal[p] = 0; }
@@ -424,30 +425,29 @@ RH_DEV void rq_insert(rq_tree &T, const rq_env &E, int32_t x)	// krmq.h:194-242 
 {
 	uint8_t *stack = reinterpret_cast<uint8_t*>(E.pb0);
 	int32_t *path = E.pp0;
-	int32_t fk = RQ_NIL;
 	const int32_t yx = E.ay ? (int32_t)E.ay[(uint32_t)x & E.mask] : (int32_t)E.an[x].y;
 	int32_t bp = T.root, bq = RQ_NIL, p, q;
 	int which = 0, top = 0, path_len = 0;
-	for (p = bp, q = bq; p != RQ_NIL; q = p, p = rq_child(T, fk, p, which)) {
+	for (p = bp, q = bq; p != RQ_NIL; q = p, p = rq_kid(T, p, which)) {
 		const int c = rq_cmp_key(yx, x, E, p);
 		if (T.bal[p] != 0) { bq = q; bp = p; top = 0; }
 		stack[top++] = (uint8_t)(which = (c > 0));
 		path[path_len++] = p;
 	}
 	T.bal[x] = 0; T.sz[x] = 1; T.l[x] = RQ_NIL; T.r[x] = RQ_NIL; T.s[x] = x;
-	if (q == RQ_NIL) T.root = x; else rq_child(T, fk, q, which) = x;
+	if (q == RQ_NIL) T.root = x; else rq_kid(T, q, which) = x;
 	if (bp == RQ_NIL) return;
 	for (int i = 0; i < path_len; ++i) ++T.sz[path[i]];
 	for (int i = path_len - 1; i >= 0; --i) { rq_update_min(T, E, path[i], T.l[path[i]], T.r[path[i]]); if (T.s[path[i]] != x) break; }
-	for (p = bp, top = 0; p != x; p = rq_child(T, fk, p, stack[top]), ++top) { if (stack[top] == 0) --T.bal[p]; else ++T.bal[p]; }
+	for (p = bp, top = 0; p != x; p = rq_kid(T, p, stack[top]), ++top) { if (stack[top] == 0) --T.bal[p]; else ++T.bal[p]; }
 	if (T.bal[bp] > -2 && T.bal[bp] < 2) return;
 	which = T.bal[bp] < 0;
 	const int b1 = which == 0 ? +1 : -1;
-	q = rq_child(T, fk, bp, 1 - which);
+	q = rq_kid(T, bp, 1 - which);
 	int32_t r;
 	if (T.bal[q] == b1) { r = rq_rotate1(T, E, bp, which); T.bal[q] = 0; T.bal[bp] = 0; }
 	else r = rq_rotate2(T, E, bp, which);
-	if (bq == RQ_NIL) T.root = r; else rq_child(T, fk, bq, bp != T.l[bq]) = r;
+	if (bq == RQ_NIL) T.root = r; else rq_kid(T, bq, bp != T.l[bq]) = r;
 }
 RH_DEV int32_t rq_find(const rq_tree &T, const rq_env &E, int32_t y, int64_t i)	// krmq.h:81-96
 {
@@ -466,16 +466,16 @@ RH_DEV void rq_erase(rq_tree &T, const rq_env &E, int32_t x)	// krmq.h:244-327, 
 	for (c = -1, p = RQ_FAKE; c; c = rq_cmp_key(yx, x, E, p)) {
 		const int which = c > 0;
 		dir[d] = (uint8_t)which; path[d++] = p;
-		p = rq_child(T, fake_l, p, which);
+		p = rq_child_get(T, fake_l, p, which);
 		if (p == RQ_NIL) return;
 	}
 	for (int i = 1; i < d; ++i) --T.sz[path[i]];
-	if (T.r[p] == RQ_NIL) rq_child(T, fake_l, path[d - 1], dir[d - 1]) = T.l[p];
+	if (T.r[p] == RQ_NIL) rq_child_set(T, fake_l, path[d - 1], dir[d - 1], T.l[p]);
 	else {
 		int32_t q = T.r[p];
 		if (T.l[q] == RQ_NIL) {
 			T.l[q] = T.l[p]; T.bal[q] = T.bal[p];
-			rq_child(T, fake_l, path[d - 1], dir[d - 1]) = q;
+			rq_child_set(T, fake_l, path[d - 1], dir[d - 1], q);
 			path[d] = q; dir[d++] = 1;
 			T.sz[q] = T.sz[p] - 1u;
 		} else {
@@ -484,7 +484,7 @@ RH_DEV void rq_erase(rq_tree &T, const rq_env &E, int32_t x)	// krmq.h:244-327, 
 			for (;;) { dir[d] = 0; path[d++] = q; r = T.l[q]; if (T.l[r] == RQ_NIL) break; q = r; }
 			T.l[r] = T.l[p]; T.l[q] = T.r[r]; T.r[r] = T.r[p];
 			T.bal[r] = T.bal[p];
-			rq_child(T, fake_l, path[e - 1], dir[e - 1]) = r;
+			rq_child_set(T, fake_l, path[e - 1], dir[e - 1], r);
 			path[e] = r; dir[e] = 1;
 			for (int i = e + 1; i < d; ++i) --T.sz[path[i]];
 			T.sz[r] = T.sz[p] - 1u;
@@ -499,11 +499,10 @@ RH_DEV void rq_erase(rq_tree &T, const rq_env &E, int32_t x)	// krmq.h:244-327, 
 		T.bal[q] = (int8_t)(T.bal[q] + b1);
 		if (T.bal[q] == b1) break;
 		else if (T.bal[q] == b2) {
-			int32_t fk = RQ_NIL;
-			const int32_t r = rq_child(T, fk, q, other);
-			if (T.bal[r] == -b1) rq_child(T, fake_l, path[d - 1], dir[d - 1]) = rq_rotate2(T, E, q, which);
+			const int32_t r = rq_kid(T, q, other);
+			if (T.bal[r] == -b1) rq_child_set(T, fake_l, path[d - 1], dir[d - 1], rq_rotate2(T, E, q, which));
 			else {
-				rq_child(T, fake_l, path[d - 1], dir[d - 1]) = rq_rotate1(T, E, q, which);
+				rq_child_set(T, fake_l, path[d - 1], dir[d - 1], rq_rotate1(T, E, q, which));
 				if (T.bal[r] == 0) { T.bal[r] = (int8_t)-b1; T.bal[q] = (int8_t)b1; break; }
 				else { T.bal[r] = 0; T.bal[q] = 0; }
 			}
