@@ -364,17 +364,17 @@ struct rq_tree {
 #define RQ_FAKE (-2)                                                // the stand-in parent of the root during a deletion (krmq.h:247)
 #define RQ_DEPTH 64
 
-struct rq_env { const rh_mm128_t *an; const int32_t *fp; float pen_gap; double *pri; uint64_t *ay; uint32_t mask; int32_t *pp0, *pp1; int8_t *pb0, *pb1; };   // pp / pb: the search paths of an operation (RQ_DEPTH entries each, in LDS: as local arrays they cost the kernel 357 VGPRs - one wavefront per SIMD - and scratch memory on every step)   // pri / ay: LDS rings of the live nodes' priorities and y words (null: computed from an / fp)
+struct rq_env { const rh_mm128_t *an; const int32_t *fp; float pen_gap; bool ring; double *pri; uint64_t *ay; uint32_t mask; int32_t *pp0, *pp1; int8_t *pb0, *pb1; };   // pp / pb: the search paths of an operation (RQ_DEPTH entries each, in LDS: as local arrays they cost the kernel 357 VGPRs - one wavefront per SIMD - and scratch memory on every step)   // pri / ay: LDS rings of the live nodes' priorities and y words (ring; else computed from an / fp - the pointers are to LDS either way, never null: a pointer that may be null is generic and read with flat instructions)
 RH_DEV double rq_pri_val(float pen_gap, int32_t f, uint64_t x, uint64_t y)
 {
 	const double g = 0.5 * (double)pen_gap;                       // (0.5 * chn_pen_gap) * (x + y): the reference's association (lchain.c:672)
 	return -((double)f + g * (double)((int32_t)x + (int32_t)y));
 }
 RH_DEV double rq_pri_of(const rq_env &E, int32_t j) { return rq_pri_val(E.pen_gap, E.fp[2 * j], E.an[j].x, E.an[j].y); }
-RH_DEV double rq_pri(const rq_env &E, int32_t j) { return E.pri ? E.pri[(uint32_t)j & E.mask] : rq_pri_of(E, j); }
+RH_DEV double rq_pri(const rq_env &E, int32_t j) { return E.ring ? E.pri[(uint32_t)j & E.mask] : rq_pri_of(E, j); }
 RH_DEV int rq_cmp_key(int32_t ya, int64_t ia, const rq_env &E, int32_t b)	// lc_elem_cmp (lchain.c:539) of key (ya, ia) against node b
 {
-	const int32_t yb = E.ay ? (int32_t)E.ay[(uint32_t)b & E.mask] : (int32_t)E.an[b].y;
+	const int32_t yb = E.ring ? (int32_t)E.ay[(uint32_t)b & E.mask] : (int32_t)E.an[b].y;
 	return ya < yb ? -1 : ya > yb ? 1 : (ia > (int64_t)b) - (ia < (int64_t)b);
 }
 // (no references that may be to the fake root's local OR to a ring: such a pointer is generic, and every access through it a flat instruction)
@@ -425,7 +425,7 @@ RH_DEV void rq_insert(rq_tree &T, const rq_env &E, int32_t x)	// krmq.h:194-242 
 {
 	uint8_t *stack = reinterpret_cast<uint8_t*>(E.pb0);
 	int32_t *path = E.pp0;
-	const int32_t yx = E.ay ? (int32_t)E.ay[(uint32_t)x & E.mask] : (int32_t)E.an[x].y;
+	const int32_t yx = E.ring ? (int32_t)E.ay[(uint32_t)x & E.mask] : (int32_t)E.an[x].y;
 	int32_t bp = T.root, bq = RQ_NIL, p, q;
 	int which = 0, top = 0, path_len = 0;
 	for (p = bp, q = bq; p != RQ_NIL; q = p, p = rq_kid(T, p, which)) {
@@ -460,7 +460,7 @@ RH_DEV void rq_erase(rq_tree &T, const rq_env &E, int32_t x)	// krmq.h:244-327, 
 	int32_t *path = E.pp0;
 	uint8_t *dir = reinterpret_cast<uint8_t*>(E.pb0);
 	int32_t fake_l = T.root;                                      // fake.p[0] = root, fake.p[1] = 0
-	const int32_t yx = E.ay ? (int32_t)E.ay[(uint32_t)x & E.mask] : (int32_t)E.an[x].y;
+	const int32_t yx = E.ring ? (int32_t)E.ay[(uint32_t)x & E.mask] : (int32_t)E.an[x].y;
 	int d = 0, c;
 	int32_t p;
 	for (c = -1, p = RQ_FAKE; c; c = rq_cmp_key(yx, x, E, p)) {
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 	for (int32_t i = n; i < n_lay; ++i) { fp[2 * i] = INT32_MIN / 2; fp[2 * i + 1] = -1; v[i] = INT32_MIN / 2; }
 	#define F_(i) fp[2 * (i)]
 	#define P_(i) fp[2 * (i) + 1]
-	const rq_env E = { an, fp, o.pen_gap, ring ? s_pri : nullptr, ring ? s_ay : nullptr, (uint32_t)RING - 1u, s_pp[0], s_pp[1], s_pb[0], s_pb[1] };
+	const rq_env E = { an, fp, o.pen_gap, ring, s_pri, s_ay, (uint32_t)RING - 1u, s_pp[0], s_pp[1], s_pb[0], s_pb[1] };
 	const int32_t bw = o.bw;
 	int32_t max_dist = max_dist_in, max_dist_inner = max_dist_inner_in;
 	if (max_dist < bw) max_dist = bw;
