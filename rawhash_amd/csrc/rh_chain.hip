@@ -384,8 +384,13 @@ RH_DEV void rq_child_set(const rq_tree &T, int32_t &fake_l, int32_t p, int which
 RH_DEV uint32_t rq_csize(const rq_tree &T, int32_t p, int which) { const int32_t c = which ? T.r[p] : T.l[p]; return c == RQ_NIL ? 0u : T.sz[c]; }
 RH_DEV void rq_update_min(rq_tree &T, const rq_env &E, int32_t p, int32_t q, int32_t r)	// krmq.h:154-157
 {
-	int32_t s = (q == RQ_NIL || rq_pri(E, p) < rq_pri(E, T.s[q])) ? p : T.s[q];
-	s = (r == RQ_NIL || rq_pri(E, s) < rq_pri(E, T.s[r])) ? s : T.s[r];
+	// (the walk is one lane waiting for its own loads: everything a step may need is loaded at once - an absent child reads p's own entry instead -, then chosen)
+	const int32_t sq = T.s[q == RQ_NIL ? p : q], sr = T.s[r == RQ_NIL ? p : r];
+	const double pp = rq_pri(E, p), pq = rq_pri(E, q == RQ_NIL ? p : sq), pr = rq_pri(E, r == RQ_NIL ? p : sr);
+	const bool keep = q == RQ_NIL || pp < pq;
+	int32_t s = keep ? p : sq;
+	const double ps = keep ? pp : pq;
+	s = (r == RQ_NIL || ps < pr) ? s : sr;
 	T.s[p] = s;
 }
 RH_DEV int32_t rq_rotate1(rq_tree &T, const rq_env &E, int32_t p, int dir)	// (a,(b,c)q)p => ((a,b)p,c)q   krmq.h:159-170
@@ -428,11 +433,14 @@ RH_DEV void rq_insert(rq_tree &T, const rq_env &E, int32_t x)	// krmq.h:194-242 
 	const int32_t yx = E.ring ? (int32_t)E.ay[(uint32_t)x & E.mask] : (int32_t)E.an[x].y;
 	int32_t bp = T.root, bq = RQ_NIL, p, q;
 	int which = 0, top = 0, path_len = 0;
-	for (p = bp, q = bq; p != RQ_NIL; q = p, p = rq_kid(T, p, which)) {
+	for (p = bp, q = bq; p != RQ_NIL;) {
+		const int32_t pl = T.l[p], pr = T.r[p];                      // (both children with the key: one wait per level, not two)
+		const int8_t pbal = T.bal[p];
 		const int c = rq_cmp_key(yx, x, E, p);
-		if (T.bal[p] != 0) { bq = q; bp = p; top = 0; }
+		if (pbal != 0) { bq = q; bp = p; top = 0; }
 		stack[top++] = (uint8_t)(which = (c > 0));
 		path[path_len++] = p;
+		q = p; p = which ? pr : pl;
 	}
 	T.bal[x] = 0; T.sz[x] = 1; T.l[x] = RQ_NIL; T.r[x] = RQ_NIL; T.s[x] = x;
 	if (q == RQ_NIL) T.root = x; else rq_kid(T, q, which) = x;
@@ -463,11 +471,14 @@ RH_DEV void rq_erase(rq_tree &T, const rq_env &E, int32_t x)	// krmq.h:244-327, 
 	const int32_t yx = E.ring ? (int32_t)E.ay[(uint32_t)x & E.mask] : (int32_t)E.an[x].y;
 	int d = 0, c;
 	int32_t p;
-	for (c = -1, p = RQ_FAKE; c; c = rq_cmp_key(yx, x, E, p)) {
+	int32_t nl = fake_l, nr = RQ_NIL;                               // the children of the node the search stands on (the fake root's: root, nil)
+	for (c = -1, p = RQ_FAKE; c;) {
 		const int which = c > 0;
 		dir[d] = (uint8_t)which; path[d++] = p;
-		p = rq_child_get(T, fake_l, p, which);
+		p = which ? nr : nl;
 		if (p == RQ_NIL) return;
+		nl = T.l[p]; nr = T.r[p];
+		c = rq_cmp_key(yx, x, E, p);
 	}
 	for (int i = 1; i < d; ++i) --T.sz[path[i]];
 	if (T.r[p] == RQ_NIL) rq_child_set(T, fake_l, path[d - 1], dir[d - 1], T.l[p]);
@@ -517,9 +528,9 @@ RH_DEV int32_t rq_rmq(const rq_tree &T, const rq_env &E, int32_t ylo, int64_t il
 	int plen[2] = {0, 0}, i, c;
 	if (T.root == RQ_NIL) return RQ_NIL;
 	int32_t p = T.root;
-	while (p != RQ_NIL) { c = rq_cmp_key(ylo, ilo, E, p); path[0][plen[0]] = p; pcmp[0][plen[0]++] = (int8_t)c; if (c < 0) p = T.l[p]; else if (c > 0) p = T.r[p]; else break; }
+	while (p != RQ_NIL) { const int32_t pl = T.l[p], pr = T.r[p]; c = rq_cmp_key(ylo, ilo, E, p); path[0][plen[0]] = p; pcmp[0][plen[0]++] = (int8_t)c; if (c < 0) p = pl; else if (c > 0) p = pr; else break; }
 	p = T.root;
-	while (p != RQ_NIL) { c = rq_cmp_key(yup, iup, E, p); path[1][plen[1]] = p; pcmp[1][plen[1]++] = (int8_t)c; if (c < 0) p = T.l[p]; else if (c > 0) p = T.r[p]; else break; }
+	while (p != RQ_NIL) { const int32_t pl = T.l[p], pr = T.r[p]; c = rq_cmp_key(yup, iup, E, p); path[1][plen[1]] = p; pcmp[1][plen[1]++] = (int8_t)c; if (c < 0) p = pl; else if (c > 0) p = pr; else break; }
 	for (i = 0; i < plen[0] && i < plen[1]; ++i) if (path[0][i] == path[1][i] && pcmp[0][i] <= 0 && pcmp[1][i] >= 0) break;
 	if (i == plen[0] || i == plen[1]) return RQ_NIL;
 	const int lca = i;
