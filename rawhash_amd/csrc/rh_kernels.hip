@@ -979,8 +979,8 @@ __global__ __launch_bounds__(NT) void k_expand(rh_dev_opt o, rh_dev_index ix, rh
 	const uint32_t nm = rr.n_match[a], nn = rr.n_new[a];
 	const uint64_t *m_val = rr.m_val + (size_t)a * rr.ev_cap;
 	const uint32_t *m_n = rr.m_n + (size_t)a * rr.ev_cap, *m_meta = rr.m_meta + (size_t)a * rr.ev_cap, *m_pref = rr.m_pref + (size_t)a * (rr.ev_cap + 1);
-	const uint32_t *pf = nm <= RH_EV_CAP ? s_pref : m_pref;        // (a whole read's matches may not fit LDS: searched where they lie)
-	if (nm <= RH_EV_CAP) for (uint32_t i = tid; i <= nm; i += NT) s_pref[i] = m_pref[i];
+	const bool in_lds = nm <= RH_EV_CAP;                            // (a whole read's matches may not fit LDS: searched where they lie - by two loops, not through one pointer that may be either: that one is generic, its loads flat)
+	if (in_lds) for (uint32_t i = tid; i <= nm; i += NT) s_pref[i] = m_pref[i];
 	__syncthreads();
 	const uint32_t q_off = rd.ev_off[r];
 	const uint64_t span = (uint64_t)(ix.sp.k + ix.sp.e - 1);
@@ -992,8 +992,10 @@ __global__ __launch_bounds__(NT) void k_expand(rh_dev_opt o, rh_dev_index ix, rh
 	uint64_t *anc8 = reinterpret_cast<uint64_t*>(rr.raw) + base;
 	for (uint32_t j = tid; j < nn; j += NT) {
 		uint32_t lo = 0, hi = nm;   // largest s with s_pref[s] <= j
-		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pf[mid] <= j) lo = mid; else hi = mid; }
-		const uint32_t s = lo, k = j - pf[s];
+		uint32_t vlo = 0;                                              // = pref[lo] (an exclusive prefix: pref[0] = 0)
+		if (in_lds) while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1, pv = s_pref[mid]; if (pv <= j) { lo = mid; vlo = pv; } else hi = mid; }
+		else while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1, pv = m_pref[mid]; if (pv <= j) { lo = mid; vlo = pv; } else hi = mid; }
+		const uint32_t s = lo, k = j - vlo;
 		const uint64_t hit = m_n[s] == 1 ? m_val[s] : ix.pos[m_val[s] + k];
 		const uint32_t meta = m_meta[s];
 		rh_mm128_t p;
