@@ -386,7 +386,7 @@ def bench_big_set(args, ctx, wl, opts, index, model, workdir, preset, wl_name, n
             with open(paf) as f:
                 want = [O.strip_mt(x) for x in f]
             bt, bs = min(runs, key=lambda r: r[1])
-            out["cpu_baseline"] = {"value": round(len(sample) / bs, 1), "unit": "reads/s", "cores": cores, "threads": bt, "kind": "reference",
+            out["cpu_baseline"] = {"value": round(len(sample) / bs, 1), "unit": "reads/s", "cores": bt, "threads": bt, "host_threads": cores, "kind": "reference",
                                    "sample": f"{n_blocks} blocks of {blk} reads spread over the {N} (first reads {starts[0]}, {starts[1]}, ... {starts[-1]}), map phase {bs:.2f} s, unmodified RawHash2 sources (oracle/Makefile)",
                                    "thread_sweep_reads_per_s": {str(t): round(len(sample) / sec, 1) for t, sec in runs}, "paf_sha1": hashlib.sha1("\n".join(want).encode()).hexdigest()}
             out["paf_sample_identical"] = got == want
@@ -535,7 +535,7 @@ def bench_ava(args):
                 want = [O.strip_mt(x) for x in f]
             got = [strip_mt(x) for x in paf_lines(index, recs[: int(off[sample])], reads.names)]
             best_t, best_s = min(runs, key=lambda r: r[1])
-            out["cpu_baseline"] = {"value": round(sample / best_s, 1), "unit": "reads/s", "cores": cores, "threads": best_t, "kind": "reference",
+            out["cpu_baseline"] = {"value": round(sample / best_s, 1), "unit": "reads/s", "cores": best_t, "threads": best_t, "host_threads": cores, "kind": "reference",
                                    "sample": f"first {sample} reads overlapped against the index of all {n}, map phase {best_s:.2f} s, unmodified RawHash2 sources (oracle/Makefile)",
                                    "thread_sweep_reads_per_s": {str(t): round(sample / sec, 1) for t, sec in runs},
                                    "reference_index_build_s": round(t_ref_index, 2)}
@@ -664,7 +664,7 @@ def cpu_baseline(ctx, index, opts, wl, model, workdir, preset, recs, args, cores
                 numa_nodes = len([d for d in os.listdir("/sys/devices/system/node") if re.fullmatch(r"node\d+", d)])
             except OSError:
                 numa_nodes = None
-            base = {"value": round(n / best_s, 1), "unit": "reads/s", "cores": cores, "threads": best_t, "kind": "reference", "memory_policy": best_nm,
+            base = {"value": round(n / best_s, 1), "unit": "reads/s", "cores": best_t, "threads": best_t, "host_threads": cores, "kind": "reference", "memory_policy": best_nm,
                     "sample": f"first {n} reads of the same synthetic set, map phase {best_s:.2f} s (file loading excluded), unmodified RawHash2 sources built by "
                               f"oracle/Makefile (-O3 -ffp-contract=off), kt_for over 500 M-sample mini-batches",
                     "thread_sweep_reads_per_s": {nm: {str(t): round(n / sec, 1) for t, sec in rr} for nm, rr in runs.items()},
