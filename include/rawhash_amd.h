@@ -271,6 +271,11 @@ RH_API int  rh_sort128x_batch(rh_ctx *ctx, uint32_t n_seg, rh_mm128_t *a, const 
    it: segments beyond the LDS classes are placed level by level in any order (a sorted order without equal keys is unique), then
    checked; has_ties[s] = 1 for the long segments that do hold equal keys and have to be redone with rh_sort128x_batch's exact passes */
 RH_API int  rh_sort128x_any_batch(rh_ctx *ctx, uint32_t n_seg, rh_mm128_t *a, const uint64_t *offsets, uint8_t *has_ties);
+/* rh_sort128x_batch with the records travelling as ONE 8-byte word each, the way the mapping path moves anchors whose fields fit: keys
+   x = strand << 63 | target << 32 | position with position < 2^lo_bits and target < 2^mid_bits, payloads y < 2^(63 - lo_bits - mid_bits); the result is
+   the same radix_sort_128x permutation (ksort.h:101-151).  any_order != 0: as the round loop runs it - long segments level by level in any order first, the
+   segments that hold equal keys again with the exact passes */
+RH_API int  rh_sort128x_packed_batch(rh_ctx *ctx, uint32_t n_seg, rh_mm128_t *a, const uint64_t *offsets, uint32_t lo_bits, uint32_t mid_bits, int any_order);
 
 /* ------------------------------------------------------------------------------------------- PAF (host) */
 /* One PAF line per record exactly as rmap.cpp:740-783 prints it; `mt_ms` fills the mt:f: tag (wall clock in the

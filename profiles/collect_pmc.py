@@ -21,13 +21,13 @@ SAMPLES, JUNK = 40000, 102
 # every kernel of the mapping path belongs to a stage of bench.py's table (prefix match on the kernel name)
 STAGE_OF = [("k_prefilter", "prefilter"), ("k_events_norm", "events_norm"), ("k_events_tstat", "events_norm"), ("k_events_peaks", "events_peaks"), ("k_events_means", "events_means"),
             ("k_sketch", "sketch"), ("k_probe", "probe"), ("k_scan_anchors", "scan"), ("k_rebase_offsets", "scan"), ("k_expand", "expand"), ("k_chain_wave", "chain"), ("k_chain_serial", "chain"), ("k_chain_rmq", "chain"), ("k_events_append", "events_means"), ("k_regions_dtw", "regions"), ("k_dtw_", "regions"),
-            ("k_zbuild", "zsort"), ("k_backtrack_spec", "backtrack"), ("k_chain_gather", "backtrack"), ("k_chain_reorder", "backtrack"), ("k_chain_keys", "backtrack"), ("k_need", "prefilter"), ("k_fetch", "prefilter"),
+            ("k_zbuild", "zsort"), ("k_backtrack_spec", "backtrack"), ("k_chain_reorder", "backtrack"), ("k_chain_keys", "backtrack"), ("k_need", "prefilter"), ("k_fetch", "prefilter"),
             ("k_regions_prep", "rsort"), ("k_regions", "regions"), ("k_carry_", "compact"), ("k_compact_active", "compact"), ("k_finalize", "finalize")]
 NOT_PATH = ("k_synth_reads", "k_ix_", "__amd_rocclr")           # bench set-up (read generator, index construction, runtime copies)
 
 # the segment sorters (k_sort_block, k_bs_*) serve four stages; which one a dispatch belongs to follows from the kernel that
 # precedes the group of sort launches (single-stream run, so dispatch order = program order)
-SORT_OWNER = {"k_expand": "sort", "k_zbuild": "zsort", "k_chain_gather": "backtrack", "k_regions_prep": "rsort"}
+SORT_OWNER = {"k_expand": "sort", "k_zbuild": "zsort", "k_backtrack_spec": "backtrack", "k_regions_prep": "rsort"}
 
 
 def stage_of(k):
@@ -50,8 +50,9 @@ def one_pass(counter, out):
     acc, owner = {}, "sort"
     for r in rows:
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if k in SORT_OWNER:
-            owner = SORT_OWNER[k]
+        for name_, ow_ in SORT_OWNER.items():
+            if k == name_ or k.startswith(name_ + "<"):
+                owner = ow_
         key = k + "@" + owner if k.startswith(("k_sort", "k_bs_")) else k
         e = acc.setdefault(key, [0, 0.0])
         e[0] += 1

@@ -31,8 +31,9 @@ def main():
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if k.startswith(NOT_PATH):
             continue
-        if k in SORT_OWNER:
-            owner = SORT_OWNER[k]
+        for name_, ow_ in SORT_OWNER.items():
+            if k == name_ or k.startswith(name_ + "<"):
+                owner = ow_
         key = k + "@" + owner if k.startswith(("k_sort", "k_bs_")) else k + "@" + (stage_of(k) or "?")
         e = acc.setdefault(key, [0, 0.0])
         e[0] += 1

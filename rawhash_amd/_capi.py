@@ -163,7 +163,7 @@ def _declare(lib):
         "rh_seed_batch": (i32, [vp, P(MapOpt), u32, vp, vp, vp, vp, vp, vp, u64, vp, vp]),
         "rh_chain_batch": (i32, [vp, P(MapOpt), u32, vp, vp, vp, u64, vp, vp, u64, vp, vp]),
         "rh_regions_batch": (i32, [vp, P(MapOpt), u32, vp, vp, vp, vp, vp, vp, u64, vp]),
-        "rh_sort128x_batch": (i32, [vp, u32, vp, vp]), "rh_sort128x_any_batch": (i32, [vp, u32, vp, vp, vp]),
+        "rh_sort128x_batch": (i32, [vp, u32, vp, vp]), "rh_sort128x_any_batch": (i32, [vp, u32, vp, vp, vp]), "rh_sort128x_packed_batch": (i32, [vp, u32, vp, vp, u32, u32, i32]),
         "rh_paf_format": (i32, [vp, P(MapRecord), cp, C.c_double, cp, C.c_size_t]),
         "rh_reads_load": (vp, [cp]), "rh_reads_destroy": (None, [vp]), "rh_reads_n": (u32, [vp]),
         "rh_reads_name": (cp, [vp, u32]), "rh_reads_batch": (i32, [vp, P(ReadBatch)]), "rh_reads_pinned": (i32, [vp]),

@@ -415,6 +415,13 @@ class Context:
         _check(self._l.rh_sort128x_batch(self.h, len(off) - 1, ptr(a), ptr(off)), self._l)
         return a
 
+    def sort128x_packed(self, arr, offsets, lo_bits, mid_bits, any_order=False):
+        """rh_sort128x_batch on one-word records (the mapping path's anchor format)."""
+        a = np.ascontiguousarray(arr, dtype=MM128).copy()
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _check(self._l.rh_sort128x_packed_batch(self.h, len(off) - 1, ptr(a), ptr(off), lo_bits, mid_bits, 1 if any_order else 0), self._l)
+        return a
+
     def sort128x_any(self, arr, offsets):
         """The sorter's any-order path (region keys): returns (sorted copy, has_ties per segment)."""
         a = np.ascontiguousarray(arr, dtype=MM128).copy()

@@ -1257,7 +1257,7 @@ namespace {
 rh_ctx *borrow_ctx(rh_ctx *c)
 {
 	rh_ctx *b = new rh_ctx();
-	b->device = c->device; b->blob_owned = false; b->logf_tab.owned = false; b->n_sub = c->n_sub > 2 ? 2 : c->n_sub; b->flight_mult = RH_MAX_IN_FLIGHT;   // (two sub-batch streams per batch in flight: four streams together - measured, 12 500-read calls on the human index, upload-inclusive: 2 x 3 streams 21.2 k reads/s, 2 x 2 29.8 k)
+	b->device = c->device; b->blob_owned = false; b->logf_tab.owned = false; b->n_sub = (c->n_sub > 2 && !getenv("RH_SUB_BATCHES")) ? 2 : c->n_sub; b->flight_mult = RH_MAX_IN_FLIGHT;   // (two sub-batch streams per batch in flight: four streams together - measured, 12 500-read calls on the human index, upload-inclusive: 2 x 3 streams 21.2 k reads/s, 2 x 2 29.8 k)
 	if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&b->e0) != hipSuccess || hipEventCreate(&b->e1) != hipSuccess) {
 		rh_set_error("cannot create the stream of a batch slot"); rh_ctx_destroy(b); return nullptr;
 	}
@@ -1741,6 +1741,39 @@ extern "C" int rh_sort128x_batch(rh_ctx *c, uint32_t n_seg, rh_mm128_t *a, const
 	RH_HIP(hipStreamSynchronize(c->stream));
 	RH_HIP(hipGetLastError());
 	if (total) RH_HIP(hipMemcpy(a, rr.anc, total * 16, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+extern "C" int rh_sort128x_packed_batch(rh_ctx *c, uint32_t n_seg, rh_mm128_t *a, const uint64_t *offsets, uint32_t lo_bits, uint32_t mid_bits, int any_order)
+{
+	// the anchor sort of the round loop on one-word records (rh_rec_fmt): key' << shift | payload
+	RH_HIP(hipSetDevice(c->device));
+	const uint64_t total = n_seg ? offsets[n_seg] : 0;
+	const uint32_t kb = 1u + lo_bits + mid_bits;
+	if (lo_bits > 30u || mid_bits > 24u || kb > 56u) { rh_set_error("packed sort: %u + %u key bits do not leave a payload", lo_bits, mid_bits); return -1; }
+	const uint32_t shift = 64u - kb;
+	std::vector<uint64_t> w((size_t)(total ? total : 1));
+	for (uint64_t i = 0; i < total; ++i) {
+		if ((a[i].x & 0x7FFFFFFF00000000ull) >> 32 >> mid_bits || (a[i].x & 0xFFFFFFFFull) >> lo_bits || a[i].y >> shift) { rh_set_error("packed sort: record %llu does not fit %u / %u key bits and a %u-bit payload", (unsigned long long)i, lo_bits, mid_bits, shift); return -1; }
+		w[i] = rh_rec8_pack_key(a[i].x, lo_bits, mid_bits) << shift | a[i].y;
+	}
+	rh_dev_round rr{};
+	uint32_t mx = 0;
+	for (uint32_t s = 0; s < n_seg; ++s) if (offsets[s + 1] - offsets[s] > mx) mx = (uint32_t)(offsets[s + 1] - offsets[s]);
+	rr.max_anchors = mx;
+	if (stage_round(c, n_seg, &rr) || stage_anchors(c, total, &rr)) return -1;
+	rr.afmt = rh_rec_fmt{1, (uint8_t)shift, (uint8_t)lo_bits, (uint8_t)mid_bits, 0};
+	rr.akey_on = kb <= 32u ? 1 : 0; rr.akey_lo = (uint8_t)lo_bits; rr.akey_mid = (uint8_t)mid_bits;
+	std::vector<uint8_t> skip(n_seg ? n_seg : 1, 0);
+	uint64_t *d_raw = reinterpret_cast<uint64_t*>(rr.raw);
+	if (h2d(d_raw, w.data(), total) || h2d(rr.a_off, offsets, (size_t)n_seg + 1) || h2d(rr.skip, skip.data(), n_seg)) return -1;
+	std::function<int(const uint8_t*)> again;
+	if (any_order) again = [&](const uint8_t *) { return h2d(d_raw, w.data(), total); };
+	if (rhk_sort(c->stream, c->dix, rr, again)) return -1;
+	RH_HIP(hipStreamSynchronize(c->stream));
+	RH_HIP(hipGetLastError());
+	if (total) RH_HIP(hipMemcpy(w.data(), rr.anc, total * 8, hipMemcpyDeviceToHost));
+	for (uint64_t i = 0; i < total; ++i) { a[i].x = rh_rec8_key(w[i], shift, lo_bits, mid_bits); a[i].y = w[i] & ((1ull << shift) - 1ull); }
 	return 0;
 }
 

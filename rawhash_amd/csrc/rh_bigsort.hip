@@ -1355,6 +1355,7 @@ __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 	// records, hole lists and destinations meet in one L2
 	const uint32_t per_xcd = gridDim.x >> 3, tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
 	if (tile >= C.hdr[1]) return;
+	if (C.hdr[7]) return;                                         // a walk of this level gave up (the host reports it with the next header): dest[] is not to be trusted
 	const uint32_t r = bs_find_range(C, tile, n_rng, &s_r);
 	const bs_range R = C.rng[0][r];
 	if (!R.exact) return;
@@ -1386,6 +1387,7 @@ __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 		if (d == b) np = p + ((hb - s_hst[b]) < s_J[b] ? 1u : 0u);
 		else {
 			const uint32_t j = dest[hb], jj = j - s_hst[d];
+			if (j >= s_hst[256]) { C.hdr[7] = 2; continue; }           // not a hole of this range: a walk left dest[] unwritten -> "token walk made no progress", no access out of bounds
 			if (jj < s_J[d]) np = jj == 0 ? s_start[d] : hp[j - 1] + 1u;
 			else np = hp[j];
 		}
@@ -1685,6 +1687,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		if ((q & 1) && !job32) { sj.kc_on = 1; sj.kc_lo = 32; sj.kc_mid = 0; sj.kc_hi = 0; }   // keys that differ below bit 32 only: 32-bit words in LDS
 		sj.big_alt = nullptr; sj.big_ws = nullptr; sj.dead_cnt = nullptr; sj.rf.up = 0;       // (the block sorter takes its keys at their original positions)
 		sj.any_order = 0; sj.redo_skip = nullptr; sj.n_redo = nullptr; sj.cnt_rw = C.small_cnt[q];
+		sj.no_redo = C.redo_skip ? 1 : 0;                              // (an any-order job: the segments whose buckets hold equal keys are redone from their input, whatever order these buckets are left in)
 		if (C.redo_skip) RH_HIP(hipMemsetAsync(C.small_tie[q], 0, ns, s));
 		if (rhk_sort_job(s, sj, all_exact, 1u)) return -1;
 		if (C.redo_skip) RH_LAUNCH(k_bs_tie_map, (ns + NT - 1) / NT, NT, 0, s, C, q, ns);

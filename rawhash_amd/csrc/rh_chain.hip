@@ -654,7 +654,8 @@ __global__ __launch_bounds__(64) void k_chain_rmq(rh_dev_opt o, rh_dev_round rr,
 	else for (int32_t k = 0; k < NR; ++k) s_t[k] = -1;
 	#define AX_(j_) (ring ? s_ax[(uint32_t)(j_) & E.mask] : an[j_].x)
 	int32_t i0 = 0, st = 0, st_inner = 0;
-	rh_mm128_t nxt = an[0];
+	rh_mm128_t nxt{};
+	if (ring && n > 0) nxt = an[0];                                 // (an empty last read of a slice starts at the end of the anchor array)
 	for (int32_t i = 0; i < n; ++i) {
 		const rh_mm128_t ai = ring ? nxt : an[i];
 		if (ring) { if (i + 1 < n) nxt = an[i + 1]; s_ax[(uint32_t)i & E.mask] = ai.x; s_ay[(uint32_t)i & E.mask] = ai.y; }

@@ -242,6 +242,10 @@ struct rh_sort_job {
 	const uint32_t *dead_cnt;
 	// 8-byte records (see rh_rec_fmt): src / dst / big_alt then point to uint64_t arrays (same record offsets)
 	rh_rec_fmt rf;
+	// the caller redoes every segment reported in need_exact from its input (the buckets of an any-order job): the LDS sorter reports equal keys and leaves it at that
+	uint8_t no_redo;
+	// the LDS sorter's path for segments without equal keys (rh_sort.hip: sort_fast); rhk_sort_job sets it (development knob RH_SORT_FAST=0: off)
+	uint8_t fast_on;
 };
 // record access of the sorters, by record type
 template <class REC> struct rh_rec_ops;

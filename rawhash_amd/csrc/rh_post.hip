@@ -3,7 +3,7 @@
 //                     radix_sort_128x order by the block sorter of rh_sort.hip (scores are full of ties -> exact mode)
 //   k_backtrack_spec  mg_chain_backtrack (lchain.c:95-194, mg_chain_bk_end :47-75): one wavefront per read, 64 candidates
 //                     walked in parallel per round, conflicts re-walked
-//   k_chain_gather, k_chain_reorder (+ block sorter)   compact_a (lchain.c:214-281)
+//   k_chain_reorder (+ block sorter)   compact_a (lchain.c:214-281), its gather being the backtrack's
 //   k_regions_*       mm_gen_regs (hit.c:100-150), mm_set_parent (:195-263), mm_select_sub (:338-367), mm_set_mapq (:502-539),
 //                     the mapping decision of map_worker_for (rmap.cpp:423-500) and the bookkeeping of ri_map_frag (:386):
 //                     k_regions_reg keeps the primaries in registers; k_regions_wave (LDS), k_regions / k_regions_big
@@ -115,7 +115,6 @@ __global__ __launch_bounds__(BT) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 	const int32_t n_z = (int32_t)rr.n_z[a];
 	unsigned char *wsr = rr.ws + base * rr.ws_stride;
 	const int2 *fp = (const int2*)wsr;                              // .x = f, .y = p
-	int32_t *v = (int32_t*)wsr + 2 * (size_t)n;
 	// "used" marks, zeroed by k_zbuild: one BYTE per anchor, plain loads and stores through the L1.  Every candidate starts with a look at its own
 	// mark (a random access, most of them used already).  Measured alternatives (human-scale step, this kernel 228 ms): marks inside a 16-byte
 	// {f, p, claim, used} record 404 ms; one BIT per anchor set with L2 atomics and read at L2 576 ms - the L1 serves most of these looks.
@@ -124,6 +123,7 @@ __global__ __launch_bounds__(BT) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 	const rh_mm128_t *zs = rr.zs + base;
 	const uint64_t *zs8 = reinterpret_cast<const uint64_t*>(rr.zs) + base;
 	uint64_t *u = rr.u + base;
+	uint32_t *ck0 = (uint32_t*)(wsr + (size_t)32 * n);               // where each accepted chain starts among the read's chained anchors (compact_a, below)
 	const int32_t min_sc = o.min_sc, min_cnt = o.min_cnt, max_drop = o.bw;
 	int32_t n_u = 0, n_v = 0;
 	uint32_t epoch = 0;
@@ -203,14 +203,22 @@ __global__ __launch_bounds__(BT) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 		const uint32_t my_rank = block_rank(accepted, s_w, n_acc);
 		const uint32_t my_off = block_excl_scan(accepted ? (uint32_t)r_cnt : 0u, s_w, total);
 		if (accepted) {
-			u[n_u + (int32_t)my_rank] = (uint64_t)(uint32_t)r_sc << 32 | (uint64_t)(uint32_t)r_cnt;
-			const int32_t off = n_v + (int32_t)my_off;
-			v[off] = i0;
-			if (r_cnt >= 2) v[off + 1] = pn1;
-			if (r_cnt >= 3) v[off + 2] = pn2;
-			if (r_cnt >= 4) v[off + 3] = pn3;
-			int32_t x = pn3;
-			for (int32_t j = 4; j < r_cnt; ++j) { x = fp[x].y; v[off + j] = x; }
+			// The first half of compact_a (lchain.c:214-243) right here, from the registers that hold the chain (round 6; until then the walk left the members'
+			// indices in v[] and a second kernel, k_chain_gather, looked every chain up again): the chain's anchors, reversed into ascending order, go to
+			// the carry staging at the chain's offset among the read's chained anchors - what the next chunk carries, in backtrack order -, the offset to
+			// ck0[], and the key compact_a orders the chains by (first anchor's x, lchain.c:262-266) to the chain sorter's input.
+			const uint32_t ci = (uint32_t)n_u + my_rank, off = (uint32_t)n_v + my_off, last = off + (uint32_t)r_cnt - 1u;
+			u[ci] = (uint64_t)(uint32_t)r_sc << 32 | (uint64_t)(uint32_t)r_cnt;
+			ck0[ci] = off;
+			int32_t x = i0;
+			rh_an_cp(rr, rr.prev_out, base + last, rr.anc, base + (uint32_t)i0);
+			if (r_cnt >= 2) { rh_an_cp(rr, rr.prev_out, base + last - 1u, rr.anc, base + (uint32_t)pn1); x = pn1; }
+			if (r_cnt >= 3) { rh_an_cp(rr, rr.prev_out, base + last - 2u, rr.anc, base + (uint32_t)pn2); x = pn2; }
+			if (r_cnt >= 4) { rh_an_cp(rr, rr.prev_out, base + last - 3u, rr.anc, base + (uint32_t)pn3); x = pn3; }
+			for (int32_t j = 4; j < r_cnt; ++j) { x = fp[x].y; rh_an_cp(rr, rr.prev_out, base + last - (uint32_t)j, rr.anc, base + (uint32_t)x); }
+			const uint64_t x0 = rh_an_ld(rr, rr.anc, base + (uint32_t)x).x;      // the chain's first anchor
+			if (rr.cfmt.rec8) reinterpret_cast<uint64_t*>(rr.raw)[base + ci] = rh_rec8_pack_key(x0, rr.cfmt.lo, rr.cfmt.mid) << rr.cfmt.shift | (uint64_t)ci;
+			else { rh_mm128_t e; e.x = x0; e.y = (uint64_t)off << 32 | (uint64_t)ci; rr.raw[base + ci] = e; }
 		}
 		n_u += (int32_t)n_acc;
 		n_v += (int32_t)total;
@@ -221,9 +229,9 @@ __global__ __launch_bounds__(BT) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 	}
 }
 
-// compact_a (lchain.c:214-281) as two workgroup kernels around the block sorter:
-//   k_chain_gather : chain start offsets (scan of the counts), chain members reversed into ascending order -> pa (= what the
-//                    next chunk carries), sort keys (first-anchor x, start << 32 | chain) -> rr.raw
+// compact_a (lchain.c:214-281) around the block sorter:
+//   k_backtrack_spec (above): a committed chain's start offset, its members reversed into ascending order -> the carry staging (= what
+//                    the next chunk carries), its sort key (first-anchor x, start << 32 | chain) -> rr.raw
 //   [rhk_sort_job  : chains into the reference's order of their first anchor]
 //   k_chain_reorder: destination offsets (scan in sorted order), chains copied back over the anchor slice, u[] permuted
 #ifndef CG_CAP
@@ -241,63 +249,6 @@ RH_DEV void chain_keys(const rh_dev_round &rr, uint64_t base, uint32_t n_u, cons
 	}
 }
 #define CG_SHORT 8            // anchors a lane copies on its own when a read has more than CG_CAP chains
-__global__ __launch_bounds__(NT) void k_chain_gather(rh_dev_round rr)
-{
-	__shared__ uint32_t s_w[NT / 64];
-	__shared__ uint32_t s_off[CG_CAP];
-	const uint32_t a = blockIdx.x, tid = threadIdx.x;
-	if (a >= rr.n_act || rr.skip[a]) return;
-	const uint32_t n_u = rr.n_u[a], n_v = rr.n_v[a];
-	if (n_u == 0) return;
-	const uint64_t base = rr.a_off[a];
-	const uint32_t n = (uint32_t)(rr.a_off[a + 1] - base);
-	unsigned char *wsr = rr.ws + base * rr.ws_stride;
-	const int32_t *v = (const int32_t*)wsr + 2 * (size_t)n;
-	uint32_t *ck0 = (uint32_t*)(wsr + (size_t)32 * n);               // n_u <= n start offsets
-	const uint64_t *u = rr.u + base;
-	rh_mm128_t *w = rr.raw + base;
-	uint32_t run = 0;
-	for (uint32_t i0 = 0; i0 < n_u; i0 += NT) {
-		const uint32_t i = i0 + tid, cnt = i < n_u ? (uint32_t)u[i] : 0u;
-		uint32_t tot;
-		const uint32_t ex = block_excl_scan(cnt, s_w, tot);
-		if (i < n_u) ck0[i] = run + ex;
-		run += tot;
-	}
-	__syncthreads();
-	// slot -> chain by binary search in the start offsets; up to CG_CAP of them are searched in LDS (ten dependent probes
-	// of an L2 array per slot otherwise)
-	const uint32_t *tab = ck0;
-	if (n_u <= CG_CAP) { for (uint32_t i = tid; i < n_u; i += NT) s_off[i] = ck0[i]; tab = s_off; __syncthreads(); }
-	if (n_u <= CG_CAP) {
-		for (uint32_t q = tid; q < n_v; q += NT) {
-			uint32_t lo = 0, hi = n_u;                               // chain whose [ck0, ck0 + cnt) holds slot q
-			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tab[mid] <= q) lo = mid; else hi = mid; }
-			const uint32_t k0 = tab[lo], ni = (uint32_t)u[lo];
-			rh_an_cp(rr, rr.prev_out, base + q, rr.anc, base + (uint32_t)v[k0 + (ni - (q - k0) - 1)]);
-		}
-	} else {
-		// thousands of chains (an unmappable read on a large index: ~2 anchors per chain): one lane per chain copies its few
-		// anchors - neighbouring lanes write neighbouring slots and nobody searches; a long chain is the whole wavefront's
-		const uint32_t l = lane_id();
-		for (uint32_t i0 = wave_id() * 64u; i0 < n_u; i0 += NT) {
-			const uint32_t i = i0 + l;
-			uint32_t k0 = 0, ni = 0;
-			if (i < n_u) { k0 = ck0[i]; ni = (uint32_t)u[i]; }
-			if (ni <= CG_SHORT) for (uint32_t j = 0; j < ni; ++j) rh_an_cp(rr, rr.prev_out, base + k0 + j, rr.anc, base + (uint32_t)v[k0 + (ni - j - 1)]);
-			uint64_t longm = __ballot(ni > CG_SHORT);
-			while (longm) {
-				const int src = __ffsll((unsigned long long)longm) - 1;
-				longm &= longm - 1;
-				const uint32_t kk = __shfl(k0, src), nn = __shfl(ni, src);
-				for (uint32_t j = l; j < nn; j += 64) rh_an_cp(rr, rr.prev_out, base + kk + j, rr.anc, base + (uint32_t)v[kk + (nn - j - 1)]);
-			}
-		}
-	}
-	__syncthreads();
-	chain_keys(rr, base, n_u, ck0, tid);
-}
-
 // the chain-order keys of the reads with skip2[a] == 0 once more, from the gathered chains (the sorter overwrote its input): rhk_backtrack's exact re-run
 __global__ __launch_bounds__(NT) void k_chain_keys(rh_dev_round rr, const uint8_t *skip2)
 {
@@ -340,7 +291,7 @@ __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_ro
 	const uint64_t *w8 = reinterpret_cast<const uint64_t*>(rr.zs) + base;
 	const bool c8 = rr.cfmt.rec8 != 0;
 	const uint64_t cmask = (1ull << rr.cfmt.shift) - 1ull;
-	const uint32_t *ck0 = (const uint32_t*)(wsr + (size_t)32 * n);   // start offsets in backtrack order (k_chain_gather)
+	const uint32_t *ck0 = (const uint32_t*)(wsr + (size_t)32 * n);   // start offsets in backtrack order (k_backtrack_spec)
 	#define CR_CHAIN(i_) (c8 ? (uint32_t)(w8[(i_)] & cmask) : (uint32_t)w[(i_)].y)
 	#define CR_FROM(i_) (c8 ? ck0[(uint32_t)(w8[(i_)] & cmask)] : (uint32_t)(w[(i_)].y >> 32))
 	uint32_t run = 0;
@@ -366,7 +317,7 @@ __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_ro
 			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tab[mid] <= q) lo = mid; else hi = mid; }
 			rh_an_cp(rr, rr.anc, base + q, rr.prev_out, base + CR_FROM(lo) + (q - tab[lo]));
 		}
-	} else {	// one lane per chain (see k_chain_gather)
+	} else {	// thousands of chains (an unmappable read on a large index: ~2 anchors per chain): one lane per chain copies its few anchors - neighbouring lanes write neighbouring slots and nobody searches; a long chain is the whole wavefront's
 		const uint32_t l = lane_id();
 		for (uint32_t i0 = wave_id() * 64u; i0 < n_u; i0 += NT) {
 			const uint32_t i = i0 + l;
@@ -1665,7 +1616,7 @@ int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 	RH_LAUNCH(k_zbuild, r.n_act, NT, 0, s, o, r);
 	// candidates (score, anchor index) -> reference order; scores are full of ties: exact permutation for every read
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_z, r.raw, r.zs, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 64, (uint8_t)(o.min_sc >= 0), 32, 0, 0, r.max_anchors };   // keys = scores >= min_sc: non-negative int32
-	sort_scratch(jb, r, r.prev_out);                               // (the carry staging is written by k_chain_gather, later)
+	sort_scratch(jb, r, r.prev_out);                               // (the carry staging is written by the backtrack, later)
 	jb.kind = 2;
 	if (r.z8) jb.rf = rh_rec_fmt{1, 32, 32, 0};                     // 8-byte candidates: key = the high word
 	if (bt_lone_on(o, r)) jb.dead_cnt = r.n_v;                      // the candidates without a predecessor (k_zbuild): the backtrack stops before them
@@ -1678,10 +1629,9 @@ int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, co
 	static const bool bt_wave = getenv("RH_BT_WAVE") != nullptr;     // RH_BT_WAVE=1: one wavefront per read (A/B aid)
 	if (bt_wave) RH_LAUNCH(k_backtrack_spec<64>, r.n_act, 64, rh_wave_lds(), s, o, rd, r);
 	else RH_LAUNCH(k_backtrack_spec<256>, r.n_act, 256, rh_wave_lds(), s, o, rd, r);
-	// compact_a: chains gathered, put into the reference's order of their first anchor, written back
-	RH_LAUNCH(k_chain_gather, r.n_act, NT, 0, s, r);
+	// compact_a: the chains (gathered by the backtrack itself) put into the reference's order of their first anchor, written back
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };   // keys = first anchors
-	sort_scratch(jb, r, r.anc);                                    // (k_chain_gather has copied every chain out of the sorted anchors; k_chain_reorder rewrites them)
+	sort_scratch(jb, r, r.anc);                                    // (the backtrack has copied every chain out of the sorted anchors; k_chain_reorder rewrites them)
 	jb.kind = 3;
 	jb.rf = r.cfmt;
 	// Two chains agree on the key only where two anchors of the read do (see rhk_sort): long lists - an unmappable read on a large index has tens

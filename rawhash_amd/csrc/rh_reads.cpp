@@ -8,6 +8,7 @@
 // Samples are decoded straight into ONE page-locked staging buffer (hipHostMalloc; plain memory when no HIP runtime answers, e.g. in
 // the CPU test suite), so rh_map_batch / rh_map_submit upload them at PCIe speed without an intermediate copy.
 #include "rh_common.h"
+#include <algorithm>
 #include <exception>
 #include <dlfcn.h>
 #include <sys/stat.h>
@@ -160,14 +161,19 @@ static rh_reads *reads_load_slow5_text(const char *path)
 		if (!have_cols) return fail("a record before the column names", line_no);
 		const char *f_id = nullptr, *f_sig = nullptr; double dig = 0, off = 0, rng = 0; uint64_t ns = 0;
 		int col = 0;
+		bool bad_num = false;
+		auto num = [&](const char *t, double &v) { char *e; v = strtod(t, &e); if (e == t || *e) bad_num = true; };
 		for (char *tok = line, *nx; tok; tok = nx, ++col) {
 			nx = strchr(tok, '\t');
 			if (nx) *nx++ = 0;
 			if (col == c_id) f_id = tok; else if (col == c_sig) f_sig = tok;
-			else if (col == c_dig) dig = strtod(tok, nullptr); else if (col == c_off) off = strtod(tok, nullptr); else if (col == c_rng) rng = strtod(tok, nullptr);
-			else if (col == c_len) ns = strtoull(tok, nullptr, 10);
+			else if (col == c_dig) num(tok, dig); else if (col == c_off) num(tok, off); else if (col == c_rng) num(tok, rng);
+			else if (col == c_len) { char *e; ns = strtoull(tok, &e, 10); if (e == tok || *e || *tok == '-') bad_num = true; }
 		}
-		if (col < n_cols && col <= c_sig) return fail("fewer fields than columns", line_no);
+		// every primary column has to be there (a line cut short after raw_signal would otherwise map with offset / range 0: wrong calibration, no error)
+		const int last_primary = std::max(std::max(std::max(c_id, c_dig), std::max(c_off, c_rng)), std::max(c_len, c_sig));
+		if (col <= last_primary) return fail("fewer fields than the primary columns need", line_no);
+		if (bad_num) return fail("digitisation / offset / range / len_raw_signal is not a number", line_no);
 		if (!f_id || !f_sig) return fail("no read_id / raw_signal field", line_no);
 		if (strlen(f_id) > kMaxNameLen || ns >= kMaxReadSamples || !(dig > 0)) return fail("implausible read (name length, signal length, digitisation)", line_no);
 		int16_t *dst = r->samples.grow(ns);

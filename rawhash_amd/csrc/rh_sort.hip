@@ -16,6 +16,7 @@
 //                   tie-free ranges keep the atomic scatter.
 // LDS per record: 8 B key (by original index) + 2 B permutation + 2 B scratch map; permutations are applied through
 // registers.  Records (16 B) are gathered from / written to HBM once.
+#include <type_traits>
 #include "rh_kernels.h"
 #include "rh_devutil.h"
 
@@ -537,6 +538,195 @@ RH_DEV void sort_run(sort_lds<CAP, KT> &L, uint32_t n, int pass)
 	KPROF(9);
 }
 
+
+// ------------------------------------------------------------------------------------------------ tie-free segments of 8-byte records
+// Round 6.  What the block sorter mostly sees - the strand x target buckets of a large index's chunks, a small index's whole chunks, chain lists - are
+// segments WITHOUT equal keys, and such a segment has one sorted order however it is reached (ksort.h:101-151 leaves equal keys in an order of its own;
+// distinct keys it simply sorts).  sort_fast gets there with the records themselves in LDS and seven LDS operations per record, where the general
+// path keeps keys, a 16-bit arrangement and a scratch map and goes through them ~25 times (its own counters: 40 % of those cycles were bank conflicts,
+// and more than a quarter of the kernel's time was waiting for the first load and for the second read of the records at the end):
+//   1. records -> registers; minimum and maximum of the packed keys (record >> shift: the fields keep their significance, rh_rec_fmt);
+//   2. bucket = (key - min) >> s with s such that the range fills NB = CAP / 2 buckets (mean 1 - 4 records each); ONE LDS atomic per record
+//      gives both the bucket's count and the record's rank inside it (16-bit counters, two to a word);
+//   3. counts -> start offsets (a thread owns NB / NT consecutive buckets, here and in 5);
+//   4. records scattered into LDS at start + rank;
+//   5. every lane sorts its buckets: the words (low key bits << 5 | place) of up to 16 records in a bitonic network in registers, equal neighbours
+//      = equal keys (they share a bucket), the records permuted inside the bucket;
+//   6. the sorted records stream out of LDS to the destination - no second read of the source.
+// Returns 0: done; 1: the segment holds equal keys (nothing written: the caller's exact passes take it from the input order); 2: not for this path
+// (a bucket of more than 16 records, more than 27 key bits below the buckets).
+template <int CAP> struct sort_fast_cfg {
+	static constexpr int nb() { int v = NT; while (v < CAP / 2) v *= 2; return v; }
+	static constexpr int NB = nb(), BPT = NB / NT, K = (CAP + NT - 1) / NT;
+	static constexpr int lb() { int l = 0; while ((1 << l) < NB) ++l; return l; }
+	static constexpr int LB = lb();
+	static constexpr bool HOLD = K <= 16;                     // records stay in registers between the passes (else they are read again: L2)
+};
+template <int CAP>
+struct alignas(16) sort_fast_lds {
+	uint64_t rec[CAP];
+	uint32_t cnt[sort_fast_cfg<CAP>::NB / 2];                 // per bucket: count, then start offset (16 bits each)
+	uint64_t r64[2 * (NT / 64)];
+	uint32_t w[NT / 64];
+	uint32_t flag;
+};
+
+template <int W>
+RH_DEV void sort_lane_net(uint32_t (&c)[W])
+{
+#pragma unroll
+	for (int kk = 2; kk <= W; kk <<= 1)
+#pragma unroll
+		for (int jj = kk >> 1; jj > 0; jj >>= 1)
+#pragma unroll
+			for (int i = 0; i < W; ++i) {
+				const int l2 = i ^ jj;
+				if (l2 > i) { const uint32_t lo = c[i] < c[l2] ? c[i] : c[l2], hi = c[i] < c[l2] ? c[l2] : c[i]; if ((i & kk) == 0) { c[i] = lo; c[l2] = hi; } else { c[i] = hi; c[l2] = lo; } }
+			}
+}
+// one bucket [st, st + m) per lane, m <= W
+template <int CAP, int W>
+RH_DEV bool sort_fast_bucket(sort_fast_lds<CAP> &F, uint32_t st, uint32_t m, uint32_t shift, uint32_t kmin_lo, uint32_t lowmask)
+{
+	uint32_t c[W];
+#pragma unroll
+	for (int j = 0; j < W; ++j) {
+		c[j] = 0xFFFFFFFFu;
+		if ((uint32_t)j < m) c[j] = (((uint32_t)(F.rec[st + j] >> shift) - kmin_lo) & lowmask) << 5 | (uint32_t)j;
+	}
+	sort_lane_net<W>(c);
+	bool tie = false;
+#pragma unroll
+	for (int j = 1; j < W; ++j) if ((uint32_t)j < m && (c[j] >> 5) == (c[j - 1] >> 5)) tie = true;
+	uint64_t nx[W];
+#pragma unroll
+	for (int j = 0; j < W; ++j) nx[j] = (uint32_t)j < m ? F.rec[st + (c[j] & 31u)] : 0ull;
+#pragma unroll
+	for (int j = 0; j < W; ++j) if ((uint32_t)j < m) F.rec[st + j] = nx[j];
+	return tie;
+}
+
+template <int CAP>
+RH_DEV int sort_fast(sort_fast_lds<CAP> &F, const uint64_t *src, uint64_t *dst, uint32_t n, uint32_t shift)
+{
+	typedef sort_fast_cfg<CAP> CF;
+	constexpr int K = CF::K, NB = CF::NB, BPT = CF::BPT, LB = CF::LB;
+	constexpr int KH = CF::HOLD ? K : 1;
+	const uint32_t tid = threadIdx.x;
+	if (n < 2) { if (n == 1 && tid == 0) dst[0] = src[0]; return 0; }
+	uint64_t r[KH];
+	uint64_t kmin = ~0ull, kmax = 0ull;
+	if constexpr (CF::HOLD) {
+#pragma unroll
+		for (int k = 0; k < KH; ++k) { const uint32_t i = tid + (uint32_t)k * NT; r[k] = i < n ? src[i] : 0ull; }
+#pragma unroll
+		for (int k = 0; k < KH; ++k) { const uint32_t i = tid + (uint32_t)k * NT; if (i < n) { const uint64_t kk = r[k] >> shift; kmin = kk < kmin ? kk : kmin; kmax = kk > kmax ? kk : kmax; } }
+	} else {
+		for (uint32_t i0 = tid; i0 < n; i0 += 8u * NT) {
+			uint64_t x[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; x[u] = i < n ? src[i] : 0ull; }
+#pragma unroll
+			for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; if (i < n) { const uint64_t kk = x[u] >> shift; kmin = kk < kmin ? kk : kmin; kmax = kk > kmax ? kk : kmax; } }
+		}
+	}
+	for (uint32_t b = tid; b < (uint32_t)NB / 2; b += NT) F.cnt[b] = 0;
+	if (tid == 0) F.flag = 0;
+	for (int d = 32; d > 0; d >>= 1) { const uint64_t a = __shfl_xor(kmin, d), b = __shfl_xor(kmax, d); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+	if (lane_id() == 0) { F.r64[wave_id()] = kmin; F.r64[NT / 64 + wave_id()] = kmax; }
+	__syncthreads();
+#pragma unroll
+	for (int q = 0; q < NT / 64; ++q) { const uint64_t a = F.r64[q], b = F.r64[NT / 64 + q]; kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+	const uint64_t range = kmax - kmin;
+	if (range == 0) return 1;                                    // n >= 2 equal keys
+	const int bits = 64 - __clzll(range);
+	const uint32_t s = bits > LB ? (uint32_t)(bits - LB) : 0u;
+	if (s > 27u) return 2;
+	const uint32_t lowmask = (1u << s) - 1u, kmin_lo = (uint32_t)kmin;
+	// bucket and rank of every record: one atomic each
+	uint32_t dr[K];
+	if constexpr (CF::HOLD) {
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const uint32_t i = tid + (uint32_t)k * NT;
+			dr[k] = 0;
+			if (i < n) { const uint32_t d = (uint32_t)(((r[k] >> shift) - kmin) >> s); const uint32_t old = atomicAdd(&F.cnt[d >> 1], 1u << (16u * (d & 1u))); dr[k] = d | ((old >> (16u * (d & 1u))) & 0xFFFFu) << 16; }
+		}
+	} else {
+#pragma unroll
+		for (int k0 = 0; k0 < K; k0 += 8) {
+			uint64_t x[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) { const uint32_t i = tid + (uint32_t)(k0 + u) * NT; x[u] = (k0 + u < K && i < n) ? src[i] : 0ull; }
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				if (k0 + u >= K) continue;
+				const uint32_t i = tid + (uint32_t)(k0 + u) * NT;
+				dr[k0 + u] = 0;
+				if (i < n) { const uint32_t d = (uint32_t)(((x[u] >> shift) - kmin) >> s); const uint32_t old = atomicAdd(&F.cnt[d >> 1], 1u << (16u * (d & 1u))); dr[k0 + u] = d | ((old >> (16u * (d & 1u))) & 0xFFFFu) << 16; }
+			}
+		}
+	}
+	__syncthreads();
+	// counts -> start offsets; this thread's buckets stay in its registers for step 5
+	uint32_t bc[BPT], bs[BPT], sum = 0, mx = 0;
+#pragma unroll
+	for (int q = 0; q < BPT; ++q) {
+		const uint32_t b = tid * (uint32_t)BPT + (uint32_t)q;
+		bc[q] = (F.cnt[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu;
+		sum += bc[q]; mx = bc[q] > mx ? bc[q] : mx;
+	}
+	uint32_t tot;
+	uint32_t ex = block_excl_scan(sum, F.w, tot);                 // (its first barrier: every thread has read its counts)
+#pragma unroll
+	for (int q = 0; q < BPT; ++q) { bs[q] = ex; ex += bc[q]; }
+	if (BPT >= 2) {
+#pragma unroll
+		for (int q = 0; q < BPT; q += 2) F.cnt[(tid * (uint32_t)BPT + (uint32_t)q) >> 1] = bs[q] | bs[q + 1 < BPT ? q + 1 : q] << 16;
+	} else {	// one bucket per thread: the even lane writes the pair
+		const uint32_t up = __shfl_xor(bs[0], 1);
+		if ((tid & 1u) == 0) F.cnt[tid >> 1] = bs[0] | up << 16;
+	}
+	if (mx > 16u) F.flag = 1;
+	__syncthreads();
+	if (F.flag) return 2;
+	// scatter
+	if constexpr (CF::HOLD) {
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const uint32_t i = tid + (uint32_t)k * NT;
+			if (i < n) { const uint32_t d = dr[k] & 0xFFFFu; F.rec[((F.cnt[d >> 1] >> (16u * (d & 1u))) & 0xFFFFu) + (dr[k] >> 16)] = r[k]; }
+		}
+	} else {
+#pragma unroll
+		for (int k0 = 0; k0 < K; k0 += 8) {
+			uint64_t x[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) { const uint32_t i = tid + (uint32_t)(k0 + u) * NT; x[u] = (k0 + u < K && i < n) ? src[i] : 0ull; }
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				if (k0 + u >= K) continue;
+				const uint32_t i = tid + (uint32_t)(k0 + u) * NT;
+				if (i < n) { const uint32_t d = dr[k0 + u] & 0xFFFFu; F.rec[((F.cnt[d >> 1] >> (16u * (d & 1u))) & 0xFFFFu) + (dr[k0 + u] >> 16)] = x[u]; }
+			}
+		}
+	}
+	__syncthreads();
+	// every lane sorts its buckets
+	bool tie = false;
+#pragma unroll
+	for (int q = 0; q < BPT; ++q) {
+		const uint32_t m = bc[q];
+		if (__ballot(m > 8u)) tie |= sort_fast_bucket<CAP, 16>(F, bs[q], m, shift, kmin_lo, lowmask);
+		else if (__ballot(m > 1u)) tie |= sort_fast_bucket<CAP, 8>(F, bs[q], m, shift, kmin_lo, lowmask);
+	}
+	if (tie) F.flag = 1;
+	__syncthreads();
+	if (F.flag) return 1;
+	for (uint32_t i = tid; i < n; i += NT) dst[i] = F.rec[i];
+	return 0;
+}
+
 // mode 0: fast pass; reads whose sorted keys show ties are redone with the exact permutation on the tied ranges
 // mode 2: exact pass on every range (keys known to be full of ties, e.g. chain scores)
 // workgroups of a class that fit the 160 KB of LDS of a CU (1 KB allocation granules) = wavefronts per SIMD the compiler
@@ -547,7 +737,9 @@ constexpr int sort_wg_per_cu() { return (int)((160u * 1024u) / ((sizeof(sort_lds
 template <int CAP, class KT, class REC>
 __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(rh_sort_job jb, uint32_t n_lo, uint32_t n_hi, int mode)
 {
-	__shared__ sort_lds<CAP, KT> L;
+	constexpr bool FAST = sizeof(REC) == 8 && sizeof(sort_fast_lds<CAP>) <= sizeof(sort_lds<CAP, KT>) + 2048;   // (the tie-free path shares the LDS of the general one)
+	__shared__ union U_ { sort_lds<CAP, KT> L; typename std::conditional<FAST, sort_fast_lds<CAP>, uint32_t>::type F; } U;
+	sort_lds<CAP, KT> &L = U.L;
 	const uint32_t a = blockIdx.x, tid = threadIdx.x;
 	if (a >= jb.n_seg || (jb.skip && jb.skip[a])) return;
 	const uint64_t base = jb.off[a];
@@ -557,6 +749,19 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 	REC *dst = reinterpret_cast<REC*>(jb.dst) + base;
 	const rh_rec_fmt rf = jb.rf;
 	KPROF_DECL;
+	if constexpr (FAST) {
+		if (mode == 0 && jb.fast_on) {	// segments without equal keys (nearly all): records in LDS, one pass into CAP / 2 buckets, a register network per bucket
+			const int fr = sort_fast<CAP>(U.F, reinterpret_cast<const uint64_t*>(src), reinterpret_cast<uint64_t*>(dst), n, rf.shift);
+#ifdef RH_KPROF
+			if (tid == 0 && jb.scratch_skip == 0) { const unsigned long long t_ = clock64(); atomicAdd(&rh_kprof_acc[13], t_ - kp_t0); kp_t0 = t_; }   // (L.prof is not set yet, and shares its bytes with the records)
+#endif
+#ifdef RH_FAST_TRACE
+			if (tid == 0) fprintf(stderr, "FAST cap %d n %u -> %d\n", CAP, n, fr);
+#endif
+			if (fr == 0 || (fr == 1 && jb.no_redo)) { if (tid == 0 && jb.need_exact) jb.need_exact[a] = (uint8_t)fr; return; }   // (no_redo: whoever asked redoes the segments that hold equal keys from their input anyway)
+			__syncthreads();
+		}
+	}
 #ifdef RH_KPROF
 	if (tid == 0) L.prof = jb.scratch_skip == 0 ? 1u : 0u;      // profile the anchor sort only
 	__syncthreads();
@@ -641,7 +846,7 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 		}
 	}
 	KPROF(12);
-	if (mode != 0 || !tie) return;
+	if (mode != 0 || !tie || jb.no_redo) return;
 	// Equal keys: their order is the reference's cycle-leader permutation.  Redo the sort from the input order on the ranges
 	// that hold tied keys only; every other record already sits at its final place, and so does each group of equal keys
 	// as a whole - only the records inside the groups are rewritten.  (The keys again: the staging above overwrote them.)
@@ -815,9 +1020,12 @@ static bool sort_keys32(const rh_sort_job &jb) { return jb.kc_on && (uint32_t)jb
 
 uint32_t rhk_sort_lds_max(const rh_sort_job &jb) { return sort_keys32(jb) ? (uint32_t)RH_SORT32_CAP3 : (uint32_t)RH_SORT_CAP4; }
 
-int rhk_sort_job(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t min_n)
+int rhk_sort_job(hipStream_t s, const rh_sort_job &job, bool all_exact, uint32_t min_n)
 {
-	if (!jb.n_seg) return 0;
+	if (!job.n_seg) return 0;
+	rh_sort_job jb = job;
+	static const bool fast_on = !(getenv("RH_SORT_FAST") && atoi(getenv("RH_SORT_FAST")) == 0);   // RH_SORT_FAST=0: the general LDS path for every segment (A/B aid)
+	jb.fast_on = fast_on && !all_exact ? 1 : 0;
 	uint32_t top;
 	static const bool tiny_on = !(RH_DEVENV("RH_SORT_TINY") && atoi(RH_DEVENV("RH_SORT_TINY")) == 0);
 	if (tiny_on && min_n < (uint32_t)RH_SORT_TINY) {	// one lane per segment of up to 32 records

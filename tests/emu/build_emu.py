@@ -39,7 +39,10 @@ def build(force=False, defines=(), tag=""):
         for f in ("rh_gpu.h", "emu_runtime.cpp"):
             shutil.copy(os.path.join(HERE, f), os.path.join(src_dir, f))
         srcs.append(os.path.join(src_dir, "emu_runtime.cpp"))
-        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-pthread", "-w",
+        # -fno-gnu-unique: a kernel template's `__shared__` arrays are function-local statics here, which g++ would emit as STB_GNU_UNIQUE symbols - ONE
+        # instance per process even across dlopen(RTLD_LOCAL), so the production-size build and the small-caps build (same names, different array sizes)
+        # would share whichever was loaded first (round 5: test_exact_sort_multi_workgroup crashed in k_bs_scatter when run on its own)
+        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-fno-gnu-unique", "-pthread", "-w",
                "-I", src_dir, "-I", os.path.join(ROOT, "include"), "-x", "c++"] + list(defines) + srcs + ["-o", out + ".tmp", "-lz"]
         subprocess.run(cmd, check=True)
         os.replace(out + ".tmp", out)

@@ -367,6 +367,55 @@ def check_sort_big(ctx, seed=0, sizes=(20000, 33000, 9000), kinds=(0, 1, 2, 3, 4
     assert len(bad) == 0, f"{len(bad)} records out of the reference's order, first at {bad[:5]}"
 
 
+def check_sort_packed(ctx, seed=0, sizes=None, any_order=False, lo=27, mid=5):
+    """The anchor sort on ONE-WORD records (the mapping path's anchor format; rh_sort.hip: sort_fast takes the segments without equal keys, the
+    general LDS path the others): anchor keys strand | target | position, segment sizes around every LDS class boundary, and per segment one of
+    - distinct keys spread over a chromosome (the usual strand x target bucket), - distinct keys on ONE strand and target, - a few pairs / triples of
+    equal keys, - keys crowded into a narrow window (buckets of more than 16 records: not for the tie-free path), - many equal keys, - two values only.
+    Result = radix_sort_128x's permutation (oracle)."""
+    rng = np.random.default_rng(seed)
+    if sizes is None:
+        sizes = [0, 1, 2, 33, 64, 65, 100, 255, 256, 257, 511, 512, 513, 700, 1500, 2047, 2048, 2049, 3000, 4095, 4096, 4097, 5000, 5632, 6000, 8191, 8192]
+    segs = []
+    for i, n in enumerate(sizes):
+        kind = i % 6
+        strand = rng.integers(0, 2, size=n, dtype=np.uint64) << np.uint64(63)
+        tmax = min(24, 1 << mid)
+        tgt = rng.integers(0, tmax, size=n, dtype=np.uint64) << np.uint64(32)
+        pos = rng.permutation(np.unique(rng.integers(0, 1 << lo, size=2 * n + 64, dtype=np.uint64)))[:n]
+        if kind == 0:
+            x = strand | tgt | pos
+        elif kind == 1:
+            x = (np.uint64(1) << np.uint64(63)) | (np.uint64(3 % tmax) << np.uint64(32)) | pos
+        elif kind == 2:
+            x = (np.uint64(2 % tmax) << np.uint64(32)) | pos
+            for _ in range(int(rng.integers(1, 4))):
+                if n >= 2:
+                    j = rng.integers(0, n, size=int(rng.integers(2, 4)))
+                    x[j] = x[j[0]]
+        elif kind == 3:    # crowded: most keys inside a window of n / 8 positions, a few far away
+            x = (np.uint64(5 % tmax) << np.uint64(32)) | (np.uint64(1 << (lo - 1)) + rng.permutation(max(n, 1) * 2).astype(np.uint64)[:n])
+            if n > 40:
+                x[rng.integers(0, n, size=3)] = (np.uint64(5 % tmax) << np.uint64(32)) | rng.integers(0, 1 << lo, size=3, dtype=np.uint64)
+        elif kind == 4:
+            x = strand | (rng.integers(0, min(3, tmax), size=n, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, max(n // 3, 2), size=n, dtype=np.uint64)
+        else:
+            x = (rng.integers(0, 2, size=n, dtype=np.uint64) << np.uint64(63)) | np.uint64(77)
+        segs.append(x.astype(np.uint64))
+    off = np.zeros(len(sizes) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in segs])
+    a = np.zeros(int(off[-1]), dtype=MM128)
+    a["x"] = np.concatenate(segs) if len(a) else np.zeros(0, dtype=np.uint64)
+    a["y"] = np.arange(len(a), dtype=np.uint64)
+    want = a.copy()
+    assert O.lib().ro_sort128x_batch(len(sizes), ptr(want), ptr(off)) == 0
+    got = ctx.sort128x_packed(a, off, lo, mid, any_order=any_order)
+    assert np.array_equal(got["x"], want["x"]), "not sorted like the reference"
+    bad = np.nonzero(got["y"] != want["y"])[0]
+    seg_of = np.searchsorted(off, bad[:5], side="right") - 1 if len(bad) else []
+    assert len(bad) == 0, f"{len(bad)} records out of the reference's order, first at {bad[:5]} (segments {list(seg_of)}, sizes {[sizes[int(q)] for q in seg_of]})"
+
+
 def check_sort_any(ctx, seed=0, sizes=(20000, 33000, 9000, 500, 70000, 12000)):
     """The any-order path of the segment sorter (region keys: score << 32 | count ^ hash): long segments without equal keys come
     out in the one sorted order there is (= the reference's); long segments with equal keys are flagged for the exact re-run;

@@ -171,6 +171,15 @@ def test_slow5_text_hand_assembled_fixture(tmp_path, product_lib):
         open(p, "w").write("\n".join(bad) + "\n")
         with pytest.raises(RhError, match=msg):
             Reads.load(p, lib=product_lib)
+    # a record cut short BEHIND raw_signal (primary columns follow it in this order) and a calibration field that is not a number: errors, not reads
+    # with offset / range 0
+    og = text(other, aux=False).splitlines()
+    for bad, msg in ((og[:7] + [og[7].rsplit("\t", 3)[0]] + og[8:], "fewer fields"),
+                     (og[:7] + [og[7].rsplit("\t", 1)[0] + "\t8192.0x"] + og[8:], "not a number")):
+        p = str(tmp_path / "bad2.slow5")
+        open(p, "w").write("\n".join(bad) + "\n")
+        with pytest.raises(RhError, match=msg):
+            Reads.load(p, lib=product_lib)
 
 
 def test_blow5_hostile_lengths_fail_before_allocating(tmp_path, product_lib):

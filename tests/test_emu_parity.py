@@ -34,6 +34,17 @@ def test_exact_sort(ctx):
     pc.check_sort(ctx, seed=3, n_seg=330, tiny=True)
 
 
+def test_sort_one_word_records(ctx, emu_lib_smallcaps):
+    """The anchor sort on 8-byte records: sort_fast (segments without equal keys: records in LDS, one bucket pass, a register network per bucket) and
+    what it hands back to the general path - at the production LDS classes and at the small ones of the test build."""
+    pc.check_sort_packed(ctx, seed=21)
+    pc.check_sort_packed(ctx, seed=22, sizes=[20000, 9000, 3000, 12000, 700, 40000], any_order=True)
+    c = Context(0, lib=emu_lib_smallcaps)
+    pc.check_sort_packed(c, seed=23, sizes=[0, 1, 40, 100, 128, 129, 200, 256, 257, 300, 384, 385, 500, 640, 641, 900, 1024, 1025, 3000])
+    pc.check_sort_packed(c, seed=24, sizes=[2000, 1100, 5000, 90, 700], any_order=True, lo=20, mid=3)
+    c.close()
+
+
 def test_exact_sort_multi_workgroup(ctx, emu_lib_smallcaps):
     """rh_bigsort.hip: segments longer than the LDS classes, at the production sizes of tiles / windows and with tiny ones
     (several levels, window refills of the token walk)."""

@@ -58,6 +58,17 @@ def test_exact_sort(ctx):
     pc.check_sort(ctx, seed=6, n_seg=5000, tiny=True)
 
 
+def test_sort_one_word_records(ctx):
+    """The anchor sort on 8-byte records (the mapping path's anchor format): the tie-free LDS path (rh_sort.hip: sort_fast) and what it hands back
+    to the exact passes, at every LDS class boundary, direct and through the any-order levels of the multi-workgroup sorter (the strand x target
+    buckets of a human-scale chunk: ~2 k records each), thousands of segments at once."""
+    pc.check_sort_packed(ctx, seed=31)
+    pc.check_sort_packed(ctx, seed=32, sizes=[int(x) for x in np.random.default_rng(32).integers(0, 8193, size=1500)])
+    pc.check_sort_packed(ctx, seed=33, sizes=[90_000, 60_000, 9_000, 200_000, 12_000, 700, 40_000, 150_000, 8_193], any_order=True)
+    pc.check_sort_packed(ctx, seed=34, sizes=[20_000 + 331 * i for i in range(120)], any_order=True)
+    pc.check_sort_packed(ctx, seed=35, sizes=[3_000 + 7 * i for i in range(400)], lo=23, mid=1)      # a small index: whole chunks in one LDS segment
+
+
 def test_stage_regions(ctx, wl):
     """a17-a19 (mm_gen_regs / mm_set_parent / mm_select_sub / mm_set_mapq) at stage level against the oracle."""
     checked, with_regs = pc.check_regions(ctx, wl, seed=9, n_reads=300, max_n=2500)
