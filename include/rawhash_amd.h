@@ -232,6 +232,7 @@ typedef struct rh_map_stats_s {
 	double   ms_total;                /* device time of the whole call (hipEvents on the context's stream) */
 	double   ms_kernel[24];           /* per-stage device time (HIP events on the context's stream), see rh_stage_name() */
 	uint32_t n_launch[24];
+	uint64_t n_rmq_class[4];          /* RH_M_RMQ / bw_long: (read, chunk) pairs chained with the trees in LDS rings of 64 / 128 / 512 nodes, or in HBM */
 } rh_map_stats_t;
 RH_API int  rh_map_last_stats(rh_ctx *ctx, rh_map_stats_t *out);
 RH_API const char *rh_stage_name(int i);

@@ -41,13 +41,21 @@ def stage_of(k):
 
 def one_pass(counter, out):
     env = dict(os.environ, RH_SUB_BATCHES="1")
-    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--",
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counter.split() + ["--output-format", "csv", "-d", out, "-o", "p", "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--workload", WORKLOAD, "--reads", str(READS), "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--no-h2d"]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
     f = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    want = counter.split()
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] in want]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    if len(want) > 1:       # several counters in one pass: {counter: acc}
+        return {c: _accumulate([r for r in rows if r["Counter_Name"] == c]) for c in want}
+    return _accumulate(rows)
+
+
+def _accumulate(rows):
     acc, owner = {}, "sort"
+    seen = set()
     for r in rows:
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         for name_, ow_ in SORT_OWNER.items():
@@ -55,7 +63,9 @@ def one_pass(counter, out):
                 owner = ow_
         key = k + "@" + owner if k.startswith(("k_sort", "k_bs_")) else k
         e = acc.setdefault(key, [0, 0.0])
-        e[0] += 1
+        if r["Dispatch_Id"] not in seen:
+            e[0] += 1
+            seen.add(r["Dispatch_Id"])
         e[1] += float(r["Counter_Value"])
     return acc
 
@@ -63,12 +73,31 @@ def one_pass(counter, out):
 def main():
     fetch = one_pass("FETCH_SIZE", "/tmp/pmc_fetch")
     write = one_pass("WRITE_SIZE", "/tmp/pmc_write")
+    # What did a read request really fetch?  FETCH_SIZE tallies every request at 64 bytes; the request-size counters say how many were 32 / 64 / 128-byte
+    # requests (round 6, after tools/probes/gather_calib.hip: on gfx950 streams AND 8- / 16-byte gathers are all 128-byte line requests -
+    # profiles/r06_gather_calib.txt - so the factor 2 of the guide holds for every access class measured).  Per kernel: read bytes = 32 n32 + 64 n64 + 128 n128,
+    # fetch_factor = that / FETCH_SIZE.  RH_PMC_REQ_SIZES=0 skips the two extra passes and applies the factor 2 throughout.
+    req, siz = {}, {}
+    if os.environ.get("RH_PMC_REQ_SIZES", "1") != "0":
+        try:
+            req = one_pass("TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum", "/tmp/pmc_req")
+            siz = one_pass("TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum", "/tmp/pmc_siz")
+        except Exception as ex:  # noqa: BLE001
+            print("request-size counters not collected:", ex)
+            req, siz = {}, {}
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
         n = fetch.get(k, write.get(k))[0]
-        rd = 2.0 * fetch.get(k, [0, 0.0])[1] * 1024.0
+        fs = fetch.get(k, [0, 0.0])[1] * 1024.0
+        rd, factor = 2.0 * fs, 2.0
+        if req and siz and k in req.get("TCC_EA0_RDREQ_sum", {}):
+            n_all = req["TCC_EA0_RDREQ_sum"][k][1]; n32 = req["TCC_EA0_RDREQ_32B_sum"].get(k, [0, 0.0])[1]
+            n64 = siz["TCC_EA0_RDREQ_64B_sum"].get(k, [0, 0.0])[1]; n128 = siz["TCC_EA0_RDREQ_128B_sum"].get(k, [0, 0.0])[1]
+            if n_all > 0 and abs((n32 + n64 + n128) - n_all) <= 0.05 * n_all + 64:      # (separate passes of the same command: counts agree to a fraction of a percent)
+                rd = 32.0 * n32 + 64.0 * n64 + 128.0 * n128
+                factor = rd / fs if fs else 2.0
         wr = write.get(k, [0, 0.0])[1] * 1024.0
-        kernels[k] = {"launches": n, "read_bytes": rd, "write_bytes": wr, "bytes_per_launch": (rd + wr) / max(n, 1)}
+        kernels[k] = {"launches": n, "read_bytes": rd, "write_bytes": wr, "bytes_per_launch": (rd + wr) / max(n, 1), "fetch_factor": round(factor, 4)}
     stages, unattributed, setup = {}, [], {"bytes": 0.0}
     for k, v in kernels.items():
         if k.startswith(NOT_PATH):
@@ -83,7 +112,7 @@ def main():
         e["bytes"] += v["read_bytes"] + v["write_bytes"]
     for e in stages.values():
         e["bytes_per_step"] = e["bytes"]          # the profiled command runs exactly one step
-    out = {"workload": WORKLOAD, "reads": READS, "samples": SAMPLES, "junk": JUNK, "commit": os.environ.get("RH_COMMIT"), "round": 5, "note": "read bytes = 2 x FETCH_SIZE KiB (gfx950), write bytes = WRITE_SIZE KiB; one stream (RH_SUB_BATCHES=1)",
+    out = {"workload": WORKLOAD, "reads": READS, "samples": SAMPLES, "junk": JUNK, "commit": os.environ.get("RH_COMMIT"), "round": 6, "note": "read bytes = 32 n32 + 64 n64 + 128 n128 from the request-size counters (fetch_factor = that / FETCH_SIZE; 2.0 where they were not collected), write bytes = WRITE_SIZE KiB; one stream (RH_SUB_BATCHES=1)",
            "path_bytes_per_step": sum(e["bytes"] for e in stages.values()), "unattributed_kernels": unattributed, "setup_bytes": setup["bytes"],
            "kernels": kernels, "stages": stages}
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
@@ -95,7 +124,7 @@ def main():
     for st, e in sorted(stages.items(), key=lambda kv: -kv[1]["bytes"]):
         print(f"{st:14s} {e['bytes'] / 1e9:9.2f} GB  {e['launches']} launches")
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["read_bytes"] - kv[1]["write_bytes"])[:14]:
-        print(f"{k:44s} launches {v['launches']:5d}  read {v['read_bytes']/1e9:8.3f} GB  write {v['write_bytes']/1e9:8.3f} GB")
+        print(f"{k:44s} launches {v['launches']:5d}  read {v['read_bytes']/1e9:8.3f} GB  write {v['write_bytes']/1e9:8.3f} GB  fetch factor {v['fetch_factor']:.3f}")
 
 
 if __name__ == "__main__":

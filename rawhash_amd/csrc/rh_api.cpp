@@ -1073,6 +1073,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 		RH_HIP(hipStreamSynchronize(s));
 		c->stats.n_events = cnt[0]; c->stats.n_seeds = cnt[1]; c->stats.n_hits = cnt[2]; c->stats.n_anchors = cnt[3]; c->stats.n_chained = cnt[4];
 		c->stats.n_samples_used = cnt[5]; c->stats.n_chunks = cnt[6];
+		for (int q = 0; q < 4; ++q) c->stats.n_rmq_class[q] = cnt[9 + q];
 		if (cnt[7]) { rh_set_error("%llu chunk(s) hold more than %d event boundaries: beyond the per-chunk arrays of the device path", (unsigned long long)cnt[7], RH_EV_CAP); return -1; }
 		if (cnt[8]) { rh_set_error("rh_read_batch_t::n_filtered is wrong for %llu read(s): not the number of samples the pA filter (rsig.c:496-503) leaves of them", (unsigned long long)cnt[8]); return -1; }
 	}
@@ -1090,6 +1091,7 @@ void add_stats(rh_map_stats_t &tot, const rh_map_stats_t &q)
 	tot.n_reads += q.n_reads; tot.n_chunks += q.n_chunks; tot.n_samples_raw += q.n_samples_raw; tot.n_samples_used += q.n_samples_used;
 	tot.n_events += q.n_events; tot.n_seeds += q.n_seeds; tot.n_hits += q.n_hits; tot.n_anchors += q.n_anchors; tot.n_chained += q.n_chained;
 	tot.ms_total += q.ms_total;
+	for (int i = 0; i < 4; ++i) tot.n_rmq_class[i] += q.n_rmq_class[i];
 	for (int i = 0; i < 24; ++i) { tot.ms_kernel[i] += q.ms_kernel[i]; tot.n_launch[i] += q.n_launch[i]; }
 }
 

@@ -571,7 +571,7 @@ RH_DEV int32_t rq_sc_simple(const rh_mm128_t &ai, const rh_mm128_t &aj, float pe
 // The widest window of live nodes each read will have - anchors [st, i) with st as the walk below moves it (the size cap only evicts more) - sorted into the
 // storage class that holds it: 0 / 1 / 2 = LDS rings of RQ_RING_S / RQ_RING / RQ_RING_BIG nodes, 3 = the arrays in HBM.  The anchors are sorted by x, so
 // "first anchor still in range of anchor i - 1" is a binary search: a lane per anchor, 64 at a time.
-__global__ __launch_bounds__(64) void k_rmq_class(rh_dev_opt o, rh_dev_round rr, const uint32_t *counts, int32_t max_dist_in, uint8_t *cls)
+__global__ __launch_bounds__(64) void k_rmq_class(rh_dev_opt o, rh_dev_round rr, const uint32_t *counts, int32_t max_dist_in, uint8_t *cls, uint32_t min_cls)
 {
 	const uint32_t a = blockIdx.x;
 	if (a >= rr.n_act || rr.skip[a]) return;
@@ -596,7 +596,13 @@ __global__ __launch_bounds__(64) void k_rmq_class(rh_dev_opt o, rh_dev_round rr,
 	}
 	atomicMax(&s_widest, widest);
 	__syncthreads();
-	if (threadIdx.x == 0) { const uint32_t w = s_widest; cls[a] = w < RQ_RING_S ? 0 : w < RQ_RING ? 1 : w < RQ_RING_BIG ? 2 : 3; }
+	if (threadIdx.x == 0) {	// (a wider class than the window needs is as good: min_cls, RH_RQ_MIN_CLASS, puts every read into class min_cls or above - the hardware tests of each class)
+		const uint32_t w = s_widest;
+		uint32_t k = w < RQ_RING_S ? 0u : w < RQ_RING ? 1u : w < RQ_RING_BIG ? 2u : 3u;
+		if (k < min_cls) k = min_cls;
+		cls[a] = (uint8_t)k;
+		if (rr.counters) atomicAdd((unsigned long long*)&rr.counters[9 + k], 1ull);
+	}
 }
 
 // (the storage is a property of the launch - RING nodes in LDS, or RING = 0: the arrays in HBM - so that the compiler sees LDS addresses, not pointers that may be either)
@@ -739,7 +745,9 @@ void rhk_chain_rmq(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r, co
 {
 	if (!r.n_act) return;
 	// (need_exact2 is idle between the anchor sort and the chain-order sort: here it holds each read's storage class)
-	RH_LAUNCH(k_rmq_class, r.n_act, 64, 0, s, o, r, counts, max_dist, r.need_exact2);
+	const char *mc = getenv("RH_RQ_MIN_CLASS");                    // 0 .. 3: no read takes a narrower storage class than this (test aid: every class on the hardware)
+	const uint32_t min_cls = mc ? (uint32_t)(atoi(mc) < 0 ? 0 : atoi(mc) > 3 ? 3 : atoi(mc)) : 0u;
+	RH_LAUNCH(k_rmq_class, r.n_act, 64, 0, s, o, r, counts, max_dist, r.need_exact2, min_cls);
 	RH_LAUNCH((k_chain_rmq<RQ_RING_S, 0>), r.n_act, 64, 0, s, o, r, counts, max_dist, max_dist_inner, cap_rmq_size, r.need_exact2);
 	RH_LAUNCH((k_chain_rmq<RQ_RING, 1>), r.n_act, 64, 0, s, o, r, counts, max_dist, max_dist_inner, cap_rmq_size, r.need_exact2);
 	RH_LAUNCH((k_chain_rmq<RQ_RING_BIG, 2>), r.n_act, 64, 0, s, o, r, counts, max_dist, max_dist_inner, cap_rmq_size, r.need_exact2);

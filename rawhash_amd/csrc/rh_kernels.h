@@ -173,6 +173,19 @@ RH_HD inline void rh_an_cp(const rh_dev_round &rr, rh_mm128_t *dst, uint64_t di,
 	else dst[di] = src[si];
 }
 
+// an anchor as the round keeps it, moved through a register without taking it apart (one-word anchors: the word in .x)
+RH_HD inline rh_mm128_t rh_an_raw_ld(const rh_dev_round &rr, const rh_mm128_t *arr, uint64_t i)
+{
+	if (rr.afmt.rec8) { rh_mm128_t r; r.x = reinterpret_cast<const uint64_t*>(arr)[i]; r.y = 0; return r; }
+	return arr[i];
+}
+RH_HD inline void rh_an_raw_st(const rh_dev_round &rr, rh_mm128_t *arr, uint64_t i, const rh_mm128_t &r)
+{
+	if (rr.afmt.rec8) reinterpret_cast<uint64_t*>(arr)[i] = r.x;
+	else arr[i] = r;
+}
+RH_HD inline uint64_t rh_an_raw_x(const rh_dev_round &rr, const rh_mm128_t &r) { return rr.afmt.rec8 ? rh_rec8_key(r.x, rr.afmt.shift, rr.afmt.lo, rr.afmt.mid) : r.x; }
+
 // ---- LDS size classes of the block sorter (rh_sort.hip)
 // Size classes = LDS footprints (12 B per record + ~4.5 KB) chosen for whole workgroups per CU; the allocation granularity
 // means a class must stay clearly below 160 KB / k to get k workgroups resident (measured: 54.0 KB gives 2, 52.4 KB gives 3).

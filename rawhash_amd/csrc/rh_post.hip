@@ -136,6 +136,7 @@ __global__ __launch_bounds__(BT) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 		bool pending = k >= n_lone && !(w0 >> 31), accepted = false;     // (bit 31: a chain of one anchor that nothing else touches - k_zbuild)
 		int32_t r_cnt = 0, r_sc = 0;
 		int32_t pn1 = 0, pn2 = 0, pn3 = 0;                             // the first anchors of the path after i0 (most chains are this short)
+		rh_mm128_t a0{}, a1{}, a2{}, a3{};                             // ... and, once the chain is accepted, the anchors themselves: requested when the lane commits, stored when the batch is settled
 		for (;;) {
 			uint32_t n_pend;
 			if (BT == 64) n_pend = (uint32_t)__popcll(__ballot(pending));
@@ -192,6 +193,12 @@ __global__ __launch_bounds__(BT) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 					for (int32_t j = 4; j < emit; ++j) { x = fp[x].y; t[x] = 1; }
 					accepted = max_s >= min_sc && emit > 0 && emit >= min_cnt;   // (score of the chain = the best drop seen = max_s)
 					r_cnt = emit; r_sc = max_s;
+					if (accepted) {	// (the loads travel while the other lanes' rounds go on)
+						a0 = rh_an_raw_ld(rr, rr.anc, base + (uint32_t)i0);
+						if (emit >= 2) a1 = rh_an_raw_ld(rr, rr.anc, base + (uint32_t)pn1);
+						if (emit >= 3) a2 = rh_an_raw_ld(rr, rr.anc, base + (uint32_t)pn2);
+						if (emit >= 4) a3 = rh_an_raw_ld(rr, rr.anc, base + (uint32_t)pn3);
+					}
 				}
 				pending = false;
 			}
@@ -210,13 +217,14 @@ __global__ __launch_bounds__(BT) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 			const uint32_t ci = (uint32_t)n_u + my_rank, off = (uint32_t)n_v + my_off, last = off + (uint32_t)r_cnt - 1u;
 			u[ci] = (uint64_t)(uint32_t)r_sc << 32 | (uint64_t)(uint32_t)r_cnt;
 			ck0[ci] = off;
-			int32_t x = i0;
-			rh_an_cp(rr, rr.prev_out, base + last, rr.anc, base + (uint32_t)i0);
-			if (r_cnt >= 2) { rh_an_cp(rr, rr.prev_out, base + last - 1u, rr.anc, base + (uint32_t)pn1); x = pn1; }
-			if (r_cnt >= 3) { rh_an_cp(rr, rr.prev_out, base + last - 2u, rr.anc, base + (uint32_t)pn2); x = pn2; }
-			if (r_cnt >= 4) { rh_an_cp(rr, rr.prev_out, base + last - 3u, rr.anc, base + (uint32_t)pn3); x = pn3; }
-			for (int32_t j = 4; j < r_cnt; ++j) { x = fp[x].y; rh_an_cp(rr, rr.prev_out, base + last - (uint32_t)j, rr.anc, base + (uint32_t)x); }
-			const uint64_t x0 = rh_an_ld(rr, rr.anc, base + (uint32_t)x).x;      // the chain's first anchor
+			rh_mm128_t af = a0;                                          // the chain's first anchor = the last of the walk
+			rh_an_raw_st(rr, rr.prev_out, base + last, a0);
+			if (r_cnt >= 2) { rh_an_raw_st(rr, rr.prev_out, base + last - 1u, a1); af = a1; }
+			if (r_cnt >= 3) { rh_an_raw_st(rr, rr.prev_out, base + last - 2u, a2); af = a2; }
+			if (r_cnt >= 4) { rh_an_raw_st(rr, rr.prev_out, base + last - 3u, a3); af = a3; }
+			int32_t x = pn3;
+			for (int32_t j = 4; j < r_cnt; ++j) { x = fp[x].y; af = rh_an_raw_ld(rr, rr.anc, base + (uint32_t)x); rh_an_raw_st(rr, rr.prev_out, base + last - (uint32_t)j, af); }
+			const uint64_t x0 = rh_an_raw_x(rr, af);
 			if (rr.cfmt.rec8) reinterpret_cast<uint64_t*>(rr.raw)[base + ci] = rh_rec8_pack_key(x0, rr.cfmt.lo, rr.cfmt.mid) << rr.cfmt.shift | (uint64_t)ci;
 			else { rh_mm128_t e; e.x = x0; e.y = (uint64_t)off << 32 | (uint64_t)ci; rr.raw[base + ci] = e; }
 		}
@@ -1626,7 +1634,7 @@ int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r)
 {
 	if (!r.n_act) return 0;
-	static const bool bt_wave = getenv("RH_BT_WAVE") != nullptr;     // RH_BT_WAVE=1: one wavefront per read (A/B aid)
+	const bool bt_wave = getenv("RH_BT_WAVE") != nullptr;            // RH_BT_WAVE=1: one wavefront per read, 64 candidates a round (A/B and test aid; read per call)
 	if (bt_wave) RH_LAUNCH(k_backtrack_spec<64>, r.n_act, 64, rh_wave_lds(), s, o, rd, r);
 	else RH_LAUNCH(k_backtrack_spec<256>, r.n_act, 256, rh_wave_lds(), s, o, rd, r);
 	// compact_a: the chains (gathered by the backtrack itself) put into the reference's order of their first anchor, written back

@@ -542,33 +542,50 @@ RH_DEV void sort_run(sort_lds<CAP, KT> &L, uint32_t n, int pass)
 // ------------------------------------------------------------------------------------------------ tie-free segments of 8-byte records
 // Round 6.  What the block sorter mostly sees - the strand x target buckets of a large index's chunks, a small index's whole chunks, chain lists - are
 // segments WITHOUT equal keys, and such a segment has one sorted order however it is reached (ksort.h:101-151 leaves equal keys in an order of its own;
-// distinct keys it simply sorts).  sort_fast gets there with the records themselves in LDS and seven LDS operations per record, where the general
+// distinct keys it simply sorts).  sort_fast gets there with the records themselves in LDS and a handful of LDS operations per record, where the general
 // path keeps keys, a 16-bit arrangement and a scratch map and goes through them ~25 times (its own counters: 40 % of those cycles were bank conflicts,
 // and more than a quarter of the kernel's time was waiting for the first load and for the second read of the records at the end):
 //   1. records -> registers; minimum and maximum of the packed keys (record >> shift: the fields keep their significance, rh_rec_fmt);
-//   2. bucket = (key - min) >> s with s such that the range fills NB = CAP / 2 buckets (mean 1 - 4 records each); ONE LDS atomic per record
-//      gives both the bucket's count and the record's rank inside it (16-bit counters, two to a word);
+//   2. bucket = ((key - min) * m) >> s2, m in 16 .. 31 and s2 such that the key range fills NB = CAP / 8 buckets to 94 % or more: 4 - 8 records a bucket
+//      whatever the range is (a plain shift fills between half and all of them); ONE LDS atomic per record gives both the bucket's count and the
+//      record's rank inside it;
 //   3. counts -> start offsets (a thread owns NB / NT consecutive buckets, here and in 5);
 //   4. records scattered into LDS at start + rank;
-//   5. every lane sorts its buckets: the words (low key bits << 5 | place) of up to 16 records in a bitonic network in registers, equal neighbours
-//      = equal keys (they share a bucket), the records permuted inside the bucket;
+//   5. every lane sorts its buckets: the words (key - the bucket's lower bound) << 5 | place of up to 16 records in a bitonic network in registers
+//      (first version: CAP / 2 buckets of 1 - 4 records, eight rounds of a 16-word network per thread - the networks were 62 % of the kernel, a
+//      round costs what it costs however few records it holds), equal neighbours = equal keys (they share a bucket), the records permuted inside the
+//      bucket; a bucket of more than 16 records - the tail, or the anchors of a mapped read at its locus, a few hundred within a few hundred positions - is sorted
+//      by a whole wavefront (network across the lanes);
 //   6. the sorted records stream out of LDS to the destination - no second read of the source.
 // Returns 0: done; 1: the segment holds equal keys (nothing written: the caller's exact passes take it from the input order); 2: not for this path
-// (a bucket of more than 16 records, more than 27 key bits below the buckets).
+// (more buckets of more than 16 records than a short list holds, or one of more than 256 / 512; a key range of more than 2^35).
 template <int CAP> struct sort_fast_cfg {
-	static constexpr int nb() { int v = NT; while (v < CAP / 2) v *= 2; return v; }
+	static constexpr int nb() { int v = NT; while (v < CAP / 8) v *= 2; return v; }
 	static constexpr int NB = nb(), BPT = NB / NT, K = (CAP + NT - 1) / NT;
 	static constexpr int lb() { int l = 0; while ((1 << l) < NB) ++l; return l; }
 	static constexpr int LB = lb();
 	static constexpr bool HOLD = K <= 16;                     // records stay in registers between the passes (else they are read again: L2)
 };
+#define SORT_FAST_BIG 48
+// a wavefront's bucket holds up to 64 x EMAX records; EMAX words a lane: 8 spill in the classes that run six wavefronts a SIMD (80 registers)
+template <int CAP> struct sort_fast_big { static constexpr int EMAX = CAP >= 4096 ? 8 : 4, MAX = 64 * EMAX; };
 template <int CAP>
 struct alignas(16) sort_fast_lds {
-	uint64_t rec[CAP];
-	uint32_t cnt[sort_fast_cfg<CAP>::NB / 2];                 // per bucket: count, then start offset (16 bits each)
+	uint64_t rec[CAP + 16 + NT];                              // (+ 16: a lane reads the 16 slots from its bucket's start whatever the bucket holds; + NT: where each thread's masked stores go)
+	uint32_t cnt[sort_fast_cfg<CAP>::NB];                     // per bucket: count, then start offset
 	uint64_t r64[2 * (NT / 64)];
 	uint32_t w[NT / 64];
-	uint32_t flag;
+	uint32_t flag, n_big;
+	uint32_t big[SORT_FAST_BIG];                              // buckets of more than 16 records (start | count << 16): a wavefront each
+	uint32_t big_lo[2 * SORT_FAST_BIG];                        // ... and the lower bound of their keys (relative to the minimum; two words)
+};
+// how a key finds its bucket, and the lower bound of a bucket's keys
+struct sort_fast_map {
+	uint64_t kmin; uint32_t shift, m, s2; double inv;
+	__device__ __forceinline__ uint64_t rel(uint64_t rec) const { return (rec >> shift) - kmin; }
+	__device__ __forceinline__ uint32_t bucket(uint64_t r) const { return (uint32_t)((r * m) >> s2); }
+	// rel >= d * 2^s2 / m for every key of bucket d; one below the rounded quotient: the double product is exact to far less than 1
+	__device__ __forceinline__ uint64_t lower(uint32_t d) const { if (m == 1u) return (uint64_t)d; const uint64_t q = (uint64_t)((double)d * inv); return q ? q - 1ull : 0ull; }
 };
 
 template <int W>
@@ -584,31 +601,100 @@ RH_DEV void sort_lane_net(uint32_t (&c)[W])
 				if (l2 > i) { const uint32_t lo = c[i] < c[l2] ? c[i] : c[l2], hi = c[i] < c[l2] ? c[l2] : c[i]; if ((i & kk) == 0) { c[i] = lo; c[l2] = hi; } else { c[i] = hi; c[l2] = lo; } }
 			}
 }
-// one bucket [st, st + m) per lane, m <= W
+// one bucket [st, st + m) per lane, m <= W <= 16; lo = lower bound of its keys (relative to the minimum): key - lo < 2^26 + 2.
+// Straight-line code, no lane-dependent branches: the W slots from st are read whatever m is (rec[] is padded), the slots beyond m take words that sort
+// behind every key and differ from one another in their upper 27 bits (no false "equal neighbours"), the stores of the slots beyond m go to a slot of the
+// thread's own behind the array.
 template <int CAP, int W>
-RH_DEV bool sort_fast_bucket(sort_fast_lds<CAP> &F, uint32_t st, uint32_t m, uint32_t shift, uint32_t kmin_lo, uint32_t lowmask)
+RH_DEV bool sort_fast_bucket(sort_fast_lds<CAP> &F, uint32_t st, uint32_t m, const sort_fast_map &M, uint64_t lo)
 {
 	uint32_t c[W];
+	const uint32_t lo32 = (uint32_t)(lo + M.kmin);                // (the difference is below 2^27: 32-bit arithmetic on the low words)
+	const uint64_t *b = F.rec + st;
 #pragma unroll
 	for (int j = 0; j < W; ++j) {
-		c[j] = 0xFFFFFFFFu;
-		if ((uint32_t)j < m) c[j] = (((uint32_t)(F.rec[st + j] >> shift) - kmin_lo) & lowmask) << 5 | (uint32_t)j;
+		const uint32_t w = ((uint32_t)(b[j] >> M.shift) - lo32) << 5 | (uint32_t)j;
+		c[j] = (uint32_t)j < m ? w : ((0x7FFFFFFu - (uint32_t)j) << 5 | (uint32_t)j);
 	}
 	sort_lane_net<W>(c);
-	bool tie = false;
+	uint32_t mind = 0xFFFFFFFFu;                                   // equal keys = neighbours that agree above bit 4
 #pragma unroll
-	for (int j = 1; j < W; ++j) if ((uint32_t)j < m && (c[j] >> 5) == (c[j - 1] >> 5)) tie = true;
+	for (int j = 1; j < W; ++j) { const uint32_t x = c[j] ^ c[j - 1]; mind = x < mind ? x : mind; }
 	uint64_t nx[W];
 #pragma unroll
-	for (int j = 0; j < W; ++j) nx[j] = (uint32_t)j < m ? F.rec[st + (c[j] & 31u)] : 0ull;
+	for (int j = 0; j < W; ++j) nx[j] = b[c[j] & 31u];
+	uint64_t *dummy = F.rec + CAP + 16 + threadIdx.x;
 #pragma unroll
-	for (int j = 0; j < W; ++j) if ((uint32_t)j < m) F.rec[st + j] = nx[j];
-	return tie;
+	for (int j = 0; j < W; ++j) { uint64_t *q = (uint32_t)j < m ? F.rec + st + j : dummy; *q = nx[j]; }
+	return mind < 32u;
+}
+// one bucket [st, st + m) of 17 .. 64 E records per WAVEFRONT: words (key - lower bound) << 16 | place, element i in lane i & 63, register i >> 6; bitonic
+// network, the steps between lanes by shuffles
+template <int CAP, int E>
+RH_DEV bool sort_fast_wave(sort_fast_lds<CAP> &F, uint32_t st, uint32_t m, const sort_fast_map &M, uint64_t lo)
+{
+	const uint32_t lane = lane_id();
+	const uint32_t lo32 = (uint32_t)(lo + M.kmin);
+	uint64_t w[E];
+#pragma unroll
+	for (int e = 0; e < E; ++e) {
+		const uint32_t i = lane + 64u * (uint32_t)e;
+		w[e] = ~0ull;
+		if (i < m) w[e] = (uint64_t)((uint32_t)(F.rec[st + i] >> M.shift) - lo32) << 16 | (uint64_t)i;
+	}
+#pragma unroll
+	for (int k = 2; k <= 64 * E; k <<= 1) {
+#pragma unroll
+		for (int j = k >> 1; j > 0; j >>= 1) {
+			if (j >= 64) {	// partners in the same lane
+#pragma unroll
+				for (int e = 0; e < E; ++e) {
+					const int pe = e ^ (j >> 6);
+					if (pe > e) {
+						const bool up = ((64 * e) & k) == 0;
+						const uint64_t lo_ = w[e] < w[pe] ? w[e] : w[pe], hi_ = w[e] < w[pe] ? w[pe] : w[e];
+						w[e] = up ? lo_ : hi_; w[pe] = up ? hi_ : lo_;
+					}
+				}
+			} else {
+#pragma unroll
+				for (int e = 0; e < E; ++e) {
+					const uint32_t i = lane + 64u * (uint32_t)e;
+					const bool up = (i & (uint32_t)k) == 0, keep_min = ((lane & (uint32_t)j) == 0) == up;
+					const uint64_t p = __shfl_xor(w[e], j);
+					const uint64_t lo_ = w[e] < p ? w[e] : p, hi_ = w[e] < p ? p : w[e];
+					w[e] = keep_min ? lo_ : hi_;
+				}
+			}
+		}
+	}
+	bool tie = false;
+	uint64_t nx[E];
+#pragma unroll
+	for (int e = 0; e < E; ++e) {
+		const uint32_t i = lane + 64u * (uint32_t)e;
+		uint64_t prev = __shfl_up(w[e], 1);
+		if (e > 0) { const uint64_t last = __shfl(w[e > 0 ? e - 1 : 0], 63); if (lane == 0) prev = last; }
+		if (i > 0 && i < m && (prev >> 16) == (w[e] >> 16)) tie = true;
+		nx[e] = i < m ? F.rec[st + (uint32_t)(w[e] & 0xFFFFu)] : 0ull;
+	}
+	RH_WAVE_SYNC();                                               // every lane has read the bucket before it is rewritten
+#pragma unroll
+	for (int e = 0; e < E; ++e) { const uint32_t i = lane + 64u * (uint32_t)e; if (i < m) F.rec[st + i] = nx[e]; }
+	return __ballot(tie) != 0;
 }
 
+#ifdef RH_KPROF
+#define FPROF(slot) do { if (prof && threadIdx.x == 0) { const unsigned long long t_ = clock64(); atomicAdd(&rh_kprof_acc[slot], t_ - fp_t0); fp_t0 = t_; } } while (0)
+#else
+#define FPROF(slot)
+#endif
 template <int CAP>
-RH_DEV int sort_fast(sort_fast_lds<CAP> &F, const uint64_t *src, uint64_t *dst, uint32_t n, uint32_t shift)
+RH_DEV int sort_fast(sort_fast_lds<CAP> &F, const uint64_t *src, uint64_t *dst, uint32_t n, uint32_t shift, bool prof)
 {
+#ifdef RH_KPROF
+	unsigned long long fp_t0 = clock64();
+#endif
 	typedef sort_fast_cfg<CAP> CF;
 	constexpr int K = CF::K, NB = CF::NB, BPT = CF::BPT, LB = CF::LB;
 	constexpr int KH = CF::HOLD ? K : 1;
@@ -630,19 +716,26 @@ RH_DEV int sort_fast(sort_fast_lds<CAP> &F, const uint64_t *src, uint64_t *dst, 
 			for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; if (i < n) { const uint64_t kk = x[u] >> shift; kmin = kk < kmin ? kk : kmin; kmax = kk > kmax ? kk : kmax; } }
 		}
 	}
-	for (uint32_t b = tid; b < (uint32_t)NB / 2; b += NT) F.cnt[b] = 0;
-	if (tid == 0) F.flag = 0;
+	for (uint32_t b = tid; b < (uint32_t)NB; b += NT) F.cnt[b] = 0;
+	if (tid == 0) { F.flag = 0; F.n_big = 0; }
 	for (int d = 32; d > 0; d >>= 1) { const uint64_t a = __shfl_xor(kmin, d), b = __shfl_xor(kmax, d); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
 	if (lane_id() == 0) { F.r64[wave_id()] = kmin; F.r64[NT / 64 + wave_id()] = kmax; }
 	__syncthreads();
 #pragma unroll
 	for (int q = 0; q < NT / 64; ++q) { const uint64_t a = F.r64[q], b = F.r64[NT / 64 + q]; kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+	FPROF(13);
 	const uint64_t range = kmax - kmin;
 	if (range == 0) return 1;                                    // n >= 2 equal keys
 	const int bits = 64 - __clzll(range);
-	const uint32_t s = bits > LB ? (uint32_t)(bits - LB) : 0u;
-	if (s > 27u) return 2;
-	const uint32_t lowmask = (1u << s) - 1u, kmin_lo = (uint32_t)kmin;
+	sort_fast_map M;
+	M.kmin = kmin; M.shift = shift; M.m = 1u; M.s2 = 0u; M.inv = 1.0;
+	if (bits > LB) {	// (range + 1) * m / 2^s2 <= NB with m the largest of 16 .. 31 that keeps it so: the last bucket used is NB * m / (m + 1) or later
+		M.s2 = (uint32_t)(bits + 4 - LB);
+		if (M.s2 > 30u) return 2;                                 // a bucket's keys would not fit 27 bits
+		const uint64_t q = ((uint64_t)NB << M.s2) / (range + 1ull);
+		M.m = q > 31ull ? 31u : (uint32_t)q;
+		M.inv = (double)(1ull << M.s2) / (double)M.m;
+	}
 	// bucket and rank of every record: one atomic each
 	uint32_t dr[K];
 	if constexpr (CF::HOLD) {
@@ -650,7 +743,7 @@ RH_DEV int sort_fast(sort_fast_lds<CAP> &F, const uint64_t *src, uint64_t *dst, 
 		for (int k = 0; k < K; ++k) {
 			const uint32_t i = tid + (uint32_t)k * NT;
 			dr[k] = 0;
-			if (i < n) { const uint32_t d = (uint32_t)(((r[k] >> shift) - kmin) >> s); const uint32_t old = atomicAdd(&F.cnt[d >> 1], 1u << (16u * (d & 1u))); dr[k] = d | ((old >> (16u * (d & 1u))) & 0xFFFFu) << 16; }
+			if (i < n) { const uint32_t d = M.bucket(M.rel(r[k])); dr[k] = d | atomicAdd(&F.cnt[d], 1u) << 16; }
 		}
 	} else {
 #pragma unroll
@@ -663,39 +756,36 @@ RH_DEV int sort_fast(sort_fast_lds<CAP> &F, const uint64_t *src, uint64_t *dst, 
 				if (k0 + u >= K) continue;
 				const uint32_t i = tid + (uint32_t)(k0 + u) * NT;
 				dr[k0 + u] = 0;
-				if (i < n) { const uint32_t d = (uint32_t)(((x[u] >> shift) - kmin) >> s); const uint32_t old = atomicAdd(&F.cnt[d >> 1], 1u << (16u * (d & 1u))); dr[k0 + u] = d | ((old >> (16u * (d & 1u))) & 0xFFFFu) << 16; }
+				if (i < n) { const uint32_t d = M.bucket(M.rel(x[u])); dr[k0 + u] = d | atomicAdd(&F.cnt[d], 1u) << 16; }
 			}
 		}
 	}
 	__syncthreads();
+	FPROF(14);
 	// counts -> start offsets; this thread's buckets stay in its registers for step 5
-	uint32_t bc[BPT], bs[BPT], sum = 0, mx = 0;
+	uint32_t bc[BPT], bs[BPT], sum = 0;
 #pragma unroll
-	for (int q = 0; q < BPT; ++q) {
-		const uint32_t b = tid * (uint32_t)BPT + (uint32_t)q;
-		bc[q] = (F.cnt[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu;
-		sum += bc[q]; mx = bc[q] > mx ? bc[q] : mx;
-	}
+	for (int q = 0; q < BPT; ++q) { bc[q] = F.cnt[tid * (uint32_t)BPT + (uint32_t)q]; sum += bc[q]; }
 	uint32_t tot;
 	uint32_t ex = block_excl_scan(sum, F.w, tot);                 // (its first barrier: every thread has read its counts)
 #pragma unroll
-	for (int q = 0; q < BPT; ++q) { bs[q] = ex; ex += bc[q]; }
-	if (BPT >= 2) {
+	for (int q = 0; q < BPT; ++q) { bs[q] = ex; ex += bc[q]; F.cnt[tid * (uint32_t)BPT + (uint32_t)q] = bs[q]; }
+	// (a bucket of more than 16 records - the tail of the distribution, or a mapped read's anchors at its locus - is a wavefront's, below; more or larger ones than the list takes: not for this path)
 #pragma unroll
-		for (int q = 0; q < BPT; q += 2) F.cnt[(tid * (uint32_t)BPT + (uint32_t)q) >> 1] = bs[q] | bs[q + 1 < BPT ? q + 1 : q] << 16;
-	} else {	// one bucket per thread: the even lane writes the pair
-		const uint32_t up = __shfl_xor(bs[0], 1);
-		if ((tid & 1u) == 0) F.cnt[tid >> 1] = bs[0] | up << 16;
+	for (int q = 0; q < BPT; ++q) if (bc[q] > 16u) {
+		const uint32_t k = bc[q] <= (uint32_t)sort_fast_big<CAP>::MAX ? atomicAdd(&F.n_big, 1u) : (uint32_t)SORT_FAST_BIG;
+		if (k < (uint32_t)SORT_FAST_BIG) { F.big[k] = bs[q] | bc[q] << 16; const uint64_t lo = M.lower(tid * (uint32_t)BPT + (uint32_t)q); F.big_lo[2 * k] = (uint32_t)lo; F.big_lo[2 * k + 1] = (uint32_t)(lo >> 32); }
+		else F.flag = 1;
 	}
-	if (mx > 16u) F.flag = 1;
 	__syncthreads();
+	FPROF(15);
 	if (F.flag) return 2;
 	// scatter
 	if constexpr (CF::HOLD) {
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
 			const uint32_t i = tid + (uint32_t)k * NT;
-			if (i < n) { const uint32_t d = dr[k] & 0xFFFFu; F.rec[((F.cnt[d >> 1] >> (16u * (d & 1u))) & 0xFFFFu) + (dr[k] >> 16)] = r[k]; }
+			if (i < n) F.rec[F.cnt[dr[k] & 0xFFFFu] + (dr[k] >> 16)] = r[k];
 		}
 	} else {
 #pragma unroll
@@ -707,23 +797,40 @@ RH_DEV int sort_fast(sort_fast_lds<CAP> &F, const uint64_t *src, uint64_t *dst, 
 			for (int u = 0; u < 8; ++u) {
 				if (k0 + u >= K) continue;
 				const uint32_t i = tid + (uint32_t)(k0 + u) * NT;
-				if (i < n) { const uint32_t d = dr[k0 + u] & 0xFFFFu; F.rec[((F.cnt[d >> 1] >> (16u * (d & 1u))) & 0xFFFFu) + (dr[k0 + u] >> 16)] = x[u]; }
+				if (i < n) F.rec[F.cnt[dr[k0 + u] & 0xFFFFu] + (dr[k0 + u] >> 16)] = x[u];
 			}
 		}
 	}
 	__syncthreads();
+	FPROF(16);
 	// every lane sorts its buckets
 	bool tie = false;
 #pragma unroll
 	for (int q = 0; q < BPT; ++q) {
-		const uint32_t m = bc[q];
-		if (__ballot(m > 8u)) tie |= sort_fast_bucket<CAP, 16>(F, bs[q], m, shift, kmin_lo, lowmask);
-		else if (__ballot(m > 1u)) tie |= sort_fast_bucket<CAP, 8>(F, bs[q], m, shift, kmin_lo, lowmask);
+		const uint32_t m = bc[q] > 16u ? 0u : bc[q];
+		const uint64_t lo = M.lower(tid * (uint32_t)BPT + (uint32_t)q);
+		if (__ballot(m > 8u)) tie |= sort_fast_bucket<CAP, 16>(F, bs[q], m, M, lo);
+		else if (__ballot(m > 1u)) tie |= sort_fast_bucket<CAP, 8>(F, bs[q], m, M, lo);
+	}
+	{
+		const uint32_t nbig = F.n_big;                                // (written before the barriers above)
+		for (uint32_t q = wave_id(); q < nbig; q += NT / 64) {
+			const uint32_t e = rh_uniform(F.big[q]), st = e & 0xFFFFu, m = e >> 16;
+			const uint64_t lo = (uint64_t)rh_uniform(F.big_lo[2 * q]) | (uint64_t)rh_uniform(F.big_lo[2 * q + 1]) << 32;
+			bool t2;
+			if (m <= 64u) t2 = sort_fast_wave<CAP, 1>(F, st, m, M, lo);
+			else if (m <= 128u) t2 = sort_fast_wave<CAP, 2>(F, st, m, M, lo);
+			else if (m <= 256u || sort_fast_big<CAP>::EMAX < 8) t2 = sort_fast_wave<CAP, 4>(F, st, m, M, lo);
+			else t2 = sort_fast_wave<CAP, sort_fast_big<CAP>::EMAX>(F, st, m, M, lo);
+			tie |= t2;
+		}
 	}
 	if (tie) F.flag = 1;
 	__syncthreads();
+	FPROF(17);
 	if (F.flag) return 1;
 	for (uint32_t i = tid; i < n; i += NT) dst[i] = F.rec[i];
+	FPROF(18);
 	return 0;
 }
 
@@ -751,9 +858,10 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 	KPROF_DECL;
 	if constexpr (FAST) {
 		if (mode == 0 && jb.fast_on) {	// segments without equal keys (nearly all): records in LDS, one pass into CAP / 2 buckets, a register network per bucket
-			const int fr = sort_fast<CAP>(U.F, reinterpret_cast<const uint64_t*>(src), reinterpret_cast<uint64_t*>(dst), n, rf.shift);
+			const int fr = sort_fast<CAP>(U.F, reinterpret_cast<const uint64_t*>(src), reinterpret_cast<uint64_t*>(dst), n, rf.shift, jb.scratch_skip == 0);
 #ifdef RH_KPROF
-			if (tid == 0 && jb.scratch_skip == 0) { const unsigned long long t_ = clock64(); atomicAdd(&rh_kprof_acc[13], t_ - kp_t0); kp_t0 = t_; }   // (L.prof is not set yet, and shares its bytes with the records)
+			kp_t0 = clock64();
+			if (tid == 0 && jb.scratch_skip == 0) { atomicAdd(&rh_kprof_acc[20 + fr], 1ull); atomicAdd(&rh_kprof_acc[23], (unsigned long long)n); }   // outcomes of the tie-free path: done / equal keys / not for it; records seen
 #endif
 #ifdef RH_FAST_TRACE
 			if (tid == 0) fprintf(stderr, "FAST cap %d n %u -> %d\n", CAP, n, fr);

@@ -385,8 +385,15 @@ def check_sort_packed(ctx, seed=0, sizes=None, any_order=False, lo=27, mid=5):
         pos = rng.permutation(np.unique(rng.integers(0, 1 << lo, size=2 * n + 64, dtype=np.uint64)))[:n]
         if kind == 0:
             x = strand | tgt | pos
-        elif kind == 1:
+        elif kind == 1:    # one strand and target, and - a mapped read's anchors at its locus - up to 400 distinct positions within a window of 600 among them
             x = (np.uint64(1) << np.uint64(63)) | (np.uint64(3 % tmax) << np.uint64(32)) | pos
+            nc = min(n // 3, 400)
+            if nc > 20:
+                w0 = int(rng.integers(0, (1 << lo) - 700))
+                x = np.unique(np.concatenate([x[nc:], (np.uint64(1) << np.uint64(63)) | (np.uint64(3 % tmax) << np.uint64(32)) | (np.uint64(w0) + rng.permutation(600).astype(np.uint64)[:nc])]))
+                while len(x) < n:
+                    x = np.unique(np.concatenate([x, (np.uint64(1) << np.uint64(63)) | (np.uint64(3 % tmax) << np.uint64(32)) | rng.integers(0, 1 << lo, size=n - len(x), dtype=np.uint64)]))
+                x = rng.permutation(x)
         elif kind == 2:
             x = (np.uint64(2 % tmax) << np.uint64(32)) | pos
             for _ in range(int(rng.integers(1, 4))):

@@ -95,6 +95,37 @@ def test_rmq_chaining(make_workload, product_lib, gpu_ctx_factory, mapopt):
     pc.check_e2e(c, w)
 
 
+@pytest.mark.parametrize("min_class", [0, 1, 2, 3])
+def test_rmq_storage_classes_on_device(make_workload, product_lib, gpu_ctx_factory, monkeypatch, min_class):
+    """The RMQ trees' four storage classes (LDS rings of 64 / 128 / 512 nodes, HBM: rh_chain.hip k_chain_rmq<RING, class>) each forced on the real device -
+    RH_RQ_MIN_CLASS puts every read into that class or a wider one, which is as exact - against the oracle, end to end and on adversarial anchor sets;
+    the per-class counters of the call say which classes ran."""
+    monkeypatch.setenv("RH_RQ_MIN_CLASS", str(min_class))
+    w = make_workload(n_reads=300, n_samples=20_000, mapopt={"flag": 2, "rmq_inner_dist": 300})
+    c = gpu_ctx_factory()
+    c.upload(w.index)
+    n_an, n_ch, n_u = pc.check_chain_synthetic(c, w, seed=17 + min_class, n_reads=120, max_n=1500)
+    assert n_ch > 0 and n_u > 0
+    pc.check_e2e(c, w)
+    cls = c.stats()["n_rmq_class"]
+    assert sum(cls[:min_class]) == 0 and cls[min_class] > 0, cls
+
+
+def test_backtrack_widths_agree(make_workload, product_lib, gpu_ctx_factory, monkeypatch):
+    """k_backtrack_spec<256> (a workgroup per read, 256 candidates a round: the default) and <64> (a wavefront per read, RH_BT_WAVE=1) against the oracle
+    on the same reads - the speculative walks commit in a different order in the two, the chains must not differ."""
+    w = make_workload(n_reads=300, n_samples=20_000)
+    for wave in (False, True):
+        if wave:
+            monkeypatch.setenv("RH_BT_WAVE", "1")
+        c = gpu_ctx_factory()
+        c.upload(w.index)
+        for n_reads, max_n, seed in ((48, 900, 41), (1200, 260, 42)):
+            n_an, n_ch, n_u = pc.check_chain_synthetic(c, w, seed=seed, n_reads=n_reads, max_n=max_n)
+            assert n_ch > 0 and n_u > 0
+        pc.check_e2e(c, w)
+
+
 @pytest.mark.parametrize("mapopt", [{"flag": 0x40}, {"flag": 0x40, "dtw_border_constraint": 0}, {"flag": 0x40, "dtw_fill_method": 0, "dtw_min_score": 5.0}],
                          ids=lambda m: "_".join(f"{k}{v}" for k, v in m.items()))
 def test_dtw_rescoring(make_workload, product_lib, gpu_ctx_factory, mapopt):
@@ -363,6 +394,9 @@ def test_golden_paf(product_lib, gpu_ctx_factory, tmp_path):
         want = golden.expected_paf(case)
         bad = [(g, x) for g, x in zip(got, want) if g != x]
         assert len(got) == len(want) and not bad, f"{case['name']}: {len(bad)} PAF lines differ, first: {bad[:1]}"
+        if case["name"] == "config3_dmel_144M_rmq":     # 35 k anchors a chunk: every storage class of the RMQ trees has its reads
+            cls = c.stats()["n_rmq_class"]
+            assert all(x > 0 for x in cls), f"RMQ storage classes that never ran at config-3 size: {cls}"
 
 
 def test_repeat_rich_golden(product_lib, gpu_ctx_factory, tmp_path):

@@ -13,7 +13,7 @@
 # WORKLOAD=ecoli|dmel|ava (default: human) selects the bench workload for one / stage / mix.
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; O=$R/gpurun_out; MODE=${1:-one}; TAG=${2:-m}; shift 2 2>/dev/null; mkdir -p $O
-WL=${WORKLOAD:+--workload $WORKLOAD}
+WL=${WORKLOAD:+--workload $WORKLOAD}; [ -n "$WORKLOAD" ] && export RH_PMC_WORKLOAD=$WORKLOAD
 line() { python - "$@" <<'PY'
 import json, sys
 for f in sys.argv[1:]:
