@@ -394,9 +394,9 @@ def test_golden_paf(product_lib, gpu_ctx_factory, tmp_path):
         want = golden.expected_paf(case)
         bad = [(g, x) for g, x in zip(got, want) if g != x]
         assert len(got) == len(want) and not bad, f"{case['name']}: {len(bad)} PAF lines differ, first: {bad[:1]}"
-        if case["name"] == "config3_dmel_144M_rmq":     # 35 k anchors a chunk: every storage class of the RMQ trees has its reads
-            cls = c.stats()["n_rmq_class"]
-            assert all(x > 0 for x in cls), f"RMQ storage classes that never ran at config-3 size: {cls}"
+        if case["name"] == "config3_dmel_144M_rmq":     # 35 k anchors a chunk: the windows of live nodes still fit the two small LDS rings (measured: 224 / 13 / 0 / 0
+            cls = c.stats()["n_rmq_class"]              # (read, chunk) pairs) - the wider classes run on the hardware in test_rmq_storage_classes_on_device
+            assert cls[0] > 0 and cls[1] > 0, f"RMQ storage classes at config-3 size: {cls}"
 
 
 def test_repeat_rich_golden(product_lib, gpu_ctx_factory, tmp_path):
