@@ -192,7 +192,7 @@ def main():
         turn += 1
         st = ctx.stats()
         for k, v in st.items():
-            if k not in ("stages", "ms_total"):
+            if k not in ("stages", "ms_total") and not isinstance(v, (list, tuple)):
                 acc[k] = acc.get(k, 0) + v
         for k, (ms, n) in st["stages"].items():
             stage_ms[k] = stage_ms.get(k, 0.0) + ms
@@ -343,7 +343,7 @@ def bench_big_set(args, ctx, wl, opts, index, model, workdir, preset, wl_name, n
         per_call.append(round(1e3 * dt, 1))
         n_mapped += int(recs["mapped"].sum())
         for k, v in ctx.stats().items():
-            if k not in ("stages", "ms_total"):
+            if k not in ("stages", "ms_total") and not isinstance(v, (list, tuple)):
                 acc[k] = acc.get(k, 0) + v
         for st in starts:
             lo, hi = max(st, s0), min(st + blk, s0 + n)
@@ -464,7 +464,7 @@ def bench_ava(args):
         recs, off = ctx.map_batch_multi(opts, reads, index, max_records=cap, device_batch=dev)
         st = ctx.stats()
         for k, v in st.items():
-            if k not in ("stages", "ms_total"):
+            if k not in ("stages", "ms_total") and not isinstance(v, (list, tuple)):
                 acc[k] = acc.get(k, 0) + v
         for k, (ms, c) in st["stages"].items():
             stage_ms[k] = stage_ms.get(k, 0.0) + ms

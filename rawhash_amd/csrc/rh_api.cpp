@@ -56,6 +56,17 @@ struct DevBuf {
 		p = nb.p; cap = nb.cap; nb.p = nullptr;
 		return 0;
 	}
+	// grow to `want` bytes if that fits, else to `bytes` (the least that will do), keeping the first `used` bytes; no growth margin on top: the caller has sized `want`
+	int ensure_keep_sized(size_t bytes, size_t want, size_t used, hipStream_t s)
+	{
+		if (bytes <= cap) return 0;
+		DevBuf nb;
+		if (want <= bytes || nb.ensure(want, false)) { if (nb.ensure(bytes, false)) return -1; g_oom = false; }
+		if (p && used) { RH_HIP(hipMemcpyAsync(nb.p, p, used, hipMemcpyDeviceToDevice, s)); RH_HIP(hipStreamSynchronize(s)); }
+		if (p) (void)hipFree(p);
+		p = nb.p; cap = nb.cap; nb.p = nullptr;
+		return 0;
+	}
 	void release() { if (p && owned) (void)hipFree(p); p = nullptr; cap = 0; owned = true; }
 	template <class T> T *as() const { return (T*)p; }
 };
@@ -1023,7 +1034,12 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 				RH_HIP(hipMemcpyAsync(c->pin + 4, c->n_act_dev.as<uint64_t>() + 2, 8, hipMemcpyDeviceToHost, s));
 				RH_HIP(hipStreamSynchronize(s));
 				const uint64_t add = c->pin[4];
-				if (c->carry[which].ensure_keep((carry_used + add + 1) * 16, carry_used * 16, s)) return -1;
+				// (one-word anchors are carried as words: 8 bytes each.  The buffer is sized once a round, from what the slices so far say about the rest of them - a growth
+				// step of a half with the old buffer still there was what large calls ran out of memory on: 262 144 reads a call, round 0, 12 GB beside 12 GB)
+				const size_t esz = (rs.afmt.rec8 && !ava) ? 8 : 16;
+				const uint64_t seen = carry_used + add, n_sl = cuts.size() - 1;
+				const uint64_t est = n_sl > si + 1 ? (uint64_t)((double)seen * (double)n_sl / (double)(si + 1) * 1.1) + 4096 : seen + 1;
+				if (c->carry[which].ensure_keep_sized((size_t)(seen + 1) * esz, (size_t)(est + 1) * esz, (size_t)carry_used * esz, s)) return -1;
 				rhk_carry_copy(s, rd, rs.act, n, rs.prev_out, c->carry_off.as<uint64_t>(), c->carry[which].as<rh_mm128_t>(), (rs.afmt.rec8 && !ava) ? 1 : 0);
 				carry_used += add;
 				return 0;
@@ -1211,6 +1227,10 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 			allow = avail / (size_t)n_sub;
 		}
 	}
+	// (what an out-of-memory retry of an earlier call taught a sub-batch context - "map in slices of so many reads" - came from that call's sizes and from
+	// what the other sub-batches happened to hold at that moment: it does not carry over, or one tight warm-up call leaves every later call mapping in crumbs)
+	c->slice_hint = 0;
+	for (rh_ctx *sc : c->subs) sc->slice_hint = 0;
 	const auto t_begin = std::chrono::steady_clock::now();
 	std::vector<int> rc(n_sub, 0);
 	std::vector<std::string> err(n_sub);
@@ -1246,6 +1266,7 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 		tot.n_reads += q.n_reads; tot.n_chunks += q.n_chunks; tot.n_samples_raw += q.n_samples_raw; tot.n_samples_used += q.n_samples_used;
 		tot.n_events += q.n_events; tot.n_seeds += q.n_seeds; tot.n_hits += q.n_hits; tot.n_anchors += q.n_anchors; tot.n_chained += q.n_chained;
 		for (int i = 0; i < 24; ++i) { tot.ms_kernel[i] += q.ms_kernel[i]; tot.n_launch[i] += q.n_launch[i]; }
+		for (int i = 0; i < 4; ++i) tot.n_rmq_class[i] += q.n_rmq_class[i];
 	}
 	tot.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 	c->stats = tot;
