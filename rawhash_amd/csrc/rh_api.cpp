@@ -84,6 +84,7 @@ struct rh_ctx_s {
 	rh_dev_index dix{};
 	bool have_index = false;
 	bool akey_on = false; uint8_t akey_lo = 0, akey_mid = 0;      // dimensions of the anchor keys of the resident index
+	size_t carry_per_read = 0;                                    // most bytes of chained anchors a round carried per read of its call, over this context's calls (map_batch_single sizes its calls by it)
 	unsigned char header[256] = {0};
 	// logf table
 	DevBuf logf_tab;
@@ -1042,6 +1043,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 				if (c->carry[which].ensure_keep_sized((size_t)(seen + 1) * esz, (size_t)(est + 1) * esz, (size_t)carry_used * esz, s)) return -1;
 				rhk_carry_copy(s, rd, rs.act, n, rs.prev_out, c->carry_off.as<uint64_t>(), c->carry[which].as<rh_mm128_t>(), (rs.afmt.rec8 && !ava) ? 1 : 0);
 				carry_used += add;
+				if (si + 2 == cuts.size() && R) { const size_t per = (size_t)(carry_used * esz / R) + 1; if (per > c->carry_per_read) c->carry_per_read = per; }   // (the round's last slice: bytes carried per read of the call)
 				return 0;
 			};
 			{ StageTimer t(c, ST_EXPAND); rhk_expand(s, o, c->dix, rd, rs); }
@@ -1130,6 +1132,11 @@ int map_batch_single(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
 			size_t per_read = (size_t)(RH_CHUNK_MAX + 64) * 12 + (size_t)RH_EV_CAP * 44 + 4096;
 			if (mo->flag & RH_M_DTW_EVALUATE_CHAINS) per_read += (size_t)mo->max_num_chunk * RH_EV_CAP * 4 * 5 + 256;   // reg->events of every chunk + the DP buffers (4 x the events so far), see dtw_regions_stage
+			// ... and what else a read keeps on the device for the whole call: its signal when the batch comes from the host, and its chained anchors in the two
+			// dense carry buffers (round 6: with 87 000 reads a sub-batch - a 262 144-read call - these were what the anchor arenas, sized before them, left no room for;
+			// the carry per read is what this context saw in its last calls, 128 KB before it has seen any)
+			if (!in->samples_on_device && R) per_read += (size_t)((in->offsets[R] - in->offsets[0]) / R) * 2 + 64;
+			per_read += 2 * (c->carry_per_read ? c->carry_per_read : ((size_t)128 << 10));
 			size_t mine = holds_arenas(c) ? c->zbuf.cap + c->t1buf.cap + c->t2buf.cap + c->sx.cap + c->sy.cap + c->m_val.cap : 0;
 			const uint64_t lim = c->mem_allow ? (uint64_t)((double)c->mem_allow / 3.0 / (double)per_read)
 			                                  : (uint64_t)(((double)free_b / (c->share > 0 ? c->share : 1) + (double)mine) / 3.0 / (double)per_read);
