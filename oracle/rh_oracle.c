@@ -950,9 +950,15 @@ static inline int32_t sc_simple(const a128 *ai, const a128 *aj, float pen_gap, f
 }
 
 /* mg_lchain_rmq lchain.c:606-756.  Same contract as chain_dp. */
+/* Diagnostic (RO_RMQ_TIE_STATS=1; round 6): how often does krmq_rmq's answer depend on the SHAPE of the tree - two or more live nodes in the query's range
+ * sharing the least priority?  [0] queries answered, [1] of them with such a tie, [2] chain_rmq calls (read x chunk), [3] of them with at least one tie. */
+static unsigned long long g_rmq_tie[4];
+void ro_debug_rmq_ties(unsigned long long *out, int reset) { for (int k = 0; k < 4; ++k) { out[k] = __atomic_load_n(&g_rmq_tie[k], __ATOMIC_RELAXED); if (reset) __atomic_store_n(&g_rmq_tie[k], 0ull, __ATOMIC_RELAXED); } }
 static a128 *chain_rmq(int max_dist, int max_dist_inner, int bw, int max_skip, int cap_rmq_size, int min_cnt, int min_sc, float pen_gap, float pen_skip,
                        int64_t *n_io, a128 *a, a128 **prev_out, int *n_u_out, uint64_t **u_out)
 {
+	const int tie_stats = getenv("RO_RMQ_TIE_STATS") != 0;
+	unsigned long long ts_q = 0, ts_t = 0;
 	const int32_t max_drop = bw;
 	int64_t n = *n_io, i, i0, st = 0, st_inner = 0;
 	*u_out = 0; *n_u_out = 0;
@@ -994,6 +1000,11 @@ static a128 *chain_rmq(int max_dist, int max_dist_inner, int bw, int max_skip, i
 		if ((q = rq_rmq(root, &lo, &hi)) != 0) {
 			int32_t sc, exact, width, n_skip = 0;
 			int64_t j = q->i;
+			if (tie_stats) {	/* the live nodes are the anchors [st, i0) */
+				int same = 0;
+				for (int64_t k = st; k < i0; ++k) { const rq_node *z = &pool[2 * k]; if (rq_cmp(z, &lo) >= 0 && rq_cmp(z, &hi) <= 0 && z->pri == q->pri) ++same; }
+				++ts_q; if (same > 1) ++ts_t;
+			}
 			sc = f[j] + sc_simple(&a[i], &a[j], pen_gap, pen_skip, &exact, &width);
 			if (width <= bw && sc > max_f) { max_f = sc; max_j = j; }
 			if (!exact && root_inner && (int32_t)a[i].y > 0) {
@@ -1023,6 +1034,7 @@ static a128 *chain_rmq(int max_dist, int max_dist_inner, int bw, int max_skip, i
 		v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
 	}
 	free(pool);
+	if (tie_stats) { __atomic_fetch_add(&g_rmq_tie[0], ts_q, __ATOMIC_RELAXED); __atomic_fetch_add(&g_rmq_tie[1], ts_t, __ATOMIC_RELAXED); __atomic_fetch_add(&g_rmq_tie[2], 1ull, __ATOMIC_RELAXED); if (ts_t) __atomic_fetch_add(&g_rmq_tie[3], 1ull, __ATOMIC_RELAXED); }
 	return chain_finish(n, a, f, p, v, t, min_cnt, min_sc, max_drop, n_io, prev_out, n_u_out, u_out);
 }
 

@@ -557,7 +557,7 @@ RH_DEV void sort_run(sort_lds<CAP, KT> &L, uint32_t n, int pass)
 //      bucket; a bucket of more than 16 records - the tail, or the anchors of a mapped read at its locus, a few hundred within a few hundred positions - is sorted
 //      by a whole wavefront (network across the lanes);
 //   6. the sorted records stream out of LDS to the destination - no second read of the source.
-// Returns 0: done; 1: the segment holds equal keys (nothing written: the caller's exact passes take it from the input order); 2: not for this path
+// Returns 0: done; 1: the segment holds equal keys (nothing written unless write_tied: the caller's exact passes take it from the input order); 2: not for this path
 // (more buckets of more than 16 records than a short list holds, or one of more than 256 / 512; a key range of more than 2^35).
 template <int CAP> struct sort_fast_cfg {
 	static constexpr int nb() { int v = NT; while (v < CAP / 8) v *= 2; return v; }
@@ -689,8 +689,11 @@ RH_DEV bool sort_fast_wave(sort_fast_lds<CAP> &F, uint32_t st, uint32_t m, const
 #else
 #define FPROF(slot)
 #endif
-template <int CAP>
-RH_DEV int sort_fast(sort_fast_lds<CAP> &F, const uint64_t *src, uint64_t *dst, uint32_t n, uint32_t shift, bool prof)
+// R16: 16-byte records {x = key, y = payload} (the region sort).  What travels through LDS is then a WORD per record, (key - least key) << 16 | place in
+// the segment - the same 8 bytes, sorted the same way with "shift" 16 and "least key" 0 - and the records themselves are fetched once, at the end, by
+// the places the sorted words name (the segment was read microseconds ago: L2).  Needs a key range below 2^48.
+template <int CAP, bool R16>
+RH_DEV int sort_fast(sort_fast_lds<CAP> &F, const void *src_, void *dst_, uint32_t n, uint32_t shift, bool write_tied, bool prof)
 {
 #ifdef RH_KPROF
 	unsigned long long fp_t0 = clock64();
@@ -699,21 +702,26 @@ RH_DEV int sort_fast(sort_fast_lds<CAP> &F, const uint64_t *src, uint64_t *dst, 
 	constexpr int K = CF::K, NB = CF::NB, BPT = CF::BPT, LB = CF::LB;
 	constexpr int KH = CF::HOLD ? K : 1;
 	const uint32_t tid = threadIdx.x;
-	if (n < 2) { if (n == 1 && tid == 0) dst[0] = src[0]; return 0; }
+	const uint64_t *src8 = reinterpret_cast<const uint64_t*>(src_);
+	const rh_mm128_t *src16 = reinterpret_cast<const rh_mm128_t*>(src_);
+	if (n < 2) { if (n == 1 && tid == 0) { if (R16) reinterpret_cast<rh_mm128_t*>(dst_)[0] = src16[0]; else reinterpret_cast<uint64_t*>(dst_)[0] = src8[0]; } return 0; }
+	// raw(i): what a thread keeps of record i - the record itself, or the key of a 16-byte one; keyof(raw): its sort key; wordof(raw, i): what goes to LDS
+	#define SF_RAW(i_) (R16 ? src16[(i_)].x : src8[(i_)])
+	#define SF_KEY(raw_) (R16 ? (raw_) : (raw_) >> shift)
 	uint64_t r[KH];
 	uint64_t kmin = ~0ull, kmax = 0ull;
 	if constexpr (CF::HOLD) {
 #pragma unroll
-		for (int k = 0; k < KH; ++k) { const uint32_t i = tid + (uint32_t)k * NT; r[k] = i < n ? src[i] : 0ull; }
+		for (int k = 0; k < KH; ++k) { const uint32_t i = tid + (uint32_t)k * NT; r[k] = i < n ? SF_RAW(i) : 0ull; }
 #pragma unroll
-		for (int k = 0; k < KH; ++k) { const uint32_t i = tid + (uint32_t)k * NT; if (i < n) { const uint64_t kk = r[k] >> shift; kmin = kk < kmin ? kk : kmin; kmax = kk > kmax ? kk : kmax; } }
+		for (int k = 0; k < KH; ++k) { const uint32_t i = tid + (uint32_t)k * NT; if (i < n) { const uint64_t kk = SF_KEY(r[k]); kmin = kk < kmin ? kk : kmin; kmax = kk > kmax ? kk : kmax; } }
 	} else {
 		for (uint32_t i0 = tid; i0 < n; i0 += 8u * NT) {
 			uint64_t x[8];
 #pragma unroll
-			for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; x[u] = i < n ? src[i] : 0ull; }
+			for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; x[u] = i < n ? SF_RAW(i) : 0ull; }
 #pragma unroll
-			for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; if (i < n) { const uint64_t kk = x[u] >> shift; kmin = kk < kmin ? kk : kmin; kmax = kk > kmax ? kk : kmax; } }
+			for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + (uint32_t)u * NT; if (i < n) { const uint64_t kk = SF_KEY(x[u]); kmin = kk < kmin ? kk : kmin; kmax = kk > kmax ? kk : kmax; } }
 		}
 	}
 	for (uint32_t b = tid; b < (uint32_t)NB; b += NT) F.cnt[b] = 0;
@@ -727,8 +735,10 @@ RH_DEV int sort_fast(sort_fast_lds<CAP> &F, const uint64_t *src, uint64_t *dst, 
 	const uint64_t range = kmax - kmin;
 	if (range == 0) return 1;                                    // n >= 2 equal keys
 	const int bits = 64 - __clzll(range);
+	if (R16 && bits > 48) return 2;                               // (key - least key) << 16 | place would not fit the word
 	sort_fast_map M;
-	M.kmin = kmin; M.shift = shift; M.m = 1u; M.s2 = 0u; M.inv = 1.0;
+	M.kmin = R16 ? 0ull : kmin; M.shift = R16 ? 16u : shift; M.m = 1u; M.s2 = 0u; M.inv = 1.0;
+	#define SF_WORD(raw_, i_) (R16 ? ((raw_) - kmin) << 16 | (uint64_t)(i_) : (raw_))
 	if (bits > LB) {	// (range + 1) * m / 2^s2 <= NB with m the largest of 16 .. 31 that keeps it so: the last bucket used is NB * m / (m + 1) or later
 		M.s2 = (uint32_t)(bits + 4 - LB);
 		if (M.s2 > 30u) return 2;                                 // a bucket's keys would not fit 27 bits
@@ -743,20 +753,20 @@ RH_DEV int sort_fast(sort_fast_lds<CAP> &F, const uint64_t *src, uint64_t *dst, 
 		for (int k = 0; k < K; ++k) {
 			const uint32_t i = tid + (uint32_t)k * NT;
 			dr[k] = 0;
-			if (i < n) { const uint32_t d = M.bucket(M.rel(r[k])); dr[k] = d | atomicAdd(&F.cnt[d], 1u) << 16; }
+			if (i < n) { const uint32_t d = M.bucket(M.rel(SF_WORD(r[k], i))); dr[k] = d | atomicAdd(&F.cnt[d], 1u) << 16; }
 		}
 	} else {
 #pragma unroll
 		for (int k0 = 0; k0 < K; k0 += 8) {
 			uint64_t x[8];
 #pragma unroll
-			for (int u = 0; u < 8; ++u) { const uint32_t i = tid + (uint32_t)(k0 + u) * NT; x[u] = (k0 + u < K && i < n) ? src[i] : 0ull; }
+			for (int u = 0; u < 8; ++u) { const uint32_t i = tid + (uint32_t)(k0 + u) * NT; x[u] = (k0 + u < K && i < n) ? SF_RAW(i) : 0ull; }
 #pragma unroll
 			for (int u = 0; u < 8; ++u) {
 				if (k0 + u >= K) continue;
 				const uint32_t i = tid + (uint32_t)(k0 + u) * NT;
 				dr[k0 + u] = 0;
-				if (i < n) { const uint32_t d = M.bucket(M.rel(x[u])); dr[k0 + u] = d | atomicAdd(&F.cnt[d], 1u) << 16; }
+				if (i < n) { const uint32_t d = M.bucket(M.rel(SF_WORD(x[u], i))); dr[k0 + u] = d | atomicAdd(&F.cnt[d], 1u) << 16; }
 			}
 		}
 	}
@@ -785,19 +795,19 @@ RH_DEV int sort_fast(sort_fast_lds<CAP> &F, const uint64_t *src, uint64_t *dst, 
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
 			const uint32_t i = tid + (uint32_t)k * NT;
-			if (i < n) F.rec[F.cnt[dr[k] & 0xFFFFu] + (dr[k] >> 16)] = r[k];
+			if (i < n) F.rec[F.cnt[dr[k] & 0xFFFFu] + (dr[k] >> 16)] = SF_WORD(r[k], i);
 		}
 	} else {
 #pragma unroll
 		for (int k0 = 0; k0 < K; k0 += 8) {
 			uint64_t x[8];
 #pragma unroll
-			for (int u = 0; u < 8; ++u) { const uint32_t i = tid + (uint32_t)(k0 + u) * NT; x[u] = (k0 + u < K && i < n) ? src[i] : 0ull; }
+			for (int u = 0; u < 8; ++u) { const uint32_t i = tid + (uint32_t)(k0 + u) * NT; x[u] = (k0 + u < K && i < n) ? SF_RAW(i) : 0ull; }
 #pragma unroll
 			for (int u = 0; u < 8; ++u) {
 				if (k0 + u >= K) continue;
 				const uint32_t i = tid + (uint32_t)(k0 + u) * NT;
-				if (i < n) F.rec[F.cnt[dr[k0 + u] & 0xFFFFu] + (dr[k0 + u] >> 16)] = x[u];
+				if (i < n) F.rec[F.cnt[dr[k0 + u] & 0xFFFFu] + (dr[k0 + u] >> 16)] = SF_WORD(x[u], i);
 			}
 		}
 	}
@@ -828,10 +838,15 @@ RH_DEV int sort_fast(sort_fast_lds<CAP> &F, const uint64_t *src, uint64_t *dst, 
 	if (tie) F.flag = 1;
 	__syncthreads();
 	FPROF(17);
-	if (F.flag) return 1;
-	for (uint32_t i = tid; i < n; i += NT) dst[i] = F.rec[i];
+	const bool tied = F.flag != 0;
+	if (tied && !write_tied) return 1;                             // (write_tied: the caller only wants to know - the segment is sorted, its equal keys in no particular order)
+	if (R16) { rh_mm128_t *dst16 = reinterpret_cast<rh_mm128_t*>(dst_); for (uint32_t i = tid; i < n; i += NT) dst16[i] = src16[(uint32_t)F.rec[i] & 0xFFFFu]; }
+	else { uint64_t *dst8 = reinterpret_cast<uint64_t*>(dst_); for (uint32_t i = tid; i < n; i += NT) dst8[i] = F.rec[i]; }
 	FPROF(18);
-	return 0;
+	#undef SF_RAW
+	#undef SF_KEY
+	#undef SF_WORD
+	return tied ? 1 : 0;
 }
 
 // mode 0: fast pass; reads whose sorted keys show ties are redone with the exact permutation on the tied ranges
@@ -844,7 +859,7 @@ constexpr int sort_wg_per_cu() { return (int)((160u * 1024u) / ((sizeof(sort_lds
 template <int CAP, class KT, class REC>
 __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(rh_sort_job jb, uint32_t n_lo, uint32_t n_hi, int mode)
 {
-	constexpr bool FAST = sizeof(REC) == 8 && sizeof(sort_fast_lds<CAP>) <= sizeof(sort_lds<CAP, KT>) + 2048;   // (the tie-free path shares the LDS of the general one)
+	constexpr bool FAST = sizeof(sort_fast_lds<CAP>) <= sizeof(sort_lds<CAP, KT>) + 2048;   // (the tie-free path shares the LDS of the general one)
 	__shared__ union U_ { sort_lds<CAP, KT> L; typename std::conditional<FAST, sort_fast_lds<CAP>, uint32_t>::type F; } U;
 	sort_lds<CAP, KT> &L = U.L;
 	const uint32_t a = blockIdx.x, tid = threadIdx.x;
@@ -858,7 +873,7 @@ __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(
 	KPROF_DECL;
 	if constexpr (FAST) {
 		if (mode == 0 && jb.fast_on) {	// segments without equal keys (nearly all): records in LDS, one pass into CAP / 2 buckets, a register network per bucket
-			const int fr = sort_fast<CAP>(U.F, reinterpret_cast<const uint64_t*>(src), reinterpret_cast<uint64_t*>(dst), n, rf.shift, jb.scratch_skip == 0);
+			const int fr = sort_fast<CAP, sizeof(REC) == 16>(U.F, src, dst, n, rf.shift, jb.no_redo != 0, jb.scratch_skip == 0);
 #ifdef RH_KPROF
 			kp_t0 = clock64();
 			if (tid == 0 && jb.scratch_skip == 0) { atomicAdd(&rh_kprof_acc[20 + fr], 1ull); atomicAdd(&rh_kprof_acc[23], (unsigned long long)n); }   // outcomes of the tie-free path: done / equal keys / not for it; records seen
