@@ -233,6 +233,7 @@ typedef struct rh_map_stats_s {
 	double   ms_kernel[24];           /* per-stage device time (HIP events on the context's stream), see rh_stage_name() */
 	uint32_t n_launch[24];
 	uint64_t n_rmq_class[4];          /* RH_M_RMQ / bw_long: (read, chunk) pairs chained with the trees in LDS rings of 64 / 128 / 512 nodes, or in HBM */
+	uint64_t n_dtw_device, n_dtw_host; /* RH_M_DTW_EVALUATE_CHAINS: (read, chunk) pairs whose MAPQ and mapping decision the device settled / that needed the host's logf */
 } rh_map_stats_t;
 RH_API int  rh_map_last_stats(rh_ctx *ctx, rh_map_stats_t *out);
 RH_API const char *rh_stage_name(int i);

@@ -81,7 +81,7 @@ class ReadBatch(C.Structure):
 class MapStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_reads", "n_chunks", "n_samples_raw", "n_samples_used", "n_events",
                                           "n_seeds", "n_hits", "n_anchors", "n_chained")] + \
-               [("ms_total", C.c_double), ("ms_kernel", C.c_double * 24), ("n_launch", C.c_uint32 * 24), ("n_rmq_class", C.c_uint64 * 4)]
+               [("ms_total", C.c_double), ("ms_kernel", C.c_double * 24), ("n_launch", C.c_uint32 * 24), ("n_rmq_class", C.c_uint64 * 4), ("n_dtw_device", C.c_uint64), ("n_dtw_host", C.c_uint64)]
 
 
 class Ticket(C.Structure):

@@ -339,6 +339,7 @@ class Context:
         d = {k: getattr(s, k) for k in ("n_reads", "n_chunks", "n_samples_raw", "n_samples_used", "n_events", "n_seeds",
                                          "n_hits", "n_anchors", "n_chained", "ms_total")}
         d["n_rmq_class"] = [int(s.n_rmq_class[i]) for i in range(4)]
+        d["n_dtw_device"], d["n_dtw_host"] = int(s.n_dtw_device), int(s.n_dtw_host)
         d["stages"] = {self._l.rh_stage_name(i).decode(): (s.ms_kernel[i], s.n_launch[i]) for i in range(24)
                        if self._l.rh_stage_name(i)}
         return d

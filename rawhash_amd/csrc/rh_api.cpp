@@ -84,6 +84,7 @@ struct rh_ctx_s {
 	rh_dev_index dix{};
 	bool have_index = false;
 	bool akey_on = false; uint8_t akey_lo = 0, akey_mid = 0;      // dimensions of the anchor keys of the resident index
+	uint64_t dtw_dev_reads = 0, dtw_host_reads = 0;              // DTW re-scoring: (read, chunk) pairs whose MAPQ / decision the device settled / the host's libm had to
 	size_t carry_per_read = 0;                                    // most bytes of chained anchors a round carried per read of its call, over this context's calls (map_batch_single sizes its calls by it)
 	unsigned char header[256] = {0};
 	// logf table
@@ -189,7 +190,7 @@ int fill_dev_opt(rh_ctx *c, const rh_mapopt_t *mo, rh_dev_opt *o)
 	}
 	o->mask_level = mo->mask_level; o->mask_len = mo->mask_len; o->pri_ratio = mo->pri_ratio; o->best_n = mo->best_n;
 	o->min_strand_sc = (int32_t)(mo->max_target_gap_length * 0.8);   // rmap.cpp:354
-	o->w_bestq = mo->w_bestq; o->w_bestmq = mo->w_bestmq; o->w_bestmc = mo->w_bestmc; o->w_threshold = mo->w_threshold;
+	o->w_bestq = mo->w_bestq; o->w_bestmq = mo->w_bestmq; o->w_bestmc = mo->w_bestmc; o->w_threshold = mo->w_threshold; o->w_bestma = mo->w_bestma;
 	o->min_mapq = mo->min_mapq; o->sample_per_base = mo->sample_per_base; o->flag = mo->flag;
 	return 0;
 }
@@ -204,6 +205,19 @@ static int dtw_regions_stage(rh_ctx *c, hipStream_t s, const rh_dev_opt &o, cons
 	if (c->dtw_n.ensure((size_t)n * 4) || c->dtw_ws.ensure((size_t)n * rs.dtw_stride * 4) || c->dtw_off.ensure((size_t)(n + 1) * 8) || c->dtw_dec.ensure((size_t)n * 12)) return -1;
 	rs.dtw_n = c->dtw_n.as<uint32_t>(); rs.dtw_ws = c->dtw_ws.as<float>();
 	rhk_regions_dtw(s, o, c->dix, rd, rs);
+	// MAPQ and the decision on the device wherever the host's logf cannot change the truncated MAPQ (k_dtw_decide); what is left - a read in ten thousand - goes
+	// the old way below.  RH_DTW_HOST_MAPQ=1: the host for every read (A/B and test aid).
+	const bool host_all = getenv("RH_DTW_HOST_MAPQ") != nullptr;    // (read per call)
+	uint32_t *n_host_d = c->n_act_dev.as<uint32_t>() + 12;
+	if (!host_all) {
+		RH_HIP(hipMemsetAsync(n_host_d, 0, 4, s));
+		rhk_dtw_decide(s, o, rd, rs, c->logf_tab.as<float>(), n_host_d);
+		RH_HIP(hipMemcpyAsync(c->pin + 7, n_host_d, 4, hipMemcpyDeviceToHost, s));
+		RH_HIP(hipStreamSynchronize(s));
+		const uint32_t n_host = (uint32_t)c->pin[7];
+		c->dtw_host_reads += n_host; c->dtw_dev_reads += n - n_host;
+		if (!n_host) return 0;
+	} else c->dtw_host_reads += n;
 	std::vector<uint32_t> nreg(n);
 	std::vector<int32_t> rep(n);
 	RH_HIP(hipMemcpyAsync(nreg.data(), rs.dtw_n, (size_t)n * 4, hipMemcpyDeviceToHost, s));
@@ -212,6 +226,7 @@ static int dtw_regions_stage(rh_ctx *c, hipStream_t s, const rh_dev_opt &o, cons
 	std::vector<uint64_t> off((size_t)n + 1, 0);
 	for (uint32_t a = 0; a < n; ++a) {
 		if (nreg[a] & 0x80000000u) { rh_set_error("DTW re-scoring: a band / matrix row does not fit the per-read DP buffer (dtw_band_radius_frac %.2f too large for this device path)", (double)mo->dtw_band_radius_frac); return -1; }
+		if (nreg[a] & 0x40000000u) nreg[a] = 0;                         // decided and committed on the device
 		off[a + 1] = off[a] + nreg[a];
 	}
 	const uint64_t T = off[n];
@@ -945,6 +960,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 	if (R == 0) return 0;
 	if (set_row_strides(c, mo, in)) return -1;
 	memset(&c->stats, 0, sizeof(c->stats));
+	c->dtw_dev_reads = 0; c->dtw_host_reads = 0;
 	c->ev_used = 0; c->ev_stage.clear();
 	const auto t_begin = std::chrono::steady_clock::now();
 	hipStream_t s = c->stream;
@@ -1092,6 +1108,7 @@ int map_batch_once(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batch_t *in, 
 		c->stats.n_events = cnt[0]; c->stats.n_seeds = cnt[1]; c->stats.n_hits = cnt[2]; c->stats.n_anchors = cnt[3]; c->stats.n_chained = cnt[4];
 		c->stats.n_samples_used = cnt[5]; c->stats.n_chunks = cnt[6];
 		for (int q = 0; q < 4; ++q) c->stats.n_rmq_class[q] = cnt[9 + q];
+		c->stats.n_dtw_device = c->dtw_dev_reads; c->stats.n_dtw_host = c->dtw_host_reads;
 		if (cnt[7]) { rh_set_error("%llu chunk(s) hold more than %d event boundaries: beyond the per-chunk arrays of the device path", (unsigned long long)cnt[7], RH_EV_CAP); return -1; }
 		if (cnt[8]) { rh_set_error("rh_read_batch_t::n_filtered is wrong for %llu read(s): not the number of samples the pA filter (rsig.c:496-503) leaves of them", (unsigned long long)cnt[8]); return -1; }
 	}
@@ -1110,6 +1127,7 @@ void add_stats(rh_map_stats_t &tot, const rh_map_stats_t &q)
 	tot.n_events += q.n_events; tot.n_seeds += q.n_seeds; tot.n_hits += q.n_hits; tot.n_anchors += q.n_anchors; tot.n_chained += q.n_chained;
 	tot.ms_total += q.ms_total;
 	for (int i = 0; i < 4; ++i) tot.n_rmq_class[i] += q.n_rmq_class[i];
+	tot.n_dtw_device += q.n_dtw_device; tot.n_dtw_host += q.n_dtw_host;
 	for (int i = 0; i < 24; ++i) { tot.ms_kernel[i] += q.ms_kernel[i]; tot.n_launch[i] += q.n_launch[i]; }
 }
 
@@ -1274,6 +1292,7 @@ extern "C" int rh_map_batch(rh_ctx *c, const rh_mapopt_t *mo, const rh_read_batc
 		tot.n_events += q.n_events; tot.n_seeds += q.n_seeds; tot.n_hits += q.n_hits; tot.n_anchors += q.n_anchors; tot.n_chained += q.n_chained;
 		for (int i = 0; i < 24; ++i) { tot.ms_kernel[i] += q.ms_kernel[i]; tot.n_launch[i] += q.n_launch[i]; }
 		for (int i = 0; i < 4; ++i) tot.n_rmq_class[i] += q.n_rmq_class[i];
+		tot.n_dtw_device += q.n_dtw_device; tot.n_dtw_host += q.n_dtw_host;
 	}
 	tot.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 	c->stats = tot;

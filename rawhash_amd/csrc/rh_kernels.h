@@ -61,7 +61,7 @@ struct rh_dev_opt {
 	uint32_t dtw_border, dtw_fill; float dtw_band_frac, dtw_match_bonus, dtw_min_score;   // RH_M_DTW_EVALUATE_CHAINS (rmap.cpp:128-208)
 	float pen_gap, pen_skip;
 	float mask_level; int32_t mask_len; float pri_ratio; int32_t best_n; int32_t min_strand_sc;
-	float w_bestq, w_bestmq, w_bestmc, w_threshold;
+	float w_bestq, w_bestmq, w_bestmc, w_threshold, w_bestma;
 	int32_t min_mapq;
 	float sample_per_base;
 	int64_t flag;
@@ -296,6 +296,7 @@ void rhk_events_append(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round
 void rhk_regions_dtw(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r);
 bool rhk_regions_fast_ok(const rh_dev_opt &o);   // the primaries-only region kernels apply (default selection: secondaries dropped, not all-chains)
 void rhk_dtw_pack(hipStream_t s, const rh_dev_round &r);
+void rhk_dtw_decide(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r, const float *logf_tab, uint32_t *n_host);   // MAPQ + decision on the device where the host's logf cannot matter; *n_host (device) += reads left to the host
 void rhk_dtw_commit(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r);
 void rhk_compact_active(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const uint32_t *act_in, uint32_t n_in, uint32_t next_chunk,
                         uint32_t *act_out, uint32_t *n_out);

@@ -1580,11 +1580,87 @@ __global__ __launch_bounds__(64) void k_regions_dtw(rh_dev_opt o, rh_dev_index i
 	if (lane == 0) rr.dtw_n[a] = (uint32_t)n_regs | (bad ? 0x80000000u : 0u);
 }
 
+// mm_set_mapq's DTW branch (hit.c:502-539) and the mapping decision (rmap.cpp:423-500) ON THE DEVICE (round 6).  The MAPQ is
+//     (int)(pen * 40 * (1 - x) * 2 * logf(alignment score))      with a fractional argument
+// and the reference's logf is the host libm's - not correctly rounded, so no device routine reproduces it bit for bit.  But the result is TRUNCATED to an
+// integer: the double-precision logarithm, rounded to float, is within half an ulp of the true value, the host's logf within an ulp or so of it (glibc: 0.82),
+// so the host's result is one of the five floats around ours - and if all five give the same integer, that integer is the reference's whatever its libm
+// returned.  A read all of whose regions are settled that way (all but ~1 in 10^4) is decided and committed here; the others are flagged (bit 30 of dtw_n) and
+// take the old way - 32 bytes per region to the host, its libm, the verdict back - which used to be two blocking round trips per slice for EVERY read.
+#define DTW_DECIDED 0x40000000u
+__global__ void k_dtw_decide(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, const float *logf_tab, uint32_t *n_host)
+{
+	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a >= rr.n_act) return;
+	const uint32_t r = rr.act[a];
+	if (rr.skip[a]) { rd.ls_ncregs[r] = 0; rr.dtw_n[a] = DTW_DECIDED; return; }   // chunk dropped: creg stays NULL (rmap.cpp:232-235, :419)
+	const uint32_t nw = rr.dtw_n[a];
+	if (nw & 0x80000000u) { atomicAdd(n_host, 1u); return; }          // a DP buffer overflowed: the host reports it
+	const int32_t nr = (int32_t)(nw & 0x3FFFFFFFu);
+	if (!nr) { regions_commit(o, rd, rr, a, r, 0, nullptr, 0); rr.dtw_n[a] = DTW_DECIDED; return; }
+	const uint64_t base = rr.a_off[a];
+	const int32_t n_u = (int32_t)rr.n_u[a];
+	unsigned char *wsr = rr.ws + base * rr.ws_stride;
+	rh_reg *rg = (rh_reg*)wsr;
+	const float *ascore = (const float*)(wsr + (size_t)64 * n_u);
+	int64_t sum_sc = 0;
+	for (int32_t i = 0; i < nr; ++i) if (rg[i].parent == rg[i].id) sum_sc += rg[i].score;
+	const float uniq_ratio = (float)sum_sc / (float)(sum_sc + (int64_t)rr.rep_len[a]);
+	bool sure = true;
+	for (int32_t i = 0; i < nr && sure; ++i) {
+		const rh_reg &q = rg[i];
+		float pen_s1 = (float)((q.score > 100 ? 1.0 : 0.01 * (double)q.score) * (double)uniq_ratio);
+		float pen_cm = q.cnt > 10 ? 1.0f : 0.1f * (float)q.cnt;
+		pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
+		const int32_t subsc = q.subsc > o.min_sc ? q.subsc : o.min_sc;
+		const float x = (float)subsc / (float)q.score0;
+		const float as = ascore[i];
+		int mapq = 0;
+		if (as > 0.0f) {
+			const float t = pen_cm * 40.0f * (1.0f - x) * 2.0f;
+			const float l0 = (float)log((double)as);
+			float c[5]; c[2] = l0; c[1] = nextafterf(l0, -INFINITY); c[0] = nextafterf(c[1], -INFINITY); c[3] = nextafterf(l0, INFINITY); c[4] = nextafterf(c[3], INFINITY);
+			mapq = (int)(t * c[0]);
+			for (int k = 1; k < 5; ++k) if ((int)(t * c[k]) != mapq) sure = false;
+		}
+		const int32_t ns1 = q.n_sub + 1;
+		if (ns1 < 0 || ns1 >= (1 << 20)) sure = false;                // (beyond the table of the host's logf(integer))
+		else mapq -= (int)(4.343f * logf_tab[ns1] + .499f);
+		mapq = mapq > 0 ? mapq : 0;
+		rg[i].mapq = (uint32_t)(mapq < 60 ? mapq : 60);
+	}
+	if (!sure) { atomicAdd(n_host, 1u); return; }
+	// the decision (rmap.cpp:423-500, one chain reported: no all-chains mode here) - the statements of the host version in dtw_regions_stage, in their order
+	int sel = 0, stop = 0;
+	if (nr == 1 && ((int32_t)rg[0].mapq >= o.min_mapq || ascore[0] >= o.dtw_min_score)) stop = 1;
+	else {
+		float meanC = 0, meanQ = 0;
+		for (int32_t i = 0; i < nr; ++i) { meanC += (float)rg[i].score; meanQ += (float)(int32_t)rg[i].mapq; }
+		meanC /= (float)nr; meanQ /= (float)nr;
+		float bestA = ascore[0];
+		int best = 0;
+		for (int32_t i = 1; i < nr; ++i) if (ascore[i] > bestA) { bestA = ascore[i]; best = i; }
+		const float bestQ = (float)(int32_t)rg[best].mapq, bestC = (float)rg[best].score;
+		float weighted = 0.0f;
+		if (bestA >= o.dtw_min_score) {
+			float r_bestma = (bestA > 0) ? (bestA / 50.0f) : 0.0f; if (r_bestma < 0) r_bestma = 0.0f;
+			float r_bestmq = (bestQ > 0) ? (1.0f - (meanQ / bestQ)) : 0.0f; if (r_bestmq < 0) r_bestmq = 0.0f;
+			float r_bestmc = (bestC > 0) ? (1.0f - (meanC / bestC)) : 0.0f; if (r_bestmc < 0) r_bestmc = 0.0f;
+			weighted = o.w_bestma * r_bestma + o.w_bestmq * r_bestmq + o.w_bestmc * r_bestmc;
+		}
+		if (weighted >= o.w_threshold) { stop = 1; sel = best; }
+	}
+	const rh_reg selr = rg[sel];
+	regions_commit(o, rd, rr, a, r, nr, &selr, stop);
+	rr.dtw_n[a] = nw | DTW_DECIDED;
+}
+
 __global__ __launch_bounds__(NT) void k_dtw_pack(rh_dev_round rr)
 {
 	const uint32_t a = blockIdx.x;
 	if (a >= rr.n_act) return;
-	const uint32_t n = rr.dtw_n[a] & 0x7FFFFFFFu;
+	if (rr.dtw_n[a] & DTW_DECIDED) return;
+	const uint32_t n = rr.dtw_n[a] & 0x3FFFFFFFu;
 	if (!n) return;
 	const uint64_t base = rr.a_off[a];
 	const int32_t n_u = (int32_t)rr.n_u[a];
@@ -1605,8 +1681,9 @@ __global__ void k_dtw_commit(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
 	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
 	if (a >= rr.n_act) return;
 	const uint32_t r = rr.act[a];
+	if (rr.dtw_n[a] & DTW_DECIDED) return;                            // decided and committed on the device (k_dtw_decide)
 	if (rr.skip[a]) { rd.ls_ncregs[r] = 0; return; }                // chunk dropped: creg stays NULL (rmap.cpp:232-235, :419)
-	const uint32_t n = rr.dtw_n[a] & 0x7FFFFFFFu;
+	const uint32_t n = rr.dtw_n[a] & 0x3FFFFFFFu;
 	if (!n) { regions_commit(o, rd, rr, a, r, 0, nullptr, 0); return; }
 	const rh_reg *rg = (const rh_reg*)(rr.ws + rr.a_off[a] * rr.ws_stride);
 	rh_reg sel = rg[rr.dtw_dec[3 * (size_t)a]];
@@ -1717,4 +1794,5 @@ void rhk_regions(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, con
 void rhk_events_append(hipStream_t s, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_events_append, r.n_act, NT, 0, s, rd, r); }
 void rhk_regions_dtw(hipStream_t s, const rh_dev_opt &o, const rh_dev_index &ix, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_regions_dtw, r.n_act, 64, 0, s, o, ix, rd, r); }
 void rhk_dtw_pack(hipStream_t s, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_dtw_pack, r.n_act, NT, 0, s, r); }
+void rhk_dtw_decide(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r, const float *logf_tab, uint32_t *n_host) { if (r.n_act) RH_LAUNCH(k_dtw_decide, (r.n_act + 63) / 64, 64, 0, s, o, rd, r, logf_tab, n_host); }
 void rhk_dtw_commit(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, const rh_dev_round &r) { if (r.n_act) RH_LAUNCH(k_dtw_commit, (r.n_act + 63) / 64, 64, 0, s, o, rd, r); }

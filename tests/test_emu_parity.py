@@ -142,6 +142,20 @@ def test_dtw_rescoring(make_workload, emu_lib, mapopt):
     c.upload(w.index)
     recs = pc.check_e2e(c, w)
     assert recs["mapped"].sum() > 0
+    st = c.stats()
+    assert st["n_dtw_device"] > 0, st       # MAPQ and decision on the device (k_dtw_decide) where the host's logf cannot change the truncated MAPQ
+    c.close()
+
+
+def test_dtw_host_mapq_path(make_workload, emu_lib, monkeypatch):
+    """... and the round trip through the host's libm that the other reads take (RH_DTW_HOST_MAPQ=1: all of them)."""
+    monkeypatch.setenv("RH_DTW_HOST_MAPQ", "1")
+    w = make_workload(lib=emu_lib, n_reads=16, n_samples=12_000, idxflag=0x10, mapopt={"flag": 0x40})
+    c = Context(0, lib=emu_lib)
+    c.upload(w.index)
+    pc.check_e2e(c, w)
+    st = c.stats()
+    assert st["n_dtw_device"] == 0 and st["n_dtw_host"] > 0, st
     c.close()
 
 

@@ -135,7 +135,20 @@ def test_dtw_rescoring(make_workload, product_lib, gpu_ctx_factory, mapopt):
     c = gpu_ctx_factory()
     c.upload(w.index)
     recs = pc.check_e2e(c, w)
+    st = c.stats()      # MAPQ and the mapping decision are the device's wherever the host's logf cannot change the truncated MAPQ (k_dtw_decide): nearly all reads
+    assert st["n_dtw_device"] > 0 and st["n_dtw_host"] * 50 <= st["n_dtw_device"], (st["n_dtw_device"], st["n_dtw_host"])
     assert recs["mapped"].sum() > 100
+
+
+def test_dtw_host_mapq_path(make_workload, product_lib, gpu_ctx_factory, monkeypatch):
+    """The reads k_dtw_decide leaves to the host's libm take the round trip every read took before round 6; RH_DTW_HOST_MAPQ=1 sends all of them that way."""
+    monkeypatch.setenv("RH_DTW_HOST_MAPQ", "1")
+    w = make_workload(n_reads=300, n_samples=20_000, idxflag=0x10, mapopt={"flag": 0x40})
+    c = gpu_ctx_factory()
+    c.upload(w.index)
+    pc.check_e2e(c, w)
+    st = c.stats()
+    assert st["n_dtw_device"] == 0 and st["n_dtw_host"] > 0
 
 
 def test_device_index_store_sig_and_dtw(make_workload, product_lib, gpu_ctx_factory, tmp_path):
