@@ -21,6 +21,7 @@
 // sorts of <= 64 records included), or are final.  Records move once per level between two scratch copies (the
 // job's own source array and `alt`); finished buckets go straight to the destination array.
 #include <cstdio>
+#include <cstring>
 #include <vector>
 #include <cstdlib>
 #include <atomic>
@@ -1540,8 +1541,18 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	}
 	C.seg_off = jb.off; C.seg_n = jb.n_seg; C.redo_skip = jb.any_order ? jb.redo_skip : nullptr;
 	if ((size_t)(p - jb.big_ws) > jb.big_ws_bytes) { rh_set_error("segment sorter: scratch of %zu bytes is too small (%zu needed)", jb.big_ws_bytes, (size_t)(p - jb.big_ws)); return -1; }
-	RH_LAUNCH(k_bs_init, 1, NT, 0, s, jb, C);
 	uint32_t *pin = (uint32_t*)jb.big_pin;
+	// The exact re-run of an any-order job (tie_path) trusts the bits that job left in this scratch.  They are only good if THAT job - same segments, same scratch layout - was the last
+	// to use the scratch: the any-order job signs the scratch when it is done (hdr[48..53]), every other job wipes the signature when it starts, and a re-run that does not find the
+	// signature it expects takes the exact passes for every range instead (correct, slower) - never somebody else's bits.
+	const uint32_t sig[6] = { 0x54494531u, jb.n_seg, (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)jb.kind, (uint32_t)(uintptr_t)jb.off };
+	if (C.tie_path) {
+		RH_HIP(hipMemcpyAsync(pin + 24, C.hdr + 48, sizeof(sig), hipMemcpyDeviceToHost, s));
+		RH_HIP(hipStreamSynchronize(s));
+		if (memcmp(pin + 24, sig, sizeof(sig)) != 0) { C.tie_path = 0; C.tie_bits = nullptr; }
+	}
+	RH_HIP(hipMemsetAsync(C.hdr + 48, 0, sizeof(sig), s));
+	RH_LAUNCH(k_bs_init, 1, NT, 0, s, jb, C);
 	static const bool trace = RH_DEVENV("RH_BS_TRACE") != nullptr;   // development aid: per-level launch shapes and times on stderr
 	static const bool walk_old = RH_DEVENV("RH_BS_WALK_OLD") != nullptr;   // development aid: the LDS-resident walkers instead of the scalar-token one
 	static const uint32_t tok_max = RH_DEVENV("RH_BS_TOK_MAX") ? (uint32_t)strtoul(RH_DEVENV("RH_BS_TOK_MAX"), nullptr, 10) : 0xFFFFFFFFu;
@@ -1695,6 +1706,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 	if (jb.any_order) {
 		RH_LAUNCH(k_bs_tie_count, 1, NT, 0, s, C);
 		RH_HIP(hipMemcpyAsync(pin, C.hdr + 12, 4, hipMemcpyDeviceToHost, s));
+		if (C.tie_bits) { memcpy(pin + 24, sig, sizeof(sig)); RH_HIP(hipMemcpyAsync(C.hdr + 48, pin + 24, sizeof(sig), hipMemcpyHostToDevice, s)); }   // signed: see above
 		RH_HIP(hipStreamSynchronize(s));
 		if (jb.n_redo) *jb.n_redo = pin[0];
 	}
