@@ -22,6 +22,20 @@
 #define CH_SMALL 16     // clusters of up to this many anchors take the one-anchor-per-lane path (measured: 12 -> 37 ms, 16 -> 33 ms, 20 -> 42 ms per step)
 #endif
 
+#ifdef RH_KPROF
+// development aid: what k_chain_wave's tiles are made of - [0] tiles, [1] anchors, [2] singletons, [3] anchors of small clusters, [4] of large ones, [5] tiles that enter the small path,
+// [6] tiles that enter the large path, [7] pair-score rounds (r) of the small path, [8] DP steps (sidx) of the small path, [9] anchors in clusters of exactly two, [10] shader clocks in the large path, [11] in the small path, [12] in the whole kernel
+__device__ unsigned long long rh_kprof_chain[16];
+extern "C" __attribute__((visibility("default"))) int rh_debug_kprof_chain(unsigned long long *out, int reset)
+{
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rh_kprof_chain), sizeof(rh_kprof_chain)) != hipSuccess) return -1;
+	if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rh_kprof_chain), z, sizeof(z)) != hipSuccess) return -1; }
+	return 0;
+}
+#define CPROF(slot, v) do { if (threadIdx.x == 0) atomicAdd(&rh_kprof_chain[slot], (unsigned long long)(v)); } while (0)
+#else
+#define CPROF(slot, v)
+#endif
 struct chain_lds {
 	uint32_t xlo[CH_RING], ylo[CH_RING];
 	int32_t f[CH_RING], p[CH_RING], v[CH_RING], t[CH_RING];
@@ -116,6 +130,13 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 		const int32_t pos = ii - cs_g;
 		if (!(bmaskB & 1ull) && smask) open_start = i0 + 63 - (int32_t)__clzll(smask);   // cluster still open at the tile's end
 		uint64_t mmask = __ballot(inb && !single && !small);       // members of the larger clusters, walked in order
+#ifdef RH_KPROF
+		CPROF(0, 1); CPROF(1, __popcll(__ballot(inb))); CPROF(2, __popcll(__ballot(inb && single))); CPROF(3, __popcll(__ballot(small))); CPROF(4, __popcll(mmask));
+		CPROF(9, __popcll(__ballot(inb && !single && ce_g - cs_g == 1)));
+		if (__ballot(small)) CPROF(5, 1);
+		if (mmask) CPROF(6, 1);
+		const unsigned long long cp_t0 = clock64();
+#endif
 		while (mmask) {
 			const int b = __builtin_ctzll(mmask);
 			mmask &= mmask - 1;
@@ -202,6 +223,9 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 			if (max_ii < 0 || ((uint32_t)(xi_lo - xlo_ii) <= D32 && f_ii < max_f)) { max_ii = i; f_ii = max_f; xlo_ii = xi_lo; }
 			__syncthreads();
 		}
+#ifdef RH_KPROF
+		const unsigned long long cp_t1 = clock64(); CPROF(10, cp_t1 - cp_t0);
+#endif
 		// Small clusters (up to CH_SMALL anchors: the bulk of a chunk's anchors), one anchor per lane.  The pair scores - the
 		// expensive, DP-independent part of lchain.c:439-505 - are computed for all anchors of the tile at once (predecessor
 		// r back, r = 1, 2, ...); the DP itself then runs in steps over the position inside the cluster: step s settles the
@@ -217,6 +241,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 			for (int r = 1; r < CH_SMALL; ++r) {
 				sc[r] = RH_SCORE_NONE;
 				if (__ballot(small && pos >= r) == 0) break;
+				CPROF(7, 1);
 				if (small && pos >= r) {
 					const uint32_t sl = (uint32_t)(ii - r) & 127u;
 					const uint32_t xj = L.s_xlo[sl], yj = L.s_ylo[sl];
@@ -227,6 +252,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 #pragma unroll
 			for (int sidx = 0; sidx < CH_SMALL; ++sidx) {
 				if (__ballot(small && pos >= sidx) == 0) break;
+				CPROF(8, 1);
 				if (small && pos == sidx) {
 					int32_t max_f = span_i, max_j = -1, n_skip = 0, end_j = 0, nwin = 0;
 					uint32_t tm = 0;                                   // bit k: the cluster's k-th anchor carries t[] == i
@@ -277,6 +303,9 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 				__syncthreads();                                     // the step's f / p / v / max_ii are in the ring
 			}
 		}
+#ifdef RH_KPROF
+		CPROF(11, clock64() - cp_t1);
+#endif
 		x_before = x_last;
 		if (last_tile) break;
 	}
