@@ -452,7 +452,7 @@ def test_config2_ecoli_scale_vs_oracle(make_workload, product_lib):
 
 @pytest.mark.timeout(1200)
 def test_human_scale_index_vs_reference(product_lib, tmp_path):
-    """BASELINE.json configs[3] at its index size: 3.1 Gbp in 24 targets, index built on the device; 512 reads of the bench's
+    """BASELINE.json configs[3] at its index size: 3.1 Gbp in 24 targets, index built on the device; 3 072 reads (round 6; 512 until then) of the bench's
     read set (preset fast) mapped by the HIP path and by the CPU side reading the .ind this library wrote - the unmodified
     reference (oracle/_ref/ref_harness) where its binary travelled, else the oracle."""
     import ctypes as C
@@ -475,7 +475,7 @@ def test_human_scale_index_vs_reference(product_lib, tmp_path):
         del seqs
         opts.update(index)
         assert index.n_positions > 4_000_000_000
-        reads = wl.reads(model, 0, 512, n_threads=min(cores, 64))
+        reads = wl.reads(model, 0, 3072, n_threads=min(cores, 64))
         recs = c.map_batch(opts, reads)
         got = [strip_mt(x) for x in paf_lines(index, recs, reads.names)]
         index.download(c, n_threads=min(cores, 64))
@@ -493,7 +493,7 @@ def test_human_scale_index_vs_reference(product_lib, tmp_path):
             O.lib().ro_mapopt_update(C.byref(mo), oix.h)
             want = [O.strip_mt(x) for x in O.paf_lines(oix, O.map_batch(oix, mo, reads.batch(), n_threads=cores), reads.names)]
         bad = [(g, x) for g, x in zip(got, want) if g != x]
-        assert len(got) == len(want) == 512 and not bad, f"{len(bad)} PAF lines differ, first: {bad[:1]}"
+        assert len(got) == len(want) == 3072 and not bad, f"{len(bad)} PAF lines differ, first: {bad[:1]}"
         assert recs["mapped"].mean() > 0.85
     finally:
         import shutil
