@@ -852,9 +852,10 @@ RH_DEV int sort_fast(sort_fast_lds<CAP> &F, const void *src_, void *dst_, uint32
 // mode 0: fast pass; reads whose sorted keys show ties are redone with the exact permutation on the tied ranges
 // mode 2: exact pass on every range (keys known to be full of ties, e.g. chain scores)
 // workgroups of a class that fit the 160 KB of LDS of a CU (1 KB allocation granules) = wavefronts per SIMD the compiler
-// has to leave registers for (4 wavefronts per workgroup, 4 SIMDs per CU)
+// has to leave registers for (4 wavefronts per workgroup, 4 SIMDs per CU).  Round 6: five, not six, for the classes up to 2048 records - with 80 registers the
+// tie-free path spilled 100 bytes a lane; with 96 it does not (k_sort_block<2048> 60 -> 56 ms)
 template <int CAP, class KT>
-constexpr int sort_wg_per_cu() { return (int)((160u * 1024u) / ((sizeof(sort_lds<CAP, KT>) + 1023u) / 1024u * 1024u)) < (CAP <= 2048 ? 6 : 4) ? (int)((160u * 1024u) / ((sizeof(sort_lds<CAP, KT>) + 1023u) / 1024u * 1024u)) : (CAP <= 2048 ? 6 : 4); }
+constexpr int sort_wg_per_cu() { return (int)((160u * 1024u) / ((sizeof(sort_lds<CAP, KT>) + 1023u) / 1024u * 1024u)) < (CAP <= 2048 ? 5 : 4) ? (int)((160u * 1024u) / ((sizeof(sort_lds<CAP, KT>) + 1023u) / 1024u * 1024u)) : (CAP <= 2048 ? 5 : 4); }
 
 template <int CAP, class KT, class REC>
 __global__ __launch_bounds__(NT, (sort_wg_per_cu<CAP, KT>())) void k_sort_block(rh_sort_job jb, uint32_t n_lo, uint32_t n_hi, int mode)
