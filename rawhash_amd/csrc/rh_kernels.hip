@@ -990,21 +990,42 @@ __global__ __launch_bounds__(NT) void k_expand(rh_dev_opt o, rh_dev_index ix, rh
 	const bool pk = rr.afmt.rec8 != 0;
 	const uint32_t plo = rr.afmt.lo, pmid = rr.afmt.mid, psh = rr.afmt.shift, pqb = rr.aq_bits;
 	uint64_t *anc8 = reinterpret_cast<uint64_t*>(rr.raw) + base;
-	for (uint32_t j = tid; j < nn; j += NT) {
-		uint32_t lo = 0, hi = nm;   // largest s with s_pref[s] <= j
-		uint32_t vlo = 0;                                              // = pref[lo] (an exclusive prefix: pref[0] = 0)
-		if (in_lds) while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1, pv = s_pref[mid]; if (pv <= j) { lo = mid; vlo = pv; } else hi = mid; }
-		else while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1, pv = m_pref[mid]; if (pv <= j) { lo = mid; vlo = pv; } else hi = mid; }
-		const uint32_t s = lo, k = j - vlo;
-		const uint64_t hit = m_n[s] == 1 ? m_val[s] : ix.pos[m_val[s] + k];
-		const uint32_t meta = m_meta[s];
-		rh_mm128_t p;
-		p.x = (hit & 0x7FFFFFFF80000000ull) | (uint64_t)((uint32_t)(hit >> 1) & 0x7FFFFFFFu);
-		if (hit & 1ull) p.x |= 1ull << 63;
-		p.y = span << 32 | (uint64_t)(uint32_t)((meta & 0x7FFFFFFFu) + q_off);   // seg_id (y >> 40) is 0 for reads
-		if (meta >> 31) p.y |= 1ull << 38;
-		if (pk) anc8[j] = rh_rec8_pack_key(p.x, plo, pmid) << psh | (uint64_t)(meta >> 31) << pqb | (uint64_t)(uint32_t)p.y;
-		else anc[j] = p;
+	// (round 6: four anchors a thread and step - search, match record, position: three dependent trips per anchor, and the late rounds' few thousand reads of 10^5
+	// anchors each leave a workgroup little else to hide them behind; the four chains are independent)
+	constexpr int XU = 4;
+	for (uint32_t j0 = tid; j0 < nn; j0 += XU * NT) {
+		uint32_t sv[XU], kv[XU];
+#pragma unroll
+		for (int u = 0; u < XU; ++u) {
+			const uint32_t j = j0 + (uint32_t)u * NT;
+			uint32_t lo = 0, hi = nm;   // largest s with s_pref[s] <= j
+			uint32_t vlo = 0;                                              // = pref[lo] (an exclusive prefix: pref[0] = 0)
+			if (j < nn) {
+				if (in_lds) while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1, pv = s_pref[mid]; if (pv <= j) { lo = mid; vlo = pv; } else hi = mid; }
+				else while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1, pv = m_pref[mid]; if (pv <= j) { lo = mid; vlo = pv; } else hi = mid; }
+			}
+			sv[u] = lo; kv[u] = j - vlo;
+		}
+		uint32_t mn[XU], meta_v[XU]; uint64_t mv[XU];
+#pragma unroll
+		for (int u = 0; u < XU; ++u) { const bool on = j0 + (uint32_t)u * NT < nn; mn[u] = on ? m_n[sv[u]] : 1u; mv[u] = on ? m_val[sv[u]] : 0ull; meta_v[u] = on ? m_meta[sv[u]] : 0u; }
+		uint64_t hitv[XU];
+#pragma unroll
+		for (int u = 0; u < XU; ++u) hitv[u] = (mn[u] == 1 || j0 + (uint32_t)u * NT >= nn) ? mv[u] : ix.pos[mv[u] + kv[u]];
+#pragma unroll
+		for (int u = 0; u < XU; ++u) {
+			const uint32_t j = j0 + (uint32_t)u * NT;
+			if (j >= nn) continue;
+			const uint64_t hit = hitv[u];
+			const uint32_t meta = meta_v[u];
+			rh_mm128_t p;
+			p.x = (hit & 0x7FFFFFFF80000000ull) | (uint64_t)((uint32_t)(hit >> 1) & 0x7FFFFFFFu);
+			if (hit & 1ull) p.x |= 1ull << 63;
+			p.y = span << 32 | (uint64_t)(uint32_t)((meta & 0x7FFFFFFFu) + q_off);   // seg_id (y >> 40) is 0 for reads
+			if (meta >> 31) p.y |= 1ull << 38;
+			if (pk) anc8[j] = rh_rec8_pack_key(p.x, plo, pmid) << psh | (uint64_t)(meta >> 31) << pqb | (uint64_t)(uint32_t)p.y;
+			else anc[j] = p;
+		}
 	}
 	if (pk) { const uint64_t *pin8 = reinterpret_cast<const uint64_t*>(rr.prev_in) + rd.prev_off[r]; for (uint32_t j = tid; j < np; j += NT) anc8[nn + j] = pin8[j]; }   // (carried anchors are words already)
 	else

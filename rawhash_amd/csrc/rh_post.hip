@@ -303,14 +303,22 @@ __global__ __launch_bounds__(NT) void k_chain_reorder(rh_dev_reads rd, rh_dev_ro
 	#define CR_CHAIN(i_) (c8 ? (uint32_t)(w8[(i_)] & cmask) : (uint32_t)w[(i_)].y)
 	#define CR_FROM(i_) (c8 ? ck0[(uint32_t)(w8[(i_)] & cmask)] : (uint32_t)(w[(i_)].y >> 32))
 	uint32_t run = 0;
-	for (uint32_t i0 = 0; i0 < n_u; i0 += NT) {
-		const uint32_t i = i0 + tid;
-		uint64_t ui = 0;
-		if (i < n_u) { ui = u[CR_CHAIN(i)]; u2[i] = ui; }
-		uint32_t tot;
-		const uint32_t ex = block_excl_scan((uint32_t)ui, s_w, tot);
-		if (i < n_u) dk[i] = run + ex;
-		run += tot;
+	constexpr uint32_t RU = 4;                                      // (round 6) four sorted chains a thread and step, NT apart: their random looks at u[] in flight together
+	for (uint32_t i0 = 0; i0 < n_u; i0 += NT * RU) {
+		uint32_t cv[RU];
+		uint64_t uq[RU];
+#pragma unroll
+		for (uint32_t q = 0; q < RU; ++q) { const uint32_t i = i0 + q * NT + tid; cv[q] = i < n_u ? CR_CHAIN(i) : 0u; }
+#pragma unroll
+		for (uint32_t q = 0; q < RU; ++q) { const uint32_t i = i0 + q * NT + tid; uq[q] = i < n_u ? u[cv[q]] : 0ull; }
+#pragma unroll
+		for (uint32_t q = 0; q < RU; ++q) {
+			const uint32_t i = i0 + q * NT + tid;
+			uint32_t tot;
+			const uint32_t ex = block_excl_scan((uint32_t)uq[q], s_w, tot);
+			if (i < n_u) { u2[i] = uq[q]; dk[i] = run + ex; }
+			run += tot;
+		}
 	}
 	__syncthreads();
 	const uint32_t *tab = dk;
@@ -722,25 +730,38 @@ __global__ __launch_bounds__(NT) void k_regions_prep(rh_dev_opt o, rh_dev_reads 
 	hash ^= rh_wang32(rd.ev_off[r] + rr.n_ev[a]) + rh_wang32(11u);
 	hash = rh_wang32(hash);
 	uint32_t carry = 0;
-	for (int32_t i0 = 0; i0 < n_u; i0 += NT) {
-		const int32_t i = i0 + (int32_t)lane;
-		const uint64_t ui = i < n_u ? u[i] : 0ull;
-		const uint32_t cnt = (uint32_t)ui;
-		uint32_t tot;
-		const uint32_t k = carry + block_excl_scan(cnt, s_w, tot);
-		if (i < n_u) {
-			rh_mm128_t f0, f1;
+	// (round 6: four chains a thread and step, NT apart - every load of the four still coalesced; the two random looks at a chain's ends are in flight for four chains at once.
+	// Four CONSECUTIVE chains a thread - a quarter of the scans - made the kernel twice as slow: loads and the 32-byte head stores four lines wide)
+	constexpr int PU = 4;
+	const uint32_t n_seg = (uint32_t)(rr.a_off[a + 1] - base);
+	for (int32_t i0 = 0; i0 < n_u; i0 += NT * PU) {
+		uint64_t uv[PU]; uint32_t kk[PU];
+#pragma unroll
+		for (int q = 0; q < PU; ++q) { const int32_t i = i0 + q * NT + (int32_t)lane; uv[q] = i < n_u ? u[i] : 0ull; }
+#pragma unroll
+		for (int q = 0; q < PU; ++q) { uint32_t tot; kk[q] = carry + block_excl_scan((uint32_t)uv[q], s_w, tot); carry += tot; }
+		rh_mm128_t f0[PU], f1[PU];
+#pragma unroll
+		for (int q = 0; q < PU; ++q) {
+			const int32_t i = i0 + q * NT + (int32_t)lane;
+			f0[q].x = 0; f0[q].y = 0; f1[q].x = 0; f1[q].y = 0;
+			if (i >= n_u) continue;
 			if (skip2 && rr.lazy_reorder) {	// the keys once more (exact re-run): the heads are there - and the gathered chains may have been the first sort's scratch
 				const rh_chain_head h0 = heads[i];
-				f0.x = h0.x0; f0.y = h0.y0; f1.x = (uint64_t)(uint32_t)h0.x1; f1.y = (uint64_t)(uint32_t)h0.y1;
-			} else chain_ends(rr, base, (uint32_t)(rr.a_off[a + 1] - base), (uint32_t)i, k, cnt, f0, f1);
-			rh_chain_head h; h.x0 = f0.x; h.y0 = f0.y; h.x1 = (int32_t)f1.x; h.y1 = (int32_t)f1.y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
+				f0[q].x = h0.x0; f0[q].y = h0.y0; f1[q].x = (uint64_t)(uint32_t)h0.x1; f1[q].y = (uint64_t)(uint32_t)h0.y1;
+			} else chain_ends(rr, base, n_seg, (uint32_t)i, kk[q], (uint32_t)uv[q], f0[q], f1[q]);
+		}
+#pragma unroll
+		for (int q = 0; q < PU; ++q) {
+			const int32_t i = i0 + q * NT + (int32_t)lane;
+			if (i >= n_u) continue;
+			const uint32_t cnt = (uint32_t)uv[q], k = kk[q];
+			rh_chain_head h; h.x0 = f0[q].x; h.y0 = f0[q].y; h.x1 = (int32_t)f1[q].x; h.y1 = (int32_t)f1[q].y; h.cnt = (int32_t)cnt; h.k = (int32_t)k;
 			heads[i] = h;
-			const uint32_t hh = (uint32_t)rh_mix64_nomask((rh_mix64_nomask(f0.x) + rh_mix64_nomask(f0.y)) ^ (uint64_t)hash);
-			rh_mm128_t e; e.x = ui ^ (uint64_t)hh; e.y = rg_pack((uint32_t)i, cnt, (int64_t)(int32_t)f0.y, (int64_t)(int32_t)f1.y + 1);
+			const uint32_t hh = (uint32_t)rh_mix64_nomask((rh_mix64_nomask(f0[q].x) + rh_mix64_nomask(f0[q].y)) ^ (uint64_t)hash);
+			rh_mm128_t e; e.x = uv[q] ^ (uint64_t)hh; e.y = rg_pack((uint32_t)i, cnt, (int64_t)(int32_t)f0[q].y, (int64_t)(int32_t)f1[q].y + 1);
 			z[i] = e;
 		}
-		carry += tot;
 	}
 }
 
