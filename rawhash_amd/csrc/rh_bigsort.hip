@@ -1378,21 +1378,34 @@ __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 	uint8_t *dgn = C.dg_next + R.beg;
 	int ps = 0;
 	{ const uint64_t low = M.s > 0 ? (M.k_or & ~M.k_and) & ((1ull << M.s) - 1ull) : 0ull; if (low) ps = (63 - __clzll(low)) & ~7; }
+	// (round 6: the loads of all the thread's records - dest[], then hp[], and the records themselves - are issued in three batches before the first store; see k_bs_scatter_any)
+	constexpr uint32_t NP_SKIP = 0xFFFFFFFFu;
+	uint32_t jv[BS_TILE_IT], npv[BS_TILE_IT], look = 0;             // look: bit it = record it has a hole to look up
+	REC recs[BS_TILE_IT];
 #pragma unroll
 	for (int it = 0; it < BS_TILE_IT; ++it) {
 		const uint32_t p = t0 + (uint32_t)it * NT + tid;
+		jv[it] = 0; npv[it] = NP_SKIP;
 		if (p >= R.n) continue;
 		const uint32_t d = q.d[it], b = q.b[it], hb = hbase + q.hb[it];
 		if (d == dead_b) continue;
-		uint32_t np;
-		if (d == b) np = p + ((hb - s_hst[b]) < s_J[b] ? 1u : 0u);
-		else {
-			const uint32_t j = dest[hb], jj = j - s_hst[d];
-			if (j >= s_hst[256]) { C.hdr[7] = 2; continue; }           // not a hole of this range: a walk left dest[] unwritten -> "token walk made no progress", no access out of bounds
-			if (jj < s_J[d]) np = jj == 0 ? s_start[d] : hp[j - 1] + 1u;
-			else np = hp[j];
-		}
-		const REC rec = src[p];
+		recs[it] = src[p];
+		if (d == b) npv[it] = p + ((hb - s_hst[b]) < s_J[b] ? 1u : 0u);
+		else { jv[it] = dest[hb]; look |= 1u << it; }
+	}
+#pragma unroll
+	for (int it = 0; it < BS_TILE_IT; ++it) {
+		if (!((look >> it) & 1u)) continue;
+		const uint32_t d = q.d[it], j = jv[it], jj = j - s_hst[d];
+		if (j >= s_hst[256]) { C.hdr[7] = 2; continue; }               // not a hole of this range: a walk left dest[] unwritten -> "token walk made no progress", no access out of bounds
+		if (jj < s_J[d]) npv[it] = jj == 0 ? s_start[d] : hp[j - 1] + 1u;
+		else npv[it] = hp[j];
+	}
+#pragma unroll
+	for (int it = 0; it < BS_TILE_IT; ++it) {
+		if (npv[it] == NP_SKIP) continue;
+		const uint32_t d = q.d[it], np = npv[it];
+		const REC rec = recs[it];
 		const uint32_t ft = s_fate[d];
 		if (ft == BS_FINAL) out_fin[np] = rec; else out_alt[np] = rec;
 		if (ft == BS_BIG) dgn[np] = (uint8_t)(rh_rec_ops<REC>::key(rec, C.rf) >> ps);
@@ -1434,12 +1447,17 @@ __global__ __launch_bounds__(NT) void k_bs_scatter_any(bs_ctx C)
 	uint8_t *dgn = C.dg_next + R.beg;
 	int ps = 0;
 	{ const uint64_t low = M.s > 0 ? (M.k_or & ~M.k_and) & ((1ull << M.s) - 1ull) : 0ull; if (low) ps = (63 - __clzll(low)) & ~7; }
+	// (round 6: every record of the thread requested before the first store - the stores may alias the loads for all the compiler knows, so a load-then-store loop
+	// waits for memory once per record and a wavefront has one 512-byte request in flight; with 32 wavefronts a CU that is ~2 TB/s whatever HBM could deliver)
+	REC recs[BS_TILE_IT];
+#pragma unroll
+	for (int it = 0; it < BS_TILE_IT; ++it) { const uint32_t p = t0 + (uint32_t)it * NT + tid; if (p < R.n) recs[it] = src[p]; }
 #pragma unroll
 	for (int it = 0; it < BS_TILE_IT; ++it) {
 		const uint32_t p = t0 + (uint32_t)it * NT + tid;
 		if (p >= R.n) continue;
 		const uint32_t np = s_start[d[it]] + s_base[d[it]] + lr[it], ft = s_fate[d[it]];
-		const REC rec = src[p];
+		const REC rec = recs[it];
 		if (ft == BS_FINAL) out_fin[np] = rec; else out_alt[np] = rec;
 		if (ft == BS_BIG) dgn[np] = (uint8_t)(rh_rec_ops<REC>::key(rec, C.rf) >> ps);
 	}
