@@ -88,7 +88,7 @@ struct bs_meta {
 	uint32_t nh;
 	uint32_t pw, pw_ncpr, pw_off, pw_slots;   // block-parallel walk (k_bs_pw_count / k_bs_pw_walk): 0 or cycles per block; cycles followed at a time; the range's snapshot slots in C.pw_snap (word offset, number)
 };
-enum { BS_EMPTY = 0, BS_FINAL = 1, BS_SMALL = 2, BS_BIG = 3 };
+enum { BS_EMPTY = 0, BS_FINAL = 1, BS_SMALL = 2, BS_BIG = 3, BS_DROP = 4 };   // DROP: a bucket of an exact re-run (tie_path) that holds no equal keys - the any-order job before it left that stretch of the destination sorted: not placed, not sorted again
 
 struct bs_ctx {
 	void *buf[2];                         // 0 = job source (overwritten), 1 = alt; records of the job's type (rh_mm128_t, or uint64_t: rf.rec8)
@@ -386,6 +386,10 @@ __global__ __launch_bounds__(NT) void k_bs_plan(bs_ctx C)
 		else fate = BS_BIG;
 	}
 	if (C.redo_skip && fate == BS_FINAL && c > 1) bs_mark_tie(C, R.beg + st, c);   // (any order: a final bucket of several records = equal keys)
+	// Round 6.  The exact re-run of the segments an any-order job found equal keys in: a bucket is an interval of the sorted order, and one without equal keys has ONE sorted
+	// order - the one that job has already written to the destination.  Only the buckets on the way to the equal keys go on (the walk of THIS level still needed all of the
+	// range's records: who arrives where depends on every one of them); the others are dropped here - until round 6 they were placed and sorted a second time.
+	if (C.tie_path && R.exact && fate != BS_EMPTY && !bs_has_tie(C, R.beg + st, c)) fate = BS_DROP;
 	const uint8_t alt = R.buf ^ 1;
 	// Buckets for the block sorter go to one of two lists of the copy that holds them: 32-bit LDS keys when the bucket's keys
 	// agree on every bit from bit 32 up and that class takes a bucket of this size, 64-bit keys otherwise.  One atomic per
@@ -1388,7 +1392,7 @@ __global__ __launch_bounds__(NT) void k_bs_scatter(bs_ctx C)
 		jv[it] = 0; npv[it] = NP_SKIP;
 		if (p >= R.n) continue;
 		const uint32_t d = q.d[it], b = q.b[it], hb = hbase + q.hb[it];
-		if (d == dead_b) continue;
+		if (d == dead_b || s_fate[d] == BS_DROP) continue;
 		recs[it] = src[p];
 		if (d == b) npv[it] = p + ((hb - s_hst[b]) < s_J[b] ? 1u : 0u);
 		else { jv[it] = dest[hb]; look |= 1u << it; }
@@ -1607,7 +1611,7 @@ int rhk_bigsort(hipStream_t s, const rh_sort_job &jb, bool all_exact, uint32_t n
 		if (level) BS_LAUNCH_REC(k_bs_fix, n_rng, C);
 		else { BS_LAUNCH_REC(k_bs_fix0, n_rng, C, gs); n_rng0 = n_rng; }
 		RH_LAUNCH(k_bs_plan, n_rng, NT, 0, s, C);
-		if (jb.any_order || C.tie_path) BS_LAUNCH_REC(k_bs_scatter_any, n_tiles, C);   // no holes, no walk: tiles reserve stretches of their buckets (tie_path: the ranges off the way to the equal keys)
+		if (jb.any_order) BS_LAUNCH_REC(k_bs_scatter_any, n_tiles, C);   // no holes, no walk: tiles reserve stretches of their buckets (an exact re-run has no such ranges any more: its buckets off the way to the equal keys are dropped, k_bs_plan)
 		if (jb.any_order) {
 			RH_LAUNCH(k_bs_next, 1, NT, 0, s, C);
 			bs_range *tmp2 = C.rng[0]; C.rng[0] = C.rng[1]; C.rng[1] = tmp2;
