@@ -1149,7 +1149,7 @@ int rhk_sort_job(hipStream_t s, const rh_sort_job &job, bool all_exact, uint32_t
 	if (!job.n_seg) return 0;
 	rh_sort_job jb = job;
 	static const bool fast_on = !(getenv("RH_SORT_FAST") && atoi(getenv("RH_SORT_FAST")) == 0);   // RH_SORT_FAST=0: the general LDS path for every segment (A/B aid)
-	jb.fast_on = fast_on && !all_exact ? 1 : 0;
+	jb.fast_on = fast_on && !all_exact && !job.tie_path ? 1 : 0;   // (an exact re-run's buckets are the ones that hold equal keys - the others are dropped, rh_bigsort.hip - so the tie-free path would only find out again)
 	uint32_t top;
 	static const bool tiny_on = !(RH_DEVENV("RH_SORT_TINY") && atoi(RH_DEVENV("RH_SORT_TINY")) == 0);
 	if (tiny_on && min_n < (uint32_t)RH_SORT_TINY) {	// one lane per segment of up to 32 records
