@@ -235,6 +235,14 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 			const uint32_t xi = (uint32_t)x, yi = (uint32_t)y;
 			const int32_t span_i = (int32_t)((y >> 32) & 63);
 			if (inb) { const uint32_t sl = (uint32_t)ii & 127u; L.s_xlo[sl] = xi; L.s_ylo[sl] = yi; L.s_span[sl] = (uint8_t)span_i; }
+			// (round 6) the FIRST anchor of every small cluster is settled here, with the staging - it has no predecessor: f = v = span, p = -1, max_ii = itself - instead of in
+			// a DP step of its own (a ballot, the generic step's code under an empty mask for 63 lanes, a barrier: one of ~3.3 steps a tile)
+			if (small && pos == 0) {
+				const uint32_t sl = (uint32_t)ii & (CH_RING - 1);
+				L.f[sl] = span_i; L.p[sl] = -1; L.v[sl] = span_i;
+				gfp[2 * ii] = span_i; gfp[2 * ii + 1] = -1; gv[ii] = span_i;
+				L.s_mi[(uint32_t)ii & 127u] = ii;
+			}
 			__syncthreads();
 			int32_t sc[CH_SMALL];
 #pragma unroll
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 				}
 			}
 #pragma unroll
-			for (int sidx = 0; sidx < CH_SMALL; ++sidx) {
+			for (int sidx = 1; sidx < CH_SMALL; ++sidx) {
 				if (__ballot(small && pos >= sidx) == 0) break;
 				CPROF(8, 1);
 				if (small && pos == sidx) {
