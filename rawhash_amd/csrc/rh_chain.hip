@@ -55,7 +55,12 @@ struct chain_lds {
 // A read with many anchors (large indexes: tens of thousands per chunk) is split over several wavefronts: the clusters are
 // independent, so wavefront `tix` takes the clusters that START in [tix * tile_len, (tix + 1) * tile_len) - it skips the
 // tail of a cluster that began before its slice and runs past the end of the slice until the next cluster starts.
-__global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr, uint32_t tiles_per_read, uint32_t tile_len)
+// fsn ("free of skips up to n"): min(max_skip, max_iter, CH_SMALL - 1), or 0 to keep the generic step everywhere (RH_CHAIN_GENERIC=1).  The step that settles position s <= fsn of a
+// small cluster can neither break on skips (that takes max_skip + 1 non-improving predecessors) nor have its window clamped by max_iter, so its window ends only where the cluster
+// starts or the target distance exceeds max_dist_t - and then lchain.c's "max_ii" (the best anchor in reach, tried when it lies BEFORE the walked window) cannot apply: whatever
+// lies before the window is out of reach.  Such a step is just the max over the window's scores; max_ii's state, which the later generic steps of longer clusters (s > fsn) start
+// from, is caught up for those clusters only.
+__global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr, uint32_t tiles_per_read, uint32_t tile_len, int32_t fsn)
 {
 	__shared__ chain_lds L;
 	const uint32_t a = blockIdx.x / tiles_per_read, tix = blockIdx.x % tiles_per_read, lane = threadIdx.x;
@@ -258,7 +263,54 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 				}
 			}
 #pragma unroll
+			for (int sidx = 1; sidx < CH_SMALL; ++sidx) {           // the skip-free steps
+				if (__ballot(small && pos >= sidx && sidx <= fsn) == 0) break;      // (fsn inside the ballot: as an exit test of its own it keeps the compiler from unrolling the loop)
+				CPROF(8, 1);
+				if (small && pos == sidx) {
+					int32_t max_f = span_i, max_j = -1;
+#pragma unroll
+					for (int r = 1; r <= sidx; ++r) {
+						if (sc[r] > CH_FAR) {                          // a pair that scores (neither RH_SCORE_NONE nor out of reach: x ascends, so everything behind an out-of-reach anchor is too)
+							const int32_t cand = sc[r] + L.f[(uint32_t)(ii - r) & (CH_RING - 1)];
+							if (cand > max_f) { max_f = cand; max_j = ii - r; }
+						}
+					}
+					int32_t vv = max_f;
+					if (max_j >= 0) { const int32_t vmj = L.v[(uint32_t)max_j & (CH_RING - 1)]; if (vmj > max_f) vv = vmj; }
+					const uint32_t sl = (uint32_t)ii & (CH_RING - 1);
+					L.f[sl] = max_f; L.p[sl] = max_j; L.v[sl] = vv;
+					gfp[2 * ii] = max_f; gfp[2 * ii + 1] = max_j; gv[ii] = vv;
+				}
+				__syncthreads();
+			}
+			const bool need_mi = small && ce_g - cs_g > fsn;         // the cluster has positions beyond fsn: generic steps follow (here or in the next tile)
+			if (__ballot(need_mi)) {
+#pragma unroll
+			for (int k = 1; k < CH_SMALL; ++k) {                    // max_ii after each skip-free position of those clusters (the rule of lchain.c:479-497, minus the pair it cannot reach)
+				if (__ballot(need_mi && pos >= k && k <= fsn) == 0) break;
+				if (need_mi && pos == k) {
+					int32_t mi = L.s_mi[(uint32_t)(ii - 1) & 127u], fmi = 0;
+					uint32_t xmi = 0;
+					if (mi >= 0) { xmi = L.s_xlo[(uint32_t)mi & 127u]; fmi = L.f[(uint32_t)mi & (CH_RING - 1)]; }
+					if (mi < 0 || (uint32_t)(xi - xmi) > D32) {
+						int32_t mx = INT32_MIN;
+						mi = -1;
+						bool reach = true;
+#pragma unroll
+						for (int r = 1; r <= k; ++r) {
+							reach = reach && sc[r] != CH_FAR;
+							if (reach) { const int32_t fj = L.f[(uint32_t)(ii - r) & (CH_RING - 1)]; if (mx < fj) { mx = fj; mi = ii - r; } }
+						}
+						if (mi >= 0) { fmi = mx; xmi = L.s_xlo[(uint32_t)mi & 127u]; }
+					}
+					if (mi < 0 || ((uint32_t)(xi - xmi) <= D32 && fmi < L.f[(uint32_t)ii & (CH_RING - 1)])) mi = ii;
+					L.s_mi[(uint32_t)ii & 127u] = mi;
+				}
+				__syncthreads();
+			}
+#pragma unroll
 			for (int sidx = 1; sidx < CH_SMALL; ++sidx) {
+				if (sidx <= fsn) continue;
 				if (__ballot(small && pos >= sidx) == 0) break;
 				CPROF(8, 1);
 				if (small && pos == sidx) {
@@ -309,6 +361,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 					L.s_mi[(uint32_t)ii & 127u] = mi;
 				}
 				__syncthreads();                                     // the step's f / p / v / max_ii are in the ring
+			}
 			}
 		}
 #ifdef RH_KPROF
@@ -796,7 +849,9 @@ void rhk_chain(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 	if (!r.n_act) return;
 	if (o.max_iter <= CH_MAX_ITER) {
 		const uint32_t tiles = r.max_anchors > (uint32_t)CH_TILE ? (r.max_anchors + CH_TILE - 1) / CH_TILE : 1u;
-		RH_LAUNCH(k_chain_wave, r.n_act * tiles, 64, rh_wave_lds(), s, o, r, tiles, tiles > 1 ? (uint32_t)CH_TILE : 0u);
+		int32_t fsn = o.max_skip < o.max_iter ? o.max_skip : o.max_iter;
+		fsn = fsn < 0 || getenv("RH_CHAIN_GENERIC") ? 0 : fsn > CH_SMALL - 1 ? CH_SMALL - 1 : fsn;
+		RH_LAUNCH(k_chain_wave, r.n_act * tiles, 64, rh_wave_lds(), s, o, r, tiles, tiles > 1 ? (uint32_t)CH_TILE : 0u, fsn);
 	}
 	else RH_LAUNCH(k_chain_serial, (r.n_act + 63) / 64, 64, 0, s, o, r);
 }

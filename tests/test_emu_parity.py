@@ -117,6 +117,22 @@ def test_rmq_chaining(make_workload, emu_lib, mapopt):
     c.close()
 
 
+CHAIN_LIMITS = [{"max_num_skips": 2, "max_chain_iter": 40}, {"max_num_skips": 25, "max_chain_iter": 5}, {"max_num_skips": 0, "max_chain_iter": 3}]
+
+
+@pytest.mark.parametrize("mapopt", CHAIN_LIMITS, ids=lambda m: "_".join(f"{k}{v}" for k, v in m.items()))
+def test_chain_skip_and_iter_limits(make_workload, emu_lib, mapopt):
+    """--max-skips / --max-iterations below the size of a small cluster: k_chain_wave's one-anchor-per-lane path then runs its generic step (skip counting, the
+    clamped window, max_ii) instead of the skip-free one every preset takes (k_chain_wave<FS>, rh_chain.hip)."""
+    w = make_workload(lib=emu_lib, n_reads=14, n_samples=12_000, mapopt=mapopt)
+    c = Context(0, lib=emu_lib)
+    c.upload(w.index)
+    n_an, n_ch, n_u = pc.check_chain_synthetic(c, w, seed=9, n_reads=24, max_n=400)
+    assert n_ch > 0 and n_u > 0
+    pc.check_e2e(c, w)
+    c.close()
+
+
 def test_rmq_tree_storage_classes(make_workload, emu_lib_smallcaps):
     """The RMQ trees live in LDS rings where a read's window of live nodes fits (three classes: RQ_RING_S / RQ_RING / RQ_RING_BIG nodes, a launch each) and in
     the read's scratch in HBM beyond that: a build with rings of 4 / 8 / 32 nodes sends reads through all four on small inputs."""

@@ -95,6 +95,26 @@ def test_rmq_chaining(make_workload, product_lib, gpu_ctx_factory, mapopt):
     pc.check_e2e(c, w)
 
 
+@pytest.mark.parametrize("mapopt", [{"max_num_skips": 2, "max_chain_iter": 40}, {"max_num_skips": 25, "max_chain_iter": 5}, {"max_num_skips": 0, "max_chain_iter": 3}],
+                         ids=lambda m: "_".join(f"{k}{v}" for k, v in m.items()))
+def test_chain_skip_and_iter_limits(make_workload, product_lib, gpu_ctx_factory, mapopt):
+    """--max-skips / --max-iterations below the size of a small cluster: the generic DP step of k_chain_wave's small-cluster path (every preset takes the skip-free
+    one, k_chain_wave<true>); plus the generic step forced under the default options (RH_CHAIN_GENERIC) in test_chain_generic_step."""
+    w = make_workload(n_reads=300, n_samples=20_000, mapopt=mapopt)
+    c = gpu_ctx_factory()
+    c.upload(w.index)
+    n_an, n_ch, n_u = pc.check_chain_synthetic(c, w, seed=26, n_reads=200, max_n=1500)
+    assert n_ch > 0 and n_u > 0
+    pc.check_e2e(c, w)
+
+
+def test_chain_generic_step(ctx, wl, monkeypatch):
+    monkeypatch.setenv("RH_CHAIN_GENERIC", "1")
+    n_an, n_ch, n_u = pc.check_chain_synthetic(ctx, wl, seed=27, n_reads=200, max_n=1500)
+    assert n_ch > 0 and n_u > 0
+    pc.check_e2e(ctx, wl)
+
+
 @pytest.mark.parametrize("min_class", [0, 1, 2, 3])
 def test_rmq_storage_classes_on_device(make_workload, product_lib, gpu_ctx_factory, monkeypatch, min_class):
     """The RMQ trees' four storage classes (LDS rings of 64 / 128 / 512 nodes, HBM: rh_chain.hip k_chain_rmq<RING, class>) each forced on the real device -
