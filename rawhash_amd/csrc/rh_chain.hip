@@ -24,7 +24,7 @@
 
 #ifdef RH_KPROF
 // development aid: what k_chain_wave's tiles are made of - [0] tiles, [1] anchors, [2] singletons, [3] anchors of small clusters, [4] of large ones, [5] tiles that enter the small path,
-// [6] tiles that enter the large path, [7] pair-score rounds (r) of the small path, [8] DP steps (sidx) of the small path, [9] anchors in clusters of exactly two, [10] shader clocks in the large path, [11] in the small path, [12] in the whole kernel
+// [6] tiles that enter the large path, [7] pair-score rounds (r) of the small path, [8] DP steps (sidx) of the small path, [9] anchors in clusters of exactly two, [10] shader clocks in the large path, [11] in the small path, [12] before either (tile set-up), [13] small path: staging + pair scores, [14] its skip-free steps, [15] max_ii catch-up + generic steps
 __device__ unsigned long long rh_kprof_chain[16];
 extern "C" __attribute__((visibility("default"))) int rh_debug_kprof_chain(unsigned long long *out, int reset)
 {
@@ -35,6 +35,12 @@ extern "C" __attribute__((visibility("default"))) int rh_debug_kprof_chain(unsig
 #define CPROF(slot, v) do { if (threadIdx.x == 0) atomicAdd(&rh_kprof_chain[slot], (unsigned long long)(v)); } while (0)
 #else
 #define CPROF(slot, v)
+#endif
+// a register pair that a load was issued into earlier: the compiler's wait for that load goes where this stands, and memory operations after it stay after it
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RH_LANDED(a, b) asm volatile("" : "+v"(a), "+v"(b) : : "memory")
+#else
+#define RH_LANDED(a, b) ((void)0)
 #endif
 struct chain_lds {
 	uint32_t xlo[CH_RING], ylo[CH_RING];
@@ -89,15 +95,22 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 	uint32_t xlo_ii = 0;
 	uint64_t x_before = T0 > 0 ? AN_(T0 - 1).x : 0ull;             // x of the anchor preceding the tile
 	// software pipeline over the tiles: A = current, B = next (needed to size a cluster that runs over the tile edge), C in flight
-	uint64_t xB = 0, yB = 0, xC = 0, yC = 0;
+	// C stays AS LOADED (one-word anchors are taken apart only when they become B, a whole tile after the load was issued): consumed any earlier, the wait for it would sit right
+	// behind the load and every tile would pay the memory latency in full
+	uint64_t xB = 0, yB = 0;
+	rh_mm128_t rawC; rawC.x = 0; rawC.y = 0;
 	if (T0 + (int32_t)lane < n) { const rh_mm128_t q = AN_(T0 + lane); xB = q.x; yB = q.y; }
-	if (T0 + 64 + (int32_t)lane < n) { const rh_mm128_t q = AN_(T0 + 64 + lane); xC = q.x; yC = q.y; }
+	if (T0 + 64 + (int32_t)lane < n) rawC = rh_an_raw_ld(rr, rr.anc, base + (uint64_t)(T0 + 64 + (int32_t)lane));
 	for (int32_t i0 = T0; i0 < n; i0 += 64) {
+#ifdef RH_KPROF
+		const unsigned long long cp_top = clock64();
+#endif
 		const int32_t ii = i0 + (int32_t)lane;
 		const bool inb_r = ii < n;
 		const uint64_t x = xB, y = yB;
-		xB = xC; yB = yC;
-		if (ii + 128 < n) { const rh_mm128_t q = AN_(ii + 128); xC = q.x; yC = q.y; } else { xC = 0; yC = 0; }
+		RH_LANDED(rawC.x, rawC.y);                                  // the load issued one tile ago is waited for HERE, before the next one is issued
+		if (ii + 64 < n) { const rh_mm128_t q = rr.afmt.rec8 ? rh_anchor_unpack(rawC.x, rr.afmt, rr.aq_bits, rr.a_span) : rawC; xB = q.x; yB = q.y; } else { xB = 0; yB = 0; }
+		if (ii + 128 < n) rawC = rh_an_raw_ld(rr, rr.anc, base + (uint64_t)(ii + 128));
 		const uint64_t xprev = (uint64_t)rh_wave_shr1((uint32_t)(x >> 32), (uint32_t)(x_before >> 32)) << 32 | rh_wave_shr1((uint32_t)x, (uint32_t)x_before);
 		const bool start_r = inb_r && (ii == 0 || (x >> 32) != (xprev >> 32) || x > xprev + D64);
 		const uint64_t x_last = (uint64_t)rh_readlane((uint32_t)(x >> 32), 63u) << 32 | rh_readlane((uint32_t)x, 63u);
@@ -136,6 +149,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 		if (!(bmaskB & 1ull) && smask) open_start = i0 + 63 - (int32_t)__clzll(smask);   // cluster still open at the tile's end
 		uint64_t mmask = __ballot(inb && !single && !small);       // members of the larger clusters, walked in order
 #ifdef RH_KPROF
+		CPROF(12, clock64() - cp_top);
 		CPROF(0, 1); CPROF(1, __popcll(__ballot(inb))); CPROF(2, __popcll(__ballot(inb && single))); CPROF(3, __popcll(__ballot(small))); CPROF(4, __popcll(mmask));
 		CPROF(9, __popcll(__ballot(inb && !single && ce_g - cs_g == 1)));
 		if (__ballot(small)) CPROF(5, 1);
@@ -262,6 +276,9 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 					        : rh_pair_score_d((int32_t)yi - (int32_t)yj, (int32_t)(xi - xj), (int32_t)L.s_span[sl], max_dist_t, max_dist_q, bw, o.pen_gap, o.pen_skip);
 				}
 			}
+#ifdef RH_KPROF
+			const unsigned long long cp_t2 = clock64(); CPROF(13, cp_t2 - cp_t1);
+#endif
 #pragma unroll
 			for (int sidx = 1; sidx < CH_SMALL; ++sidx) {           // the skip-free steps
 				if (__ballot(small && pos >= sidx && sidx <= fsn) == 0) break;      // (fsn inside the ballot: as an exit test of its own it keeps the compiler from unrolling the loop)
@@ -283,6 +300,9 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 				}
 				__syncthreads();
 			}
+#ifdef RH_KPROF
+			const unsigned long long cp_t3 = clock64(); CPROF(14, cp_t3 - cp_t2);
+#endif
 			const bool need_mi = small && ce_g - cs_g > fsn;         // the cluster has positions beyond fsn: generic steps follow (here or in the next tile)
 			if (__ballot(need_mi)) {
 #pragma unroll
@@ -363,6 +383,9 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 				__syncthreads();                                     // the step's f / p / v / max_ii are in the ring
 			}
 			}
+#ifdef RH_KPROF
+			CPROF(15, clock64() - cp_t3);
+#endif
 		}
 #ifdef RH_KPROF
 		CPROF(11, clock64() - cp_t1);

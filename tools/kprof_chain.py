@@ -9,6 +9,6 @@ bench.main()
 out = (C.c_ulonglong * 16)()
 _capi.lib().rh_debug_kprof_chain(out, 0)
 names = ["tiles", "anchors", "singletons", "anchors in small clusters", "anchors in large clusters", "tiles entering the small path", "tiles entering the large path",
-         "pair-score rounds (small path)", "DP steps (small path)", "anchors in clusters of two", "clocks: large path", "clocks: small path"]
+         "pair-score rounds (small path)", "DP steps (small path)", "anchors in clusters of two", "clocks: large path", "clocks: small path", "clocks: tile set-up", "clocks: staging + pair scores", "clocks: skip-free steps", "clocks: max_ii catch-up + generic steps"]
 for i, n in enumerate(names):
     print(f"slot {i:2d} {n:34s} {out[i]:16d}")
