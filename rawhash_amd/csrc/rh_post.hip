@@ -33,7 +33,21 @@ extern "C" __attribute__((visibility("default"))) int rh_debug_kprof_post(unsign
 // ------------------------------------------------------------------------------------------------ k_zbuild
 // candidates without a predecessor are passed over by the backtrack (see k_zbuild): plain chaining, one-word anchors (one span), chains of >= 2 anchors
 RH_HD inline bool bt_lone_on(const rh_dev_opt &o, const rh_dev_round &rr) { return o.min_cnt >= 2 && rr.afmt.rec8 && !(o.flag & RH_M_RMQ) && !(o.bw_long > o.bw); }
-__global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
+// The backtrack's "used" marks and claim stamps of a read with up to BT_LDS_ANCHORS anchors live in LDS (k_backtrack_spec<BT, LMW > 0>): a bit per anchor, the stamps in a table of
+// BT_LDS_CLAIMS (x 2 for 512 threads) words indexed by the anchor's low bits.  lds_cap = that limit, or 0 when the LDS form is off (RH_BT_LDS=0, RH_BT_WAVE=1): k_zbuild zeroes
+// the marks and stamps in HBM only for the reads that keep them there.
+#ifndef BT_LDS_ANCHORS
+#define BT_LDS_ANCHORS 524288   // the largest of three classes (a quarter, a half, all of it: 16 / 32 / 64 KB of marks)
+#endif
+#ifndef BT_LDS_THREADS
+#define BT_LDS_THREADS 512   // a workgroup of the two larger LDS classes: eight wavefronts share a read's marks - the 32 KB class runs 3 workgroups = 24 wavefronts a CU instead of 4 = 16 (measured: 67 -> 59 ms a step; the 16 KB class is better off with 256 threads, 54 against 64 ms)
+#endif
+#ifndef BT_LDS_CLAIMS
+#define BT_LDS_CLAIMS 2048
+#endif
+inline int bt_lds_min_class() { const char *e = getenv("RH_BT_LDS_MIN_CLASS"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : v > 3 ? 3 : v; }   // test aid: no read takes a narrower class than this (3 = HBM)
+inline uint32_t bt_lds_cap() { return (getenv("RH_BT_LDS") && atoi(getenv("RH_BT_LDS")) == 0) || getenv("RH_BT_WAVE") || bt_lds_min_class() == 3 ? 0u : (uint32_t)BT_LDS_ANCHORS; }
+__global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr, uint32_t lds_cap)
 {
 	__shared__ uint32_t s_w[NT / 64];
 	const uint32_t a = blockIdx.x, tid = threadIdx.x;
@@ -45,9 +59,11 @@ __global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 	rh_mm128_t *z = rr.raw + base;               // the unsorted anchor copy is dead after the anchor sort
 	uint64_t *z8 = reinterpret_cast<uint64_t*>(rr.raw) + base;   // rr.z8: 8-byte candidates  score << 32 | anchor
 	uint32_t *t4 = (uint32_t*)(rr.ws + base * rr.ws_stride + (size_t)16 * n);   // backtrack's "touched" marks (1 B per anchor)
-	for (int32_t i = (int32_t)tid; i < (n + 3) / 4; i += NT) t4[i] = 0u;
 	uint32_t *claim = (uint32_t*)(rr.ws + base * rr.ws_stride + (size_t)20 * n);   // k_backtrack_spec's per-anchor claim stamps
-	for (int32_t i = (int32_t)tid; i < n; i += NT) claim[i] = 0u;
+	if ((uint32_t)n > lds_cap) {
+		for (int32_t i = (int32_t)tid; i < (n + 3) / 4; i += NT) t4[i] = 0u;
+		for (int32_t i = (int32_t)tid; i < n; i += NT) claim[i] = 0u;
+	}
 	// A candidate WITHOUT A PREDECESSOR - most anchors of an unmappable read - is a chain of one anchor: with min_num_anchors >= 2
 	// mg_chain_backtrack marks it used and drops it (lchain.c:148-170), and nobody ever looks at that mark: an anchor that chains onto another scores
 	// more than its own span (mg_lchain_dp starts max_f at the span and takes a predecessor only if that beats it, lchain.c:443, 463, 489), every anchor of the round has the
@@ -101,17 +117,34 @@ __global__ __launch_bounds__(NT) void k_zbuild(rh_dev_opt o, rh_dev_round rr)
 // BT = 64: one wavefront per read.  BT = 256 (round 5): a WORKGROUP per read, 256 candidates per round - the reads of the late rounds are fewer than the chip has
 // wave slots (6 500 unmappable reads of 10^5 candidates each) and a read's batches are a serial chain of ~10 us rounds, so the kernel took as long as
 // its slowest read; four wavefronts walk four times the candidates per round (same CU, same L1: the marks stay plain loads and stores).
-template <int BT>
-__global__ __launch_bounds__(BT) void k_backtrack_spec(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr)
+// LM (round 6): the marks and stamps in LDS for the reads of up to lds_cap anchors - a bit per anchor (atomic OR), the stamps in a table indexed by the anchor's low bits.  Two
+// anchors that share a table word can only make a lane see a better lane's stamp where there is none: it walks again next round (the best pending lane holds the highest stamp
+// of the round wherever it stamped, so it always commits), the result is the same.  Per chain of two this takes the mark line, the stamp line (an L2 read-modify-write) and their
+// write-backs out of the kernel's random HBM lines, which leaves the {f, p} line and the anchors' line.  The reads above lds_cap take the <BT, false> launch.
+// LMW = the marks' 32-bit words (0: marks and stamps in HBM); the launch takes the reads of lo_cap < n <= 32 LMW anchors (LMW = 0: n > lo_cap).
+template <int BT, int LMW>
+__global__ __launch_bounds__(BT) void k_backtrack_spec(rh_dev_opt o, rh_dev_reads rd, rh_dev_round rr, uint32_t lo_cap)
 {
-	constexpr int SH = BT > 64 ? 8 : 6;                              // stamp = round << SH | priority
+	constexpr bool LM = LMW > 0;
+	constexpr int SH = BT > 256 ? 9 : BT > 64 ? 8 : 6;               // stamp = round << SH | priority
 	__shared__ uint32_t s_w[BT / 64 + 1];
+	__shared__ uint32_t s_bits[LM ? LMW : 1];
+	constexpr uint32_t CL = (uint32_t)BT_LDS_CLAIMS * (BT > 256 ? 2u : 1u);
+	__shared__ uint32_t s_claim[LM ? CL : 1];
 	const uint32_t a = blockIdx.x, lane = threadIdx.x;               // ("lane" = the candidate's place in the batch, 0 = best score)
 	if (a >= rr.n_act) return;
-	if (rr.skip[a]) { if (lane == 0) { rr.n_u[a] = 0; rr.n_v[a] = 0; } return; }
-	const uint32_t r = rr.act[a];
 	const uint64_t base = rr.a_off[a];
 	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
+	if ((uint32_t)n <= lo_cap || (LM && (uint32_t)n > 32u * (uint32_t)LMW)) return;   // another launch's read
+	if (rr.skip[a]) { if (lane == 0) { rr.n_u[a] = 0; rr.n_v[a] = 0; } return; }
+	const uint32_t r = rr.act[a];
+	if (LM) {
+		for (uint32_t k = lane; k < ((uint32_t)n + 31u) / 32u; k += BT) s_bits[k] = 0u;
+		for (uint32_t k = lane; k < CL; k += BT) s_claim[k] = 0u;
+	}
+	#define BK_USED(i) (LM ? (uint8_t)((s_bits[(uint32_t)(i) >> 5] >> ((uint32_t)(i) & 31u)) & 1u) : t[(i)])
+	#define BK_MARK(i) do { if (LM) atomicOr(&s_bits[(uint32_t)(i) >> 5], 1u << ((uint32_t)(i) & 31u)); else t[(i)] = 1; } while (0)
+	#define BK_STAMP(i) do { if (LM) atomicMax(&s_claim[(uint32_t)(i) & (CL - 1u)], stamp); else atomicMax(&claim[(i)], stamp); } while (0)
 	const int32_t n_z = (int32_t)rr.n_z[a];
 	unsigned char *wsr = rr.ws + base * rr.ws_stride;
 	const int2 *fp = (const int2*)wsr;                              // .x = f, .y = p
@@ -147,19 +180,19 @@ __global__ __launch_bounds__(BT) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 			const uint32_t stamp = epoch << SH | ((uint32_t)BT - 1u - lane);
 			bool walked = false;
 			int32_t zx = 0, path = 0, max_s = 0, emit = 0;             // path = unused anchors reached after i0; emit = anchors i0 .. before max_i
-			if (pending && t[i0] == 0) {
+			if (pending && BK_USED(i0) == 0) {
 				walked = true;
 				int2 rec = fp[i0];
 				zx = rec.x;
-				if (!solo) atomicMax(&claim[i0], stamp);
+				if (!solo) BK_STAMP(i0);
 				for (;;) {	// mg_chain_bk_end (lchain.c:47-75): back until a used anchor, the start, or a score drop > max_drop
 					const int32_t i = rec.y;
 					int32_t sdrop = zx;
 					uint8_t ti = 0;
 					if (i >= 0) {
-						rec = fp[i]; ti = t[i]; sdrop = zx - rec.x;
+						rec = fp[i]; ti = BK_USED(i); sdrop = zx - rec.x;
 						if (ti == 0) {	// (a used anchor ends every walk that reaches it: nobody's to take, nothing to stamp)
-							if (!solo) atomicMax(&claim[i], stamp);
+							if (!solo) BK_STAMP(i);
 							++path;
 							if (path == 1) pn1 = i; else if (path == 2) pn2 = i; else if (path == 3) pn3 = i;
 						}
@@ -173,7 +206,7 @@ __global__ __launch_bounds__(BT) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 			__syncthreads();                                          // every stamp of the round is in
 			bool conflict = false;
 			if (walked && !solo) {	// read at L2, where the stamps were combined; the cached anchors' reads are independent of each other
-				#define BK_CLAIM(i) __hip_atomic_load(&claim[(i)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)   /* an L2 read, no read-modify-write */
+				#define BK_CLAIM(i) (LM ? s_claim[(uint32_t)(i) & (CL - 1u)] : __hip_atomic_load(&claim[(i)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))   /* HBM form: an L2 read, no read-modify-write */
 				const uint32_t c0 = BK_CLAIM(i0);
 				const uint32_t c1 = path >= 1 ? BK_CLAIM(pn1) : stamp;
 				const uint32_t c2 = path >= 2 ? BK_CLAIM(pn2) : stamp;
@@ -185,12 +218,12 @@ __global__ __launch_bounds__(BT) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 			}
 			if (pending && !conflict) {
 				if (walked) {	// anchors i0 .. (exclusive) max_i form the chain; the marks stay even if it is rejected, as in the reference
-					if (emit >= 1) t[i0] = 1;
-					if (emit >= 2) t[pn1] = 1;
-					if (emit >= 3) t[pn2] = 1;
-					if (emit >= 4) t[pn3] = 1;
+					if (emit >= 1) BK_MARK(i0);
+					if (emit >= 2) BK_MARK(pn1);
+					if (emit >= 3) BK_MARK(pn2);
+					if (emit >= 4) BK_MARK(pn3);
 					int32_t x = pn3;
-					for (int32_t j = 4; j < emit; ++j) { x = fp[x].y; t[x] = 1; }
+					for (int32_t j = 4; j < emit; ++j) { x = fp[x].y; BK_MARK(x); }
 					accepted = max_s >= min_sc && emit > 0 && emit >= min_cnt;   // (score of the chain = the best drop seen = max_s)
 					r_cnt = emit; r_sc = max_s;
 					if (accepted) {	// (the loads travel while the other lanes' rounds go on)
@@ -235,6 +268,9 @@ __global__ __launch_bounds__(BT) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 		rr.n_u[a] = (uint32_t)n_u; rr.n_v[a] = (uint32_t)n_v;
 		if (n_u == 0) { rd.n_prev[r] = 0; rd.prev_off[r] = base; }
 	}
+	#undef BK_USED
+	#undef BK_MARK
+	#undef BK_STAMP
 }
 
 // compact_a (lchain.c:214-281) around the block sorter:
@@ -1719,7 +1755,7 @@ static void sort_scratch(rh_sort_job &jb, const rh_dev_round &r, rh_mm128_t *idl
 int rhk_zsort(hipStream_t s, const rh_dev_opt &o, const rh_dev_round &r)
 {
 	if (!r.n_act) return 0;
-	RH_LAUNCH(k_zbuild, r.n_act, NT, 0, s, o, r);
+	RH_LAUNCH(k_zbuild, r.n_act, NT, 0, s, o, r, bt_lds_cap());
 	// candidates (score, anchor index) -> reference order; scores are full of ties: exact permutation for every read
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_z, r.raw, r.zs, r.need_exact, r.ws, RH_WS_PER_ANCHOR, 64, (uint8_t)(o.min_sc >= 0), 32, 0, 0, r.max_anchors };   // keys = scores >= min_sc: non-negative int32
 	sort_scratch(jb, r, r.prev_out);                               // (the carry staging is written by the backtrack, later)
@@ -1733,8 +1769,18 @@ int rhk_backtrack(hipStream_t s, const rh_dev_opt &o, const rh_dev_reads &rd, co
 {
 	if (!r.n_act) return 0;
 	const bool bt_wave = getenv("RH_BT_WAVE") != nullptr;            // RH_BT_WAVE=1: one wavefront per read, 64 candidates a round (A/B and test aid; read per call)
-	if (bt_wave) RH_LAUNCH(k_backtrack_spec<64>, r.n_act, 64, rh_wave_lds(), s, o, rd, r);
-	else RH_LAUNCH(k_backtrack_spec<256>, r.n_act, 256, rh_wave_lds(), s, o, rd, r);
+	const uint32_t lds_cap = bt_lds_cap();                           // (the same value k_zbuild got: both read the environment per call)
+	const uint32_t top = r.max_anchors ? r.max_anchors : 0xFFFFFFFFu;
+	if (bt_wave) RH_LAUNCH((k_backtrack_spec<64, 0>), r.n_act, 64, rh_wave_lds(), s, o, rd, r, 0u);
+	else if (!lds_cap) RH_LAUNCH((k_backtrack_spec<256, 0>), r.n_act, 256, rh_wave_lds(), s, o, rd, r, 0u);
+	else {   // three LDS classes (16 / 32 / 64 KB of marks: 6 / 4 / 2 workgroups a CU), each launched if the round has such reads, and HBM beyond
+		constexpr int W0 = BT_LDS_ANCHORS / 128, W1 = BT_LDS_ANCHORS / 64, W2 = BT_LDS_ANCHORS / 32;
+		const int mc = bt_lds_min_class();
+		if (mc == 0) RH_LAUNCH((k_backtrack_spec<256, W0>), r.n_act, 256, 0, s, o, rd, r, 0u);
+		if (mc <= 1 && (mc == 1 || top > 32u * W0)) RH_LAUNCH((k_backtrack_spec<BT_LDS_THREADS, W1>), r.n_act, BT_LDS_THREADS, 0, s, o, rd, r, mc == 1 ? 0u : 32u * W0);
+		if (mc == 2 || top > 32u * W1) RH_LAUNCH((k_backtrack_spec<BT_LDS_THREADS, W2>), r.n_act, BT_LDS_THREADS, 0, s, o, rd, r, mc == 2 ? 0u : 32u * W1);
+		if (top > 32u * W2) RH_LAUNCH((k_backtrack_spec<256, 0>), r.n_act, 256, rh_wave_lds(), s, o, rd, r, 32u * W2);
+	}
 	// compact_a: the chains (gathered by the backtrack itself) put into the reference's order of their first anchor, written back
 	rh_sort_job jb = { r.n_act, r.skip, r.a_off, r.n_u, r.raw, r.zs, r.need_exact2, r.ws, RH_WS_PER_ANCHOR, 64, r.akey_on, r.akey_lo, r.akey_mid, 1, r.max_anchors };   // keys = first anchors
 	sort_scratch(jb, r, r.anc);                                    // (the backtrack has copied every chain out of the sorted anchors; k_chain_reorder rewrites them)

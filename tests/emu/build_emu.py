@@ -12,7 +12,7 @@ OUT = os.path.join(BUILD, "librawhash_emu.so")
 
 # small LDS caps so that the oversized-read fallbacks (the *_big kernels) are exercised on small test inputs
 SMALL_CAPS = ("-DRG_CAP=8", "-DRGW_CAP=48", "-DRGW_CAP0=16", "-DRGR_PRIM_CAP=5", "-DRGB_PCAP=64", "-DRGR_DIRECT=20", "-DCG_CAP=8", "-DPF_TILES=40", "-DRH_SORT_CAP0=128", "-DRH_SORT_CAP1=384", "-DRH_SORT_CAP2=512", "-DRH_SORT_CAP3=768", "-DRH_SORT_CAP4=1024", "-DRH_SORT32_CAPH=256", "-DRH_SORT32_CAP1=384", "-DRH_SORT32_CAP2=640", "-DRH_SORT32_CAP3=1024", "-DIX_L=64", "-DIX_WU=3", "-DCH_TILE=128", "-DBS_TILE_IT=1", "-DBS_WIN_BYTES=1024", "-DBS_LANES_MIN_RANGES=100000", "-DBS_MULTI_MIN_RANGES=1", "-DBS_MW_PERIOD=5", "-DBS_MW_G16_FROM=3", "-DBS_MW_G32_FROM=10",
-              "-DPW_MIN_HOLES=256", "-DPW_MIN_C0=16", "-DPW_MAX_CYCLE=4096", "-DPW_WIN_CAP=400", "-DPW_BLK_HOLES=200", "-DPW_RING_BYTES=4096", "-DPW_TEST_FEW_SLOTS", "-DRQ_RING_S=4", "-DRQ_RING=8", "-DRQ_RING_BIG=32")
+              "-DPW_MIN_HOLES=256", "-DPW_MIN_C0=16", "-DPW_MAX_CYCLE=4096", "-DPW_WIN_CAP=400", "-DPW_BLK_HOLES=200", "-DPW_RING_BYTES=4096", "-DPW_TEST_FEW_SLOTS", "-DRQ_RING_S=4", "-DRQ_RING=8", "-DRQ_RING_BIG=32", "-DBT_LDS_ANCHORS=512", "-DBT_LDS_CLAIMS=64")
 
 
 def build(force=False, defines=(), tag=""):

@@ -115,6 +115,16 @@ def test_chain_generic_step(ctx, wl, monkeypatch):
     pc.check_e2e(ctx, wl)
 
 
+@pytest.mark.parametrize("bt_class", [1, 2, 3])
+def test_backtrack_mark_classes(ctx, wl, monkeypatch, bt_class):
+    """The backtrack's used-marks and claim stamps: LDS bits + a stamp table for reads of up to 131 072 / 262 144 / 524 288 anchors (k_backtrack_spec<256 | 512, words>,
+    rh_post.hip), HBM beyond.  Small inputs only reach the first class by themselves: RH_BT_LDS_MIN_CLASS sends every read through the second, the third and the HBM form."""
+    monkeypatch.setenv("RH_BT_LDS_MIN_CLASS", str(bt_class))
+    n_an, n_ch, n_u = pc.check_chain_synthetic(ctx, wl, seed=30 + bt_class, n_reads=200, max_n=1500)
+    assert n_ch > 0 and n_u > 0
+    pc.check_e2e(ctx, wl)
+
+
 @pytest.mark.parametrize("min_class", [0, 1, 2, 3])
 def test_rmq_storage_classes_on_device(make_workload, product_lib, gpu_ctx_factory, monkeypatch, min_class):
     """The RMQ trees' four storage classes (LDS rings of 64 / 128 / 512 nodes, HBM: rh_chain.hip k_chain_rmq<RING, class>) each forced on the real device -
