@@ -135,7 +135,7 @@ __global__ __launch_bounds__(BT) void k_backtrack_spec(rh_dev_opt o, rh_dev_read
 	if (a >= rr.n_act) return;
 	const uint64_t base = rr.a_off[a];
 	const int32_t n = (int32_t)(rr.a_off[a + 1] - base);
-	if ((uint32_t)n <= lo_cap || (LM && (uint32_t)n > 32u * (uint32_t)LMW)) return;   // another launch's read
+	if ((lo_cap && (uint32_t)n <= lo_cap) || (LM && (uint32_t)n > 32u * (uint32_t)LMW)) return;   // another launch's read (lo_cap = 0: the narrowest class launched, which also takes the reads without anchors)
 	if (rr.skip[a]) { if (lane == 0) { rr.n_u[a] = 0; rr.n_v[a] = 0; } return; }
 	const uint32_t r = rr.act[a];
 	if (LM) {
