@@ -36,12 +36,6 @@ extern "C" __attribute__((visibility("default"))) int rh_debug_kprof_chain(unsig
 #else
 #define CPROF(slot, v)
 #endif
-// a register pair that a load was issued into earlier: the compiler's wait for that load goes where this stands, and memory operations after it stay after it
-#if defined(__HIP_DEVICE_COMPILE__)
-#define RH_LANDED(a, b) asm volatile("" : "+v"(a), "+v"(b) : : "memory")
-#else
-#define RH_LANDED(a, b) ((void)0)
-#endif
 struct chain_lds {
 	uint32_t xlo[CH_RING], ylo[CH_RING];
 	int32_t f[CH_RING], p[CH_RING], v[CH_RING], t[CH_RING];

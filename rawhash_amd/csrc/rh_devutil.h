@@ -12,6 +12,15 @@ RH_DEV uint32_t lanes_below(uint64_t m) { return (uint32_t)__popcll(m & ((1ull <
 
 // Order-preserving rank of the calling thread among the threads of the block with pred set; total = their number.
 // s_w: LDS scratch of (blockDim.x / 64) words.  Contains two block barriers.
+// a register pair that a load was issued into earlier: the compiler's wait for that load goes where this stands, and memory operations after it stay after it
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RH_LANDED(a, b) asm volatile("" : "+v"(a), "+v"(b) : : "memory")
+#define RH_LANDED3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c) : : "memory")
+#else
+#define RH_LANDED(a, b) ((void)0)
+#define RH_LANDED3(a, b, c) ((void)0)
+#endif
+
 RH_DEV uint32_t block_rank(bool pred, uint32_t *s_w, uint32_t &total)
 {
 	const uint64_t m = __ballot(pred);

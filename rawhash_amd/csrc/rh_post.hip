@@ -1189,14 +1189,17 @@ __global__ __launch_bounds__(64) void k_regions_batch(rh_dev_opt o, rh_dev_reads
 	const bool hard = (o.flag & RH_M_HARD_MLEVEL) != 0;
 	if (lane == 0) { L.kk = 0; L.lmax = 0; }
 	__syncthreads();
+	// the next tile's keys are requested a tile ahead and stay as loaded until the tile starts (taken apart at once, the wait would sit right behind the load: a round trip a tile)
+	rh_mm128_t zn; zn.x = 0; zn.y = 0;
+	if ((int32_t)lane < n_u) zn = zs[n_u - 1 - (int32_t)lane];         // descending: larger score first (hit.c:124-126)
 	for (int32_t i0 = 0; i0 < n_u; i0 += 64) {
 		const int32_t i = i0 + (int32_t)lane;
 		int32_t si = 0, ei = 0, sci = 0, cni = 0;
 		bool pending = i < n_u;
-		if (pending) {
-			const rh_mm128_t zi = zs[n_u - 1 - i];                    // descending: larger score first (hit.c:124-126)
-			sci = (int32_t)(zi.x >> 32); rg_unpack(zi.y, heads, si, ei, cni);
-		}
+		RH_LANDED(zn.x, zn.y);
+		if (pending) { sci = (int32_t)(zn.x >> 32); rg_unpack(zn.y, heads, si, ei, cni); }
+		RH_LANDED3(si, ei, cni);                                       // (a head looked up by rg_unpack - rare - is waited for before the next request goes out, not behind it)
+		if (i + 64 < n_u) zn = zs[n_u - 1 - (i + 64)];
 		bool need_eval = pending;
 		int32_t sel = -1;
 		while (__ballot(pending)) {
