@@ -95,6 +95,13 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 	rh_mm128_t rawC; rawC.x = 0; rawC.y = 0;
 	if (T0 + (int32_t)lane < n) { const rh_mm128_t q = AN_(T0 + lane); xB = q.x; yB = q.y; }
 	if (T0 + 64 + (int32_t)lane < n) rawC = rh_an_raw_ld(rr, rr.anc, base + (uint64_t)(T0 + 64 + (int32_t)lane));
+	// An anchor's DP output {f, p}, v stays in its lane's registers while its tile is worked on and is stored - two coalesced stores a tile - at the top of the NEXT tile, after the
+	// wait for the prefetched anchors: stored where it is computed (a few lanes a step, several steps a tile) the wait at the next tile's top, which waits for every outstanding
+	// memory operation, would also sit right behind the tile's last stores.  (Nothing reads them back before: the ring serves the last 256 anchors.)
+	int32_t of = 0, op = -1, ov = 0, oii = 0;
+	bool ohave = false;
+	int2 *gfp2 = reinterpret_cast<int2*>(gfp);
+	#define CH_FLUSH() do { if (ohave) { int2 w_; w_.x = of; w_.y = op; gfp2[oii] = w_; gv[oii] = ov; ohave = false; } } while (0)
 	for (int32_t i0 = T0; i0 < n; i0 += 64) {
 #ifdef RH_KPROF
 		const unsigned long long cp_top = clock64();
@@ -103,6 +110,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 		const bool inb_r = ii < n;
 		const uint64_t x = xB, y = yB;
 		RH_LANDED(rawC.x, rawC.y);                                  // the load issued one tile ago is waited for HERE, before the next one is issued
+		CH_FLUSH();
 		if (ii + 64 < n) { const rh_mm128_t q = rr.afmt.rec8 ? rh_anchor_unpack(rawC.x, rr.afmt, rr.aq_bits, rr.a_span) : rawC; xB = q.x; yB = q.y; } else { xB = 0; yB = 0; }
 		if (ii + 128 < n) rawC = rh_an_raw_ld(rr, rr.anc, base + (uint64_t)(ii + 128));
 		const uint64_t xprev = (uint64_t)rh_wave_shr1((uint32_t)(x >> 32), (uint32_t)(x_before >> 32)) << 32 | rh_wave_shr1((uint32_t)x, (uint32_t)x_before);
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 		const uint64_t bmaskB = __ballot(ii + 64 >= n || (xB >> 32) != (xprevB >> 32) || xB > xprevB + D64);   // same for the next tile
 		const bool nstart = lane < 63 ? ((bmask >> (lane + 1)) & 1ull) != 0 : (bmaskB & 1ull) != 0;
 		const bool single = start && nstart;
-		if (inb && single) { const int32_t sp = (int32_t)((y >> 32) & 63); gfp[2 * ii] = sp; gfp[2 * ii + 1] = -1; gv[ii] = sp; }
+		if (inb && single) { const int32_t sp = (int32_t)((y >> 32) & 63); of = sp; op = -1; ov = sp; }
 		// the cluster [cs_g, ce_g] (global indices) of every anchor of the tile, from the boundary masks
 		int32_t cs_g, ce_g;
 		{
@@ -228,9 +236,9 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 				const int32_t vmj = (i - max_j < CH_RING) ? L.v[(uint32_t)max_j & (CH_RING - 1)] : __hip_atomic_load(&gv[max_j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if (vmj > max_f) vv = vmj;
 			}
+			if (lane == (uint32_t)b) { of = max_f; op = max_j; ov = vv; }
 			if (lane == 0) {
 				const uint32_t sl = (uint32_t)i & (CH_RING - 1);
-				gfp[2 * i] = max_f; gfp[2 * i + 1] = max_j; gv[i] = vv;
 				L.xlo[sl] = xi_lo; L.ylo[sl] = yi_lo; L.span[sl] = (uint8_t)span_i; L.f[sl] = max_f; L.p[sl] = max_j; L.v[sl] = vv;
 			}
 			if (max_ii < 0 || ((uint32_t)(xi_lo - xlo_ii) <= D32 && f_ii < max_f)) { max_ii = i; f_ii = max_f; xlo_ii = xi_lo; }
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 			if (small && pos == 0) {
 				const uint32_t sl = (uint32_t)ii & (CH_RING - 1);
 				L.f[sl] = span_i; L.p[sl] = -1; L.v[sl] = span_i;
-				gfp[2 * ii] = span_i; gfp[2 * ii + 1] = -1; gv[ii] = span_i;
+				of = span_i; op = -1; ov = span_i;
 				L.s_mi[(uint32_t)ii & 127u] = ii;
 			}
 			__syncthreads();
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 					if (max_j >= 0) { const int32_t vmj = L.v[(uint32_t)max_j & (CH_RING - 1)]; if (vmj > max_f) vv = vmj; }
 					const uint32_t sl = (uint32_t)ii & (CH_RING - 1);
 					L.f[sl] = max_f; L.p[sl] = max_j; L.v[sl] = vv;
-					gfp[2 * ii] = max_f; gfp[2 * ii + 1] = max_j; gv[ii] = vv;
+					of = max_f; op = max_j; ov = vv;
 				}
 				__syncthreads();
 			}
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 					if (max_j >= 0) { const int32_t vmj = L.v[(uint32_t)max_j & (CH_RING - 1)]; if (vmj > max_f) vv = vmj; }
 					const uint32_t sl = (uint32_t)ii & (CH_RING - 1);
 					L.f[sl] = max_f; L.p[sl] = max_j; L.v[sl] = vv;
-					gfp[2 * ii] = max_f; gfp[2 * ii + 1] = max_j; gv[ii] = vv;
+					of = max_f; op = max_j; ov = vv;
 					if (mi < 0 || ((uint32_t)(xi - xmi) <= D32 && fmi < max_f)) mi = ii;
 					L.s_mi[(uint32_t)ii & 127u] = mi;
 				}
@@ -384,9 +392,12 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 #ifdef RH_KPROF
 		CPROF(11, clock64() - cp_t1);
 #endif
+		ohave = inb; oii = ii;
 		x_before = x_last;
 		if (last_tile) break;
 	}
+	CH_FLUSH();
+	#undef CH_FLUSH
 	#undef AN_
 }
 
