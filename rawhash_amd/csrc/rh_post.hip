@@ -1,8 +1,8 @@
 // Post-DP stages:
 //   k_zbuild          candidates f[i] >= min_sc for backtracking (lchain.c:126-140); they are then put into the reference's
 //                     radix_sort_128x order by the block sorter of rh_sort.hip (scores are full of ties -> exact mode)
-//   k_backtrack_spec  mg_chain_backtrack (lchain.c:95-194, mg_chain_bk_end :47-75): one wavefront per read, 64 candidates
-//                     walked in parallel per round, conflicts re-walked
+//   k_backtrack_spec  mg_chain_backtrack (lchain.c:95-194, mg_chain_bk_end :47-75): a workgroup per read, 256 / 512 candidates
+//                     walked in parallel per round, conflicts re-walked; used-marks and claim stamps in LDS (HBM for the largest reads)
 //   k_chain_reorder (+ block sorter)   compact_a (lchain.c:214-281), its gather being the backtrack's
 //   k_regions_*       mm_gen_regs (hit.c:100-150), mm_set_parent (:195-263), mm_select_sub (:338-367), mm_set_mapq (:502-539),
 //                     the mapping decision of map_worker_for (rmap.cpp:423-500) and the bookkeeping of ri_map_frag (:386):
