@@ -338,23 +338,20 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 				if (small && pos == sidx) {
 					int32_t max_f = span_i, max_j = -1, n_skip = 0, end_j = 0, nwin = 0;
 					uint32_t tm = 0;                                   // bit k: the cluster's k-th anchor carries t[] == i
-					bool broke = false, far = false;
-					int32_t fr[CH_SMALL];
+					bool broke = false;
+					// the window: the predecessors in reach (x ascends along the cluster: behind the first one out of reach all are) and within max_iter
+#pragma unroll
+					for (int r = 1; r <= sidx; ++r) if (nwin == r - 1 && sc[r] != CH_FAR && r <= max_iter) nwin = r;
 #pragma unroll
 					for (int r = 1; r <= sidx; ++r) {
-						fr[r] = 0;
-						if (far || sc[r] == CH_FAR || r > max_iter) far = true;
-						else {
-							nwin = r;
+						if (__ballot(!broke && r <= nwin) == 0) break;  // every lane of the step is through with its walk (a chain that runs straight breaks on max_skip at its 7th predecessor: the steps of the long clusters stop there instead of running all sidx rounds under an empty mask)
+						if (!broke && r <= nwin && sc[r] != RH_SCORE_NONE) {
 							const uint32_t sl = (uint32_t)(ii - r) & (CH_RING - 1);
 							const int32_t fj = L.f[sl], pj = L.p[sl];
-							fr[r] = fj;
-							if (!broke && sc[r] != RH_SCORE_NONE) {
-								const int32_t cand = sc[r] + fj;
-								if (cand > max_f) { max_f = cand; max_j = ii - r; if (n_skip > 0) --n_skip; }
-								else if ((tm >> (sidx - r)) & 1u) { if (++n_skip > max_skip) { broke = true; end_j = ii - r; } }
-								if (!broke && pj >= 0) tm |= 1u << (pj - cs_g);
-							}
+							const int32_t cand = sc[r] + fj;
+							if (cand > max_f) { max_f = cand; max_j = ii - r; if (n_skip > 0) --n_skip; }
+							else if ((tm >> (sidx - r)) & 1u) { if (++n_skip > max_skip) { broke = true; end_j = ii - r; } }
+							if (!broke && pj >= 0) tm |= 1u << (pj - cs_g);
 						}
 					}
 					if (!broke) end_j = ii - nwin - 1;
@@ -366,7 +363,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(rh_dev_opt o, rh_dev_round rr
 						int32_t mx = INT32_MIN;
 						mi = -1;
 #pragma unroll
-						for (int r = 1; r <= sidx; ++r) if (r <= nwin && mx < fr[r]) { mx = fr[r]; mi = ii - r; }
+						for (int r = 1; r <= sidx; ++r) if (r <= nwin) { const int32_t fj = L.f[(uint32_t)(ii - r) & (CH_RING - 1)]; if (mx < fj) { mx = fj; mi = ii - r; } }
 						if (mi >= 0) { fmi = mx; xmi = L.s_xlo[(uint32_t)mi & 127u]; }
 					}
 					if (mi >= 0 && mi < end_j) {
